@@ -1,0 +1,464 @@
+"""CPU oracle for the BNV-Fusion local-fusion + SDF-decode hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file restates, op for op in PyTorch-CPU fp32,
+what the reference (likojack/bnv_fusion, mounted at /root/reference in the build
+container) computes on the path SURVEY.md section 8 scopes.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; the product package (``bnv_fusion_amd``) never does and has no CPU
+fallback.
+
+Parity pin: the reference has no tests of its own, so the
+oracle is pinned against outputs of the reference itself, captured in the build
+container by ``tests/golden/make_golden.py`` (reference imported under the
+shims of ``tests/golden/ref_shims.py``) and committed as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this file against every one of them
+(voxel ids / counts bit-exact, floats to <= 1e-6).  The tcnn (fp16
+FullyFusedMLP) variant is the exception: its reference arithmetic is CUDA-only
+and cannot be executed here, so ``tcnn_*`` below is "parity unpinned" (layout
+verified statistically in SURVEY.md Appendix A only).
+
+All file:line citations are relative to /root/reference.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------- #
+# voxel index <-> flat id <-> world   (src/utils/voxel_utils.py)
+# --------------------------------------------------------------------------- #
+
+
+def get_world_range(dimensions, voxel_size):
+    """voxel_utils.py:83-88 -- pads one voxel each side; float64 numpy."""
+    dimensions = np.asarray(dimensions, dtype=np.float64)
+    min_ = -dimensions / 2 - voxel_size
+    max_ = dimensions / 2 + voxel_size
+    n_xyz = np.ceil((max_ - min_) / voxel_size).astype(int).tolist()
+    max_ = min_ + voxel_size * np.asarray(n_xyz)
+    return min_, max_, n_xyz
+
+
+def flatten(voxels, n_xyz):
+    """voxel_utils.py:62-65."""
+    return voxels[..., 0] * n_xyz[1] * n_xyz[2] + voxels[..., 1] * n_xyz[2] + voxels[..., 2]
+
+
+def unflatten(flat_id, n_xyz):
+    """voxel_utils.py:68-80 (torch branch)."""
+    x = torch.div(flat_id, (n_xyz[1] * n_xyz[2]), rounding_mode="floor")
+    rest = flat_id % (n_xyz[1] * n_xyz[2])
+    y = torch.div(rest, n_xyz[2], rounding_mode="floor")
+    z = flat_id - x * n_xyz[1] * n_xyz[2] - y * n_xyz[2]
+    return torch.stack([x, y, z], dim=-1)
+
+
+_CORNER_IS_CEIL = (  # (x, y, z) uses ceil?  -- the order of modules.py:590-655 / fusion/utils.py:98-167
+    (0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1))
+
+
+def get_neighbors(points, as_int=False):
+    """points [b, n, s, 3] -> [b, 8, n, s, 3].
+
+    ``as_int=True``  : ReplicateNeRFModel.get_neighbors, modules.py:586-655 (``.int()``)
+    ``as_int=False`` : fusion/utils.py:98-167 (float corners, used by SparseVolume.decode_pts)
+    """
+    fl, ce = torch.floor(points), torch.ceil(points)
+    out = []
+    for cx, cy, cz in _CORNER_IS_CEIL:
+        out.append(torch.stack([(ce if cx else fl)[..., 0], (ce if cy else fl)[..., 1],
+                                (ce if cz else fl)[..., 2]], dim=-1))
+    out = torch.stack(out, dim=1)
+    return out.int() if as_int else out
+
+
+# --------------------------------------------------------------------------- #
+# networks
+# --------------------------------------------------------------------------- #
+
+
+def load_weights(npz_path):
+    """Converted checkpoint (tests/golden/convert_checkpoints.py) -> dict of torch tensors."""
+    with np.load(npz_path) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def pointnet_encoder(sd, x):
+    """PointNetEncoder.forward(x, global_feat=False), pointnet_utils.py:246-266.
+    x [B, 6, P] -> [B, 8, P].  BatchNorm1d in eval mode (run_e2e.py:234)."""
+    p = "pointnet_backbone."
+    for i in (1, 2, 3, 4):
+        x = F.conv1d(x, sd[f"{p}conv{i}.weight"], sd[f"{p}conv{i}.bias"])
+        x = F.batch_norm(x, sd[f"{p}bn{i}.running_mean"], sd[f"{p}bn{i}.running_var"],
+                         sd[f"{p}bn{i}.weight"], sd[f"{p}bn{i}.bias"], False, 0.1, 1e-5)
+        if i < 4:
+            x = F.relu(x)
+    return x
+
+
+def xyz_encoding(t):
+    """positional_encoding(num_encoding_functions=1, include_input=True), modules.py:81-123.
+    [..., 3] -> [..., 9] = [t, sin(t * 1.0), cos(t * 1.0)]."""
+    freq = 2.0 ** torch.linspace(0.0, 0.0, 1, dtype=t.dtype)
+    enc = [t]
+    for f in freq:
+        for fn in (torch.sin, torch.cos):
+            enc.append(fn(t * f))
+    return torch.cat(enc, dim=-1)
+
+
+def geo_forward(sd, x, num_layers=4):
+    """ReplicateNeRFModel.geo_forward, modules.py:657-662.  [..., 17] -> [..., 1]."""
+    for i in range(num_layers):
+        x = F.relu(F.linear(x, sd[f"nerf.geo_layer{i}.weight"], sd[f"nerf.geo_layer{i}.bias"]))
+    return F.linear(x, sd["nerf.fc_alpha.weight"], sd["nerf.fc_alpha.bias"])
+
+
+def forward_with_mask(sd, input_feats, mask):
+    """modules.py:774-783 -- MLP on the masked rows only, zeros elsewhere."""
+    shapes = list(input_feats.shape)
+    mask = mask.reshape(-1)
+    flat = input_feats.reshape(-1, shapes[-1])
+    alpha = geo_forward(sd, flat[mask])
+    out = torch.zeros_like(flat[:, :1], dtype=alpha.dtype)
+    out[mask] = alpha
+    return out.reshape(shapes[:-1] + [1])
+
+
+# --------------------------------------------------------------------------- #
+# encode  (LitFusionPointNet.encode_pointcloud, local_point_fusion.py:81-165)
+# --------------------------------------------------------------------------- #
+
+
+def get_relative_xyz(xyz, bound_min, voxel_size):
+    """local_point_fusion.py:153-165."""
+    xyz_zeroed = xyz - bound_min
+    xyz_normalized = xyz_zeroed / voxel_size
+    grid_id = get_neighbors(xyz_normalized.unsqueeze(1), as_int=True).squeeze(2)  # [B, 8, N, 3] i32
+    relative = (xyz_normalized.unsqueeze(1) - grid_id) * voxel_size
+    return relative, grid_id
+
+
+def encode_pointcloud(sd, input_pts, n_xyz, bound_min, bound_max, voxel_size,
+                      min_pts_in_grid=8, return_dense=False):
+    """local_point_fusion.py:81-151.  input_pts [1, N, 6] f32.
+    sparse: (feats [U',8], pcounts [U',1] i64, flat_ids [U'] i64, grid_ids [U',3] i64, n_avg_pts)
+    dense : (feat_grids [1,8,X,Y,Z], mask [1,1,X,Y,Z], unique_flat_ids [U], flat_ids [1,P])."""
+    res = [int(v) for v in n_xyz]
+    in_xyz = input_pts[:, :, :3] * 1.
+    in_normal = input_pts[:, :, 3:]
+    bound_mask = (in_xyz[0, :, 0] < bound_max[0] - voxel_size) \
+        * (in_xyz[0, :, 1] < bound_max[1] - voxel_size) \
+        * (in_xyz[0, :, 2] < bound_max[2] - voxel_size) \
+        * (in_xyz[0, :, 0] > bound_min[0] + voxel_size) \
+        * (in_xyz[0, :, 1] > bound_min[1] + voxel_size) \
+        * (in_xyz[0, :, 2] > bound_min[2] + voxel_size)
+    if torch.sum(bound_mask) == 0:
+        return None, None, None, None, None
+    in_xyz = in_xyz[:, bound_mask, :]
+    in_normal = in_normal[:, bound_mask, :]
+    relative_xyz, grid_id = get_relative_xyz(in_xyz, bound_min, voxel_size)
+    grid_id = grid_id.reshape(1, -1, 3)
+    pointnet_input = torch.cat([relative_xyz, in_normal.unsqueeze(1).repeat(1, 8, 1, 1)], dim=-1)
+    pointnet_input = pointnet_input.reshape(1, -1, 6)
+    # forward(normalize=True), local_point_fusion.py:51-65
+    pointnet_input[:, :, :3] = pointnet_input[:, :, :3] / voxel_size
+    assert torch.min(pointnet_input[:, :, :3]) >= -1 and torch.max(pointnet_input[:, :, :3]) <= 1
+    point_feats = pointnet_encoder(sd, pointnet_input.permute(0, 2, 1))  # [1, 8, P]
+    flat_ids = flatten(grid_id, n_xyz).long()
+    unique_flat_ids, pinds, pcounts = torch.unique(flat_ids[0], return_inverse=True, return_counts=True)
+    unique_grid_ids = unflatten(unique_flat_ids, n_xyz).long()
+    assert torch.max(unique_grid_ids[:, 0]) < res[0] and torch.max(unique_grid_ids[:, 1]) < res[1]
+    assert torch.max(unique_grid_ids[:, 2]) < res[2] and torch.min(unique_grid_ids) >= 0
+    # torch_scatter.scatter_mean (local_point_fusion.py:125): sum / max(count, 1)
+    U = unique_flat_ids.shape[0]
+    idx = pinds[None, None, :].expand_as(point_feats)
+    total = torch.zeros((1, point_feats.shape[1], U), dtype=point_feats.dtype).scatter_add_(2, idx, point_feats)
+    count = torch.zeros_like(total).scatter_add_(2, idx, torch.ones_like(point_feats))
+    point_feats_mean = total / count.clamp(min=1)
+    point_feats_mean[:, :, pcounts < min_pts_in_grid] = 0
+    if return_dense:
+        feat_grids = torch.zeros((1, point_feats.shape[1], *res), dtype=point_feats.dtype)
+        mask = torch.zeros((1, 1, *res), dtype=point_feats.dtype)
+        g = unique_grid_ids
+        mask[0, 0, g[:, 0], g[:, 1], g[:, 2]] = pcounts.type(point_feats.type())
+        feat_grids[0, :, g[:, 0], g[:, 1], g[:, 2]] = point_feats_mean
+        return feat_grids, mask, unique_flat_ids, flat_ids
+    n_avg_pts = torch.mean(pcounts.type(point_feats.type()))
+    valid = pcounts >= min_pts_in_grid
+    point_feats_mean = point_feats_mean[:, :, valid]
+    pcounts = pcounts[valid]
+    unique_flat_ids = unique_flat_ids[valid]
+    unique_grid_ids = unflatten(unique_flat_ids, n_xyz).long()
+    return point_feats_mean[0].permute(1, 0), pcounts.unsqueeze(-1), unique_flat_ids, unique_grid_ids, n_avg_pts
+
+
+# --------------------------------------------------------------------------- #
+# sparse volume  (SparseVolume, sparse_volume.py:484-695)
+# --------------------------------------------------------------------------- #
+
+
+class OracleSparseVolume:
+    """Semantics of sparse_volume.py:484-695 with the Open3D hash map replaced by a
+    Python dict (key tuple -> buffer row, insertion order = buffer order)."""
+
+    def __init__(self, n_feats, voxel_size, dimensions, min_pts_in_grid):
+        min_coords, max_coords, n_xyz = get_world_range(dimensions, voxel_size)
+        self.dimensions = dimensions
+        self.voxel_size = voxel_size
+        self.min_coords = torch.from_numpy(min_coords).float()   # sparse_volume.py:495
+        self.max_coords = torch.from_numpy(max_coords).float()
+        self.n_xyz = torch.from_numpy(np.asarray(n_xyz)).long()  # sparse_volume.py:497
+        self.n_feats = n_feats
+        self.min_pts_in_grid = min_pts_in_grid
+        self._map = {}
+        self._keys, self._feats, self._w, self._hits = [], [], [], []
+        self.features = self.weights = self.num_hits = self.active_coordinates = None
+        self._tensor_map = None
+        self.n_pts_list = []
+
+    def track_n_pts(self, n_pts):
+        """sparse_volume.py:508-513."""
+        self.n_pts_list.append(float(n_pts))
+
+    def _rows(self, keys, table):
+        kl = keys.reshape(-1, 3).long().tolist()
+        return [table.get(tuple(k), -1) for k in kl]
+
+    def query(self, keys):
+        """sparse_volume.py:661-695: zeros for absent keys."""
+        shapes = list(keys.shape)
+        n = int(np.prod(shapes[:-1]))
+        if n == 0:
+            return None, None, None
+        rows = self._rows(keys, self._map)
+        f = torch.zeros((n, self.n_feats))
+        w = torch.zeros((n, 1))
+        h = torch.zeros((n, 1))
+        for i, r in enumerate(rows):
+            if r >= 0:
+                f[i], w[i], h[i] = self._feats[r], self._w[r], self._hits[r]
+        return (f.reshape(shapes[:-1] + [self.n_feats]), w.reshape(shapes[:-1] + [1]),
+                h.reshape(shapes[:-1] + [1]))
+
+    def insert(self, keys, new_feats, new_weights, new_num_hits):
+        """sparse_volume.py:561-585: upsert (new keys appended, existing keys overwritten)."""
+        if len(keys) == 0:
+            return None
+        kl = keys.reshape(-1, 3).long().tolist()
+        for i, k in enumerate(kl):
+            k = tuple(k)
+            r = self._map.get(k)
+            if r is None:
+                self._map[k] = len(self._keys)
+                self._keys.append(k)
+                self._feats.append(new_feats[i].detach().clone())
+                self._w.append(new_weights[i].detach().clone())
+                self._hits.append(new_num_hits[i].detach().clone())
+            else:
+                self._feats[r] = new_feats[i].detach().clone()
+                self._w[r] = new_weights[i].detach().clone()
+                self._hits[r] = new_num_hits[i].detach().clone()
+
+    def to_tensor(self):
+        """sparse_volume.py:525-559: snapshot of the active entries + key -> row index."""
+        self.active_coordinates = torch.tensor(self._keys, dtype=torch.int64).reshape(-1, 3)
+        self.features = torch.stack(self._feats) if self._feats else torch.zeros((0, self.n_feats))
+        self.weights = torch.stack(self._w).reshape(-1, 1) if self._w else torch.zeros((0, 1))
+        self.num_hits = torch.stack(self._hits).reshape(-1, 1) if self._hits else torch.zeros((0, 1))
+        self._tensor_map = {k: i for i, k in enumerate(self._keys)}
+        return self.active_coordinates, self.features, self.weights, self.num_hits
+
+    def _query_tensor(self, keys):
+        """sparse_volume.py:625-659: lookup in the to_tensor() snapshot."""
+        shapes = list(keys.shape)
+        n = int(np.prod(shapes[:-1]))
+        rows = torch.tensor(self._rows(keys, self._tensor_map), dtype=torch.int64)
+        found = rows >= 0
+        f = torch.zeros((n, self.n_feats))
+        w = torch.zeros((n, 1))
+        h = torch.zeros((n, 1))
+        f[found] = self.features[rows[found]]
+        w[found] = self.weights[rows[found]]
+        h[found] = self.num_hits[rows[found]]
+        return (f.reshape(shapes[:-1] + [self.n_feats]), w.reshape(shapes[:-1] + [1]),
+                h.reshape(shapes[:-1] + [1]))
+
+    def count_optim(self, keys):
+        """sparse_volume.py:602-622: weights[row] += 1 for found keys (index_put, no accumulate:
+        duplicated rows are incremented once)."""
+        rows = torch.tensor(self._rows(keys, self._tensor_map), dtype=torch.int64)
+        rows = rows[rows >= 0]
+        self.weights[rows] += 1
+
+    def decode_pts(self, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True):
+        return decode_pts(self, coords, sd, sdf_delta, is_coords, query_tensor)
+
+
+def integrate(volume, fine_coords, fine_feats, fine_weights):
+    """LitFusionPointNet._integrate + _update, local_point_fusion.py:647-673."""
+    fine_weights = torch.clip(fine_weights / 32, max=1)
+    old_f, old_w, hits = volume.query(fine_coords)
+    new_f = new_w = None
+    if len(fine_coords) > 0:
+        new_w = old_w + fine_weights
+        new_f = (old_f * old_w + fine_feats * fine_weights) / new_w
+    volume.insert(fine_coords, new_f, new_w, hits)
+
+
+# --------------------------------------------------------------------------- #
+# decode
+# --------------------------------------------------------------------------- #
+
+
+def decode_pts(volume, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True):
+    """SparseVolume.decode_pts, sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1]."""
+    if not is_coords:
+        coords = (coords - volume.min_coords) / volume.voxel_size
+    neighbor_coords = get_neighbors(coords)                      # float corners [1, 8, B, S, 3]
+    local_coords = coords.unsqueeze(1) - neighbor_coords
+    assert torch.min(local_coords) >= -1 and torch.max(local_coords) <= 1
+    weights_unmasked = torch.prod(1 - torch.abs(local_coords), dim=-1, keepdim=True)
+    if query_tensor:
+        feats, weights, _ = volume._query_tensor(neighbor_coords)
+    else:
+        feats, weights, _ = volume.query(neighbor_coords)
+    mask = torch.min(weights, dim=1)[0] >= volume.min_pts_in_grid
+    nerf_in = torch.cat([xyz_encoding(local_coords), feats], dim=-1)
+    alpha = geo_forward(sd, nerf_in)
+    alpha = alpha * volume.voxel_size
+    normalizer = torch.sum(weights_unmasked, dim=1, keepdim=True)
+    weights_unmasked = weights_unmasked / normalizer
+    alpha = torch.sum(alpha * weights_unmasked, dim=1)
+    alpha = torch.where(mask, alpha, torch.zeros_like(alpha) + volume.voxel_size)
+    if sdf_delta is not None:
+        g = neighbor_coords / (volume.n_xyz - 1)
+        g = (g * 2 - 1)[..., [2, 1, 0]]
+        d = F.grid_sample(sdf_delta, g, mode="nearest", padding_mode="zeros", align_corners=True)
+        d = d.permute(0, 2, 3, 4, 1)
+        alpha = alpha + torch.sum(d * weights_unmasked, dim=1)
+    return alpha
+
+
+def lattice_coords(origins, step_size=0.5):
+    """The 3x3x3 per-voxel lattice of SparseVolume.meshlize, sparse_volume.py:718-731.
+    origins [B, 3] integer voxel coords -> [1, B, 27, 3] f32 (float64 numpy, then .float())."""
+    origin = np.asarray(origins, dtype=np.int64)
+    range_ = np.arange(0, 1 + step_size, step_size) - 0.5
+    vc = np.stack(np.meshgrid(range_, range_, range_, indexing="ij"), axis=-1)
+    vc = np.tile(vc, (len(origin), 1, 1, 1, 1))
+    vc += origin[:, None, None, None, :]
+    return torch.from_numpy(vc).float().reshape(1, len(origin), -1, 3)
+
+
+def decode_feature_grid_w_pts(sd, voxel_coords, feat_grid, pts_weight, voxel_size, min_pts_in_grid=8):
+    """LitFusionPointNet.decode_feature_grid_w_pts with global_coords=False and
+    interpolate_decode=True, local_point_fusion.py:265-329 (+ decode_implicit :372-379,
+    LocalNeRFModel.forward(test=True) modules.py:941-960).  voxel_coords [1, Q, 3] -> sdf [1, Q]."""
+    h, w, d = feat_grid.shape[-3:]
+    res = torch.tensor([h, w, d])
+    neighbor_coords = get_neighbors(voxel_coords.unsqueeze(1), as_int=True).squeeze(2)  # [1, 8, Q, 3] i32
+    g = neighbor_coords / (res - 1)
+    g = (g * 2 - 1)[..., [2, 1, 0]].unsqueeze(0)
+    nf = F.grid_sample(feat_grid, g, mode="nearest", padding_mode="zeros", align_corners=True)
+    pw = F.grid_sample(pts_weight, g, mode="nearest", padding_mode="zeros", align_corners=True)
+    pw = pw * (pw >= min_pts_in_grid)
+    nf = nf.squeeze(2).permute(0, 2, 3, 1)          # [1, 8, Q, F]
+    pw = pw.squeeze(2).permute(0, 2, 3, 1)[..., 0]  # [1, 8, Q]
+    rel = voxel_coords.unsqueeze(1) - neighbor_coords
+    bw = torch.prod(1 - torch.abs(rel), dim=-1)
+    bw = bw / torch.sum(bw, dim=1, keepdim=True)
+    rel_xyz = rel * voxel_size
+    pts = rel_xyz / voxel_size                       # decode_implicit(normalize=True)
+    geo_in = torch.cat([xyz_encoding(pts[..., :3]), nf], dim=-1)
+    sdf = forward_with_mask(sd, geo_in, pw >= min_pts_in_grid) * voxel_size
+    sdf = torch.sum(sdf[..., 0] * bw, dim=1)
+    valid = torch.sum(pw, dim=1) > 0
+    sdf = torch.where(valid, sdf, torch.ones_like(sdf) * voxel_size)
+    return sdf, nf
+
+
+# --------------------------------------------------------------------------- #
+# tcnn (FullyFusedMLP) variant -- PARITY UNPINNED (see module docstring)
+# --------------------------------------------------------------------------- #
+
+
+def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True):
+    """tiny-cuda-nn FullyFusedMLP restated: identity encoding pads the input to a multiple of 16
+    with 1.0; ``n_hidden`` hidden layers of ``width`` with ReLU, no bias, output padded to 16;
+    weights row-major [out, in] in one flat vector (call sites
+    pointnet_utils.py:274-279, modules.py:171-176).  ``half`` rounds weights, inputs and every
+    layer output to fp16 as the CUDA kernel stores them (fp32 accumulate)."""
+    q = (lambda t: t.half().float()) if half else (lambda t: t)
+    n = x.shape[0]
+    pad = torch.ones((n, n_in_padded - x.shape[1]), dtype=x.dtype)
+    h = q(torch.cat([x, pad], dim=1))
+    dims = [n_in_padded] + [width] * n_hidden + [16]
+    off = 0
+    for i in range(len(dims) - 1):
+        w = q(params[off: off + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]))
+        off += dims[i + 1] * dims[i]
+        h = h @ w.t()
+        if i < len(dims) - 2:
+            h = F.relu(h)
+        h = q(h)
+    return h[:, :n_out]
+
+
+# --------------------------------------------------------------------------- #
+# synthetic benchmark frames -- dataset path restated
+# --------------------------------------------------------------------------- #
+
+
+def depth_to_input_pts(depth, intr, T_wc, max_depth=10.0):
+    """FusionInferenceAbstractDataset.__getitem__, fusion_inference_dataset.py:40-90, with the
+    kornia-0.6.2 normals it calls (:52-59) restated as in geometry.py:515-527: xyz map ->
+    normalised 3x3 Sobel (replicate pad, /8) -> cross(d/du, d/dv) -> L2 normalise; float64
+    throughout, world transform by T_wc.  depth [H, W] metres (0 = invalid) -> [N, 6] float64."""
+    depth = np.asarray(depth, dtype=np.float64)
+    H, W = depth.shape
+    fx, fy, cx, cy = intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2]
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    xyz = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], axis=0)  # [3, H, W]
+    p = np.pad(xyz, ((0, 0), (1, 1), (1, 1)), mode="edge")
+    gx = (p[:, :-2, 2:] + 2 * p[:, 1:-1, 2:] + p[:, 2:, 2:]
+          - p[:, :-2, :-2] - 2 * p[:, 1:-1, :-2] - p[:, 2:, :-2]) / 8.0
+    gy = (p[:, 2:, :-2] + 2 * p[:, 2:, 1:-1] + p[:, 2:, 2:]
+          - p[:, :-2, :-2] - 2 * p[:, :-2, 1:-1] - p[:, :-2, 2:]) / 8.0
+    n = np.cross(gx, gy, axis=0)
+    n = n / np.maximum(np.linalg.norm(n, axis=0, keepdims=True), 1e-12)
+    mask = (depth > 0) & (depth < max_depth)
+    pts_c = xyz.reshape(3, -1).T
+    nrm_c = n.reshape(3, -1).T
+    R, t = T_wc[:3, :3], T_wc[:3, 3]
+    pts_w = pts_c @ R.T + t
+    nrm_w = nrm_c @ R.T
+    return np.concatenate([pts_w, nrm_w], axis=-1)[mask.reshape(-1)]
+
+
+def synthetic_depth(t, H=480, W=640, seed=0):
+    """depth(u,v) = 1.5 + 0.2 sin(u/40) cos(v/30) + N(0, 0.002) m,
+    quantised to uint16 millimetres as the datasets store it (common.py:93)."""
+    rng = np.random.default_rng(seed + 1000 * t)
+    v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    d = 1.5 + 0.2 * np.sin(u / 40.0) * np.cos(v / 30.0) + rng.normal(0.0, 0.002, size=(H, W))
+    return np.round(d * 1000.0).astype(np.uint16).astype(np.float64) / 1000.0
+
+
+def synthetic_pose(t):
+    """T_wc(t) = translate(0, 0, -1.5) . R_y(0.5 deg * t)."""
+    a = math.radians(0.5 * t)
+    T = np.eye(4)
+    T[:3, :3] = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    T[:3, 3] = [0.0, 0.0, -1.5]
+    return T
+
+
+SYNTHETIC_INTRINSICS = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1.0]])
+
+
+def synthetic_frame(t, H=480, W=640, seed=0):
+    """One benchmark frame -> input_pts [1, N, 6] float32 (float64 -> .float(), run_e2e.py:249)."""
+    pts = depth_to_input_pts(synthetic_depth(t, H, W, seed), SYNTHETIC_INTRINSICS, synthetic_pose(t))
+    return torch.from_numpy(pts).float().unsqueeze(0)

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WEIGHTS_FP32 = os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz")
+WEIGHTS_TCNN = os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,144 @@
+"""Pins oracle/bnv_oracle.py against the vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bnv_oracle as orc
+from conftest import GOLDEN, WEIGHTS_FP32
+
+torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+FLOAT_TOL = 2e-6  # same ATen ops as the reference; only thread-count summation order may differ
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return orc.load_weights(WEIGHTS_FP32)
+
+
+def _vol(z):
+    return orc.OracleSparseVolume(8, float(z["voxel_size"]), z["dims"], 8)
+
+
+@pytest.mark.parametrize("name", ["encode_64", "encode_128"])
+def test_encode_sparse_matches_reference(sd, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    vol = _vol(z)
+    pts = torch.from_numpy(z["input_pts"])
+    f, c, ids, g, n = orc.encode_pointcloud(sd, pts, vol.n_xyz, vol.min_coords, vol.max_coords, vol.voxel_size)
+    assert np.array_equal(ids.numpy(), z["flat_ids"])          # bit-exact
+    assert np.array_equal(c.numpy(), z["pcounts"]) and c.dtype == torch.int64
+    assert np.array_equal(g.numpy(), z["grid_ids"])
+    assert float(n) == float(z["n_avg_pts"])
+    assert np.abs(f.numpy() - z["feats"]).max() <= FLOAT_TOL
+
+
+def test_encode_dense_matches_reference(sd):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(z)
+    fg, mask, uids, flat_all = orc.encode_pointcloud(
+        sd, torch.from_numpy(z["input_pts"]), vol.n_xyz, vol.min_coords, vol.max_coords, vol.voxel_size,
+        return_dense=True)
+    assert np.array_equal(uids.numpy(), z["dense_unique_flat_ids"])
+    assert np.array_equal(flat_all[0].numpy(), z["dense_flat_ids_all"].astype(np.int64))
+    assert np.array_equal(mask[0, 0].reshape(-1).nonzero()[:, 0].numpy(), z["dense_nonzero"])
+    assert np.array_equal(mask[0, 0].reshape(-1)[uids].numpy(), z["dense_counts"])
+    assert np.abs(fg[0].reshape(8, -1)[:, uids].T.numpy() - z["dense_feats"]).max() <= FLOAT_TOL
+
+
+def test_encode_empty_returns_none(sd):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(z)
+    pts = torch.from_numpy(z["input_pts"]).clone()
+    pts[..., :3] += 100.0
+    out = orc.encode_pointcloud(sd, pts, vol.n_xyz, vol.min_coords, vol.max_coords, vol.voxel_size)
+    assert out == (None,) * 5
+
+
+@pytest.fixture(scope="module")
+def fused_volume(sd):
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    vol = _vol(z)
+    for fr in z["frames"]:
+        f, c, _, g, n = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords,
+                                              vol.max_coords, vol.voxel_size)
+        vol.track_n_pts(n)
+        orc.integrate(vol, g, f, c)
+    vol.to_tensor()
+    return vol, z
+
+
+def test_sequence_volume_matches_reference(fused_volume):
+    vol, z = fused_volume
+    assert np.array_equal(vol.active_coordinates.numpy(), z["keys_insertion"])
+    k = vol.active_coordinates.numpy()
+    order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+    assert np.array_equal(k[order], z["keys_sorted"])
+    assert np.abs(vol.weights.numpy()[order] - z["weights_sorted"]).max() <= 1e-6
+    assert np.abs(vol.features.numpy()[order] - z["features_sorted"]).max() <= FLOAT_TOL
+    assert np.array_equal(vol.num_hits.numpy()[order], z["num_hits_sorted"])
+    assert np.allclose(vol.n_pts_list, z["n_pts_list"])
+
+
+def test_decode_pts_matches_reference(sd, fused_volume):
+    vol, _ = fused_volume
+    z = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    lat = torch.from_numpy(z["lattice_coords"])
+    rnd = torch.from_numpy(z["random_coords"])
+    delta = torch.from_numpy(z["sdf_delta"])
+    assert np.array_equal(orc.lattice_coords(z["origins"]).numpy(), z["lattice_coords"])
+    cases = {
+        "lattice_qt": vol.decode_pts(lat, sd, None, is_coords=True, query_tensor=True),
+        "lattice_q": vol.decode_pts(lat, sd, None, is_coords=True, query_tensor=False),
+        "lattice_delta": vol.decode_pts(lat, sd, delta, is_coords=True, query_tensor=True),
+        "random_qt": vol.decode_pts(rnd, sd, None, is_coords=True, query_tensor=True),
+        "random_world_out": vol.decode_pts(torch.from_numpy(z["random_world_coords"]), sd, None,
+                                           is_coords=False, query_tensor=False),
+        "random_delta": vol.decode_pts(rnd, sd, delta, is_coords=True, query_tensor=True),
+    }
+    for k, v in cases.items():
+        assert v.shape == z[k].shape, k
+        assert np.abs(v.numpy() - z[k]).max() <= FLOAT_TOL, k
+        assert np.array_equal(v.numpy() == vol.voxel_size, z[k] == np.float32(vol.voxel_size)), k
+    # count_optim then decode
+    w0 = vol.weights.clone()
+    vol.count_optim(orc.get_neighbors(rnd))
+    k = vol.active_coordinates.numpy()
+    order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+    assert np.array_equal(vol.weights.numpy()[order], z["weights_after_count_optim_sorted"])
+    out = vol.decode_pts(rnd, sd, None, is_coords=True, query_tensor=True)
+    assert np.abs(out.numpy() - z["random_after_count_optim"]).max() <= FLOAT_TOL
+    vol.weights.copy_(w0)
+
+
+def test_dense_decode_matches_reference(sd):
+    z = np.load(os.path.join(GOLDEN, "dense_decode_64.npz"))
+    vol = _vol(z)
+    fg, mask, _, _ = orc.encode_pointcloud(sd, torch.from_numpy(z["input_pts"]), vol.n_xyz, vol.min_coords,
+                                           vol.max_coords, vol.voxel_size, return_dense=True)
+    sdf, _ = orc.decode_feature_grid_w_pts(sd, torch.from_numpy(z["queries"]), fg, mask, vol.voxel_size)
+    assert sdf.shape == z["sdf"].shape
+    assert np.abs(sdf.numpy() - z["sdf"]).max() <= FLOAT_TOL
+    assert 0 < (z["sdf"] == np.float32(vol.voxel_size)).sum() < z["sdf"].size
+
+
+def test_known_answers(sd, fused_volume):
+    """SURVEY.md section 8c known-answer properties (no reference import needed)."""
+    vol, z = fused_volume
+    # (iv) flatten(unflatten(id)) == id
+    ids = torch.randint(0, 64 ** 3, (1000,))
+    assert torch.equal(orc.flatten(orc.unflatten(ids, vol.n_xyz), vol.n_xyz), ids)
+    # (iii) a lattice point with a missing corner decodes to exactly voxel_size
+    far = orc.lattice_coords(np.array([[3, 3, 3]]))
+    assert torch.all(vol.decode_pts(far, sd, None, is_coords=True) == vol.voxel_size)
+    # (i) idempotence: fusing one frame k times keeps features, weights = k * min(count/32, 1)
+    v2 = _vol(z)
+    fr = torch.from_numpy(z["frames"][0])
+    f, c, _, g, _ = orc.encode_pointcloud(sd, fr, v2.n_xyz, v2.min_coords, v2.max_coords, v2.voxel_size)
+    for _ in range(3):
+        orc.integrate(v2, g, f, c)
+    v2.to_tensor()
+    assert np.abs(v2.features.numpy() - f.numpy()).max() < 5e-6
+    assert np.allclose(v2.weights.numpy(), 3 * np.minimum(c.numpy() / 32.0, 1.0), atol=1e-6)
