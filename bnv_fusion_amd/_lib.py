@@ -1,0 +1,119 @@
+"""ctypes binding of libbnv_fusion_hip.so (C ABI: include/bnv_fusion.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbnv_fusion_hip.so")
+
+# every symbol include/bnv_fusion.h declares
+SYMBOLS = [
+    "bnv_init", "bnv_num_compute_units", "bnv_status_string", "bnv_last_hip_error",
+    "bnv_encode_workspace_bytes", "bnv_encode_workspace_reset", "bnv_pointnet_pack_floats",
+    "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_voxelize_pairs",
+    "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
+    "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
+    "bnv_decode_pts", "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
+]
+
+
+class Grid(C.Structure):
+    _fields_ = [("bound_min", C.c_float * 3), ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3),
+                ("voxel_size", C.c_float), ("n_xyz", C.c_int32 * 3), ("min_pts_in_grid", C.c_int32),
+                ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_block_log2", C.c_int32)]
+
+
+class EncodeCounters(C.Structure):
+    _fields_ = [("n_valid_points", C.c_int32), ("n_unique", C.c_int32), ("n_out", C.c_int32),
+                ("n_avg_pts", C.c_float), ("error", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Volume(C.Structure):
+    _fields_ = [("slot_keys", C.c_void_p), ("slot_rows", C.c_void_p), ("n_slots", C.c_int64),
+                ("row_coords", C.c_void_p), ("features", C.c_void_p), ("weights", C.c_void_p),
+                ("num_hits", C.c_void_p), ("row_capacity", C.c_int64), ("n_rows", C.c_void_p),
+                ("n_feats", C.c_int32)]
+
+
+class SdfDelta(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("dims", C.c_int32 * 3)]
+
+
+class BnvError(RuntimeError):
+    pass
+
+
+_lib = None
+_initialised_device = None
+
+
+def load():
+    """Loads the shared library (building is the job of __graft_entry__.build / csrc/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python bnv_fusion_amd/csrc/build.py` "
+            "(hipcc, gfx950).  bnv_fusion_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+    sig = {
+        "bnv_init": (C.c_int, [C.c_int]),
+        "bnv_num_compute_units": (C.c_int, []),
+        "bnv_status_string": (C.c_char_p, [C.c_int]),
+        "bnv_last_hip_error": (C.c_int, []),
+        "bnv_encode_workspace_bytes": (sz, [i64, C.POINTER(i32)]),
+        "bnv_encode_workspace_reset": (C.c_int, [vp, sz, vp]),
+        "bnv_pointnet_pack_floats": (sz, []),
+        "bnv_sdfmlp_pack_floats": (sz, []),
+        "bnv_encode_pointcloud": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, vp, vp, vp, vp, i64, C.c_int,
+                                            vp, vp]),
+        "bnv_voxelize_pairs": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, vp, vp, vp]),
+        "bnv_volume_clear": (C.c_int, [C.POINTER(Volume), vp]),
+        "bnv_volume_rehash": (C.c_int, [C.POINTER(Volume), vp]),
+        "bnv_volume_workspace_bytes": (sz, [i64]),
+        "bnv_volume_integrate": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, sz, vp]),
+        "bnv_volume_insert": (C.c_int, [C.POINTER(Volume), vp, vp, vp, vp, i64, vp, sz, vp]),
+        "bnv_volume_query": (C.c_int, [C.POINTER(Volume), vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
+        "bnv_volume_count_optim": (C.c_int, [C.POINTER(Volume), vp, i64, vp, i64, vp, i32, vp]),
+        "bnv_decode_pts": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, C.c_int,
+                                     C.POINTER(SdfDelta), vp, vp]),
+        "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
+        "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64,
+                                         C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
+        "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, vp, vp]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        lib = load()
+        msg = lib.bnv_status_string(status).decode()
+        raise BnvError(f"{what} failed: {msg} (status {status}, hip error {lib.bnv_last_hip_error()})")
+
+
+def require_device(device_index):
+    """bnv_init on first use; raises if no MI355X-class device / library is available."""
+    global _initialised_device
+    lib = load()
+    if _initialised_device != device_index:
+        check(lib.bnv_init(int(device_index)), "bnv_init")
+        _initialised_device = device_index
+    return lib
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

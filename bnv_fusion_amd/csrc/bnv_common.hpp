@@ -1,0 +1,118 @@
+// Shared device helpers for the gfx950 kernels (wave64, CDNA4).  Compiled with
+// -ffp-contract=off: every float op below rounds exactly once, like the reference's ATen CPU ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bnv_fusion.h"
+
+namespace bnv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+extern int g_num_cus;
+extern int g_last_hip_error;
+
+#define BNV_HIP_CHECK(expr)                      \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) {                      \
+      bnv::g_last_hip_error = (int)_e;           \
+      return BNV_ERR_HIP;                        \
+    }                                            \
+  } while (0)
+
+#define BNV_LAUNCH_CHECK() BNV_HIP_CHECK(hipGetLastError())
+
+// Corner order of get_neighbors (modules.py:590-655): bit0 = x uses ceil, bit1 = y, bit2 = z.
+__device__ __constant__ const unsigned char kCornerCeilBits[8] = {0, 1, 2, 4, 3, 5, 6, 7};
+
+// Normalised voxel coordinate of one axis: (x - bound_min) / voxel, two IEEE fp32 roundings
+// (local_point_fusion.py:159-160).
+__device__ __forceinline__ float voxel_coord(float x, float bmin, float voxel) {
+  return __fdiv_rn(__fsub_rn(x, bmin), voxel);
+}
+
+__device__ __forceinline__ bool in_bounds(float x, float y, float z, const bnv_grid_t& g) {
+  // strict, one-voxel margin (local_point_fusion.py:94-100); NaN fails every comparison.
+  return (x < g.bound_hi[0]) && (y < g.bound_hi[1]) && (z < g.bound_hi[2]) &&
+         (x > g.bound_lo[0]) && (y > g.bound_lo[1]) && (z > g.bound_lo[2]);
+}
+
+// rel = ((xn - gid) * voxel) / voxel  (local_point_fusion.py:163-164 then :59)
+__device__ __forceinline__ float relative_coord(float xn, int gid, float voxel) {
+  float t = __fsub_rn(xn, (float)gid);
+  return __fdiv_rn(__fmul_rn(t, voxel), voxel);
+}
+
+__device__ __forceinline__ uint32_t mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// Shard owner of a voxel: hash of its block coordinate.
+__device__ __forceinline__ int voxel_owner(int x, int y, int z, const bnv_grid_t& g) {
+  if (g.shard_world <= 1) return 0;
+  const int s = g.shard_block_log2;
+  uint64_t b = ((uint64_t)(uint32_t)(x >> s) << 42) | ((uint64_t)(uint32_t)(y >> s) << 21) |
+               (uint64_t)(uint32_t)(z >> s);
+  return (int)(mix64(b) % (uint32_t)g.shard_world);
+}
+
+// ---- packed volume keys -------------------------------------------------------------------
+constexpr uint64_t kEmptyKey = ~0ULL;
+constexpr int64_t kKeyOffset = 1 << 20;
+
+__device__ __forceinline__ bool pack_key(int64_t x, int64_t y, int64_t z, uint64_t* key) {
+  const int64_t a = x + kKeyOffset, b = y + kKeyOffset, c = z + kKeyOffset;
+  if ((uint64_t)a >= (1u << 21) || (uint64_t)b >= (1u << 21) || (uint64_t)c >= (1u << 21)) return false;
+  *key = ((uint64_t)a << 42) | ((uint64_t)b << 21) | (uint64_t)c;
+  return true;
+}
+
+// Row of a key in the slot table, or -1.  Linear probing; rows < 0 are "being inserted".
+__device__ __forceinline__ int volume_find(const uint64_t* __restrict__ slot_keys,
+                                           const int32_t* __restrict__ slot_rows, uint32_t mask,
+                                           uint64_t key) {
+  uint32_t s = mix64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    const uint64_t k = slot_keys[s];
+    if (k == key) return slot_rows[s];
+    if (k == kEmptyKey) return -1;
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+// ---- block-wide exclusive scan of one uint32 per thread (256 or 1024 threads) ---------------
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_totals,
+                                                         uint32_t* block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) lds_wave_totals[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) {
+    const uint32_t t = lds_wave_totals[w];
+    if (w < wave) base += t;
+    total += t;
+  }
+  __syncthreads();
+  *block_total = total;
+  return base + incl - v;
+}
+
+}  // namespace bnv

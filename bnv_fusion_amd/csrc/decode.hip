@@ -1,0 +1,567 @@
+// decode.hip -- SDF decode (reference sparse_volume.py:768-833, local_point_fusion.py:265-379,
+// modules.py:81-123,657-662) on gfx950.
+//
+// One MLP core, 17 -> 256 -> 256 -> 256 -> 256 -> 1 in exact fp32 on v_mfma_f32_32x32x2_f32:
+//   * a workgroup (8 waves) evaluates a tile of 128 inputs; wave w owns output features
+//     [32w, 32w+32) of every layer for all 128 inputs (4 MFMA column tiles of 32);
+//   * activations live in LDS as HL[kb][h][j][4] (feature 8kb+4h+i of input j): a wave reads its
+//     B operands with conflict-free ds_read_b128 and writes its D registers back with
+//     ds_write_b128 -- D register 4q+i of lane (j,h) IS feature 32w+8q+4h+i, the same layout;
+//   * weights stream from L2 (0.8 MB, resident in every XCD's 4 MB L2) as one coalesced
+//     dwordx4 per lane per 8-deep K block, pre-permuted on the host (weights.py: pack_sdf_mlp).
+// Three front/back-ends share it:
+//   PTS      SparseVolume.decode_pts at arbitrary points: 8 corner evaluations per point;
+//   LATTICE  per-voxel table g[row][27] = MLP(enc(l), feat[row]) * voxel, l in {-.5,0,.5}^3 --
+//            on the 3x3x3 meshing lattice every (point, corner) input is one of those 27 per
+//            corner voxel, so the MLP runs 27x per corner voxel instead of 216x per voxel;
+//   DENSE    decode_feature_grid_w_pts on dense grids.
+#include "bnv_common.hpp"
+
+namespace bnv {
+
+constexpr int DM = 128;  // MLP inputs per tile
+
+// packed SDF-MLP weights (floats)
+constexpr int SD_W0 = 0;                      // [8 w][3 kb][64 lane][4]
+constexpr int SD_W1 = SD_W0 + 8 * 3 * 256;    // [8 w][32 kb][64 lane][4]
+constexpr int SD_W2 = SD_W1 + 65536;
+constexpr int SD_W3 = SD_W2 + 65536;
+constexpr int SD_B0 = SD_W3 + 65536;          // [256] x 4
+constexpr int SD_WA = SD_B0 + 4 * 256;        // fc_alpha weight [256]
+constexpr int SD_BA = SD_WA + 256;            // fc_alpha bias, padded to 4
+constexpr int SD_TOTAL = SD_BA + 4;
+
+// LDS (floats)
+constexpr int L_HL = 0;                       // [32 kb][2 h][128 j][4]
+constexpr int L_PART = L_HL + 32 * 2 * DM * 4;  // [8 w][2 h][128]
+constexpr int L_ALPHA = L_PART + 16 * DM;     // [128]
+constexpr int L_WTRI = L_ALPHA + DM;          // [128] trilinear weight of the evaluation
+constexpr int L_WVOL = L_WTRI + DM;           // [128] volume weight (or dense count) of its corner
+constexpr int L_DELTA = L_WVOL + DM;          // [128] sdf_delta sample of its corner
+constexpr int L_TOTAL = L_DELTA + DM;         // 35,328 floats = 141,312 B
+
+enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2 };
+
+struct DecodeArgs {
+  bnv_volume_t vol;
+  bnv_grid_t grid;
+  const float* features;
+  const float* weights;
+  int64_t row_limit;
+  const float* pack;
+  const float* coords;
+  int64_t n;
+  int is_coords;
+  bnv_sdf_delta_t delta;
+  float* out;
+  // LATTICE
+  const int32_t* list;
+  const int32_t* n_list;
+  float* table;
+  // DENSE
+  const float* feat_grid;
+  const float* pts_weight;
+  int32_t dims[3];
+};
+
+__device__ __forceinline__ f32x16 frag256(const float* __restrict__ b, int w, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *(const f32x4*)&b[w * 32 + 8 * q + 4 * h];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[4 * q + i] = t[i];
+  }
+  return v;
+}
+
+template <int NKB>
+__device__ __forceinline__ void mlp_layer(const float* __restrict__ wp, const float* __restrict__ bias,
+                                          const float* __restrict__ hl, f32x16 (&acc)[4], int w, int lane,
+                                          int j, int h) {
+  const f32x16 b0 = frag256(bias, w, h);
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
+  const float* wl = wp + (size_t)w * NKB * 256 + lane * 4;
+  const float* hb = hl + (h * DM + j) * 4;
+#pragma unroll 4
+  for (int kb = 0; kb < NKB; ++kb) {
+    const f32x4 a = *(const f32x4*)(wl + kb * 256);
+    f32x4 b[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) b[pt] = *(const f32x4*)(hb + (kb * 2 * DM + pt * 32) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[pt][i], acc[pt], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_relu(float* __restrict__ hl, const f32x16 (&acc)[4], int w, int j, int h) {
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[pt][4 * q + i], 0.f);
+      *(f32x4*)&hl[(((4 * w + q) * 2 + h) * DM + pt * 32 + j) * 4] = v;
+    }
+  }
+}
+
+// Runs the MLP on the 128 inputs staged in HL[kb 0..2]; leaves alpha[128] (raw network output).
+__device__ __forceinline__ void sdf_mlp_tile(float* __restrict__ lds, const float* __restrict__ pack) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  float* hl = lds + L_HL;
+  f32x16 acc[4];
+  mlp_layer<3>(pack + SD_W0, pack + SD_B0, hl, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu(hl, acc, w, j, h);
+  __syncthreads();
+  mlp_layer<32>(pack + SD_W1, pack + SD_B0 + 256, hl, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu(hl, acc, w, j, h);
+  __syncthreads();
+  mlp_layer<32>(pack + SD_W2, pack + SD_B0 + 512, hl, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu(hl, acc, w, j, h);
+  __syncthreads();
+  mlp_layer<32>(pack + SD_W3, pack + SD_B0 + 768, hl, acc, w, lane, j, h);
+  // fc_alpha: 256 -> 1.  Each lane reduces its 16 features, partials are summed in a fixed order.
+  const f32x16 wa = frag256(pack + SD_WA, w, h);
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], fmaxf(acc[pt][r], 0.f), s);
+    lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < DM) {
+    float s = pack[SD_BA];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s += lds[L_PART + p * DM + threadIdx.x];
+    lds[L_ALPHA + threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// writes the 17 network inputs [local(3), sin(3), cos(3), feat(8)] of evaluation j into HL
+__device__ __forceinline__ void stage_input(float* __restrict__ hl, int j, const float (&loc)[3],
+                                            const float (&feat)[8]) {
+  const float s0 = sinf(loc[0]), s1 = sinf(loc[1]), s2 = sinf(loc[2]);
+  const float c0 = cosf(loc[0]), c1 = cosf(loc[1]), c2 = cosf(loc[2]);
+  const f32x4 v0 = {loc[0], loc[1], loc[2], s0};
+  const f32x4 v1 = {s1, s2, c0, c1};
+  const f32x4 v2 = {c2, feat[0], feat[1], feat[2]};
+  const f32x4 v3 = {feat[3], feat[4], feat[5], feat[6]};
+  const f32x4 v4 = {feat[7], 0.f, 0.f, 0.f};
+  const f32x4 v5 = {0.f, 0.f, 0.f, 0.f};
+  *(f32x4*)&hl[((0 * 2 + 0) * DM + j) * 4] = v0;
+  *(f32x4*)&hl[((0 * 2 + 1) * DM + j) * 4] = v1;
+  *(f32x4*)&hl[((1 * 2 + 0) * DM + j) * 4] = v2;
+  *(f32x4*)&hl[((1 * 2 + 1) * DM + j) * 4] = v3;
+  *(f32x4*)&hl[((2 * 2 + 0) * DM + j) * 4] = v4;
+  *(f32x4*)&hl[((2 * 2 + 1) * DM + j) * 4] = v5;
+}
+
+// F.grid_sample(mode="nearest", padding_mode="zeros", align_corners=True) of the TSDF prior at a
+// corner given in voxel units (sparse_volume.py:820-829): coordinate a -> index along dims[a].
+__device__ __forceinline__ float sample_delta(const bnv_sdf_delta_t& d, const bnv_grid_t& g, const float (&c)[3]) {
+  int idx[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float t = __fdiv_rn(c[a], (float)(g.n_xyz[a] - 1));
+    t = __fsub_rn(__fmul_rn(t, 2.f), 1.f);
+    t = __fmul_rn(__fdiv_rn(__fadd_rn(t, 1.f), 2.f), (float)(d.dims[a] - 1));
+    const float r = nearbyintf(t);
+    if (!(r >= 0.f) || !(r <= (float)(d.dims[a] - 1))) return 0.f;
+    idx[a] = (int)r;
+  }
+  return d.data[((size_t)idx[0] * d.dims[1] + idx[1]) * d.dims[2] + idx[2]];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hl = lds + L_HL;
+  const float voxel = A.grid.voxel_size;
+  int64_t n_tiles;
+  int64_t n_evals = 0;
+  if constexpr (MODE == MODE_LATTICE) {
+    n_evals = (int64_t)(*A.n_list) * 27;
+    n_tiles = (n_evals + DM - 1) / DM;
+  } else {
+    n_tiles = (A.n + 15) / 16;
+  }
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---------------- front end: one thread per MLP input ---------------------------------
+    if (threadIdx.x < DM) {
+      const int j = threadIdx.x;
+      float loc[3] = {0.f, 0.f, 0.f};
+      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float wtri = 0.f, wvol = 0.f, dlt = 0.f;
+      if constexpr (MODE == MODE_LATTICE) {
+        const int64_t e = tile * DM + j;
+        if (e < n_evals) {
+          const int64_t ci = e / 27;
+          const int l = (int)(e - ci * 27);
+          const int row = A.list[ci];
+          loc[0] = (float)(l / 9 - 1) * 0.5f;
+          loc[1] = (float)((l / 3) % 3 - 1) * 0.5f;
+          loc[2] = (float)(l % 3 - 1) * 0.5f;
+          const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+          const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            feat[f] = f0[f];
+            feat[4 + f] = f1[f];
+          }
+        }
+      } else {
+        const int64_t q = tile * 16 + (j >> 3);
+        const int cb = kCornerCeilBits[j & 7];
+        if (q < A.n) {
+          float c[3], corner[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            c[a] = A.coords[q * 3 + a];
+            if (MODE == MODE_PTS && !A.is_coords)  // (coords - min_coords) / voxel_size (:793)
+              c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
+            corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
+            loc[a] = __fsub_rn(c[a], corner[a]);
+          }
+          wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
+          if constexpr (MODE == MODE_PTS) {
+            uint64_t key;
+            int row = -1;
+            if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
+              row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
+            if (row >= A.row_limit) row = -1;
+            if (row >= 0) {
+              const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+              const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+              for (int f = 0; f < 4; ++f) {
+                feat[f] = f0[f];
+                feat[4 + f] = f1[f];
+              }
+              wvol = A.weights[row];
+            }
+            if (A.delta.data) dlt = sample_delta(A.delta, A.grid, corner);
+          } else {  // MODE_DENSE: nearest gather == direct index, zero outside (:296-310)
+            const int x = (int)corner[0], y = (int)corner[1], z = (int)corner[2];
+            if (x >= 0 && y >= 0 && z >= 0 && x < A.dims[0] && y < A.dims[1] && z < A.dims[2]) {
+              const size_t plane = (size_t)A.dims[0] * A.dims[1] * A.dims[2];
+              const size_t o = ((size_t)x * A.dims[1] + y) * A.dims[2] + z;
+#pragma unroll
+              for (int f = 0; f < 8; ++f) feat[f] = A.feat_grid[f * plane + o];
+              wvol = A.pts_weight[o];
+            }
+            // relative_xyz = rel * voxel; decode_implicit divides it by voxel again (:321,:374)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) loc[a] = __fdiv_rn(__fmul_rn(loc[a], voxel), voxel);
+          }
+        }
+      }
+      stage_input(hl, j, loc, feat);
+      lds[L_WTRI + j] = wtri;
+      lds[L_WVOL + j] = wvol;
+      lds[L_DELTA + j] = dlt;
+    }
+    __syncthreads();
+    // ---------------- MLP -----------------------------------------------------------------
+    sdf_mlp_tile(lds, A.pack);
+    // ---------------- back end ------------------------------------------------------------
+    if constexpr (MODE == MODE_LATTICE) {
+      if (threadIdx.x < DM) {
+        const int64_t e = tile * DM + threadIdx.x;
+        if (e < n_evals) {
+          const int64_t ci = e / 27;
+          const int l = (int)(e - ci * 27);
+          A.table[(size_t)A.list[ci] * 27 + l] = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
+        }
+      }
+    } else {
+      if (threadIdx.x < 16) {
+        const int64_t q = tile * 16 + threadIdx.x;
+        if (q < A.n) {
+          const int b = threadIdx.x * 8;
+          float norm = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) norm = __fadd_rn(norm, lds[L_WTRI + b + k]);
+          float acc = 0.f, dacc = 0.f, wmin = 3.4e38f, wsum = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float wk = __fdiv_rn(lds[L_WTRI + b + k], norm);
+            const float wv = lds[L_WVOL + b + k];
+            float a = __fmul_rn(lds[L_ALPHA + b + k], voxel);
+            if constexpr (MODE == MODE_DENSE) {
+              const bool ok = wv >= (float)A.grid.min_pts_in_grid;  // forward_with_mask (modules.py:774-783)
+              a = ok ? a : 0.f;
+              wsum = __fadd_rn(wsum, ok ? wv : 0.f);
+            }
+            acc = __fadd_rn(acc, __fmul_rn(a, wk));
+            dacc = __fadd_rn(dacc, __fmul_rn(lds[L_DELTA + b + k], wk));
+            wmin = fminf(wmin, wv);
+          }
+          float out;
+          if constexpr (MODE == MODE_DENSE) {
+            out = (wsum > 0.f) ? acc : voxel;  // any corner valid (:328-329)
+          } else {
+            out = (wmin >= (float)A.grid.min_pts_in_grid) ? acc : voxel;  // all corners valid (:809,:818)
+            if (A.delta.data) out = __fadd_rn(out, dacc);
+          }
+          A.out[q] = out;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- lattice decode: neighbour lookup + blend ------------------------------------------------
+struct LatticeWs {
+  int32_t* nbr_rows;  // [n][27]
+  int32_t* list;      // [list_capacity] rows whose table is needed
+  int32_t* n_list;    // [1]
+  int32_t* stamp;     // [row_capacity]
+  float* table;       // [row_capacity][27]
+  int64_t list_capacity;
+};
+
+static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws) {
+  if (n < 1) n = 1;
+  int64_t cap = 27 * n;
+  if (cap > row_capacity) cap = row_capacity;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off = (off + bytes + 255) / 256 * 256;
+    return p;
+  };
+  // stamp and table first: they persist across calls with the same row_capacity
+  char* st = take(row_capacity * 4);
+  char* tb = take(row_capacity * 27 * 4);
+  char* nl = take(256);
+  char* nb = take(n * 27 * 4);
+  char* li = take(cap * 4);
+  if (ws) {
+    ws->stamp = (int32_t*)st;
+    ws->table = (float*)tb;
+    ws->n_list = (int32_t*)nl;
+    ws->nbr_rows = (int32_t*)nb;
+    ws->list = (int32_t*)li;
+    ws->list_capacity = cap;
+  }
+  return off;
+}
+
+__global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const int64_t* __restrict__ origins,
+                                                           int64_t n, const float* __restrict__ weights,
+                                                           int64_t row_limit, float min_pts,
+                                                           int32_t* __restrict__ nbr_rows,
+                                                           int32_t* __restrict__ stamp, int32_t epoch,
+                                                           int32_t* __restrict__ list, int32_t* __restrict__ n_list) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * 27) return;
+  const int64_t b = t / 27;
+  const int nb = (int)(t - b * 27);
+  const int64_t x = origins[b * 3 + 0] + (nb / 9 - 1);
+  const int64_t y = origins[b * 3 + 1] + ((nb / 3) % 3 - 1);
+  const int64_t z = origins[b * 3 + 2] + (nb % 3 - 1);
+  uint64_t key;
+  int row = -1;
+  if (pack_key(x, y, z, &key)) row = volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+  if (row >= row_limit) row = -1;
+  bool usable = false;
+  if (row >= 0) usable = weights[row] >= min_pts;
+  // rows below min_pts can only ever appear under a false mask: mark them as unusable corners
+  nbr_rows[t] = usable ? row : -1;
+  if (usable && atomicExch(&stamp[row], epoch) != epoch) list[atomicAdd(n_list, 1)] = row;
+}
+
+__global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
+                                                       const float* __restrict__ table, bnv_grid_t g,
+                                                       const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
+                                                       float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * 27) return;
+  const int64_t b = t / 27;
+  const int p = (int)(t - b * 27);
+  const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};  // lattice point = origin + 0.5 * d
+  float wk[8];
+  int rowk[8], lk[8];
+  float ck[8][3];
+  float norm = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int cb = kCornerCeilBits[k];
+    int nbi = 0, li = 0;
+    float w = 1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      int nb_a = 0, loc2 = 0;  // neighbour offset of the corner voxel, 2 * local coordinate
+      if (d[a] != 0) {
+        if ((cb >> a) & 1) {
+          nb_a = (d[a] + 1) / 2;
+          loc2 = -1;
+        } else {
+          nb_a = (d[a] - 1) / 2;
+          loc2 = 1;
+        }
+        w = __fmul_rn(w, 0.5f);
+      }
+      nbi = nbi * 3 + (nb_a + 1);
+      li = li * 3 + (loc2 + 1);
+      ck[k][a] = (float)(origins[b * 3 + a] + nb_a);
+    }
+    wk[k] = w;
+    lk[k] = li;
+    rowk[k] = nbr_rows[b * 27 + nbi];
+    norm = __fadd_rn(norm, w);
+  }
+  bool ok = true;
+  float acc = 0.f, dacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = __fdiv_rn(wk[k], norm);
+    if (rowk[k] < 0) ok = false;
+    const float a = rowk[k] >= 0 ? table[(size_t)rowk[k] * 27 + lk[k]] : 0.f;
+    acc = __fadd_rn(acc, __fmul_rn(a, w));
+    if (delta.data) dacc = __fadd_rn(dacc, __fmul_rn(sample_delta(delta, g, ck[k]), w));
+  }
+  float o = ok ? acc : g.voxel_size;
+  if (delta.data) o = __fadd_rn(o, dacc);
+  out[t] = o;
+}
+
+static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
+  int64_t grid = g_num_cus;
+  if (n_tiles_hint < grid) grid = n_tiles_hint;
+  if (grid < 1) grid = 1;
+  if (mode == MODE_PTS)
+    hipLaunchKernelGGL(k_decode<MODE_PTS>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
+  else if (mode == MODE_LATTICE)
+    hipLaunchKernelGGL(k_decode<MODE_LATTICE>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
+  else
+    hipLaunchKernelGGL(k_decode<MODE_DENSE>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+static bool vol_ok_ro(const bnv_volume_t* v) {
+  return v && v->slot_keys && v->slot_rows && v->n_slots > 0 && (v->n_slots & (v->n_slots - 1)) == 0 &&
+         v->n_feats == 8;
+}
+
+}  // namespace bnv
+
+using namespace bnv;
+
+extern "C" {
+
+int bnv_decode_init() {
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_PTS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_LATTICE>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L_TOTAL * 4));
+  return BNV_OK;
+}
+
+size_t bnv_sdfmlp_pack_floats(void) { return SD_TOTAL; }
+
+int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
+                   int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,
+                   const bnv_sdf_delta_t* delta, float* out_sdf, bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!coords || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
+  DecodeArgs a = {};
+  a.vol = *vol;
+  a.grid = *grid;
+  a.features = features;
+  a.weights = weights;
+  a.row_limit = row_limit;
+  a.pack = sdfmlp_pack;
+  a.coords = coords;
+  a.n = n;
+  a.is_coords = is_coords;
+  if (delta) a.delta = *delta;
+  a.out = out_sdf;
+  return launch_decode(MODE_PTS, a, (n + 15) / 16, (hipStream_t)stream);
+}
+
+int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims[3], float voxel_size,
+                     int32_t min_pts_in_grid, const float* sdfmlp_pack, const float* voxel_coords, int64_t n,
+                     float* out_sdf, bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!feat_grid || !pts_weight || !dims || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!voxel_coords || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
+  DecodeArgs a = {};
+  a.grid.voxel_size = voxel_size;
+  a.grid.min_pts_in_grid = min_pts_in_grid;
+  a.pack = sdfmlp_pack;
+  a.coords = voxel_coords;
+  a.n = n;
+  a.is_coords = 1;
+  a.out = out_sdf;
+  a.feat_grid = feat_grid;
+  a.pts_weight = pts_weight;
+  a.dims[0] = dims[0];
+  a.dims[1] = dims[1];
+  a.dims[2] = dims[2];
+  return launch_decode(MODE_DENSE, a, (n + 15) / 16, (hipStream_t)stream);
+}
+
+size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity) {
+  return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr);
+}
+
+int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                       const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
+                       int64_t n, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, int32_t epoch,
+                       float* out_sdf, bnv_stream_t stream_) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || n < 0 || epoch == 0)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!origins || !out_sdf || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  LatticeWs ws;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 4, stream));
+  const unsigned nb = (unsigned)((n * 27 + 255) / 256);
+  hipLaunchKernelGGL(k_lattice_neighbors, dim3(nb), dim3(256), 0, stream, *vol, origins, n, weights, row_limit,
+                     (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch, ws.list, ws.n_list);
+  BNV_LAUNCH_CHECK();
+  DecodeArgs a = {};
+  a.vol = *vol;
+  a.grid = *grid;
+  a.features = features;
+  a.weights = weights;
+  a.row_limit = row_limit;
+  a.pack = sdfmlp_pack;
+  a.list = ws.list;
+  a.n_list = ws.n_list;
+  a.table = ws.table;
+  const int rc = launch_decode(MODE_LATTICE, a, (ws.list_capacity * 27 + DM - 1) / DM, stream);
+  if (rc != BNV_OK) return rc;
+  bnv_sdf_delta_t d = {};
+  if (delta) d = *delta;
+  hipLaunchKernelGGL(k_lattice_blend, dim3(nb), dim3(256), 0, stream, ws.nbr_rows, n, ws.table, *grid, origins, d,
+                     out_sdf);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+}  // extern "C"

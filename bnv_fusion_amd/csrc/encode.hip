@@ -1,0 +1,610 @@
+// encode.hip -- LitFusionPointNet.encode_pointcloud (reference local_point_fusion.py:81-165)
+// as five gfx950 kernels:
+//
+//   k_mark            points -> 8 corner voxels -> atomicOr into a grid bitmap            (HBM/L2)
+//   k_scan_*          popcount prefix over the bitmap: the rank of a voxel's bit IS its
+//                     position in torch.unique's ascending output (replaces sort+unique)  (HBM/L2)
+//   k_pointnet_scatter  per (point, corner) pair: 6->128->128->128->8 MLP on fp32 MFMA
+//                     (v_mfma_f32_32x32x2_f32, transposed chaining: layer L's D registers are
+//                     layer L+1's B operands, no cross-lane traffic), then order-independent
+//                     64-bit fixed-point atomics into per-voxel accumulators               (MFMA)
+//   k_finalize_*      mean, min-points filter, ordered compaction, unflatten, cleanup      (HBM)
+//
+// Layout of one MFMA tile: 32 pairs = 32 consecutive points x one corner; lane l = (j = l & 31:
+// pair, h = l >> 5).  D register r of a 32-feature block holds feature (r&3) + 8*(r>>2) + 4*h of
+// pair j, so the K-step that consumes D[r] as its B operand contracts features
+// {f0(r), f0(r)+4}; the packed A operands (weights) are pre-permuted on the host to match
+// (bnv_fusion_amd/weights.py: pack_pointnet).
+#include "bnv_common.hpp"
+
+namespace bnv {
+
+int g_num_cus = 0;
+int g_last_hip_error = 0;
+
+// ------------------------------------------------------------------------------------------
+// packed point-encoder weights (floats)
+// ------------------------------------------------------------------------------------------
+constexpr int PN_W1 = 0;                        // [3 kstep][4 mb][64 lane]
+constexpr int PN_W2 = PN_W1 + 3 * 4 * 64;       // [4 mb][4 nb][4 rq][64 lane][4]
+constexpr int PN_W3 = PN_W2 + 128 * 128;        // same
+constexpr int PN_W4 = PN_W3 + 128 * 128;        // [4 nb][4 rq][2 h][8 n][4]
+constexpr int PN_B1 = PN_W4 + 4 * 4 * 2 * 8 * 4;  // [128]
+constexpr int PN_B2 = PN_B1 + 128;
+constexpr int PN_B3 = PN_B2 + 128;
+constexpr int PN_B4 = PN_B3 + 128;              // [8]
+constexpr int PN_TOTAL = PN_B4 + 8;             // 34,952 floats = 139,808 B of LDS
+
+constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exact integers
+
+// ------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------
+struct EncodeWs {
+  uint32_t* bitmap;       // [n_words]
+  uint32_t* word_prefix;  // [n_words]
+  uint32_t* block_sums;   // [n_scan_blocks + 1]
+  int32_t* ids;           // [max_unique] flat voxel id of slot s (ascending)
+  int32_t* counts;        // [max_unique]
+  long long* acc;         // [max_unique][8] fixed-point feature sums
+  int64_t n_words;
+  int64_t max_unique;
+  int64_t n_scan_blocks;
+};
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 elements per block
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char* base, EncodeWs* ws) {
+  const int64_t nvox = (int64_t)n_xyz[0] * n_xyz[1] * n_xyz[2];
+  const int64_t n_words = (nvox + 31) / 32;
+  int64_t max_unique = 8 * max_points;
+  if (max_unique > nvox) max_unique = nvox;
+  if (max_unique < 1) max_unique = 1;
+  const int64_t nb_words = (n_words + kScanTile - 1) / kScanTile;
+  const int64_t nb_unique = (max_unique + kScanTile - 1) / kScanTile;
+  const int64_t n_scan_blocks = nb_words > nb_unique ? nb_words : nb_unique;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off = align_up(off + bytes, 256);
+    return p;
+  };
+  char* p_bitmap = take(n_words * 4);
+  char* p_prefix = take(n_words * 4);
+  char* p_sums = take((n_scan_blocks + 1) * 4);
+  char* p_ids = take(max_unique * 4);
+  char* p_counts = take(max_unique * 4);
+  char* p_acc = take(max_unique * 8 * 8);
+  if (ws) {
+    ws->bitmap = (uint32_t*)p_bitmap;
+    ws->word_prefix = (uint32_t*)p_prefix;
+    ws->block_sums = (uint32_t*)p_sums;
+    ws->ids = (int32_t*)p_ids;
+    ws->counts = (int32_t*)p_counts;
+    ws->acc = (long long*)p_acc;
+    ws->n_words = n_words;
+    ws->max_unique = max_unique;
+    ws->n_scan_blocks = n_scan_blocks;
+  }
+  return off;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mark: one thread per point
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
+                                              uint32_t* __restrict__ bitmap,
+                                              bnv_encode_counters_t* __restrict__ counters) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < n_points) {
+    x = pts[(size_t)i * 6 + 0];
+    y = pts[(size_t)i * 6 + 1];
+    z = pts[(size_t)i * 6 + 2];
+    valid = in_bounds(x, y, z, g);
+  }
+  if (valid) {
+    const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+    const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+    const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+    const int fx = (int)floorf(xn), cx = (int)ceilf(xn);
+    const int fy = (int)floorf(yn), cy = (int)ceilf(yn);
+    const int fz = (int)floorf(zn), cz = (int)ceilf(zn);
+    const int nyz = g.n_xyz[1] * g.n_xyz[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
+      // duplicates (floor == ceil) just set the same bit again
+      if ((k & 1) && cx == fx) continue;
+      if ((k & 2) && cy == fy) continue;
+      if ((k & 4) && cz == fz) continue;
+      const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+      atomicOr(&bitmap[id >> 5], 1u << (id & 31));
+    }
+  }
+  const unsigned long long b = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters->n_valid_points, (int)__popcll(b));
+}
+
+// ------------------------------------------------------------------------------------------
+// three-phase device-wide exclusive scan over f(idx)
+// ------------------------------------------------------------------------------------------
+struct PopcWords {
+  const uint32_t* words;
+  __device__ uint32_t operator()(int64_t i) const { return __popc(words[i]); }
+};
+struct ValidFlags {  // 1 where the voxel in slot s is emitted
+  const int32_t* counts;
+  const int32_t* ids;
+  bnv_grid_t g;
+  int emit_all;
+  __device__ uint32_t operator()(int64_t s) const {
+    if (!emit_all && counts[s] < g.min_pts_in_grid) return 0;
+    if (g.shard_world > 1) {
+      const int id = ids[s];
+      const int nyz = g.n_xyz[1] * g.n_xyz[2];
+      const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+      if (voxel_owner(x, y, z, g) != g.shard_rank) return 0;
+    }
+    return 1;
+  }
+};
+
+template <class F>
+__global__ __launch_bounds__(kScanThreads) void k_scan_partial(F f, const int32_t* __restrict__ n_dev,
+                                                               int64_t n_static,
+                                                               uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+  if (base < n) {
+#pragma unroll
+    for (int e = 0; e < kScanItems; ++e)
+      if (base + e < n) s += f(base + e);
+  }
+  uint32_t total;
+  block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one block of 1024 threads: exclusive scan of block_sums[0:n_blocks) in place, total appended
+__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
+                                                   int32_t* __restrict__ total_out) {
+  __shared__ uint32_t wave_tot[16];
+  uint32_t carry = 0;
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = (i < n_blocks) ? block_sums[i] : 0;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<1024>(v, wave_tot, &total);
+    if (i < n_blocks) block_sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    block_sums[n_blocks] = carry;
+    if (total_out) *total_out = (int32_t)carry;
+  }
+}
+
+// apply phase for the bitmap: word_prefix + expansion of set bits into ids[]
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply_bitmap(const uint32_t* __restrict__ bitmap,
+                                                                   int64_t n_words,
+                                                                   const uint32_t* __restrict__ block_sums,
+                                                                   uint32_t* __restrict__ word_prefix,
+                                                                   int32_t* __restrict__ ids, int64_t max_unique,
+                                                                   bnv_encode_counters_t* __restrict__ counters) {
+  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  uint32_t w[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    w[e] = (base + e < n_words) ? bitmap[base + e] : 0u;
+    s += __popc(w[e]);
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
+  if (total == 0) {  // nothing set in this tile: prefixes are never read for clear words
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    if (base + e < n_words) {
+      uint32_t bits = w[e];
+      if (bits) {
+        word_prefix[base + e] = run;
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (run < max_unique) ids[run] = (int32_t)((base + e) * 32 + b);
+          else counters->error = 1;
+          ++run;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_pointnet_scatter
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+  return v;
+}
+
+__device__ __forceinline__ f32x16 bias_init(const float* __restrict__ b, int mb, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *(const f32x4*)&b[mb * 32 + 8 * q + 4 * h];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[4 * q + i] = t[i];
+  }
+  return v;
+}
+
+// 128 -> 128 layer: out[mb] += W[mb][nb] * in[nb]
+__device__ __forceinline__ void layer128(const float* __restrict__ wp, const float* __restrict__ bias,
+                                         const f32x16 (&in)[4], f32x16 (&out)[4], int lane, int h) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) out[mb] = bias_init(bias, mb, h);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 a[4];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+        a[mb] = *(const f32x4*)&wp[(((mb * 4 + nb) * 4 + rq) * 64 + lane) * 4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+          out[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][i], in[nb][4 * rq + i], out[mb], 0, 0, 0);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
+    const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
+    const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
+    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // stage all packed weights into LDS once per workgroup (persistent grid)
+  for (int i = threadIdx.x * 4; i < PN_TOTAL; i += 512 * 4)
+    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n_pblocks = (n_points + 31) >> 5;
+  const int n_tiles = n_pblocks * 8;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+
+  for (int t = blockIdx.x * 8 + wave; t < n_tiles; t += gridDim.x * 8) {
+    const int k = t / n_pblocks;           // corner, uniform over the tile
+    const int pb = t - k * n_pblocks;
+    const int i = pb * 32 + j;
+    float in0 = 0.f, in1 = 0.f, in2 = 0.f;  // this lane's half of the 6 inputs: features 2s + h
+    int slot = -1;
+    bool valid = false;
+    if (i < n_points) {
+      const float* p = pts + (size_t)i * 6;
+      const float x = p[0], y = p[1], z = p[2];
+      valid = in_bounds(x, y, z, g);
+      if (valid) {
+        const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+        const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+        const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+        const int gx = (k & 1) ? (int)ceilf(xn) : (int)floorf(xn);
+        const int gy = (k & 2) ? (int)ceilf(yn) : (int)floorf(yn);
+        const int gz = (k & 4) ? (int)ceilf(zn) : (int)floorf(zn);
+        if (voxel_owner(gx, gy, gz, g) == g.shard_rank) {
+          const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+          const uint32_t word = bitmap[id >> 5];
+          slot = (int)(word_prefix[id >> 5] + __popc(word & ((1u << (id & 31)) - 1u)));
+        }
+        const float rx = relative_coord(xn, gx, g.voxel_size);
+        const float ry = relative_coord(yn, gy, g.voxel_size);
+        const float rz = relative_coord(zn, gz, g.voxel_size);
+        // inputs [rx, ry, rz, nx, ny, nz]; K-step s contracts inputs (2s, 2s+1) = (h=0, h=1)
+        in0 = h ? ry : rx;
+        in1 = h ? p[3] : rz;
+        in2 = h ? p[5] : p[4];
+      }
+    }
+    // the tile is skipped when no lane contributes (wave-uniform branch)
+    if (__ballot(slot >= 0) == 0ULL) continue;
+
+    // ---- layer 1: 6 -> 128 --------------------------------------------------------------
+    f32x16 ha[4], hb[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) ha[mb] = bias_init(lds + PN_B1, mb, h);
+    {
+      const float bin[3] = {in0, in1, in2};
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+          ha[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[PN_W1 + (s * 4 + mb) * 64 + lane], bin[s],
+                                                        ha[mb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) ha[mb] = relu16(ha[mb]);
+    // ---- layers 2, 3: 128 -> 128 ---------------------------------------------------------
+    layer128(lds + PN_W2, lds + PN_B2, ha, hb, lane, h);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) hb[mb] = relu16(hb[mb]);
+    layer128(lds + PN_W3, lds + PN_B3, hb, ha, lane, h);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) ha[mb] = relu16(ha[mb]);
+    // ---- layer 4: 128 -> 8 (rows 8..31 of the MFMA tile are zero padding) ------------------
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    {
+      const f32x4 b4 = *(const f32x4*)&lds[PN_B4 + 4 * h];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = b4[r];
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        if (j < 8) a = *(const f32x4*)&lds[PN_W4 + ((((nb * 4 + rq) * 2 + h) * 8) + j) * 4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], ha[nb][4 * rq + i], o, 0, 0, 0);
+      }
+    }
+    // ---- scatter: lane (j, h) holds output features 4h .. 4h+3 of pair j -------------------
+    if (slot >= 0) {
+      long long* dst = acc + (size_t)slot * 8 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long v = __float2ll_rn(o[q] * kFixedScale);
+        atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v);
+      }
+      if (h == 0) atomicAdd(&counts[slot], 1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// finalize: ordered compaction of the emitted voxels + cleanup of the per-frame scratch
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void k_finalize(
+    bnv_grid_t g, int emit_all, uint32_t* __restrict__ bitmap, int32_t* __restrict__ ids,
+    int32_t* __restrict__ counts, long long* __restrict__ acc, const uint32_t* __restrict__ block_sums,
+    float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts, int64_t* __restrict__ out_flat,
+    int64_t* __restrict__ out_grid, int64_t out_capacity, bnv_encode_counters_t* __restrict__ counters) {
+  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  const int64_t n = counters->n_unique;
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  if ((int64_t)blockIdx.x * kScanTile >= n) return;
+  ValidFlags flags{counts, ids, g, emit_all};
+  uint32_t fl[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    fl[e] = (base + e < n) ? flags(base + e) : 0u;
+    s += fl[e];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+#pragma unroll
+  for (int e = 0; e < kScanItems; ++e) {
+    const int64_t sl = base + e;
+    if (sl >= n) break;
+    const int id = ids[sl];
+    const int c = counts[sl];
+    if (fl[e]) {
+      if ((int64_t)run < out_capacity) {
+        const bool keep = c >= g.min_pts_in_grid;  // emit_all: features zeroed below min_pts (:126)
+        const float inv_scale = 1.0f / kFixedScale;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          // mean = sum / max(count, 1) (torch_scatter.scatter_mean); the fixed-point sum is exact
+          const double sum = (double)acc[sl * 8 + f] * (double)inv_scale;
+          out_feats[(size_t)run * 8 + f] = keep ? (float)(sum / (double)(c > 1 ? c : 1)) : 0.f;
+        }
+        out_pcounts[run] = c;
+        out_flat[run] = id;
+        const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+        out_grid[(size_t)run * 3 + 0] = x;
+        out_grid[(size_t)run * 3 + 1] = y;
+        out_grid[(size_t)run * 3 + 2] = z;
+      } else {
+        counters->error = 2;
+      }
+      ++run;
+    }
+    // leave the scratch clean for the next frame
+    counts[sl] = 0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) acc[sl * 8 + f] = 0;
+    bitmap[id >> 5] = 0u;
+  }
+}
+
+__global__ void k_finalize_counters(const uint32_t* __restrict__ block_sums, int n_blocks,
+                                    bnv_encode_counters_t* __restrict__ counters) {
+  // n_avg_pts = mean over ALL U voxels of the pair count (local_point_fusion.py:143); every valid
+  // point contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid.
+  const int U = counters->n_unique;
+  counters->n_out = (int32_t)block_sums[n_blocks];
+  counters->n_avg_pts = (U > 0) ? __fdiv_rn((float)(8 * counters->n_valid_points), (float)U) : 0.f;
+}
+
+__global__ void k_set_unique(const uint32_t* __restrict__ block_sums, int n_blocks,
+                             bnv_encode_counters_t* __restrict__ counters) {
+  counters->n_unique = (int32_t)block_sums[n_blocks];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_voxelize_pairs (dense path + tests)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_voxelize_pairs(const float* __restrict__ pts, int n_points,
+                                                       bnv_grid_t g, int32_t* __restrict__ grid_ids,
+                                                       int64_t* __restrict__ flat_ids,
+                                                       float* __restrict__ rel_xyz,
+                                                       uint8_t* __restrict__ bound_mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_points) return;
+  const float x = pts[(size_t)i * 6 + 0], y = pts[(size_t)i * 6 + 1], z = pts[(size_t)i * 6 + 2];
+  if (bound_mask) bound_mask[i] = in_bounds(x, y, z, g) ? 1 : 0;
+  const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+  const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+  const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int cb = kCornerCeilBits[k];  // pair order follows the reference's corner order
+    const int gx = (cb & 1) ? (int)ceilf(xn) : (int)floorf(xn);
+    const int gy = (cb & 2) ? (int)ceilf(yn) : (int)floorf(yn);
+    const int gz = (cb & 4) ? (int)ceilf(zn) : (int)floorf(zn);
+    const size_t p = (size_t)k * n_points + i;
+    if (grid_ids) {
+      grid_ids[p * 3 + 0] = gx;
+      grid_ids[p * 3 + 1] = gy;
+      grid_ids[p * 3 + 2] = gz;
+    }
+    if (flat_ids) flat_ids[p] = (int64_t)(gx * nyz + gy * g.n_xyz[2] + gz);  // int32 arithmetic as the reference
+    if (rel_xyz) {
+      rel_xyz[p * 3 + 0] = relative_coord(xn, gx, g.voxel_size);
+      rel_xyz[p * 3 + 1] = relative_coord(yn, gy, g.voxel_size);
+      rel_xyz[p * 3 + 2] = relative_coord(zn, gz, g.voxel_size);
+    }
+  }
+}
+
+}  // namespace bnv
+
+using namespace bnv;
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int bnv_init(int device) {
+  BNV_HIP_CHECK(hipSetDevice(device));
+  int cus = 0;
+  BNV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  g_num_cus = cus;
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
+  extern int bnv_decode_init();
+  return bnv_decode_init();
+}
+
+int bnv_num_compute_units(void) { return g_num_cus; }
+int bnv_last_hip_error(void) { return g_last_hip_error; }
+
+const char* bnv_status_string(int s) {
+  switch (s) {
+    case BNV_OK: return "ok";
+    case BNV_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case BNV_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case BNV_ERR_HIP: return "HIP runtime error";
+    case BNV_ERR_NOT_INITIALISED: return "bnv_init not called";
+    case BNV_ERR_CAPACITY: return "capacity exceeded";
+    default: return "unknown";
+  }
+}
+
+size_t bnv_pointnet_pack_floats(void) { return PN_TOTAL; }
+
+size_t bnv_encode_workspace_bytes(int64_t max_points, const int32_t n_xyz[3]) {
+  return encode_ws_layout(max_points, n_xyz, nullptr, nullptr);
+}
+
+int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream) {
+  if (!ws) return BNV_ERR_INVALID_ARGUMENT;
+  BNV_HIP_CHECK(hipMemsetAsync(ws, 0, ws_bytes, (hipStream_t)stream));
+  return BNV_OK;
+}
+
+int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                          const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, float* out_feats,
+                          int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                          int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
+                          bnv_stream_t stream_) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
+      n_points > (1 << 27))
+    return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_grid_t g = *grid_host;
+  if ((int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] >= (1LL << 31)) return BNV_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  EncodeWs ws;
+  const size_t need = encode_ws_layout(n_points, g.n_xyz, (char*)ws_ptr, &ws);
+  if (need > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
+  if (n_points == 0) return BNV_OK;
+  const int n = (int)n_points;
+
+  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, counters);
+  BNV_LAUNCH_CHECK();
+  // sorted-unique via bitmap rank
+  const int nb_words = (int)((ws.n_words + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(k_scan_partial<PopcWords>, dim3(nb_words), dim3(kScanThreads), 0, stream,
+                     PopcWords{ws.bitmap}, (const int32_t*)nullptr, ws.n_words, ws.block_sums);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_set_unique, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_words, counters);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_apply_bitmap, dim3(nb_words), dim3(kScanThreads), 0, stream, ws.bitmap, ws.n_words,
+                     ws.block_sums, ws.word_prefix, ws.ids, ws.max_unique, counters);
+  BNV_LAUNCH_CHECK();
+  // point encoder + scatter
+  const int n_tiles = ((n + 31) / 32) * 8;
+  int grid_pn = g_num_cus;
+  if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
+  hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
+                     pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+  BNV_LAUNCH_CHECK();
+  // ordered compaction of the emitted voxels; the number of slots is only known on the device,
+  // so the scan grids cover max_unique and blocks past n_unique exit at once
+  const int nb_u = (int)((ws.max_unique + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(k_scan_partial<ValidFlags>, dim3(nb_u), dim3(kScanThreads), 0, stream,
+                     ValidFlags{ws.counts, ws.ids, g, emit_all}, &counters->n_unique, (int64_t)0, ws.block_sums);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_finalize_counters, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_u, counters);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
+                     ws.counts, ws.acc, ws.block_sums, out_feats, out_pcounts, out_flat_ids, out_grid_ids,
+                     out_capacity, counters);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_voxelize_pairs(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                       int32_t* grid_ids, int64_t* flat_ids, float* rel_xyz, uint8_t* bound_mask,
+                       bnv_stream_t stream) {
+  if (!input_pts || !grid_host || n_points < 0 || n_points > (1 << 27)) return BNV_ERR_INVALID_ARGUMENT;
+  if (n_points == 0) return BNV_OK;
+  hipLaunchKernelGGL(k_voxelize_pairs, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, input_pts, (int)n_points, *grid_host, grid_ids, flat_ids, rel_xyz,
+                     bound_mask);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+}  // extern "C"

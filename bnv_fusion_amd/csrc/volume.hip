@@ -1,0 +1,369 @@
+// volume.hip -- SparseVolume (reference sparse_volume.py:484-695) on gfx950.
+//
+// Index: open-addressing hash table, 64-bit packed (x,y,z) key -> row, linear probing, CAS insert.
+// Payload: dense row arrays (coords, features[8], weight, num_hits) in insertion order, so
+// to_tensor() is a slice.  New rows are numbered by an ORDERED prefix sum over the batch (not by
+// an atomic counter), so row order -- and every later result -- is reproducible run to run.
+//
+// All kernels are HBM/L2-latency bound gather/scatter: one thread per key, 64-B payload rows.
+#include "bnv_common.hpp"
+
+namespace bnv {
+
+constexpr int kVolThreads = 256;
+constexpr int kVolItems = 8;
+constexpr int kVolTile = kVolThreads * kVolItems;
+
+struct VolWs {
+  int32_t* slot_of;        // [n] slot index of each key (or -1: key out of range)
+  int32_t* is_new;         // [n] 1 if this thread's CAS created the slot
+  uint32_t* block_sums;    // [n_blocks + 1]
+  int32_t* total_new;      // [1]
+  int32_t* error;          // [1]
+};
+
+static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
+  if (n < 1) n = 1;
+  const int64_t nb = (n + kVolTile - 1) / kVolTile;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off = (off + bytes + 255) / 256 * 256;
+    return p;
+  };
+  char* a = take(n * 4);
+  char* b = take(n * 4);
+  char* c = take((nb + 1) * 4);
+  char* d = take(256);
+  if (ws) {
+    ws->slot_of = (int32_t*)a;
+    ws->is_new = (int32_t*)b;
+    ws->block_sums = (uint32_t*)c;
+    ws->total_new = (int32_t*)d;
+    ws->error = (int32_t*)d + 1;
+  }
+  return off;
+}
+
+__global__ __launch_bounds__(256) void k_vol_clear(uint64_t* __restrict__ slot_keys,
+                                                   int32_t* __restrict__ slot_rows, int64_t n_slots,
+                                                   int32_t* __restrict__ n_rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n_slots) {
+    slot_keys[i] = kEmptyKey;
+    slot_rows[i] = -1;
+  }
+  if (i == 0 && n_rows) *n_rows = 0;
+}
+
+// probe / CAS-insert one key per thread; records the slot and whether this thread created it
+__global__ __launch_bounds__(256) void k_vol_probe_insert(bnv_volume_t v, const int64_t* __restrict__ coords,
+                                                          int64_t n, int32_t* __restrict__ slot_of,
+                                                          int32_t* __restrict__ is_new,
+                                                          int32_t* __restrict__ error) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key;
+  int32_t slot = -1, created = 0;
+  if (pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key)) {
+    const uint32_t mask = (uint32_t)(v.n_slots - 1);
+    uint32_t s = mix64(key) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+      uint64_t k = v.slot_keys[s];
+      if (k == kEmptyKey) {
+        k = atomicCAS((unsigned long long*)&v.slot_keys[s], (unsigned long long)kEmptyKey,
+                      (unsigned long long)key);
+        if (k == kEmptyKey) {
+          slot = (int32_t)s;
+          created = 1;
+          break;
+        }
+      }
+      if (k == key) {
+        slot = (int32_t)s;
+        break;
+      }
+      s = (s + 1) & mask;
+    }
+    if (slot < 0) *error = 1;  // table full
+  } else {
+    *error = 2;  // coordinate outside the 21-bit key range
+  }
+  slot_of[i] = slot;
+  is_new[i] = created;
+}
+
+__global__ __launch_bounds__(kVolThreads) void k_vol_scan_partial(const int32_t* __restrict__ is_new, int64_t n,
+                                                                  uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[kVolThreads / 64];
+  const int64_t base = (int64_t)blockIdx.x * kVolTile + (int64_t)threadIdx.x * kVolItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int e = 0; e < kVolItems; ++e)
+    if (base + e < n) s += (uint32_t)is_new[base + e];
+  uint32_t total;
+  block_exclusive_scan<kVolThreads>(s, wave_tot, &total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_vol_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
+                                                       int32_t* __restrict__ total_out) {
+  __shared__ uint32_t wave_tot[16];
+  uint32_t carry = 0;
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t val = (i < n_blocks) ? block_sums[i] : 0;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<1024>(val, wave_tot, &total);
+    if (i < n_blocks) block_sums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *total_out = (int32_t)carry;
+}
+
+// assigns rows to the created slots in batch order: row = n_rows + (number of created keys before i)
+__global__ __launch_bounds__(kVolThreads) void k_vol_assign_rows(bnv_volume_t v, const int64_t* __restrict__ coords,
+                                                                 int64_t n, const int32_t* __restrict__ slot_of,
+                                                                 const int32_t* __restrict__ is_new,
+                                                                 const uint32_t* __restrict__ block_sums,
+                                                                 int32_t* __restrict__ error) {
+  __shared__ uint32_t wave_tot[kVolThreads / 64];
+  const int64_t base = (int64_t)blockIdx.x * kVolTile + (int64_t)threadIdx.x * kVolItems;
+  uint32_t fl[kVolItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int e = 0; e < kVolItems; ++e) {
+    fl[e] = (base + e < n) ? (uint32_t)is_new[base + e] : 0u;
+    s += fl[e];
+  }
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<kVolThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
+  const int32_t first = *v.n_rows;
+#pragma unroll
+  for (int e = 0; e < kVolItems; ++e) {
+    if (fl[e]) {
+      const int64_t i = base + e;
+      const int64_t row = (int64_t)first + run;
+      if (row < v.row_capacity) {
+        v.slot_rows[slot_of[i]] = (int32_t)row;
+        v.row_coords[row * 3 + 0] = coords[i * 3 + 0];
+        v.row_coords[row * 3 + 1] = coords[i * 3 + 1];
+        v.row_coords[row * 3 + 2] = coords[i * 3 + 2];
+        // a fresh row reads as zeros (SparseVolume.query of an absent key, sparse_volume.py:677-679)
+        for (int f = 0; f < v.n_feats; ++f) v.features[row * v.n_feats + f] = 0.f;
+        v.weights[row] = 0.f;
+        v.num_hits[row] = 0.f;
+      } else {
+        *error = 3;
+      }
+      ++run;
+    }
+  }
+}
+
+__global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __restrict__ total_new) {
+  *n_rows += *total_new;
+}
+
+// _integrate/_update (local_point_fusion.py:647-673) on rows that now all exist
+__global__ __launch_bounds__(256) void k_vol_integrate_apply(bnv_volume_t v, const float* __restrict__ feats,
+                                                             const int64_t* __restrict__ pcounts, int64_t n,
+                                                             const int32_t* __restrict__ slot_of) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t slot = slot_of[i];
+  if (slot < 0) return;
+  const int64_t row = v.slot_rows[slot];
+  if (row < 0 || row >= v.row_capacity) return;
+  // fine_weights = clip(pcounts / 32, max=1)   (:660; int64 / 32 -> float32 true division)
+  const float w = fminf(__fdiv_rn((float)pcounts[i], 32.0f), 1.0f);
+  const float w_old = v.weights[row];
+  const float w_new = __fadd_rn(w_old, w);  // updated_weights = old + new (:649)
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const float fo = v.features[row * 8 + f];
+    const float fn = feats[i * 8 + f];
+    // (old_feats * old_weights + new_feats * new_weights) / updated_weights (:650)
+    v.features[row * 8 + f] = __fdiv_rn(__fadd_rn(__fmul_rn(fo, w_old), __fmul_rn(fn, w)), w_new);
+  }
+  v.weights[row] = w_new;
+  // num_hits is carried through unchanged (:661-672)
+}
+
+__global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const float* __restrict__ feats,
+                                                          const float* __restrict__ weights,
+                                                          const float* __restrict__ hits, int64_t n,
+                                                          const int32_t* __restrict__ slot_of) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t slot = slot_of[i];
+  if (slot < 0) return;
+  const int64_t row = v.slot_rows[slot];
+  if (row < 0 || row >= v.row_capacity) return;
+  for (int f = 0; f < v.n_feats; ++f) v.features[row * v.n_feats + f] = feats[i * v.n_feats + f];
+  v.weights[row] = weights[i];
+  v.num_hits[row] = hits[i];
+}
+
+__global__ __launch_bounds__(256) void k_vol_query(bnv_volume_t v, const int64_t* __restrict__ coords, int64_t n,
+                                                   const float* __restrict__ features,
+                                                   const float* __restrict__ weights,
+                                                   const float* __restrict__ hits, int64_t row_limit,
+                                                   float* __restrict__ out_f, float* __restrict__ out_w,
+                                                   float* __restrict__ out_h, int32_t* __restrict__ out_rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key;
+  int row = -1;
+  if (pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key))
+    row = volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+  if (row >= row_limit) row = -1;
+  if (out_rows) out_rows[i] = row;
+  if (out_f)
+    for (int f = 0; f < v.n_feats; ++f) out_f[i * v.n_feats + f] = row >= 0 ? features[(int64_t)row * v.n_feats + f] : 0.f;
+  if (out_w) out_w[i] = row >= 0 ? weights[row] : 0.f;
+  if (out_h) out_h[i] = row >= 0 ? hits[row] : 0.f;
+}
+
+// weights[rows] += 1 with index_put semantics: each distinct row once (sparse_volume.py:622)
+__global__ __launch_bounds__(256) void k_vol_count_optim(bnv_volume_t v, const int64_t* __restrict__ coords,
+                                                         int64_t n, float* __restrict__ weights,
+                                                         int64_t row_limit, int32_t* __restrict__ stamp,
+                                                         int32_t epoch) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key;
+  if (!pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key)) return;
+  const int row = volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+  if (row < 0 || row >= row_limit) return;
+  if (atomicExch(&stamp[row], epoch) != epoch) weights[row] = __fadd_rn(weights[row], 1.0f);
+}
+
+__global__ __launch_bounds__(256) void k_vol_rehash(bnv_volume_t v, int32_t* __restrict__ error) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= *v.n_rows) return;
+  uint64_t key;
+  if (!pack_key(v.row_coords[row * 3 + 0], v.row_coords[row * 3 + 1], v.row_coords[row * 3 + 2], &key)) return;
+  const uint32_t mask = (uint32_t)(v.n_slots - 1);
+  uint32_t s = mix64(key) & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    if (atomicCAS((unsigned long long*)&v.slot_keys[s], (unsigned long long)kEmptyKey,
+                  (unsigned long long)key) == kEmptyKey) {
+      v.slot_rows[s] = (int32_t)row;
+      return;
+    }
+    s = (s + 1) & mask;
+  }
+  if (error) *error = 1;
+}
+
+static bool vol_ok(const bnv_volume_t* v) {
+  return v && v->slot_keys && v->slot_rows && v->row_coords && v->features && v->weights && v->num_hits &&
+         v->n_rows && v->n_slots > 0 && (v->n_slots & (v->n_slots - 1)) == 0 && v->n_slots <= (1LL << 31) &&
+         v->row_capacity > 0 && v->n_feats == 8;
+}
+
+static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const VolWs& ws,
+                           hipStream_t stream) {
+  const unsigned nb256 = (unsigned)((n + 255) / 256);
+  const int nbt = (int)((n + kVolTile - 1) / kVolTile);
+  BNV_HIP_CHECK(hipMemsetAsync(ws.total_new, 0, 8, stream));
+  hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, ws.slot_of, ws.is_new,
+                     ws.error);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_scan_partial, dim3(nbt), dim3(kVolThreads), 0, stream, ws.is_new, n, ws.block_sums);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nbt, ws.total_new);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_assign_rows, dim3(nbt), dim3(kVolThreads), 0, stream, v, coords, n, ws.slot_of,
+                     ws.is_new, ws.block_sums, ws.error);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_commit, dim3(1), dim3(1), 0, stream, v.n_rows, ws.total_new);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+}  // namespace bnv
+
+using namespace bnv;
+
+extern "C" {
+
+size_t bnv_volume_workspace_bytes(int64_t max_keys) { return vol_ws_layout(max_keys, nullptr, nullptr); }
+
+int bnv_volume_clear(const bnv_volume_t* vol, bnv_stream_t stream) {
+  if (!vol_ok(vol)) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_vol_clear, dim3((unsigned)((vol->n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     vol->slot_keys, vol->slot_rows, vol->n_slots, vol->n_rows);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_rehash(const bnv_volume_t* vol, bnv_stream_t stream) {
+  if (!vol_ok(vol)) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_vol_clear, dim3((unsigned)((vol->n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     vol->slot_keys, vol->slot_rows, vol->n_slots, (int32_t*)nullptr);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_rehash, dim3((unsigned)((vol->row_capacity + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, *vol, (int32_t*)nullptr);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const float* feats,
+                         const int64_t* pcounts, int64_t n, void* ws_ptr, size_t ws_bytes,
+                         bnv_stream_t stream_) {
+  if (!vol_ok(vol) || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!coords || !feats || !pcounts || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  VolWs ws;
+  if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = vol_upsert_rows(*vol, coords, n, ws, stream);
+  if (rc != BNV_OK) return rc;
+  hipLaunchKernelGGL(k_vol_integrate_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, feats,
+                     pcounts, n, ws.slot_of);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_insert(const bnv_volume_t* vol, const int64_t* coords, const float* feats,
+                      const float* weights, const float* num_hits, int64_t n, void* ws_ptr,
+                      size_t ws_bytes, bnv_stream_t stream_) {
+  if (!vol_ok(vol) || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!coords || !feats || !weights || !num_hits || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  VolWs ws;
+  if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = vol_upsert_rows(*vol, coords, n, ws, stream);
+  if (rc != BNV_OK) return rc;
+  hipLaunchKernelGGL(k_vol_insert_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, feats,
+                     weights, num_hits, n, ws.slot_of);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_query(const bnv_volume_t* vol, const int64_t* coords, int64_t n, const float* features,
+                     const float* weights, const float* num_hits, int64_t row_limit, float* out_feats,
+                     float* out_weights, float* out_hits, int32_t* out_rows, bnv_stream_t stream) {
+  if (!vol_ok(vol) || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!coords || !features || !weights || !num_hits) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_vol_query, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *vol,
+                     coords, n, features, weights, num_hits, row_limit, out_feats, out_weights, out_hits, out_rows);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_count_optim(const bnv_volume_t* vol, const int64_t* coords, int64_t n, float* weights,
+                           int64_t row_limit, int32_t* stamp, int32_t epoch, bnv_stream_t stream) {
+  if (!vol_ok(vol) || n < 0 || !stamp || !weights) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  hipLaunchKernelGGL(k_vol_count_optim, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     *vol, coords, n, weights, row_limit, stamp, epoch);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+}  // extern "C"

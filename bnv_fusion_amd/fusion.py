@@ -1,0 +1,288 @@
+"""LitFusionPointNet -- drop-in for the reference class of the same name
+(src/models/fusion/local_point_fusion.py:21-65, 81-165, 265-379, 647-673) on MI355X.
+
+Same call surface as run_e2e.py uses: construction from the Hydra-style cfg,
+``load_state_dict`` with the reference's checkpoint keys, ``eval()/cuda()/freeze()``,
+``encode_pointcloud``, ``_integrate``, ``decode_feature_grid_w_pts``, ``decode_implicit`` and a
+``.nerf`` with ``xyz_encoding / geo_forward / get_neighbors``.  The arithmetic runs in the HIP
+kernels of csrc/; this file only marshals torch tensors.  The fp32 checkpoint path
+(``model.tiny_cuda=False``) is implemented; there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, weights
+from .sparse_volume import make_grid
+
+_CORNER_IS_CEIL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1))
+
+
+def _get(cfg, name, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(name, default)
+    return getattr(cfg, name, default)
+
+
+def get_neighbors(points, as_int=False):
+    """[b, n, s, 3] -> [b, 8, n, s, 3] floor/ceil corners in the reference order
+    (modules.py:586-655 with ``.int()``; fusion/utils.py:98-167 without)."""
+    fl, ce = torch.floor(points), torch.ceil(points)
+    out = torch.stack([torch.stack([(ce if cx else fl)[..., 0], (ce if cy else fl)[..., 1],
+                                    (ce if cz else fl)[..., 2]], dim=-1) for cx, cy, cz in _CORNER_IS_CEIL], dim=1)
+    return out.int() if as_int else out
+
+
+class LocalNeRFModel(nn.Module):
+    """The SDF decoder's parameters + the small helper surface SparseVolume.decode_pts and the
+    global optimiser call (modules.py:81-123, 586-662, 923-971).  ``sdf_pack`` is the pre-permuted
+    operand buffer the HIP decode kernels read."""
+
+    def __init__(self, feat_dims=8, hidden_size=256, num_layers=4, num_encoding_fn_xyz=1, **_):
+        super().__init__()
+        if (feat_dims, hidden_size, num_layers, num_encoding_fn_xyz) != (8, 256, 4, 1):
+            raise NotImplementedError("HIP decode kernels are built for 17->256x4->1 (fusion_pointnet_model.yaml)")
+        dims = [3 + 6 * num_encoding_fn_xyz + feat_dims] + [hidden_size] * num_layers
+        for i in range(num_layers):
+            setattr(self, f"geo_layer{i}", nn.Linear(dims[i], dims[i + 1]))
+        self.fc_alpha = nn.Linear(hidden_size, 1)
+        self.num_layers = num_layers
+        self.register_buffer("sdf_pack", torch.zeros(int(_lib.load().bnv_sdfmlp_pack_floats())), persistent=False)
+
+    def repack(self):
+        sd = {"nerf." + k: v for k, v in self.state_dict().items()}
+        self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_mlp(sd)))
+
+    @staticmethod
+    def xyz_encoding(t):
+        return torch.cat([t, torch.sin(t * 1.0), torch.cos(t * 1.0)], dim=-1)
+
+    def get_neighbors(self, points):
+        return get_neighbors(points, as_int=True)
+
+    def geo_forward(self, xyz):
+        """modules.py:657-662 on an arbitrary [..., 17] tensor (torch ops; differentiable).  The
+        per-frame decode does not come through here -- see SparseVolume.decode_pts."""
+        for i in range(self.num_layers):
+            xyz = F.relu(getattr(self, f"geo_layer{i}")(xyz))
+        return self.fc_alpha(xyz)
+
+
+class LitFusionPointNet(nn.Module):
+    def __init__(self, cfg, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        model = _get(cfg, "model")
+        trainer = _get(cfg, "trainer")
+        if _get(model, "tiny_cuda", False):
+            raise NotImplementedError("tiny-cuda-nn (fp16 FullyFusedMLP) checkpoints are not supported yet")
+        self.dense_volume = bool(_get(trainer, "dense_volume", False)) if trainer is not None else False
+        self.feat_dims = int(_get(model, "feature_vector_size", 8))
+        nerf_cfg = _get(model, "nerf") or {}
+        nerf_kwargs = dict(nerf_cfg) if isinstance(nerf_cfg, dict) else {k: getattr(nerf_cfg, k) for k in (
+            "hidden_size", "num_layers", "num_encoding_fn_xyz") if hasattr(nerf_cfg, k)}
+        self.interpolate_decode = bool(_get(nerf_cfg, "interpolate_decode", True))
+        self.nerf = LocalNeRFModel(self.feat_dims, **{k: nerf_kwargs[k] for k in (
+            "hidden_size", "num_layers", "num_encoding_fn_xyz") if k in nerf_kwargs})
+        self.pointnet_backbone = _PointNetParams(self.feat_dims)
+        self.voxel_size = _get(model, "voxel_size")
+        self.min_pts_in_grid = int(_get(model, "min_pts_in_grid", 8))
+        self.training_global = bool(_get(model, "training_global", False))
+        self.shard = (0, 1, 3)   # (rank, world, block_log2) of the spatial sharding; see distributed.py
+        self.register_buffer("pointnet_pack", torch.zeros(int(_lib.load().bnv_pointnet_pack_floats())),
+                             persistent=False)
+        self._enc_ws = None
+        self._enc_ws_key = None
+        self._grid_cache = {}
+
+    # ---- nn.Module plumbing --------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.pointnet_pack.device
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in state_dict.items()
+              if not k.startswith("nerf.color_layer") and not k.startswith("nerf.fc_rgb")}
+        res = super().load_state_dict(sd, strict=strict)
+        self.repack()
+        return res
+
+    def repack(self):
+        sd = {k: v for k, v in self.state_dict().items()}
+        self.pointnet_pack.copy_(torch.from_numpy(weights.pack_pointnet(sd)))
+        self.nerf.repack()
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        self.eval()
+        return self
+
+    def _lib_for(self, t):
+        if not t.is_cuda:
+            raise _lib.BnvError("bnv_fusion_amd runs on the GPU only: move the model and its inputs to cuda "
+                                "(there is no CPU fallback)")
+        return _lib.require_device(t.device.index or 0)
+
+    @staticmethod
+    def _ident(x):
+        if isinstance(x, torch.Tensor):
+            return ("t", x.data_ptr(), x._version, x.device)
+        return tuple(float(v) for v in x)
+
+    def _grid(self, n_xyz, bound_min, bound_max, voxel_size):
+        """bnv_grid_t for these arguments; cached on tensor identity so that the per-frame call with
+        the volume's own (device) tensors costs no device->host reads."""
+        key = (self._ident(n_xyz), self._ident(bound_min), self._ident(bound_max), float(voxel_size),
+               self.min_pts_in_grid, self.shard)
+        hit = self._grid_cache.get(key)
+        if hit is None:
+            res = [int(v) for v in n_xyz]
+            hit = (make_grid(res, bound_min, bound_max, voxel_size, self.min_pts_in_grid, self.shard), res)
+            self._grid_cache = {key: hit}
+        return hit
+
+    # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
+    def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
+        lib = self._lib_for(self.pointnet_pack)
+        assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
+        pts = input_pts[0].detach().float().contiguous()
+        dev = pts.device
+        n = int(pts.shape[0])
+        grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
+        nvox = res[0] * res[1] * res[2]
+        n_arr = (C.c_int32 * 3)(*res)
+        need = int(lib.bnv_encode_workspace_bytes(n, n_arr))
+        key = (tuple(res), dev)
+        if self._enc_ws is None or self._enc_ws_key != key or self._enc_ws.numel() < need:
+            self._enc_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)  # zero = clean
+            self._enc_ws_key = key
+        emit_all = 1 if return_dense else 0
+        cap = min(8 * n, nvox) if return_dense else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
+        cap = max(cap, 1)
+        feats = torch.empty((cap, 8), dtype=torch.float32, device=dev)
+        pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
+        flat_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+        grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+        counters = torch.zeros(8, dtype=torch.int32, device=dev)
+        _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
+                                             _lib.ptr(self._enc_ws), self._enc_ws.numel(), _lib.ptr(feats),
+                                             _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids), cap,
+                                             emit_all, _lib.ptr(counters), _lib.stream_ptr()),
+                   "bnv_encode_pointcloud")
+        host = counters.cpu()                       # the one device->host sync of the frame
+        n_valid, n_unique, n_out, err = int(host[0]), int(host[1]), int(host[2]), int(host[4])
+        if err:
+            raise _lib.BnvError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+        if n_valid == 0:                            # local_point_fusion.py:101-102
+            return None, None, None, None, None
+        if not return_dense:
+            n_avg_pts = counters[3:4].view(torch.float32)[0]
+            return feats[:n_out], pcounts[:n_out].unsqueeze(-1), flat_ids[:n_out], grid_ids[:n_out], n_avg_pts
+        # dense contract (local_point_fusion.py:127-141): grids + unique ids + per-pair flat ids
+        g = grid_ids[:n_out]
+        feat_grids = torch.zeros((1, 8, *res), dtype=torch.float32, device=dev)
+        mask = torch.zeros((1, 1, *res), dtype=torch.float32, device=dev)
+        mask[0, 0, g[:, 0], g[:, 1], g[:, 2]] = pcounts[:n_out].float()
+        feat_grids[0, :, g[:, 0], g[:, 1], g[:, 2]] = feats[:n_out].t()
+        bmask = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(lib.bnv_voxelize_pairs(_lib.ptr(pts), n, C.byref(grid), None, None, None, _lib.ptr(bmask),
+                                          _lib.stream_ptr()), "bnv_voxelize_pairs")
+        kept = pts[bmask.bool()].contiguous()
+        pair_ids = torch.empty(8 * kept.shape[0], dtype=torch.int64, device=dev)
+        _lib.check(lib.bnv_voxelize_pairs(_lib.ptr(kept), int(kept.shape[0]), C.byref(grid), None,
+                                          _lib.ptr(pair_ids), None, None, _lib.stream_ptr()), "bnv_voxelize_pairs")
+        return feat_grids, mask, flat_ids[:n_out], pair_ids.unsqueeze(0)
+
+    def get_relative_xyz(self, xyz, bound_min, voxel_size, n_xyz=(1, 1, 1)):
+        """local_point_fusion.py:153-165: xyz [1, N, 3] -> (relative_xyz [1, 8, N, 3] f32,
+        grid_id [1, 8, N, 3] i32)."""
+        lib = self._lib_for(xyz)
+        n = int(xyz.shape[1])
+        pts = torch.zeros((n, 6), dtype=torch.float32, device=xyz.device)
+        pts[:, :3] = xyz[0]
+        grid = make_grid(n_xyz, bound_min, bound_min, voxel_size, self.min_pts_in_grid)
+        gid = torch.empty((8 * n, 3), dtype=torch.int32, device=xyz.device)
+        rel = torch.empty((8 * n, 3), dtype=torch.float32, device=xyz.device)
+        _lib.check(lib.bnv_voxelize_pairs(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(gid), None, _lib.ptr(rel), None,
+                                          _lib.stream_ptr()), "bnv_voxelize_pairs")
+        # the kernel returns rel / voxel (what forward(normalize=True) feeds the encoder)
+        return rel.reshape(1, 8, n, 3) * voxel_size, gid.reshape(1, 8, n, 3)
+
+    # ---- integrate (local_point_fusion.py:647-673) ------------------------------------------------
+    def _integrate(self, volume_object, fine_coords, fine_feats, fine_weights):
+        volume_object.integrate(fine_coords, fine_feats, fine_weights)
+
+    # ---- dense decode (local_point_fusion.py:265-379) ---------------------------------------------
+    def decode_feature_grid_w_pts(self, voxel_coords, feat_grid, pts_weight, voxel_size, bound_min,
+                                  gradient=False, global_coords=True):
+        if global_coords or not self.interpolate_decode or gradient:
+            raise NotImplementedError("only global_coords=False / interpolate_decode=True / gradient=False "
+                                      "(the fusion_pointnet_model.yaml configuration) runs on the HIP path")
+        lib = self._lib_for(voxel_coords)
+        q = voxel_coords.detach().reshape(-1, 3).float().contiguous()
+        n = int(q.shape[0])
+        fg = feat_grid.detach().float().contiguous()
+        pw = pts_weight.detach().float().contiguous()
+        dims = (C.c_int32 * 3)(*[int(v) for v in fg.shape[-3:]])
+        out = torch.empty(n, dtype=torch.float32, device=q.device)
+        _lib.check(lib.bnv_decode_dense(_lib.ptr(fg), _lib.ptr(pw), dims, float(np.float32(voxel_size)),
+                                        self.min_pts_in_grid, _lib.ptr(self.nerf.sdf_pack), _lib.ptr(q), n,
+                                        _lib.ptr(out), _lib.stream_ptr()), "bnv_decode_dense")
+        # the reference also returns the gathered neighbour features [1, 8, Q, F]
+        nb = get_neighbors(voxel_coords.unsqueeze(1), as_int=True).squeeze(2).long()
+        X, Y, Z = [int(v) for v in fg.shape[-3:]]
+        inside = ((nb >= 0) & (nb < torch.tensor([X, Y, Z], device=nb.device))).all(-1)
+        nbc = nb.clamp(min=0)
+        nbc = torch.minimum(nbc, torch.tensor([X - 1, Y - 1, Z - 1], device=nb.device))
+        nf = fg[0][:, nbc[..., 0], nbc[..., 1], nbc[..., 2]].permute(1, 2, 3, 0) * inside.unsqueeze(-1)
+        return out.reshape(1, n), nf
+
+    def decode_implicit(self, feat_grid, points, normalize, voxel_size=None, mask=None, test=False):
+        """local_point_fusion.py:372-379 via LocalNeRFModel.forward (modules.py:941-971); torch ops."""
+        if normalize:
+            points = points / voxel_size
+        enc = self.nerf.xyz_encoding(points[..., :3])
+        if not test:
+            feat_grid = feat_grid.unsqueeze(1).repeat(1, points.shape[1], 1)
+        geo_in = torch.cat([enc, feat_grid], dim=-1)
+        if mask is not None:
+            flat = geo_in.reshape(-1, geo_in.shape[-1])
+            m = mask.reshape(-1)
+            out = torch.zeros_like(flat[:, :1])
+            out[m] = self.nerf.geo_forward(flat[m])
+            pred = out.reshape(list(geo_in.shape[:-1]) + [1])
+        else:
+            pred = self.nerf.geo_forward(geo_in)
+        return pred * voxel_size if normalize else pred
+
+
+class _PointNetParams(nn.Module):
+    """Parameter container with the reference's PointNetEncoder names (pointnet_utils.py:230-244)."""
+
+    def __init__(self, feat_dims):
+        super().__init__()
+        self.conv1 = nn.Conv1d(6, 128, 1)
+        self.conv2 = nn.Conv1d(128, 128, 1)
+        self.conv3 = nn.Conv1d(128, 128, 1)
+        self.conv4 = nn.Conv1d(128, feat_dims, 1)
+        self.bn1, self.bn2, self.bn3 = nn.BatchNorm1d(128), nn.BatchNorm1d(128), nn.BatchNorm1d(128)
+        self.bn4 = nn.BatchNorm1d(feat_dims)
+
+
+def load_pretrained(device="cuda:0", voxel_size=0.01, min_pts_in_grid=8, path=None):
+    """Model with the converted reference checkpoint (weights/pointnet_fp32.npz), frozen, on device."""
+    cfg = {"trainer": {"dense_volume": False},
+           "model": {"feature_vector_size": 8, "voxel_size": voxel_size, "tiny_cuda": False,
+                     "min_pts_in_grid": min_pts_in_grid,
+                     "nerf": {"hidden_size": 256, "num_layers": 4, "num_encoding_fn_xyz": 1,
+                              "interpolate_decode": True}}}
+    model = LitFusionPointNet(cfg)
+    model.load_state_dict(weights.load_npz(path or weights.DEFAULT_FP32))
+    model.eval()
+    model.to(device)
+    model.freeze()
+    return model

@@ -1,0 +1,51 @@
+"""NeuralMap -- the per-frame driver of the reference (src/run_e2e.py:27-109, 164-167) reduced to
+the hot path: encode -> track_n_pts -> _integrate -> (decode of the voxels this frame touched).
+
+``integrate(frame)`` has the reference's contract (run_e2e.py:78-98; the TSDF side fusion of
+:99-109 is a "next" row).  ``fuse_and_decode`` is one unit of the benchmark metric
+("depth frames/sec fused+decoded"): it additionally decodes the 3x3x3 meshing
+lattice of every voxel the frame's encode returned.
+"""
+import torch
+
+from .sparse_volume import SparseVolume
+
+
+class NeuralMap:
+    def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
+                 capacity=100000, device="cuda:0"):
+        self.pointnet = pointnet
+        self.volume = SparseVolume(feature_vector_size, voxel_size, dimensions, min_pts_in_grid,
+                                   capacity=capacity, device=device)
+        self.voxel_size = voxel_size
+        self.dimensions = dimensions
+        self.sdf_delta = None
+
+    def integrate(self, frame):
+        """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU.
+        Returns the voxel coordinates the frame touched ([U', 3] int64) or None."""
+        if len(frame["input_pts"]) == 0:
+            return None
+        with torch.no_grad():
+            fine_feats, fine_weights, _, fine_coords, fine_n_pts = self.pointnet.encode_pointcloud(
+                frame["input_pts"], self.volume.n_xyz, self.volume.min_coords, self.volume.max_coords,
+                self.volume.voxel_size, return_dense=self.pointnet.dense_volume)
+            if fine_feats is None:
+                return None
+            self.volume.track_n_pts(fine_n_pts)
+            self.pointnet._integrate(self.volume, fine_coords, fine_feats, fine_weights)
+        return fine_coords
+
+    def fuse_and_decode(self, frame):
+        """One benchmark work unit: integrate + SDF lattice [U', 27] of the touched voxels (live
+        volume values, i.e. decode_pts(..., is_coords=True, query_tensor=False))."""
+        coords = self.integrate(frame)
+        if coords is None:
+            return None, None
+        sdf = self.volume.decode_lattice(coords, self.pointnet.nerf, self.sdf_delta, query_tensor=False)
+        return coords, sdf
+
+    def extract_sdf(self):
+        """run_e2e.py:164-167 up to (not including) marching cubes."""
+        self.volume.to_tensor()
+        return self.volume.meshlize(self.pointnet.nerf, self.sdf_delta)

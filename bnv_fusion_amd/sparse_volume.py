@@ -1,0 +1,348 @@
+"""SparseVolume -- drop-in for the reference class of the same name
+(src/models/sparse_volume.py:484-892), backed by the HIP hash volume (csrc/volume.hip) and the
+HIP decode kernels (csrc/decode.hip).  Same constructor, attributes and method names; tensors
+live on the GPU; torch only owns the memory.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def get_world_range(dimensions, voxel_size):
+    """voxel_utils.py:83-88 (float64 numpy, one voxel of padding each side)."""
+    dimensions = np.asarray(dimensions, dtype=np.float64)
+    min_ = -dimensions / 2 - voxel_size
+    max_ = dimensions / 2 + voxel_size
+    n_xyz = np.ceil((max_ - min_) / voxel_size).astype(int).tolist()
+    max_ = min_ + voxel_size * np.asarray(n_xyz)
+    return min_, max_, n_xyz
+
+
+def make_grid(n_xyz, bound_min, bound_max, voxel_size, min_pts_in_grid, shard=(0, 1, 3)):
+    """bnv_grid_t with the float32 values the reference compares against: ``bound_max - voxel_size``
+    and ``bound_min + voxel_size`` are float32-tensor (op) python-float results
+    (local_point_fusion.py:94-100), evaluated here with the same torch CPU ops."""
+    bmin = torch.as_tensor(bound_min).detach().float().cpu().reshape(3)
+    bmax = torch.as_tensor(bound_max).detach().float().cpu().reshape(3)
+    lo = bmin + voxel_size
+    hi = bmax - voxel_size
+    g = _lib.Grid()
+    for a in range(3):
+        g.bound_min[a] = float(bmin[a])
+        g.bound_lo[a] = float(lo[a])
+        g.bound_hi[a] = float(hi[a])
+        g.n_xyz[a] = int(n_xyz[a])
+    g.voxel_size = float(np.float32(voxel_size))
+    g.min_pts_in_grid = int(min_pts_in_grid)
+    g.shard_rank, g.shard_world, g.shard_block_log2 = int(shard[0]), int(shard[1]), int(shard[2])
+    return g
+
+
+def _pow2_at_least(x):
+    p = 1
+    while p < x:
+        p *= 2
+    return p
+
+
+class SparseVolume:
+    def __init__(self, n_feats, voxel_size, dimensions, min_pts_in_grid, capacity=100000, device="cuda:0"):
+        min_coords, max_coords, n_xyz = get_world_range(dimensions, voxel_size)
+        self.device = device
+        self._dev = torch.device(device)
+        self._lib = _lib.require_device(self._dev.index or 0)
+        self.dimensions = dimensions
+        self.voxel_size = voxel_size
+        self.min_coords = torch.from_numpy(min_coords).float().to(device)   # sparse_volume.py:495
+        self.max_coords = torch.from_numpy(max_coords).float().to(device)
+        self.n_xyz = torch.from_numpy(np.asarray(n_xyz)).long().to(device)  # sparse_volume.py:497
+        self._n_xyz_host = [int(v) for v in n_xyz]
+        self.n_feats = n_feats
+        if n_feats != 8:
+            raise ValueError("the HIP volume stores 8-float features (model.feature_vector_size=8)")
+        self.min_pts_in_grid = min_pts_in_grid
+        self.shard = (0, 1, 3)
+        self._grid = make_grid(n_xyz, min_coords, max_coords, voxel_size, min_pts_in_grid, self.shard)
+        self._ws = None
+        self._lattice_ws = None
+        self._stamp = None
+        self._epoch = 0
+        self.reset(capacity)
+        self.avg_n_pts = 0
+        self.n_pts_list = []
+        self.n_frames = 0
+        self.min_pts = 1000
+        self.max_pts = 0
+
+    # ---- bookkeeping (sparse_volume.py:508-523) ------------------------------------------------
+    def track_n_pts(self, n_pts):
+        n_pts = float(n_pts)
+        self.n_pts_list.append(n_pts)
+        self.avg_n_pts = (self.avg_n_pts * self.n_frames + n_pts) / (self.n_frames + 1)
+        self.n_frames += 1
+        self.min_pts = min(self.min_pts, n_pts)
+        self.max_pts = max(self.max_pts, n_pts)
+
+    def print_statistic(self):
+        print("===========")
+        p = np.percentile(self.n_pts_list, [25, 50, 75]) if self.n_pts_list else [0, 0, 0]
+        self.per_25, self.per_50, self.per_75 = p[0], p[1], p[2]
+        print(f"25%: {p[0]}, 50%: {p[1]}, 75%:{p[2]}")
+        print(f"mean: {self.avg_n_pts}, min: {self.min_pts}, max:{self.max_pts}")
+        print("===========")
+
+    # ---- storage ---------------------------------------------------------------------------------
+    def reset(self, capacity):
+        """sparse_volume.py:587-600."""
+        cap = max(int(capacity), 1024)
+        d = self._dev
+        self._row_capacity = cap
+        self._n_slots = _pow2_at_least(2 * cap)
+        self._slot_keys = torch.empty(self._n_slots, dtype=torch.int64, device=d)
+        self._slot_rows = torch.empty(self._n_slots, dtype=torch.int32, device=d)
+        self._row_coords = torch.zeros((cap, 3), dtype=torch.int64, device=d)
+        self._features = torch.zeros((cap, 8), dtype=torch.float32, device=d)
+        self._weights = torch.zeros(cap, dtype=torch.float32, device=d)
+        self._num_hits = torch.zeros(cap, dtype=torch.float32, device=d)
+        self._n_rows = torch.zeros(1, dtype=torch.int32, device=d)
+        self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
+        self._lattice_ws = None
+        self._stamp = None
+        _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
+        self.tensor_indexer = None
+        self.features = None
+        self.weights = None
+        self.num_hits = None
+        self.active_coordinates = None
+        self._snapshot_rows = 0
+
+    def _struct(self):
+        v = _lib.Volume()
+        v.slot_keys = self._slot_keys.data_ptr()
+        v.slot_rows = self._slot_rows.data_ptr()
+        v.n_slots = self._n_slots
+        v.row_coords = self._row_coords.data_ptr()
+        v.features = self._features.data_ptr()
+        v.weights = self._weights.data_ptr()
+        v.num_hits = self._num_hits.data_ptr()
+        v.row_capacity = self._row_capacity
+        v.n_rows = self._n_rows.data_ptr()
+        v.n_feats = 8
+        return v
+
+    def num_rows(self):
+        """Exact number of active voxels (one device->host read)."""
+        n = int(self._n_rows.item())
+        self._rows_upper = n
+        return n
+
+    def _reserve(self, n_new):
+        """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows)."""
+        if self._rows_upper + n_new <= self._row_capacity:
+            return
+        n = self.num_rows()
+        if n + n_new <= self._row_capacity:
+            return
+        cap = max(2 * self._row_capacity, n + n_new)
+        d = self._dev
+
+        def grow(t, shape):
+            o = torch.zeros(shape, dtype=t.dtype, device=d)
+            o[:n] = t[:n]
+            return o
+
+        self._row_coords = grow(self._row_coords, (cap, 3))
+        self._features = grow(self._features, (cap, 8))
+        self._weights = grow(self._weights, (cap,))
+        self._num_hits = grow(self._num_hits, (cap,))
+        self._row_capacity = cap
+        self._n_slots = _pow2_at_least(2 * cap)
+        self._slot_keys = torch.empty(self._n_slots, dtype=torch.int64, device=d)
+        self._slot_rows = torch.empty(self._n_slots, dtype=torch.int32, device=d)
+        self._lattice_ws = None
+        self._stamp = None
+        _lib.check(self._lib.bnv_volume_rehash(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_rehash")
+
+    def _workspace(self, n):
+        need = int(self._lib.bnv_volume_workspace_bytes(int(n)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.zeros(max(need, 1 << 20), dtype=torch.uint8, device=self._dev)
+        return self._ws
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def integrate(self, coords, feats, pcounts):
+        """Fused LitFusionPointNet._integrate (local_point_fusion.py:647-673): query + running
+        average + upsert for UNIQUE keys in one pass."""
+        n = int(coords.shape[0])
+        if n == 0:
+            return
+        coords = coords.reshape(-1, 3).long().contiguous()
+        feats = feats.float().contiguous()
+        pcounts = pcounts.reshape(-1).long().contiguous()
+        self._reserve(n)
+        ws = self._workspace(n)
+        _lib.check(self._lib.bnv_volume_integrate(C.byref(self._struct()), _lib.ptr(coords), _lib.ptr(feats),
+                                                  _lib.ptr(pcounts), n, _lib.ptr(ws), ws.numel(),
+                                                  _lib.stream_ptr()), "bnv_volume_integrate")
+        self._rows_upper += n
+
+    def insert(self, keys, new_feats, new_weights, new_num_hits):
+        """sparse_volume.py:561-585 (upsert)."""
+        if len(keys) == 0:
+            return None
+        keys = keys.reshape(-1, 3).long().contiguous()
+        n = int(keys.shape[0])
+        f = new_feats.detach().float().reshape(n, 8).contiguous()
+        w = new_weights.detach().float().reshape(n).contiguous()
+        h = new_num_hits.detach().float().reshape(n).contiguous()
+        self._reserve(n)
+        ws = self._workspace(n)
+        _lib.check(self._lib.bnv_volume_insert(C.byref(self._struct()), _lib.ptr(keys), _lib.ptr(f), _lib.ptr(w),
+                                               _lib.ptr(h), n, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "bnv_volume_insert")
+        self._rows_upper += n
+
+    def to_tensor(self):
+        """sparse_volume.py:525-559: snapshot (copy) of the active entries, in buffer order."""
+        n = self.num_rows()
+        self.active_coordinates = self._row_coords[:n].clone()
+        self.features = self._features[:n].clone()
+        self.weights = self._weights[:n].clone().unsqueeze(-1)
+        self.num_hits = self._num_hits[:n].clone().unsqueeze(-1)
+        self._snapshot_rows = n
+        self.tensor_indexer = True
+        return self.active_coordinates, self.features, self.weights, self.num_hits
+
+    def _lookup(self, keys, feats, weights, hits, limit):
+        shapes = list(keys.shape)
+        assert shapes[-1] == 3
+        n = int(np.prod(shapes[:-1]))
+        k = keys.reshape(-1, 3).long().contiguous()
+        of = torch.empty((n, 8), dtype=torch.float32, device=self._dev)
+        ow = torch.empty((n, 1), dtype=torch.float32, device=self._dev)
+        oh = torch.empty((n, 1), dtype=torch.float32, device=self._dev)
+        _lib.check(self._lib.bnv_volume_query(C.byref(self._struct()), _lib.ptr(k), n, _lib.ptr(feats),
+                                              _lib.ptr(weights), _lib.ptr(hits), int(limit), _lib.ptr(of),
+                                              _lib.ptr(ow), _lib.ptr(oh), None, _lib.stream_ptr()),
+                   "bnv_volume_query")
+        return (of.reshape(shapes[:-1] + [8]), ow.reshape(shapes[:-1] + [1]), oh.reshape(shapes[:-1] + [1]))
+
+    def query(self, keys):
+        """sparse_volume.py:661-695: live values, zeros for absent keys."""
+        if int(np.prod(list(keys.shape)[:-1])) == 0:
+            return None, None, None
+        return self._lookup(keys, self._features, self._weights, self._num_hits, self._row_capacity)
+
+    def _snapshot(self):
+        assert self.features is not None, "call self.to_tensor() first."
+        f = self.features.detach()
+        w = self.weights.detach()
+        h = self.num_hits.detach()
+        if not (f.is_contiguous() and w.is_contiguous() and h.is_contiguous()):
+            raise ValueError("volume.features / weights / num_hits must stay contiguous")
+        return f, w, h, min(int(f.shape[0]), self._snapshot_rows)
+
+    def _query_tensor(self, keys):
+        """sparse_volume.py:625-659: values of the to_tensor() snapshot."""
+        f, w, h, lim = self._snapshot()
+        return self._lookup(keys, f, w, h, lim)
+
+    def count_optim(self, keys):
+        """sparse_volume.py:602-622."""
+        f, w, h, lim = self._snapshot()
+        k = keys.reshape(-1, 3).long().contiguous()
+        if self._stamp is None or self._stamp.numel() < self._row_capacity:
+            self._stamp = torch.zeros(self._row_capacity, dtype=torch.int32, device=self._dev)
+        self._epoch += 1
+        _lib.check(self._lib.bnv_volume_count_optim(C.byref(self._struct()), _lib.ptr(k), int(k.shape[0]),
+                                                    _lib.ptr(w), lim, _lib.ptr(self._stamp), self._epoch,
+                                                    _lib.stream_ptr()), "bnv_volume_count_optim")
+
+    # ---- decode ------------------------------------------------------------------------------------
+    def _delta(self, sdf_delta):
+        d = _lib.SdfDelta()
+        keep = None
+        if sdf_delta is not None:
+            keep = sdf_delta.detach().float().contiguous()
+            assert keep.dim() == 5 and keep.shape[0] == 1 and keep.shape[1] == 1
+            d.data = keep.data_ptr()
+            for a in range(3):
+                d.dims[a] = int(keep.shape[2 + a])
+        return d, keep
+
+    def _values(self, query_tensor):
+        if query_tensor:
+            f, w, _, lim = self._snapshot()
+            return f, w, lim
+        return self._features, self._weights, self._row_capacity
+
+    def decode_pts(self, coords, nerf, sdf_delta=None, is_coords=False, query_tensor=True):
+        """sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1]."""
+        shape = list(coords.shape)
+        c = coords.detach().reshape(-1, 3).float().contiguous()
+        n = int(c.shape[0])
+        f, w, lim = self._values(query_tensor)
+        d, keep = self._delta(sdf_delta)
+        out = torch.empty(n, dtype=torch.float32, device=self._dev)
+        _lib.check(self._lib.bnv_decode_pts(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w),
+                                            int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(c), n,
+                                            1 if is_coords else 0, C.byref(d), _lib.ptr(out), _lib.stream_ptr()),
+                   "bnv_decode_pts")
+        return out.reshape(shape[:-1] + [1])
+
+    def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True):
+        """decode_pts on the 3x3x3 lattice {-0.5, 0, 0.5}^3 around integer voxel ``origins`` [B, 3]
+        (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27]."""
+        o = origins.detach().reshape(-1, 3).long().contiguous()
+        n = int(o.shape[0])
+        out = torch.empty((n, 27), dtype=torch.float32, device=self._dev)
+        if n == 0:
+            return out
+        f, w, lim = self._values(query_tensor)
+        d, keep = self._delta(sdf_delta)
+        need = int(self._lib.bnv_decode_lattice_workspace_bytes(n, self._row_capacity))
+        if self._lattice_ws is None or self._lattice_ws.numel() < need:
+            # zero-filled: the per-row stamps at the front of the workspace must start at 0
+            self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            self._lattice_epoch = 0
+        self._lattice_epoch += 1
+        _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
+                                                _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
+                                                C.byref(d), _lib.ptr(self._lattice_ws), self._lattice_ws.numel(),
+                                                self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
+                   "bnv_decode_lattice")
+        return out
+
+    def meshlize(self, nerf, sdf_delta=None, path=None):
+        """sparse_volume.py:697-766.  The SDF lattice is decoded on the GPU; the per-voxel marching
+        cubes + trimesh assembly of the reference (skimage / trimesh) is outside this path
+        (SURVEY.md section 8 f-4): returns (active_pts, sdf [M, 3, 3, 3]) instead of a trimesh."""
+        assert self.active_coordinates is not None, "call self.to_tensor() first."
+        active_pts = self.active_coordinates * self.voxel_size + self.min_coords
+        sdf = self.decode_lattice(self.active_coordinates, nerf, sdf_delta, query_tensor=True)
+        return active_pts, sdf.reshape(-1, 3, 3, 3)
+
+    # ---- persistence (sparse_volume.py:835-892) ----------------------------------------------------
+    def save(self, path):
+        self.print_statistic()
+        n = self._snapshot_rows
+        out_dict = {
+            "25%": getattr(self, "per_25", None), "50%": getattr(self, "per_50", None),
+            "75%": getattr(self, "per_75", None), "dimensions": self.dimensions,
+            "voxel_size": self.voxel_size, "mean": self.avg_n_pts, "min": self.min_pts,
+            "active_keys": self.active_coordinates, "active_vals": torch.arange(n, device=self._dev)[:, None],
+            "features": self.features, "weights": self.weights, "num_hits": self.num_hits,
+            "active_coordinates": self.active_coordinates,
+        }
+        torch.save(out_dict, path + "_sparse_volume.pth")
+
+    def load(self, path):
+        volume = torch.load(path, map_location=self._dev)
+        coords = volume["active_coordinates"].to(self._dev)
+        self.reset(max(len(coords), 1024))
+        self.insert(coords, volume["features"].to(self._dev), volume["weights"].to(self._dev),
+                    volume["num_hits"].to(self._dev))
+        self.to_tensor()

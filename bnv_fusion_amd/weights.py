@@ -1,0 +1,102 @@
+"""Weights of the fp32 point encoder / SDF decoder: loading, BatchNorm folding and the
+pre-permuted MFMA operand layouts the kernels read (csrc/encode.hip, csrc/decode.hip).
+
+State-dict key names are the reference's, so either the converted
+``weights/pointnet_fp32.npz`` or a ``torch.load(ckpt)['state_dict']`` can be passed in.
+"""
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_FP32 = os.path.join(_HERE, "weights", "pointnet_fp32.npz")
+DEFAULT_TCNN = os.path.join(_HERE, "weights", "pointnet_tcnn.npz")
+
+BN_EPS = 1e-5  # nn.BatchNorm1d default (pointnet_utils.py:240-243)
+
+
+def load_npz(path=DEFAULT_FP32):
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _np(v):
+    return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+
+
+def fold_pointnet(sd):
+    """conv1d(k=1) + eval-mode BatchNorm1d -> one affine map per layer (float64 fold).
+    pointnet_utils.py:246-266: y = (W x + b - mean) / sqrt(var + eps) * gamma + beta."""
+    out = []
+    for i in (1, 2, 3, 4):
+        p = "pointnet_backbone."
+        W = _np(sd[f"{p}conv{i}.weight"]).astype(np.float64)[:, :, 0]
+        b = _np(sd[f"{p}conv{i}.bias"]).astype(np.float64)
+        s = _np(sd[f"{p}bn{i}.weight"]).astype(np.float64) / np.sqrt(
+            _np(sd[f"{p}bn{i}.running_var"]).astype(np.float64) + BN_EPS)
+        Wf = W * s[:, None]
+        bf = (b - _np(sd[f"{p}bn{i}.running_mean"]).astype(np.float64)) * s + _np(sd[f"{p}bn{i}.bias"]).astype(
+            np.float64)
+        out.append((Wf.astype(np.float32), bf.astype(np.float32)))
+    return out
+
+
+def pack_pointnet(sd):
+    """-> float32 [34952] in the PN_* layout of csrc/encode.hip.
+
+    MFMA tile: lane l = (n = l & 31, h = l >> 5).  A K-step that consumes D register r of input
+    block nb contracts input features nb*32 + f0(r) + 4h with f0(r) = (r & 3) + 8 (r >> 2); for
+    r = 4 rq + i that is nb*32 + 8 rq + i + 4h."""
+    (W1, b1), (W2, b2), (W3, b3), (W4, b4) = fold_pointnet(sd)
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+    # W1p[s][mb][l] = W1[mb*32 + n][2s + h]
+    w1p = np.zeros((3, 4, 64), np.float32)
+    for s in range(3):
+        for mb in range(4):
+            w1p[s, mb] = W1[mb * 32 + n, 2 * s + h]
+
+    def pack128(W):
+        o = np.zeros((4, 4, 4, 64, 4), np.float32)
+        for mb in range(4):
+            for nb in range(4):
+                for rq in range(4):
+                    for i in range(4):
+                        o[mb, nb, rq, :, i] = W[mb * 32 + n, nb * 32 + 8 * rq + i + 4 * h]
+        return o
+
+    w4p = np.zeros((4, 4, 2, 8, 4), np.float32)
+    for nb in range(4):
+        for rq in range(4):
+            for hh in range(2):
+                for i in range(4):
+                    w4p[nb, rq, hh, :, i] = W4[:, nb * 32 + 8 * rq + i + 4 * hh]
+    return np.concatenate([w1p.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4p.ravel(),
+                           b1, b2, b3, b4]).astype(np.float32)
+
+
+def pack_sdf_mlp(sd):
+    """-> float32 [SD_TOTAL] in the SD_* layout of csrc/decode.hip.
+    Wp[w][kb][l][i] = W[32 w + (l & 31)][8 kb + 4 (l >> 5) + i]; layer 0 has K = 17 padded to 24."""
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+
+    def pack(W, nkb):
+        K = W.shape[1]
+        o = np.zeros((8, nkb, 64, 4), np.float32)
+        for w in range(8):
+            for kb in range(nkb):
+                for i in range(4):
+                    k = 8 * kb + 4 * h + i
+                    ok = k < K
+                    o[w, kb, ok, i] = W[32 * w + n[ok], k[ok]]
+        return o.ravel()
+
+    Ws = [_np(sd[f"nerf.geo_layer{i}.weight"]).astype(np.float32) for i in range(4)]
+    bs = [_np(sd[f"nerf.geo_layer{i}.bias"]).astype(np.float32) for i in range(4)]
+    assert Ws[0].shape == (256, 17) and all(W.shape == (256, 256) for W in Ws[1:])
+    wa = _np(sd["nerf.fc_alpha.weight"]).astype(np.float32).reshape(256)
+    ba = np.zeros(4, np.float32)
+    ba[0] = _np(sd["nerf.fc_alpha.bias"]).reshape(-1)[0]
+    return np.concatenate([pack(Ws[0], 3), pack(Ws[1], 32), pack(Ws[2], 32), pack(Ws[3], 32),
+                           bs[0], bs[1], bs[2], bs[3], wa, ba]).astype(np.float32)

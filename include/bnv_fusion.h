@@ -1,0 +1,186 @@
+/*
+ * bnv_fusion.h -- C ABI of the MI355X (gfx950) implementation of BNV-Fusion's per-frame
+ * local-fusion + SDF-decode hot path.
+ *
+ * The reference (likojack/bnv_fusion) has no FFI for this path: the boundary there is a Python
+ * duck type (LitFusionPointNet / SparseVolume).  The entry points below are what a binding of
+ * those methods needs; each cites the reference code it replaces (paths relative to the
+ * reference repo).  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory (the library never allocates device memory);
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*) and returns
+ *     immediately; it returns 0 on success or a negative bnv_status code, never throws;
+ *   - counts that are only known on the device are written to caller-provided device structs;
+ *     the caller synchronises the stream before reading them.
+ *   - build: hipcc --offload-arch=gfx950 (bnv_fusion_amd/csrc/build.py); no CPU fallback exists.
+ */
+#ifndef BNV_FUSION_H
+#define BNV_FUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bnv_stream_t; /* hipStream_t */
+
+enum bnv_status {
+  BNV_OK = 0,
+  BNV_ERR_INVALID_ARGUMENT = -1,
+  BNV_ERR_WORKSPACE_TOO_SMALL = -2,
+  BNV_ERR_HIP = -3,          /* a HIP runtime call failed; see bnv_last_hip_error() */
+  BNV_ERR_NOT_INITIALISED = -4,
+  BNV_ERR_CAPACITY = -5
+};
+
+/* Voxel grid of one SparseVolume (sparse_volume.py:485-500, voxel_utils.py:83-88).  The float
+ * members are the float32 values the reference holds: bound_min = float32(min_coords);
+ * bound_lo = float32(min_coords) + float32(voxel), bound_hi = float32(max_coords) - float32(voxel)
+ * evaluated in float32 (local_point_fusion.py:94-100). */
+typedef struct bnv_grid {
+  float bound_min[3];
+  float bound_lo[3];
+  float bound_hi[3];
+  float voxel_size;
+  int32_t n_xyz[3];
+  int32_t min_pts_in_grid;
+  /* spatial sharding of the active-voxel set: a voxel is owned by
+   * hash(block coordinate) % shard_world, blocks of (1 << shard_block_log2)^3 voxels.
+   * shard_world = 1 disables sharding. */
+  int32_t shard_rank;
+  int32_t shard_world;
+  int32_t shard_block_log2;
+} bnv_grid_t;
+
+/* Device-side result counters of bnv_encode_pointcloud. */
+typedef struct bnv_encode_counters {
+  int32_t n_valid_points; /* points that passed the bounds mask                                 */
+  int32_t n_unique;       /* U : voxels touched by >= 1 (point, corner) pair                    */
+  int32_t n_out;          /* U': rows written (count >= min_pts_in_grid and owned by this shard) */
+  float n_avg_pts;        /* mean pair count over all U voxels (local_point_fusion.py:143)       */
+  int32_t error;          /* != 0: an output capacity was exceeded                               */
+  int32_t reserved[3];
+} bnv_encode_counters_t;
+
+/* Sparse feature volume = open-addressing hash (packed 3x21-bit key -> row) + dense row arrays
+ * (replaces open3d.core.HashMap, sparse_volume.py:588-594).  All arrays are caller-owned. */
+typedef struct bnv_volume {
+  uint64_t* slot_keys;   /* [n_slots]  packed key, ~0 = empty                 */
+  int32_t* slot_rows;    /* [n_slots]  row index                              */
+  int64_t n_slots;       /* power of two                                      */
+  int64_t* row_coords;   /* [row_capacity, 3] voxel coordinates (int64)       */
+  float* features;       /* [row_capacity, n_feats]                           */
+  float* weights;        /* [row_capacity]                                    */
+  float* num_hits;       /* [row_capacity]                                    */
+  int64_t row_capacity;
+  int32_t* n_rows;       /* device scalar: number of rows in use              */
+  int32_t n_feats;       /* 8                                                 */
+} bnv_volume_t;
+
+/* ------------------------------------------------------------------------------------------ */
+int bnv_init(int device);           /* query the device, opt kernels in to large LDS          */
+int bnv_num_compute_units(void);
+const char* bnv_status_string(int status);
+int bnv_last_hip_error(void);
+
+/* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
+
+/* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points. */
+size_t bnv_encode_workspace_bytes(int64_t max_points, const int32_t n_xyz[3]);
+/* Zero the scratch (once after allocation; encode leaves it clean for the next frame). */
+int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream);
+
+/* Packed-weight sizes (floats) of the fp32 point encoder / SDF decoder; layouts in DESIGN.md. */
+size_t bnv_pointnet_pack_floats(void);
+size_t bnv_sdfmlp_pack_floats(void);
+
+/* input_pts [n_points, 6] f32 (world xyz, world normal).
+ * Runs: bounds mask (:94-104), 8-corner voxelisation (:153-165, modules.py:586-655), the point
+ * encoder on every (point, corner) pair (pointnet_utils.py:246-266, BatchNorm folded), sorted
+ * unique voxel ids + counts (torch.unique, :118-119), per-voxel mean (torch_scatter.scatter_mean,
+ * :125), min-points filter and repack (:143-151).
+ * Outputs (capacity rows each): feats [.,8] f32, pcounts [.] i64, flat_ids [.] i64 ascending,
+ * grid_ids [.,3] i64.  emit_all != 0 writes all U voxels with features zeroed where
+ * count < min_pts (the return_dense=True contract, :126-141). */
+int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                          const float* pointnet_pack, void* ws, size_t ws_bytes,
+                          float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids,
+                          int64_t* out_grid_ids, int64_t out_capacity, int emit_all,
+                          bnv_encode_counters_t* counters, bnv_stream_t stream);
+
+/* get_relative_xyz + flatten for every pair, pair index p = corner * n_points + i
+ * (local_point_fusion.py:106-117, voxel_utils.py:62-65).  No bounds mask (the caller compacts).
+ * grid_ids [8n,3] i32, flat_ids [8n] i64, rel_xyz [8n,3] f32 (already divided by voxel_size as
+ * forward(normalize=True) does, :58-59).  Any output may be NULL. */
+int bnv_voxelize_pairs(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                       int32_t* grid_ids, int64_t* flat_ids, float* rel_xyz, uint8_t* bound_mask,
+                       bnv_stream_t stream);
+
+/* ---- volume: SparseVolume (sparse_volume.py:484-695) ---------------------------------------- */
+
+int bnv_volume_clear(const bnv_volume_t* vol_host, bnv_stream_t stream);
+/* Rebuild the slot table from row_coords[0:n_rows) (after the caller enlarged it). */
+int bnv_volume_rehash(const bnv_volume_t* vol_host, bnv_stream_t stream);
+size_t bnv_volume_workspace_bytes(int64_t max_keys);
+
+/* LitFusionPointNet._integrate + _update (local_point_fusion.py:647-673) fused with
+ * SparseVolume.query/insert (sparse_volume.py:561-585, 661-695): for n UNIQUE keys,
+ * w = min(count/32, 1); f = (f_old*w_old + f*w)/(w_old + w); upsert.  coords [n,3] i64,
+ * feats [n,8], pcounts [n] i64. */
+int bnv_volume_integrate(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
+                         const int64_t* pcounts, int64_t n, void* ws, size_t ws_bytes,
+                         bnv_stream_t stream);
+/* SparseVolume.insert (upsert with explicit values), sparse_volume.py:561-585. */
+int bnv_volume_insert(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
+                      const float* weights, const float* num_hits, int64_t n, void* ws,
+                      size_t ws_bytes, bnv_stream_t stream);
+/* SparseVolume.query / _query_tensor (sparse_volume.py:625-695): zeros for absent keys.
+ * Values are read from (features, weights, num_hits) given here -- the live arrays or a
+ * to_tensor() snapshot; rows >= row_limit count as absent.  out_rows (optional) gets the row or -1. */
+int bnv_volume_query(const bnv_volume_t* vol_host, const int64_t* coords, int64_t n,
+                     const float* features, const float* weights, const float* num_hits,
+                     int64_t row_limit, float* out_feats, float* out_weights, float* out_hits,
+                     int32_t* out_rows, bnv_stream_t stream);
+/* SparseVolume.count_optim (sparse_volume.py:602-622): weights[row] += 1 once per distinct row. */
+int bnv_volume_count_optim(const bnv_volume_t* vol_host, const int64_t* coords, int64_t n,
+                           float* weights, int64_t row_limit, int32_t* stamp, int32_t epoch,
+                           bnv_stream_t stream);
+
+/* ---- decode --------------------------------------------------------------------------------- */
+
+/* Optional TSDF prior sampled by nearest grid_sample (sparse_volume.py:819-832). */
+typedef struct bnv_sdf_delta {
+  const float* data; /* [dx, dy, dz] or NULL */
+  int32_t dims[3];
+} bnv_sdf_delta_t;
+
+/* SparseVolume.decode_pts (sparse_volume.py:768-833) at arbitrary points: coords [n,3] f32,
+ * voxel units if is_coords else world; out [n] f32. */
+int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                   const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                   const float* coords, int64_t n, int is_coords, const bnv_sdf_delta_t* delta_host,
+                   float* out_sdf, bnv_stream_t stream);
+
+size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
+/* The same decode for the 3x3x3 lattice {-0.5,0,0.5}^3 around n integer voxel origins
+ * (SparseVolume.meshlize's decode_pts call, sparse_volume.py:717-738): out [n,27] f32.
+ * Evaluates the MLP once per (corner voxel, local offset) instead of 8x per lattice point. */
+int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
+                       const float* features, const float* weights, int64_t row_limit,
+                       const float* sdfmlp_pack, const int64_t* origins, int64_t n,
+                       const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
+                       float* out_sdf, bnv_stream_t stream);
+
+/* LitFusionPointNet.decode_feature_grid_w_pts, global_coords=False / interpolate_decode=True
+ * (local_point_fusion.py:265-329): dense feat_grid [8,X,Y,Z], pts_weight [X,Y,Z];
+ * voxel_coords [n,3] f32 -> out [n]. */
+int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims_host[3],
+                     float voxel_size, int32_t min_pts_in_grid, const float* sdfmlp_pack,
+                     const float* voxel_coords, int64_t n, float* out_sdf, bnv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNV_FUSION_H */

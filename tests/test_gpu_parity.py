@@ -1,0 +1,343 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the oracle.  Needs a real MI355X: run with  -m gpu.
+
+Bars (BASELINE.json north_star): voxel indices / counts bit-exact; floats within 1e-4 absolute
+(fp32; summation order differs from ATen's, nothing else).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, WEIGHTS_FP32
+
+pytestmark = pytest.mark.gpu
+
+SDF_TOL = 1e-4      # north_star: SDF max-abs-err < 1e-4
+FEAT_TOL = 1e-4     # per-voxel encoder features (|f| ~ O(1))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def bnv():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (no CPU fallback exists)")
+    import bnv_fusion_amd
+    return bnv_fusion_amd
+
+
+@pytest.fixture(scope="module")
+def model(bnv):
+    return bnv.load_pretrained(device=DEV, voxel_size=0.02)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import bnv_oracle
+    return bnv_oracle
+
+
+@pytest.fixture(scope="module")
+def sd(orc):
+    return orc.load_weights(WEIGHTS_FP32)
+
+
+def _vol(bnv, z):
+    return bnv.SparseVolume(8, float(z["voxel_size"]), z["dims"], 8, device=DEV)
+
+
+def _encode(model, vol, pts, dense=False):
+    return model.encode_pointcloud(pts.to(DEV), vol.n_xyz, vol.min_coords, vol.max_coords, vol.voxel_size,
+                                   return_dense=dense)
+
+
+# ---------------------------------------------------------------------------------------------
+# encode
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["encode_64", "encode_128"])
+def test_encode_sparse_vs_reference_golden(bnv, model, name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    vol = _vol(bnv, z)
+    f, c, ids, g, n = _encode(model, vol, torch.from_numpy(z["input_pts"]))
+    assert np.array_equal(ids.cpu().numpy(), z["flat_ids"])        # bit-exact, ascending
+    assert c.dtype == torch.int64 and np.array_equal(c.cpu().numpy(), z["pcounts"])
+    assert g.dtype == torch.int64 and np.array_equal(g.cpu().numpy(), z["grid_ids"])
+    assert float(n) == float(z["n_avg_pts"])
+    err = np.abs(f.cpu().numpy() - z["feats"]).max()
+    assert err <= FEAT_TOL, err
+
+
+def test_encode_is_deterministic(bnv, model):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(bnv, z)
+    a = _encode(model, vol, torch.from_numpy(z["input_pts"]))
+    b = _encode(model, vol, torch.from_numpy(z["input_pts"]))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_encode_dense_vs_reference_golden(bnv, model):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(bnv, z)
+    fg, mask, uids, flat_all = _encode(model, vol, torch.from_numpy(z["input_pts"]), dense=True)
+    assert np.array_equal(uids.cpu().numpy(), z["dense_unique_flat_ids"])
+    assert np.array_equal(flat_all[0].cpu().numpy(), z["dense_flat_ids_all"].astype(np.int64))
+    assert np.array_equal(mask[0, 0].reshape(-1).nonzero()[:, 0].cpu().numpy(), z["dense_nonzero"])
+    assert np.array_equal(mask[0, 0].reshape(-1)[uids].cpu().numpy(), z["dense_counts"])
+    err = np.abs(fg[0].reshape(8, -1)[:, uids].T.cpu().numpy() - z["dense_feats"]).max()
+    assert err <= FEAT_TOL, err
+
+
+def test_encode_empty_and_ragged(bnv, model):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(bnv, z)
+    pts = torch.from_numpy(z["input_pts"]).clone()
+    far = pts.clone()
+    far[..., :3] += 100.0
+    assert _encode(model, vol, far) == (None,) * 5          # local_point_fusion.py:101-102
+    nan = pts.clone()
+    nan[..., :3] = float("nan")
+    assert _encode(model, vol, nan) == (None,) * 5
+    for n in (1, 31, 33, 1000):                              # ragged tile tails
+        out = _encode(model, vol, pts[:, :n])
+        assert out[0] is None or out[2].shape[0] == out[0].shape[0]
+
+
+def test_voxelize_pairs_bit_exact_vs_oracle(bnv, model, orc):
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(bnv, z)
+    xyz = torch.from_numpy(z["input_pts"])[:, :, :3]
+    rel, gid = model.get_relative_xyz(xyz.to(DEV), vol.min_coords, vol.voxel_size)
+    rel_o, gid_o = orc.get_relative_xyz(xyz, vol.min_coords.cpu(), vol.voxel_size)
+    assert torch.equal(gid.cpu(), gid_o)
+    # the kernel keeps rel / voxel (the encoder input); compare that quantity exactly
+    assert torch.equal((rel / vol.voxel_size).cpu(), (rel_o / vol.voxel_size))
+
+
+# ---------------------------------------------------------------------------------------------
+# volume
+# ---------------------------------------------------------------------------------------------
+def _sorted_state(vol):
+    k = vol.active_coordinates.cpu().numpy()
+    order = np.lexsort((k[:, 2], k[:, 1], k[:, 0]))
+    return k[order], vol.features.detach().cpu().numpy()[order], vol.weights.cpu().numpy()[order], order
+
+
+def test_integrate_sequence_vs_reference_golden(bnv, model, orc, sd):
+    """oracle encode (CPU) -> HIP _integrate: isolates the hash volume + running average."""
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    vol = _vol(bnv, z)
+    ovol = orc.OracleSparseVolume(8, float(z["voxel_size"]), z["dims"], 8)
+    for fr in z["frames"]:
+        f, c, _, g, _ = orc.encode_pointcloud(sd, torch.from_numpy(fr), ovol.n_xyz, ovol.min_coords,
+                                              ovol.max_coords, ovol.voxel_size)
+        model._integrate(vol, g.to(DEV), f.to(DEV), c.to(DEV))
+    vol.to_tensor()
+    assert np.array_equal(vol.active_coordinates.cpu().numpy(), z["keys_insertion"])  # buffer order reproducible
+    k, f, w, _ = _sorted_state(vol)
+    assert np.array_equal(k, z["keys_sorted"])
+    assert np.array_equal(w, z["weights_sorted"])            # same fp32 op sequence -> bit-exact
+    assert np.abs(f - z["features_sorted"]).max() <= 2e-6
+    assert np.all(vol.num_hits.cpu().numpy() == 0)
+
+
+def test_full_chain_sequence_vs_reference_golden(bnv, model):
+    """HIP encode -> HIP _integrate over 12 frames vs the reference's final volume."""
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    nm = bnv.NeuralMap(z["dims"], float(z["voxel_size"]), model, device=DEV)
+    for fr in z["frames"]:
+        nm.integrate({"input_pts": torch.from_numpy(fr).to(DEV)})
+    nm.volume.to_tensor()
+    k, f, w, _ = _sorted_state(nm.volume)
+    assert np.array_equal(k, z["keys_sorted"])
+    assert np.array_equal(w, z["weights_sorted"])
+    assert np.abs(f - z["features_sorted"]).max() <= FEAT_TOL
+    assert np.allclose(nm.volume.n_pts_list, z["n_pts_list"])
+
+
+def test_volume_query_insert_grow(bnv):
+    vol = bnv.SparseVolume(8, 0.02, np.array([1.24] * 3), 8, capacity=1024, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    keys = torch.unique(torch.randint(-50, 200, (5000, 3), generator=g), dim=0)
+    n = len(keys)
+    feats = torch.randn(n, 8, generator=g)
+    w = torch.rand(n, 1, generator=g)
+    h = torch.zeros(n, 1)
+    half = n // 2
+    vol.insert(keys[:half].to(DEV), feats[:half].to(DEV), w[:half].to(DEV), h[:half].to(DEV))
+    vol.insert(keys.to(DEV), feats.to(DEV), w.to(DEV), h.to(DEV))        # overwrite + append + grow
+    assert vol.num_rows() == n
+    f, ww, hh = vol.query(keys.to(DEV))
+    assert torch.equal(f.cpu(), feats) and torch.equal(ww.cpu(), w)
+    missing = keys + 1000
+    f, ww, hh = vol.query(missing.to(DEV))
+    assert float(f.abs().sum()) == 0 and float(ww.abs().sum()) == 0
+    coords, f2, w2, _ = vol.to_tensor()
+    assert torch.equal(coords.cpu(), keys)                               # insertion (batch) order
+    # keys inserted after the snapshot are invisible to _query_tensor (sparse_volume.py:625-659)
+    extra = torch.tensor([[900, 900, 900]])
+    vol.insert(extra.to(DEV), torch.ones(1, 8, device=DEV), torch.ones(1, 1, device=DEV),
+               torch.zeros(1, 1, device=DEV))
+    assert float(vol._query_tensor(extra.to(DEV))[1].sum()) == 0
+    assert float(vol.query(extra.to(DEV))[1].sum()) == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# decode
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_volume(bnv):
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    vol = _vol(bnv, z)
+    n = len(z["keys_sorted"])
+    vol.insert(torch.from_numpy(z["keys_sorted"]).to(DEV), torch.from_numpy(z["features_sorted"]).to(DEV),
+               torch.from_numpy(z["weights_sorted"]).to(DEV), torch.zeros(n, 1, device=DEV))
+    vol.to_tensor()
+    return vol
+
+
+def test_decode_pts_vs_reference_golden(bnv, model, golden_volume):
+    vol = golden_volume
+    z = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    lat = torch.from_numpy(z["lattice_coords"]).to(DEV)
+    rnd = torch.from_numpy(z["random_coords"]).to(DEV)
+    delta = torch.from_numpy(z["sdf_delta"]).to(DEV)
+    v = np.float32(vol.voxel_size)
+    cases = {
+        "lattice_qt": vol.decode_pts(lat, model.nerf, None, is_coords=True, query_tensor=True),
+        "lattice_q": vol.decode_pts(lat, model.nerf, None, is_coords=True, query_tensor=False),
+        "lattice_delta": vol.decode_pts(lat, model.nerf, delta, is_coords=True, query_tensor=True),
+        "random_qt": vol.decode_pts(rnd, model.nerf, None, is_coords=True, query_tensor=True),
+        "random_world_out": vol.decode_pts(torch.from_numpy(z["random_world_coords"]).to(DEV), model.nerf, None,
+                                           is_coords=False, query_tensor=False),
+        "random_delta": vol.decode_pts(rnd, model.nerf, delta, is_coords=True, query_tensor=True),
+    }
+    for k, out in cases.items():
+        out = out.cpu().numpy()
+        assert out.shape == z[k].shape, k
+        assert np.abs(out - z[k]).max() <= SDF_TOL, (k, np.abs(out - z[k]).max())
+        if "delta" not in k:
+            assert np.array_equal(out == v, z[k] == v), k          # mask decisions identical
+
+
+def test_decode_lattice_vs_reference_golden(bnv, model, golden_volume):
+    """The per-voxel-table lattice decode against the reference's 8-corner decode_pts."""
+    vol = golden_volume
+    z = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    origins = torch.from_numpy(z["origins"]).to(DEV)
+    delta = torch.from_numpy(z["sdf_delta"]).to(DEV)
+    v = np.float32(vol.voxel_size)
+    for key, kw in (("lattice_qt", dict(query_tensor=True)), ("lattice_q", dict(query_tensor=False)),
+                    ("lattice_delta", dict(query_tensor=True, sdf_delta=delta))):
+        out = vol.decode_lattice(origins, model.nerf, **kw).cpu().numpy()
+        ref = z[key][0, :, :, 0]
+        assert out.shape == ref.shape
+        assert np.abs(out - ref).max() <= SDF_TOL, (key, np.abs(out - ref).max())
+        if "delta" not in key:
+            assert np.array_equal(out == v, ref == v), key
+    # voxels with a missing neighbour decode to exactly voxel_size (SURVEY 8c known answer iii)
+    far = torch.tensor([[3, 3, 3], [60, 2, 7]], device=DEV)
+    assert torch.all(vol.decode_lattice(far, model.nerf) == vol.voxel_size)
+
+
+def test_count_optim_vs_reference_golden(bnv, model, golden_volume):
+    vol = golden_volume
+    z = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    rnd = torch.from_numpy(z["random_coords"]).to(DEV)
+    w0 = vol.weights.clone()
+    vol.count_optim(bnv.get_neighbors(rnd))
+    # rows of golden_volume are key-sorted, like the golden vector
+    assert np.array_equal(vol.weights.cpu().numpy(), z["weights_after_count_optim_sorted"])
+    out = vol.decode_pts(rnd, model.nerf, None, is_coords=True, query_tensor=True).cpu().numpy()
+    assert np.abs(out - z["random_after_count_optim"]).max() <= SDF_TOL
+    vol.weights.copy_(w0)
+
+
+def test_dense_decode_vs_reference_golden(bnv, model):
+    z = np.load(os.path.join(GOLDEN, "dense_decode_64.npz"))
+    vol = _vol(bnv, z)
+    fg, mask, _, _ = _encode(model, vol, torch.from_numpy(z["input_pts"]), dense=True)
+    sdf, nf = model.decode_feature_grid_w_pts(torch.from_numpy(z["queries"]).to(DEV), fg, mask, vol.voxel_size,
+                                              vol.min_coords, global_coords=False)
+    out = sdf.cpu().numpy()
+    assert out.shape == z["sdf"].shape
+    assert np.abs(out - z["sdf"]).max() <= SDF_TOL, np.abs(out - z["sdf"]).max()
+    v = np.float32(vol.voxel_size)
+    assert np.array_equal(out == v, z["sdf"] == v)
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE configs: 640x480 depth, 256^3 grid, voxel 0.01)
+# ---------------------------------------------------------------------------------------------
+_LATTICE = [[x, y, z] for x in (-.5, 0, .5) for y in (-.5, 0, .5) for z in (-.5, 0, .5)]
+_NBR = [[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)]
+
+
+@pytest.fixture(scope="module")
+def big(bnv):
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[256]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV)
+    frames = [torch.from_numpy(synthetic.frame(t)).to(DEV) for t in range(2)]
+    return model, nm, frames
+
+
+def test_full_size_encode_properties(big, orc, sd):
+    model, nm, frames = big
+    vol = nm.volume
+    assert vol.n_xyz.tolist() == [256, 256, 256]
+    f, c, ids, g, n = _encode(model, vol, frames[0])
+    assert torch.all(ids[1:] > ids[:-1])                                   # sorted, unique
+    assert torch.all(c >= 8)
+    assert torch.equal(ids, (g[:, 0] * 256 + g[:, 1]) * 256 + g[:, 2])     # flatten(unflatten(id)) == id
+    # voxel ids / counts bit-exact vs the oracle's torch.unique on the same points
+    pts = frames[0].cpu()
+    rel, gid = orc.get_relative_xyz(pts[:, :, :3], vol.min_coords.cpu(), vol.voxel_size)
+    flat = orc.flatten(gid.reshape(1, -1, 3), vol.n_xyz.cpu()).long()
+    u, cnt = torch.unique(flat[0], return_counts=True)
+    keep = cnt >= 8
+    assert torch.equal(ids.cpu(), u[keep]) and torch.equal(c.cpu()[:, 0], cnt[keep])
+    assert float(n) == float(torch.mean(cnt.float()))
+    # features of a sample of voxels vs the oracle (encoder on the pairs of those voxels only)
+    sel = torch.randperm(int(keep.sum()), generator=torch.Generator().manual_seed(0))[:64]
+    npts = pts.shape[1]
+    for s in sel.tolist():
+        pair = (flat[0] == int(u[keep][s])).nonzero()[:, 0]
+        k_, i_ = pair // npts, pair % npts
+        x = torch.cat([(rel[0, k_, i_] / vol.voxel_size), pts[0, i_, 3:]], -1)
+        ref = orc.pointnet_encoder(sd, x.t()[None])[0].mean(1)
+        assert (f[s].cpu() - ref).abs().max() <= FEAT_TOL
+
+
+def test_full_size_fuse_decode_properties(big, orc, sd):
+    model, nm, frames = big
+    vol = nm.volume
+    # idempotence (SURVEY 8c i): fusing the same frame k times keeps features, weights = k*min(c/32,1)
+    f, c, ids, g, n = _encode(model, vol, frames[0])
+    for _ in range(9):
+        model._integrate(vol, g, f, c)
+    fq, wq, _ = vol.query(g)
+    assert (fq - f).abs().max() < 5e-6
+    assert torch.allclose(wq[:, 0], 9 * torch.clamp(c[:, 0].float() / 32, max=1.0), atol=1e-5)
+    # lattice decode == general 8-corner decode on the same lattice points (two HIP paths)
+    sub = g[:: max(1, len(g) // 4000)]
+    lat = vol.decode_lattice(sub, model.nerf, query_tensor=False)
+    coords = sub[:, None, :].float() + torch.tensor(_LATTICE, device=DEV)[None]
+    gen = vol.decode_pts(coords[None], model.nerf, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+    assert (lat - gen).abs().max() <= 2e-6
+    assert torch.equal(lat == vol.voxel_size, gen == vol.voxel_size)
+    live = float((lat != vol.voxel_size).float().mean())
+    assert live > 0.2, live
+    # ... and against the oracle on a small sample of voxels (oracle volume = the queried rows)
+    pick = sub[torch.randperm(len(sub), generator=torch.Generator().manual_seed(1))[:40]].cpu()
+    nbr = torch.unique((pick[:, None, :] + torch.tensor(_NBR)[None]).reshape(-1, 3), dim=0)
+    fo, wo, _ = vol.query(nbr.to(DEV))
+    ovol = orc.OracleSparseVolume(8, vol.voxel_size, vol.dimensions, 8)
+    present = wo[:, 0].cpu() > 0
+    ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
+    ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True,
+                          query_tensor=False)[0, :, :, 0]
+    got = vol.decode_lattice(pick.to(DEV), model.nerf, query_tensor=False).cpu()
+    assert (got - ref).abs().max() <= SDF_TOL, float((got - ref).abs().max())
+    assert torch.equal(got == vol.voxel_size, ref == vol.voxel_size)
