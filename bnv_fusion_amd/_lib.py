@@ -15,6 +15,7 @@ SYMBOLS = [
     "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_voxelize_pairs",
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
+    "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
     "bnv_decode_pts", "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
 
@@ -69,7 +70,7 @@ def load():
         "bnv_encode_workspace_reset": (C.c_int, [vp, sz, vp]),
         "bnv_pointnet_pack_floats": (sz, []),
         "bnv_sdfmlp_pack_floats": (sz, []),
-        "bnv_encode_pointcloud": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, vp, vp, vp, vp, i64, C.c_int,
+        "bnv_encode_pointcloud": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64, C.c_int,
                                             vp, vp]),
         "bnv_voxelize_pairs": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, vp, vp, vp]),
         "bnv_volume_clear": (C.c_int, [C.POINTER(Volume), vp]),
@@ -82,6 +83,9 @@ def load():
         "bnv_decode_pts": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, C.c_int,
                                      C.POINTER(SdfDelta), vp, vp]),
         "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
+        "bnv_decode_lattice_count_offset": (sz, [i64]),
+        "bnv_profile_enable": (C.c_int, [C.c_int]),
+        "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, vp, vp]),

@@ -15,6 +15,17 @@ constexpr int kWave = 64;
 extern int g_num_cus;
 extern int g_last_hip_error;
 
+// optional HIP-event timing of the dominant kernels (bnv_profile_enable / bnv_profile_read)
+enum ProfKind { PROF_POINTNET = 0, PROF_DECODE_LATTICE = 1, PROF_DECODE_PTS = 2, PROF_DECODE_DENSE = 3, PROF_KINDS = 4 };
+extern bool g_prof_on;
+void prof_mark(int kind, bool begin, hipStream_t stream);
+struct ProfScope {
+  int kind;
+  hipStream_t stream;
+  ProfScope(int k, hipStream_t s) : kind(k), stream(s) { if (g_prof_on) prof_mark(kind, true, stream); }
+  ~ProfScope() { if (g_prof_on) prof_mark(kind, false, stream); }
+};
+
 #define BNV_HIP_CHECK(expr)                      \
   do {                                           \
     hipError_t _e = (expr);                      \

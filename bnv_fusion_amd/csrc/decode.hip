@@ -445,6 +445,8 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   int64_t grid = g_num_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
+  ProfScope prof(mode == MODE_PTS ? PROF_DECODE_PTS : mode == MODE_LATTICE ? PROF_DECODE_LATTICE : PROF_DECODE_DENSE,
+                 stream);
   if (mode == MODE_PTS)
     hipLaunchKernelGGL(k_decode<MODE_PTS>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
   else if (mode == MODE_LATTICE)
@@ -525,6 +527,12 @@ int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int3
 
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity) {
   return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr);
+}
+
+size_t bnv_decode_lattice_count_offset(int64_t row_capacity) {
+  LatticeWs ws;
+  lattice_ws_layout(1, row_capacity, (char*)256, &ws);
+  return (size_t)((char*)ws.n_list - (char*)256);
 }
 
 int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,

@@ -15,12 +15,35 @@
 // pair j, so the K-step that consumes D[r] as its B operand contracts features
 // {f0(r), f0(r)+4}; the packed A operands (weights) are pre-permuted on the host to match
 // (bnv_fusion_amd/weights.py: pack_pointnet).
+#include <utility>
+#include <vector>
+
 #include "bnv_common.hpp"
 
 namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
+
+// ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
+bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events[PROF_KINDS];
+static size_t g_prof_used[PROF_KINDS] = {0, 0, 0, 0};
+
+void prof_mark(int kind, bool begin, hipStream_t stream) {
+  auto& ring = g_prof_events[kind];
+  if (begin) {
+    if (g_prof_used[kind] == ring.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      ring.emplace_back(a, b);
+    }
+    hipEventRecord(ring[g_prof_used[kind]].first, stream);
+  } else if (g_prof_used[kind] < ring.size()) {
+    hipEventRecord(ring[g_prof_used[kind]].second, stream);
+    ++g_prof_used[kind];
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // packed point-encoder weights (floats)
@@ -484,9 +507,10 @@ __global__ __launch_bounds__(256) void k_voxelize_pairs(const float* __restrict_
     }
     if (flat_ids) flat_ids[p] = (int64_t)(gx * nyz + gy * g.n_xyz[2] + gz);  // int32 arithmetic as the reference
     if (rel_xyz) {
-      rel_xyz[p * 3 + 0] = relative_coord(xn, gx, g.voxel_size);
-      rel_xyz[p * 3 + 1] = relative_coord(yn, gy, g.voxel_size);
-      rel_xyz[p * 3 + 2] = relative_coord(zn, gz, g.voxel_size);
+      // relative_xyz = (xyz_normalized - grid_id) * voxel_size (local_point_fusion.py:163-164)
+      rel_xyz[p * 3 + 0] = __fmul_rn(__fsub_rn(xn, (float)gx), g.voxel_size);
+      rel_xyz[p * 3 + 1] = __fmul_rn(__fsub_rn(yn, (float)gy), g.voxel_size);
+      rel_xyz[p * 3 + 2] = __fmul_rn(__fsub_rn(zn, (float)gz), g.voxel_size);
     }
   }
 }
@@ -528,6 +552,28 @@ const char* bnv_status_string(int s) {
 
 size_t bnv_pointnet_pack_floats(void) { return PN_TOTAL; }
 
+int bnv_profile_enable(int on) {
+  for (int k = 0; k < PROF_KINDS; ++k) g_prof_used[k] = 0;
+  g_prof_on = on != 0;
+  return BNV_OK;
+}
+
+int bnv_profile_read(double* total_ms, int64_t* launches) {
+  if (!total_ms || !launches) return BNV_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    double ms = 0.0;
+    for (size_t i = 0; i < g_prof_used[k]; ++i) {
+      float t = 0.f;
+      BNV_HIP_CHECK(hipEventSynchronize(g_prof_events[k][i].second));
+      BNV_HIP_CHECK(hipEventElapsedTime(&t, g_prof_events[k][i].first, g_prof_events[k][i].second));
+      ms += t;
+    }
+    total_ms[k] = ms;
+    launches[k] = (int64_t)g_prof_used[k];
+  }
+  return BNV_OK;
+}
+
 size_t bnv_encode_workspace_bytes(int64_t max_points, const int32_t n_xyz[3]) {
   return encode_ws_layout(max_points, n_xyz, nullptr, nullptr);
 }
@@ -539,19 +585,22 @@ int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream) {
 }
 
 int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
-                          const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, float* out_feats,
+                          const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
+                          float* out_feats,
                           int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                           int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
                           bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
-      n_points > (1 << 27))
+      n_points > (1 << 27) || ws_max_points < n_points)
     return BNV_ERR_INVALID_ARGUMENT;
   const bnv_grid_t g = *grid_host;
   if ((int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] >= (1LL << 31)) return BNV_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   EncodeWs ws;
-  const size_t need = encode_ws_layout(n_points, g.n_xyz, (char*)ws_ptr, &ws);
+  // the layout is a function of the workspace's capacity, not of this frame's point count, so
+  // the scratch the previous frame left clean stays where this frame expects it
+  const size_t need = encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws);
   if (need > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
   if (n_points == 0) return BNV_OK;
@@ -575,8 +624,11 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   const int n_tiles = ((n + 31) / 32) * 8;
   int grid_pn = g_num_cus;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
-  hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
-                     pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+  {
+    ProfScope prof(PROF_POINTNET, stream);
+    hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
+                       pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+  }
   BNV_LAUNCH_CHECK();
   // ordered compaction of the emitted voxels; the number of slots is only known on the device,
   // so the scan grids cover max_unique and blocks past n_unique exit at once

@@ -9,6 +9,7 @@ kernels of csrc/; this file only marshals torch tensors.  The fp32 checkpoint pa
 (``model.tiny_cuda=False``) is implemented; there is no CPU fallback.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -96,6 +97,7 @@ class LitFusionPointNet(nn.Module):
                              persistent=False)
         self._enc_ws = None
         self._enc_ws_key = None
+        self._enc_ws_points = 0
         self._grid_cache = {}
 
     # ---- nn.Module plumbing --------------------------------------------------------------------
@@ -127,23 +129,23 @@ class LitFusionPointNet(nn.Module):
                                 "(there is no CPU fallback)")
         return _lib.require_device(t.device.index or 0)
 
-    @staticmethod
-    def _ident(x):
-        if isinstance(x, torch.Tensor):
-            return ("t", x.data_ptr(), x._version, x.device)
-        return tuple(float(v) for v in x)
-
     def _grid(self, n_xyz, bound_min, bound_max, voxel_size):
-        """bnv_grid_t for these arguments; cached on tensor identity so that the per-frame call with
-        the volume's own (device) tensors costs no device->host reads."""
-        key = (self._ident(n_xyz), self._ident(bound_min), self._ident(bound_max), float(voxel_size),
-               self.min_pts_in_grid, self.shard)
-        hit = self._grid_cache.get(key)
-        if hit is None:
-            res = [int(v) for v in n_xyz]
-            hit = (make_grid(res, bound_min, bound_max, voxel_size, self.min_pts_in_grid, self.shard), res)
-            self._grid_cache = {key: hit}
-        return hit
+        """bnv_grid_t for these arguments.  Cached while the caller keeps passing the SAME tensor
+        objects (the volume's own attributes, unmodified), so the per-frame call costs no
+        device->host reads; anything else is re-read."""
+        args = (n_xyz, bound_min, bound_max)
+        c = self._grid_cache
+        if c and c["voxel"] == float(voxel_size) and c["extra"] == (self.min_pts_in_grid, self.shard) and all(
+                isinstance(a, torch.Tensor) and r() is a and a._version == v
+                for a, r, v in zip(args, c["refs"], c["versions"])):
+            return c["grid"], c["res"]
+        res = [int(v) for v in n_xyz]
+        grid = make_grid(res, bound_min, bound_max, voxel_size, self.min_pts_in_grid, self.shard)
+        if all(isinstance(a, torch.Tensor) for a in args):
+            self._grid_cache = {"voxel": float(voxel_size), "extra": (self.min_pts_in_grid, self.shard),
+                                "refs": [weakref.ref(a) for a in args], "versions": [a._version for a in args],
+                                "grid": grid, "res": res}
+        return grid, res
 
     # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
     def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
@@ -155,10 +157,11 @@ class LitFusionPointNet(nn.Module):
         grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
         nvox = res[0] * res[1] * res[2]
         n_arr = (C.c_int32 * 3)(*res)
-        need = int(lib.bnv_encode_workspace_bytes(n, n_arr))
         key = (tuple(res), dev)
-        if self._enc_ws is None or self._enc_ws_key != key or self._enc_ws.numel() < need:
-            self._enc_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)  # zero = clean
+        if self._enc_ws is None or self._enc_ws_key != key or self._enc_ws_points < n:
+            self._enc_ws_points = max(n, 1024) if self._enc_ws_key != key else max(n, 2 * self._enc_ws_points)
+            need = int(lib.bnv_encode_workspace_bytes(self._enc_ws_points, n_arr))
+            self._enc_ws = torch.zeros(need, dtype=torch.uint8, device=dev)   # zero-filled = clean
             self._enc_ws_key = key
         emit_all = 1 if return_dense else 0
         cap = min(8 * n, nvox) if return_dense else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
@@ -169,7 +172,8 @@ class LitFusionPointNet(nn.Module):
         grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
         counters = torch.zeros(8, dtype=torch.int32, device=dev)
         _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
-                                             _lib.ptr(self._enc_ws), self._enc_ws.numel(), _lib.ptr(feats),
+                                             _lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points,
+                                             _lib.ptr(feats),
                                              _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids), cap,
                                              emit_all, _lib.ptr(counters), _lib.stream_ptr()),
                    "bnv_encode_pointcloud")
@@ -209,8 +213,7 @@ class LitFusionPointNet(nn.Module):
         rel = torch.empty((8 * n, 3), dtype=torch.float32, device=xyz.device)
         _lib.check(lib.bnv_voxelize_pairs(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(gid), None, _lib.ptr(rel), None,
                                           _lib.stream_ptr()), "bnv_voxelize_pairs")
-        # the kernel returns rel / voxel (what forward(normalize=True) feeds the encoder)
-        return rel.reshape(1, 8, n, 3) * voxel_size, gid.reshape(1, 8, n, 3)
+        return rel.reshape(1, 8, n, 3), gid.reshape(1, 8, n, 3)
 
     # ---- integrate (local_point_fusion.py:647-673) ------------------------------------------------
     def _integrate(self, volume_object, fine_coords, fine_feats, fine_weights):

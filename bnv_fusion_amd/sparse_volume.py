@@ -316,6 +316,12 @@ class SparseVolume:
                    "bnv_decode_lattice")
         return out
 
+    def last_lattice_table_rows(self):
+        """Device int32 tensor [1]: corner voxels whose 27-entry SDF table the last decode_lattice
+        call evaluated (27 MLP evaluations each)."""
+        off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
+        return self._lattice_ws[off: off + 4].view(torch.int32)
+
     def meshlize(self, nerf, sdf_delta=None, path=None):
         """sparse_volume.py:697-766.  The SDF lattice is decoded on the GPU; the per-voxel marching
         cubes + trimesh assembly of the reference (skimage / trimesh) is outside this path

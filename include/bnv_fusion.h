@@ -85,9 +85,17 @@ int bnv_num_compute_units(void);
 const char* bnv_status_string(int status);
 int bnv_last_hip_error(void);
 
+/* Optional timing of the dominant kernels with HIP events recorded on their launch stream.
+ * kinds: 0 point-encoder MLP + scatter, 1 lattice-table SDF MLP, 2 decode_pts SDF MLP,
+ * 3 dense-decode SDF MLP.  bnv_profile_read synchronises the recorded events and returns the
+ * summed kernel time (ms) and launch count per kind since bnv_profile_enable(1). */
+int bnv_profile_enable(int on);
+int bnv_profile_read(double* total_ms_host /*[4]*/, int64_t* launches_host /*[4]*/);
+
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
-/* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points. */
+/* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points.  The scratch is
+ * laid out for the max_points it was sized for: pass that same value as ws_max_points. */
 size_t bnv_encode_workspace_bytes(int64_t max_points, const int32_t n_xyz[3]);
 /* Zero the scratch (once after allocation; encode leaves it clean for the next frame). */
 int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream);
@@ -106,14 +114,14 @@ size_t bnv_sdfmlp_pack_floats(void);
  * count < min_pts (the return_dense=True contract, :126-141). */
 int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
                           const float* pointnet_pack, void* ws, size_t ws_bytes,
-                          float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids,
+                          int64_t ws_max_points, float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids,
                           int64_t* out_grid_ids, int64_t out_capacity, int emit_all,
                           bnv_encode_counters_t* counters, bnv_stream_t stream);
 
 /* get_relative_xyz + flatten for every pair, pair index p = corner * n_points + i
  * (local_point_fusion.py:106-117, voxel_utils.py:62-65).  No bounds mask (the caller compacts).
- * grid_ids [8n,3] i32, flat_ids [8n] i64, rel_xyz [8n,3] f32 (already divided by voxel_size as
- * forward(normalize=True) does, :58-59).  Any output may be NULL. */
+ * grid_ids [8n,3] i32, flat_ids [8n] i64, rel_xyz [8n,3] f32 = (xn - grid_id) * voxel_size.
+ * Any output may be NULL. */
 int bnv_voxelize_pairs(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
                        int32_t* grid_ids, int64_t* flat_ids, float* rel_xyz, uint8_t* bound_mask,
                        bnv_stream_t stream);
@@ -164,6 +172,9 @@ int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, co
                    float* out_sdf, bnv_stream_t stream);
 
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
+/* Byte offset, inside that workspace, of the int32 device counter holding the number of corner
+ * voxels whose 27-entry table the last bnv_decode_lattice evaluated (for FLOP accounting). */
+size_t bnv_decode_lattice_count_offset(int64_t row_capacity);
 /* The same decode for the 3x3x3 lattice {-0.5,0,0.5}^3 around n integer voxel origins
  * (SparseVolume.meshlize's decode_pts call, sparse_volume.py:717-738): out [n,27] f32.
  * Evaluates the MLP once per (corner voxel, local offset) instead of 8x per lattice point. */

@@ -33,7 +33,7 @@ def test_library_exports_every_symbol():
     # without bnv_init every compute entry refuses to run instead of silently doing nothing
     import ctypes as C
     g = _lib.Grid()
-    rc = lib.bnv_encode_pointcloud(C.c_void_p(8), 1, C.byref(g), C.c_void_p(8), C.c_void_p(8), 1 << 30,
+    rc = lib.bnv_encode_pointcloud(C.c_void_p(8), 1, C.byref(g), C.c_void_p(8), C.c_void_p(8), 1 << 30, 1,
                                    None, None, None, None, 0, 0, C.c_void_p(8), None)
     assert rc != 0
 

@@ -110,8 +110,7 @@ def test_voxelize_pairs_bit_exact_vs_oracle(bnv, model, orc):
     rel, gid = model.get_relative_xyz(xyz.to(DEV), vol.min_coords, vol.voxel_size)
     rel_o, gid_o = orc.get_relative_xyz(xyz, vol.min_coords.cpu(), vol.voxel_size)
     assert torch.equal(gid.cpu(), gid_o)
-    # the kernel keeps rel / voxel (the encoder input); compare that quantity exactly
-    assert torch.equal((rel / vol.voxel_size).cpu(), (rel_o / vol.voxel_size))
+    assert torch.equal(rel.cpu(), rel_o)      # same two fp32 roundings as the reference
 
 
 # ---------------------------------------------------------------------------------------------
@@ -315,11 +314,11 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
     vol = nm.volume
     # idempotence (SURVEY 8c i): fusing the same frame k times keeps features, weights = k*min(c/32,1)
     f, c, ids, g, n = _encode(model, vol, frames[0])
-    for _ in range(9):
+    for _ in range(32):                   # count >= 8 -> weight 32 * min(c/32, 1) >= 8: every voxel live
         model._integrate(vol, g, f, c)
     fq, wq, _ = vol.query(g)
-    assert (fq - f).abs().max() < 5e-6
-    assert torch.allclose(wq[:, 0], 9 * torch.clamp(c[:, 0].float() / 32, max=1.0), atol=1e-5)
+    assert (fq - f).abs().max() < 2e-5
+    assert torch.allclose(wq[:, 0], 32 * torch.clamp(c[:, 0].float() / 32, max=1.0), atol=1e-4)
     # lattice decode == general 8-corner decode on the same lattice points (two HIP paths)
     sub = g[:: max(1, len(g) // 4000)]
     lat = vol.decode_lattice(sub, model.nerf, query_tensor=False)
