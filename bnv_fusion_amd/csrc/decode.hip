@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            int64_t row_limit, float min_pts,
                                                            int32_t* __restrict__ nbr_rows,
                                                            int32_t* __restrict__ stamp, int32_t epoch,
-                                                           int32_t* __restrict__ list, int32_t* __restrict__ n_list) {
+                                                           int32_t* __restrict__ list, int32_t* __restrict__ n_list,
+                                                           const uint8_t* __restrict__ row_skip) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
@@ -383,7 +384,9 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   if (row >= 0) usable = weights[row] >= min_pts;
   // rows below min_pts can only ever appear under a false mask: mark them as unusable corners
   nbr_rows[t] = usable ? row : -1;
-  if (usable && atomicExch(&stamp[row], epoch) != epoch) list[atomicAdd(n_list, 1)] = row;
+  // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
+  if (usable && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
+    list[atomicAdd(n_list, 1)] = row;
 }
 
 __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
@@ -535,41 +538,84 @@ size_t bnv_decode_lattice_count_offset(int64_t row_capacity) {
   return (size_t)((char*)ws.n_list - (char*)256);
 }
 
-int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                       const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
-                       int64_t n, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, int32_t epoch,
-                       float* out_sdf, bnv_stream_t stream_) {
-  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || n < 0 || epoch == 0)
-    return BNV_ERR_INVALID_ARGUMENT;
-  if (n == 0) return BNV_OK;
-  if (!origins || !out_sdf || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+size_t bnv_decode_lattice_table_offset(int64_t row_capacity) {
+  LatticeWs ws;
+  lattice_ws_layout(1, row_capacity, (char*)256, &ws);
+  return (size_t)((char*)ws.table - (char*)256);
+}
+
+size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity) {
+  LatticeWs ws;
+  lattice_ws_layout(n_voxels, row_capacity, (char*)256, &ws);
+  return (size_t)((char*)ws.list - (char*)256);
+}
+
+int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights, int64_t row_limit,
+                          const int64_t* origins, int64_t n, const uint8_t* row_skip, int build_list, void* ws_ptr,
+                          size_t ws_bytes, int32_t epoch, bnv_stream_t stream_) {
+  if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (!ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 4, stream));
-  const unsigned nb = (unsigned)((n * 27 + 255) / 256);
-  hipLaunchKernelGGL(k_lattice_neighbors, dim3(nb), dim3(256), 0, stream, *vol, origins, n, weights, row_limit,
-                     (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch, ws.list, ws.n_list);
+  if (build_list) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 4, stream));
+  if (n == 0) return BNV_OK;
+  if (!origins) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
+                     n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
+                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip);
   BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                      const float* sdfmlp_pack, int64_t n_voxels, void* ws_ptr, size_t ws_bytes,
+                      bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  LatticeWs ws;
+  if (lattice_ws_layout(n_voxels, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes)
+    return BNV_ERR_WORKSPACE_TOO_SMALL;
   DecodeArgs a = {};
   a.vol = *vol;
   a.grid = *grid;
   a.features = features;
-  a.weights = weights;
-  a.row_limit = row_limit;
   a.pack = sdfmlp_pack;
   a.list = ws.list;
   a.n_list = ws.n_list;
   a.table = ws.table;
-  const int rc = launch_decode(MODE_LATTICE, a, (ws.list_capacity * 27 + DM - 1) / DM, stream);
-  if (rc != BNV_OK) return rc;
+  return launch_decode(MODE_LATTICE, a, (ws.list_capacity * 27 + DM - 1) / DM, (hipStream_t)stream);
+}
+
+int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
+                      const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, float* out_sdf,
+                      bnv_stream_t stream) {
+  if (!vol_ok_ro(vol) || !grid || n < 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!origins || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
+  LatticeWs ws;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   bnv_sdf_delta_t d = {};
   if (delta) d = *delta;
-  hipLaunchKernelGGL(k_lattice_blend, dim3(nb), dim3(256), 0, stream, ws.nbr_rows, n, ws.table, *grid, origins, d,
-                     out_sdf);
+  hipLaunchKernelGGL(k_lattice_blend, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                       const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
+                       int64_t n, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, int32_t epoch,
+                       float* out_sdf, bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, nullptr, 1, ws_ptr, ws_bytes, epoch,
+                                 stream);
+  if (rc != BNV_OK) return rc;
+  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, ws_ptr, ws_bytes, stream);
+  if (rc != BNV_OK) return rc;
+  return bnv_lattice_blend(vol, grid, origins, n, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
 
 }  // extern "C"

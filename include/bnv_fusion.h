@@ -184,6 +184,26 @@ int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host
                        const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
                        float* out_sdf, bnv_stream_t stream);
 
+/* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
+ * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
+ *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
+ *              min_pts); with build_list, appends each distinct usable row (not flagged in
+ *              row_skip) to the work list;
+ *   table:     table[row][27] = SDF-MLP(enc(l), features[row]) * voxel for every listed row;
+ *   blend:     out[n,27] from the neighbour rows and the table. */
+int bnv_lattice_neighbors(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* weights,
+                          int64_t row_limit, const int64_t* origins, int64_t n, const uint8_t* row_skip,
+                          int build_list, void* ws, size_t ws_bytes, int32_t epoch, bnv_stream_t stream);
+int bnv_lattice_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                      const float* sdfmlp_pack, int64_t n_voxels, void* ws, size_t ws_bytes,
+                      bnv_stream_t stream);
+int bnv_lattice_blend(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const int64_t* origins,
+                      int64_t n, const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, float* out_sdf,
+                      bnv_stream_t stream);
+/* Byte offsets of the table [row_capacity,27] f32 and of the row work list inside the workspace. */
+size_t bnv_decode_lattice_table_offset(int64_t row_capacity);
+size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity);
+
 /* LitFusionPointNet.decode_feature_grid_w_pts, global_coords=False / interpolate_decode=True
  * (local_point_fusion.py:265-329): dense feat_grid [8,X,Y,Z], pts_weight [X,Y,Z];
  * voxel_coords [n,3] f32 -> out [n]. */

@@ -1,0 +1,140 @@
+"""World-size-2 gloo test (CPU) of the sharded frame logic in bnv_fusion_amd/distributed.py:
+ownership partition, the two variable-size all-gathers and the halo assembly.  The compute of each
+shard is done by an oracle-backed backend (test infrastructure); the union of the shards' SDF
+lattices must equal the single-process oracle decode of the same frames."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, WEIGHTS_FP32
+
+_OFF27 = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
+_CEIL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1))
+
+
+class OracleShardBackend:
+    def __init__(self, dims, voxel, rank, world):
+        from oracle import bnv_oracle as orc
+        from bnv_fusion_amd.distributed import voxel_owner
+        self.orc, self.owner = orc, voxel_owner
+        self.sd = orc.load_weights(WEIGHTS_FP32)
+        self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+        self.rank, self.world, self.voxel = rank, world, voxel
+
+    def encode_integrate(self, frame):
+        o, v = self.orc, self.vol
+        f, c, ids, g, n = o.encode_pointcloud(self.sd, frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
+                                              v.voxel_size)
+        own = torch.from_numpy(self.owner(g.numpy(), self.world) == self.rank)
+        o.integrate(v, g[own], f[own], c[own])
+        return g[own]
+
+    def tables_for(self, touched):
+        o, v = self.orc, self.vol
+        nb = np.unique((touched.numpy()[:, None, :] + _OFF27[None]).reshape(-1, 3), axis=0)
+        keep = [k for k in map(tuple, nb.tolist()) if k in v._map and float(v._w[v._map[k]]) >= v.min_pts_in_grid]
+        if not keep:
+            return torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0), torch.zeros((0, 27))
+        rows = [v._map[k] for k in keep]
+        feats = torch.stack([v._feats[r] for r in rows])                       # [m, 8]
+        loc = torch.tensor(_OFF27, dtype=torch.float32) * 0.5                  # l index = (lx+1)*9+(ly+1)*3+(lz+1)
+        x = torch.cat([o.xyz_encoding(loc)[None].expand(len(rows), 27, 9), feats[:, None, :].expand(-1, 27, 8)], -1)
+        table = o.geo_forward(self.sd, x)[..., 0] * self.voxel
+        w = torch.stack([v._w[r].reshape(()) for r in rows])
+        return torch.tensor(keep, dtype=torch.int64), w, table
+
+    def install_and_blend(self, owned, rec_c, rec_w, rec_t):
+        halo = {tuple(k): i for i, k in enumerate(rec_c.tolist())}
+        out = torch.full((len(owned), 27), float(np.float32(self.voxel)))
+        for b, o3 in enumerate(owned.tolist()):
+            for p, d in enumerate(_OFF27.tolist()):
+                acc, ok, ws = 0.0, True, []
+                terms = []
+                for cx in _CEIL:
+                    key, l, w = [], 0, 1.0
+                    for a in range(3):
+                        if d[a] == 0:
+                            nb_a, loc2 = 0, 0
+                        elif cx[a]:
+                            nb_a, loc2 = (d[a] + 1) // 2, -1
+                        else:
+                            nb_a, loc2 = (d[a] - 1) // 2, 1
+                        if d[a] != 0:
+                            w *= 0.5
+                        key.append(o3[a] + nb_a)
+                        l = l * 3 + (loc2 + 1)
+                    i = halo.get(tuple(key))
+                    if i is None:
+                        ok = False
+                        break
+                    terms.append((float(rec_t[i, l]), w))
+                if ok:
+                    norm = sum(w for _, w in terms)
+                    out[b, p] = float(sum(np.float32(t) * np.float32(w / norm) for t, w in terms))
+        return out
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, frames, dims, voxel, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bnv_fusion_amd.distributed import ShardedNeuralMap, all_gather_var
+    nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world))
+    for fr in frames:
+        owned, sdf = nm.fuse_and_decode({"input_pts": torch.from_numpy(fr)})
+    allc = all_gather_var(owned)
+    alls = all_gather_var(sdf)
+    if rank == 0:
+        ret["coords"], ret["sdf"], ret["n0"] = allc.numpy(), alls.numpy(), len(owned)
+    dist.destroy_process_group()
+
+
+def test_two_shards_equal_single_process():
+    from oracle import bnv_oracle as orc
+    from bnv_fusion_amd.distributed import voxel_owner
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    frames = list(z["frames"])      # 12 frames x 6000 points: weights reach min_pts
+    dims, voxel = z["dims"], float(z["voxel_size"])
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), frames, dims, voxel, ret), nprocs=2, join=True)
+        coords, sdf, n0 = ret["coords"], ret["sdf"], ret["n0"]
+    # single-process reference
+    sd = orc.load_weights(WEIGHTS_FP32)
+    vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    for fr in frames:
+        f, c, _, g, _ = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
+        orc.integrate(vol, g, f, c)
+    ref = vol.decode_pts(orc.lattice_coords(g.numpy()), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+    # the shards partition the touched set exactly, by the ownership hash
+    own = voxel_owner(coords, 2)
+    assert np.all(own[:n0] == 0) and np.all(own[n0:] == 1) and 0 < n0 < len(coords)
+    order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+    assert np.array_equal(coords[order], g.numpy())
+    assert np.abs(sdf[order] - ref.numpy()).max() < 2e-6
+    assert np.array_equal(sdf[order] == np.float32(voxel), ref.numpy() == np.float32(voxel))
+    assert (ref != voxel).float().mean() > 0.05          # the decode mask is live in this test
+
+
+def test_owner_hash_is_balanced_and_blocked():
+    from bnv_fusion_amd.distributed import voxel_owner
+    g = np.stack(np.meshgrid(np.arange(64), np.arange(64), np.arange(64), indexing="ij"), -1).reshape(-1, 3)
+    o = voxel_owner(g, 8)
+    assert np.array_equal(voxel_owner(g, 1), np.zeros(len(g), dtype=np.int64))
+    cnt = np.bincount(o, minlength=8)
+    assert cnt.min() > 0.5 * cnt.mean() and cnt.max() < 1.6 * cnt.mean()
+    blk = (g >> 3)
+    key = (blk[:, 0] * 8 + blk[:, 1]) * 8 + blk[:, 2]
+    for k in np.unique(key)[:20]:
+        assert len(np.unique(o[key == k])) == 1           # whole 8^3 blocks share an owner
