@@ -26,7 +26,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 2 * (6 * 128 + 128 * 128 + 128 * 128 + 128 * 8)          # 69,120  point encoder
 FLOP_PER_EVAL = 2 * (17 * 256 + 3 * 256 * 256 + 256)                      # 402,432 SDF MLP
-PEAK_F32_MFMA_TFLOPS = 157.3                                              # MI355X_MICROARCH.md
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md: f32-in / f16-in
+MODE_NAME = {0: "fp32_exact", 1: "split_f16"}
+DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
+         1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate"}
 
 
 def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
@@ -83,6 +86,9 @@ def main():
                     help="frames fused (untimed setup) before warm-up so that voxel weights reach "
                          "min_pts_in_grid and the decode mask is live (SURVEY.md section 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1],
+                    help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
+    ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,65 +122,113 @@ def main():
 
     for t in range(args.preroll):                       # setup: make the decode mask live
         nm.integrate(frames[t])
-    for t in range(args.preroll, args.preroll + args.warmup):
-        nm.fuse_and_decode(frames[t])
 
     lib = _lib.load()
-    lib.bnv_profile_enable(1)
-    table_rows = []
-    n_vox = []
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    live = None
-    for t in range(args.preroll + args.warmup, n_frames):
-        coords, sdf = nm.fuse_and_decode(frames[t])
-        table_rows.append(nm.volume.last_lattice_table_rows().clone())   # async 4-byte device copy
-        n_vox.append(0 if coords is None else int(coords.shape[0]))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    prof_ms = (C.c_double * 4)()
-    prof_n = (C.c_int64 * 4)()
-    lib.bnv_profile_read(prof_ms, prof_n)
-    lib.bnv_profile_enable(0)
-    live = float((sdf != voxel).float().mean()) if sdf is not None and sdf.numel() else 0.0
-    rows = torch.stack(table_rows).cpu().numpy().reshape(-1)
+
+    def timed(mode, first, steps, warm):
+        """`warm` untimed frames, then times exactly `steps` frames from index `first`, in MLP mode `mode`."""
+        bnv.set_mlp_mode(mode)
+        for t in range(first - warm, first):
+            nm.fuse_and_decode(frames[t])
+        lib.bnv_profile_enable(1)
+        table_rows, n_vox = [], []
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(first, first + steps):
+            coords, sdf = nm.fuse_and_decode(frames[t])
+            table_rows.append(nm.volume.last_lattice_table_rows().clone())   # async 4-byte device copy
+            n_vox.append(0 if coords is None else int(coords.shape[0]))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        prof_ms = (C.c_double * 4)()
+        prof_n = (C.c_int64 * 4)()
+        lib.bnv_profile_read(prof_ms, prof_n)
+        lib.bnv_profile_enable(0)
+        rows = torch.stack(table_rows).cpu().numpy().reshape(-1)
+        live = float((sdf != voxel).float().mean()) if sdf is not None and sdf.numel() else 0.0
+        dec_ms = prof_ms[1] / max(prof_n[1], 1)
+        enc_ms = prof_ms[0] / max(prof_n[0], 1)
+        dec_flop = float(rows.mean()) * 27 * FLOP_PER_EVAL
+        enc_flop = 8.0 * n_points * FLOP_PER_PAIR
+        return {"elapsed": elapsed, "steps": steps, "fps": steps / elapsed, "rows": float(rows.mean()),
+                "n_vox": float(np.mean(n_vox)), "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
+                "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
+                "enc_tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0, "dec_flop": dec_flop,
+                "coords": coords, "sdf": sdf}
+
+    first = args.preroll + args.warmup
+    main_run = timed(args.mlp_mode, first, args.steps, args.warmup)
+    alt = None
+    if not args.no_alt_mode and world == 1:
+        # the other arithmetic mode on a few of the same frames (volume state differs only by those fusions)
+        alt = timed(1 - args.mlp_mode, first, min(args.steps, 8), 1)
+        bnv.set_mlp_mode(args.mlp_mode)
+    elapsed = main_run["elapsed"]
+
+    # parity spot check of the timed configuration against the oracle (40 voxels of the last frame)
+    parity = None
+    if world == 1 and main_run["coords"] is not None:
+        from oracle import bnv_oracle as orc           # checker only
+        sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+        g = main_run["coords"]
+        pick = g[torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)].cpu()
+        off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
+        nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
+        fo, wo, _ = nm.volume.query(nbr.to(dev))
+        ovol = orc.OracleSparseVolume(8, voxel, np.array([dims] * 3), 8)
+        present = wo[:, 0].cpu() > 0
+        ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
+        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+        got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
+        parity = {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
+                  "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}
 
     if rank == 0:
         fps = args.steps / elapsed
-        # dominant kernel: the lattice-table SDF MLP (k_decode<LATTICE>), exact fp32 on MFMA
-        dec_ms = prof_ms[1] / max(prof_n[1], 1)
-        dec_flop = float(rows.mean()) * 27 * FLOP_PER_EVAL
-        enc_ms = prof_ms[0] / max(prof_n[0], 1)
-        enc_flop = 8.0 * n_points * FLOP_PER_PAIR
-        achieved = dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0
+        m = args.mlp_mode
+        peak = PEAK_TFLOPS[m]
         out = {
             "metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE[m], "data": "synthetic",
             "config": {"workload": f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, "
                                    f"voxel {voxel}, fp32 pointnet.ckpt weights; step = encode_pointcloud + "
                                    "_integrate + decode of the 3x3x3 lattice of every touched voxel",
                        "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
-                       "voxels_per_frame": float(np.mean(n_vox)), "sdf_values_per_frame": 27.0 * float(np.mean(n_vox)),
-                       "decode_live_fraction": live,
+                       "mlp_mode": MODE_NAME[m],
+                       "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
+                       "decode_live_fraction": main_run["live"],
                        "parallelism": "1 GPU" if world == 1 else f"spatial-hash voxel sharding x{world} + RCCL all-gather"},
-            "roofline": {"bound": "mfma", "kernel": "k_decode<LATTICE> (SDF MLP 17-256x4-1, v_mfma_f32_32x32x2_f32)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "avg_kernel_ms": dec_ms, "flop_per_launch": dec_flop,
-                         "mlp_evals_per_launch": float(rows.mean()) * 27},
-            "kernels": {"pointnet_scatter": {"avg_ms": enc_ms, "tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0,
-                                             "frac_of_f32_mfma_peak": (enc_flop / (enc_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if enc_ms else 0}},
+            # dominant kernel: the lattice-table SDF MLP.  achieved = algorithmic FLOPs (402,432 per MLP
+            # evaluation x evaluations per launch; the split mode issues 3 MFMA products per algorithmic
+            # product, which are NOT counted) / mean kernel time from HIP events on the launch stream
+            "roofline": {"bound": "mfma", "kernel": f"k_decode<LATTICE,{MODE_NAME[m]}> (SDF MLP 17-256x4-1)",
+                         "achieved": main_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
+                         "frac": main_run["dec_tflops"] / peak, "traffic": None,
+                         "avg_kernel_ms": main_run["dec_ms"], "flop_per_launch": main_run["dec_flop"],
+                         "mlp_evals_per_launch": main_run["rows"] * 27,
+                         "mfma_issue_frac": main_run["dec_tflops"] * (3 if m == 1 else 1) / peak},
+            "kernels": {"pointnet_scatter": {"avg_ms": main_run["enc_ms"], "tflops": main_run["enc_tflops"],
+                                             "frac_of_peak": main_run["enc_tflops"] / peak}},
+            "parity": parity,
         }
+        if alt is not None:
+            am = 1 - m
+            out["other_mlp_mode"] = {"mlp_mode": MODE_NAME[am], "dtype": DTYPE[am], "value": alt["fps"],
+                                     "unit": "frames/s", "steps": alt["steps"],
+                                     "ms_per_step": 1e3 * alt["elapsed"] / alt["steps"],
+                                     "decode_kernel_ms": alt["dec_ms"], "decode_tflops": alt["dec_tflops"],
+                                     "decode_frac_of_peak": alt["dec_tflops"] / PEAK_TFLOPS[am],
+                                     "pointnet_kernel_ms": alt["enc_ms"], "pointnet_tflops": alt["enc_tflops"]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_host, args.grid)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]

@@ -4,3 +4,18 @@ See DESIGN.md (layout, kernels, rooflines) and INTEGRATION.md (how run_e2e.py pi
 from .fusion import LitFusionPointNet, LocalNeRFModel, get_neighbors, load_pretrained  # noqa: F401
 from .sparse_volume import SparseVolume, get_world_range  # noqa: F401
 from .neural_map import NeuralMap  # noqa: F401
+
+
+MLP_MODE_FP32_EXACT = 0     # v_mfma_f32_32x32x2_f32
+MLP_MODE_SPLIT_F16 = 1      # fp32 operands split into f16 hi + lo, 3 products on the f16 MFMA (default)
+
+
+def set_mlp_mode(mode):
+    """Selects the arithmetic of the two MLP kernels (see include/bnv_fusion.h: bnv_set_mlp_mode)."""
+    from . import _lib
+    _lib.check(_lib.load().bnv_set_mlp_mode(int(mode)), "bnv_set_mlp_mode")
+
+
+def get_mlp_mode():
+    from . import _lib
+    return int(_lib.load().bnv_get_mlp_mode())

@@ -30,6 +30,14 @@ constexpr int SD_B0 = SD_W3 + 65536;          // [256] x 4
 constexpr int SD_WA = SD_B0 + 4 * 256;        // fc_alpha weight [256]
 constexpr int SD_BA = SD_WA + 256;            // fc_alpha bias, padded to 4
 constexpr int SD_TOTAL = SD_BA + 4;
+// split-operand variant, appended to the same pack (units: 16-bit halves from float offset SD_TOTAL)
+constexpr int SH_W0 = 0;                          // [8 w][2 ks][2 hi/lo][64 lane][8]
+constexpr int SH_W1 = SH_W0 + 8 * 2 * 2 * 64 * 8; // [8 w][16 ks][2 hi/lo][64 lane][8]
+constexpr int SH_W2 = SH_W1 + 8 * 16 * 2 * 64 * 8;
+constexpr int SH_W3 = SH_W2 + 8 * 16 * 2 * 64 * 8;
+constexpr int SH_TOTAL = SH_W3 + 8 * 16 * 2 * 64 * 8;   // 409,600 halves
+constexpr int SD_PACK_FLOATS = SD_TOTAL + SH_TOTAL / 2;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // LDS (floats)
 constexpr int L_HL = 0;                       // [32 kb][2 h][128 j][4]
@@ -170,6 +178,129 @@ __device__ __forceinline__ void stage_input(float* __restrict__ hl, int j, const
   *(f32x4*)&hl[((2 * 2 + 1) * DM + j) * 4] = v5;
 }
 
+
+// ---- split-operand MLP core: x = hi + lo (f16), a.b ~ ah.bh + ah.bl + al.bh on the f16 MFMA ----
+// LDS: HH[ks][h][j][8 halves] (hi) at L_HL, HLo (lo) 64 KB behind it; slot jj of lane half h in
+// K-step ks is feature 16 ks + 8 (jj >> 2) + 4 h + (jj & 3), which makes D registers 8 ksl .. 8 ksl+7
+// of wave w exactly the 8 slots of K-step 2 w + ksl.
+constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
+
+template <int NKS>
+__device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                                            const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
+                                            int j, int h) {
+  const f32x16 b0 = frag256(bias, w, h);
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
+  const _Float16* wl = wp + (size_t)w * NKS * 2 * 64 * 8 + lane * 8;
+  const float* hh = lds + L_HL + (h * DM + j) * 4;
+  const float* hl = lds + L_HLO + (h * DM + j) * 4;
+#pragma unroll 2
+  for (int ks = 0; ks < NKS; ++ks) {
+    const half8 ah = *(const half8*)(wl + (ks * 2) * 64 * 8);
+    const half8 al = *(const half8*)(wl + (ks * 2 + 1) * 64 * 8);
+    half8 bh[4], bl[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      bh[pt] = *(const half8*)(hh + (ks * 2 * DM + pt * 32) * 4);
+      bl[pt] = *(const half8*)(hl + (ks * 2 * DM + pt * 32) * 4);
+    }
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt], acc[pt], 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x16 (&acc)[4], int w, int j, int h) {
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = fmaxf(acc[pt][8 * ksl + e], 0.f);
+        const _Float16 t = (_Float16)x;
+        hi[e] = t;
+        lo[e] = (_Float16)(x - (float)t);
+      }
+      const int o = (((2 * w + ksl) * 2 + h) * DM + pt * 32 + j) * 4;
+      *(half8*)&lds[L_HL + o] = hi;
+      *(half8*)&lds[L_HLO + o] = lo;
+    }
+  }
+}
+
+__device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const float* __restrict__ pack) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
+  f32x16 acc[4];
+  mlp_layer_h<2>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu_h(lds, acc, w, j, h);
+  __syncthreads();
+  mlp_layer_h<16>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu_h(lds, acc, w, j, h);
+  __syncthreads();
+  mlp_layer_h<16>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+  __syncthreads();
+  store_relu_h(lds, acc, w, j, h);
+  __syncthreads();
+  mlp_layer_h<16>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+  const f32x16 wa = frag256(pack + SD_WA, w, h);
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], fmaxf(acc[pt][r], 0.f), s);
+    lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < DM) {
+    float s = pack[SD_BA];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s += lds[L_PART + p * DM + threadIdx.x];
+    lds[L_ALPHA + threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+
+// inputs of evaluation j in the split layout: features 0..16 (+15 zero) over K-steps 0, 1
+__device__ __forceinline__ void stage_input_h(float* __restrict__ lds, int j, const float (&loc)[3],
+                                              const float (&feat)[8]) {
+  float in[32];
+#pragma unroll
+  for (int f = 0; f < 32; ++f) in[f] = 0.f;
+  in[0] = loc[0]; in[1] = loc[1]; in[2] = loc[2];
+  in[3] = sinf(loc[0]); in[4] = sinf(loc[1]); in[5] = sinf(loc[2]);
+  in[6] = cosf(loc[0]); in[7] = cosf(loc[1]); in[8] = cosf(loc[2]);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) in[9 + f] = feat[f];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      half8 hi, lo;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
+        const _Float16 t = (_Float16)x;
+        hi[jj] = t;
+        lo[jj] = (_Float16)(x - (float)t);
+      }
+      const int o = ((ks * 2 + hh) * DM + j) * 4;
+      *(half8*)&lds[L_HL + o] = hi;
+      *(half8*)&lds[L_HLO + o] = lo;
+    }
+  }
+}
+
 // F.grid_sample(mode="nearest", padding_mode="zeros", align_corners=True) of the TSDF prior at a
 // corner given in voxel units (sparse_volume.py:820-829): coordinate a -> index along dims[a].
 __device__ __forceinline__ float sample_delta(const bnv_sdf_delta_t& d, const bnv_grid_t& g, const float (&c)[3]) {
@@ -186,7 +317,7 @@ __device__ __forceinline__ float sample_delta(const bnv_sdf_delta_t& d, const bn
   return d.data[((size_t)idx[0] * d.dims[1] + idx[1]) * d.dims[2] + idx[2]];
 }
 
-template <int MODE>
+template <int MODE, int PREC>
 __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hl = lds + L_HL;
@@ -269,14 +400,16 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
           }
         }
       }
-      stage_input(hl, j, loc, feat);
+      if constexpr (PREC == 1) stage_input_h(lds, j, loc, feat);
+      else stage_input(hl, j, loc, feat);
       lds[L_WTRI + j] = wtri;
       lds[L_WVOL + j] = wvol;
       lds[L_DELTA + j] = dlt;
     }
     __syncthreads();
     // ---------------- MLP -----------------------------------------------------------------
-    sdf_mlp_tile(lds, A.pack);
+    if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
+    else sdf_mlp_tile(lds, A.pack);
     // ---------------- back end ------------------------------------------------------------
     if constexpr (MODE == MODE_LATTICE) {
       if (threadIdx.x < DM) {
@@ -450,12 +583,18 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   if (grid < 1) grid = 1;
   ProfScope prof(mode == MODE_PTS ? PROF_DECODE_PTS : mode == MODE_LATTICE ? PROF_DECODE_LATTICE : PROF_DECODE_DENSE,
                  stream);
-  if (mode == MODE_PTS)
-    hipLaunchKernelGGL(k_decode<MODE_PTS>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
-  else if (mode == MODE_LATTICE)
-    hipLaunchKernelGGL(k_decode<MODE_LATTICE>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
-  else
-    hipLaunchKernelGGL(k_decode<MODE_DENSE>, dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args);
+#define BNV_LAUNCH_DECODE(M, P) \
+  hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args)
+  if (g_mlp_mode == 1) {
+    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 1);
+    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
+    else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
+  } else {
+    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 0);
+    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 0);
+    else BNV_LAUNCH_DECODE(MODE_DENSE, 0);
+  }
+#undef BNV_LAUNCH_DECODE
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -472,16 +611,19 @@ using namespace bnv;
 extern "C" {
 
 int bnv_decode_init() {
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_PTS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_LATTICE>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<MODE_DENSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L_TOTAL * 4));
+#define BNV_OPT_IN(M, P) \
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4))
+  BNV_OPT_IN(MODE_PTS, 0);
+  BNV_OPT_IN(MODE_LATTICE, 0);
+  BNV_OPT_IN(MODE_DENSE, 0);
+  BNV_OPT_IN(MODE_PTS, 1);
+  BNV_OPT_IN(MODE_LATTICE, 1);
+  BNV_OPT_IN(MODE_DENSE, 1);
+#undef BNV_OPT_IN
   return BNV_OK;
 }
 
-size_t bnv_sdfmlp_pack_floats(void) { return SD_TOTAL; }
+size_t bnv_sdfmlp_pack_floats(void) { return SD_PACK_FLOATS; }
 
 int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
                    int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,

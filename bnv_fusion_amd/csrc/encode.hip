@@ -24,6 +24,7 @@ namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
+int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo on the f16 MFMA
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
 bool g_prof_on = false;
@@ -57,6 +58,15 @@ constexpr int PN_B2 = PN_B1 + 128;
 constexpr int PN_B3 = PN_B2 + 128;
 constexpr int PN_B4 = PN_B3 + 128;              // [8]
 constexpr int PN_TOTAL = PN_B4 + 8;             // 34,952 floats = 139,808 B of LDS
+
+// split-operand variant (appended to the same pack, units: 16-bit halves from float offset PN_TOTAL)
+constexpr int PH_W1 = 0;                        // [4 mb][2 hi/lo][64 lane][8]
+constexpr int PH_W2 = PH_W1 + 4 * 2 * 64 * 8;   // [4 mb][4 nb][2 ksl][2 hi/lo][64 lane][8]
+constexpr int PH_W3 = PH_W2 + 4 * 4 * 2 * 2 * 64 * 8;
+constexpr int PH_W4 = PH_W3 + 4 * 4 * 2 * 2 * 64 * 8;   // [4 nb][2 ksl][2 hi/lo][2 h][8 n][8]
+constexpr int PH_TOTAL = PH_W4 + 4 * 2 * 2 * 2 * 8 * 8; // 71,680 halves = 143,360 B
+constexpr int PN_PACK_FLOATS = PN_TOTAL + PH_TOTAL / 2;
+constexpr int PH_LDS_BYTES = PH_TOTAL * 2 + (128 * 3 + 8) * 4;  // halves + fp32 biases = 144,928 B
 
 constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exact integers
 
@@ -405,6 +415,187 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_pointnet_scatter_h: the same network with every fp32 operand split into f16 hi + lo
+// (x = hi + lo to ~22 bits; f16 subnormals are kept by the MFMA) and a.b ~ ah.bh + ah.bl + al.bh
+// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-class results at 16/3 x the fp32 MFMA rate.
+// K-step (nb, ksl) consumes D registers 8*ksl .. 8*ksl+7 of input block nb: operand slot jj of lane
+// half h is feature nb*32 + 16*ksl + 8*(jj>>2) + 4*h + (jj&3).
+// ------------------------------------------------------------------------------------------
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, half8* hi, half8* lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float x = v[base + e];
+    if (relu) x = fmaxf(x, 0.f);
+    const _Float16 h = (_Float16)x;
+    (*hi)[e] = h;
+    (*lo)[e] = (_Float16)(x - (float)h);
+  }
+}
+
+__device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                                           const half8 (&inh)[8], const half8 (&inl)[8], f32x16 (&out)[4],
+                                           int lane, int h) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) out[mb] = bias_init(bias, mb, h);
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      half8 ah[4], al[4];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const _Float16* w = wp + ((((mb * 4 + nb) * 2 + ksl) * 2) * 64 + lane) * 8;
+        ah[mb] = *(const half8*)w;
+        al[mb] = *(const half8*)(w + 64 * 8);
+      }
+      const half8 bh = inh[nb * 2 + ksl], bl = inl[nb * 2 + ksl];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh, out[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl, out[mb], 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh, out[mb], 0, 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
+    const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
+    const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
+    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  _Float16* wh = (_Float16*)lds;                       // PH_TOTAL halves
+  float* lb = lds + PH_TOTAL / 2;                      // b1 b2 b3 b4
+  for (int i = threadIdx.x * 4; i < PH_TOTAL / 2; i += 512 * 4)
+    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[PN_TOTAL + i];
+  for (int i = threadIdx.x; i < 128 * 3 + 8; i += 512) lb[i] = wpack[PN_B1 + i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n_pblocks = (n_points + 31) >> 5;
+  const int n_tiles = n_pblocks * 8;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+
+  for (int t = blockIdx.x * 8 + wave; t < n_tiles; t += gridDim.x * 8) {
+    const int k = t / n_pblocks;
+    const int pb = t - k * n_pblocks;
+    const int i = pb * 32 + j;
+    float in[4] = {0.f, 0.f, 0.f, 0.f};  // slots 0..3 of this lane half: features 4h .. 4h+3 of [rel(3), normal(3)]
+    int slot = -1;
+    if (i < n_points) {
+      const float* p = pts + (size_t)i * 6;
+      const float x = p[0], y = p[1], z = p[2];
+      if (in_bounds(x, y, z, g)) {
+        const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+        const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+        const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+        const int gx = (k & 1) ? (int)ceilf(xn) : (int)floorf(xn);
+        const int gy = (k & 2) ? (int)ceilf(yn) : (int)floorf(yn);
+        const int gz = (k & 4) ? (int)ceilf(zn) : (int)floorf(zn);
+        if (voxel_owner(gx, gy, gz, g) == g.shard_rank) {
+          const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+          const uint32_t word = bitmap[id >> 5];
+          slot = (int)(word_prefix[id >> 5] + __popc(word & ((1u << (id & 31)) - 1u)));
+        }
+        if (h == 0) {
+          in[0] = relative_coord(xn, gx, g.voxel_size);
+          in[1] = relative_coord(yn, gy, g.voxel_size);
+          in[2] = relative_coord(zn, gz, g.voxel_size);
+          in[3] = p[3];
+        } else {
+          in[0] = p[4];
+          in[1] = p[5];
+        }
+      }
+    }
+    if (__ballot(slot >= 0) == 0ULL) continue;
+
+    // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots) -----------------------------
+    f32x16 ha[4], hb[4];
+    {
+      half8 bh, bl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? in[e] : 0.f;
+        const _Float16 hh = (_Float16)x;
+        bh[e] = hh;
+        bl[e] = (_Float16)(x - (float)hh);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) {
+        const _Float16* w = wh + PH_W1 + ((mb * 2) * 64 + lane) * 8;
+        const half8 ahi = *(const half8*)w, alo = *(const half8*)(w + 64 * 8);
+        f32x16 c = bias_init(lb, mb, h);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
+        ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh, c, 0, 0, 0);
+      }
+    }
+    half8 sh[8], sl[8];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+    }
+    layer128_h(wh + PH_W2, lb + 128, sh, sl, hb, lane, h);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      split8(hb[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+    }
+    layer128_h(wh + PH_W3, lb + 256, sh, sl, ha, lane, h);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+    }
+    // ---- layer 4: 128 -> 8 ------------------------------------------------------------------
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    {
+      const f32x4 b4 = *(const f32x4*)&lb[384 + 4 * h];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = b4[r];
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        half8 ahi, alo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ahi[e] = (_Float16)0.f;
+          alo[e] = (_Float16)0.f;
+        }
+        if (j < 8) {
+          const _Float16* w = wh + PH_W4 + (((((nb * 2 + ksl) * 2) * 2 + h) * 8) + j) * 8;
+          ahi = *(const half8*)w;
+          alo = *(const half8*)(w + 2 * 8 * 8);
+        }
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, sh[nb * 2 + ksl], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sl[nb * 2 + ksl], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sh[nb * 2 + ksl], o, 0, 0, 0);
+      }
+    }
+    if (slot >= 0) {
+      long long* dst = acc + (size_t)slot * 8 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long v = __float2ll_rn(o[q] * kFixedScale);
+        atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v);
+      }
+      if (h == 0) atomicAdd(&counts[slot], 1);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // finalize: ordered compaction of the emitted voxels + cleanup of the per-frame scratch
 // ------------------------------------------------------------------------------------------
@@ -531,6 +722,8 @@ int bnv_init(int device) {
   g_num_cus = cus;
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES));
   extern int bnv_decode_init();
   return bnv_decode_init();
 }
@@ -550,7 +743,14 @@ const char* bnv_status_string(int s) {
   }
 }
 
-size_t bnv_pointnet_pack_floats(void) { return PN_TOTAL; }
+size_t bnv_pointnet_pack_floats(void) { return PN_PACK_FLOATS; }
+
+int bnv_set_mlp_mode(int mode) {
+  if (mode != 0 && mode != 1) return BNV_ERR_INVALID_ARGUMENT;
+  g_mlp_mode = mode;
+  return BNV_OK;
+}
+int bnv_get_mlp_mode(void) { return g_mlp_mode; }
 
 int bnv_profile_enable(int on) {
   for (int k = 0; k < PROF_KINDS; ++k) g_prof_used[k] = 0;
@@ -626,8 +826,12 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
   {
     ProfScope prof(PROF_POINTNET, stream);
-    hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
-                       pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+    if (g_mlp_mode == 1)
+      hipLaunchKernelGGL(k_pointnet_scatter_h, dim3(grid_pn), dim3(512), PH_LDS_BYTES, stream, input_pts, n, g,
+                         pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+    else
+      hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
+                         pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
   }
   BNV_LAUNCH_CHECK();
   // ordered compaction of the emitted voxels; the number of slots is only known on the device,

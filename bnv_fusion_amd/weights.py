@@ -71,8 +71,55 @@ def pack_pointnet(sd):
             for hh in range(2):
                 for i in range(4):
                     w4p[nb, rq, hh, :, i] = W4[:, nb * 32 + 8 * rq + i + 4 * hh]
-    return np.concatenate([w1p.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4p.ravel(),
-                           b1, b2, b3, b4]).astype(np.float32)
+    fp32_part = np.concatenate([w1p.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4p.ravel(),
+                                b1, b2, b3, b4]).astype(np.float32)
+    return np.concatenate([fp32_part, _pack_pointnet_split(W1, W2, W3, W4)])
+
+
+def split_f16(x):
+    """fp32 -> (hi, lo) float16 with x ~ hi + lo (about 22 significant bits; lo may be subnormal)."""
+    x = np.asarray(x, dtype=np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def _slot_feature(jj, h):
+    """Feature (within a 16-deep K-step) held in operand slot jj of lane half h."""
+    return 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+
+def _pack_pointnet_split(W1, W2, W3, W4):
+    """Split-operand layout PH_* of csrc/encode.hip, returned as float32 words (2 halves each)."""
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+    jj = np.arange(8)
+    # W1: one K-step over the 6 inputs (padded to 16): [4 mb][hi/lo][64][8]
+    w1 = np.zeros((4, 2, 64, 8), np.float16)
+    W1p = np.zeros((128, 16), np.float32)
+    W1p[:, :6] = W1
+    for mb in range(4):
+        v = W1p[(mb * 32 + n)[:, None], _slot_feature(jj[None, :], h[:, None])]
+        w1[mb, 0], w1[mb, 1] = split_f16(v)
+
+    def pack128(W):
+        o = np.zeros((4, 4, 2, 2, 64, 8), np.float16)
+        for mb in range(4):
+            for nb in range(4):
+                for ksl in range(2):
+                    v = W[(mb * 32 + n)[:, None], nb * 32 + 16 * ksl + _slot_feature(jj[None, :], h[:, None])]
+                    o[mb, nb, ksl, 0], o[mb, nb, ksl, 1] = split_f16(v)
+        return o
+
+    w4 = np.zeros((4, 2, 2, 2, 8, 8), np.float16)      # [nb][ksl][hi/lo][h][n][8]
+    for nb in range(4):
+        for ksl in range(2):
+            for hh in range(2):
+                v = W4[np.arange(8)[:, None], nb * 32 + 16 * ksl + _slot_feature(jj[None, :], hh)]
+                w4[nb, ksl, 0, hh], w4[nb, ksl, 1, hh] = split_f16(v)
+    halves = np.concatenate([w1.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4.ravel()])
+    assert halves.size == 71680
+    return halves.view(np.float32)
 
 
 def pack_sdf_mlp(sd):
@@ -98,5 +145,22 @@ def pack_sdf_mlp(sd):
     wa = _np(sd["nerf.fc_alpha.weight"]).astype(np.float32).reshape(256)
     ba = np.zeros(4, np.float32)
     ba[0] = _np(sd["nerf.fc_alpha.bias"]).reshape(-1)[0]
-    return np.concatenate([pack(Ws[0], 3), pack(Ws[1], 32), pack(Ws[2], 32), pack(Ws[3], 32),
-                           bs[0], bs[1], bs[2], bs[3], wa, ba]).astype(np.float32)
+    fp32_part = np.concatenate([pack(Ws[0], 3), pack(Ws[1], 32), pack(Ws[2], 32), pack(Ws[3], 32),
+                                bs[0], bs[1], bs[2], bs[3], wa, ba]).astype(np.float32)
+
+    def pack_split(W, nks):
+        """[8 w][nks][hi/lo][64 lane][8]: slot jj of lane (n, h) = W[32 w + n][16 ks + slot_feature(jj, h)]."""
+        Wp = np.zeros((256, 16 * nks), np.float32)
+        Wp[:, :W.shape[1]] = W
+        jj = np.arange(8)
+        o = np.zeros((8, nks, 2, 64, 8), np.float16)
+        for w in range(8):
+            for ks in range(nks):
+                v = Wp[(32 * w + n)[:, None], 16 * ks + _slot_feature(jj[None, :], h[:, None])]
+                o[w, ks, 0], o[w, ks, 1] = split_f16(v)
+        return o.ravel()
+
+    halves = np.concatenate([pack_split(Ws[0], 2), pack_split(Ws[1], 16), pack_split(Ws[2], 16),
+                             pack_split(Ws[3], 16)])
+    assert halves.size == 409600
+    return np.concatenate([fp32_part, halves.view(np.float32)])

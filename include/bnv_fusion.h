@@ -85,6 +85,15 @@ int bnv_num_compute_units(void);
 const char* bnv_status_string(int status);
 int bnv_last_hip_error(void);
 
+/* Arithmetic of the two MLPs (point encoder, SDF decoder).  Both modes take fp32 inputs/weights and
+ * accumulate in fp32:
+ *   0  exact fp32: v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain), 157 TFLOP/s peak;
+ *   1  (default) split operands: every fp32 operand x = hi + lo with hi, lo in f16 (about 22 significant
+ *      bits; f16 subnormals are kept), a.b ~ ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16:
+ *      fp32-class accuracy (differences at the level of fp32 summation order) at 16/3 the MFMA rate. */
+int bnv_set_mlp_mode(int mode);
+int bnv_get_mlp_mode(void);
+
 /* Optional timing of the dominant kernels with HIP events recorded on their launch stream.
  * kinds: 0 point-encoder MLP + scatter, 1 lattice-table SDF MLP, 2 decode_pts SDF MLP,
  * 3 dense-decode SDF MLP.  bnv_profile_read synchronises the recorded events and returns the

@@ -19,12 +19,15 @@ FEAT_TOL = 1e-4     # per-voxel encoder features (|f| ~ O(1))
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module")
-def bnv():
+@pytest.fixture(scope="module", params=["split_f16", "fp32_exact"])
+def bnv(request):
+    """Every test of this module runs in both MLP arithmetic modes (include/bnv_fusion.h)."""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU (no CPU fallback exists)")
     import bnv_fusion_amd
-    return bnv_fusion_amd
+    bnv_fusion_amd.set_mlp_mode(1 if request.param == "split_f16" else 0)
+    yield bnv_fusion_amd
+    bnv_fusion_amd.set_mlp_mode(1)
 
 
 @pytest.fixture(scope="module")

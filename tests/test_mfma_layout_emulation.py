@@ -35,7 +35,7 @@ def test_pointnet_pack_matches_direct_mlp():
     PN_W4 = PN_W3 + 16384
     PN_B1 = PN_W4 + 1024
     PN_B2, PN_B3, PN_B4 = PN_B1 + 128, PN_B1 + 256, PN_B1 + 384
-    assert pack.size == PN_B4 + 8 == 34952
+    assert PN_B4 + 8 == 34952 and pack.size == 34952 + 71680 // 2
     rng = np.random.default_rng(0)
     x = rng.uniform(-1, 1, size=(32, 6))  # 32 pairs
 
@@ -90,7 +90,7 @@ def test_sdf_mlp_pack_matches_direct_mlp():
     SD_W2, SD_W3 = SD_W1 + 65536, SD_W1 + 2 * 65536
     SD_B0 = SD_W3 + 65536
     SD_WA, SD_BA = SD_B0 + 1024, SD_B0 + 1024 + 256
-    assert pack.size == SD_BA + 4
+    assert pack.size == SD_BA + 4 + 409600 // 2
     DM = 128
     rng = np.random.default_rng(1)
     x = rng.uniform(-1, 1, size=(DM, 17))
@@ -135,6 +135,178 @@ def test_sdf_mlp_pack_matches_direct_mlp():
         wa = frag(SD_WA, w)
         for pt in range(4):
             s = (wa * np.maximum(accs[w][pt], 0)).sum(1)  # per lane
+            for l in range(64):
+                alpha[pt * 32 + N_[l]] += s[l]
+    tsd = orc.load_weights(WEIGHTS_FP32)
+    ref = orc.geo_forward(tsd, torch.from_numpy(x).float())[:, 0].numpy()
+    assert np.abs(alpha - ref).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# split-operand (f16 hi + lo) layouts on v_mfma_f32_32x32x16_f16.  Operand slot jj of lane (n, h)
+# pairs with slot jj of lane (m, h) of the other operand (verified on hardware by
+# tools/probe_mfma_f16.hip); D layout as above.
+# ---------------------------------------------------------------------------------------------
+def mfma16(a, b, c):
+    """a, b: [64, 8] per-lane operand slots; c: [64, 16]."""
+    A = np.zeros((32, 2, 8))
+    B = np.zeros((32, 2, 8))
+    A[N_, H_] = a
+    B[N_, H_] = b
+    D = np.einsum("ihj,nhj->in", A, B)
+    return c + D[ROW, N_[:, None]]
+
+
+def _split(x):
+    hi = np.asarray(x, np.float32).astype(np.float16)
+    lo = (np.asarray(x, np.float32) - hi.astype(np.float32)).astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def _mfma3(ah, al, bh, bl, c):
+    return mfma16(ah, bh, mfma16(ah, bl, mfma16(al, bh, c)))
+
+
+def test_pointnet_split_pack_matches_direct_mlp():
+    sd = W.load_npz(WEIGHTS_FP32)
+    pack = W.pack_pointnet(sd)
+    halves = pack[34952:].view(np.float16).astype(np.float64)
+    fp = pack[:34952].astype(np.float64)
+    PH_W1, PH_W2 = 0, 4096
+    PH_W3, PH_W4 = PH_W2 + 32768, PH_W2 + 65536
+    PN_B1 = 33536 + 1024
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)
+    J8 = np.arange(8)
+
+    def bias_init(off, mb):
+        v = np.zeros((64, 16))
+        for q in range(4):
+            for i in range(4):
+                v[:, 4 * q + i] = fp[off + mb * 32 + 8 * q + 4 * H_ + i]
+        return v
+
+    xin = np.zeros((64, 8), np.float32)
+    for l in range(64):
+        if H_[l] == 0:
+            xin[l, :4] = x[N_[l], :4]
+        else:
+            xin[l, :2] = x[N_[l], 4:6]
+    bh, bl = _split(xin)
+    ha = []
+    for mb in range(4):
+        w = PH_W1 + ((mb * 2) * 64 + LANE[:, None]) * 8 + J8[None, :]
+        ha.append(_mfma3(halves[w], halves[w + 512], bh, bl, bias_init(PN_B1, mb)))
+
+    def to_ops(hs):
+        oh, ol = [], []
+        for nb in range(4):
+            for ksl in range(2):
+                a, b = _split(np.maximum(hs[nb][:, 8 * ksl: 8 * ksl + 8], 0).astype(np.float32))
+                oh.append(a)
+                ol.append(b)
+        return oh, ol
+
+    def layer(woff, boff, oh, ol):
+        out = [bias_init(boff, mb) for mb in range(4)]
+        for nb in range(4):
+            for ksl in range(2):
+                for mb in range(4):
+                    w = woff + ((((mb * 4 + nb) * 2 + ksl) * 2) * 64 + LANE[:, None]) * 8 + J8[None, :]
+                    out[mb] = _mfma3(halves[w], halves[w + 512], oh[nb * 2 + ksl], ol[nb * 2 + ksl], out[mb])
+        return out
+
+    oh, ol = to_ops(ha)
+    hb = layer(PH_W2, PN_B1 + 128, oh, ol)
+    oh, ol = to_ops(hb)
+    ha = layer(PH_W3, PN_B1 + 256, oh, ol)
+    oh, ol = to_ops(ha)
+    o = np.zeros((64, 16))
+    for r in range(4):
+        o[:, r] = fp[PN_B1 + 384 + 4 * H_ + r]
+    for nb in range(4):
+        for ksl in range(2):
+            w = PH_W4 + (((((nb * 2 + ksl) * 2) * 2 + H_[:, None]) * 8) + np.minimum(N_, 7)[:, None]) * 8 + J8[None, :]
+            ahi = np.where((N_ < 8)[:, None], halves[w], 0.0)
+            alo = np.where((N_ < 8)[:, None], halves[w + 128], 0.0)
+            o = _mfma3(ahi, alo, oh[nb * 2 + ksl], ol[nb * 2 + ksl], o)
+    got = np.zeros((32, 8))
+    for l in range(64):
+        for q in range(4):
+            got[N_[l], 4 * H_[l] + q] = o[l, q]
+    tsd = orc.load_weights(WEIGHTS_FP32)
+    ref = orc.pointnet_encoder(tsd, torch.from_numpy(x.T[None]).float())[0].T.numpy()
+    assert np.abs(got - ref).max() < 2e-5
+
+
+def test_sdf_mlp_split_pack_matches_direct_mlp():
+    sd = W.load_npz(WEIGHTS_FP32)
+    pack = W.pack_sdf_mlp(sd)
+    SD_TOTAL = 6144 + 3 * 65536 + 1024 + 256 + 4
+    fp = pack[:SD_TOTAL].astype(np.float64)
+    halves = pack[SD_TOTAL:].view(np.float16).astype(np.float64)
+    SD_B0 = 6144 + 3 * 65536
+    SD_WA, SD_BA = SD_B0 + 1024, SD_B0 + 1280
+    SH = [0, 16384, 16384 + 131072, 16384 + 2 * 131072]
+    DM = 128
+    J8 = np.arange(8)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, size=(DM, 17)).astype(np.float32)
+    xin = np.zeros((DM, 32), np.float32)
+    xin[:, :17] = x
+
+    def feature(ks, h, jj):
+        return 16 * ks + 8 * (jj >> 2) + 4 * h + (jj & 3)
+
+    def stage(vals, nks):     # vals [DM, 16 nks] -> hi/lo planes [nks][2][DM][8]
+        hi = np.zeros((nks, 2, DM, 8))
+        lo = np.zeros((nks, 2, DM, 8))
+        for ks in range(nks):
+            for h in range(2):
+                a, b = _split(vals[:, feature(ks, h, J8)])
+                hi[ks, h], lo[ks, h] = a, b
+        return hi, lo
+
+    def frag(off, w):
+        v = np.zeros((64, 16))
+        for q in range(4):
+            for i in range(4):
+                v[:, 4 * q + i] = fp[off + w * 32 + 8 * q + 4 * H_ + i]
+        return v
+
+    def layer(woff, boff, nks, hi, lo):
+        accs = []
+        for w in range(8):
+            acc = [frag(boff, w) for _ in range(4)]
+            for ks in range(nks):
+                wi = woff + w * nks * 2 * 512 + ((ks * 2) * 64 + LANE[:, None]) * 8 + J8[None, :]
+                ah, al = halves[wi], halves[wi + 512]
+                for pt in range(4):
+                    acc[pt] = _mfma3(ah, al, hi[ks, H_, pt * 32 + N_], lo[ks, H_, pt * 32 + N_], acc[pt])
+            accs.append(acc)
+        return accs
+
+    def store(accs):
+        hi = np.zeros((16, 2, DM, 8))
+        lo = np.zeros((16, 2, DM, 8))
+        for w in range(8):
+            for pt in range(4):
+                for ksl in range(2):
+                    a, b = _split(np.maximum(accs[w][pt][:, 8 * ksl: 8 * ksl + 8], 0).astype(np.float32))
+                    hi[2 * w + ksl, H_, pt * 32 + N_] = a
+                    lo[2 * w + ksl, H_, pt * 32 + N_] = b
+        return hi, lo
+
+    hi, lo = stage(xin, 2)
+    hi, lo = store(layer(SH[0], SD_B0, 2, hi, lo))
+    hi, lo = store(layer(SH[1], SD_B0 + 256, 16, hi, lo))
+    hi, lo = store(layer(SH[2], SD_B0 + 512, 16, hi, lo))
+    accs = layer(SH[3], SD_B0 + 768, 16, hi, lo)
+    alpha = np.full(DM, fp[SD_BA])
+    for w in range(8):
+        wa = frag(SD_WA, w)
+        for pt in range(4):
+            s = (wa * np.maximum(accs[w][pt], 0)).sum(1)
             for l in range(64):
                 alpha[pt * 32 + N_[l]] += s[l]
     tsd = orc.load_weights(WEIGHTS_FP32)
