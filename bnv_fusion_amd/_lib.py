@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbnv_fusion_hip.so")
+LIB_PATH = os.environ.get("BNV_FUSION_LIB") or os.path.join(_HERE, "libbnv_fusion_hip.so")
 
 # every symbol include/bnv_fusion.h declares
 SYMBOLS = [
@@ -17,7 +17,7 @@ SYMBOLS = [
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
     "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
-    "bnv_lattice_table", "bnv_lattice_blend",
+    "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
 
@@ -90,7 +90,8 @@ def load():
         "bnv_decode_lattice_list_offset": (sz, [i64, i64]),
         "bnv_lattice_neighbors": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, i64, vp, C.c_int, vp, sz,
                                             i32, vp]),
-        "bnv_lattice_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, sz, vp]),
+        "bnv_lattice_mark": (C.c_int, [C.POINTER(Volume), i64, vp, sz, vp]),
+        "bnv_lattice_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, C.c_int, vp, sz, vp]),
         "bnv_lattice_blend": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, C.POINTER(SdfDelta), vp, sz, vp,
                                         vp]),
         "bnv_set_mlp_mode": (C.c_int, [C.c_int]),

@@ -62,10 +62,12 @@ struct DecodeArgs {
   int is_coords;
   bnv_sdf_delta_t delta;
   float* out;
-  // LATTICE
+  // LATTICE: work list of rows (27 evaluations each) or, if `entries` is set, of (row << 5 | l) entries
   const int32_t* list;
   const int32_t* n_list;
   float* table;
+  const int32_t* entries;
+  uint32_t* need_mask;
   // DENSE
   const float* feat_grid;
   const float* pts_weight;
@@ -185,6 +187,13 @@ __device__ __forceinline__ void stage_input(float* __restrict__ hl, int j, const
 // of wave w exactly the 8 slots of K-step 2 w + ksl.
 constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
 
+// ReLU as one v_max_f32 (fmaxf() costs an extra canonicalising v_max under IEEE mode)
+__device__ __forceinline__ float relu1(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 template <int NKS>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
                                             const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
@@ -195,23 +204,43 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
   const _Float16* wl = wp + (size_t)w * NKS * 2 * 64 * 8 + lane * 8;
   const float* hh = lds + L_HL + (h * DM + j) * 4;
   const float* hl = lds + L_HLO + (h * DM + j) * 4;
-#pragma unroll 2
-  for (int ks = 0; ks < NKS; ++ks) {
-    const half8 ah = *(const half8*)(wl + (ks * 2) * 64 * 8);
-    const half8 al = *(const half8*)(wl + (ks * 2 + 1) * 64 * 8);
-    half8 bh[4], bl[4];
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      bh[pt] = *(const half8*)(hh + (ks * 2 * DM + pt * 32) * 4);
-      bl[pt] = *(const half8*)(hl + (ks * 2 * DM + pt * 32) * 4);
-    }
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[pt], acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[pt], acc[pt], 0, 0, 0);
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[pt], acc[pt], 0, 0, 0);
+  // software pipeline over the K-steps (fully unrolled, all indices static): weight fragments come
+  // from L2 two steps ahead (3-deep register ring), activation fragments from LDS one step ahead
+  half8 ah[3], al[3], bh[2][4], bl[2][4];
+#define BNV_LOAD_A(ks)                                              \
+  {                                                                 \
+    ah[(ks) % 3] = *(const half8*)(wl + ((ks) * 2) * 64 * 8);       \
+    al[(ks) % 3] = *(const half8*)(wl + ((ks) * 2 + 1) * 64 * 8);   \
   }
+#define BNV_LOAD_B(ks)                                                                    \
+  {                                                                                       \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
+      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
+      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
+    }                                                                                     \
+  }
+  BNV_LOAD_A(0);
+  if (NKS > 1) BNV_LOAD_A(1);
+  BNV_LOAD_B(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
+    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this step's MFMAs (the scheduler sinks them)
+    const half8 a_hi = ah[ks % 3], a_lo = al[ks % 3];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_A
+#undef BNV_LOAD_B
 }
 
 __device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x16 (&acc)[4], int w, int j, int h) {
@@ -222,7 +251,7 @@ __device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x
       half8 hi, lo;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float x = fmaxf(acc[pt][8 * ksl + e], 0.f);
+        const float x = relu1(acc[pt][8 * ksl + e]);
         const _Float16 t = (_Float16)x;
         hi[e] = t;
         lo[e] = (_Float16)(x - (float)t);
@@ -325,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
   int64_t n_tiles;
   int64_t n_evals = 0;
   if constexpr (MODE == MODE_LATTICE) {
-    n_evals = (int64_t)(*A.n_list) * 27;
+    n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
     n_tiles = (n_evals + DM - 1) / DM;
   } else {
     n_tiles = (A.n + 15) / 16;
@@ -340,9 +369,16 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
       if constexpr (MODE == MODE_LATTICE) {
         const int64_t e = tile * DM + j;
         if (e < n_evals) {
-          const int64_t ci = e / 27;
-          const int l = (int)(e - ci * 27);
-          const int row = A.list[ci];
+          int row, l;
+          if (A.entries) {
+            const int ent = A.entries[e];
+            row = ent >> 5;
+            l = ent & 31;
+          } else {
+            const int64_t ci = e / 27;
+            l = (int)(e - ci * 27);
+            row = A.list[ci];
+          }
           loc[0] = (float)(l / 9 - 1) * 0.5f;
           loc[1] = (float)((l / 3) % 3 - 1) * 0.5f;
           loc[2] = (float)(l % 3 - 1) * 0.5f;
@@ -415,9 +451,18 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
       if (threadIdx.x < DM) {
         const int64_t e = tile * DM + threadIdx.x;
         if (e < n_evals) {
-          const int64_t ci = e / 27;
-          const int l = (int)(e - ci * 27);
-          A.table[(size_t)A.list[ci] * 27 + l] = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
+          int row, l;
+          if (A.entries) {
+            const int ent = A.entries[e];
+            row = ent >> 5;
+            l = ent & 31;
+            A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
+          } else {
+            const int64_t ci = e / 27;
+            l = (int)(e - ci * 27);
+            row = A.list[ci];
+          }
+          A.table[(size_t)row * 27 + l] = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
         }
       }
     } else {
@@ -465,7 +510,10 @@ struct LatticeWs {
   int32_t* n_list;    // [1]
   int32_t* stamp;     // [row_capacity]
   float* table;       // [row_capacity][27]
+  uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
+  int32_t* entries;   // [entry_capacity] (row << 5) | l
   int64_t list_capacity;
+  int64_t entry_capacity;
 };
 
 static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws) {
@@ -481,10 +529,17 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   // stamp and table first: they persist across calls with the same row_capacity
   char* st = take(row_capacity * 4);
   char* tb = take(row_capacity * 27 * 4);
+  char* nm = take(row_capacity * 4);
   char* nl = take(256);
   char* nb = take(n * 27 * 4);
   char* li = take(cap * 4);
+  int64_t ecap = 27 * cap;
+  if (ecap > 216 * n) ecap = 216 * n;
+  char* en = take(ecap * 4);
   if (ws) {
+    ws->need_mask = (uint32_t*)nm;
+    ws->entries = (int32_t*)en;
+    ws->entry_capacity = ecap;
     ws->stamp = (int32_t*)st;
     ws->table = (float*)tb;
     ws->n_list = (int32_t*)nl;
@@ -520,6 +575,72 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
   if (usable && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
     list[atomicAdd(n_list, 1)] = row;
+}
+
+// One thread per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is
+// LIVE), flags the 8 (row, l) table entries it reads; the first thread to flag an entry appends it to
+// the MLP work list.  Entries of masked points are never evaluated.
+constexpr int kMarkThreads = 1024;
+__global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
+                                                               uint32_t* __restrict__ need_mask,
+                                                               int32_t* __restrict__ entries,
+                                                               int32_t* __restrict__ n_entries,
+                                                               int64_t entry_capacity) {
+  // new entries are collected per block in LDS and appended with ONE global atomic per block
+  __shared__ int s_buf[kMarkThreads * 8];
+  __shared__ int s_count, s_base;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  const int64_t t = (int64_t)blockIdx.x * kMarkThreads + threadIdx.x;
+  if (t < n * 27) {
+    const int64_t b = t / 27;
+    const int p = (int)(t - b * 27);
+    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    int rowk[8], lk[8];
+    bool live = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int nbi = 0, li = 0;
+      bool dup = false;  // ceil == floor on an axis with d == 0: same entry as the floor corner
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int nb_a = 0, loc2 = 0;
+        if (d[a] != 0) {
+          if ((k >> a) & 1) {
+            nb_a = (d[a] + 1) / 2;
+            loc2 = -1;
+          } else {
+            nb_a = (d[a] - 1) / 2;
+            loc2 = 1;
+          }
+        } else if ((k >> a) & 1) {
+          dup = true;
+        }
+        nbi = nbi * 3 + (nb_a + 1);
+        li = li * 3 + (loc2 + 1);
+      }
+      const int row = nbr_rows[b * 27 + nbi];
+      if (row < 0) live = false;
+      rowk[k] = dup ? -1 : row;
+      lk[k] = li;
+    }
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (rowk[k] < 0) continue;
+        const uint32_t bit = 1u << lk[k];
+        if (!(atomicOr(&need_mask[rowk[k]], bit) & bit)) s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int cnt = s_count;
+  if (cnt == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(n_entries, cnt);
+  __syncthreads();
+  const int base = s_base;
+  for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
+    if (base + i < entry_capacity) entries[base + i] = s_buf[i];
 }
 
 __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
@@ -710,8 +831,22 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   return BNV_OK;
 }
 
+int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, void* ws_ptr, size_t ws_bytes, bnv_stream_t stream_) {
+  if (!vol_ok_ro(vol) || n < 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  LatticeWs ws;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 4, stream));
+  if (n == 0) return BNV_OK;
+  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
+                     dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
 int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                      const float* sdfmlp_pack, int64_t n_voxels, void* ws_ptr, size_t ws_bytes,
+                      const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr, size_t ws_bytes,
                       bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
@@ -726,7 +861,10 @@ int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const flo
   a.list = ws.list;
   a.n_list = ws.n_list;
   a.table = ws.table;
-  return launch_decode(MODE_LATTICE, a, (ws.list_capacity * 27 + DM - 1) / DM, (hipStream_t)stream);
+  a.need_mask = ws.need_mask;
+  a.entries = use_entries ? ws.entries : nullptr;
+  const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
+  return launch_decode(MODE_LATTICE, a, (evals + DM - 1) / DM, (hipStream_t)stream);
 }
 
 int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
@@ -752,10 +890,13 @@ int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const fl
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
-  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, nullptr, 1, ws_ptr, ws_bytes, epoch,
+  // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend
+  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, nullptr, 0, ws_ptr, ws_bytes, epoch,
                                  stream);
   if (rc != BNV_OK) return rc;
-  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, ws_ptr, ws_bytes, stream);
+  rc = bnv_lattice_mark(vol, n, ws_ptr, ws_bytes, stream);
+  if (rc != BNV_OK) return rc;
+  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;
   return bnv_lattice_blend(vol, grid, origins, n, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }

@@ -307,6 +307,42 @@ __device__ __forceinline__ void layer128(const float* __restrict__ wp, const flo
   }
 }
 
+// Scatter of one tile: lane (j, h) holds output features 4h .. 4h+3 of pair j.  Consecutive pairs are
+// neighbouring pixels and mostly fall into the same voxel, so the values are first converted to 2^32
+// fixed point (exact), summed over each run of equal slots with a segmented scan across the 32 pairs
+// (integer adds: associative, so the result is bit-identical to per-pair atomics), and only the last
+// lane of a run issues the atomics.
+__device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, int h, int32_t* __restrict__ counts,
+                                             long long* __restrict__ acc) {
+  long long v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = slot >= 0 ? __float2ll_rn(o[q] * kFixedScale) : 0LL;
+  int cnt = slot >= 0 ? 1 : 0;
+  const int prev = __shfl_up(slot, 1, 32);
+  const int next = __shfl_down(slot, 1, 32);
+  int closed = (j == 0 || prev != slot) ? 1 : 0;  // run head: takes nothing from lower lanes
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    long long vo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vo[q] = __shfl_up(v[q], d, 32);
+    const int co = __shfl_up(cnt, d, 32);
+    const int fo = __shfl_up(closed, d, 32);
+    if (j >= d && !closed) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += vo[q];
+      cnt += co;
+      closed |= fo;
+    }
+  }
+  if (slot >= 0 && (j == 31 || next != slot)) {
+    long long* dst = acc + (size_t)slot * 8 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v[q]);
+    if (h == 0) atomicAdd(&counts[slot], cnt);
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
@@ -402,16 +438,7 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
           o = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], ha[nb][4 * rq + i], o, 0, 0, 0);
       }
     }
-    // ---- scatter: lane (j, h) holds output features 4h .. 4h+3 of pair j -------------------
-    if (slot >= 0) {
-      long long* dst = acc + (size_t)slot * 8 + 4 * h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long v = __float2ll_rn(o[q] * kFixedScale);
-        atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v);
-      }
-      if (h == 0) atomicAdd(&counts[slot], 1);
-    }
+    scatter_tile(o, slot, j, h, counts, acc);
   }
 }
 
@@ -429,7 +456,7 @@ __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, hal
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float x = v[base + e];
-    if (relu) x = fmaxf(x, 0.f);
+    if (relu) asm("v_max_f32 %0, 0, %1" : "=v"(x) : "v"(x));  // one op; fmaxf adds a canonicalising v_max
     const _Float16 h = (_Float16)x;
     (*hi)[e] = h;
     (*lo)[e] = (_Float16)(x - (float)h);
@@ -441,26 +468,28 @@ __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, cons
                                            int lane, int h) {
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb) out[mb] = bias_init(bias, mb, h);
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-    for (int ksl = 0; ksl < 2; ++ksl) {
-      half8 ah[4], al[4];
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const _Float16* w = wp + ((((mb * 4 + nb) * 2 + ksl) * 2) * 64 + lane) * 8;
-        ah[mb] = *(const half8*)w;
-        al[mb] = *(const half8*)(w + 64 * 8);
-      }
-      const half8 bh = inh[nb * 2 + ksl], bl = inl[nb * 2 + ksl];
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mb], bh, out[mb], 0, 0, 0);
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bl, out[mb], 0, 0, 0);
-#pragma unroll
-      for (int mb = 0; mb < 4; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mb], bh, out[mb], 0, 0, 0);
-    }
+  // 32 steps q = (K-step g = (nb, ksl), output block mb): three accumulate-chained products per step
+  // (chained MFMAs on one accumulator issue back to back); the weight fragments of step q+1 are
+  // fetched from LDS before the MFMAs of step q.
+  half8 ah[2], al[2];
+#define BNV_LOAD_W(q)                                                                       \
+  {                                                                                         \
+    const _Float16* w = wp + (((((q) & 3) * 8 + ((q) >> 2)) * 2) * 64 + lane) * 8;           \
+    ah[(q) & 1] = *(const half8*)w;                                                         \
+    al[(q) & 1] = *(const half8*)(w + 64 * 8);                                              \
   }
+  BNV_LOAD_W(0);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    if (q + 1 < 32) BNV_LOAD_W(q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int g = q >> 2, mb = q & 3;
+    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q & 1], inh[g], out[mb], 0, 0, 0);
+    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inl[g], out[mb], 0, 0, 0);
+    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inh[g], out[mb], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_W
 }
 
 __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
@@ -482,38 +511,70 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
   const int n_tiles = n_pblocks * 8;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
 
-  for (int t = blockIdx.x * 8 + wave; t < n_tiles; t += gridDim.x * 8) {
-    const int k = t / n_pblocks;
-    const int pb = t - k * n_pblocks;
-    const int i = pb * 32 + j;
-    float in[4] = {0.f, 0.f, 0.f, 0.f};  // slots 0..3 of this lane half: features 4h .. 4h+3 of [rel(3), normal(3)]
-    int slot = -1;
-    if (i < n_points) {
-      const float* p = pts + (size_t)i * 6;
-      const float x = p[0], y = p[1], z = p[2];
-      if (in_bounds(x, y, z, g)) {
-        const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
-        const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
-        const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
-        const int gx = (k & 1) ? (int)ceilf(xn) : (int)floorf(xn);
-        const int gy = (k & 2) ? (int)ceilf(yn) : (int)floorf(yn);
-        const int gz = (k & 4) ? (int)ceilf(zn) : (int)floorf(zn);
-        if (voxel_owner(gx, gy, gz, g) == g.shard_rank) {
-          const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
-          const uint32_t word = bitmap[id >> 5];
-          slot = (int)(word_prefix[id >> 5] + __popc(word & ((1u << (id & 31)) - 1u)));
-        }
-        if (h == 0) {
-          in[0] = relative_coord(xn, gx, g.voxel_size);
-          in[1] = relative_coord(yn, gy, g.voxel_size);
-          in[2] = relative_coord(zn, gz, g.voxel_size);
-          in[3] = p[3];
-        } else {
-          in[0] = p[4];
-          in[1] = p[5];
-        }
+  // Software pipeline over this wave's tiles: while tile t runs its MLP, the point of tile t+2 and the
+  // bitmap / prefix words of tile t+1 are in flight (three dependent memory latencies per tile).
+  const int tstep = gridDim.x * 8;
+  const int t0 = blockIdx.x * 8 + wave;
+  float raw[6];                 // stage 1 (tile t+2): the raw point
+  bool raw_ok = false;
+  float nin[4];                 // stage 2 (tile t+1): network inputs, voxel id, its bitmap/prefix words
+  uint32_t n_id = 0, n_word = 0, n_pref = 0;
+  bool n_own = false;
+  auto stage1 = [&](int t) {
+    raw_ok = false;
+    if (t < n_tiles) {
+      const int k = t / n_pblocks;
+      const int i = (t - k * n_pblocks) * 32 + j;
+      if (i < n_points) {
+        const float* p = pts + (size_t)i * 6;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) raw[c] = p[c];
+        raw_ok = true;
       }
     }
+  };
+  auto stage2 = [&](int t) {
+    n_own = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nin[c] = 0.f;
+    if (raw_ok && in_bounds(raw[0], raw[1], raw[2], g)) {
+      const int k = t / n_pblocks;
+      const float xn = voxel_coord(raw[0], g.bound_min[0], g.voxel_size);
+      const float yn = voxel_coord(raw[1], g.bound_min[1], g.voxel_size);
+      const float zn = voxel_coord(raw[2], g.bound_min[2], g.voxel_size);
+      const int gx = (k & 1) ? (int)ceilf(xn) : (int)floorf(xn);
+      const int gy = (k & 2) ? (int)ceilf(yn) : (int)floorf(yn);
+      const int gz = (k & 4) ? (int)ceilf(zn) : (int)floorf(zn);
+      if (voxel_owner(gx, gy, gz, g) == g.shard_rank) {
+        n_own = true;
+        n_id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+        n_word = bitmap[n_id >> 5];
+        n_pref = word_prefix[n_id >> 5];
+      }
+      if (h == 0) {
+        nin[0] = relative_coord(xn, gx, g.voxel_size);
+        nin[1] = relative_coord(yn, gy, g.voxel_size);
+        nin[2] = relative_coord(zn, gz, g.voxel_size);
+        nin[3] = raw[3];
+      } else {
+        nin[0] = raw[4];
+        nin[1] = raw[5];
+      }
+    }
+  };
+  stage1(t0);
+  stage2(t0);
+  stage1(t0 + tstep);
+
+  for (int t = t0; t < n_tiles; t += tstep) {
+    // stage 3 (tile t): slot from the words fetched one MLP ago
+    float in[4];  // slots 0..3 of this lane half: features 4h .. 4h+3 of [rel(3), normal(3)]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) in[c] = nin[c];
+    const int slot = n_own ? (int)(n_pref + __popc(n_word & ((1u << (n_id & 31)) - 1u))) : -1;
+    stage2(t + tstep);      // consumes the point fetched one MLP ago, issues its bitmap / prefix loads
+    stage1(t + 2 * tstep);  // issues the next point load
+    __builtin_amdgcn_sched_barrier(0);
     if (__ballot(slot >= 0) == 0ULL) continue;
 
     // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots) -----------------------------
@@ -584,15 +645,7 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sh[nb * 2 + ksl], o, 0, 0, 0);
       }
     }
-    if (slot >= 0) {
-      long long* dst = acc + (size_t)slot * 8 + 4 * h;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long long v = __float2ll_rn(o[q] * kFixedScale);
-        atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v);
-      }
-      if (h == 0) atomicAdd(&counts[slot], 1);
-    }
+    scatter_tile(o, slot, j, h, counts, acc);
   }
 }
 

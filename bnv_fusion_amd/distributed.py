@@ -131,7 +131,7 @@ class HipShardBackend:
                                                 _lib.ptr(ws), ws.numel(), self._epoch, _lib.stream_ptr()),
                    "bnv_lattice_neighbors")
         _lib.check(v._lib.bnv_lattice_table(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._features),
-                                            _lib.ptr(self.pointnet.nerf.sdf_pack), n, _lib.ptr(ws), ws.numel(),
+                                            _lib.ptr(self.pointnet.nerf.sdf_pack), n, 0, _lib.ptr(ws), ws.numel(),
                                             _lib.stream_ptr()), "bnv_lattice_table")
         m = int(v.last_lattice_table_rows().item())
         off = int(v._lib.bnv_decode_lattice_list_offset(max(n, 1), v._row_capacity))

@@ -317,10 +317,16 @@ class SparseVolume:
         return out
 
     def last_lattice_table_rows(self):
-        """Device int32 tensor [1]: corner voxels whose 27-entry SDF table the last decode_lattice
-        call evaluated (27 MLP evaluations each)."""
+        """Device int32 tensor [1]: rows listed by the last bnv_lattice_neighbors(build_list) (sharded
+        path: 27 MLP evaluations each)."""
         off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
         return self._lattice_ws[off: off + 4].view(torch.int32)
+
+    def last_lattice_evals(self):
+        """Device int32 tensor [1]: SDF-MLP evaluations of the last decode_lattice call (table entries
+        read by live lattice points)."""
+        off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
+        return self._lattice_ws[off + 4: off + 8].view(torch.int32)
 
     def meshlize(self, nerf, sdf_delta=None, path=None):
         """sparse_volume.py:697-766.  The SDF lattice is decoded on the GPU; the per-voxel marching

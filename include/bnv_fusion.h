@@ -181,8 +181,9 @@ int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, co
                    float* out_sdf, bnv_stream_t stream);
 
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
-/* Byte offset, inside that workspace, of the int32 device counter holding the number of corner
- * voxels whose 27-entry table the last bnv_decode_lattice evaluated (for FLOP accounting). */
+/* Byte offset, inside that workspace, of two int32 device counters: [0] rows listed by
+ * bnv_lattice_neighbors(build_list), [1] table entries (= MLP evaluations) listed by bnv_lattice_mark /
+ * evaluated by the last bnv_decode_lattice (for FLOP accounting). */
 size_t bnv_decode_lattice_count_offset(int64_t row_capacity);
 /* The same decode for the 3x3x3 lattice {-0.5,0,0.5}^3 around n integer voxel origins
  * (SparseVolume.meshlize's decode_pts call, sparse_volume.py:717-738): out [n,27] f32.
@@ -198,13 +199,17 @@ int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
  *              min_pts); with build_list, appends each distinct usable row (not flagged in
  *              row_skip) to the work list;
- *   table:     table[row][27] = SDF-MLP(enc(l), features[row]) * voxel for every listed row;
+ *   mark:      (single-volume path) flags the (row, l) table entries read by LIVE lattice points --
+ *              all 8 corner voxels usable -- and lists them; masked points cost no MLP work;
+ *   table:     table[row][l] = SDF-MLP(enc(l), features[row]) * voxel for every listed entry
+ *              (use_entries) or all 27 l of every listed row;
  *   blend:     out[n,27] from the neighbour rows and the table. */
 int bnv_lattice_neighbors(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* weights,
                           int64_t row_limit, const int64_t* origins, int64_t n, const uint8_t* row_skip,
                           int build_list, void* ws, size_t ws_bytes, int32_t epoch, bnv_stream_t stream);
+int bnv_lattice_mark(const bnv_volume_t* vol_host, int64_t n, void* ws, size_t ws_bytes, bnv_stream_t stream);
 int bnv_lattice_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
-                      const float* sdfmlp_pack, int64_t n_voxels, void* ws, size_t ws_bytes,
+                      const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws, size_t ws_bytes,
                       bnv_stream_t stream);
 int bnv_lattice_blend(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const int64_t* origins,
                       int64_t n, const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, float* out_sdf,
