@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
+    ap.add_argument("--parallelism", default="frame", choices=["frame", "spatial"],
+                    help="N > 1: 'frame' = ranks encode/decode different frames of a batch, replicated volume, one "
+                         "all-gather per batch (throughput scaling); 'spatial' = voxels sharded by spatial hash, "
+                         "table all-gather per frame")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,18 +101,28 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    # one rank per GPU; BNV_DIST_BACKEND=gloo lets several ranks share a GPU for functional testing
+    backend = os.environ.get("BNV_DIST_BACKEND", "nccl")
+    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_dev)
+    dev = f"cuda:{local_dev}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     import bnv_fusion_amd as bnv
     from bnv_fusion_amd import synthetic, _lib
 
     dims, voxel = synthetic.GRID_DIMS[args.grid]
     model = bnv.load_pretrained(device=dev, voxel_size=voxel)
-    if world > 1:
+    frame_parallel = world > 1 and args.parallelism == "frame"
+    if frame_parallel:
+        from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
+    elif world > 1:
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
     else:
@@ -120,27 +134,44 @@ def main():
     frames = [{"input_pts": torch.from_numpy(f).to(dev)} for f in frames_host]
     n_points = int(frames_host[0].shape[1])
 
-    for t in range(args.preroll):                       # setup: make the decode mask live
-        nm.integrate(frames[t])
+    def run_frames(first, count, decode=True):
+        """Processes frames [first, first+count) in order; returns this rank's last (coords, sdf)."""
+        last = (None, None)
+        if frame_parallel:
+            for t0 in range(first, first + count, world):
+                out = nm.process_batch(frames[t0: min(t0 + world, first + count)], decode=decode)
+                if out[0] is not None:
+                    last = out
+        else:
+            for t in range(first, first + count):
+                last = nm.fuse_and_decode(frames[t]) if decode else (nm.integrate(frames[t]), None)
+        return last
+
+    run_frames(0, args.preroll, decode=False)           # setup: make the decode mask live
 
     lib = _lib.load()
 
     def timed(mode, first, steps, warm):
         """`warm` untimed frames, then times exactly `steps` frames from index `first`, in MLP mode `mode`."""
         bnv.set_mlp_mode(mode)
-        for t in range(first - warm, first):
-            nm.fuse_and_decode(frames[t])
+        run_frames(first - warm, warm)
         lib.bnv_profile_enable(1)
         table_rows, n_vox = [], []
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for t in range(first, first + steps):
-            coords, sdf = nm.fuse_and_decode(frames[t])
-            table_rows.append((nm.volume.last_lattice_table_rows() * 27 if world > 1
-                               else nm.volume.last_lattice_evals()).clone())   # async 4-byte device copy
+        if frame_parallel:
+            coords, sdf = run_frames(first, steps)
+            table_rows.append(nm.volume.last_lattice_evals().clone() if coords is not None
+                              else torch.zeros(1, dtype=torch.int32, device=dev))
             n_vox.append(0 if coords is None else int(coords.shape[0]))
+        else:
+            for t in range(first, first + steps):
+                coords, sdf = nm.fuse_and_decode(frames[t])
+                table_rows.append((nm.volume.last_lattice_table_rows() * 27 if world > 1
+                                   else nm.volume.last_lattice_evals()).clone())   # async 4-byte device copy
+                n_vox.append(0 if coords is None else int(coords.shape[0]))
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -208,7 +239,11 @@ def main():
                        "mlp_mode": MODE_NAME[m],
                        "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
                        "decode_live_fraction": main_run["live"],
-                       "parallelism": "1 GPU" if world == 1 else f"spatial-hash voxel sharding x{world} + RCCL all-gather"},
+                       "parallelism": ("1 GPU" if world == 1 else
+                                       f"frame-parallel x{world}: ranks encode/decode different frames of a batch, "
+                                       "replicated volume, one RCCL all-gather of encoded voxels per batch"
+                                       if frame_parallel else
+                                       f"spatial-hash voxel sharding x{world} + RCCL all-gather of SDF tables per frame")},
             # dominant kernel: the lattice-table SDF MLP.  achieved = algorithmic FLOPs (402,432 per MLP
             # evaluation x evaluations per launch; the split mode issues 3 MFMA products per algorithmic
             # product, which are NOT counted) / mean kernel time from HIP events on the launch stream

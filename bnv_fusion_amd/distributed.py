@@ -199,3 +199,110 @@ class ShardedNeuralMap:
             rec_c = all_gather_var(rc, self.group)
             sdf = self.backend.install_and_blend(owned, rec_c, rec[:, 0].contiguous(), rec[:, 1:].contiguous())
         return owned, sdf
+
+
+# =============================================================================================
+# Frame-parallel mode: throughput scaling of one frame stream
+# =============================================================================================
+class HipFrameBackend:
+    """Full (replicated) volume on one GPU; the three per-frame phases as separate calls."""
+
+    def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, capacity=1 << 20, device="cuda:0"):
+        from .sparse_volume import SparseVolume
+        self.pointnet = pointnet
+        self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
+        self.dev = self.volume._dev
+
+    def encode(self, frame):
+        """-> (coords [n,3] i64, counts [n] i64, feats [n,8] f32, n_avg float tensor) of one frame."""
+        v = self.volume
+        self.pointnet.shard = (0, 1, BLOCK_LOG2)
+        f, c, _, g, n_avg = self.pointnet.encode_pointcloud(frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
+                                                            v.voxel_size, return_dense=False)
+        if f is None:
+            z = torch.zeros
+            return (z((0, 3), dtype=torch.int64, device=self.dev), z(0, dtype=torch.int64, device=self.dev),
+                    z((0, 8), device=self.dev), z((), device=self.dev))
+        return g, c.reshape(-1), f, n_avg
+
+    def integrate(self, coords, counts, feats, n_avg):
+        if coords.shape[0] == 0:
+            return
+        self.volume.track_n_pts(n_avg)
+        self.volume.integrate(coords, feats, counts)
+
+    def decode(self, coords):
+        return self.volume.decode_lattice(coords, self.pointnet.nerf, None, query_tensor=False)
+
+
+class FrameParallelNeuralMap:
+    """N ranks process a batch of up to N consecutive frames together:
+
+      1. rank r encodes frame r of the batch (encode_pointcloud is a pure function of the frame);
+      2. ONE variable-size all-gather of the encoded voxels (coords, count, 8 features = 64 B each,
+         plus one header row per rank carrying n_avg_pts);
+      3. every rank replays _integrate for all frames of the batch IN FRAME ORDER on its replicated
+         volume, and decodes the lattice of frame r right after integrating frame r.
+
+    Every volume goes through exactly the single-GPU sequence of states, so all outputs equal the
+    one-GPU run; decode (the largest kernel) and encode are spread over the ranks, only the cheap
+    upserts are replicated."""
+
+    def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
+                 group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = backend or HipFrameBackend(dimensions, voxel_size, pointnet, min_pts_in_grid, device=device)
+        self.volume = getattr(self.backend, "volume", None)
+
+    @staticmethod
+    def _pack(coords, counts, feats, n_avg):
+        n = coords.shape[0]
+        rec = torch.zeros((n + 1, 8), dtype=torch.int64, device=coords.device)
+        rec[0, 0] = n
+        rec[0, 1:2] = n_avg.reshape(1).float().view(torch.int32).long()
+        rec[1:, :3] = coords
+        rec[1:, 3] = counts
+        rec[1:, 4:] = feats.contiguous().view(torch.int64).reshape(n, 4)
+        return rec
+
+    @staticmethod
+    def _unpack(rec):
+        coords = rec[1:, :3].contiguous()
+        counts = rec[1:, 3].contiguous()
+        feats = rec[1:, 4:].contiguous().view(torch.float32).reshape(-1, 8)
+        n_avg = rec[0, 1:2].int().view(torch.float32)[0]
+        return coords, counts, feats, n_avg
+
+    def process_batch(self, frames, decode=True):
+        """frames: list of up to `world` frame dicts, the SAME list on every rank.
+        Returns (coords, sdf) of the frame this rank decoded (None, None if it had none)."""
+        import torch.distributed as dist
+        b = len(frames)
+        assert 1 <= b <= self.world
+        with torch.no_grad():
+            if self.rank < b:
+                rec = self._pack(*self.backend.encode(frames[self.rank]))
+            else:
+                rec = torch.zeros((0, 8), dtype=torch.int64, device=self._dev())
+            sizes = torch.zeros(self.world, dtype=torch.int64, device=rec.device)
+            sizes[self.rank] = rec.shape[0]
+            dist.all_reduce(sizes, group=self.group)
+            sizes = sizes.tolist()
+            m = max(max(sizes), 1)
+            pad = torch.zeros((m, 8), dtype=torch.int64, device=rec.device)
+            pad[: rec.shape[0]] = rec
+            out = torch.empty((self.world, m, 8), dtype=torch.int64, device=rec.device)
+            dist.all_gather_into_tensor(out.view(-1, 8), pad, group=self.group)
+            mine = (None, None)
+            for s in range(b):
+                coords, counts, feats, n_avg = self._unpack(out[s, : sizes[s]])
+                self.backend.integrate(coords, counts, feats, n_avg)
+                if decode and s == self.rank:
+                    mine = (coords, self.backend.decode(coords))
+        return mine
+
+    def _dev(self):
+        return getattr(self.backend, "dev", torch.device("cpu"))

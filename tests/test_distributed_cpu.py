@@ -138,3 +138,73 @@ def test_owner_hash_is_balanced_and_blocked():
     key = (blk[:, 0] * 8 + blk[:, 1]) * 8 + blk[:, 2]
     for k in np.unique(key)[:20]:
         assert len(np.unique(o[key == k])) == 1           # whole 8^3 blocks share an owner
+
+
+# ---------------------------------------------------------------------------------------------
+# frame-parallel mode
+# ---------------------------------------------------------------------------------------------
+class OracleFrameBackend:
+    def __init__(self, dims, voxel):
+        from oracle import bnv_oracle as orc
+        self.orc = orc
+        self.sd = orc.load_weights(WEIGHTS_FP32)
+        self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+        self.dev = torch.device("cpu")
+
+    def encode(self, frame):
+        v = self.vol
+        f, c, _, g, n = self.orc.encode_pointcloud(self.sd, frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
+                                                   v.voxel_size)
+        return g, c.reshape(-1), f, n
+
+    def integrate(self, coords, counts, feats, n_avg):
+        self.vol.track_n_pts(n_avg)
+        self.orc.integrate(self.vol, coords, feats, counts.reshape(-1, 1))
+
+    def decode(self, coords):
+        o = self.orc      # a sample of the voxels keeps the CPU suite fast; the exchange logic is what is tested
+        return self.vol.decode_pts(o.lattice_coords(coords.numpy()[::12]), self.sd, None, is_coords=True,
+                                   query_tensor=False)[0, :, :, 0]
+
+
+def _fp_worker(rank, world, port, frames, dims, voxel, ret):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+    nm = FrameParallelNeuralMap(dims, voxel, None, backend=OracleFrameBackend(dims, voxel))
+    outs = []
+    fr = [{"input_pts": torch.from_numpy(f)} for f in frames]
+    for t0 in range(0, len(fr), world):              # the last batch is ragged (11 frames, world 2)
+        c, sdf = nm.process_batch(fr[t0: t0 + world])
+        if c is not None:
+            outs.append((t0 + rank, c.numpy(), sdf.numpy()))
+    ret[rank] = (outs, np.asarray(nm.backend.vol.n_pts_list), len(nm.backend.vol._keys))
+    dist.destroy_process_group()
+
+
+def test_frame_parallel_equals_single_process():
+    from oracle import bnv_oracle as orc
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    frames = list(z["frames"])[:11]
+    dims, voxel = z["dims"], float(z["voxel_size"])
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_fp_worker, args=(2, _free_port(), frames, dims, voxel, ret), nprocs=2, join=True)
+        got = {t: (c, s) for r in (0, 1) for t, c, s in ret[r][0]}
+        npts = [ret[r][1] for r in (0, 1)]
+        nkeys = [ret[r][2] for r in (0, 1)]
+    sd = orc.load_weights(WEIGHTS_FP32)
+    vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    assert sorted(got) == list(range(11))            # every frame decoded exactly once
+    for t, fr in enumerate(frames):
+        f, c, _, g, n = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
+        vol.track_n_pts(n)
+        orc.integrate(vol, g, f, c)
+        ref = vol.decode_pts(orc.lattice_coords(g.numpy()[::12]), sd, None, is_coords=True,
+                             query_tensor=False)[0, :, :, 0]
+        assert np.array_equal(got[t][0], g.numpy())
+        assert np.array_equal(got[t][1], ref.numpy())           # same ops in the same order: bit-identical
+    assert nkeys[0] == nkeys[1] == len(vol._keys)               # replicated volumes stay in lock step
+    assert np.allclose(npts[0], vol.n_pts_list) and np.allclose(npts[1], vol.n_pts_list)
