@@ -32,6 +32,26 @@ DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate"}
 
 
+def pmc_traffic_bytes(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_summary.csv; separate --pmc runs): 2 x FETCH_SIZE + WRITE_SIZE, in KB
+    units, FETCH doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
+    if not os.path.exists(path):
+        return None
+    fetch = write = None
+    for line in open(path):
+        if kernel_substr in line:
+            parts = line.strip().rsplit(",", 3)
+            if parts[1] == "FETCH_SIZE":
+                fetch = float(parts[2])
+            elif parts[1] == "WRITE_SIZE":
+                write = float(parts[2])
+    if fetch is None or write is None:
+        return None
+    return (2.0 * fetch + write) * 1024.0
+
+
 def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
     """The oracle (PyTorch-CPU restatement of the reference) timed on this box's host cores on a
     bounded sample: one full-frame encode + integrate, and the lattice decode of
@@ -249,7 +269,10 @@ def main():
             # product, which are NOT counted) / mean kernel time from HIP events on the launch stream
             "roofline": {"bound": "mfma", "kernel": f"k_decode<LATTICE,{MODE_NAME[m]}> (SDF MLP 17-256x4-1)",
                          "achieved": main_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": main_run["dec_tflops"] / peak, "traffic": None,
+                         "frac": main_run["dec_tflops"] / peak,
+                         "traffic": pmc_traffic_bytes("k_decode<1, 1>") if (m == 1 and world == 1) else None,
+                         "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv); "
+                                         "algorithmic bytes = 40 B x evaluations",
                          "avg_kernel_ms": main_run["dec_ms"], "flop_per_launch": main_run["dec_flop"],
                          "mlp_evals_per_launch": main_run["rows"],
                          "mfma_issue_frac": main_run["dec_tflops"] * (3 if m == 1 else 1) / peak},
