@@ -52,9 +52,9 @@ def pmc_traffic_bytes(kernel_substr):
     return (2.0 * fetch + write) * 1024.0
 
 
-def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
+def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
     """The oracle (PyTorch-CPU restatement of the reference) timed on this box's host cores on a
-    bounded sample: one full-frame encode + integrate, and the lattice decode of
+    bounded sample: one full frame depth -> points + encode + integrate, and the lattice decode of
     ``n_decode_voxels`` voxels scaled to the frame's voxel count."""
     from oracle import bnv_oracle as orc           # checker / baseline only
     from bnv_fusion_amd import synthetic
@@ -63,7 +63,11 @@ def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
     vol = orc.OracleSparseVolume(8, voxel, np.array([dims] * 3), 8)
     # thread count: the fastest of a few candidates on a 40k-point encode (all cores is NOT the
     # fastest on a many-core host), so the baseline is not handicapped
-    probe = torch.from_numpy(frames_host[0])[:, :40000]
+    t0 = time.perf_counter()
+    pts_np = orc.depth_to_input_pts(depth_mm.astype(np.float64) / 1000.0, intr, T_wc)
+    t_front = time.perf_counter() - t0
+    frame0 = pts_np.astype(np.float32)[None]
+    probe = torch.from_numpy(frame0)[:, :40000]
     best = None
     for th in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128, 256)}):
         torch.set_num_threads(th)
@@ -76,7 +80,7 @@ def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
             best = (dt, th)
     threads = best[1]
     torch.set_num_threads(threads)
-    pts = torch.from_numpy(frames_host[0])
+    pts = torch.from_numpy(frame0)
     with torch.no_grad():
         t0 = time.perf_counter()
         f, c, ids, g, n = orc.encode_pointcloud(sd, pts, vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
@@ -88,12 +92,12 @@ def cpu_baseline(frames_host, grid, n_decode_voxels=1500):
         t0 = time.perf_counter()
         vol.decode_pts(orc.lattice_coords(sel.numpy()), sd, None, is_coords=True, query_tensor=False)
         t_dec = (time.perf_counter() - t0) * len(g) / len(sel)
-    total = t_enc + t_int + t_dec
+    total = t_front + t_enc + t_int + t_dec
     return {"value": 1.0 / total, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle (PyTorch-CPU fp32 restatement, {threads} threads): 1 full 640x480 frame encode "
-                       f"{t_enc:.2f}s + integrate {t_int:.2f}s + lattice decode of {len(sel)} of {len(g)} voxels "
-                       f"scaled to the frame = {t_dec:.2f}s"),
-            "encode_s": t_enc, "integrate_s": t_int, "decode_s_scaled": t_dec}
+            "sample": (f"oracle (PyTorch-CPU fp32 restatement, {threads} threads; numpy float64 front end): 1 full "
+                       f"640x480 frame depth->points {t_front:.2f}s + encode {t_enc:.2f}s + integrate {t_int:.2f}s + "
+                       f"lattice decode of {len(sel)} of {len(g)} voxels scaled to the frame = {t_dec:.2f}s"),
+            "front_end_s": t_front, "encode_s": t_enc, "integrate_s": t_int, "decode_s_scaled": t_dec}
 
 
 def main():
@@ -109,6 +113,9 @@ def main():
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
+    ap.add_argument("--input", default="depth", choices=["depth", "points"],
+                    help="'depth' (default): a step starts from the uint16 depth image resident in HBM and runs the "
+                         "GPU front end (unprojection + normals); 'points': from precomputed input_pts")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "spatial"],
                     help="N > 1: 'frame' = ranks encode/decode different frames of a batch, replicated volume, one "
                          "all-gather per batch (throughput scaling); 'spatial' = voxels sharded by spatial hash, "
@@ -150,9 +157,16 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
     n_frames = args.preroll + args.warmup + args.steps
-    frames_host = [synthetic.frame(t) for t in range(n_frames)]
-    frames = [{"input_pts": torch.from_numpy(f).to(dev)} for f in frames_host]
-    n_points = int(frames_host[0].shape[1])
+    depth_host = [synthetic.depth_u16(t) for t in range(n_frames)]
+    intr = synthetic.intrinsics()
+    if args.input == "depth":
+        frames = [{"depth": torch.from_numpy(d).to(dev), "intr_mat": intr, "T_wc": synthetic.pose(t)}
+                  for t, d in enumerate(depth_host)]
+    else:
+        frames = [{"input_pts": torch.from_numpy(synthetic.depth_to_input_pts(
+            d.astype(np.float64) / 1000.0, intr, synthetic.pose(t)).astype(np.float32)[None]).to(dev)}
+            for t, d in enumerate(depth_host)]
+    n_points = int((depth_host[0] > 0).sum())
 
     def run_frames(first, count, decode=True):
         """Processes frames [first, first+count) in order; returns this rank's last (coords, sdf)."""
@@ -253,8 +267,11 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": DTYPE[m], "data": "synthetic",
             "config": {"workload": f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, "
-                                   f"voxel {voxel}, fp32 pointnet.ckpt weights; step = encode_pointcloud + "
-                                   "_integrate + decode of the 3x3x3 lattice of every touched voxel",
+                                   f"voxel {voxel}, fp32 pointnet.ckpt weights; step = "
+                                   + ("uint16 depth image -> points + normals (GPU front end) + "
+                                      if args.input == "depth" else "")
+                                   + "encode_pointcloud + _integrate + decode of the 3x3x3 lattice of every "
+                                     "touched voxel",
                        "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
                        "mlp_mode": MODE_NAME[m],
                        "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
@@ -289,7 +306,7 @@ def main():
                                      "decode_frac_of_peak": alt["dec_tflops"] / PEAK_TFLOPS[am],
                                      "pointnet_kernel_ms": alt["enc_ms"], "pointnet_tflops": alt["enc_tflops"]}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_host, args.grid)
+            out["cpu_baseline"] = cpu_baseline(depth_host[0], intr, synthetic.pose(0), args.grid)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -110,8 +110,9 @@ class HipShardBackend:
     def encode_integrate(self, frame):
         v = self.volume
         self.pointnet.shard = (self.rank, self.world, BLOCK_LOG2)
+        from .neural_map import frame_input_pts
         f, c, _, coords, n_avg = self.pointnet.encode_pointcloud(
-            frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, return_dense=False)
+            frame_input_pts(frame), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, return_dense=False)
         if f is None:
             return torch.zeros((0, 3), dtype=torch.int64, device=self.dev)
         v.track_n_pts(n_avg)
@@ -217,8 +218,9 @@ class HipFrameBackend:
         """-> (coords [n,3] i64, counts [n] i64, feats [n,8] f32, n_avg float tensor) of one frame."""
         v = self.volume
         self.pointnet.shard = (0, 1, BLOCK_LOG2)
-        f, c, _, g, n_avg = self.pointnet.encode_pointcloud(frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
-                                                            v.voxel_size, return_dense=False)
+        from .neural_map import frame_input_pts
+        f, c, _, g, n_avg = self.pointnet.encode_pointcloud(frame_input_pts(frame), v.n_xyz, v.min_coords,
+                                                            v.max_coords, v.voxel_size, return_dense=False)
         if f is None:
             z = torch.zeros
             return (z((0, 3), dtype=torch.int64, device=self.dev), z(0, dtype=torch.int64, device=self.dev),

@@ -11,6 +11,18 @@ import torch
 from .sparse_volume import SparseVolume
 
 
+def frame_input_pts(frame, max_depth=10.0):
+    """``frame['input_pts']`` if present (the reference's dataset output), else built on the GPU from
+    ``frame['depth']`` (uint16 mm or float metres), ``frame['intr_mat']`` and ``frame['T_wc']`` by the
+    front-end kernel (csrc/frontend.hip) -- without a host read: invalid pixels are NaN rows that the
+    encoder's bounds mask drops."""
+    if "input_pts" in frame:
+        return frame["input_pts"]
+    from .frontend import depth_to_input_pts
+    pts, _ = depth_to_input_pts(frame["depth"], frame["intr_mat"], frame["T_wc"], max_depth=max_depth, compact=False)
+    return pts
+
+
 class NeuralMap:
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
                  capacity=100000, device="cuda:0"):
@@ -22,13 +34,15 @@ class NeuralMap:
         self.sdf_delta = None
 
     def integrate(self, frame):
-        """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU.
+        """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU (or a depth frame, see
+        frame_input_pts).
         Returns the voxel coordinates the frame touched ([U', 3] int64) or None."""
-        if len(frame["input_pts"]) == 0:
+        input_pts = frame_input_pts(frame)
+        if len(input_pts) == 0:
             return None
         with torch.no_grad():
             fine_feats, fine_weights, _, fine_coords, fine_n_pts = self.pointnet.encode_pointcloud(
-                frame["input_pts"], self.volume.n_xyz, self.volume.min_coords, self.volume.max_coords,
+                input_pts, self.volume.n_xyz, self.volume.min_coords, self.volume.max_coords,
                 self.volume.voxel_size, return_dense=self.pointnet.dense_volume)
             if fine_feats is None:
                 return None

