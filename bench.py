@@ -153,7 +153,8 @@ def main():
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
     else:
-        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=1 << 20, device=dev)
+        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=1 << 20, device=dev,
+                           tsdf=(args.input == "depth"))
 
     # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
     n_frames = args.preroll + args.warmup + args.steps
@@ -270,7 +271,9 @@ def main():
                                    f"voxel {voxel}, fp32 pointnet.ckpt weights; step = "
                                    + ("uint16 depth image -> points + normals (GPU front end) + "
                                       if args.input == "depth" else "")
-                                   + "encode_pointcloud + _integrate + decode of the 3x3x3 lattice of every "
+                                   + "encode_pointcloud + _integrate + "
+                                   + ("TSDF side fusion at 0.025 m + " if (args.input == "depth" and world == 1) else "")
+                                   + "decode of the 3x3x3 lattice of every "
                                      "touched voxel",
                        "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
                        "mlp_mode": MODE_NAME[m],

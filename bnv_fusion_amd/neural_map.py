@@ -25,13 +25,36 @@ def frame_input_pts(frame, max_depth=10.0):
 
 class NeuralMap:
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
-                 capacity=100000, device="cuda:0"):
+                 capacity=100000, device="cuda:0", tsdf=False, truncated_units=10, sdf_delta_weight=0.1):
         self.pointnet = pointnet
         self.volume = SparseVolume(feature_vector_size, voxel_size, dimensions, min_pts_in_grid,
                                    capacity=capacity, device=device)
         self.voxel_size = voxel_size
         self.dimensions = dimensions
         self.sdf_delta = None
+        self.tsdf_vol = None
+        self.tsdf_voxel_size = 0.025                                      # run_e2e.py:58
+        self.truncated_dist = min(truncated_units * voxel_size * 0.5, 0.1)  # run_e2e.py:54
+        self.sdf_delta_weight = sdf_delta_weight                          # fusion_pointnet_model.yaml:44,47
+        if tsdf:                                                          # run_e2e.py:60-71
+            import numpy as np
+            from .sparse_volume import get_world_range
+            from .tsdf import TSDFVolume
+            mn, mx, _ = get_world_range(dimensions, self.tsdf_voxel_size)
+            self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), self.tsdf_voxel_size, device=device)
+
+    def prepare_tsdf_volume(self):
+        """run_e2e.py:169-186 -> sdf_delta [1, 1, X, Y, Z] for decode_pts / meshlize."""
+        return self.tsdf_vol.sdf_delta(self.truncated_dist, self.sdf_delta_weight)
+
+    def _integrate_tsdf(self, frame):
+        """run_e2e.py:99-109: TSDF side fusion of the same frame (depth in metres, no colour here)."""
+        if self.tsdf_vol is None or "depth" not in frame:
+            return
+        d = frame["depth"]
+        if d.dtype in (torch.uint16, torch.int16):
+            d = d.to(torch.float32) / 1000.0
+        self.tsdf_vol.integrate(frame.get("rgb"), d, frame["intr_mat"], frame["T_wc"], obs_weight=1.)
 
     def integrate(self, frame):
         """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU (or a depth frame, see
@@ -48,6 +71,7 @@ class NeuralMap:
                 return None
             self.volume.track_n_pts(fine_n_pts)
             self.pointnet._integrate(self.volume, fine_coords, fine_feats, fine_weights)
+            self._integrate_tsdf(frame)
         return fine_coords
 
     def fuse_and_decode(self, frame):
@@ -62,4 +86,5 @@ class NeuralMap:
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""
         self.volume.to_tensor()
-        return self.volume.meshlize(self.pointnet.nerf, self.sdf_delta)
+        delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
+        return self.volume.meshlize(self.pointnet.nerf, delta)

@@ -1,0 +1,57 @@
+"""TSDFVolume -- drop-in for the reference's third_parties/fusion.py:19-300 on MI355X
+(SURVEY.md section 8 f-1).  Same constructor and ``integrate`` / ``get_volume`` surface; the volumes live on
+the GPU (``get_volume`` copies to host arrays like the reference's GPU mode does)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class TSDFVolume:
+    def __init__(self, vol_bnds, voxel_size, use_gpu=True, device="cuda:0"):
+        vol_bnds = np.asarray(vol_bnds, dtype=np.float64).copy()
+        assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
+        self._dev = torch.device(device)
+        self._lib = _lib.require_device(self._dev.index or 0)
+        self._vol_bnds = vol_bnds
+        self._voxel_size = float(voxel_size)
+        self._trunc_margin = 5 * self._voxel_size                      # fusion.py:36
+        self._color_const = 256 * 256
+        self._vol_dim = np.ceil((vol_bnds[:, 1] - vol_bnds[:, 0]) / self._voxel_size).copy(order="C").astype(int)
+        self._vol_bnds[:, 1] = self._vol_bnds[:, 0] + self._vol_dim * self._voxel_size
+        self._vol_origin = self._vol_bnds[:, 0].copy(order="C").astype(np.float32)
+        dims = tuple(int(v) for v in self._vol_dim)
+        # fusion.py:51-55: tsdf initialised to -trunc_margin (ones * 0 - margin), weights and colour to 0
+        self.tsdf = torch.full(dims, -self._trunc_margin, dtype=torch.float32, device=self._dev)
+        self.weight = torch.zeros(dims, dtype=torch.float32, device=self._dev)
+        self.color = torch.zeros(dims, dtype=torch.float32, device=self._dev)
+        self.gpu_mode = True
+
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):
+        """fusion.py:208-250.  depth_im [H, W] metres (numpy or tensor); color_im [H, W, 3] in [0, 255] or None."""
+        depth = torch.as_tensor(depth_im).to(self._dev, torch.float32).contiguous()
+        im_h, im_w = int(depth.shape[0]), int(depth.shape[1])
+        col = None
+        if color_im is not None:
+            c = torch.as_tensor(color_im).to(self._dev, torch.float32)
+            col = torch.floor(c[..., 2] * self._color_const + c[..., 1] * 256 + c[..., 0]).contiguous()  # :223-224
+        dim = (C.c_int32 * 3)(*[int(v) for v in self._vol_dim])
+        org = (C.c_float * 3)(*self._vol_origin.tolist())
+        intr = (C.c_float * 9)(*np.asarray(cam_intr, dtype=np.float64)[:3, :3].reshape(-1).astype(np.float32).tolist())
+        pose = (C.c_float * 16)(*np.asarray(cam_pose, dtype=np.float64).reshape(-1).astype(np.float32).tolist())
+        _lib.check(self._lib.bnv_tsdf_integrate(
+            _lib.ptr(self.tsdf), _lib.ptr(self.weight), _lib.ptr(self.color if col is not None else None), dim, org,
+            np.float32(self._voxel_size), np.float32(self._trunc_margin), _lib.ptr(depth), _lib.ptr(col), im_h, im_w,
+            intr, pose, float(obs_weight), _lib.stream_ptr()), "bnv_tsdf_integrate")
+
+    def get_volume(self):
+        return self.tsdf.cpu().numpy(), self.color.cpu().numpy()
+
+    def sdf_delta(self, truncated_dist, sdf_delta_weight=1.0):
+        """NeuralMap.prepare_tsdf_volume (run_e2e.py:169-186) without leaving the GPU:
+        tsdf * (voxel * 5), clipped to +-truncated_dist, times sdf_delta_weight -> [1, 1, X, Y, Z]."""
+        v = self.tsdf * (self._voxel_size * 5)
+        v = torch.clip(v[None, None], min=-truncated_dist, max=truncated_dist)
+        return v * sdf_delta_weight

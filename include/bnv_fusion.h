@@ -112,6 +112,16 @@ int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const 
                         const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes,
                         float* out_pts, int32_t* n_out, bnv_stream_t stream);
 
+/* ---- TSDF side fusion: TSDFVolume.integrate (third_parties/fusion.py:68-141, called per frame from
+ * run_e2e.py:99-109).  tsdf / weight / color [dx,dy,dz] f32 (color may be NULL); depth_im [h,w] f32 metres
+ * (0 = invalid); color_im [h,w] f32 folded b*65536+g*256+r or NULL; intr 3x3 and pose 4x4 row-major f32 on
+ * the HOST; trunc_margin = 5 * voxel_size in the reference. */
+int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+                       const float origin_host[3], float voxel_size, float trunc_margin,
+                       const float* depth_im, const float* color_im, int im_h, int im_w,
+                       const float intr_host[9], const float pose_host[16], float obs_weight,
+                       bnv_stream_t stream);
+
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
 /* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points.  The scratch is

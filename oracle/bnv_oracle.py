@@ -448,6 +448,42 @@ def depth_to_input_pts(depth, intr, T_wc, max_depth=10.0):
     return out[mask.reshape(-1)]
 
 
+def tsdf_integrate(tsdf, weight, vol_origin, voxel_size, depth_im, cam_intr, cam_pose, obs_weight=1.0):
+    """TSDFVolume.integrate as its inline CUDA kernel computes it (third_parties/fusion.py:68-126), in
+    numpy float32, un-fused multiply-adds.  PARITY UNPINNED: the kernel needs pycuda, its CPU twin needs
+    numba, neither exists here; anchored on the source and on the call site run_e2e.py:99-109.
+    tsdf / weight [X, Y, Z] float32 are updated in place; colour is not restated."""
+    f = np.float32
+    X, Y, Z = tsdf.shape
+    vx, vy, vz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
+    org = np.asarray(vol_origin, dtype=f)
+    vs = f(voxel_size)
+    trunc = f(5 * float(voxel_size))
+    K = np.asarray(cam_intr, dtype=np.float64)[:3, :3].astype(f)
+    P = np.asarray(cam_pose, dtype=np.float64).astype(f)
+    pt = [org[i] + v.astype(f) * vs for i, v in enumerate((vx, vy, vz))]
+    t = [pt[i] - P[i, 3] for i in range(3)]
+    cam = [(P[0, i] * t[0] + P[1, i] * t[1]) + P[2, i] * t[2] for i in range(3)]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ux = K[0, 0] * (cam[0] / cam[2]) + K[0, 2]
+        uy = K[1, 1] * (cam[1] / cam[2]) + K[1, 2]
+    rnd = lambda a: np.where(np.isfinite(a), np.sign(a) * np.floor(np.abs(a) + f(0.5)), -1).astype(np.int64)  # roundf
+    px, py = rnd(ux), rnd(uy)
+    H, W = depth_im.shape
+    ok = (px >= 0) & (px < W) & (py >= 0) & (py < H) & ~(cam[2] < 0)
+    d = np.zeros_like(cam[2])
+    d[ok] = np.asarray(depth_im, dtype=f)[py[ok], px[ok]]
+    ok &= d != 0
+    diff = d - cam[2]
+    ok &= ~(diff < -trunc)
+    dist = np.minimum(f(1.0), diff / trunc)
+    w_old = weight[ok]
+    w_new = w_old + f(obs_weight)
+    weight[ok] = w_new
+    tsdf[ok] = (tsdf[ok] * w_old + f(obs_weight) * dist[ok]) / w_new
+    return tsdf, weight
+
+
 def synthetic_depth(t, H=480, W=640, seed=0):
     """depth(u,v) = 1.5 + 0.2 sin(u/40) cos(v/30) + N(0, 0.002) m,
     quantised to uint16 millimetres as the datasets store it (common.py:93)."""

@@ -427,3 +427,53 @@ def test_depth_front_end_feeds_encode_identically(bnv, orc):
     full, n = depth_to_input_pts(torch.from_numpy(mm).to(DEV), intr, T, compact=False)
     c = _encode(model, vol, full)                      # NaN-padded rows are masked out
     assert torch.equal(a[2], c[2]) and torch.equal(a[0], c[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# TSDF side fusion
+# ---------------------------------------------------------------------------------------------
+def test_tsdf_integrate_vs_oracle(bnv, orc):
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.tsdf import TSDFVolume
+    dims = np.array([2.54] * 3)
+    mn, mx, _ = bnv.get_world_range(dims, 0.025)                 # run_e2e.py:62-71
+    bnds = np.stack([mn, mx], 1)
+    vol = TSDFVolume(bnds.copy(), 0.025, device=DEV)
+    tsdf = np.full(tuple(vol._vol_dim), -vol._trunc_margin, dtype=np.float32)
+    wgt = np.zeros_like(tsdf)
+    for t in range(3):
+        depth = synthetic.depth_u16(t).astype(np.float32) / 1000.0
+        depth[50:80, 100:160] = 0
+        vol.integrate(None, depth, synthetic.intrinsics(), synthetic.pose(t), obs_weight=1.0)
+        orc.tsdf_integrate(tsdf, wgt, vol._vol_origin, 0.025, depth, synthetic.intrinsics(), synthetic.pose(t))
+    got, _ = vol.get_volume()
+    gw = vol.weight.cpu().numpy()
+    # identical fp32 op order; a voxel projecting within rounding of a pixel boundary may pick the other pixel
+    same_w = np.mean(gw == wgt)
+    assert same_w > 0.9999, same_w
+    close = np.abs(got - tsdf) <= 1e-6
+    assert np.mean(close) > 0.999, np.mean(close)
+    assert (gw > 0).sum() > 1000
+    sd = vol.sdf_delta(truncated_dist=0.025)
+    assert sd.shape == (1, 1) + tuple(vol._vol_dim) and float(sd.abs().max()) <= 0.025 + 1e-7
+
+
+def test_neural_map_depth_frames_with_tsdf_prior(bnv):
+    """The run_e2e.py loop shape on depth frames: front end + encode + _integrate + TSDF, then
+    extract_sdf with the TSDF prior as sdf_delta (run_e2e.py:164-186)."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    for t in range(10):
+        fr = {"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+              "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)}
+        coords = nm.integrate(fr)
+        assert coords is not None and len(coords) > 1000
+    assert float((nm.tsdf_vol.weight > 0).float().mean()) > 0.01
+    pts, sdf = nm.extract_sdf()
+    assert sdf.shape[1:] == (3, 3, 3) and torch.isfinite(sdf).all()
+    plain = nm.volume.decode_lattice(nm.volume.active_coordinates, model.nerf, None, query_tensor=True)
+    delta = nm.prepare_tsdf_volume()
+    assert delta.shape[:2] == (1, 1) and float(delta.abs().max()) <= nm.truncated_dist + 1e-7
+    assert (sdf.reshape(-1, 27) - plain).abs().max() <= nm.truncated_dist + 1e-6   # prior adds at most trunc
