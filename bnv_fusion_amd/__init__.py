@@ -8,12 +8,15 @@ from .neural_map import NeuralMap  # noqa: F401
 
 MLP_MODE_FP32_EXACT = 0     # v_mfma_f32_32x32x2_f32
 MLP_MODE_SPLIT_F16 = 1      # fp32 operands split into f16 hi + lo, 3 products on the f16 MFMA (default)
+MLP_MODE_TCNN = 2           # tiny-cuda-nn fp16 networks (selected automatically by tiny_cuda models)
 
 
 def set_mlp_mode(mode):
     """Selects the arithmetic of the two MLP kernels (see include/bnv_fusion.h: bnv_set_mlp_mode)."""
     from . import _lib
     _lib.check(_lib.load().bnv_set_mlp_mode(int(mode)), "bnv_set_mlp_mode")
+    if int(mode) in (0, 1):
+        _lib.fp32_mode = int(mode)
 
 
 def get_mlp_mode():

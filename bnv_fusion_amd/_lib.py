@@ -50,6 +50,7 @@ class BnvError(RuntimeError):
 
 _lib = None
 _initialised_device = None
+fp32_mode = 1   # MLP mode used by fp32-checkpoint models (0 exact fp32, 1 split-f16); see set_mlp_mode
 
 
 def load():

@@ -187,12 +187,10 @@ __device__ __forceinline__ void stage_input(float* __restrict__ hl, int j, const
 // of wave w exactly the 8 slots of K-step 2 w + ksl.
 constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
 
-// ReLU as one v_max_f32 (fmaxf() costs an extra canonicalising v_max under IEEE mode)
-__device__ __forceinline__ float relu1(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
+// ReLU as ONE instruction the compiler can see: v_med3_f32(x, 0, +inf).  (fmaxf() costs an extra
+// canonicalising v_max under IEEE mode; an inline-asm v_max would hide the MFMA-result -> VALU hazard
+// from the compiler, which pads wait states only around instructions it knows.)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 
 template <int NKS>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
@@ -330,6 +328,103 @@ __device__ __forceinline__ void stage_input_h(float* __restrict__ lds, int j, co
   }
 }
 
+
+// ---- tiny-cuda-nn SDF decoder (reference default checkpoint; tcnnNeRFModel, modules.py:136-253):
+// 17 inputs padded to 32 with 1.0 -> 64 -> 64 -> 64 -> 16 (output 0 used), ReLU, no bias, fp16.
+// The network is small enough that ONE wave runs all layers for 32 evaluations in registers (no
+// barriers between layers); waves 0..3 of the workgroup cover the tile's 128 evaluations.
+// Pack (halves): W0 [2 mb][2 ks][64 lane][8] | W1, W2 [2 mb][4 g][64][8] | W3 [4 g][64][8] (rows >= 16 zero).
+constexpr int ST_W0 = 0;
+constexpr int ST_W1 = ST_W0 + 2 * 2 * 64 * 8;
+constexpr int ST_W2 = ST_W1 + 2 * 4 * 64 * 8;
+constexpr int ST_W3 = ST_W2 + 2 * 4 * 64 * 8;
+constexpr int ST_TOTAL = ST_W3 + 4 * 64 * 8;  // 12,288 halves
+
+__device__ __forceinline__ half8 relu_half8(const f32x16& v, int base) {
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (_Float16)relu1(v[base + e]);
+  return r;
+}
+
+__device__ __forceinline__ void sdf_mlp_tile_t(float* __restrict__ lds, const float* __restrict__ pack) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  if (w < 4) {
+    const _Float16* ph = (const _Float16*)pack;
+    const int col = w * 32 + j;
+    f32x16 a0[2], a1[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a0[mb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8 b = *(const half8*)&lds[L_HL + ((ks * 2 + h) * DM + col) * 4];
+        a0[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&ph[ST_W0 + ((mb * 2 + ks) * 64 + lane) * 8], b,
+                                                        a0[mb], 0, 0, 0);
+      }
+    }
+    half8 s[4];
+    auto layer64 = [&](int woff, const f32x16 (&in)[2], f32x16 (&out)[2]) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        s[nb * 2] = relu_half8(in[nb], 0);
+        s[nb * 2 + 1] = relu_half8(in[nb], 8);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[mb][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&ph[woff + ((mb * 4 + g) * 64 + lane) * 8],
+                                                          s[g], out[mb], 0, 0, 0);
+      }
+    };
+    layer64(ST_W1, a0, a1);
+    layer64(ST_W2, a1, a0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      s[nb * 2] = relu_half8(a0[nb], 0);
+      s[nb * 2 + 1] = relu_half8(a0[nb], 8);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&ph[ST_W3 + (g * 64 + lane) * 8], s[g], o, 0, 0, 0);
+    // output 0 = row 0 of the tile = register 0 of the lanes with h == 0; the network returns fp16
+    if (h == 0) lds[L_ALPHA + col] = (float)(_Float16)o[0];
+  }
+  __syncthreads();
+}
+
+// inputs of evaluation j for the tcnn decoder: 17 features, padded to 32 with 1.0, f16
+__device__ __forceinline__ void stage_input_t(float* __restrict__ lds, int j, const float (&loc)[3],
+                                              const float (&feat)[8]) {
+  float in[32];
+#pragma unroll
+  for (int f = 0; f < 32; ++f) in[f] = 1.0f;
+  in[0] = loc[0]; in[1] = loc[1]; in[2] = loc[2];
+  in[3] = sinf(loc[0]); in[4] = sinf(loc[1]); in[5] = sinf(loc[2]);
+  in[6] = cosf(loc[0]); in[7] = cosf(loc[1]); in[8] = cosf(loc[2]);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) in[9 + f] = feat[f];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      half8 v;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v[jj] = (_Float16)in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
+      *(half8*)&lds[L_HL + ((ks * 2 + hh) * DM + j) * 4] = v;
+    }
+  }
+}
+
 // F.grid_sample(mode="nearest", padding_mode="zeros", align_corners=True) of the TSDF prior at a
 // corner given in voxel units (sparse_volume.py:820-829): coordinate a -> index along dims[a].
 __device__ __forceinline__ float sample_delta(const bnv_sdf_delta_t& d, const bnv_grid_t& g, const float (&c)[3]) {
@@ -436,7 +531,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
           }
         }
       }
-      if constexpr (PREC == 1) stage_input_h(lds, j, loc, feat);
+      if constexpr (PREC == 2) stage_input_t(lds, j, loc, feat);
+      else if constexpr (PREC == 1) stage_input_h(lds, j, loc, feat);
       else stage_input(hl, j, loc, feat);
       lds[L_WTRI + j] = wtri;
       lds[L_WVOL + j] = wvol;
@@ -444,7 +540,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
     }
     __syncthreads();
     // ---------------- MLP -----------------------------------------------------------------
-    if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
+    if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
+    else if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
     else sdf_mlp_tile(lds, A.pack);
     // ---------------- back end ------------------------------------------------------------
     if constexpr (MODE == MODE_LATTICE) {
@@ -462,7 +559,9 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
             l = (int)(e - ci * 27);
             row = A.list[ci];
           }
-          A.table[(size_t)row * 27 + l] = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
+          float av = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
+          if constexpr (PREC == 2) av = (float)(_Float16)av;  // half tensor * python float stays half (sparse_volume.py:813)
+          A.table[(size_t)row * 27 + l] = av;
         }
       }
     } else {
@@ -479,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
             const float wk = __fdiv_rn(lds[L_WTRI + b + k], norm);
             const float wv = lds[L_WVOL + b + k];
             float a = __fmul_rn(lds[L_ALPHA + b + k], voxel);
+            if constexpr (PREC == 2) a = (float)(_Float16)a;
             if constexpr (MODE == MODE_DENSE) {
               const bool ok = wv >= (float)A.grid.min_pts_in_grid;  // forward_with_mask (modules.py:774-783)
               a = ok ? a : 0.f;
@@ -706,7 +806,11 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
                  stream);
 #define BNV_LAUNCH_DECODE(M, P) \
   hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args)
-  if (g_mlp_mode == 1) {
+  if (g_mlp_mode == 2) {
+    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 2);
+    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
+    else BNV_LAUNCH_DECODE(MODE_DENSE, 2);
+  } else if (g_mlp_mode == 1) {
     if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 1);
     else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
@@ -740,6 +844,9 @@ int bnv_decode_init() {
   BNV_OPT_IN(MODE_PTS, 1);
   BNV_OPT_IN(MODE_LATTICE, 1);
   BNV_OPT_IN(MODE_DENSE, 1);
+  BNV_OPT_IN(MODE_PTS, 2);
+  BNV_OPT_IN(MODE_LATTICE, 2);
+  BNV_OPT_IN(MODE_DENSE, 2);
 #undef BNV_OPT_IN
   return BNV_OK;
 }

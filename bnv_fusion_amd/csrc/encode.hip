@@ -24,7 +24,7 @@ namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
-int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo on the f16 MFMA
+int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
 bool g_prof_on = false;
@@ -456,7 +456,7 @@ __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, hal
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float x = v[base + e];
-    if (relu) asm("v_max_f32 %0, 0, %1" : "=v"(x) : "v"(x));  // one op; fmaxf adds a canonicalising v_max
+    if (relu) x = __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());  // one compiler-visible op (no asm: MFMA hazards)
     const _Float16 h = (_Float16)x;
     (*hi)[e] = h;
     (*lo)[e] = (_Float16)(x - (float)h);
@@ -650,6 +650,127 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pointnet_scatter_t: the tiny-cuda-nn point encoder of the reference's default checkpoint
+// (pointnet_tcnn.ckpt; tcnnPointNetEncoder, pointnet_utils.py:269-294; FullyFusedMLP per
+// src/models/tcnn_config.json): 6 inputs padded to 16 with 1.0 -> 64 -> 64 -> 64 -> 16 (first 8 used),
+// ReLU, no bias, fp16 weights and activations.  Here: f16 MFMA with fp32 accumulation, activations
+// rounded to f16 between layers and at the output, as the CUDA kernel stores them.
+// Pack (halves): W1 [2 mb][64 lane][8] | W2, W3 [2 mb][4 g][64][8] | W4 [4 g][64][8] (rows >= 16 zero).
+// ------------------------------------------------------------------------------------------
+constexpr int PT_W1 = 0;
+constexpr int PT_W2 = PT_W1 + 2 * 64 * 8;
+constexpr int PT_W3 = PT_W2 + 2 * 4 * 64 * 8;
+constexpr int PT_W4 = PT_W3 + 2 * 4 * 64 * 8;
+constexpr int PT_TOTAL = PT_W4 + 4 * 64 * 8;  // 11,264 halves = 22,528 B
+
+__device__ __forceinline__ half8 to_half8_relu(const f32x16& v, int base) {
+  half8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    r[e] = (_Float16)__builtin_amdgcn_fmed3f(v[base + e], 0.f, __builtin_inff());
+  }
+  return r;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_pointnet_scatter_t(
+    const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
+    const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
+    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+  __shared__ __attribute__((aligned(16))) _Float16 wh[PT_TOTAL];
+  for (int i = threadIdx.x * 4; i < PT_TOTAL / 2; i += 256 * 4)
+    *(f32x4*)&((float*)wh)[i] = *(const f32x4*)&wpack[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n_pblocks = (n_points + 31) >> 5;
+  const int n_tiles = n_pblocks * 8;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  for (int t = blockIdx.x * 4 + wave; t < n_tiles; t += gridDim.x * 4) {
+    const int k = t / n_pblocks;
+    const int i = (t - k * n_pblocks) * 32 + j;
+    // operand slots of this lane half: features 8 (jj >> 2) + 4 h + (jj & 3); inputs 0..5, the rest 1.0
+    half8 b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b[e] = (_Float16)1.0f;
+    int slot = -1;
+    bool valid = false;
+    if (i < n_points) {
+      const float* p = pts + (size_t)i * 6;
+      const float x = p[0], y = p[1], z = p[2];
+      if (in_bounds(x, y, z, g)) {
+        valid = true;
+        const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+        const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+        const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+        const int gx = (k & 1) ? (int)ceilf(xn) : (int)floorf(xn);
+        const int gy = (k & 2) ? (int)ceilf(yn) : (int)floorf(yn);
+        const int gz = (k & 4) ? (int)ceilf(zn) : (int)floorf(zn);
+        if (voxel_owner(gx, gy, gz, g) == g.shard_rank) {
+          const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+          const uint32_t word = bitmap[id >> 5];
+          slot = (int)(word_prefix[id >> 5] + __popc(word & ((1u << (id & 31)) - 1u)));
+        }
+        if (h == 0) {
+          b[0] = (_Float16)relative_coord(xn, gx, g.voxel_size);
+          b[1] = (_Float16)relative_coord(yn, gy, g.voxel_size);
+          b[2] = (_Float16)relative_coord(zn, gz, g.voxel_size);
+          b[3] = (_Float16)p[3];
+        } else {
+          b[0] = (_Float16)p[4];
+          b[1] = (_Float16)p[5];
+        }
+      }
+    }
+    if (__ballot(slot >= 0) == 0ULL) continue;
+    (void)valid;
+    f32x16 ha[2], hb[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+      ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[PT_W1 + (mb * 64 + lane) * 8], b, zero16(),
+                                                      0, 0, 0);
+    half8 s[4];
+    auto layer64 = [&](int woff, const f32x16 (&in)[2], f32x16 (&out)[2]) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        s[nb * 2] = to_half8_relu(in[nb], 0);
+        s[nb * 2 + 1] = to_half8_relu(in[nb], 8);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        out[mb] = zero16();
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk)
+          out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[woff + ((mb * 4 + gk) * 64 + lane) * 8],
+                                                          s[gk], out[mb], 0, 0, 0);
+      }
+    };
+    layer64(PT_W2, ha, hb);
+    layer64(PT_W3, hb, ha);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      s[nb * 2] = to_half8_relu(ha[nb], 0);
+      s[nb * 2 + 1] = to_half8_relu(ha[nb], 8);
+    }
+    f32x16 o = zero16();
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk)
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[PT_W4 + (gk * 64 + lane) * 8], s[gk], o, 0, 0, 0);
+    // the network returns fp16; lane (j, h) holds outputs 4h .. 4h+3 of pair j
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (float)(_Float16)o[q];
+    scatter_tile(o, slot, j, h, counts, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // finalize: ordered compaction of the emitted voxels + cleanup of the per-frame scratch
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanThreads) void k_finalize(
@@ -799,7 +920,7 @@ const char* bnv_status_string(int s) {
 size_t bnv_pointnet_pack_floats(void) { return PN_PACK_FLOATS; }
 
 int bnv_set_mlp_mode(int mode) {
-  if (mode != 0 && mode != 1) return BNV_ERR_INVALID_ARGUMENT;
+  if (mode < 0 || mode > 2) return BNV_ERR_INVALID_ARGUMENT;
   g_mlp_mode = mode;
   return BNV_OK;
 }
@@ -879,7 +1000,11 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
   {
     ProfScope prof(PROF_POINTNET, stream);
-    if (g_mlp_mode == 1)
+    if (g_mlp_mode == 2)
+      hipLaunchKernelGGL(k_pointnet_scatter_t, dim3(g_num_cus * 4 < (n_tiles + 3) / 4 ? g_num_cus * 4 : (n_tiles + 3) / 4),
+                         dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
+                         ws.acc);
+    else if (g_mlp_mode == 1)
       hipLaunchKernelGGL(k_pointnet_scatter_h, dim3(grid_pn), dim3(512), PH_LDS_BYTES, stream, input_pts, n, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     else

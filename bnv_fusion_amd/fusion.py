@@ -5,8 +5,9 @@ Same call surface as run_e2e.py uses: construction from t
 ``load_state_dict`` with the reference's checkpoint keys, ``eval()/cuda()/freeze()``,
 ``encode_pointcloud``, ``_integrate``, ``decode_feature_grid_w_pts``, ``decode_implicit`` and a
 ``.nerf`` with ``xyz_encoding / geo_forward / get_neighbors``.  The arithmetic runs in the HIP
-kernels of csrc/; this file only marshals torch tensors.  The fp32 checkpoint path
-(``model.tiny_cuda=False``) is implemented; there is no CPU fallback.
+kernels of csrc/; this file only marshals torch tensors.  Both checkpoints are supported: the fp32 networks
+(``model.tiny_cuda=False``, pointnet.ckpt) and the tiny-cuda-nn fp16 networks of the reference's default
+configuration (``tiny_cuda=True``, pointnet_tcnn.ckpt).  There is no CPU fallback.
 """
 import ctypes as C
 import weakref
@@ -72,23 +73,69 @@ class LocalNeRFModel(nn.Module):
         return self.fc_alpha(xyz)
 
 
+class _TcnnParams(nn.Module):
+    """Holds ``model.params`` like tinycudann.NetworkWithInputEncoding does (checkpoint key ``*.model.params``)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.params = nn.Parameter(torch.zeros(n))
+
+
+class TcnnNeRFModel(nn.Module):
+    """SDF decoder of the reference's default checkpoint (tcnnNeRFModel, modules.py:136-253): identity
+    encoding padded to 32 with 1.0, FullyFusedMLP 64 x 3 -> 16, fp16.  ``sdf_pack`` feeds MLP mode 2."""
+    mlp_mode = 2
+
+    def __init__(self):
+        super().__init__()
+        self.model = _TcnnParams(64 * 32 + 64 * 64 * 2 + 16 * 64)
+        self.register_buffer("sdf_pack", torch.zeros(12288 // 2), persistent=False)
+
+    def repack(self):
+        self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn(self.model.params.detach().cpu().numpy())))
+
+    xyz_encoding = staticmethod(LocalNeRFModel.xyz_encoding)
+
+    def get_neighbors(self, points):
+        return get_neighbors(points, as_int=True)
+
+    def geo_forward(self, xyz):
+        """modules.py:249-253 (torch emulation of the fp16 network; the per-frame decode runs in HIP)."""
+        shapes = list(xyz.shape)
+        x = xyz.reshape(-1, shapes[-1]).half()
+        x = torch.cat([x, torch.ones((x.shape[0], 32 - x.shape[1]), dtype=x.dtype, device=x.device)], 1)
+        off = 0
+        dims = [32, 64, 64, 64, 16]
+        for i in range(4):
+            w = self.model.params[off: off + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]).half()
+            off += dims[i + 1] * dims[i]
+            x = (x.float() @ w.float().t())
+            x = (torch.relu(x) if i < 3 else x).half()
+        return x[:, :1].reshape(shapes[:-1] + [1])
+
+
 class LitFusionPointNet(nn.Module):
     def __init__(self, cfg, **kwargs):
         super().__init__()
         self.cfg = cfg
         model = _get(cfg, "model")
         trainer = _get(cfg, "trainer")
-        if _get(model, "tiny_cuda", False):
-            raise NotImplementedError("tiny-cuda-nn (fp16 FullyFusedMLP) checkpoints are not supported yet")
+        self.tiny_cuda = bool(_get(model, "tiny_cuda", False))
         self.dense_volume = bool(_get(trainer, "dense_volume", False)) if trainer is not None else False
         self.feat_dims = int(_get(model, "feature_vector_size", 8))
         nerf_cfg = _get(model, "nerf") or {}
         nerf_kwargs = dict(nerf_cfg) if isinstance(nerf_cfg, dict) else {k: getattr(nerf_cfg, k) for k in (
             "hidden_size", "num_layers", "num_encoding_fn_xyz") if hasattr(nerf_cfg, k)}
         self.interpolate_decode = bool(_get(nerf_cfg, "interpolate_decode", True))
-        self.nerf = LocalNeRFModel(self.feat_dims, **{k: nerf_kwargs[k] for k in (
-            "hidden_size", "num_layers", "num_encoding_fn_xyz") if k in nerf_kwargs})
-        self.pointnet_backbone = _PointNetParams(self.feat_dims)
+        if self.tiny_cuda:
+            # the networks are fixed by src/models/tcnn_config.json (FullyFusedMLP, 64 neurons, 3 hidden layers)
+            self.nerf = TcnnNeRFModel()
+            self.pointnet_backbone = nn.Module()
+            self.pointnet_backbone.model = _TcnnParams(64 * 16 + 64 * 64 * 2 + 16 * 64)
+        else:
+            self.nerf = LocalNeRFModel(self.feat_dims, **{k: nerf_kwargs[k] for k in (
+                "hidden_size", "num_layers", "num_encoding_fn_xyz") if k in nerf_kwargs})
+            self.pointnet_backbone = _PointNetParams(self.feat_dims)
         self.voxel_size = _get(model, "voxel_size")
         self.min_pts_in_grid = int(_get(model, "min_pts_in_grid", 8))
         self.training_global = bool(_get(model, "training_global", False))
@@ -113,9 +160,20 @@ class LitFusionPointNet(nn.Module):
         return res
 
     def repack(self):
-        sd = {k: v for k, v in self.state_dict().items()}
-        self.pointnet_pack.copy_(torch.from_numpy(weights.pack_pointnet(sd)))
+        self.pointnet_pack.zero_()
+        if self.tiny_cuda:
+            w = torch.from_numpy(weights.pack_pointnet_tcnn(self.pointnet_backbone.model.params.detach().cpu().numpy()))
+        else:
+            w = torch.from_numpy(weights.pack_pointnet({k: v for k, v in self.state_dict().items()}))
+        self.pointnet_pack[: w.numel()].copy_(w)
         self.nerf.repack()
+
+    def _select_mode(self, lib):
+        """MLP arithmetic for this model's kernels: 2 for tcnn checkpoints, else the fp32 mode in force."""
+        if self.tiny_cuda:
+            lib.bnv_set_mlp_mode(2)
+        elif lib.bnv_get_mlp_mode() == 2:
+            lib.bnv_set_mlp_mode(_lib.fp32_mode)
 
     def freeze(self):
         for p in self.parameters():
@@ -150,6 +208,7 @@ class LitFusionPointNet(nn.Module):
     # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
     def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
         lib = self._lib_for(self.pointnet_pack)
+        self._select_mode(lib)
         assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
         pts = input_pts[0].detach().float().contiguous()
         dev = pts.device
@@ -226,6 +285,7 @@ class LitFusionPointNet(nn.Module):
             raise NotImplementedError("only global_coords=False / interpolate_decode=True / gradient=False "
                                       "(the fusion_pointnet_model.yaml configuration) runs on the HIP path")
         lib = self._lib_for(voxel_coords)
+        self._select_mode(lib)
         q = voxel_coords.detach().reshape(-1, 3).float().contiguous()
         n = int(q.shape[0])
         fg = feat_grid.detach().float().contiguous()
@@ -276,15 +336,16 @@ class _PointNetParams(nn.Module):
         self.bn4 = nn.BatchNorm1d(feat_dims)
 
 
-def load_pretrained(device="cuda:0", voxel_size=0.01, min_pts_in_grid=8, path=None):
-    """Model with the converted reference checkpoint (weights/pointnet_fp32.npz), frozen, on device."""
+def load_pretrained(device="cuda:0", voxel_size=0.01, min_pts_in_grid=8, path=None, tiny_cuda=False):
+    """Model with a converted reference checkpoint (weights/pointnet_fp32.npz, or pointnet_tcnn.npz when
+    ``tiny_cuda``), frozen, on device."""
     cfg = {"trainer": {"dense_volume": False},
-           "model": {"feature_vector_size": 8, "voxel_size": voxel_size, "tiny_cuda": False,
+           "model": {"feature_vector_size": 8, "voxel_size": voxel_size, "tiny_cuda": tiny_cuda,
                      "min_pts_in_grid": min_pts_in_grid,
                      "nerf": {"hidden_size": 256, "num_layers": 4, "num_encoding_fn_xyz": 1,
                               "interpolate_decode": True}}}
     model = LitFusionPointNet(cfg)
-    model.load_state_dict(weights.load_npz(path or weights.DEFAULT_FP32))
+    model.load_state_dict(weights.load_npz(path or (weights.DEFAULT_TCNN if tiny_cuda else weights.DEFAULT_FP32)))
     model.eval()
     model.to(device)
     model.freeze()

@@ -273,6 +273,12 @@ class SparseVolume:
                 d.dims[a] = int(keep.shape[2 + a])
         return d, keep
 
+    def _select_mode(self, nerf):
+        if getattr(nerf, "mlp_mode", None) == 2:
+            self._lib.bnv_set_mlp_mode(2)
+        elif self._lib.bnv_get_mlp_mode() == 2:
+            self._lib.bnv_set_mlp_mode(_lib.fp32_mode)
+
     def _values(self, query_tensor):
         if query_tensor:
             f, w, _, lim = self._snapshot()
@@ -281,6 +287,7 @@ class SparseVolume:
 
     def decode_pts(self, coords, nerf, sdf_delta=None, is_coords=False, query_tensor=True):
         """sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1]."""
+        self._select_mode(nerf)
         shape = list(coords.shape)
         c = coords.detach().reshape(-1, 3).float().contiguous()
         n = int(c.shape[0])
@@ -296,6 +303,7 @@ class SparseVolume:
     def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True):
         """decode_pts on the 3x3x3 lattice {-0.5, 0, 0.5}^3 around integer voxel ``origins`` [B, 3]
         (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27]."""
+        self._select_mode(nerf)
         o = origins.detach().reshape(-1, 3).long().contiguous()
         n = int(o.shape[0])
         out = torch.empty((n, 27), dtype=torch.float32, device=self._dev)

@@ -164,3 +164,58 @@ def pack_sdf_mlp(sd):
                              pack_split(Ws[3], 16)])
     assert halves.size == 409600
     return np.concatenate([fp32_part, halves.view(np.float32)])
+
+
+# --------------------------------------------------------------------------------------------------
+# tiny-cuda-nn checkpoints (pointnet_tcnn.ckpt): one flat fp32 master vector per network holding the
+# row-major [out, in] matrices of FullyFusedMLP in order.
+# --------------------------------------------------------------------------------------------------
+def _split_tcnn(params, n_in_padded, width=64, n_hidden=3):
+    params = _np(params).astype(np.float32).reshape(-1)
+    dims = [n_in_padded] + [width] * n_hidden + [16]
+    mats, off = [], 0
+    for i in range(len(dims) - 1):
+        mats.append(params[off: off + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]))
+        off += dims[i + 1] * dims[i]
+    assert off == params.size, (off, params.size)
+    return mats
+
+
+def _pack_tcnn(mats):
+    """-> float32 words holding f16 fragments: first layer [2 mb][nks][64][8]; hidden layers
+    [2 mb][4 g][64][8] with g = (input block nb, ksl); output layer [4 g][64][8] (rows >= 16 zero)."""
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+    jj = np.arange(8)
+    sf = _slot_feature(jj[None, :], h[:, None])
+    out = []
+    W0 = mats[0]
+    nks = W0.shape[1] // 16
+    o = np.zeros((2, nks, 64, 8), np.float16)
+    for mb in range(2):
+        for ks in range(nks):
+            o[mb, ks] = W0[(mb * 32 + n)[:, None], 16 * ks + sf]
+    out.append(o.ravel())
+    for W in mats[1:-1]:
+        o = np.zeros((2, 4, 64, 8), np.float16)
+        for mb in range(2):
+            for g in range(4):
+                o[mb, g] = W[(mb * 32 + n)[:, None], (g >> 1) * 32 + 16 * (g & 1) + sf]
+        out.append(o.ravel())
+    Wl = np.zeros((32, 64), np.float32)
+    Wl[:16] = mats[-1]
+    o = np.zeros((4, 64, 8), np.float16)
+    for g in range(4):
+        o[g] = Wl[n[:, None], (g >> 1) * 32 + 16 * (g & 1) + sf]
+    out.append(o.ravel())
+    return np.concatenate(out).view(np.float32)
+
+
+def pack_pointnet_tcnn(params):
+    """tcnnPointNetEncoder (pointnet_utils.py:269-294): 16 | 64 | 64 | 64 | 16 -> PT_* layout of csrc/encode.hip."""
+    return _pack_tcnn(_split_tcnn(params, 16))
+
+
+def pack_sdf_tcnn(params):
+    """tcnnNeRFModel (modules.py:136-253): 32 | 64 | 64 | 64 | 16 -> ST_* layout of csrc/decode.hip."""
+    return _pack_tcnn(_split_tcnn(params, 32))

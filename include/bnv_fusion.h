@@ -90,7 +90,10 @@ int bnv_last_hip_error(void);
  *   0  exact fp32: v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain), 157 TFLOP/s peak;
  *   1  (default) split operands: every fp32 operand x = hi + lo with hi, lo in f16 (about 22 significant
  *      bits; f16 subnormals are kept), a.b ~ ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16:
- *      fp32-class accuracy (differences at the level of fp32 summation order) at 16/3 the MFMA rate. */
+ *      fp32-class accuracy (differences at the level of fp32 summation order) at 16/3 the MFMA rate;
+ *   2  the tiny-cuda-nn networks of the reference's default checkpoint (pointnet_tcnn.ckpt): inputs
+ *      padded with 1.0, 64-wide, no bias, fp16 weights and activations, f16 MFMA with fp32
+ *      accumulation.  The pack buffers then hold the tcnn layouts (weights.py: pack_*_tcnn). */
 int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 

@@ -141,7 +141,7 @@ def get_relative_xyz(xyz, bound_min, voxel_size):
 
 
 def encode_pointcloud(sd, input_pts, n_xyz, bound_min, bound_max, voxel_size,
-                      min_pts_in_grid=8, return_dense=False):
+                      min_pts_in_grid=8, return_dense=False, encoder=None):
     """local_point_fusion.py:81-151.  input_pts [1, N, 6] f32.
     sparse: (feats [U',8], pcounts [U',1] i64, flat_ids [U'] i64, grid_ids [U',3] i64, n_avg_pts)
     dense : (feat_grids [1,8,X,Y,Z], mask [1,1,X,Y,Z], unique_flat_ids [U], flat_ids [1,P])."""
@@ -165,7 +165,7 @@ def encode_pointcloud(sd, input_pts, n_xyz, bound_min, bound_max, voxel_size,
     # forward(normalize=True), local_point_fusion.py:51-65
     pointnet_input[:, :, :3] = pointnet_input[:, :, :3] / voxel_size
     assert torch.min(pointnet_input[:, :, :3]) >= -1 and torch.max(pointnet_input[:, :, :3]) <= 1
-    point_feats = pointnet_encoder(sd, pointnet_input.permute(0, 2, 1))  # [1, 8, P]
+    point_feats = (encoder or (lambda x: pointnet_encoder(sd, x)))(pointnet_input.permute(0, 2, 1))  # [1, 8, P]
     flat_ids = flatten(grid_id, n_xyz).long()
     unique_flat_ids, pinds, pcounts = torch.unique(flat_ids[0], return_inverse=True, return_counts=True)
     unique_grid_ids = unflatten(unique_flat_ids, n_xyz).long()
@@ -292,8 +292,8 @@ class OracleSparseVolume:
         rows = rows[rows >= 0]
         self.weights[rows] += 1
 
-    def decode_pts(self, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True):
-        return decode_pts(self, coords, sd, sdf_delta, is_coords, query_tensor)
+    def decode_pts(self, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True, geo=None):
+        return decode_pts(self, coords, sd, sdf_delta, is_coords, query_tensor, geo)
 
 
 def integrate(volume, fine_coords, fine_feats, fine_weights):
@@ -312,8 +312,10 @@ def integrate(volume, fine_coords, fine_feats, fine_weights):
 # --------------------------------------------------------------------------- #
 
 
-def decode_pts(volume, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True):
-    """SparseVolume.decode_pts, sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1]."""
+def decode_pts(volume, coords, sd, sdf_delta=None, is_coords=False, query_tensor=True, geo=None):
+    """SparseVolume.decode_pts, sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1].
+    ``geo``: alternative nerf.geo_forward (tcnn variant); its fp16 output keeps ``alpha * voxel_size`` in
+    fp16 as torch does for a half tensor times a python float."""
     if not is_coords:
         coords = (coords - volume.min_coords) / volume.voxel_size
     neighbor_coords = get_neighbors(coords)                      # float corners [1, 8, B, S, 3]
@@ -326,8 +328,11 @@ def decode_pts(volume, coords, sd, sdf_delta=None, is_coords=False, query_tensor
         feats, weights, _ = volume.query(neighbor_coords)
     mask = torch.min(weights, dim=1)[0] >= volume.min_pts_in_grid
     nerf_in = torch.cat([xyz_encoding(local_coords), feats], dim=-1)
-    alpha = geo_forward(sd, nerf_in)
-    alpha = alpha * volume.voxel_size
+    if geo is None:
+        alpha = geo_forward(sd, nerf_in)
+        alpha = alpha * volume.voxel_size
+    else:
+        alpha = (geo(nerf_in).half() * volume.voxel_size).float()
     normalizer = torch.sum(weights_unmasked, dim=1, keepdim=True)
     weights_unmasked = weights_unmasked / normalizer
     alpha = torch.sum(alpha * weights_unmasked, dim=1)
@@ -404,6 +409,19 @@ def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True):
             h = F.relu(h)
         h = q(h)
     return h[:, :n_out]
+
+
+def tcnn_point_encoder(params):
+    """tcnnPointNetEncoder.forward(x, global_feat=False), pointnet_utils.py:283-294: x [1, 6, P] -> [1, 8, P]."""
+    return lambda x: tcnn_mlp(params, x[0].t(), 16, 8).t()[None]
+
+
+def tcnn_geo_forward(params):
+    """tcnnNeRFModel.geo_forward, modules.py:249-253: [..., 17] -> [..., 1]."""
+    def f(x):
+        shp = list(x.shape)
+        return tcnn_mlp(params, x.reshape(-1, shp[-1]), 32, 1).reshape(shp[:-1] + [1])
+    return f
 
 
 # --------------------------------------------------------------------------- #

@@ -477,3 +477,53 @@ def test_neural_map_depth_frames_with_tsdf_prior(bnv):
     delta = nm.prepare_tsdf_volume()
     assert delta.shape[:2] == (1, 1) and float(delta.abs().max()) <= nm.truncated_dist + 1e-7
     assert (sdf.reshape(-1, 27) - plain).abs().max() <= nm.truncated_dist + 1e-6   # prior adds at most trunc
+
+
+# ---------------------------------------------------------------------------------------------
+# tiny-cuda-nn checkpoint (the reference's default configuration).  PARITY UNPINNED against the
+# reference itself (its fp16 CUDA kernels cannot run here): checked against the oracle's fp16
+# restatement of the FullyFusedMLP layout, at fp16-level tolerances.
+# ---------------------------------------------------------------------------------------------
+def test_tcnn_checkpoint_encode_decode_vs_oracle(bnv, orc):
+    from conftest import WEIGHTS_TCNN
+    tsd = orc.load_weights(WEIGHTS_TCNN)
+    enc = orc.tcnn_point_encoder(tsd["pointnet_backbone.model.params"])
+    geo = orc.tcnn_geo_forward(tsd["nerf.model.params"])
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    dims, voxel = z["dims"], float(z["voxel_size"])
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel, tiny_cuda=True)
+    assert sorted(model.state_dict()) == ["nerf.model.params", "pointnet_backbone.model.params"]
+    nm = bnv.NeuralMap(dims, voxel, model, device=DEV)
+    ovol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    for fr in z["frames"]:
+        pts = torch.from_numpy(fr)
+        f, c, ids, g, n = model.encode_pointcloud(pts.to(DEV), nm.volume.n_xyz, nm.volume.min_coords,
+                                                  nm.volume.max_coords, voxel, return_dense=False)
+        fo, co, ido, go, no = orc.encode_pointcloud(None, pts, ovol.n_xyz, ovol.min_coords, ovol.max_coords, voxel,
+                                                    encoder=enc)
+        assert torch.equal(ids.cpu(), ido) and torch.equal(c.cpu(), co) and float(n) == float(no)
+        assert (f.cpu() - fo).abs().max() <= 3e-3, float((f.cpu() - fo).abs().max())
+        model._integrate(nm.volume, g, f, c)
+        orc.integrate(ovol, go, fo, co)
+    # decode (general 8-corner path and lattice path) against the oracle decode on the ORACLE's volume
+    # re-created from the GPU volume's values, so that only the decoder differs
+    nm.volume.to_tensor()
+    k = nm.volume.active_coordinates.cpu()
+    ov2 = orc.OracleSparseVolume(8, voxel, dims, 8)
+    ov2.insert(k, nm.volume.features.cpu(), nm.volume.weights.cpu(), nm.volume.num_hits.cpu())
+    ov2.to_tensor()
+    valid = (nm.volume.weights[:, 0] >= 8).nonzero()[:, 0][:120]
+    origins = nm.volume.active_coordinates[valid]
+    ref = ov2.decode_pts(orc.lattice_coords(origins.cpu().numpy()), None, None, is_coords=True, geo=geo)[0, :, :, 0]
+    lat = nm.volume.decode_lattice(origins, model.nerf, query_tensor=True).cpu()
+    coords = origins[:, None, :].float() + torch.tensor(_LATTICE, device=DEV)[None]
+    gen = nm.volume.decode_pts(coords[None], model.nerf, None, is_coords=True)[0, :, :, 0].cpu()
+    assert torch.equal(lat == voxel, ref == voxel) and torch.equal(gen == voxel, ref == voxel)
+    assert float((ref != voxel).float().mean()) > 0.05
+    assert (lat - gen).abs().max() <= 2e-6
+    assert (lat - ref).abs().max() <= 1e-4, float((lat - ref).abs().max())     # SDF = fp16 net output x 0.02
+    # a tcnn model and an fp32 model can alternate in one process (the MLP mode follows the model)
+    m32 = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    a = m32.encode_pointcloud(torch.from_numpy(z["frames"][0]).to(DEV), nm.volume.n_xyz, nm.volume.min_coords,
+                              nm.volume.max_coords, voxel, return_dense=False)
+    assert bnv.get_mlp_mode() in (0, 1) and a[0].shape[1] == 8

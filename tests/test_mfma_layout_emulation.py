@@ -312,3 +312,62 @@ def test_sdf_mlp_split_pack_matches_direct_mlp():
     tsd = orc.load_weights(WEIGHTS_FP32)
     ref = orc.geo_forward(tsd, torch.from_numpy(x).float())[:, 0].numpy()
     assert np.abs(alpha - ref).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# tcnn (FullyFusedMLP) layouts: f16 operands only, activations rounded to f16 between layers
+# ---------------------------------------------------------------------------------------------
+def _emulate_tcnn(halves, first_nks, x_padded, n_out_rows):
+    """x_padded [32 evals, 16 * first_nks] -> network outputs [32, n_out_rows] with the kernels' index math."""
+    J8 = np.arange(8)
+    sf = 8 * (J8 >> 2)[None, :] + 4 * H_[:, None] + (J8 & 3)[None, :]        # slot -> feature within a K-step
+    f16 = lambda a: np.asarray(a, np.float32).astype(np.float16).astype(np.float64)
+    off = 0
+    acc = [np.zeros((64, 16)) for _ in range(2)]
+    for mb in range(2):
+        for ks in range(first_nks):
+            w = halves[off + ((mb * first_nks + ks) * 64 + LANE[:, None]) * 8 + J8[None, :]]
+            b = f16(x_padded[N_[:, None], 16 * ks + sf])
+            acc[mb] = mfma16(w, b, acc[mb])
+    off += 2 * first_nks * 512
+    for _ in range(2):
+        s = [f16(np.maximum(acc[nb][:, 8 * ksl: 8 * ksl + 8], 0)) for nb in range(2) for ksl in range(2)]
+        new = [np.zeros((64, 16)) for _ in range(2)]
+        for mb in range(2):
+            for g in range(4):
+                w = halves[off + ((mb * 4 + g) * 64 + LANE[:, None]) * 8 + J8[None, :]]
+                new[mb] = mfma16(w, s[g], new[mb])
+        acc = new
+        off += 2 * 4 * 512
+    s = [f16(np.maximum(acc[nb][:, 8 * ksl: 8 * ksl + 8], 0)) for nb in range(2) for ksl in range(2)]
+    o = np.zeros((64, 16))
+    for g in range(4):
+        o = mfma16(halves[off + (g * 64 + LANE[:, None]) * 8 + J8[None, :]], s[g], o)
+    out = np.zeros((32, 32))
+    out[ROW, N_[:, None]] = 0
+    for l in range(64):
+        for r in range(16):
+            out[N_[l], ROW[l, r]] = o[l, r]
+    return f16(out[:, :n_out_rows])
+
+
+def test_tcnn_packs_match_oracle_restatement():
+    from conftest import WEIGHTS_TCNN
+    z = np.load(WEIGHTS_TCNN)
+    rng = np.random.default_rng(4)
+    # point encoder: 6 inputs padded to 16 with 1.0 -> first 8 outputs
+    x = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)
+    xp = np.ones((32, 16), np.float32)
+    xp[:, :6] = x
+    halves = W.pack_pointnet_tcnn(z["pointnet_backbone.model.params"]).view(np.float16).astype(np.float64)
+    got = _emulate_tcnn(halves, 1, xp, 8)
+    ref = orc.tcnn_mlp(torch.from_numpy(z["pointnet_backbone.model.params"]), torch.from_numpy(x), 16, 8).numpy()
+    assert np.abs(got - ref).max() < 4e-3          # fp16 activations; accumulation order differs
+    # SDF decoder: 17 inputs padded to 32 -> output 0
+    x = rng.uniform(-1, 1, size=(32, 17)).astype(np.float32)
+    xp = np.ones((32, 32), np.float32)
+    xp[:, :17] = x
+    halves = W.pack_sdf_tcnn(z["nerf.model.params"]).view(np.float16).astype(np.float64)
+    got = _emulate_tcnn(halves, 2, xp, 1)
+    ref = orc.tcnn_mlp(torch.from_numpy(z["nerf.model.params"]), torch.from_numpy(x), 32, 1).numpy()
+    assert np.abs(got - ref).max() < 4e-3
