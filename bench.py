@@ -26,10 +26,13 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PAIR = 2 * (6 * 128 + 128 * 128 + 128 * 128 + 128 * 8)          # 69,120  point encoder
 FLOP_PER_EVAL = 2 * (17 * 256 + 3 * 256 * 256 + 256)                      # 402,432 SDF MLP
-PEAK_TFLOPS = {0: 157.3, 1: 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md: f32-in / f16-in
-MODE_NAME = {0: "fp32_exact", 1: "split_f16"}
+FLOP_PER_PAIR_TCNN = 2 * (16 * 64 + 2 * 64 * 64 + 64 * 16)                # 20,480  tcnn encoder
+FLOP_PER_EVAL_TCNN = 2 * (32 * 64 + 2 * 64 * 64 + 64 * 16)                # 22,528  tcnn decoder
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md: f32-in / f16-in
+MODE_NAME = {0: "fp32_exact", 1: "split_f16", 2: "tcnn_f16"}
 DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
-         1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate"}
+         1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
+         2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate"}
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -113,6 +116,9 @@ def main():
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
+    ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"],
+                    help="fp32: pointnet.ckpt networks (oracle-pinned; the headline); tcnn: the reference's default "
+                         "tiny-cuda-nn fp16 networks (pointnet_tcnn.ckpt)")
     ap.add_argument("--input", default="depth", choices=["depth", "points"],
                     help="'depth' (default): a step starts from the uint16 depth image resident in HBM and runs the "
                          "GPU front end (unprojection + normals); 'points': from precomputed input_pts")
@@ -144,7 +150,11 @@ def main():
     from bnv_fusion_amd import synthetic, _lib
 
     dims, voxel = synthetic.GRID_DIMS[args.grid]
-    model = bnv.load_pretrained(device=dev, voxel_size=voxel)
+    tcnn = args.checkpoint == "tcnn"
+    model = bnv.load_pretrained(device=dev, voxel_size=voxel, tiny_cuda=tcnn)
+    if tcnn:
+        args.no_alt_mode = True
+        args.mlp_mode = 2
     frame_parallel = world > 1 and args.parallelism == "frame"
     if frame_parallel:
         from bnv_fusion_amd.distributed import FrameParallelNeuralMap
@@ -188,7 +198,8 @@ def main():
 
     def timed(mode, first, steps, warm):
         """`warm` untimed frames, then times exactly `steps` frames from index `first`, in MLP mode `mode`."""
-        bnv.set_mlp_mode(mode)
+        if mode != 2:
+            bnv.set_mlp_mode(mode)
         run_frames(first - warm, warm)
         lib.bnv_profile_enable(1)
         table_rows, n_vox = [], []
@@ -223,8 +234,8 @@ def main():
         live = float((sdf != voxel).float().mean()) if sdf is not None and sdf.numel() else 0.0
         dec_ms = prof_ms[1] / max(prof_n[1], 1)
         enc_ms = prof_ms[0] / max(prof_n[0], 1)
-        dec_flop = float(rows.mean()) * FLOP_PER_EVAL
-        enc_flop = 8.0 * n_points * FLOP_PER_PAIR
+        dec_flop = float(rows.mean()) * (FLOP_PER_EVAL_TCNN if mode == 2 else FLOP_PER_EVAL)
+        enc_flop = 8.0 * n_points * (FLOP_PER_PAIR_TCNN if mode == 2 else FLOP_PER_PAIR)
         return {"elapsed": elapsed, "steps": steps, "fps": steps / elapsed, "rows": float(rows.mean()),
                 "n_vox": float(np.mean(n_vox)), "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
                 "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
@@ -245,6 +256,10 @@ def main():
     if world == 1 and main_run["coords"] is not None:
         from oracle import bnv_oracle as orc           # checker only
         sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+        geo = None
+        if tcnn:
+            geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
+                ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
         g = main_run["coords"]
         pick = g[torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)].cpu()
         off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
@@ -253,9 +268,11 @@ def main():
         ovol = orc.OracleSparseVolume(8, voxel, np.array([dims] * 3), 8)
         present = wo[:, 0].cpu() > 0
         ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
-        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
+                              geo=geo)[0, :, :, 0]
         got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
         parity = {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
+                  "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
                   "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}
 
     if rank == 0:
@@ -268,7 +285,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": DTYPE[m], "data": "synthetic",
             "config": {"workload": f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, "
-                                   f"voxel {voxel}, fp32 pointnet.ckpt weights; step = "
+                                   f"voxel {voxel}, {'pointnet_tcnn.ckpt (fp16 tcnn)' if tcnn else 'fp32 pointnet.ckpt'} weights; step = "
                                    + ("uint16 depth image -> points + normals (GPU front end) + "
                                       if args.input == "depth" else "")
                                    + "encode_pointcloud + _integrate + "
@@ -290,7 +307,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"k_decode<LATTICE,{MODE_NAME[m]}> (SDF MLP 17-256x4-1)",
                          "achieved": main_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": main_run["dec_tflops"] / peak,
-                         "traffic": pmc_traffic_bytes("k_decode<1, 1>") if (m == 1 and world == 1) else None,
+                         "traffic": pmc_traffic_bytes("k_decode<1, 1>") if (m == 1 and world == 1 and not tcnn) else None,
                          "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv); "
                                          "algorithmic bytes = 40 B x evaluations",
                          "avg_kernel_ms": main_run["dec_ms"], "flop_per_launch": main_run["dec_flop"],
@@ -308,7 +325,7 @@ def main():
                                      "decode_kernel_ms": alt["dec_ms"], "decode_tflops": alt["dec_tflops"],
                                      "decode_frac_of_peak": alt["dec_tflops"] / PEAK_TFLOPS[am],
                                      "pointnet_kernel_ms": alt["enc_ms"], "pointnet_tflops": alt["enc_tflops"]}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not tcnn:
             out["cpu_baseline"] = cpu_baseline(depth_host[0], intr, synthetic.pose(0), args.grid)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
         print(json.dumps(out))

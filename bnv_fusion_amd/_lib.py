@@ -91,7 +91,7 @@ def load():
         "bnv_decode_lattice_list_offset": (sz, [i64, i64]),
         "bnv_lattice_neighbors": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, i64, vp, C.c_int, vp, sz,
                                             i32, vp]),
-        "bnv_lattice_mark": (C.c_int, [C.POINTER(Volume), i64, vp, sz, vp]),
+        "bnv_lattice_mark": (C.c_int, [C.POINTER(Volume), i64, vp, sz, i32, vp]),
         "bnv_lattice_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, C.c_int, vp, sz, vp]),
         "bnv_lattice_blend": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, C.POINTER(SdfDelta), vp, sz, vp,
                                         vp]),

@@ -611,6 +611,7 @@ struct LatticeWs {
   int32_t* stamp;     // [row_capacity]
   float* table;       // [row_capacity][27]
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
+  int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
   int64_t list_capacity;
   int64_t entry_capacity;
@@ -630,6 +631,7 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   char* st = take(row_capacity * 4);
   char* tb = take(row_capacity * 27 * 4);
   char* nm = take(row_capacity * 4);
+  char* os = take(row_capacity * 4);
   char* nl = take(256);
   char* nb = take(n * 27 * 4);
   char* li = take(cap * 4);
@@ -638,6 +640,7 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   char* en = take(ecap * 4);
   if (ws) {
     ws->need_mask = (uint32_t*)nm;
+    ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
     ws->entry_capacity = ecap;
     ws->stamp = (int32_t*)st;
@@ -656,7 +659,8 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            int32_t* __restrict__ nbr_rows,
                                                            int32_t* __restrict__ stamp, int32_t epoch,
                                                            int32_t* __restrict__ list, int32_t* __restrict__ n_list,
-                                                           const uint8_t* __restrict__ row_skip) {
+                                                           const uint8_t* __restrict__ row_skip,
+                                                           int32_t* __restrict__ origin_stamp) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   if (row >= 0) usable = weights[row] >= min_pts;
   // rows below min_pts can only ever appear under a false mask: mark them as unusable corners
   nbr_rows[t] = usable ? row : -1;
+  if (nb == 13 && row >= 0 && origin_stamp) origin_stamp[row] = epoch;  // this row is a decoded origin of this call
   // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
   if (usable && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
     list[atomicAdd(n_list, 1)] = row;
@@ -682,6 +687,7 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
 // the MLP work list.  Entries of masked points are never evaluated.
 constexpr int kMarkThreads = 1024;
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
+                                                               const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
@@ -723,6 +729,12 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
       if (row < 0) live = false;
       rowk[k] = dup ? -1 : row;
       lk[k] = li;
+    }
+    // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
+    // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
+    if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
+      const int owner = nbr_rows[b * 27 + ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
+      if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
     }
     if (live) {
 #pragma unroll
@@ -933,20 +945,21 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
                      n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
-                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip);
+                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
 
-int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, void* ws_ptr, size_t ws_bytes, bnv_stream_t stream_) {
-  if (!vol_ok_ro(vol) || n < 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, void* ws_ptr, size_t ws_bytes, int32_t epoch,
+                     bnv_stream_t stream_) {
+  if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
   BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 4, stream));
   if (n == 0) return BNV_OK;
   hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
-                     dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+                     dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
                      ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
@@ -1001,7 +1014,7 @@ int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const fl
   int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, nullptr, 0, ws_ptr, ws_bytes, epoch,
                                  stream);
   if (rc != BNV_OK) return rc;
-  rc = bnv_lattice_mark(vol, n, ws_ptr, ws_bytes, stream);
+  rc = bnv_lattice_mark(vol, n, ws_ptr, ws_bytes, epoch, stream);
   if (rc != BNV_OK) return rc;
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;

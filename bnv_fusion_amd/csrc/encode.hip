@@ -141,23 +141,30 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
     z = pts[(size_t)i * 6 + 2];
     valid = in_bounds(x, y, z, g);
   }
+  // ~20 pairs fall into each voxel and neighbouring pixels (= neighbouring lanes) mostly share it, so
+  // an atomic is issued only when the previous lane targets a different voxel AND the bit is not
+  // already visible (a stale read only costs a redundant atomicOr, never a missed one).
+  int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
     const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
     const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
     const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
-    const int fx = (int)floorf(xn), cx = (int)ceilf(xn);
-    const int fy = (int)floorf(yn), cy = (int)ceilf(yn);
-    const int fz = (int)floorf(zn), cz = (int)ceilf(zn);
-    const int nyz = g.n_xyz[1] * g.n_xyz[2];
+    fx = (int)floorf(xn), cx = (int)ceilf(xn);
+    fy = (int)floorf(yn), cy = (int)ceilf(yn);
+    fz = (int)floorf(zn), cz = (int)ceilf(zn);
+  }
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
-      // duplicates (floor == ceil) just set the same bit again
-      if ((k & 1) && cx == fx) continue;
-      if ((k & 2) && cy == fy) continue;
-      if ((k & 4) && cz == fz) continue;
-      const uint32_t id = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
-      atomicOr(&bitmap[id >> 5], 1u << (id & 31));
+  for (int k = 0; k < 8; ++k) {
+    const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
+    // duplicates (floor == ceil) would set the same bit again
+    const bool dup = ((k & 1) && cx == fx) || ((k & 2) && cy == fy) || ((k & 4) && cz == fz);
+    const int id = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + gz) : -1;
+    const int prev = __shfl_up(id, 1);
+    if (id >= 0 && !(lane > 0 && prev == id)) {
+      const uint32_t bit = 1u << (id & 31);
+      if (!(bitmap[id >> 5] & bit)) atomicOr(&bitmap[id >> 5], bit);
     }
   }
   const unsigned long long b = __ballot(valid);

@@ -231,7 +231,8 @@ int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host
 int bnv_lattice_neighbors(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* weights,
                           int64_t row_limit, const int64_t* origins, int64_t n, const uint8_t* row_skip,
                           int build_list, void* ws, size_t ws_bytes, int32_t epoch, bnv_stream_t stream);
-int bnv_lattice_mark(const bnv_volume_t* vol_host, int64_t n, void* ws, size_t ws_bytes, bnv_stream_t stream);
+int bnv_lattice_mark(const bnv_volume_t* vol_host, int64_t n, void* ws, size_t ws_bytes, int32_t epoch,
+                     bnv_stream_t stream);
 int bnv_lattice_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
                       const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws, size_t ws_bytes,
                       bnv_stream_t stream);
