@@ -2,7 +2,7 @@
 and SDF decode hot path, behind the reference's LitFusionPointNet / SparseVolume call surface.
 See DESIGN.md (layout, kernels, rooflines) and INTEGRATION.md (how run_e2e.py picks it up)."""
 from .fusion import LitFusionPointNet, LocalNeRFModel, get_neighbors, load_pretrained  # noqa: F401
-from .sparse_volume import SparseVolume, get_world_range  # noqa: F401
+from .sparse_volume import SparseVolume, VolumeList, get_world_range  # noqa: F401
 from .neural_map import NeuralMap  # noqa: F401
 
 

@@ -366,3 +366,55 @@ class SparseVolume:
         self.insert(coords, volume["features"].to(self._dev), volume["weights"].to(self._dev),
                     volume["num_hits"].to(self._dev))
         self.to_tensor()
+
+
+class VolumeList:
+    """Drop-in for the reference's VolumeList (sparse_volume.py:895-1158): a thin wrapper around one
+    ``fine_volume`` used by the Lightning test path (local_point_fusion.py:773-799, 801-864)."""
+
+    def __init__(self, n_feats, voxel_size, dimensions, min_pts_in_grid, capacity=100000, device="cuda:0"):
+        self.fine_volume = SparseVolume(n_feats, voxel_size, dimensions, min_pts_in_grid, capacity, device)
+        self.fine_min_coords = self.fine_volume.min_coords
+        self.fine_max_coords = self.fine_volume.max_coords
+        self.fine_n_xyz = self.fine_volume.n_xyz
+        self.fine_voxel_size = voxel_size
+        self.device = device
+
+    def to_tensor(self):
+        (self.fine_active_coords, self.fine_feats, self.fine_weights,
+         self.fine_num_hits) = self.fine_volume.to_tensor()
+
+    def query(self, keys):
+        return self.fine_volume.query(keys)
+
+    def insert(self, keys, new_feats, new_weights, new_num_hits):
+        self.fine_volume.insert(keys, new_feats, new_weights, new_num_hits)
+
+    def decode_pts(self, pts, nerf, sdf_delta=None, query_tensor=True):
+        """sparse_volume.py:1123-1150: world points -> SDF.  The world -> voxel conversion
+        ``(pts - min) / voxel`` happens inside the kernel with the reference's two fp32 roundings."""
+        return self.fine_volume.decode_pts(pts, nerf, sdf_delta=sdf_delta[0] if sdf_delta is not None else None,
+                                           is_coords=False, query_tensor=query_tensor)
+
+    def meshlize_coords(self, coords, nerf, sdf_delta=None, volume_resolution=None):
+        """sparse_volume.py:970-1032 up to (not including) marching cubes: the SDF lattice [n, 3, 3, 3] of
+        the given voxel coordinates that exist in the volume, decoded from live values.  The reference
+        converts the lattice to world coordinates and back in fp32 (:1001, :1141), which perturbs the
+        exact half-integer lattice by an ulp; that path is reproduced by decode_pts(pts) -- here the
+        exact lattice is used (SparseVolume.meshlize's formulation)."""
+        c = coords.reshape(-1, 3).long()
+        _, w, _ = self.fine_volume.query(c)
+        present = w[:, 0] > 0
+        c = c[present]
+        sdf = self.fine_volume.decode_lattice(c, nerf, sdf_delta[0] if sdf_delta is not None else None,
+                                              query_tensor=False)
+        return c, sdf.reshape(-1, 3, 3, 3)
+
+    def meshlize(self, nerf, sdf_delta=None, volume_resolution=None, path=None):
+        return self.fine_volume.meshlize(nerf, sdf_delta[0] if sdf_delta is not None else None, path)
+
+    def save(self, path):
+        self.fine_volume.save(path + "_fine")
+
+    def load(self, path):
+        self.fine_volume.load(path)

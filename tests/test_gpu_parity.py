@@ -527,3 +527,20 @@ def test_tcnn_checkpoint_encode_decode_vs_oracle(bnv, orc):
     a = m32.encode_pointcloud(torch.from_numpy(z["frames"][0]).to(DEV), nm.volume.n_xyz, nm.volume.min_coords,
                               nm.volume.max_coords, voxel, return_dense=False)
     assert bnv.get_mlp_mode() in (0, 1) and a[0].shape[1] == 8
+
+
+def test_volume_list_wrapper(bnv, model, golden_volume):
+    """VolumeList (sparse_volume.py:895-1158): world-coordinate decode and the touched-voxel lattice driver."""
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    d = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    vl = bnv.VolumeList(8, float(z["voxel_size"]), z["dims"], 8, device=DEV)
+    n = len(z["keys_sorted"])
+    vl.insert(torch.from_numpy(z["keys_sorted"]).to(DEV), torch.from_numpy(z["features_sorted"]).to(DEV),
+              torch.from_numpy(z["weights_sorted"]).to(DEV), torch.zeros(n, 1, device=DEV))
+    vl.to_tensor()
+    out = vl.decode_pts(torch.from_numpy(d["random_world_coords"]).to(DEV), model.nerf, None, query_tensor=False)
+    assert np.abs(out.cpu().numpy() - d["random_world_out"]).max() <= SDF_TOL
+    coords = torch.cat([torch.from_numpy(d["origins"]), torch.tensor([[1, 1, 1]])]).to(DEV)   # one absent voxel
+    kept, sdf = vl.meshlize_coords(coords, model.nerf)
+    assert kept.shape[0] == len(d["origins"]) and sdf.shape[1:] == (3, 3, 3)
+    assert np.abs(sdf.reshape(-1, 27).cpu().numpy() - d["lattice_q"][0, :, :, 0]).max() <= SDF_TOL
