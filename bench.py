@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--input", default="depth", choices=["depth", "points"],
                     help="'depth' (default): a step starts from the uint16 depth image resident in HBM and runs the "
                          "GPU front end (unprojection + normals); 'points': from precomputed input_pts")
+    ap.add_argument("--sync-frames", action="store_true",
+                    help="1 GPU: use the synchronous per-frame API (one host sync mid-frame) instead of the "
+                         "pipelined fuse_and_decode_async")
     ap.add_argument("--parallelism", default="frame", choices=["frame", "spatial"],
                     help="N > 1: 'frame' = ranks encode/decode different frames of a batch, replicated volume, one "
                          "all-gather per batch (throughput scaling); 'spatial' = voxels sharded by spatial hash, "
@@ -179,7 +182,7 @@ def main():
             for t, d in enumerate(depth_host)]
     n_points = int((depth_host[0] > 0).sum())
 
-    def run_frames(first, count, decode=True):
+    def run_frames(first, count, decode=True, collect=None):
         """Processes frames [first, first+count) in order; returns this rank's last (coords, sdf)."""
         last = (None, None)
         if frame_parallel:
@@ -187,9 +190,25 @@ def main():
                 out = nm.process_batch(frames[t0: min(t0 + world, first + count)], decode=decode)
                 if out[0] is not None:
                     last = out
+        elif world == 1 and not args.sync_frames:
+            # software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU
+            # never waits for the host (each result() waits on that frame's own event only)
+            pending = None
+            for t in range(first, first + count):
+                h = nm.fuse_and_decode_async(frames[t], decode=decode)
+                if pending is not None:
+                    r = pending.result()
+                    if collect is not None:
+                        collect(r)
+                pending = h
+            last = pending.result()
+            if collect is not None:
+                collect(last)
         else:
             for t in range(first, first + count):
                 last = nm.fuse_and_decode(frames[t]) if decode else (nm.integrate(frames[t]), None)
+                if collect is not None:
+                    collect(last)
         return last
 
     run_frames(0, args.preroll, decode=False)           # setup: make the decode mask live
@@ -207,17 +226,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        def collect(res):
+            c, _ = res
+            n_vox.append(0 if c is None else int(c.shape[0]))
+
         if frame_parallel:
             coords, sdf = run_frames(first, steps)
             table_rows.append(nm.volume.last_lattice_evals().clone() if coords is not None
                               else torch.zeros(1, dtype=torch.int32, device=dev))
             n_vox.append(0 if coords is None else int(coords.shape[0]))
-        else:
+        elif world > 1:
             for t in range(first, first + steps):
                 coords, sdf = nm.fuse_and_decode(frames[t])
-                table_rows.append((nm.volume.last_lattice_table_rows() * 27 if world > 1
-                                   else nm.volume.last_lattice_evals()).clone())   # async 4-byte device copy
+                table_rows.append((nm.volume.last_lattice_table_rows() * 27).clone())
                 n_vox.append(0 if coords is None else int(coords.shape[0]))
+        else:
+            coords, sdf = run_frames(first, steps, collect=collect)
+            table_rows.append(nm.volume.last_lattice_evals().clone())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

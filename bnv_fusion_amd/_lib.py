@@ -79,7 +79,7 @@ def load():
         "bnv_volume_clear": (C.c_int, [C.POINTER(Volume), vp]),
         "bnv_volume_rehash": (C.c_int, [C.POINTER(Volume), vp]),
         "bnv_volume_workspace_bytes": (sz, [i64]),
-        "bnv_volume_integrate": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, sz, vp]),
+        "bnv_volume_integrate": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, vp, sz, vp]),
         "bnv_volume_insert": (C.c_int, [C.POINTER(Volume), vp, vp, vp, vp, i64, vp, sz, vp]),
         "bnv_volume_query": (C.c_int, [C.POINTER(Volume), vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         "bnv_volume_count_optim": (C.c_int, [C.POINTER(Volume), vp, i64, vp, i64, vp, i32, vp]),
@@ -89,12 +89,12 @@ def load():
         "bnv_decode_lattice_count_offset": (sz, [i64]),
         "bnv_decode_lattice_table_offset": (sz, [i64]),
         "bnv_decode_lattice_list_offset": (sz, [i64, i64]),
-        "bnv_lattice_neighbors": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, i64, vp, C.c_int, vp, sz,
-                                            i32, vp]),
-        "bnv_lattice_mark": (C.c_int, [C.POINTER(Volume), i64, vp, sz, i32, vp]),
+        "bnv_lattice_neighbors": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, i64, vp, vp, C.c_int, vp,
+                                            sz, i32, vp]),
+        "bnv_lattice_mark": (C.c_int, [C.POINTER(Volume), i64, vp, vp, sz, i32, vp]),
         "bnv_lattice_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, C.c_int, vp, sz, vp]),
-        "bnv_lattice_blend": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, C.POINTER(SdfDelta), vp, sz, vp,
-                                        vp]),
+        "bnv_lattice_blend": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, C.POINTER(SdfDelta), vp, sz,
+                                        vp, vp]),
         "bnv_depth_workspace_bytes": (sz, [C.c_int, C.c_int]),
         "bnv_depth_to_points": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_double, vp, sz, vp, vp, vp]),
@@ -104,7 +104,7 @@ def load():
         "bnv_get_mlp_mode": (C.c_int, []),
         "bnv_profile_enable": (C.c_int, [C.c_int]),
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
-        "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64,
+        "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, vp, vp]),
     }

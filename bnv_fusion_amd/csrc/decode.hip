@@ -660,7 +660,9 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            int32_t* __restrict__ stamp, int32_t epoch,
                                                            int32_t* __restrict__ list, int32_t* __restrict__ n_list,
                                                            const uint8_t* __restrict__ row_skip,
-                                                           int32_t* __restrict__ origin_stamp) {
+                                                           int32_t* __restrict__ origin_stamp,
+                                                           const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;  // count from device memory; n = grid capacity
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
@@ -691,7 +693,9 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
                                                                uint32_t* __restrict__ need_mask,
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
-                                                               int64_t entry_capacity) {
+                                                               int64_t entry_capacity,
+                                                               const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
   // new entries are collected per block in LDS and appended with ONE global atomic per block
   __shared__ int s_buf[kMarkThreads * 8];
   __shared__ int s_count, s_base;
@@ -758,7 +762,8 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
 __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                        const float* __restrict__ table, bnv_grid_t g,
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const int32_t* __restrict__ n_dev) {
+  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
@@ -933,8 +938,8 @@ size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity) {
 }
 
 int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights, int64_t row_limit,
-                          const int64_t* origins, int64_t n, const uint8_t* row_skip, int build_list, void* ws_ptr,
-                          size_t ws_bytes, int32_t epoch, bnv_stream_t stream_) {
+                          const int64_t* origins, int64_t n, const int32_t* n_dev, const uint8_t* row_skip,
+                          int build_list, void* ws_ptr, size_t ws_bytes, int32_t epoch, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   if (!ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
@@ -945,13 +950,13 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
                      n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
-                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp);
+                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
 
-int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, void* ws_ptr, size_t ws_bytes, int32_t epoch,
-                     bnv_stream_t stream_) {
+int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
+                     int32_t epoch, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
@@ -960,7 +965,7 @@ int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, void* ws_ptr, size_t ws
   if (n == 0) return BNV_OK;
   hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity);
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -988,8 +993,8 @@ int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const flo
 }
 
 int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
-                      const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, float* out_sdf,
-                      bnv_stream_t stream) {
+                      const int32_t* n_dev, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes,
+                      float* out_sdf, bnv_stream_t stream) {
   if (!vol_ok_ro(vol) || !grid || n < 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   if (!origins || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
@@ -998,27 +1003,27 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
   bnv_sdf_delta_t d = {};
   if (delta) d = *delta;
   hipLaunchKernelGGL(k_lattice_blend, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf);
+                     ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
 
 int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
                        const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
-                       int64_t n, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes, int32_t epoch,
-                       float* out_sdf, bnv_stream_t stream) {
+                       int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes,
+                       int32_t epoch, float* out_sdf, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend
-  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, nullptr, 0, ws_ptr, ws_bytes, epoch,
-                                 stream);
+  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
+                                 epoch, stream);
   if (rc != BNV_OK) return rc;
-  rc = bnv_lattice_mark(vol, n, ws_ptr, ws_bytes, epoch, stream);
+  rc = bnv_lattice_mark(vol, n, n_dev, ws_ptr, ws_bytes, epoch, stream);
   if (rc != BNV_OK) return rc;
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;
-  return bnv_lattice_blend(vol, grid, origins, n, delta, ws_ptr, ws_bytes, out_sdf, stream);
+  return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
 
 }  // extern "C"

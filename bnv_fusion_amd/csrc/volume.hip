@@ -57,10 +57,20 @@ __global__ __launch_bounds__(256) void k_vol_clear(uint64_t* __restrict__ slot_k
 }
 
 // probe / CAS-insert one key per thread; records the slot and whether this thread created it
+// every kernel of the upsert takes its element count either from the host (n) or, when n_dev is set,
+// from device memory (then n is only the capacity the grid was sized for)
+__device__ __forceinline__ int64_t dev_count(int64_t n, const int32_t* n_dev) {
+  if (!n_dev) return n;
+  const int64_t m = *n_dev;
+  return m < n ? m : n;
+}
+
 __global__ __launch_bounds__(256) void k_vol_probe_insert(bnv_volume_t v, const int64_t* __restrict__ coords,
-                                                          int64_t n, int32_t* __restrict__ slot_of,
+                                                          int64_t n, const int32_t* __restrict__ n_dev,
+                                                          int32_t* __restrict__ slot_of,
                                                           int32_t* __restrict__ is_new,
                                                           int32_t* __restrict__ error) {
+  n = dev_count(n, n_dev);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   uint64_t key;
@@ -94,8 +104,10 @@ __global__ __launch_bounds__(256) void k_vol_probe_insert(bnv_volume_t v, const 
 }
 
 __global__ __launch_bounds__(kVolThreads) void k_vol_scan_partial(const int32_t* __restrict__ is_new, int64_t n,
+                                                                  const int32_t* __restrict__ n_dev,
                                                                   uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wave_tot[kVolThreads / 64];
+  n = dev_count(n, n_dev);
   const int64_t base = (int64_t)blockIdx.x * kVolTile + (int64_t)threadIdx.x * kVolItems;
   uint32_t s = 0;
 #pragma unroll
@@ -123,11 +135,13 @@ __global__ __launch_bounds__(1024) void k_vol_scan_top(uint32_t* __restrict__ bl
 
 // assigns rows to the created slots in batch order: row = n_rows + (number of created keys before i)
 __global__ __launch_bounds__(kVolThreads) void k_vol_assign_rows(bnv_volume_t v, const int64_t* __restrict__ coords,
-                                                                 int64_t n, const int32_t* __restrict__ slot_of,
+                                                                 int64_t n, const int32_t* __restrict__ n_dev,
+                                                                 const int32_t* __restrict__ slot_of,
                                                                  const int32_t* __restrict__ is_new,
                                                                  const uint32_t* __restrict__ block_sums,
                                                                  int32_t* __restrict__ error) {
   __shared__ uint32_t wave_tot[kVolThreads / 64];
+  n = dev_count(n, n_dev);
   const int64_t base = (int64_t)blockIdx.x * kVolTile + (int64_t)threadIdx.x * kVolItems;
   uint32_t fl[kVolItems];
   uint32_t s = 0;
@@ -168,7 +182,9 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
 // _integrate/_update (local_point_fusion.py:647-673) on rows that now all exist
 __global__ __launch_bounds__(256) void k_vol_integrate_apply(bnv_volume_t v, const float* __restrict__ feats,
                                                              const int64_t* __restrict__ pcounts, int64_t n,
+                                                             const int32_t* __restrict__ n_dev,
                                                              const int32_t* __restrict__ slot_of) {
+  n = dev_count(n, n_dev);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int32_t slot = slot_of[i];
@@ -193,7 +209,9 @@ __global__ __launch_bounds__(256) void k_vol_integrate_apply(bnv_volume_t v, con
 __global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const float* __restrict__ feats,
                                                           const float* __restrict__ weights,
                                                           const float* __restrict__ hits, int64_t n,
+                                                          const int32_t* __restrict__ n_dev,
                                                           const int32_t* __restrict__ slot_of) {
+  n = dev_count(n, n_dev);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int32_t slot = slot_of[i];
@@ -263,20 +281,21 @@ static bool vol_ok(const bnv_volume_t* v) {
          v->row_capacity > 0 && v->n_feats == 8;
 }
 
-static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const VolWs& ws,
-                           hipStream_t stream) {
+static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const int32_t* n_dev,
+                           const VolWs& ws, hipStream_t stream) {
   const unsigned nb256 = (unsigned)((n + 255) / 256);
   const int nbt = (int)((n + kVolTile - 1) / kVolTile);
   BNV_HIP_CHECK(hipMemsetAsync(ws.total_new, 0, 8, stream));
-  hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, ws.slot_of, ws.is_new,
-                     ws.error);
+  hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, n_dev, ws.slot_of,
+                     ws.is_new, ws.error);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_scan_partial, dim3(nbt), dim3(kVolThreads), 0, stream, ws.is_new, n, ws.block_sums);
+  hipLaunchKernelGGL(k_vol_scan_partial, dim3(nbt), dim3(kVolThreads), 0, stream, ws.is_new, n, n_dev,
+                     ws.block_sums);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nbt, ws.total_new);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_assign_rows, dim3(nbt), dim3(kVolThreads), 0, stream, v, coords, n, ws.slot_of,
-                     ws.is_new, ws.block_sums, ws.error);
+  hipLaunchKernelGGL(k_vol_assign_rows, dim3(nbt), dim3(kVolThreads), 0, stream, v, coords, n, n_dev,
+                     ws.slot_of, ws.is_new, ws.block_sums, ws.error);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_commit, dim3(1), dim3(1), 0, stream, v.n_rows, ws.total_new);
   BNV_LAUNCH_CHECK();
@@ -311,7 +330,7 @@ int bnv_volume_rehash(const bnv_volume_t* vol, bnv_stream_t stream) {
 }
 
 int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const float* feats,
-                         const int64_t* pcounts, int64_t n, void* ws_ptr, size_t ws_bytes,
+                         const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
                          bnv_stream_t stream_) {
   if (!vol_ok(vol) || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
@@ -319,10 +338,10 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   VolWs ws;
   if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  const int rc = vol_upsert_rows(*vol, coords, n, ws, stream);
+  const int rc = vol_upsert_rows(*vol, coords, n, n_dev, ws, stream);
   if (rc != BNV_OK) return rc;
   hipLaunchKernelGGL(k_vol_integrate_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, feats,
-                     pcounts, n, ws.slot_of);
+                     pcounts, n, n_dev, ws.slot_of);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -336,10 +355,10 @@ int bnv_volume_insert(const bnv_volume_t* vol, const int64_t* coords, const floa
   VolWs ws;
   if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  const int rc = vol_upsert_rows(*vol, coords, n, ws, stream);
+  const int rc = vol_upsert_rows(*vol, coords, n, nullptr, ws, stream);
   if (rc != BNV_OK) return rc;
   hipLaunchKernelGGL(k_vol_insert_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, feats,
-                     weights, num_hits, n, ws.slot_of);
+                     weights, num_hits, n, (const int32_t*)nullptr, ws.slot_of);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

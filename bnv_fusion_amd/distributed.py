@@ -128,7 +128,7 @@ class HipShardBackend:
         self._epoch += 1
         t = touched.reshape(-1, 3).long().contiguous()
         _lib.check(v._lib.bnv_lattice_neighbors(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._weights),
-                                                v._row_capacity, _lib.ptr(t), n, _lib.ptr(self._ghost), 1,
+                                                v._row_capacity, _lib.ptr(t), n, None, _lib.ptr(self._ghost), 1,
                                                 _lib.ptr(ws), ws.numel(), self._epoch, _lib.stream_ptr()),
                    "bnv_lattice_neighbors")
         _lib.check(v._lib.bnv_lattice_table(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._features),
@@ -160,10 +160,10 @@ class HipShardBackend:
         self._epoch += 1
         o = owned_touched.reshape(-1, 3).long().contiguous()
         _lib.check(v._lib.bnv_lattice_neighbors(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._weights),
-                                                v._row_capacity, _lib.ptr(o), n, None, 0, _lib.ptr(ws), ws.numel(),
+                                                v._row_capacity, _lib.ptr(o), n, None, None, 0, _lib.ptr(ws), ws.numel(),
                                                 self._epoch, _lib.stream_ptr()), "bnv_lattice_neighbors")
         d = _lib.SdfDelta()
-        _lib.check(v._lib.bnv_lattice_blend(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(o), n, C.byref(d),
+        _lib.check(v._lib.bnv_lattice_blend(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(o), n, None, C.byref(d),
                                             _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_lattice_blend")
         return out

@@ -206,7 +206,11 @@ class LitFusionPointNet(nn.Module):
         return grid, res
 
     # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
-    def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
+    def encode_pointcloud_async(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=False):
+        """Enqueues the encode and returns WITHOUT synchronising: capacity-sized output buffers
+        (feats [cap,8], pcounts [cap] i64, flat_ids [cap] i64, grid_ids [cap,3] i64) and the device
+        counters (int32 [8]: n_valid, n_unique, n_out, n_avg_pts as float bits, error).  Downstream kernels
+        read n_out from ``counters[2:3]`` on the device."""
         lib = self._lib_for(self.pointnet_pack)
         self._select_mode(lib)
         assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
@@ -222,8 +226,7 @@ class LitFusionPointNet(nn.Module):
             need = int(lib.bnv_encode_workspace_bytes(self._enc_ws_points, n_arr))
             self._enc_ws = torch.zeros(need, dtype=torch.uint8, device=dev)   # zero-filled = clean
             self._enc_ws_key = key
-        emit_all = 1 if return_dense else 0
-        cap = min(8 * n, nvox) if return_dense else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
+        cap = min(8 * n, nvox) if emit_all else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
         cap = max(cap, 1)
         feats = torch.empty((cap, 8), dtype=torch.float32, device=dev)
         pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
@@ -232,10 +235,19 @@ class LitFusionPointNet(nn.Module):
         counters = torch.zeros(8, dtype=torch.int32, device=dev)
         _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
                                              _lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points,
-                                             _lib.ptr(feats),
-                                             _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids), cap,
-                                             emit_all, _lib.ptr(counters), _lib.stream_ptr()),
-                   "bnv_encode_pointcloud")
+                                             _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids),
+                                             _lib.ptr(grid_ids), cap, 1 if emit_all else 0, _lib.ptr(counters),
+                                             _lib.stream_ptr()), "bnv_encode_pointcloud")
+        return feats, pcounts, flat_ids, grid_ids, counters, cap
+
+    def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
+        lib = self._lib_for(self.pointnet_pack)
+        feats, pcounts, flat_ids, grid_ids, counters, cap = self.encode_pointcloud_async(
+            input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=return_dense)
+        pts = input_pts[0].detach().float().contiguous()
+        dev = pts.device
+        n = int(pts.shape[0])
+        grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
         host = counters.cpu()                       # the one device->host sync of the frame
         n_valid, n_unique, n_out, err = int(host[0]), int(host[1]), int(host[2]), int(host[4])
         if err:

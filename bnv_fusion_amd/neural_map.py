@@ -23,6 +23,34 @@ def frame_input_pts(frame, max_depth=10.0):
     return pts
 
 
+class FrameHandle:
+    """A frame enqueued by NeuralMap.fuse_and_decode_async.  ``result()`` waits for THAT frame only (a HIP
+    event recorded behind its last kernel) and returns (coords [U',3] i64, sdf [U',27] or None)."""
+
+    def __init__(self, nm, bufs, host_counters, event, cap, sdf):
+        self._nm, self._bufs, self._host, self._event, self._cap, self._sdf = nm, bufs, host_counters, event, cap, sdf
+        self._done = None
+
+    def result(self):
+        if self._done is not None:
+            return self._done
+        self._event.synchronize()
+        h = self._host
+        n_valid, n_out, err = int(h[0]), int(h[2]), int(h[4])
+        vol = self._nm.volume
+        vol._rows_upper -= self._cap - n_out          # the reservation was made for the capacity bound
+        if err:
+            raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+        if n_valid == 0:
+            self._done = (None, None)
+        else:
+            vol.track_n_pts(float(h[3:4].view(torch.float32)[0]))
+            feats, pcounts, flat_ids, grid_ids = self._bufs
+            self._done = (grid_ids[:n_out], None if self._sdf is None else self._sdf[:n_out])
+        self._bufs = None
+        return self._done
+
+
 class NeuralMap:
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
                  capacity=100000, device="cuda:0", tsdf=False, truncated_units=10, sdf_delta_weight=0.1):
@@ -82,6 +110,26 @@ class NeuralMap:
             return None, None
         sdf = self.volume.decode_lattice(coords, self.pointnet.nerf, self.sdf_delta, query_tensor=False)
         return coords, sdf
+
+    def fuse_and_decode_async(self, frame, decode=True):
+        """The same work as fuse_and_decode, enqueued without any host synchronisation: integrate and the
+        lattice decode read the frame's voxel count from device memory.  Returns a FrameHandle; call
+        ``.result()`` after enqueuing the NEXT frame to keep the GPU busy."""
+        with torch.no_grad():
+            v = self.volume
+            input_pts = frame_input_pts(frame)
+            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
+                input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+            n_dev = counters[2:3]
+            v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
+            self._integrate_tsdf(frame)
+            sdf = v.decode_lattice(grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False,
+                                   n_dev=n_dev) if decode else None
+            host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+            host.copy_(counters, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf)
 
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""

@@ -173,9 +173,10 @@ class SparseVolume:
         return self._ws
 
     # ---- reference API ---------------------------------------------------------------------------
-    def integrate(self, coords, feats, pcounts):
+    def integrate(self, coords, feats, pcounts, n_dev=None):
         """Fused LitFusionPointNet._integrate (local_point_fusion.py:647-673): query + running
-        average + upsert for UNIQUE keys in one pass."""
+        average + upsert for UNIQUE keys in one pass.  ``n_dev`` (device int32 [1]): take the element
+        count from the device; the tensors are then capacity-sized buffers (no host sync needed)."""
         n = int(coords.shape[0])
         if n == 0:
             return
@@ -185,7 +186,7 @@ class SparseVolume:
         self._reserve(n)
         ws = self._workspace(n)
         _lib.check(self._lib.bnv_volume_integrate(C.byref(self._struct()), _lib.ptr(coords), _lib.ptr(feats),
-                                                  _lib.ptr(pcounts), n, _lib.ptr(ws), ws.numel(),
+                                                  _lib.ptr(pcounts), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()), "bnv_volume_integrate")
         self._rows_upper += n
 
@@ -300,7 +301,7 @@ class SparseVolume:
                    "bnv_decode_pts")
         return out.reshape(shape[:-1] + [1])
 
-    def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True):
+    def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True, n_dev=None):
         """decode_pts on the 3x3x3 lattice {-0.5, 0, 0.5}^3 around integer voxel ``origins`` [B, 3]
         (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27]."""
         self._select_mode(nerf)
@@ -319,7 +320,8 @@ class SparseVolume:
         self._lattice_epoch += 1
         _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
-                                                C.byref(d), _lib.ptr(self._lattice_ws), self._lattice_ws.numel(),
+                                                _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
+                                                self._lattice_ws.numel(),
                                                 self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_decode_lattice")
         return out

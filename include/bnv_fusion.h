@@ -169,10 +169,12 @@ size_t bnv_volume_workspace_bytes(int64_t max_keys);
 /* LitFusionPointNet._integrate + _update (local_point_fusion.py:647-673) fused with
  * SparseVolume.query/insert (sparse_volume.py:561-585, 661-695): for n UNIQUE keys,
  * w = min(count/32, 1); f = (f_old*w_old + f*w)/(w_old + w); upsert.  coords [n,3] i64,
- * feats [n,8], pcounts [n] i64. */
+ * feats [n,8], pcounts [n] i64.  If n_dev (a device int32, e.g. &counters->n_out of the encode that
+ * produced the inputs) is not NULL the element count is read on the device and n is only the
+ * capacity the launch is sized for -- no host synchronisation between encode and integrate. */
 int bnv_volume_integrate(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
-                         const int64_t* pcounts, int64_t n, void* ws, size_t ws_bytes,
-                         bnv_stream_t stream);
+                         const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws,
+                         size_t ws_bytes, bnv_stream_t stream);
 /* SparseVolume.insert (upsert with explicit values), sparse_volume.py:561-585. */
 int bnv_volume_insert(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
                       const float* weights, const float* num_hits, int64_t n, void* ws,
@@ -211,10 +213,11 @@ size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity
 size_t bnv_decode_lattice_count_offset(int64_t row_capacity);
 /* The same decode for the 3x3x3 lattice {-0.5,0,0.5}^3 around n integer voxel origins
  * (SparseVolume.meshlize's decode_pts call, sparse_volume.py:717-738): out [n,27] f32.
- * Evaluates the MLP once per (corner voxel, local offset) instead of 8x per lattice point. */
+ * Evaluates the MLP once per (corner voxel, local offset) instead of 8x per lattice point.
+ * n_dev: optional device-side count as in bnv_volume_integrate (n = capacity). */
 int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
                        const float* features, const float* weights, int64_t row_limit,
-                       const float* sdfmlp_pack, const int64_t* origins, int64_t n,
+                       const float* sdfmlp_pack, const int64_t* origins, int64_t n, const int32_t* n_dev,
                        const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
                        float* out_sdf, bnv_stream_t stream);
 
@@ -229,16 +232,17 @@ int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host
  *              (use_entries) or all 27 l of every listed row;
  *   blend:     out[n,27] from the neighbour rows and the table. */
 int bnv_lattice_neighbors(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* weights,
-                          int64_t row_limit, const int64_t* origins, int64_t n, const uint8_t* row_skip,
-                          int build_list, void* ws, size_t ws_bytes, int32_t epoch, bnv_stream_t stream);
-int bnv_lattice_mark(const bnv_volume_t* vol_host, int64_t n, void* ws, size_t ws_bytes, int32_t epoch,
-                     bnv_stream_t stream);
+                          int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
+                          const uint8_t* row_skip, int build_list, void* ws, size_t ws_bytes, int32_t epoch,
+                          bnv_stream_t stream);
+int bnv_lattice_mark(const bnv_volume_t* vol_host, int64_t n, const int32_t* n_dev, void* ws, size_t ws_bytes,
+                     int32_t epoch, bnv_stream_t stream);
 int bnv_lattice_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
                       const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws, size_t ws_bytes,
                       bnv_stream_t stream);
 int bnv_lattice_blend(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const int64_t* origins,
-                      int64_t n, const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, float* out_sdf,
-                      bnv_stream_t stream);
+                      int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta_host, void* ws,
+                      size_t ws_bytes, float* out_sdf, bnv_stream_t stream);
 /* Byte offsets of the table [row_capacity,27] f32 and of the row work list inside the workspace. */
 size_t bnv_decode_lattice_table_offset(int64_t row_capacity);
 size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity);

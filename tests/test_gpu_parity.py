@@ -544,3 +544,31 @@ def test_volume_list_wrapper(bnv, model, golden_volume):
     kept, sdf = vl.meshlize_coords(coords, model.nerf)
     assert kept.shape[0] == len(d["origins"]) and sdf.shape[1:] == (3, 3, 3)
     assert np.abs(sdf.reshape(-1, 27).cpu().numpy() - d["lattice_q"][0, :, :, 0]).max() <= SDF_TOL
+
+
+def test_async_frames_equal_sync_frames(bnv):
+    """fuse_and_decode_async (device-side counts, no mid-frame sync, results collected one frame late)
+    produces exactly what the synchronous API produces."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    a = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    b = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+               "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)} for t in range(12)]
+    sync_out = [a.fuse_and_decode(f) for f in frames]
+    handles, async_out = [], []
+    for f in frames:
+        handles.append(b.fuse_and_decode_async(f))
+        if len(handles) > 1:
+            async_out.append(handles[-2].result())
+    async_out.append(handles[-1].result())
+    for (c0, s0), (c1, s1) in zip(sync_out, async_out):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    assert a.volume.num_rows() == b.volume.num_rows() and b.volume._rows_upper == b.volume.num_rows()
+    assert np.allclose(a.volume.n_pts_list, b.volume.n_pts_list)
+    assert torch.equal(a.tsdf_vol.tsdf, b.tsdf_vol.tsdf)
+    # an empty frame yields (None, None) and leaves the volume untouched
+    far = {"input_pts": torch.full((1, 100, 6), 50.0, device=DEV)}
+    assert b.fuse_and_decode_async(far).result() == (None, None)
+    assert b.volume.num_rows() == a.volume.num_rows()
