@@ -572,3 +572,63 @@ def test_async_frames_equal_sync_frames(bnv):
     far = {"input_pts": torch.full((1, 100, 6), 50.0, device=DEV)}
     assert b.fuse_and_decode_async(far).result() == (None, None)
     assert b.volume.num_rows() == a.volume.num_rows()
+
+
+@pytest.mark.parametrize("grid", [128, 512])
+def test_other_baseline_grids(bnv, orc, grid):
+    """BASELINE configs 1 and 3: 128^3 (voxel 0.02) and 512^3 (voxel 0.01) grids, full 640x480 frame:
+    voxel ids / counts bit-exact against the oracle's torch.unique, fuse + decode runs and is live."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[grid]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV)
+    assert nm.volume.n_xyz.tolist() == [grid] * 3
+    fr = {"depth": torch.from_numpy(synthetic.depth_u16(0)).to(DEV), "intr_mat": synthetic.intrinsics(),
+          "T_wc": synthetic.pose(0)}
+    from bnv_fusion_amd.neural_map import frame_input_pts
+    pts = frame_input_pts(fr)
+    f, c, ids, g, n = model.encode_pointcloud(pts, nm.volume.n_xyz, nm.volume.min_coords, nm.volume.max_coords,
+                                              voxel, return_dense=False)
+    valid = ~torch.isnan(pts[0, :, 0])
+    rel, gid = orc.get_relative_xyz(pts[:, valid, :3].cpu(), nm.volume.min_coords.cpu(), voxel)
+    u, cnt = torch.unique(orc.flatten(gid.reshape(1, -1, 3), nm.volume.n_xyz.cpu()).long()[0], return_counts=True)
+    keep = cnt >= 8
+    assert torch.equal(ids.cpu(), u[keep]) and torch.equal(c.cpu()[:, 0], cnt[keep])
+    for _ in range(32):
+        model._integrate(nm.volume, g, f, c)
+    sdf = nm.volume.decode_lattice(g, model.nerf, query_tensor=False)
+    assert torch.isfinite(sdf).all() and float((sdf != voxel).float().mean()) > 0.2
+
+
+def test_non_cubic_volume_and_save_load(bnv, orc, sd, tmp_path):
+    """Non-cubic grid (distinct n_x, n_y, n_z strides) against the oracle, then SparseVolume.save/load."""
+    dims, voxel = np.array([1.0, 1.5, 0.7]), 0.02
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    vol = bnv.SparseVolume(8, voxel, dims, 8, device=DEV)
+    ovol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    assert vol.n_xyz.tolist() == ovol.n_xyz.tolist() and len(set(vol.n_xyz.tolist())) == 3
+    g = torch.Generator().manual_seed(3)
+    xy = (torch.rand(20000, 2, generator=g) - 0.5) * torch.tensor([0.4, 0.6])   # dense: weights reach 8
+    z = 0.1 * torch.sin(xy[:, 0] * 7) * torch.cos(xy[:, 1] * 4)
+    nrm = torch.nn.functional.normalize(torch.randn(20000, 3, generator=g), dim=-1)
+    pts = torch.cat([xy, z[:, None], nrm], -1)[None]
+    for _ in range(9):
+        f, c, ids, gg, n = _encode(model, vol, pts)
+        fo, co, ido, go, no = orc.encode_pointcloud(sd, pts, ovol.n_xyz, ovol.min_coords, ovol.max_coords, voxel)
+        assert torch.equal(ids.cpu(), ido) and torch.equal(c.cpu(), co) and torch.equal(gg.cpu(), go)
+        assert (f.cpu() - fo).abs().max() <= FEAT_TOL
+        model._integrate(vol, gg, f, c)
+        orc.integrate(ovol, go, fo, co)
+    ref = ovol.decode_pts(orc.lattice_coords(go.numpy()[:200]), sd, None, is_coords=True, query_tensor=False)
+    got = vol.decode_lattice(gg[:200], model.nerf, query_tensor=False)
+    assert (got.cpu() - ref[0, :, :, 0]).abs().max() <= SDF_TOL
+    assert float((ref != voxel).float().mean()) > 0.05
+    # save / load (sparse_volume.py:835-892)
+    vol.to_tensor()
+    vol.save(str(tmp_path / "final"))
+    v2 = bnv.SparseVolume(8, voxel, dims, 8, device=DEV)
+    v2.load(str(tmp_path / "final") + "_sparse_volume.pth")
+    assert torch.equal(v2.active_coordinates, vol.active_coordinates)
+    assert torch.equal(v2.features, vol.features) and torch.equal(v2.weights, vol.weights)
+    got2 = v2.decode_lattice(gg[:200], model.nerf, query_tensor=True)
+    assert torch.equal(got2, got)
