@@ -362,7 +362,8 @@ class SparseVolume:
         torch.save(out_dict, path + "_sparse_volume.pth")
 
     def load(self, path):
-        volume = torch.load(path, map_location=self._dev)
+        # the reference's file format (a dict with numpy entries) predates torch's weights_only default
+        volume = torch.load(path, map_location=self._dev, weights_only=False)
         coords = volume["active_coordinates"].to(self._dev)
         self.reset(max(len(coords), 1024))
         self.insert(coords, volume["features"].to(self._dev), volume["weights"].to(self._dev),
