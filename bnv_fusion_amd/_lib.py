@@ -15,7 +15,7 @@ SYMBOLS = [
     "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_voxelize_pairs",
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
-    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_tsdf_integrate", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
+    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_tsdf_integrate", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
@@ -102,6 +102,7 @@ def load():
                                          C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, vp]),
         "bnv_set_mlp_mode": (C.c_int, [C.c_int]),
         "bnv_get_mlp_mode": (C.c_int, []),
+        "bnv_set_option": (C.c_int, [C.c_char_p, C.c_int]),
         "bnv_profile_enable": (C.c_int, [C.c_int]),
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,

@@ -15,6 +15,8 @@
 //            on the 3x3x3 meshing lattice every (point, corner) input is one of those 27 per
 //            corner voxel, so the MLP runs 27x per corner voxel instead of 216x per voxel;
 //   DENSE    decode_feature_grid_w_pts on dense grids.
+#include <string.h>
+
 #include "bnv_common.hpp"
 
 namespace bnv {
@@ -603,6 +605,216 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_decode_lattice_h64: the hot case (lattice table, split-operand mode) with 64-evaluation tiles and
+// 4-wave workgroups, two workgroups per CU.  The two waves that share a SIMD then belong to different
+// workgroups and run out of phase, so one wave's barrier / convert / store phase overlaps the other's
+// MFMAs (the 128-evaluation kernel moves all 8 waves of a CU in lock step: MFMA pipe 61 % busy).
+// MEASURED (tools/ab_h64.py, interleaved A/B, 4 rounds): 1.32-1.45 ms vs 1.19-1.41 ms for the 128-evaluation
+// kernel -- the doubled L2 weight traffic cancels the overlap.  Kept as an option, off by default.
+// Wave w owns output features [64w, 64w+64) (two 32-row blocks) for the tile's 64 evaluations (two
+// 32-column tiles): each weight fragment feeds 2 column tiles instead of 4, i.e. twice the L2 weight traffic.
+// ---------------------------------------------------------------------------------------------------
+constexpr int DQ = 64;
+constexpr int Q_HL = 0;                              // hi plane [16 ks][2 h][64 j][8 halves] = 32 KB
+constexpr int Q_HLO = Q_HL + 16 * 2 * DQ * 4;        // lo plane
+constexpr int Q_PART = Q_HLO + 16 * 2 * DQ * 4;      // [4 w][2 nb][2 h][64]
+constexpr int Q_ALPHA = Q_PART + 16 * DQ;
+constexpr int Q_TOTAL = Q_ALPHA + DQ;                // 17,472 floats = 69,888 B
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// weight fragment fetch through a buffer descriptor: wave-uniform base (SGPRs) + one shared per-lane
+// byte offset + a scalar offset per load -- no 64-bit address VGPR per load (with flat loads the compiler
+// hoists dozens of lane-constant addresses out of the tile loop and spills them)
+__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(half8, v);
+}
+
+template <int NKS>
+__device__ __forceinline__ void mlp_layer_q(const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                                            const float* __restrict__ lds, f32x16 (&acc)[2][2], int w, int lane,
+                                            int j, int h) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const f32x16 b0 = frag256(bias, 2 * w + nb, h);
+    acc[nb][0] = b0;
+    acc[nb][1] = b0;
+  }
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 8 * NKS * 2 * 64 * 8 * 2, 0x00020000);
+  const int voff = lane * 16;
+  const int sbase = (2 * w) * NKS * 2 * 1024;  // bytes; this wave's two 32-row blocks are contiguous
+  const float* hh = lds + Q_HL + (h * DQ + j) * 4;
+  const float* hl = lds + Q_HLO + (h * DQ + j) * 4;
+  half8 ah[3][2], al[3][2], bh[2][2], bl[2][2];
+#define BNV_LOAD_A(ks)                                                                  \
+  {                                                                                     \
+    ah[(ks) % 3][0] = load_frag(rs, voff, sbase + ((ks) * 2) * 1024);                    \
+    al[(ks) % 3][0] = load_frag(rs, voff, sbase + ((ks) * 2 + 1) * 1024);                \
+    ah[(ks) % 3][1] = load_frag(rs, voff, sbase + (NKS * 2 + (ks) * 2) * 1024);          \
+    al[(ks) % 3][1] = load_frag(rs, voff, sbase + (NKS * 2 + (ks) * 2 + 1) * 1024);      \
+  }
+#define BNV_LOAD_B(ks)                                                                   \
+  {                                                                                      \
+    _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                   \
+      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DQ + pt * 32) * 4);            \
+      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DQ + pt * 32) * 4);            \
+    }                                                                                    \
+  }
+  BNV_LOAD_A(0);
+  if (NKS > 1) BNV_LOAD_A(1);
+  BNV_LOAD_B(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
+    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks % 3][nb], bh[ks & 1][pt], acc[nb][pt], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks % 3][nb], bl[ks & 1][pt], acc[nb][pt], 0, 0, 0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt)
+        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks % 3][nb], bh[ks & 1][pt], acc[nb][pt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_A
+#undef BNV_LOAD_B
+}
+
+__device__ __forceinline__ void store_relu_q(float* __restrict__ lds, const f32x16 (&acc)[2][2], int w, int j, int h) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+      for (int ksl = 0; ksl < 2; ++ksl) {
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = relu1(acc[nb][pt][8 * ksl + e]);
+          const _Float16 t = (_Float16)x;
+          hi[e] = t;
+          lo[e] = (_Float16)(x - (float)t);
+        }
+        const int o = (((2 * (2 * w + nb) + ksl) * 2 + h) * DQ + pt * 32 + j) * 4;
+        *(half8*)&lds[Q_HL + o] = hi;
+        *(half8*)&lds[Q_HLO + o] = lo;
+      }
+}
+
+__global__ __launch_bounds__(256, 2) void k_decode_lattice_h64(DecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const float voxel = A.grid.voxel_size;
+  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
+  const int64_t n_tiles = (n_evals + DQ - 1) / DQ;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const _Float16* ph = (const _Float16*)(A.pack + SD_TOTAL);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int row = -1, l = 0;
+    if (threadIdx.x < DQ) {
+      const int64_t e = tile * DQ + threadIdx.x;
+      float loc[3] = {0.f, 0.f, 0.f};
+      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (e < n_evals) {
+        if (A.entries) {
+          const int ent = A.entries[e];
+          row = ent >> 5;
+          l = ent & 31;
+        } else {
+          const int64_t ci = e / 27;
+          l = (int)(e - ci * 27);
+          row = A.list[ci];
+        }
+        loc[0] = (float)(l / 9 - 1) * 0.5f;
+        loc[1] = (float)((l / 3) % 3 - 1) * 0.5f;
+        loc[2] = (float)(l % 3 - 1) * 0.5f;
+        const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+        const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          feat[f] = f0[f];
+          feat[4 + f] = f1[f];
+        }
+      }
+      // inputs in the split layout (features 0..16, zero padded to 32), DQ columns
+      float in[32];
+#pragma unroll
+      for (int f = 0; f < 32; ++f) in[f] = 0.f;
+      in[0] = loc[0]; in[1] = loc[1]; in[2] = loc[2];
+      in[3] = sinf(loc[0]); in[4] = sinf(loc[1]); in[5] = sinf(loc[2]);
+      in[6] = cosf(loc[0]); in[7] = cosf(loc[1]); in[8] = cosf(loc[2]);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) in[9 + f] = feat[f];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          half8 hi, lo;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) {
+            const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
+            const _Float16 t = (_Float16)x;
+            hi[jj] = t;
+            lo[jj] = (_Float16)(x - (float)t);
+          }
+          const int o = ((ks * 2 + hh) * DQ + threadIdx.x) * 4;
+          *(half8*)&lds[Q_HL + o] = hi;
+          *(half8*)&lds[Q_HLO + o] = lo;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+    mlp_layer_q<2>(ph + SH_W0, A.pack + SD_B0, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_relu_q(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_q<16>(ph + SH_W1, A.pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_relu_q(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_q<16>(ph + SH_W2, A.pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_relu_q(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_q<16>(ph + SH_W3, A.pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const f32x16 wa = frag256(A.pack + SD_WA, 2 * w + nb, h);
+#pragma unroll
+      for (int pt = 0; pt < 2; ++pt) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc = fmaf(wa[r], relu1(acc[nb][pt][r]), sacc);
+        lds[Q_PART + (((w * 2 + nb) * 2) + h) * DQ + pt * 32 + j] = sacc;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < DQ) {
+      float sacc = A.pack[SD_BA];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) sacc += lds[Q_PART + p * DQ + threadIdx.x];
+      if (row >= 0) {
+        if (A.entries) A.need_mask[row] = 0u;
+        A.table[(size_t)row * 27 + l] = __fmul_rn(sacc, voxel);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- lattice decode: neighbour lookup + blend ------------------------------------------------
 struct LatticeWs {
   int32_t* nbr_rows;  // [n][27]
@@ -815,7 +1027,18 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   out[t] = o;
 }
 
+int g_lattice_h64 = 0;  // 1: 64-evaluation tiles, 2 workgroups per CU (bnv_set_option); measured 4 % slower
+
 static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
+  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_h64) {
+    int64_t grid = 2 * (int64_t)g_num_cus;
+    if (2 * n_tiles_hint < grid) grid = 2 * n_tiles_hint;
+    if (grid < 1) grid = 1;
+    ProfScope prof(PROF_DECODE_LATTICE, stream);
+    hipLaunchKernelGGL(k_decode_lattice_h64, dim3((unsigned)grid), dim3(256), Q_TOTAL * 4, stream, args);
+    BNV_LAUNCH_CHECK();
+    return BNV_OK;
+  }
   int64_t grid = g_num_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
@@ -865,10 +1088,21 @@ int bnv_decode_init() {
   BNV_OPT_IN(MODE_LATTICE, 2);
   BNV_OPT_IN(MODE_DENSE, 2);
 #undef BNV_OPT_IN
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_lattice_h64, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    Q_TOTAL * 4));
   return BNV_OK;
 }
 
 size_t bnv_sdfmlp_pack_floats(void) { return SD_PACK_FLOATS; }
+
+int bnv_set_option(const char* name, int value) {
+  if (!name) return BNV_ERR_INVALID_ARGUMENT;
+  if (!strcmp(name, "lattice_h64")) {
+    g_lattice_h64 = value;
+    return BNV_OK;
+  }
+  return BNV_ERR_INVALID_ARGUMENT;
+}
 
 int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
                    int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,

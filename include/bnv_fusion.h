@@ -97,6 +97,11 @@ int bnv_last_hip_error(void);
 int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 
+/* Tuning switches (A/B experiments; defaults are the measured-best):
+ *   "lattice_h64"  0 (default): lattice-table MLP in split mode uses 128-evaluation tiles, 1 workgroup per CU;
+ *                  1: 64-evaluation tiles, 2 workgroups per CU (measured about 4 % slower). */
+int bnv_set_option(const char* name, int value);
+
 /* Optional timing of the dominant kernels with HIP events recorded on their launch stream.
  * kinds: 0 point-encoder MLP + scatter, 1 lattice-table SDF MLP, 2 decode_pts SDF MLP,
  * 3 dense-decode SDF MLP.  bnv_profile_read synchronises the recorded events and returns the
