@@ -194,11 +194,17 @@ constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
 // from the compiler, which pads wait states only around instructions it knows.)
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 
-template <int NKS>
+template <int NKS, bool BIAS = true>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
                                             const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
                                             int j, int h) {
-  const f32x16 b0 = frag256(bias, w, h);
+  f32x16 b0;
+  if constexpr (BIAS) {
+    b0 = frag256(bias, w, h);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b0[r] = 0.f;
+  }
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
   const _Float16* wl = wp + (size_t)w * NKS * 2 * 64 * 8 + lane * 8;
@@ -540,11 +546,29 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
       lds[L_WVOL + j] = wvol;
       lds[L_DELTA + j] = dlt;
     }
-    __syncthreads();
     // ---------------- MLP -----------------------------------------------------------------
-    if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
-    else if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
-    else sdf_mlp_tile(lds, A.pack);
+    bool run_mlp = true;
+    if constexpr (MODE == MODE_PTS) {
+      // a query whose 8 corners are not all observed decodes to the constant voxel_size (:809,:818); ray
+      // samples of the global optimiser are mostly such free-space points and come in runs along the ray:
+      // a tile with no live query skips the MLP (its alpha values are never selected)
+      __syncthreads();
+      int live = 0;
+      if (threadIdx.x < 16 && tile * 16 + threadIdx.x < A.n) {
+        float wmin = 3.4e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wmin = fminf(wmin, lds[L_WVOL + threadIdx.x * 8 + k]);
+        live = wmin >= (float)A.grid.min_pts_in_grid;
+      }
+      run_mlp = __syncthreads_or(live) != 0;
+    } else {
+      __syncthreads();
+    }
+    if (run_mlp) {
+      if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
+      else if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
+      else sdf_mlp_tile(lds, A.pack);
+    }
     // ---------------- back end ------------------------------------------------------------
     if constexpr (MODE == MODE_LATTICE) {
       if (threadIdx.x < DM) {
@@ -606,6 +630,297 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_decode_pts_bwd: d(loss)/d(volume features) of k_decode<PTS> -- what the global optimiser needs
+// (run_e2e.py:111-162 makes volume.features an nn.Parameter and back-propagates the ray loss of
+// render_utils.py:461-560 through SparseVolume.decode_pts, sparse_volume.py:768-833).
+// Only the features carry gradient (the decoder is frozen, the query points are data).
+//
+// Per 128-evaluation tile: the forward MLP is recomputed in split-f16 arithmetic keeping ONE BIT per
+// pre-activation (z > 0) in registers -- the lane that owns z_l[feature][evaluation] in the forward D
+// layout owns the same position of W_{l+1}^T delta_{l+1} in the backward pass, so the ReLU masks never
+// leave the lane.  The backward pass is the same transposed-chaining MLP run on the transposed weight
+// packs: delta_3 = wa * [z3 > 0]; delta_l = (W_{l+1}^T delta_{l+1}) * [z_l > 0]; g_in = W_0^T delta_0.
+// It propagates d(alpha)/d(input) with a unit seed per evaluation, so its operands stay O(1) whatever the
+// scale of the loss (an f16 split of 1e-7-sized loss gradients would underflow); the evaluation's
+// incoming gradient go = grad_sdf[q] * voxel * w_k / sum(w) * [mask_q] multiplies the 8 feature rows of
+// g_in in fp32 at the very end, followed by float atomics into grad_features[row].  Tiles whose 16
+// queries are all masked (free space: most ray samples) skip the MLP altogether.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// weight fragment fetch through a buffer descriptor: wave-uniform base (SGPRs) + one shared per-lane
+// byte offset + a scalar offset per load -- no 64-bit address VGPR per load (with flat loads the compiler
+// hoists dozens of lane-constant addresses out of the tile loop and spills them)
+__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(half8, v);
+}
+
+// mlp_layer_h with the weight fragments fetched by buffer loads (used where several layers' worth of
+// hoisted flat addresses would not fit the register file)
+template <int NKS, bool BIAS>
+__device__ __forceinline__ void mlp_layer_hb(const _Float16* __restrict__ wp, const float* __restrict__ bias,
+                                             const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
+                                             int j, int h) {
+  f32x16 b0;
+  if constexpr (BIAS) {
+    b0 = frag256(bias, w, h);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) b0[r] = 0.f;
+  }
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 8 * NKS * 2 * 64 * 8 * 2, 0x00020000);
+  const int voff = lane * 16;
+  const int sbase = w * NKS * 2 * 1024;
+  const float* hh = lds + L_HL + (h * DM + j) * 4;
+  const float* hl = lds + L_HLO + (h * DM + j) * 4;
+  half8 ah[3], al[3], bh[2][4], bl[2][4];
+#define BNV_LOAD_A(ks)                                                  \
+  {                                                                     \
+    ah[(ks) % 3] = load_frag(rs, voff, sbase + ((ks) * 2) * 1024);      \
+    al[(ks) % 3] = load_frag(rs, voff, sbase + ((ks) * 2 + 1) * 1024);  \
+  }
+#define BNV_LOAD_B(ks)                                                                    \
+  {                                                                                       \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
+      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
+      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
+    }                                                                                     \
+  }
+  BNV_LOAD_A(0);
+  if (NKS > 1) BNV_LOAD_A(1);
+  BNV_LOAD_B(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
+    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const half8 a_hi = ah[ks % 3], a_lo = al[ks % 3];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_A
+#undef BNV_LOAD_B
+}
+
+constexpr int SB_W3T = 0;                          // [8 w][16 ks][2 hi/lo][64 lane][8]: W3^T
+constexpr int SB_W2T = SB_W3T + 8 * 16 * 2 * 64 * 8;
+constexpr int SB_W1T = SB_W2T + 8 * 16 * 2 * 64 * 8;
+constexpr int SB_W0T = SB_W1T + 8 * 16 * 2 * 64 * 8;  // [16 ks][2][64][8]: W0^T, 17 rows padded to 32
+constexpr int SB_TOTAL = SB_W0T + 16 * 2 * 64 * 8;    // 409,600 halves
+constexpr int SB_PACK_FLOATS = SB_TOTAL / 2;
+
+struct DecodeBwdArgs {
+  DecodeArgs d;
+  const float* bwd_pack;
+  const float* grad_out;
+  float* grad_features;
+};
+
+// bit (pt * 16 + r) = [acc[pt][r] > 0].  Built as a shift-or chain: with independent (cmp << k) terms the
+// compiler keeps all 64 selected constants live and spills them.
+__device__ __forceinline__ uint64_t positive_bits(const f32x16 (&acc)[4]) {
+  uint32_t m[2] = {0u, 0u};
+#pragma unroll
+  for (int pt = 3; pt >= 0; --pt) {
+#pragma unroll
+    for (int r = 15; r >= 0; --r) m[pt >> 1] = (m[pt >> 1] << 1) | (uint32_t)(acc[pt][r] > 0.f);
+  }
+  return ((uint64_t)m[1] << 32) | m[0];
+}
+
+// acc <- acc where the bit is set, else 0, then split + store as the next layer's B operand
+__device__ __forceinline__ void store_masked_h(float* __restrict__ lds, const f32x16 (&acc)[4], uint64_t m, int w,
+                                               int j, int h) {
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+#pragma unroll
+    for (int ksl = 0; ksl < 2; ++ksl) {
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = ((m >> (pt * 16 + 8 * ksl + e)) & 1) ? acc[pt][8 * ksl + e] : 0.f;
+        const _Float16 t = (_Float16)x;
+        hi[e] = t;
+        lo[e] = (_Float16)(x - (float)t);
+      }
+      const int o = (((2 * w + ksl) * 2 + h) * DM + pt * 32 + j) * 4;
+      *(half8*)&lds[L_HL + o] = hi;
+      *(half8*)&lds[L_HLO + o] = lo;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DecodeArgs& A = B.d;
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int* l_row = (int*)(lds + L_DELTA);
+  const int64_t n_tiles = (A.n + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---------------- front end (as k_decode<PTS>), also remembers the row of every evaluation -------
+    if (threadIdx.x < DM) {
+      const int e = threadIdx.x;
+      float loc[3] = {0.f, 0.f, 0.f};
+      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float wtri = 0.f, wvol = 0.f;
+      int row = -1;
+      const int64_t q = tile * 16 + (e >> 3);
+      const int cb = kCornerCeilBits[e & 7];
+      if (q < A.n) {
+        float c[3], corner[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          c[a] = A.coords[q * 3 + a];
+          if (!A.is_coords) c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
+          corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
+          loc[a] = __fsub_rn(c[a], corner[a]);
+        }
+        wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
+        uint64_t key;
+        if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
+          row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
+        if (row >= A.row_limit) row = -1;
+        if (row >= 0) {
+          const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+          const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            feat[f] = f0[f];
+            feat[4 + f] = f1[f];
+          }
+          wvol = A.weights[row];
+        }
+      }
+      stage_input_h(lds, e, loc, feat);
+      lds[L_WTRI + e] = wtri;
+      lds[L_WVOL + e] = wvol;
+      l_row[e] = row;
+    }
+    __syncthreads();
+    // incoming gradient of every evaluation: d out_q / d alpha_k = voxel * w_k / sum(w) under the mask
+    float go = 0.f;
+    if (threadIdx.x < DM) {
+      const int e = threadIdx.x;
+      const int64_t q = tile * 16 + (e >> 3);
+      if (q < A.n) {
+        const int b = e & ~7;
+        float norm = 0.f, wmin = 3.4e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          norm = __fadd_rn(norm, lds[L_WTRI + b + k]);
+          wmin = fminf(wmin, lds[L_WVOL + b + k]);
+        }
+        if (wmin >= (float)A.grid.min_pts_in_grid)
+          go = B.grad_out[q] * voxel * __fdiv_rn(lds[L_WTRI + e], norm);
+      }
+      lds[L_ALPHA + e] = go;
+    }
+    if (!__syncthreads_or(go != 0.f)) continue;  // every query of the tile is masked: no gradient
+    // launder the weight pointers once per tile: otherwise the bias / fc_alpha fragments (80 VGPRs) are
+    // hoisted out of the tile loop as loop invariants and the MLP spills
+    const float* pack = A.pack;
+    const float* bpack = B.bwd_pack;
+    asm volatile("" : "+s"(pack), "+s"(bpack));
+    const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
+    const _Float16* pb = (const _Float16*)bpack;
+    // ---------------- forward, keeping the sign bits of the pre-activations ---------------------------
+    f32x16 acc[4];
+    mlp_layer_hb<2, true>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
+    const uint64_t m0 = positive_bits(acc);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_hb<16, true>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+    const uint64_t m1 = positive_bits(acc);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_hb<16, true>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+    const uint64_t m2 = positive_bits(acc);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    __syncthreads();
+    mlp_layer_hb<16, true>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+    // ---------------- backward with a unit seed: delta_3 = wa * [z3 > 0] ------------------------------
+    {
+      const uint64_t m3 = positive_bits(acc);
+      const f32x16 wa = frag256(pack + SD_WA, w, h);
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) acc[pt] = wa;
+      __syncthreads();
+      store_masked_h(lds, acc, m3, w, j, h);
+    }
+    __syncthreads();
+    mlp_layer_hb<16, false>(pb + SB_W3T, nullptr, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_masked_h(lds, acc, m2, w, j, h);
+    __syncthreads();
+    mlp_layer_hb<16, false>(pb + SB_W2T, nullptr, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_masked_h(lds, acc, m1, w, j, h);
+    __syncthreads();
+    mlp_layer_hb<16, false>(pb + SB_W1T, nullptr, lds, acc, w, lane, j, h);
+    __syncthreads();
+    store_masked_h(lds, acc, m0, w, j, h);
+    __syncthreads();
+    // g_in = W0^T delta_0: 32 (17 used) x 128; wave w < 4 takes column block w
+    if (w < 4) {
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+      const _Float16* wl = pb + SB_W0T + lane * 8;
+      const float* hh = lds + L_HL + (h * DM + w * 32 + j) * 4;
+      const float* hl = lds + L_HLO + (h * DM + w * 32 + j) * 4;
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const half8 a_hi = *(const half8*)(wl + (ks * 2) * 64 * 8);
+        const half8 a_lo = *(const half8*)(wl + (ks * 2 + 1) * 64 * 8);
+        const half8 b_hi = *(const half8*)(hh + ks * 2 * DM * 4);
+        const half8 b_lo = *(const half8*)(hl + ks * 2 * DM * 4);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, g, 0, 0, 0);
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, g, 0, 0, 0);
+      }
+      // D row (r&3) + 8 (r>>2) + 4 h is network input 9 + f for feature f: h = 0 holds f = 0, 1, 2 (r = 5, 6, 7)
+      // and f = 7 (r = 8); h = 1 holds f = 3..6 (r = 4..7)
+      const int col = w * 32 + j;
+      const float s = lds[L_ALPHA + col];
+      const int row = l_row[col];
+      if (s != 0.f && row >= 0) {
+        float* gf = B.grad_features + (size_t)row * 8;
+        if (h == 0) {
+          unsafeAtomicAdd(gf + 0, g[5] * s);
+          unsafeAtomicAdd(gf + 1, g[6] * s);
+          unsafeAtomicAdd(gf + 2, g[7] * s);
+          unsafeAtomicAdd(gf + 7, g[8] * s);
+        } else {
+          unsafeAtomicAdd(gf + 3, g[4] * s);
+          unsafeAtomicAdd(gf + 4, g[5] * s);
+          unsafeAtomicAdd(gf + 5, g[6] * s);
+          unsafeAtomicAdd(gf + 6, g[7] * s);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_decode_lattice_h64: the hot case (lattice table, split-operand mode) with 64-evaluation tiles and
 // 4-wave workgroups, two workgroups per CU.  The two waves that share a SIMD then belong to different
 // workgroups and run out of phase, so one wave's barrier / convert / store phase overlaps the other's
@@ -621,16 +936,6 @@ constexpr int Q_HLO = Q_HL + 16 * 2 * DQ * 4;        // lo plane
 constexpr int Q_PART = Q_HLO + 16 * 2 * DQ * 4;      // [4 w][2 nb][2 h][64]
 constexpr int Q_ALPHA = Q_PART + 16 * DQ;
 constexpr int Q_TOTAL = Q_ALPHA + DQ;                // 17,472 floats = 69,888 B
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// weight fragment fetch through a buffer descriptor: wave-uniform base (SGPRs) + one shared per-lane
-// byte offset + a scalar offset per load -- no 64-bit address VGPR per load (with flat loads the compiler
-// hoists dozens of lane-constant addresses out of the tile loop and spills them)
-__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-  return __builtin_bit_cast(half8, v);
-}
 
 template <int NKS>
 __device__ __forceinline__ void mlp_layer_q(const _Float16* __restrict__ wp, const float* __restrict__ bias,
@@ -1090,6 +1395,8 @@ int bnv_decode_init() {
 #undef BNV_OPT_IN
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_lattice_h64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Q_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L_TOTAL * 4));
   return BNV_OK;
 }
 
@@ -1124,6 +1431,39 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
   if (delta) a.delta = *delta;
   a.out = out_sdf;
   return launch_decode(MODE_PTS, a, (n + 15) / 16, (hipStream_t)stream);
+}
+
+size_t bnv_sdfmlp_bwd_pack_floats(void) { return SB_PACK_FLOATS; }
+
+int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                            const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                            const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
+                            const float* grad_sdf, float* grad_features, bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (g_mlp_mode == 2) return BNV_ERR_INVALID_ARGUMENT;  // fp32 decoder only
+  if (n == 0) return BNV_OK;
+  if (!coords || !grad_sdf || !grad_features) return BNV_ERR_INVALID_ARGUMENT;
+  DecodeBwdArgs b = {};
+  b.d.vol = *vol;
+  b.d.grid = *grid;
+  b.d.features = features;
+  b.d.weights = weights;
+  b.d.row_limit = row_limit;
+  b.d.pack = sdfmlp_pack;
+  b.d.coords = coords;
+  b.d.n = n;
+  b.d.is_coords = is_coords;
+  b.bwd_pack = sdfmlp_bwd_pack;
+  b.grad_out = grad_sdf;
+  b.grad_features = grad_features;
+  int64_t nblk = (n + 15) / 16;
+  if (nblk > g_num_cus) nblk = g_num_cus;
+  ProfScope prof(PROF_DECODE_PTS, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
 }
 
 int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims[3], float voxel_size,

@@ -53,10 +53,14 @@ class LocalNeRFModel(nn.Module):
         self.fc_alpha = nn.Linear(hidden_size, 1)
         self.num_layers = num_layers
         self.register_buffer("sdf_pack", torch.zeros(int(_lib.load().bnv_sdfmlp_pack_floats())), persistent=False)
+        # transposed layers for the backward of decode_pts w.r.t. the volume features (global optimiser)
+        self.register_buffer("sdf_bwd_pack", torch.zeros(int(_lib.load().bnv_sdfmlp_bwd_pack_floats())),
+                             persistent=False)
 
     def repack(self):
         sd = {"nerf." + k: v for k, v in self.state_dict().items()}
         self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_mlp(sd)))
+        self.sdf_bwd_pack.copy_(torch.from_numpy(weights.pack_sdf_mlp_bwd(sd)))
 
     @staticmethod
     def xyz_encoding(t):

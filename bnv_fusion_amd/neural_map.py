@@ -62,7 +62,9 @@ class NeuralMap:
         self.sdf_delta = None
         self.tsdf_vol = None
         self.tsdf_voxel_size = 0.025                                      # run_e2e.py:58
+        self.truncated_units = truncated_units
         self.truncated_dist = min(truncated_units * voxel_size * 0.5, 0.1)  # run_e2e.py:54
+        self.frames = []                                                  # key frames for optimize() (run_e2e.py:73)
         self.sdf_delta_weight = sdf_delta_weight                          # fusion_pointnet_model.yaml:44,47
         if tsdf:                                                          # run_e2e.py:60-71
             import numpy as np
@@ -130,6 +132,30 @@ class NeuralMap:
             ev = torch.cuda.Event()
             ev.record()
         return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf)
+
+    def optimize(self, n_iters, last_frame=-1, sampling_size=5000, train_ray_splits=1000, ray_max_dist=3,
+                 lr=0.001, generator=None):
+        """run_e2e.py:111-162: ``n_iters`` Adam steps on the volume features; every step samples
+        ``sampling_size`` rays of one random key frame of ``self.frames[last_frame:]`` (dicts with ``depth``
+        [H, W] uint16 mm / float m, ``intr_mat``, ``T_wc`` on the device -- the reference re-reads the depth
+        png in DataLoader workers, fusion_inference_dataset.py:329-420).  Defaults are the values of
+        fusion_pointnet_model.yaml / fusion_inference_dataset.yaml."""
+        from .optimize import optimize_volume, sample_key_frame
+        delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
+        lo = 0 if last_frame == -1 else last_frame
+        cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
+
+        def batches():
+            for _ in range(n_iters):
+                f = self.frames[int(torch.randint(lo, len(self.frames), (1,), generator=cpu_gen))]
+                d = f["depth"]
+                if d.dtype in (torch.uint16, torch.int16):
+                    d = d.to(torch.float32) / 1000.0
+                yield sample_key_frame(d, f["intr_mat"], f["T_wc"], sampling_size, ray_max_dist, generator)
+
+        return optimize_volume(self.volume, self.pointnet.nerf, batches(), self.truncated_units,
+                               self.truncated_dist, ray_max_dist, sdf_delta=delta,
+                               train_ray_splits=train_ray_splits, lr=lr, generator=generator)
 
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""

@@ -1,0 +1,192 @@
+"""Global optimisation of the fused feature volume against the depth frames -- the second level of
+the reference's bi-level fusion (src/run_e2e.py:111-162, src/utils/render_utils.py:77-94, 191-233,
+411-590, src/datasets/fusion_inference_dataset.py:308-420).
+
+Function names and arguments mirror the reference module so a maintainer can swap
+``from src.utils.render_utils import calculate_loss`` for this one.  Everything here is device-side
+torch glue (a few thousand rays per step); the heavy part -- ``SparseVolume.decode_pts`` forward and
+its backward into ``volume.features`` -- are the HIP kernels behind ``bnv_decode_pts`` /
+``bnv_decode_pts_backward``.
+
+Randomness: pass ``generator=`` (a CPU or device ``torch.Generator``) for reproducible draws; a CPU
+generator reproduces the reference's CPU stream bit for bit (used by the parity tests).
+"""
+import torch
+import torch.nn.functional as F
+
+from .fusion import get_neighbors
+
+
+def _rand(shape, device, generator):
+    if generator is not None and generator.device.type == "cpu":
+        return torch.rand(*shape, generator=generator).to(device)
+    return torch.rand(*shape, device=device, generator=generator)
+
+
+def lift(x, y, z, intrinsics):
+    """render_utils.py:411-428: pixel (x, y) at depth z -> homogeneous camera coordinates."""
+    intrinsics = intrinsics.to(x.device)
+    fx, fy = intrinsics[:, 0, 0].unsqueeze(-1), intrinsics[:, 1, 1].unsqueeze(-1)
+    cx, cy = intrinsics[:, 0, 2].unsqueeze(-1), intrinsics[:, 1, 2].unsqueeze(-1)
+    sk = intrinsics[:, 0, 1].unsqueeze(-1)
+    x_lift = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
+    y_lift = (y - cy) / fy * z
+    return torch.stack((x_lift, y_lift, z, torch.ones_like(z)), dim=-1)
+
+
+def get_camera_params(uv, pose, intrinsics):
+    """render_utils.py:431-458 for 4x4 camera-to-world poses -> (unit ray_dirs [b, n, 3], cam_loc [b, 3])."""
+    if pose.shape[1] == 7:
+        raise NotImplementedError("quaternion poses are not used on this path (run_e2e.py passes T_wc 4x4)")
+    cam_loc = pose[:, :3, 3]
+    z_cam = uv[:, :, 0] * 0.0 + 1.0
+    cam_pts = lift(uv[:, :, 0], uv[:, :, 1], z_cam, intrinsics).permute(0, 2, 1)
+    world = torch.bmm(pose, cam_pts).permute(0, 2, 1)[:, :, :3]
+    return F.normalize(world - cam_loc[:, None, :], dim=2), cam_loc
+
+
+def stratified_sampling(n_pts, n_samples, distances, generator=None):
+    """render_utils.py:77-94.  distances [(b), N, 1] -> one uniform sample per stratum, [b, N, S, 1]."""
+    if distances.dim() < 3:
+        distances = distances.unsqueeze(0)
+    b, n_pts = distances.shape[:2]
+    edges = torch.linspace(0, 1, steps=n_samples, device=distances.device).unsqueeze(0).repeat(b, n_pts, 1)
+    edges = edges * distances
+    mids = 0.5 * (edges[..., 1:] + edges[..., :-1])
+    upper = torch.cat([mids, edges[..., -1:]], dim=-1)
+    lower = torch.cat([edges[..., :1], mids], dim=-1)
+    t = _rand((b, n_pts, n_samples), distances.device, generator)
+    return (lower + (upper - lower) * t).unsqueeze(-1)
+
+
+def hierarchical_sampling(n_fine_samples, n_coarse_samples, depths, surface, ray_directions, cam_loc,
+                          offset_distance=0.5, max_depth=5.0, generator=None):
+    """render_utils.py:191-233: fine samples within +-offset_distance of the observed surface plus coarse
+    samples from the camera to the surface, sorted along the ray -> (pts [b, N, S, 3], dists [b, N, S, 1])."""
+    n_pts = ray_directions.shape[1]
+    back = torch.where(depths - offset_distance < 0, depths, torch.zeros_like(depths) + offset_distance)
+    start_pts = surface - back.unsqueeze(-1) * ray_directions
+    start_depths = torch.sqrt(torch.sum((start_pts - cam_loc.unsqueeze(1)) ** 2, dim=-1))
+    span = torch.zeros_like(ray_directions[:, :, :1]) + offset_distance * 2
+    fine = stratified_sampling(n_pts, n_fine_samples, span, generator)
+    fine = fine + start_depths.unsqueeze(-1).unsqueeze(-1)
+    coarse = stratified_sampling(n_pts, n_coarse_samples, depths.unsqueeze(-1), generator)
+    dists, _ = torch.sort(torch.cat([fine, coarse], -2), -2)
+    pts = cam_loc.unsqueeze(1).unsqueeze(1) + dists * ray_directions.unsqueeze(2)
+    return pts, dists
+
+
+def render_with_rays(volume, rays, nerf, sdf_delta, truncated_units, truncated_dist, ray_max_dist,
+                     generator=None):
+    """render_utils.py:461-505: sample every ray, bump the optimisation counter of the touched voxels
+    and decode the SDF at the samples (differentiable w.r.t. ``volume.features``)."""
+    ray_dirs, cam_loc = get_camera_params(rays["uv"], rays["T_wc"], rays["intr_mat"])
+    gt_depths = torch.sqrt(torch.sum((rays["gt_pts"] - cam_loc.unsqueeze(1)) ** 2, dim=-1))
+    pts, dists = hierarchical_sampling(truncated_units * 2, int(ray_max_dist * 5), gt_depths, rays["gt_pts"],
+                                       ray_dirs, cam_loc, offset_distance=truncated_dist,
+                                       max_depth=ray_max_dist, generator=generator)
+    coords = (pts - volume.min_coords) / volume.voxel_size
+    volume.count_optim(get_neighbors(coords))
+    pred_sdf = volume.decode_pts(pts, nerf, sdf_delta=sdf_delta)[..., 0]
+    return {"cam_loc": cam_loc, "ray_dirs": ray_dirs, "sdf_on_rays": pred_sdf, "pts_on_rays": pts}
+
+
+def compute_sdf_loss(rays, pred_sdf, pred_pts, cam_loc, num_valid_pixels, truncated_dist):
+    """render_utils.py:508-549: L1 between the decoded SDF and the signed distance to the nearest valid
+    surface point of the pixel's 3x3 neighbourhood, on samples in front of / just behind the surface."""
+    gt_depths = torch.sqrt(torch.sum((rays["gt_pts"] - cam_loc.unsqueeze(1)) ** 2, dim=-1)).unsqueeze(-1)
+    depths = torch.sqrt(torch.sum((pred_pts - cam_loc.unsqueeze(1).unsqueeze(1)) ** 2, dim=-1))
+    gt_sdf = torch.clip(gt_depths - depths, min=-truncated_dist, max=truncated_dist)
+    valid_map = gt_sdf > max(-truncated_dist * 0.5, -0.05)
+    d = torch.sqrt(torch.sum((rays["neighbor_pts"].unsqueeze(2) - pred_pts.unsqueeze(3)) ** 2, dim=-1))
+    nb_mask = rays["neighbor_masks"].unsqueeze(2).repeat(1, 1, pred_pts.shape[2], 1)
+    d = torch.where(nb_mask.bool(), d, torch.ones_like(d) * 10000)
+    nearest = torch.min(d, dim=-1)[0]
+    sign = torch.where(gt_sdf > 0, torch.ones_like(gt_sdf), torch.ones_like(gt_sdf) * -1)
+    target = torch.clip(nearest * sign, min=-truncated_dist, max=truncated_dist)
+    l1 = F.l1_loss(pred_sdf, target, reduction="none") * valid_map
+    return (l1 * rays["mask"].unsqueeze(-1)).sum() / num_valid_pixels
+
+
+def calculate_loss(volume, rays, nerf, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
+                   generator=None):
+    """render_utils.py:551-590 -> {"depth_bce_loss": scalar}."""
+    num_valid_pixels = torch.sum(rays["mask"]) + 1e-4
+    out = render_with_rays(volume, rays, nerf, sdf_delta, truncated_units, truncated_dist, ray_max_dist,
+                           generator=generator)
+    loss = compute_sdf_loss(rays, out["sdf_on_rays"], out["pts_on_rays"], out["cam_loc"], num_valid_pixels,
+                            truncated_dist)
+    return {"depth_bce_loss": loss}
+
+
+def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generator=None):
+    """IterableInferenceDataset._sample_key_frame (fusion_inference_dataset.py:373-420) for a depth map
+    already on the device: ``sampling_size`` random pixels with their back-projected world points, validity
+    and 3x3 neighbourhoods.  depth [H, W] metres; intr_mat [3, 3]; T_wc [4, 4] -> rays dict (batch 1)."""
+    dev = depth.device
+    intr_mat, T_wc = torch.as_tensor(intr_mat), torch.as_tensor(T_wc)
+    depth = depth.to(torch.float64)
+    mask = (depth > 0) & (depth < ray_max_dist)                       # common.py:110-113
+    depth = depth * mask
+    H, W = depth.shape
+    K = intr_mat.to(dev, torch.float32)
+    T = T_wc.to(dev, torch.float32).to(torch.float64)
+    # geometry.py:163-168 forms the normalised pixel coordinates in float32 before the float64 product
+    u = ((torch.arange(W, device=dev, dtype=torch.float32) - K[0, 2]) / K[0, 0]).to(torch.float64)
+    v = ((torch.arange(H, device=dev, dtype=torch.float32) - K[1, 2]) / K[1, 1]).to(torch.float64)
+    pts_c = torch.stack([u[None, :].expand(H, W), v[:, None].expand(H, W), torch.ones_like(depth)], -1)
+    pts_c = pts_c * depth[..., None]                                  # geometry.py:150-171
+    pts_w = pts_c.reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    if generator is not None and generator.device.type == "cpu":
+        idx = torch.randperm(H * W, generator=generator)[:sampling_size].to(dev)
+    else:
+        idx = torch.randperm(H * W, device=dev, generator=generator)[:sampling_size]
+    px, py = idx % W, idx // W
+    uv = torch.stack([px, py], -1).float()
+    r = torch.arange(-1, 2, device=dev)
+    oy, ox = torch.meshgrid(r, r, indexing="ij")                      # np.meshgrid(range_, range_) order: x fastest
+    nx = (px[:, None] + ox.reshape(-1)[None]).clamp(0, W - 1)
+    ny = (py[:, None] + oy.reshape(-1)[None]).clamp(0, H - 1)
+    nidx = ny * W + nx
+    pts_map = pts_w
+    return {
+        "uv": uv.unsqueeze(0),
+        "rgb": torch.zeros(1, len(idx), 3, device=dev),
+        "gt_pts": pts_map[idx].float().unsqueeze(0),
+        "intr_mat": intr_mat.to(dev).float().reshape(1, 3, 3),
+        "T_wc": T_wc.to(dev).float().reshape(1, 4, 4),
+        "mask": mask.reshape(-1)[idx].float().unsqueeze(0),
+        "neighbor_pts": pts_map[nidx].float().unsqueeze(0),
+        "neighbor_masks": mask.reshape(-1)[nidx].float().unsqueeze(0),
+    }
+
+
+def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
+                    train_ray_splits=1000, lr=0.001, generator=None):
+    """NeuralMap.optimize (run_e2e.py:111-162): Adam on ``volume.features`` over an iterable of ray
+    batches, ``train_ray_splits`` rays per backward, then the optimised features are written back into the
+    hash volume.  Returns the list of per-iteration losses (device scalars)."""
+    volume.to_tensor()
+    volume.features = torch.nn.Parameter(volume.features)
+    optimizer = torch.optim.Adam([volume.features], lr=lr)
+    history = []
+    for rays in ray_batches:
+        optimizer.zero_grad()
+        if torch.isnan(rays["T_wc"]).any():
+            continue
+        n_rays = rays["uv"].shape[1]
+        total = None
+        for indx in torch.split(torch.arange(n_rays, device=rays["uv"].device), train_ray_splits, dim=0):
+            part = {k: (torch.index_select(v, 1, indx) if k not in ("T_wc", "intr_mat") else v)
+                    for k, v in rays.items()}
+            out = calculate_loss(volume, part, nerf, truncated_units, truncated_dist, ray_max_dist,
+                                 sdf_delta=sdf_delta, generator=generator)
+            loss = sum(v for k, v in out.items() if k[0] != "_")
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        optimizer.step()
+        history.append(total)
+    feats = volume.features.detach()
+    volume.features = feats
+    volume.insert(volume.active_coordinates, feats, volume.weights, volume.num_hits)
+    return history

@@ -287,7 +287,19 @@ class SparseVolume:
         return self._features, self._weights, self._row_capacity
 
     def decode_pts(self, coords, nerf, sdf_delta=None, is_coords=False, query_tensor=True):
-        """sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1]."""
+        """sparse_volume.py:768-833.  coords [1, B, S, 3] -> [1, B, S, 1].
+
+        When ``volume.features`` requires grad (run_e2e.py:114 wraps it in nn.Parameter for the global
+        optimiser) and ``query_tensor`` is set, the result is differentiable w.r.t. the features: the
+        backward is the HIP kernel behind ``bnv_decode_pts_backward``."""
+        if (query_tensor and torch.is_grad_enabled() and self.features is not None
+                and self.features.requires_grad):
+            shape = list(coords.shape)
+            out = _DecodePts.apply(self.features, self, coords, nerf, sdf_delta, bool(is_coords))
+            return out.reshape(shape[:-1] + [1])
+        return self._decode_pts_forward(coords, nerf, sdf_delta, is_coords, query_tensor)
+
+    def _decode_pts_forward(self, coords, nerf, sdf_delta, is_coords, query_tensor):
         self._select_mode(nerf)
         shape = list(coords.shape)
         c = coords.detach().reshape(-1, 3).float().contiguous()
@@ -369,6 +381,36 @@ class SparseVolume:
         self.insert(coords, volume["features"].to(self._dev), volume["weights"].to(self._dev),
                     volume["num_hits"].to(self._dev))
         self.to_tensor()
+
+
+class _DecodePts(torch.autograd.Function):
+    """SparseVolume.decode_pts as an autograd node whose only differentiable input is the
+    ``to_tensor()`` feature table (what render_utils.py:493-497 back-propagates into)."""
+
+    @staticmethod
+    def forward(ctx, features, volume, coords, nerf, sdf_delta, is_coords):
+        if not hasattr(nerf, "sdf_bwd_pack"):
+            raise NotImplementedError("decode_pts backward is implemented for the fp32 decoder (LocalNeRFModel)")
+        out = volume._decode_pts_forward(coords, nerf, sdf_delta, is_coords, True)
+        ctx.volume, ctx.nerf, ctx.is_coords = volume, nerf, is_coords
+        ctx.save_for_backward(features, coords.detach().reshape(-1, 3).float().contiguous(),
+                              volume.weights.detach().clone())
+        return out.reshape(-1)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, c, w = ctx.saved_tensors
+        volume, nerf = ctx.volume, ctx.nerf
+        volume._select_mode(nerf)
+        f = features.detach()
+        lim = min(int(f.shape[0]), volume._snapshot_rows)
+        g = grad_out.detach().reshape(-1).float().contiguous()
+        grad_f = torch.zeros_like(f)
+        _lib.check(volume._lib.bnv_decode_pts_backward(
+            C.byref(volume._struct()), C.byref(volume._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+            _lib.ptr(nerf.sdf_pack), _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]),
+            1 if ctx.is_coords else 0, _lib.ptr(g), _lib.ptr(grad_f), _lib.stream_ptr()), "bnv_decode_pts_backward")
+        return grad_f, None, None, None, None, None
 
 
 class VolumeList:

@@ -122,6 +122,32 @@ def _pack_pointnet_split(W1, W2, W3, W4):
     return halves.view(np.float32)
 
 
+def _pack_split(W, nks, n_blocks=8):
+    """[n_blocks w][nks][hi/lo][64 lane][8] halves: slot jj of lane (n, h) = W[32 w + n][16 ks + slot_feature(jj, h)]
+    (rows / columns beyond W's shape are zero)."""
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+    Wp = np.zeros((32 * n_blocks, 16 * nks), np.float32)
+    Wp[:W.shape[0], :W.shape[1]] = W
+    jj = np.arange(8)
+    o = np.zeros((n_blocks, nks, 2, 64, 8), np.float16)
+    for w in range(n_blocks):
+        for ks in range(nks):
+            v = Wp[(32 * w + n)[:, None], 16 * ks + _slot_feature(jj[None, :], h[:, None])]
+            o[w, ks, 0], o[w, ks, 1] = split_f16(v)
+    return o.ravel()
+
+
+def pack_sdf_mlp_bwd(sd):
+    """Transposed layers for bnv_decode_pts_backward -> float32 [204800] (SB_* layout of csrc/decode.hip):
+    W3^T, W2^T, W1^T as 256x256 split packs, then W0^T (17 x 256, rows padded to 32)."""
+    Ws = [_np(sd[f"nerf.geo_layer{i}.weight"]).astype(np.float32) for i in range(4)]
+    halves = np.concatenate([_pack_split(Ws[3].T, 16), _pack_split(Ws[2].T, 16), _pack_split(Ws[1].T, 16),
+                             _pack_split(Ws[0].T, 16, n_blocks=1)])
+    assert halves.size == 409600
+    return halves.view(np.float32).copy()
+
+
 def pack_sdf_mlp(sd):
     """-> float32 [SD_TOTAL] in the SD_* layout of csrc/decode.hip.
     Wp[w][kb][l][i] = W[32 w + (l & 31)][8 kb + 4 (l >> 5) + i]; layer 0 has K = 17 padded to 24."""
@@ -148,20 +174,8 @@ def pack_sdf_mlp(sd):
     fp32_part = np.concatenate([pack(Ws[0], 3), pack(Ws[1], 32), pack(Ws[2], 32), pack(Ws[3], 32),
                                 bs[0], bs[1], bs[2], bs[3], wa, ba]).astype(np.float32)
 
-    def pack_split(W, nks):
-        """[8 w][nks][hi/lo][64 lane][8]: slot jj of lane (n, h) = W[32 w + n][16 ks + slot_feature(jj, h)]."""
-        Wp = np.zeros((256, 16 * nks), np.float32)
-        Wp[:, :W.shape[1]] = W
-        jj = np.arange(8)
-        o = np.zeros((8, nks, 2, 64, 8), np.float16)
-        for w in range(8):
-            for ks in range(nks):
-                v = Wp[(32 * w + n)[:, None], 16 * ks + _slot_feature(jj[None, :], h[:, None])]
-                o[w, ks, 0], o[w, ks, 1] = split_f16(v)
-        return o.ravel()
-
-    halves = np.concatenate([pack_split(Ws[0], 2), pack_split(Ws[1], 16), pack_split(Ws[2], 16),
-                             pack_split(Ws[3], 16)])
+    halves = np.concatenate([_pack_split(Ws[0], 2), _pack_split(Ws[1], 16), _pack_split(Ws[2], 16),
+                             _pack_split(Ws[3], 16)])
     assert halves.size == 409600
     return np.concatenate([fp32_part, halves.view(np.float32)])
 

@@ -211,6 +211,20 @@ int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, co
                    const float* coords, int64_t n, int is_coords, const bnv_sdf_delta_t* delta_host,
                    float* out_sdf, bnv_stream_t stream);
 
+/* Backward of bnv_decode_pts with respect to the volume features -- the autograd edge the global
+ * optimiser relies on: run_e2e.py:111-162 turns volume.features into an nn.Parameter and
+ * back-propagates render_utils.py:551-590 (calculate_loss) through SparseVolume.decode_pts
+ * (sparse_volume.py:768-833).  grad_sdf [n] = d loss / d out_sdf; grad_features [row_limit, 8] is
+ * ACCUMULATED into (the caller zeroes it).  The decoder weights are frozen and the points are data, so
+ * nothing else receives gradient; sdf_delta is additive and does not enter.  sdfmlp_bwd_pack holds the
+ * transposed layers (bnv_sdfmlp_bwd_pack_floats(); weights.py: pack_sdf_mlp_bwd).  fp32 decoder only. */
+size_t bnv_sdfmlp_bwd_pack_floats(void);
+int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
+                            const float* features, const float* weights, int64_t row_limit,
+                            const float* sdfmlp_pack, const float* sdfmlp_bwd_pack, const float* coords,
+                            int64_t n, int is_coords, const float* grad_sdf, float* grad_features,
+                            bnv_stream_t stream);
+
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
 /* Byte offset, inside that workspace, of two int32 device counters: [0] rows listed by
  * bnv_lattice_neighbors(build_list), [1] table entries (= MLP evaluations) listed by bnv_lattice_mark /

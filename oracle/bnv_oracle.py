@@ -502,6 +502,85 @@ def tsdf_integrate(tsdf, weight, vol_origin, voxel_size, depth_im, cam_intr, cam
     return tsdf, weight
 
 
+# --------------------------------------------------------------------------- #
+# global optimiser edge: ray sampling + SDF loss, src/utils/render_utils.py
+# Pinned by tests/golden/optimize_64.npz / decode_grad_64.npz (make_golden_grad.py).  Gradients come
+# from torch autograd through decode_pts above (volume.features with requires_grad).
+# --------------------------------------------------------------------------- #
+
+
+def camera_rays(uv, T_wc, intr):
+    """get_camera_params + lift for a 4x4 pose (render_utils.py:411-458): unit ray directions [b, n, 3]
+    through pixel coordinates uv [b, n, 2] and the camera centre [b, 3]."""
+    fx, fy = intr[:, 0, 0, None], intr[:, 1, 1, None]
+    cx, cy, sk = intr[:, 0, 2, None], intr[:, 1, 2, None], intr[:, 0, 1, None]
+    x, y = uv[..., 0], uv[..., 1]
+    z = x * 0.0 + 1.0
+    xl = (x - cx + cy * sk / fy - sk * y / fy) / fx * z
+    yl = (y - cy) / fy * z
+    cam = torch.stack([xl, yl, z, torch.ones_like(z)], dim=-1)             # [b, n, 4]
+    world = torch.bmm(T_wc, cam.permute(0, 2, 1)).permute(0, 2, 1)[..., :3]
+    centre = T_wc[:, :3, 3]
+    return F.normalize(world - centre[:, None, :], dim=2), centre
+
+
+def stratified_samples(n_samples, lengths, rand):
+    """stratified_sampling (render_utils.py:77-94): one uniform draw inside each of n_samples strata of
+    [0, length]; ``lengths`` [b, n, 1]; ``rand(b, n, s)`` supplies the uniforms -> [b, n, s, 1]."""
+    b, n = lengths.shape[:2]
+    edges = torch.linspace(0, 1, steps=n_samples).unsqueeze(0).repeat(b, n, 1) * lengths
+    mids = 0.5 * (edges[..., 1:] + edges[..., :-1])
+    upper = torch.cat([mids, edges[..., -1:]], dim=-1)
+    lower = torch.cat([edges[..., :1], mids], dim=-1)
+    return (lower + (upper - lower) * rand(b, n, n_samples)).unsqueeze(-1)
+
+
+def hierarchical_samples(n_fine, n_coarse, depths, surface, dirs, centre, offset, rand):
+    """hierarchical_sampling (render_utils.py:191-233): n_fine samples in [depth - offset, depth + offset]
+    around the observed surface + n_coarse along the whole ray up to the surface, sorted by distance."""
+    back = torch.where(depths - offset < 0, depths, torch.zeros_like(depths) + offset)
+    start = surface - back.unsqueeze(-1) * dirs
+    start_depth = torch.sqrt(torch.sum((start - centre.unsqueeze(1)) ** 2, dim=-1))
+    span = torch.zeros_like(dirs[:, :, :1]) + offset * 2
+    fine = stratified_samples(n_fine, span, rand)
+    fine = fine + start_depth.unsqueeze(-1).unsqueeze(-1)
+    coarse = stratified_samples(n_coarse, depths.unsqueeze(-1), rand)
+    dists, _ = torch.sort(torch.cat([fine, coarse], -2), -2)
+    pts = centre.unsqueeze(1).unsqueeze(1) + dists * dirs.unsqueeze(2)
+    return pts, dists
+
+
+def sdf_ray_loss(rays, pred_sdf, pts, centre, n_valid, truncated_dist):
+    """compute_sdf_loss (render_utils.py:508-549): L1 between the decoded SDF and the signed distance to the
+    nearest valid neighbouring surface point, on samples in front of / just behind the surface."""
+    gt_depth = torch.sqrt(torch.sum((rays["gt_pts"] - centre.unsqueeze(1)) ** 2, dim=-1)).unsqueeze(-1)
+    depth = torch.sqrt(torch.sum((pts - centre.unsqueeze(1).unsqueeze(1)) ** 2, dim=-1))
+    gt_sdf = torch.clip(gt_depth - depth, min=-truncated_dist, max=truncated_dist)
+    valid = gt_sdf > max(-truncated_dist * 0.5, -0.05)
+    d = torch.sqrt(torch.sum((rays["neighbor_pts"].unsqueeze(2) - pts.unsqueeze(3)) ** 2, dim=-1))
+    nm = rays["neighbor_masks"].unsqueeze(2).repeat(1, 1, pts.shape[2], 1)
+    d = torch.where(nm.bool(), d, torch.ones_like(d) * 10000)
+    nearest = torch.min(d, dim=-1)[0]
+    sign = torch.where(gt_sdf > 0, torch.ones_like(gt_sdf), torch.ones_like(gt_sdf) * -1)
+    target = torch.clip(nearest * sign, min=-truncated_dist, max=truncated_dist)
+    l1 = F.l1_loss(pred_sdf, target, reduction="none") * valid
+    return (l1 * rays["mask"].unsqueeze(-1)).sum() / n_valid
+
+
+def calculate_loss(volume, rays, sd, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None, rand=None):
+    """calculate_loss + render_with_rays (render_utils.py:461-505, 551-590) -> (loss dict, sampled pts)."""
+    rand = rand or (lambda *shape: torch.rand(*shape))
+    n_valid = torch.sum(rays["mask"]) + 1e-4
+    dirs, centre = camera_rays(rays["uv"], rays["T_wc"], rays["intr_mat"])
+    gt_depth = torch.sqrt(torch.sum((rays["gt_pts"] - centre.unsqueeze(1)) ** 2, dim=-1))
+    pts, _ = hierarchical_samples(truncated_units * 2, int(ray_max_dist * 5), gt_depth, rays["gt_pts"], dirs,
+                                  centre, truncated_dist, rand)
+    coords = (pts - volume.min_coords) / volume.voxel_size
+    volume.count_optim(get_neighbors(coords))
+    pred = volume.decode_pts(pts, sd, sdf_delta=sdf_delta)[..., 0]
+    return {"depth_bce_loss": sdf_ray_loss(rays, pred, pts, centre, n_valid, truncated_dist)}, pts
+
+
 def synthetic_depth(t, H=480, W=640, seed=0):
     """depth(u,v) = 1.5 + 0.2 sin(u/40) cos(v/30) + N(0, 0.002) m,
     quantised to uint16 millimetres as the datasets store it (common.py:93)."""

@@ -142,3 +142,50 @@ def test_known_answers(sd, fused_volume):
     v2.to_tensor()
     assert np.abs(v2.features.numpy() - f.numpy()).max() < 5e-6
     assert np.allclose(v2.weights.numpy(), 3 * np.minimum(c.numpy() / 32.0, 1.0), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# global-optimiser edge: gradients and the ray loss of the reference
+# (tests/golden/make_golden_grad.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture()
+def insertion_volume():
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    pos = {tuple(k): i for i, k in enumerate(z["keys_sorted"].tolist())}
+    perm = np.array([pos[tuple(k)] for k in z["keys_insertion"].tolist()])
+    vol = _vol(z)
+    vol.insert(torch.from_numpy(z["keys_insertion"]), torch.from_numpy(z["features_sorted"][perm]),
+               torch.from_numpy(z["weights_sorted"][perm]), torch.from_numpy(z["num_hits_sorted"][perm]))
+    vol.to_tensor()
+    vol.features.requires_grad_(True)
+    return vol
+
+
+@pytest.mark.parametrize("name,key", [("random", "random_coords"), ("lattice", "lattice_coords")])
+def test_decode_pts_gradient_matches_reference(sd, insertion_volume, name, key):
+    vol = insertion_volume
+    dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    gr = np.load(os.path.join(GOLDEN, "decode_grad_64.npz"))
+    out = vol.decode_pts(torch.from_numpy(dec[key]), sd, torch.from_numpy(dec["sdf_delta"]), is_coords=True)
+    assert np.abs(out.detach().numpy() - gr[name + "_sdf"]).max() <= FLOAT_TOL
+    (out * torch.from_numpy(gr[name + "_grad_out"])).sum().backward()
+    ref = gr[name + "_grad_features"]
+    assert np.abs(vol.features.grad.numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_calculate_loss_matches_reference(sd, insertion_volume):
+    vol = insertion_volume
+    dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    op = np.load(os.path.join(GOLDEN, "optimize_64.npz"))
+    rays = {k[5:]: torch.from_numpy(op[k]) for k in op.files if k.startswith("rays_")}
+    gen = torch.Generator().manual_seed(int(op["seed"]))
+    loss, pts = orc.calculate_loss(vol, rays, sd, int(op["truncated_units"]), float(op["truncated_dist"]),
+                                   int(op["ray_max_dist"]), sdf_delta=torch.from_numpy(dec["sdf_delta"]),
+                                   rand=lambda *s: torch.rand(*s, generator=gen))
+    assert np.abs(pts.numpy() - op["pts"]).max() <= 1e-7
+    assert np.array_equal(vol.weights.numpy(), op["weights_after"])          # count_optim
+    loss = loss["depth_bce_loss"]
+    assert abs(float(loss.detach()) - float(op["depth_bce_loss"])) <= 1e-6
+    loss.backward()
+    ref = op["grad_features"]
+    assert np.abs(vol.features.grad.numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
