@@ -161,7 +161,7 @@ def main():
     frame_parallel = world > 1 and args.parallelism == "frame"
     if frame_parallel:
         from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
+        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev, tsdf=(args.input == "depth"))
     elif world > 1:
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
@@ -186,8 +186,15 @@ def main():
         """Processes frames [first, first+count) in order; returns this rank's last (coords, sdf)."""
         last = (None, None)
         if frame_parallel:
-            for t0 in range(first, first + count, world):
-                out = nm.process_batch(frames[t0: min(t0 + world, first + count)], decode=decode)
+            # batches of `world` consecutive frames, software-pipelined (batch k+1's encode + all-gather are
+            # enqueued before batch k's integrate + decode); only the last handle is read back on the host
+            batches = [frames[t0: min(t0 + world, first + count)] for t0 in range(first, first + count, world)]
+            handle = None
+            for handle in nm.process_stream(batches, decode=decode):
+                pass
+            nm.flush()
+            if handle is not None:
+                out = handle.result()
                 if out[0] is not None:
                     last = out
         elif world == 1 and not args.sync_frames:
@@ -278,7 +285,7 @@ def main():
 
     # parity spot check of the timed configuration against the oracle (40 voxels of the last frame)
     parity = None
-    if world == 1 and main_run["coords"] is not None:
+    if (world == 1 or frame_parallel) and rank == 0 and main_run["coords"] is not None:
         from oracle import bnv_oracle as orc           # checker only
         sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
         geo = None
@@ -314,7 +321,8 @@ def main():
                                    + ("uint16 depth image -> points + normals (GPU front end) + "
                                       if args.input == "depth" else "")
                                    + "encode_pointcloud + _integrate + "
-                                   + ("TSDF side fusion at 0.025 m + " if (args.input == "depth" and world == 1) else "")
+                                   + ("TSDF side fusion at 0.025 m + " if (args.input == "depth" and
+                                                                          (world == 1 or frame_parallel)) else "")
                                    + "decode of the 3x3x3 lattice of every "
                                      "touched voxel",
                        "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,

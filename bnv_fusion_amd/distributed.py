@@ -205,106 +205,240 @@ class ShardedNeuralMap:
 # =============================================================================================
 # Frame-parallel mode: throughput scaling of one frame stream
 # =============================================================================================
-class HipFrameBackend:
-    """Full (replicated) volume on one GPU; the three per-frame phases as separate calls."""
+# ---------------------------------------------------------------------------------------------------
+# frame-parallel mode
+# ---------------------------------------------------------------------------------------------------
+# One encoded frame travels as a fixed-size flat int64 RECORD, struct-of-arrays so that every section is a
+# contiguous view the kernels read in place:
+#   [0, 8)            header: word 0 = int32 counters[0:2] ... exactly the 8 int32 device counters of
+#                     bnv_encode_pointcloud in words 0..3 (n_valid, n_unique | n_out, n_avg bits | error, -)
+#   [8, 8 + 3R)       grid_ids  [R, 3] int64
+#   [8 + 3R, 8 + 4R)  pcounts   [R]    int64
+#   [8 + 4R, 8 + 8R)  feats     [R, 8] float32
+# R = the record capacity, equal on every rank.  Rows >= n_out are don't-care.
+REC_HDR = 8
 
-    def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, capacity=1 << 20, device="cuda:0"):
+
+def record_words(rows):
+    return REC_HDR + 8 * int(rows)
+
+
+def record_views(rec, rows):
+    """-> (counters int32 [8], grid_ids [R, 3] i64, pcounts [R] i64, feats [R, 8] f32): views, no copies."""
+    R = int(rows)
+    return (rec[:4].view(torch.int32), rec[REC_HDR: REC_HDR + 3 * R].view(R, 3), rec[REC_HDR + 3 * R: REC_HDR + 4 * R],
+            rec[REC_HDR + 4 * R: REC_HDR + 8 * R].view(torch.float32).view(R, 8))
+
+
+class HipFrameBackend:
+    """Full (replicated) volume on one GPU; the per-frame phases as separate, host-sync-free calls."""
+
+    def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, capacity=1 << 20, device="cuda:0",
+                 tsdf=False):
         from .sparse_volume import SparseVolume
         self.pointnet = pointnet
         self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
         self.dev = self.volume._dev
+        self.tsdf_vol = None
+        if tsdf:                                               # run_e2e.py:60-71, as NeuralMap does
+            from .sparse_volume import get_world_range
+            from .tsdf import TSDFVolume
+            mn, mx, _ = get_world_range(dimensions, 0.025)
+            self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
+        self._scratch_ids = None
 
-    def encode(self, frame):
-        """-> (coords [n,3] i64, counts [n] i64, feats [n,8] f32, n_avg float tensor) of one frame."""
+    def record_rows(self, frame):
+        """Upper bound of the voxels one frame can emit (every emitted voxel holds >= min_pts pairs)."""
+        from .neural_map import frame_input_pts
+        if "input_pts" in frame:
+            n = int(frame["input_pts"].shape[1])
+        else:
+            n = int(frame["depth"].shape[-2] * frame["depth"].shape[-1])
+        return 8 * n // max(self.pointnet.min_pts_in_grid, 1) + 1
+
+    def encode_record(self, frame, rows):
+        """Encodes one frame straight into a new record (the encoder writes the record's sections)."""
+        from .neural_map import frame_input_pts
         v = self.volume
         self.pointnet.shard = (0, 1, BLOCK_LOG2)
-        from .neural_map import frame_input_pts
-        f, c, _, g, n_avg = self.pointnet.encode_pointcloud(frame_input_pts(frame), v.n_xyz, v.min_coords,
-                                                            v.max_coords, v.voxel_size, return_dense=False)
-        if f is None:
-            z = torch.zeros
-            return (z((0, 3), dtype=torch.int64, device=self.dev), z(0, dtype=torch.int64, device=self.dev),
-                    z((0, 8), device=self.dev), z((), device=self.dev))
-        return g, c.reshape(-1), f, n_avg
+        rec = torch.empty(record_words(rows), dtype=torch.int64, device=self.dev)
+        counters, grid_ids, pcounts, feats = record_views(rec, rows)
+        if self._scratch_ids is None or self._scratch_ids.numel() < rows:
+            self._scratch_ids = torch.empty(rows, dtype=torch.int64, device=self.dev)
+        _, _, _, _, cnt, _ = self.pointnet.encode_pointcloud_async(
+            frame_input_pts(frame), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size,
+            out=(feats, pcounts, self._scratch_ids, grid_ids))
+        counters.copy_(cnt)
+        return rec
 
-    def integrate(self, coords, counts, feats, n_avg):
-        if coords.shape[0] == 0:
-            return
-        self.volume.track_n_pts(n_avg)
-        self.volume.integrate(coords, feats, counts)
+    def empty_record(self, rows):
+        rec = torch.empty(record_words(rows), dtype=torch.int64, device=self.dev)
+        rec[:REC_HDR] = 0
+        return rec
 
-    def decode(self, coords):
-        return self.volume.decode_lattice(coords, self.pointnet.nerf, None, query_tensor=False)
+    def integrate_record(self, rec, rows, frame=None):
+        counters, grid_ids, pcounts, feats = record_views(rec, rows)
+        self.volume.integrate(grid_ids, feats, pcounts, n_dev=counters[2:3])
+        if self.tsdf_vol is not None and frame is not None and "depth" in frame:
+            d = frame["depth"]
+            if d.dtype in (torch.uint16, torch.int16):
+                d = d.to(torch.float32) / 1000.0
+            self.tsdf_vol.integrate(frame.get("rgb"), d, frame["intr_mat"], frame["T_wc"], obs_weight=1.)
+
+    def decode_record(self, rec, rows):
+        counters, grid_ids, _, _ = record_views(rec, rows)
+        return self.volume.decode_lattice(grid_ids, self.pointnet.nerf, None, query_tensor=False,
+                                          n_dev=counters[2:3])
+
+    def account(self, headers, rows):
+        """Host bookkeeping once a batch's headers are on the host: n_avg_pts statistics
+        (sparse_volume.py:508-523), the row reservation made for the capacity bound, overflow check."""
+        for h in headers:
+            c = h[:4].view(torch.int32)
+            n_valid, n_out, err = int(c[0]), int(c[2]), int(c[4])
+            self.volume._rows_upper -= rows - n_out
+            if err:
+                raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+            if n_valid:
+                self.volume.track_n_pts(float(c[3:4].view(torch.float32)[0]))
+
+    def unaccounted(self, rows):
+        """A frame that was skipped (fewer frames than ranks): undo nothing, nothing was reserved."""
+
+    def pinned(self, shape):
+        return torch.empty(shape, dtype=torch.int64, pin_memory=True)
+
+    def event(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    def slice_result(self, rec, rows, sdf, n_out):
+        _, grid_ids, _, _ = record_views(rec, rows)
+        return grid_ids[:n_out], None if sdf is None else sdf[:n_out]
+
+
+class BatchHandle:
+    """One batch of FrameParallelNeuralMap.  ``result()`` -> (coords [U', 3], sdf [U', 27]) of the frame
+    THIS rank decoded, or (None, None); waits for that batch only."""
+
+    def __init__(self, fp, rec, sdf, host_hdr, event, n_frames):
+        self._fp, self._rec, self._sdf, self._host, self._event, self._b = fp, rec, sdf, host_hdr, event, n_frames
+        self._accounted = False
+        self._done = None
+
+    def _account(self):
+        if not self._accounted:
+            if self._event is not None:
+                self._event.synchronize()
+            self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows)
+            self._accounted = True
+
+    def result(self):
+        if self._done is None:
+            self._account()
+            fp = self._fp
+            if self._rec is None:
+                self._done = (None, None)
+            else:
+                c = self._host[fp.rank][:4].view(torch.int32)
+                if int(c[0]) == 0:
+                    self._done = (None, None)
+                else:
+                    self._done = fp.backend.slice_result(self._rec, fp.rows, self._sdf, int(c[2]))
+            self._rec = self._sdf = None
+        return self._done
 
 
 class FrameParallelNeuralMap:
     """N ranks process a batch of up to N consecutive frames together:
 
-      1. rank r encodes frame r of the batch (encode_pointcloud is a pure function of the frame);
-      2. ONE variable-size all-gather of the encoded voxels (coords, count, 8 features = 64 B each,
-         plus one header row per rank carrying n_avg_pts);
-      3. every rank replays _integrate for all frames of the batch IN FRAME ORDER on its replicated
-         volume, and decodes the lattice of frame r right after integrating frame r.
+      1. rank r encodes frame r of the batch (encode_pointcloud is a pure function of the frame) straight
+         into a fixed-size record;
+      2. ONE all-gather of the records (64 B per voxel slot; sizes are fixed, so no size exchange and no
+         host synchronisation -- element counts travel in the record header and are read on the device);
+      3. every rank replays _integrate (and the TSDF side fusion) for all frames of the batch IN FRAME
+         ORDER on its replicated volume, and decodes the lattice of frame r right after integrating frame r.
 
     Every volume goes through exactly the single-GPU sequence of states, so all outputs equal the
     one-GPU run; decode (the largest kernel) and encode are spread over the ranks, only the cheap
-    upserts are replicated."""
+    upserts are replicated.  ``process_stream`` software-pipelines the batches: batch k+1 is encoded and
+    its all-gather started (RCCL's own stream) BEFORE batch k is integrated and decoded, so the exchange
+    overlaps the decode kernels."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None):
+                 group=None, tsdf=False, record_rows=None):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.backend = backend or HipFrameBackend(dimensions, voxel_size, pointnet, min_pts_in_grid, device=device)
+        self.backend = backend or HipFrameBackend(dimensions, voxel_size, pointnet, min_pts_in_grid, device=device,
+                                                  tsdf=tsdf)
         self.volume = getattr(self.backend, "volume", None)
+        self.rows = record_rows
+        self._last = None
 
-    @staticmethod
-    def _pack(coords, counts, feats, n_avg):
-        n = coords.shape[0]
-        rec = torch.zeros((n + 1, 8), dtype=torch.int64, device=coords.device)
-        rec[0, 0] = n
-        rec[0, 1:2] = n_avg.reshape(1).float().view(torch.int32).long()
-        rec[1:, :3] = coords
-        rec[1:, 3] = counts
-        rec[1:, 4:] = feats.contiguous().view(torch.int64).reshape(n, 4)
-        return rec
+    def _agree_rows(self, frames):
+        """One-time: the record capacity all ranks use (max over ranks of the local bound)."""
+        import torch.distributed as dist
+        local = max(self.backend.record_rows(f) for f in frames)
+        t = torch.tensor([local], dtype=torch.int64, device=self.backend.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.rows = int(t.item())
 
-    @staticmethod
-    def _unpack(rec):
-        coords = rec[1:, :3].contiguous()
-        counts = rec[1:, 3].contiguous()
-        feats = rec[1:, 4:].contiguous().view(torch.float32).reshape(-1, 8)
-        n_avg = rec[0, 1:2].int().view(torch.float32)[0]
-        return coords, counts, feats, n_avg
+    def submit(self, frames):
+        """Encode this rank's frame of the batch and start the all-gather; returns a ticket."""
+        import torch.distributed as dist
+        b = len(frames)
+        assert 1 <= b <= self.world
+        if self.rows is None:
+            self._agree_rows(frames)
+        be = self.backend
+        with torch.no_grad():
+            rec = be.encode_record(frames[self.rank], self.rows) if self.rank < b else be.empty_record(self.rows)
+            out = torch.empty((self.world, record_words(self.rows)), dtype=torch.int64, device=rec.device)
+            work = dist.all_gather_into_tensor(out.view(-1), rec, group=self.group, async_op=True)
+        return {"frames": frames, "out": out, "work": work, "rec": rec}
+
+    def finish(self, ticket, decode=True):
+        """Integrate the whole batch in frame order, decode this rank's frame; returns a BatchHandle."""
+        be = self.backend
+        frames, out = ticket["frames"], ticket["out"]
+        b = len(frames)
+        ticket["work"].wait()
+        if self._last is not None:          # previous batch's headers are on the host by now: bookkeeping
+            self._last._account()
+        with torch.no_grad():
+            host = be.pinned((self.world, REC_HDR))
+            host.copy_(out[:, :REC_HDR], non_blocking=True)
+            sdf = mine = None
+            for s in range(b):
+                be.integrate_record(out[s], self.rows, frames[s])
+                if decode and s == self.rank:
+                    sdf = be.decode_record(out[s], self.rows)
+                if s == self.rank:
+                    mine = out[s]
+            ev = be.event()
+        self._last = BatchHandle(self, mine, sdf, host, ev, b)
+        return self._last
 
     def process_batch(self, frames, decode=True):
         """frames: list of up to `world` frame dicts, the SAME list on every rank.
         Returns (coords, sdf) of the frame this rank decoded (None, None if it had none)."""
-        import torch.distributed as dist
-        b = len(frames)
-        assert 1 <= b <= self.world
-        with torch.no_grad():
-            if self.rank < b:
-                rec = self._pack(*self.backend.encode(frames[self.rank]))
-            else:
-                rec = torch.zeros((0, 8), dtype=torch.int64, device=self._dev())
-            sizes = torch.zeros(self.world, dtype=torch.int64, device=rec.device)
-            sizes[self.rank] = rec.shape[0]
-            dist.all_reduce(sizes, group=self.group)
-            sizes = sizes.tolist()
-            m = max(max(sizes), 1)
-            pad = torch.zeros((m, 8), dtype=torch.int64, device=rec.device)
-            pad[: rec.shape[0]] = rec
-            out = torch.empty((self.world, m, 8), dtype=torch.int64, device=rec.device)
-            dist.all_gather_into_tensor(out.view(-1, 8), pad, group=self.group)
-            mine = (None, None)
-            for s in range(b):
-                coords, counts, feats, n_avg = self._unpack(out[s, : sizes[s]])
-                self.backend.integrate(coords, counts, feats, n_avg)
-                if decode and s == self.rank:
-                    mine = (coords, self.backend.decode(coords))
-        return mine
+        return self.finish(self.submit(frames), decode).result()
+
+    def process_stream(self, batches, decode=True):
+        """batches: list of frame lists (each up to `world` long, the same on every rank).  Yields one
+        BatchHandle per batch; batch k+1's encode + exchange are enqueued before batch k's integrate + decode."""
+        ticket = self.submit(batches[0]) if batches else None
+        for i in range(len(batches)):
+            nxt = self.submit(batches[i + 1]) if i + 1 < len(batches) else None
+            yield self.finish(ticket, decode)
+            ticket = nxt
+
+    def flush(self):
+        if self._last is not None:
+            self._last._account()
 
     def _dev(self):
         return getattr(self.backend, "dev", torch.device("cpu"))

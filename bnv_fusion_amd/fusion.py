@@ -210,11 +210,12 @@ class LitFusionPointNet(nn.Module):
         return grid, res
 
     # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
-    def encode_pointcloud_async(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=False):
+    def encode_pointcloud_async(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=False, out=None):
         """Enqueues the encode and returns WITHOUT synchronising: capacity-sized output buffers
         (feats [cap,8], pcounts [cap] i64, flat_ids [cap] i64, grid_ids [cap,3] i64) and the device
         counters (int32 [8]: n_valid, n_unique, n_out, n_avg_pts as float bits, error).  Downstream kernels
-        read n_out from ``counters[2:3]`` on the device."""
+        read n_out from ``counters[2:3]`` on the device.  ``out``: caller-provided contiguous buffers
+        (feats, pcounts, flat_ids, grid_ids) to write into; their row count is the capacity."""
         lib = self._lib_for(self.pointnet_pack)
         self._select_mode(lib)
         assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
@@ -230,12 +231,20 @@ class LitFusionPointNet(nn.Module):
             need = int(lib.bnv_encode_workspace_bytes(self._enc_ws_points, n_arr))
             self._enc_ws = torch.zeros(need, dtype=torch.uint8, device=dev)   # zero-filled = clean
             self._enc_ws_key = key
-        cap = min(8 * n, nvox) if emit_all else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
-        cap = max(cap, 1)
-        feats = torch.empty((cap, 8), dtype=torch.float32, device=dev)
-        pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
-        flat_ids = torch.empty(cap, dtype=torch.int64, device=dev)
-        grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
+        if out is not None:
+            feats, pcounts, flat_ids, grid_ids = out
+            cap = int(grid_ids.shape[0])
+            assert feats.shape == (cap, 8) and feats.dtype == torch.float32 and feats.is_contiguous()
+            assert grid_ids.shape == (cap, 3) and grid_ids.dtype == torch.int64 and grid_ids.is_contiguous()
+            assert pcounts.dtype == torch.int64 and pcounts.numel() >= cap and pcounts.is_contiguous()
+            assert flat_ids.dtype == torch.int64 and flat_ids.numel() >= cap and flat_ids.is_contiguous()
+        else:
+            cap = min(8 * n, nvox) if emit_all else min(8 * n // max(self.min_pts_in_grid, 1) + 1, nvox)
+            cap = max(cap, 1)
+            feats = torch.empty((cap, 8), dtype=torch.float32, device=dev)
+            pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
+            flat_ids = torch.empty(cap, dtype=torch.int64, device=dev)
+            grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
         counters = torch.zeros(8, dtype=torch.int32, device=dev)
         _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
                                              _lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points,

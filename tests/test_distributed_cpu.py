@@ -144,6 +144,8 @@ def test_owner_hash_is_balanced_and_blocked():
 # frame-parallel mode
 # ---------------------------------------------------------------------------------------------
 class OracleFrameBackend:
+    """The frame-backend protocol of bnv_fusion_amd.distributed (fixed-size records) on top of the oracle."""
+
     def __init__(self, dims, voxel):
         from oracle import bnv_oracle as orc
         self.orc = orc
@@ -151,20 +153,57 @@ class OracleFrameBackend:
         self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
         self.dev = torch.device("cpu")
 
-    def encode(self, frame):
+    def record_rows(self, frame):
+        return 8 * int(frame["input_pts"].shape[1]) // 8 + 1
+
+    def empty_record(self, rows):
+        from bnv_fusion_amd.distributed import record_words
+        return torch.zeros(record_words(rows), dtype=torch.int64)
+
+    def encode_record(self, frame, rows):
+        from bnv_fusion_amd.distributed import record_views
         v = self.vol
         f, c, _, g, n = self.orc.encode_pointcloud(self.sd, frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
                                                    v.voxel_size)
-        return g, c.reshape(-1), f, n
+        rec = self.empty_record(rows)
+        rec[8:] = 0x7ff8dead                      # rows beyond n_out are don't-care: poison them
+        counters, grid_ids, pcounts, feats = record_views(rec, rows)
+        k = len(g)
+        counters[0], counters[2] = 1, k
+        counters[3:4] = torch.tensor([float(n)]).view(torch.int32)
+        grid_ids[:k], pcounts[:k], feats[:k] = g, c.reshape(-1), f
+        return rec
 
-    def integrate(self, coords, counts, feats, n_avg):
-        self.vol.track_n_pts(n_avg)
-        self.orc.integrate(self.vol, coords, feats, counts.reshape(-1, 1))
+    def _valid(self, rec, rows):
+        from bnv_fusion_amd.distributed import record_views
+        counters, grid_ids, pcounts, feats = record_views(rec, rows)
+        k = int(counters[2])
+        return grid_ids[:k], pcounts[:k], feats[:k]
 
-    def decode(self, coords):
+    def integrate_record(self, rec, rows, frame=None):
+        g, c, f = self._valid(rec, rows)
+        self.orc.integrate(self.vol, g, f, c.reshape(-1, 1))
+
+    def decode_record(self, rec, rows):
+        g, _, _ = self._valid(rec, rows)
         o = self.orc      # a sample of the voxels keeps the CPU suite fast; the exchange logic is what is tested
-        return self.vol.decode_pts(o.lattice_coords(coords.numpy()[::12]), self.sd, None, is_coords=True,
+        return self.vol.decode_pts(o.lattice_coords(g.numpy()[::12]), self.sd, None, is_coords=True,
                                    query_tensor=False)[0, :, :, 0]
+
+    def account(self, headers, rows):
+        for h in headers:
+            c = h[:4].view(torch.int32)
+            if int(c[0]):
+                self.vol.track_n_pts(float(c[3:4].view(torch.float32)[0]))
+
+    def pinned(self, shape):
+        return torch.empty(shape, dtype=torch.int64)
+
+    def event(self):
+        return None
+
+    def slice_result(self, rec, rows, sdf, n_out):
+        return self._valid(rec, rows)[0], sdf
 
 
 def _fp_worker(rank, world, port, frames, dims, voxel, ret):
@@ -176,10 +215,16 @@ def _fp_worker(rank, world, port, frames, dims, voxel, ret):
     nm = FrameParallelNeuralMap(dims, voxel, None, backend=OracleFrameBackend(dims, voxel))
     outs = []
     fr = [{"input_pts": torch.from_numpy(f)} for f in frames]
-    for t0 in range(0, len(fr), world):              # the last batch is ragged (11 frames, world 2)
-        c, sdf = nm.process_batch(fr[t0: t0 + world])
+    batches = [fr[t0: t0 + world] for t0 in range(0, len(fr), world)]   # the last batch is ragged (11 frames, world 2)
+    # first 2 batches one by one, the rest through the pipelined stream (encode k+1 before integrate k)
+    for i in range(2):
+        c, sdf = nm.process_batch(batches[i])
+        outs.append((i * world + rank, c.numpy(), sdf.numpy()))
+    for i, h in enumerate(nm.process_stream(batches[2:]), start=2):
+        c, sdf = h.result()
         if c is not None:
-            outs.append((t0 + rank, c.numpy(), sdf.numpy()))
+            outs.append((i * world + rank, c.numpy(), sdf.numpy()))
+    nm.flush()
     ret[rank] = (outs, np.asarray(nm.backend.vol.n_pts_list), len(nm.backend.vol._keys))
     dist.destroy_process_group()
 

@@ -632,3 +632,40 @@ def test_non_cubic_volume_and_save_load(bnv, orc, sd, tmp_path):
     assert torch.equal(v2.features, vol.features) and torch.equal(v2.weights, vol.weights)
     got2 = v2.decode_lattice(gg[:200], model.nerf, query_tensor=True)
     assert torch.equal(got2, got)
+
+
+def test_frame_parallel_record_path_equals_neural_map(bnv):
+    """The frame-parallel multi-GPU mode (distributed.FrameParallelNeuralMap) on its HIP backend, run here as a
+    one-rank group: encode straight into the fixed-size record, all-gather, device-side counts, pipelined
+    stream (batch k+1 encoded before batch k is integrated) -- bit-identical to the sequential NeuralMap.
+    (World-2 exchange logic: tests/test_distributed_cpu.py on gloo.)"""
+    import socket
+    import torch.distributed as dist
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+    dims, voxel = synthetic.GRID_DIMS[128]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+               "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)} for t in range(12)]
+    ref_nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    ref = [ref_nm.fuse_and_decode(f) for f in frames]
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        created = True
+    try:
+        fp = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+        got = [fp.process_batch([frames[0]]), fp.process_batch([frames[1]])]
+        got += [h.result() for h in fp.process_stream([[f] for f in frames[2:]])]
+        fp.flush()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for (c0, s0), (c1, s1) in zip(ref, got):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    assert fp.volume.num_rows() == ref_nm.volume.num_rows()
+    assert torch.equal(fp.backend.tsdf_vol.tsdf, ref_nm.tsdf_vol.tsdf)
+    assert np.allclose(fp.volume.n_pts_list, ref_nm.volume.n_pts_list)
