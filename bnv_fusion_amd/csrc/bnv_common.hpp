@@ -20,6 +20,14 @@ extern int g_mlp_mode;
 enum ProfKind { PROF_POINTNET = 0, PROF_DECODE_LATTICE = 1, PROF_DECODE_PTS = 2, PROF_DECODE_DENSE = 3, PROF_KINDS = 4 };
 extern bool g_prof_on;
 void prof_mark(int kind, bool begin, hipStream_t stream);
+// ReLU as ONE instruction: v_max_i32 on the bit pattern (a float with the sign bit set is a negative
+// int; -0.0 -> +0.0).  fmaxf() and fmed3 both cost an extra canonicalising v_max under IEEE mode, and an
+// inline-asm v_max_f32 would hide the MFMA-result -> VALU hazard from the compiler.
+__device__ __forceinline__ float relu_bits(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 struct ProfScope {
   int kind;
   hipStream_t stream;

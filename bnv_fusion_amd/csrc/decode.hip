@@ -52,6 +52,25 @@ constexpr int L_TOTAL = L_DELTA + DM;         // 35,328 floats = 141,312 B
 
 enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2 };
 
+// Phase timing of the decode tile loop (development builds only: -DBNV_PHASE_PROF, tools/phase_prof.py).
+// Thread 0 of every workgroup accumulates shader-clock deltas per phase in LDS and adds them to
+// g_phase_cycles at kernel end.
+#ifdef BNV_PHASE_PROF
+constexpr int L_PROF = L_TOTAL;  // [8 waves][32] x u64 behind the regular LDS layout
+__device__ unsigned long long g_phase_cycles[8 * 32];
+#define BNV_PH(i)                                                                 \
+  do {                                                                            \
+    if ((threadIdx.x & 63) == 0) {                                                \
+      unsigned long long* _p = (unsigned long long*)(lds + L_PROF) + (threadIdx.x >> 6) * 32; \
+      const unsigned long long _t = clock64();                                    \
+      _p[i] += _t - _p[31];                                                       \
+      _p[31] = _t;                                                                \
+    }                                                                             \
+  } while (0)
+#else
+#define BNV_PH(i)
+#endif
+
 struct DecodeArgs {
   bnv_volume_t vol;
   bnv_grid_t grid;
@@ -118,7 +137,7 @@ __device__ __forceinline__ void store_relu(float* __restrict__ hl, const f32x16 
     for (int q = 0; q < 4; ++q) {
       f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[pt][4 * q + i], 0.f);
+      for (int i = 0; i < 4; ++i) v[i] = relu_bits(acc[pt][4 * q + i]);
       *(f32x4*)&hl[(((4 * w + q) * 2 + h) * DM + pt * 32 + j) * 4] = v;
     }
   }
@@ -150,7 +169,7 @@ __device__ __forceinline__ void sdf_mlp_tile(float* __restrict__ lds, const floa
   for (int pt = 0; pt < 4; ++pt) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], fmaxf(acc[pt][r], 0.f), s);
+    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], relu_bits(acc[pt][r]), s);
     lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = s;
   }
   __syncthreads();
@@ -189,10 +208,7 @@ __device__ __forceinline__ void stage_input(float* __restrict__ hl, int j, const
 // of wave w exactly the 8 slots of K-step 2 w + ksl.
 constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
 
-// ReLU as ONE instruction the compiler can see: v_med3_f32(x, 0, +inf).  (fmaxf() costs an extra
-// canonicalising v_max under IEEE mode; an inline-asm v_max would hide the MFMA-result -> VALU hazard
-// from the compiler, which pads wait states only around instructions it knows.)
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+__device__ __forceinline__ float relu1(float x) { return relu_bits(x); }
 
 template <int NKS, bool BIAS = true>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
@@ -232,7 +248,6 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
   for (int ks = 0; ks < NKS; ++ks) {
     if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
     if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetches above this step's MFMAs (the scheduler sinks them)
     const half8 a_hi = ah[ks % 3], a_lo = al[ks % 3];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
@@ -243,6 +258,23 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
       acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+    // Issue order inside the step: every prefetch goes into the shadow of an MFMA (one memory instruction
+    // behind each of the first ten MFMAs).  A wave then keeps the MFMA pipe busy on its own; with all ten
+    // loads clustered at the top of the step a lone wave reached only 55-70 % (tools/phase_prof.py).
+    if (ks + 1 < NKS) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+    }
+    if (ks + 2 < NKS) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef BNV_LOAD_A
@@ -276,27 +308,42 @@ __device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const fl
   const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
   f32x16 acc[4];
   mlp_layer_h<2>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
+  BNV_PH(1);
   __syncthreads();
+  BNV_PH(2);
   store_relu_h(lds, acc, w, j, h);
+  BNV_PH(3);
   __syncthreads();
+  BNV_PH(4);
   mlp_layer_h<16>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+  BNV_PH(5);
   __syncthreads();
+  BNV_PH(6);
   store_relu_h(lds, acc, w, j, h);
+  BNV_PH(7);
   __syncthreads();
+  BNV_PH(8);
   mlp_layer_h<16>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+  BNV_PH(9);
   __syncthreads();
+  BNV_PH(10);
   store_relu_h(lds, acc, w, j, h);
+  BNV_PH(11);
   __syncthreads();
+  BNV_PH(12);
   mlp_layer_h<16>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+  BNV_PH(13);
   const f32x16 wa = frag256(pack + SD_WA, w, h);
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], fmaxf(acc[pt][r], 0.f), s);
+    for (int r = 0; r < 16; ++r) s = fmaf(wa[r], relu_bits(acc[pt][r]), s);
     lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = s;
   }
+  BNV_PH(14);
   __syncthreads();
+  BNV_PH(15);
   if (threadIdx.x < DM) {
     float s = pack[SD_BA];
 #pragma unroll
@@ -304,6 +351,7 @@ __device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const fl
     lds[L_ALPHA + threadIdx.x] = s;
   }
   __syncthreads();
+  BNV_PH(16);
 }
 
 // inputs of evaluation j in the split layout: features 0..16 (+15 zero) over K-steps 0, 1
@@ -462,6 +510,11 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
   } else {
     n_tiles = (A.n + 15) / 16;
   }
+#ifdef BNV_PHASE_PROF
+  if (threadIdx.x < 256) ((unsigned long long*)(lds + L_PROF))[threadIdx.x] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) ((unsigned long long*)(lds + L_PROF))[(threadIdx.x >> 6) * 32 + 31] = clock64();
+#endif
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---------------- front end: one thread per MLP input ---------------------------------
     if (threadIdx.x < DM) {
@@ -562,7 +615,9 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
       }
       run_mlp = __syncthreads_or(live) != 0;
     } else {
+      BNV_PH(0);
       __syncthreads();
+      BNV_PH(18);
     }
     if (run_mlp) {
       if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
@@ -625,8 +680,16 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
         }
       }
     }
+    BNV_PH(17);
     __syncthreads();
+    BNV_PH(19);
   }
+#ifdef BNV_PHASE_PROF
+  __syncthreads();
+  if (threadIdx.x < 256 && (threadIdx.x & 31) != 31)
+    atomicAdd(&g_phase_cycles[threadIdx.x], ((unsigned long long*)(lds + L_PROF))[threadIdx.x]);
+  if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[31], 1ull);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -975,7 +1038,6 @@ __device__ __forceinline__ void mlp_layer_q(const _Float16* __restrict__ wp, con
   for (int ks = 0; ks < NKS; ++ks) {
     if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
     if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -991,6 +1053,20 @@ __device__ __forceinline__ void mlp_layer_q(const _Float16* __restrict__ wp, con
 #pragma unroll
       for (int pt = 0; pt < 2; ++pt)
         acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks % 3][nb], bh[ks & 1][pt], acc[nb][pt], 0, 0, 0);
+    if (ks + 1 < NKS) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    if (ks + 2 < NKS) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef BNV_LOAD_A
@@ -1334,6 +1410,12 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
 
 int g_lattice_h64 = 0;  // 1: 64-evaluation tiles, 2 workgroups per CU (bnv_set_option); measured 4 % slower
 
+#ifdef BNV_PHASE_PROF
+constexpr int kProfLds = 2048;
+#else
+constexpr int kProfLds = 0;
+#endif
+
 static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
   if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_h64) {
     int64_t grid = 2 * (int64_t)g_num_cus;
@@ -1350,7 +1432,7 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   ProfScope prof(mode == MODE_PTS ? PROF_DECODE_PTS : mode == MODE_LATTICE ? PROF_DECODE_LATTICE : PROF_DECODE_DENSE,
                  stream);
 #define BNV_LAUNCH_DECODE(M, P) \
-  hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4, stream, args)
+  hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4 + kProfLds, stream, args)
   if (g_mlp_mode == 2) {
     if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 2);
     else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
@@ -1382,7 +1464,7 @@ extern "C" {
 
 int bnv_decode_init() {
 #define BNV_OPT_IN(M, P) \
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4))
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4 + kProfLds))
   BNV_OPT_IN(MODE_PTS, 0);
   BNV_OPT_IN(MODE_LATTICE, 0);
   BNV_OPT_IN(MODE_DENSE, 0);
@@ -1401,6 +1483,17 @@ int bnv_decode_init() {
 }
 
 size_t bnv_sdfmlp_pack_floats(void) { return SD_PACK_FLOATS; }
+
+#ifdef BNV_PHASE_PROF
+// development builds only (not in include/bnv_fusion.h): read and reset the phase cycle counters
+int bnv_dev_phase_read(unsigned long long* out256) {
+  BNV_HIP_CHECK(hipDeviceSynchronize());
+  BNV_HIP_CHECK(hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_phase_cycles), 256 * sizeof(unsigned long long)));
+  unsigned long long z[256] = {};
+  BNV_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof(z)));
+  return BNV_OK;
+}
+#endif
 
 int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;

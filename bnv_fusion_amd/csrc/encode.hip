@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply_bitmap(const uint32
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+  for (int r = 0; r < 16; ++r) v[r] = relu_bits(v[r]);
   return v;
 }
 
@@ -463,7 +463,7 @@ __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, hal
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float x = v[base + e];
-    if (relu) x = __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());  // one compiler-visible op (no asm: MFMA hazards)
+    if (relu) x = relu_bits(x);
     const _Float16 h = (_Float16)x;
     (*hi)[e] = h;
     (*lo)[e] = (_Float16)(x - (float)h);
@@ -674,7 +674,7 @@ __device__ __forceinline__ half8 to_half8_relu(const f32x16& v, int base) {
   half8 r;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    r[e] = (_Float16)__builtin_amdgcn_fmed3f(v[base + e], 0.f, __builtin_inff());
+    r[e] = (_Float16)relu_bits(v[base + e]);
   }
   return r;
 }

@@ -1,0 +1,55 @@
+"""Phase breakdown of the lattice-table decode kernel (development tool).
+Build the instrumented library first:
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -DBNV_PHASE_PROF \
+        bnv_fusion_amd/csrc/{encode,volume,decode,frontend,tsdf}.hip -o tools/libbnv_phase_prof.so
+then:  BNV_FUSION_LIB=tools/libbnv_phase_prof.so python tools/phase_prof.py
+Thread 0 of every workgroup accumulates shader-clock deltas between phase marks."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+os.environ.setdefault("BNV_FUSION_LIB", os.path.abspath("tools/libbnv_phase_prof.so"))
+import bnv_fusion_amd as bnv  # noqa: E402
+from bnv_fusion_amd import synthetic, _lib  # noqa: E402
+
+NAMES = {0: "front end (gather, stage)", 18: "barrier after front end", 1: "L0 mfma", 2: "barrier", 3: "L0 relu+split+store",
+         4: "barrier", 5: "L1 mfma", 6: "barrier", 7: "L1 store", 8: "barrier", 9: "L2 mfma", 10: "barrier",
+         11: "L2 store", 12: "barrier", 13: "L3 mfma", 14: "fc_alpha partials", 15: "barrier",
+         16: "alpha reduce + barrier", 17: "table write", 19: "end barrier"}
+ORDER = [0, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19]
+
+dev = "cuda:0"
+dims, voxel = synthetic.GRID_DIMS[256]
+model = bnv.load_pretrained(device=dev, voxel_size=voxel)
+nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=1 << 20, device=dev, tsdf=True)
+frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).to(dev), "intr_mat": synthetic.intrinsics(),
+           "T_wc": synthetic.pose(t)} for t in range(40)]
+for f in frames[:30]:
+    nm.integrate(f)
+lib = _lib.load()
+lib.bnv_dev_phase_read.argtypes = [C.POINTER(C.c_ulonglong)]
+buf = (C.c_ulonglong * 256)()
+for f in frames[30:34]:
+    nm.fuse_and_decode(f)
+lib.bnv_dev_phase_read(buf)                      # reset after warm-up
+n = 6
+evals = 0
+for f in frames[34:34 + n]:
+    nm.fuse_and_decode(f)
+    evals += int(nm.volume.last_lattice_evals())
+lib.bnv_dev_phase_read(buf)
+v = np.array(list(buf), dtype=np.float64).reshape(8, 32)
+blocks = v[0, 31]
+tiles = evals / 128.0
+tot = v[0, :31].sum()
+print(f"{n} launches, {int(blocks)} workgroups, {evals} evaluations = {tiles:.0f} tiles; "
+      f"{tot / tiles:.0f} cycles per tile; columns = waves 0..7 (cycles per tile)")
+for i in ORDER:
+    print(f"  {NAMES[i]:28s}" + "".join(f"{v[w, i] / tiles:8.0f}" for w in range(8)) + f"   {100 * v[0, i] / tot:5.1f} % (w0)")
+mf = v[:, [1, 5, 9, 13]].sum(1)
+print("  MFMA phases total %          " + "".join(f"{100 * mf[w] / tot:8.1f}" for w in range(8)))
+print("  ideal MFMA-bound tile = 600 MFMA x 32 cyc x 2 waves/SIMD = 38400 cyc")
