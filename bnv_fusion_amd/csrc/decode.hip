@@ -210,6 +210,9 @@ constexpr int L_HLO = L_HL + 16 * 2 * DM * 4;  // float offset of the lo plane
 
 __device__ __forceinline__ float relu1(float x) { return relu_bits(x); }
 
+#ifndef BNV_A_AHEAD
+#define BNV_A_AHEAD 2
+#endif
 template <int NKS, bool BIAS = true>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
                                             const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
@@ -227,12 +230,13 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
   const float* hh = lds + L_HL + (h * DM + j) * 4;
   const float* hl = lds + L_HLO + (h * DM + j) * 4;
   // software pipeline over the K-steps (fully unrolled, all indices static): weight fragments come
-  // from L2 two steps ahead (3-deep register ring), activation fragments from LDS one step ahead
-  half8 ah[3], al[3], bh[2][4], bl[2][4];
+  // from L2 kAhead steps ahead (register ring), activation fragments from LDS one step ahead
+  constexpr int kAhead = BNV_A_AHEAD, kRing = kAhead + 1;
+  half8 ah[kRing], al[kRing], bh[2][4], bl[2][4];
 #define BNV_LOAD_A(ks)                                              \
   {                                                                 \
-    ah[(ks) % 3] = *(const half8*)(wl + ((ks) * 2) * 64 * 8);       \
-    al[(ks) % 3] = *(const half8*)(wl + ((ks) * 2 + 1) * 64 * 8);   \
+    ah[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2) * 64 * 8);     \
+    al[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2 + 1) * 64 * 8); \
   }
 #define BNV_LOAD_B(ks)                                                                    \
   {                                                                                       \
@@ -241,14 +245,15 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
       bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
     }                                                                                     \
   }
-  BNV_LOAD_A(0);
-  if (NKS > 1) BNV_LOAD_A(1);
+#pragma unroll
+  for (int p = 0; p < kAhead; ++p)
+    if (p < NKS) BNV_LOAD_A(p);
   BNV_LOAD_B(0);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
-    if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
+    if (ks + kAhead < NKS) BNV_LOAD_A(ks + kAhead);
     if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    const half8 a_hi = ah[ks % 3], a_lo = al[ks % 3];
+    const half8 a_hi = ah[ks % kRing], a_lo = al[ks % kRing];
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
       acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
@@ -268,7 +273,7 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
       }
     }
-    if (ks + 2 < NKS) {
+    if (ks + kAhead < NKS) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA

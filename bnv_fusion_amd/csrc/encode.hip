@@ -66,7 +66,7 @@ constexpr int PH_W3 = PH_W2 + 4 * 4 * 2 * 2 * 64 * 8;
 constexpr int PH_W4 = PH_W3 + 4 * 4 * 2 * 2 * 64 * 8;   // [4 nb][2 ksl][2 hi/lo][2 h][8 n][8]
 constexpr int PH_TOTAL = PH_W4 + 4 * 2 * 2 * 2 * 8 * 8; // 71,680 halves = 143,360 B
 constexpr int PN_PACK_FLOATS = PN_TOTAL + PH_TOTAL / 2;
-constexpr int PH_LDS_BYTES = PH_TOTAL * 2 + (128 * 3 + 8) * 4;  // halves + fp32 biases = 144,928 B
+constexpr int PH_LDS_BYTES = PH_TOTAL * 2 + (128 * 3 + 8) * 4 + 16;  // halves + fp32 biases + tile counter = 144,944 B
 
 constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exact integers
 
@@ -499,6 +499,23 @@ __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, cons
 #undef BNV_LOAD_W
 }
 
+#ifdef BNV_PHASE_PROF
+__device__ unsigned long long g_enc_phase[8 * 16];
+#define BNV_EPH(i)                                                                          \
+  do {                                                                                      \
+    if ((threadIdx.x & 63) == 0) {                                                          \
+      unsigned long long* _p = (unsigned long long*)((char*)lds + PH_LDS_BYTES) + (threadIdx.x >> 6) * 16; \
+      const unsigned long long _t = clock64();                                              \
+      _p[i] += _t - _p[15];                                                                 \
+      _p[15] = _t;                                                                          \
+    }                                                                                       \
+  } while (0)
+constexpr int kEncProfLds = 8 * 16 * 8;
+#else
+#define BNV_EPH(i)
+constexpr int kEncProfLds = 0;
+#endif
+
 __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
@@ -509,6 +526,8 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
   for (int i = threadIdx.x * 4; i < PH_TOTAL / 2; i += 512 * 4)
     *(f32x4*)&lds[i] = *(const f32x4*)&wpack[PN_TOTAL + i];
   for (int i = threadIdx.x; i < 128 * 3 + 8; i += 512) lb[i] = wpack[PN_B1 + i];
+  int* tile_ctr = (int*)((char*)lds + PH_TOTAL * 2 + (128 * 3 + 8) * 4);
+  if (threadIdx.x == 0) *tile_ctr = 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -520,8 +539,18 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
 
   // Software pipeline over this wave's tiles: while tile t runs its MLP, the point of tile t+2 and the
   // bitmap / prefix words of tile t+1 are in flight (three dependent memory latencies per tile).
+  // The workgroup's tiles {8 b + k + i * 8 * gridDim} are handed to its 8 waves DYNAMICALLY (LDS counter):
+  // of the two waves on a SIMD the older one wins issue arbitration and runs ~1.4x faster, so with a
+  // static split the younger waves were still working when the older ones had finished
+  // (tools/phase_prof.py).  The scatter is order-independent, so results do not depend on who takes what.
   const int tstep = gridDim.x * 8;
-  const int t0 = blockIdx.x * 8 + wave;
+  (void)wave;
+  auto grab = [&]() -> int {
+    int c = 0;
+    if (lane == 0) c = atomicAdd(tile_ctr, 1);
+    c = __builtin_amdgcn_readfirstlane(c);
+    return blockIdx.x * 8 + (c & 7) + (c >> 3) * tstep;
+  };
   float raw[6];                 // stage 1 (tile t+2): the raw point
   bool raw_ok = false;
   float nin[4];                 // stage 2 (tile t+1): network inputs, voxel id, its bitmap/prefix words
@@ -569,19 +598,28 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
       }
     }
   };
-  stage1(t0);
-  stage2(t0);
-  stage1(t0 + tstep);
+  int t = grab();
+  stage1(t);
+  stage2(t);
+  int t_next = grab(), t_next2 = 0;
+  stage1(t_next);
+#ifdef BNV_PHASE_PROF
+  if ((threadIdx.x & 63) < 16)
+    ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)] = 0;
+  if ((threadIdx.x & 63) == 0) ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + 15] = clock64();
+#endif
 
-  for (int t = t0; t < n_tiles; t += tstep) {
+  for (; t < n_tiles; t = t_next, t_next = t_next2) {
     // stage 3 (tile t): slot from the words fetched one MLP ago
     float in[4];  // slots 0..3 of this lane half: features 4h .. 4h+3 of [rel(3), normal(3)]
 #pragma unroll
     for (int c = 0; c < 4; ++c) in[c] = nin[c];
     const int slot = n_own ? (int)(n_pref + __popc(n_word & ((1u << (n_id & 31)) - 1u))) : -1;
-    stage2(t + tstep);      // consumes the point fetched one MLP ago, issues its bitmap / prefix loads
-    stage1(t + 2 * tstep);  // issues the next point load
+    stage2(t_next);         // consumes the point fetched one MLP ago, issues its bitmap / prefix loads
+    t_next2 = grab();
+    stage1(t_next2);        // issues the next point load
     __builtin_amdgcn_sched_barrier(0);
+    BNV_EPH(0);
     if (__ballot(slot >= 0) == 0ULL) continue;
 
     // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots) -----------------------------
@@ -605,24 +643,30 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
         ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh, c, 0, 0, 0);
       }
     }
+    BNV_EPH(1);
     half8 sh[8], sl[8];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
       split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
+    BNV_EPH(2);
     layer128_h(wh + PH_W2, lb + 128, sh, sl, hb, lane, h);
+    BNV_EPH(3);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       split8(hb[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
       split8(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
+    BNV_EPH(4);
     layer128_h(wh + PH_W3, lb + 256, sh, sl, ha, lane, h);
+    BNV_EPH(5);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
       split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
       split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
+    BNV_EPH(6);
     // ---- layer 4: 128 -> 8 ------------------------------------------------------------------
     f32x16 o;
 #pragma unroll
@@ -632,28 +676,40 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = b4[r];
     }
+    // A rows >= 8 only feed output rows >= 8, which nobody reads: every lane loads row (j & 7), no
+    // predication and no zero fill; all 16 fragments are fetched before the accumulate chain starts.
+    half8 w4h[2][2], w4l[2][2];
+#define BNV_LOAD_W4(gp)                                                                             \
+  {                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
+      const _Float16* w = wh + PH_W4 + (((((gp) * 2 + u) * 2) * 2 + h) * 8 + (j & 7)) * 8;          \
+      w4h[(gp) & 1][u] = *(const half8*)w;                                                          \
+      w4l[(gp) & 1][u] = *(const half8*)(w + 2 * 8 * 8);                                            \
+    }                                                                                               \
+  }
+    __builtin_amdgcn_sched_barrier(0);  // keep these loads below layer 3 (register peak)
+    BNV_LOAD_W4(0);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
+    for (int gp = 0; gp < 4; ++gp) {       // pairs of K-steps; the next pair's fragments load under this pair's MFMAs
+      if (gp + 1 < 4) BNV_LOAD_W4(gp + 1);
 #pragma unroll
-      for (int ksl = 0; ksl < 2; ++ksl) {
-        half8 ahi, alo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ahi[e] = (_Float16)0.f;
-          alo[e] = (_Float16)0.f;
-        }
-        if (j < 8) {
-          const _Float16* w = wh + PH_W4 + (((((nb * 2 + ksl) * 2) * 2 + h) * 8) + j) * 8;
-          ahi = *(const half8*)w;
-          alo = *(const half8*)(w + 2 * 8 * 8);
-        }
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, sh[nb * 2 + ksl], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sl[nb * 2 + ksl], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, sh[nb * 2 + ksl], o, 0, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        const int gq = gp * 2 + u;
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4l[gp & 1][u], sh[gq], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sl[gq], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sh[gq], o, 0, 0, 0);
       }
     }
+#undef BNV_LOAD_W4
+    BNV_EPH(7);
     scatter_tile(o, slot, j, h, counts, acc);
+    BNV_EPH(8);
   }
+#ifdef BNV_PHASE_PROF
+  if ((threadIdx.x & 63) < 15)
+    atomicAdd(&g_enc_phase[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)],
+              ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -896,6 +952,17 @@ using namespace bnv;
 // ==========================================================================================
 extern "C" {
 
+#ifdef BNV_PHASE_PROF
+int bnv_dev_enc_phase_read(unsigned long long* out128) {
+  BNV_HIP_CHECK(hipDeviceSynchronize());
+  BNV_HIP_CHECK(hipMemcpyFromSymbol(out128, HIP_SYMBOL(bnv::g_enc_phase), 128 * sizeof(unsigned long long)));
+  unsigned long long z[128] = {};
+  BNV_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(bnv::g_enc_phase), z, sizeof(z)));
+  return BNV_OK;
+}
+#endif
+
+
 int bnv_init(int device) {
   BNV_HIP_CHECK(hipSetDevice(device));
   int cus = 0;
@@ -904,7 +971,7 @@ int bnv_init(int device) {
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
   extern int bnv_decode_init();
   return bnv_decode_init();
 }
@@ -1012,7 +1079,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
                          ws.acc);
     else if (g_mlp_mode == 1)
-      hipLaunchKernelGGL(k_pointnet_scatter_h, dim3(grid_pn), dim3(512), PH_LDS_BYTES, stream, input_pts, n, g,
+      hipLaunchKernelGGL(k_pointnet_scatter_h, dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream, input_pts, n, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     else
       hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
