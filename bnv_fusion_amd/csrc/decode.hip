@@ -40,6 +40,16 @@ constexpr int SH_W3 = SH_W2 + 8 * 16 * 2 * 64 * 8;
 constexpr int SH_TOTAL = SH_W3 + 8 * 16 * 2 * 64 * 8;   // 409,600 halves
 constexpr int SD_PACK_FLOATS = SD_TOTAL + SH_TOTAL / 2;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// weight fragment fetch through a buffer descriptor: wave-uniform base (SGPRs) + one shared per-lane
+// byte offset + a scalar offset per load -- no 64-bit address VGPR per load (with flat loads the compiler
+// hoists dozens of lane-constant addresses out of the tile loop and spills them)
+__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_bit_cast(half8, v);
+}
+
 
 // LDS (floats)
 constexpr int L_HL = 0;                       // [32 kb][2 h][128 j][4]
@@ -714,16 +724,6 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
 // g_in in fp32 at the very end, followed by float atomics into grad_features[row].  Tiles whose 16
 // queries are all masked (free space: most ray samples) skip the MLP altogether.
 // ---------------------------------------------------------------------------------------------------
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// weight fragment fetch through a buffer descriptor: wave-uniform base (SGPRs) + one shared per-lane
-// byte offset + a scalar offset per load -- no 64-bit address VGPR per load (with flat loads the compiler
-// hoists dozens of lane-constant addresses out of the tile loop and spills them)
-__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
-  return __builtin_bit_cast(half8, v);
-}
-
 // mlp_layer_h with the weight fragments fetched by buffer loads (used where several layers' worth of
 // hoisted flat addresses would not fit the register file)
 template <int NKS, bool BIAS>
@@ -985,6 +985,250 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
       }
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_lattice_table_h: the hot kernel (lattice table, split-operand mode), software-pipelined ACROSS tiles
+// and layers.  Same arithmetic as k_decode<LATTICE, 1> (bit-identical tables); what changes is when
+// things are fetched (tools/phase_prof.py showed 5 % of a tile in the gather/stage front end, ~600 idle
+// cycles at every layer start waiting for the first weight fragments, 11 barriers per tile):
+//  * the work-list entry of tile t+2 and the features of tile t+1 are loaded while tile t runs its MLP;
+//    the inputs of tile t+1 are split and staged into a separate LDS buffer (PARK) in the shadow of layer
+//    0's store phase, and layer 0 reads its B operands from PARK -- no gather on the critical path;
+//  * the weight-fragment ring runs continuously through the 50 K-steps of a tile and on into the next
+//    tile: the first fragments of layer L+1 are requested during the last K-steps of layer L, so they
+//    arrive during the convert/store phase and its barriers;
+//  * sin / cos of the lattice offsets {-.5, 0, .5} are two constants; the final reduction writes the table
+//    directly; 7 barriers per tile.
+// ---------------------------------------------------------------------------------------------------
+constexpr int T_PARK_HI = L_PART + 16 * DM;            // [2 ks][2 h][128 j][8 halves] = 8 KB
+constexpr int T_PARK_LO = T_PARK_HI + 2 * 2 * DM * 4;  // lo plane
+constexpr int T_TOTAL = T_PARK_LO + 2 * 2 * DM * 4;    // 38,912 floats = 155,648 B
+constexpr int kTRing = 5, kTAhead = 3;                 // 50 K-steps per tile: 50 % 5 == 0 keeps the ring phase
+
+struct ARing {
+  half8 hi[kTRing], lo[kTRing];
+};
+
+// One layer of the chain.  BASE = K-steps before this layer within the tile (ring phase); the ring holds
+// this layer's fragments 0 .. kTAhead-1 on entry; the last kTAhead steps request the NEXT layer's first
+// fragments from wp_next (its per-wave stride NEXT_NKS).
+template <int NKS, int BASE, int NEXT_NKS>
+__device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
+                                            const float* __restrict__ bias, const float* __restrict__ hh,
+                                            const float* __restrict__ hl, ARing& ring, f32x16 (&acc)[4], int w,
+                                            int h) {
+  // weight fragments through the buffer descriptor of the whole split pack: `off` / `off_next` are the byte
+  // offsets of this / the next layer, the per-wave and per-fragment parts are scalar too -- no 64-bit address
+  // VGPRs for the 100 loads of a tile (flat loads get their addresses hoisted out of the tile loop and spill)
+  const f32x16 b0 = frag256(bias, w, h);
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
+  const int sl = off + w * NKS * 2 * 1024;
+  const int sn = off_next + w * NEXT_NKS * 2 * 1024;
+  half8 bh[2][4], bl[2][4];
+#define BNV_LOAD_B(ks)                                                                    \
+  {                                                                                       \
+    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
+      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
+      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
+    }                                                                                     \
+  }
+  BNV_LOAD_B(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int nx = ks + kTAhead;  // the fragment requested during this step
+    bool loads_a = false;
+    if (nx < NKS) {
+      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2) * 1024);
+      ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2 + 1) * 1024);
+      loads_a = true;
+    } else if (nx - NKS < NEXT_NKS && nx - NKS < kTAhead) {
+      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2) * 1024);
+      ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2 + 1) * 1024);
+      loads_a = true;
+    }
+    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
+    const half8 a_hi = ring.hi[(BASE + ks) % kTRing], a_lo = ring.lo[(BASE + ks) % kTRing];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+    if (ks + 1 < NKS) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
+    }
+    if (loads_a) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_B
+}
+
+// (row, l) of evaluation e of the work list, or row = -1 beyond its end
+__device__ __forceinline__ int lattice_entry(const DecodeArgs& A, int64_t e, int64_t n_evals) {
+  if (e >= n_evals) return -1;
+  if (A.entries) return A.entries[e];
+  const int64_t ci = e / 27;
+  return (A.list[ci] << 5) | (int)(e - ci * 27);
+}
+
+__global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
+  const int64_t n_tiles = (n_evals + DM - 1) / DM;
+  const float* pack = A.pack;
+  const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
+  const float s5 = sinf(0.5f), c5 = cosf(0.5f);
+  const bool gatherer = threadIdx.x < DM;
+
+  // stage the 17 network inputs of (entry ent, features f0 f1) into PARK at column e
+  auto stage_park = [&](int e, int ent, const f32x4& f0, const f32x4& f1) {
+    float in[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) in[f] = 0.f;
+    if (ent >= 0) {
+      const int l = ent & 31;
+      const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
+      const int li[3] = {lx, ly, lz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        in[a] = (float)li[a] * 0.5f;
+        in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
+        in[6 + a] = li[a] == 0 ? 1.f : c5;
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        in[9 + f] = f0[f];
+        in[13 + f] = f1[f];
+      }
+    } else {
+      in[6] = in[7] = in[8] = 1.f;  // what k_decode stages for an empty column: cos(0)
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        half8 hi, lo;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
+          const _Float16 t = (_Float16)x;
+          hi[jj] = t;
+          lo[jj] = (_Float16)(x - (float)t);
+        }
+        const int o = ((ks * 2 + hh) * DM + e) * 4;
+        *(half8*)&lds[T_PARK_HI + o] = hi;
+        *(half8*)&lds[T_PARK_LO + o] = lo;
+      }
+    }
+  };
+  auto load_feats = [&](int ent, f32x4& f0, f32x4& f1) {
+    if (ent >= 0) {
+      const size_t row = (size_t)(ent >> 5);
+      f0 = *(const f32x4*)&A.features[row * 8];
+      f1 = *(const f32x4*)&A.features[row * 8 + 4];
+    }
+  };
+
+  // ---- prologue: inputs of the first tile into PARK, entry of the second tile, first weight fragments
+  int64_t tile = blockIdx.x;
+  int ent_cur = -1, ent_nx = -1;
+  f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+  if (gatherer) {
+    if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
+    if (tile + gridDim.x < n_tiles) ent_nx = lattice_entry(A, (tile + gridDim.x) * DM + threadIdx.x, n_evals);
+    load_feats(ent_cur, f0, f1);
+    stage_park(threadIdx.x, ent_cur, f0, f1);
+  }
+  ARing ring;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph, 0, SH_TOTAL * 2, 0x00020000);
+  const int voff = lane * 16;
+  constexpr int O0 = SH_W0 * 2, O1 = SH_W1 * 2, O2 = SH_W2 * 2, O3 = SH_W3 * 2;  // byte offsets of the layers
+  {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // layer 0 has 2 K-steps; its third request slot belongs to layer 1
+      ring.hi[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2) * 1024);
+      ring.lo[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2 + 1) * 1024);
+    }
+    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);
+    ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
+  }
+  __syncthreads();
+
+  const float* park_hh = lds + T_PARK_HI + (h * DM + j) * 4;
+  const float* park_hl = lds + T_PARK_LO + (h * DM + j) * 4;
+  const float* hl_hh = lds + L_HL + (h * DM + j) * 4;
+  const float* hl_hl = lds + L_HLO + (h * DM + j) * 4;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    // ---- requests for the following tiles (gather lanes): features of tile+1, entry of tile+2 --------
+    int ent_nx2 = -1;
+    if (gatherer) {
+      f0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      load_feats(ent_nx, f0, f1);
+      const int64_t t2 = tile + 2 * (int64_t)gridDim.x;
+      if (t2 < n_tiles) ent_nx2 = lattice_entry(A, t2 * DM + threadIdx.x, n_evals);
+    }
+    f32x16 acc[4];
+    // layer 0 (B from PARK); K-steps 0, 1 of the tile; requests fragments 1, 2 of layer 1 (0 is in the ring)
+    chain_layer<2, 0, 16>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, w, h);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    if (gatherer) stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
+    __syncthreads();
+    chain_layer<16, 2, 16>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, w, h);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    __syncthreads();
+    chain_layer<16, 18, 16>(rs, voff, O2, O3, pack + SD_B0 + 512, hl_hh, hl_hl, ring, acc, w, h);
+    __syncthreads();
+    store_relu_h(lds, acc, w, j, h);
+    __syncthreads();
+    // layer 3; its last steps request layer 0's two fragments and layer 1's first for the NEXT tile
+    chain_layer<16, 34, 2>(rs, voff, O3, O0, pack + SD_B0 + 768, hl_hh, hl_hl, ring, acc, w, h);
+    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);  // (50 + 2) % 5: layer 1's fragment 0, next tile
+    ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
+    // fc_alpha: 256 -> 1
+    const f32x16 wa = frag256(pack + SD_WA, w, h);
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum = fmaf(wa[r], relu_bits(acc[pt][r]), sum);
+      lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = sum;
+    }
+    __syncthreads();
+    if (gatherer) {
+      if (ent_cur >= 0) {
+        float sum = pack[SD_BA];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + threadIdx.x];
+        const int row = ent_cur >> 5;
+        A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
+        if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
+      }
+      ent_cur = ent_nx;
+      ent_nx = ent_nx2;
+    }
   }
 }
 
@@ -1414,6 +1658,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
 }
 
 int g_lattice_h64 = 0;  // 1: 64-evaluation tiles, 2 workgroups per CU (bnv_set_option); measured 4 % slower
+int g_lattice_pipe = 1; // 1: k_lattice_table_h (cross-tile / cross-layer pipelined); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
 constexpr int kProfLds = 2048;
@@ -1434,6 +1679,12 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   int64_t grid = g_num_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
+  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_pipe) {
+    ProfScope prof(PROF_DECODE_LATTICE, stream);
+    hipLaunchKernelGGL(k_lattice_table_h, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+    BNV_LAUNCH_CHECK();
+    return BNV_OK;
+  }
   ProfScope prof(mode == MODE_PTS ? PROF_DECODE_PTS : mode == MODE_LATTICE ? PROF_DECODE_LATTICE : PROF_DECODE_DENSE,
                  stream);
 #define BNV_LAUNCH_DECODE(M, P) \
@@ -1482,6 +1733,8 @@ int bnv_decode_init() {
 #undef BNV_OPT_IN
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_lattice_h64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Q_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L_TOTAL * 4));
   return BNV_OK;
@@ -1504,6 +1757,10 @@ int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;
   if (!strcmp(name, "lattice_h64")) {
     g_lattice_h64 = value;
+    return BNV_OK;
+  }
+  if (!strcmp(name, "lattice_pipe")) {
+    g_lattice_pipe = value;
     return BNV_OK;
   }
   return BNV_ERR_INVALID_ARGUMENT;
