@@ -19,6 +19,7 @@ SYMBOLS = [
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_decode_pts_backward",
+    "bnv_mc_count", "bnv_mc_emit",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
 
@@ -89,6 +90,8 @@ def load():
         "bnv_sdfmlp_bwd_pack_floats": (sz, []),
         "bnv_decode_pts_backward": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, vp, i64,
                                               C.c_int, vp, vp, vp]),
+        "bnv_mc_count": (C.c_int, [vp, i64, vp, C.c_float, vp, vp, vp]),
+        "bnv_mc_emit": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp, vp, vp, vp]),
         "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
         "bnv_decode_lattice_count_offset": (sz, [i64]),
         "bnv_decode_lattice_table_offset": (sz, [i64]),

@@ -161,4 +161,22 @@ class NeuralMap:
         """run_e2e.py:164-167 up to (not including) marching cubes."""
         self.volume.to_tensor()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
-        return self.volume.meshlize(self.pointnet.nerf, delta)
+        return self.volume.meshlize_sdf(self.pointnet.nerf, delta)
+
+    def extract_mesh(self, path=None):
+        """run_e2e.py:164-167: mesh of the whole volume (TSDF prior included when enabled) -> TriMesh or None."""
+        delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
+        self.volume.to_tensor()
+        out = self.volume.meshlize(self.pointnet.nerf, delta, path)
+        return None if out is None else out[1]
+
+    def save(self, working_dir, scan_id="scan"):
+        """run_e2e.py:188-194: the TSDF volume as <scan_id>.npy (metres) and the feature volume as
+        final_sparse_volume.pth (sparse_volume.py:835-860)."""
+        import os
+        import numpy as np
+        if self.tsdf_vol is not None:
+            tsdf, _ = self.tsdf_vol.get_volume()
+            np.save(os.path.join(working_dir, scan_id + ".npy"), tsdf * (self.tsdf_voxel_size * 5))
+        self.volume.to_tensor()
+        self.volume.save(os.path.join(working_dir, "final"))

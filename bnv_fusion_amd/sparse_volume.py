@@ -351,15 +351,29 @@ class SparseVolume:
         return self._lattice_ws[off + 4: off + 8].view(torch.int32)
 
     def meshlize(self, nerf, sdf_delta=None, path=None):
-        """sparse_volume.py:697-766.  The SDF lattice is decoded on the GPU; the per-voxel marching
-        cubes + trimesh assembly of the reference (skimage / trimesh) is outside this path
-        (SURVEY.md section 8 f-4): returns (active_pts, sdf [M, 3, 3, 3]) instead of a trimesh."""
+        """sparse_volume.py:697-766: decode the 3x3x3 lattice of every active voxel and run per-voxel
+        marching cubes -- both on the GPU.  Returns (active_pts, mesh) like the reference (None when no
+        voxel straddles the surface); ``mesh`` is a bnv_fusion_amd.mesh.TriMesh (vertices / faces /
+        export), standing in for trimesh.Trimesh(process=False)."""
+        from .mesh import TriMesh, marching_cubes_lattice
+        assert self.active_coordinates is not None, "call self.to_tensor() first."
+        active_pts = self.active_coordinates * self.voxel_size + self.min_coords
+        sdf = self.decode_lattice(self.active_coordinates, nerf, sdf_delta, query_tensor=True)
+        verts, faces = marching_cubes_lattice(sdf, self.active_coordinates, self.voxel_size, self.min_coords)
+        if faces.shape[0] == 0:
+            return None
+        mesh = TriMesh(verts.cpu().numpy(), faces.cpu().numpy())
+        if path is not None:
+            mesh.export(path)
+        return active_pts.detach().cpu().numpy(), mesh
+
+    def meshlize_sdf(self, nerf, sdf_delta=None):
+        """The decode half of meshlize only: (active_pts, sdf [M, 3, 3, 3]) on the device."""
         assert self.active_coordinates is not None, "call self.to_tensor() first."
         active_pts = self.active_coordinates * self.voxel_size + self.min_coords
         sdf = self.decode_lattice(self.active_coordinates, nerf, sdf_delta, query_tensor=True)
         return active_pts, sdf.reshape(-1, 3, 3, 3)
 
-    # ---- persistence (sparse_volume.py:835-892) ----------------------------------------------------
     def save(self, path):
         self.print_statistic()
         n = self._snapshot_rows
@@ -456,7 +470,9 @@ class VolumeList:
         return c, sdf.reshape(-1, 3, 3, 3)
 
     def meshlize(self, nerf, sdf_delta=None, volume_resolution=None, path=None):
-        return self.fine_volume.meshlize(nerf, sdf_delta[0] if sdf_delta is not None else None, path)
+        """sparse_volume.py:1034-1121 -> trimesh-like mesh (the reference drops active_pts here)."""
+        out = self.fine_volume.meshlize(nerf, sdf_delta[0] if sdf_delta is not None else None, path)
+        return None if out is None else out[1]
 
     def save(self, path):
         self.fine_volume.save(path + "_fine")

@@ -225,6 +225,22 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid
                             int64_t n, int is_coords, const float* grad_sdf, float* grad_features,
                             bnv_stream_t stream);
 
+/* ---- per-voxel marching cubes on decoded lattices -------------------------------------------- */
+
+/* SparseVolume.meshlize after the decode (sparse_volume.py:740-756): for every voxel whose 3x3x3
+ * lattice sdf [n, 27] straddles `level` (max > level and min < level) the 8 cells are triangulated;
+ * vertex = level crossing of a lattice edge (linear), in world units:
+ * ((index + t) * 0.5 + origin - 0.5) * voxel_size + min_coords.  tri_table: int8 [256, 16] edge triples,
+ * -1 terminated (bnv_fusion_amd/mc_tables.py; scikit-image's Lewiner tables are not available here, so
+ * the triangulation inside ambiguous cells is that table's).  Two passes: bnv_mc_count writes the
+ * triangle count of every voxel; the caller prefix-sums them (exclusive, int64) and sizes `vertices`
+ * [3 T, 3] f32; bnv_mc_emit writes the triangle soup in voxel / cell / table order. */
+int bnv_mc_count(const float* sdf, int64_t n, const int32_t* n_dev, float level, const int8_t* tri_table,
+                 int32_t* counts, bnv_stream_t stream);
+int bnv_mc_emit(const float* sdf, const int64_t* origins, int64_t n, const int32_t* n_dev, float level,
+                float voxel_size, const float min_coords[3], const int8_t* tri_table,
+                const int64_t* tri_offsets, float* vertices, bnv_stream_t stream);
+
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
 /* Byte offset, inside that workspace, of two int32 device counters: [0] rows listed by
  * bnv_lattice_neighbors(build_list), [1] table entries (= MLP evaluations) listed by bnv_lattice_mark /

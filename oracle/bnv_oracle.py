@@ -581,6 +581,103 @@ def calculate_loss(volume, rays, sd, truncated_units, truncated_dist, ray_max_di
     return {"depth_bce_loss": sdf_ray_loss(rays, pred, pts, centre, n_valid, truncated_dist)}, pts
 
 
+# --------------------------------------------------------------------------- #
+# per-voxel marching cubes.  PARITY UNPINNED: the reference calls
+# skimage.measure.marching_cubes (scikit-image 0.18.3, Lewiner et al. 2003) on every active voxel's 3x3x3
+# lattice (sparse_volume.py:740-751); scikit-image is absent here and its 33-case tables cannot be restated
+# from memory.  What every marching-cubes variant shares is restated: one vertex per sign-changing lattice
+# edge at the linear-interpolation point, triangles spanning exactly those vertices inside each cell, the
+# per-voxel gate ``max > level and min < level``, and the coordinate chain of :749-756.  The triangulation of
+# a cell (which vertices are joined) follows the face rule documented in bnv_fusion_amd/mc_tables.py and
+# may differ from Lewiner's in ambiguous configurations.
+# --------------------------------------------------------------------------- #
+_MC_CORNERS = [((c >> 2) & 1, (c >> 1) & 1, c & 1) for c in range(8)]
+_MC_EDGES = [(a, b) for a in range(8) for b in range(a + 1, 8) if bin(a ^ b).count("1") == 1]
+
+
+def _mc_cell_loops(inside):
+    """Closed loops of crossed edges of one cube: per face join crossed edges pairwise (4 crossed: around
+    each inside corner), then walk the resulting degree-2 graph."""
+    eid = {e: i for i, e in enumerate(_MC_EDGES)}
+    link = {}
+    for axis in range(3):
+        for side in (0, 1):
+            ring = []
+            for du, dv in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = [du, dv]
+                p.insert(axis, side)
+                ring.append(4 * p[0] + 2 * p[1] + p[2])
+            fe = [eid[tuple(sorted((ring[k], ring[(k + 1) % 4])))] for k in range(4)]
+            cr = [k for k in range(4) if inside[ring[k]] != inside[ring[(k + 1) % 4]]]
+            if len(cr) == 2:
+                segs = [(fe[cr[0]], fe[cr[1]])]
+            elif len(cr) == 4:
+                segs = [(fe[k - 1], fe[k]) for k in range(4) if inside[ring[k]]]
+            else:
+                segs = []
+            for a, b in segs:
+                link.setdefault(a, []).append(b)
+                link.setdefault(b, []).append(a)
+    loops, todo = [], set(link)
+    while todo:
+        start = min(todo)
+        loop, prev, cur = [start], -1, start
+        todo.discard(start)
+        while True:
+            cand = [n for n in link[cur] if n != prev] or link[cur]
+            n = cand[0]
+            if n == start:
+                break
+            loop.append(n)
+            todo.discard(n)
+            prev, cur = cur, n
+        loops.append(loop)
+    return loops
+
+
+def marching_cubes_voxels(sdf, origins, voxel_size, min_coords, level=0.0):
+    """sdf [n, 3, 3, 3] (lattice {-.5, 0, .5}^3 of every voxel), origins [n, 3] int -> (vertices [3T, 3]
+    float32 world coordinates, faces [T, 3]) as a triangle soup, voxels / cells / loops in order."""
+    sdf = np.asarray(sdf, dtype=np.float32)
+    origins = np.asarray(origins)
+    mn = np.asarray(min_coords, dtype=np.float32)
+    verts = []
+    for v in range(len(sdf)):
+        s = sdf[v]
+        if not (s.max() > level and s.min() < level):            # sparse_volume.py:742
+            continue
+        for cx in range(2):
+            for cy in range(2):
+                for cz in range(2):
+                    val = [s[cx + dx, cy + dy, cz + dz] for dx, dy, dz in _MC_CORNERS]
+                    inside = [x < level for x in val]
+                    if all(inside) or not any(inside):
+                        continue
+                    pos = {}
+                    for e, (a, b) in enumerate(_MC_EDGES):
+                        if inside[a] != inside[b]:
+                            t = np.float32(level - val[a]) / np.float32(val[b] - val[a])
+                            pa = np.array(_MC_CORNERS[a], np.float32) + np.array([cx, cy, cz], np.float32)
+                            pb = np.array(_MC_CORNERS[b], np.float32) + np.array([cx, cy, cz], np.float32)
+                            p = (pa + t * (pb - pa)) * np.float32(0.5)            # spacing 0.5 (:719)
+                            p = p + (origins[v].astype(np.float32) - np.float32(0.5))   # :749
+                            pos[e] = p * np.float32(voxel_size) + mn              # :756
+                    for loop in _mc_cell_loops(inside):
+                        mid = {e: (np.array(_MC_CORNERS[_MC_EDGES[e][0]], float)
+                                   + np.array(_MC_CORNERS[_MC_EDGES[e][1]], float)) / 2 for e in loop}
+                        nrm = sum(np.cross(mid[loop[k]], mid[loop[(k + 1) % len(loop)]]) for k in range(len(loop)))
+                        g = sum((np.array(_MC_CORNERS[_MC_EDGES[e][1]], float) - np.array(_MC_CORNERS[_MC_EDGES[e][0]], float))
+                                * (1 if inside[_MC_EDGES[e][0]] else -1) for e in loop)
+                        if np.dot(nrm, g) < 0:
+                            loop = loop[::-1]
+                        for k in range(1, len(loop) - 1):
+                            verts += [pos[loop[0]], pos[loop[k]], pos[loop[k + 1]]]
+    if not verts:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64)
+    verts = np.stack(verts).astype(np.float32)
+    return verts, np.arange(len(verts), dtype=np.int64).reshape(-1, 3)
+
+
 def synthetic_depth(t, H=480, W=640, seed=0):
     """depth(u,v) = 1.5 + 0.2 sin(u/40) cos(v/30) + N(0, 0.002) m,
     quantised to uint16 millimetres as the datasets store it (common.py:93)."""

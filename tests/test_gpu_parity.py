@@ -458,7 +458,7 @@ def test_tsdf_integrate_vs_oracle(bnv, orc):
     assert sd.shape == (1, 1) + tuple(vol._vol_dim) and float(sd.abs().max()) <= 0.025 + 1e-7
 
 
-def test_neural_map_depth_frames_with_tsdf_prior(bnv):
+def test_neural_map_depth_frames_with_tsdf_prior(bnv, tmp_path):
     """The run_e2e.py loop shape on depth frames: front end + encode + _integrate + TSDF, then
     extract_sdf with the TSDF prior as sdf_delta (run_e2e.py:164-186)."""
     from bnv_fusion_amd import synthetic
@@ -477,6 +477,15 @@ def test_neural_map_depth_frames_with_tsdf_prior(bnv):
     delta = nm.prepare_tsdf_volume()
     assert delta.shape[:2] == (1, 1) and float(delta.abs().max()) <= nm.truncated_dist + 1e-7
     assert (sdf.reshape(-1, 27) - plain).abs().max() <= nm.truncated_dist + 1e-6   # prior adds at most trunc
+    # run_e2e.py:164-167, 188-194: mesh of the map and the on-disk artefacts the reference's refiner reads
+    mesh = nm.extract_mesh(path=str(tmp_path / "final.ply"))
+    assert mesh is not None and len(mesh.faces) > 1000 and np.isfinite(mesh.vertices).all()
+    nm.save(str(tmp_path), scan_id="scene0")
+    t = np.load(tmp_path / "scene0.npy")
+    assert t.shape == tuple(nm.tsdf_vol.tsdf.shape) and abs(t).max() <= 0.025 * 5 + 1e-6
+    v2 = bnv.SparseVolume(8, voxel, np.array([dims] * 3), 8, device=DEV)
+    v2.load(str(tmp_path / "final_sparse_volume.pth"))
+    assert torch.equal(v2.active_coordinates, nm.volume.active_coordinates)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -669,3 +678,62 @@ def test_frame_parallel_record_path_equals_neural_map(bnv):
     assert fp.volume.num_rows() == ref_nm.volume.num_rows()
     assert torch.equal(fp.backend.tsdf_vol.tsdf, ref_nm.tsdf_vol.tsdf)
     assert np.allclose(fp.volume.n_pts_list, ref_nm.volume.n_pts_list)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-voxel marching cubes.  PARITY UNPINNED against scikit-image (absent): checked
+# against the oracle's table-free mesher and against properties every marching-cubes variant shares.
+# ---------------------------------------------------------------------------------------------
+def test_marching_cubes_vs_oracle_and_properties(bnv, model, golden_volume, orc):
+    from bnv_fusion_amd.mesh import marching_cubes_lattice
+    vol = golden_volume
+    # (1) the decoded lattices of the golden volume: identical triangle soup to the oracle's mesher
+    coords = vol.active_coordinates
+    sdf = vol.decode_lattice(coords, model.nerf, None, query_tensor=True)
+    verts, faces = marching_cubes_lattice(sdf, coords, vol.voxel_size, vol.min_coords)
+    ref_v, ref_f = orc.marching_cubes_voxels(sdf.cpu().numpy().reshape(-1, 3, 3, 3), coords.cpu().numpy(),
+                                             vol.voxel_size, vol.min_coords.cpu().numpy())
+    assert faces.shape[0] > 500 and tuple(verts.shape) == ref_v.shape
+    assert np.array_equal(faces.cpu().numpy(), ref_f)
+    assert np.abs(verts.cpu().numpy() - ref_v).max() <= 1e-6
+    # (2) every vertex is the level crossing of a lattice edge of its voxel
+    v = (verts.cpu().numpy().astype(np.float64) - vol.min_coords.cpu().numpy()) / vol.voxel_size
+    on_grid = np.isclose(v * 2, np.round(v * 2), atol=1e-3).sum(1)
+    assert (on_grid >= 2).all()                                       # two coordinates lie on the half-voxel grid
+    # (3) a sphere: closed, consistently oriented, right area, normals towards sdf > 0
+    R, c = 3.3, torch.tensor([6.2, 6.1, 5.9])
+    o = torch.stack(torch.meshgrid(*[torch.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    r = torch.arange(3) * 0.5 - 0.5
+    lat = torch.stack(torch.meshgrid(r, r, r, indexing="ij"), -1)
+    s = ((o[:, None, None, None, :] + lat[None] - c).norm(dim=-1) - R).float()
+    sv, sf = marching_cubes_lattice(s.to(DEV), o.to(DEV), 1.0, torch.zeros(3))
+    tri = sv.cpu().numpy().reshape(-1, 3, 3).astype(np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1).sum()
+    assert abs(area - 4 * np.pi * R * R) < 0.02 * 4 * np.pi * R * R
+    q = np.round(tri.reshape(-1, 3) * 4096).astype(np.int64)
+    _, inv = np.unique((q[:, 0] << 42) + (q[:, 1] << 21) + q[:, 2], return_inverse=True)
+    f = inv.reshape(-1, 3)
+    edges = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    fwd = {tuple(e) for e in edges.tolist()}
+    assert len(fwd) == len(edges) and all((b, a) in fwd for a, b in fwd)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert (np.einsum("ij,ij->i", nrm, tri.mean(1) - c.numpy()) > 0).all()
+    # (4) nothing to mesh -> empty; meshlize end to end + PLY export
+    e_v, e_f = marching_cubes_lattice(torch.full((4, 27), 0.02, device=DEV), o[:4].to(DEV), 1.0, torch.zeros(3))
+    assert e_v.shape == (0, 3) and e_f.shape == (0, 3)
+
+
+def test_meshlize_returns_mesh_like_the_reference(bnv, model, golden_volume, tmp_path):
+    vol = golden_volume
+    out = vol.meshlize(model.nerf, None, path=str(tmp_path / "m.ply"))
+    assert out is not None
+    active_pts, mesh = out
+    assert active_pts.shape == (vol.active_coordinates.shape[0], 3)
+    assert mesh.faces.shape[1] == 3 and mesh.vertices.shape[0] == 3 * mesh.faces.shape[0]
+    lo, hi = vol.min_coords.cpu().numpy(), vol.max_coords.cpu().numpy()
+    assert (mesh.vertices >= lo - 1e-5).all() and (mesh.vertices <= hi + vol.voxel_size).all()
+    data = open(tmp_path / "m.ply", "rb").read()
+    assert data.startswith(b"ply\nformat binary_little_endian 1.0\n")
+    n_before = len(mesh.vertices)
+    mesh.merge_vertices()
+    assert len(mesh.vertices) < n_before and mesh.faces.max() == len(mesh.vertices) - 1
