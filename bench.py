@@ -337,10 +337,10 @@ def main():
             # dominant kernel: the lattice-table SDF MLP.  achieved = algorithmic FLOPs (402,432 per MLP
             # evaluation x evaluations per launch; the split mode issues 3 MFMA products per algorithmic
             # product, which are NOT counted) / mean kernel time from HIP events on the launch stream
-            "roofline": {"bound": "mfma", "kernel": f"k_decode<LATTICE,{MODE_NAME[m]}> (SDF MLP 17-256x4-1)",
+            "roofline": {"bound": "mfma", "kernel": ("k_lattice_table_h" if m == 1 else f"k_decode<LATTICE,{MODE_NAME[m]}>") + " (SDF MLP 17-256x4-1)",
                          "achieved": main_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": main_run["dec_tflops"] / peak,
-                         "traffic": pmc_traffic_bytes("k_decode<1, 1>") if (m == 1 and world == 1 and not tcnn) else None,
+                         "traffic": pmc_traffic_bytes("k_lattice_table_h") if (m == 1 and world == 1 and not tcnn) else None,
                          "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv); "
                                          "algorithmic bytes = 40 B x evaluations",
                          "avg_kernel_ms": main_run["dec_ms"], "flop_per_launch": main_run["dec_flop"],
