@@ -410,6 +410,7 @@ constexpr int ST_W1 = ST_W0 + 2 * 2 * 64 * 8;
 constexpr int ST_W2 = ST_W1 + 2 * 4 * 64 * 8;
 constexpr int ST_W3 = ST_W2 + 2 * 4 * 64 * 8;
 constexpr int ST_TOTAL = ST_W3 + 4 * 64 * 8;  // 12,288 halves
+static_assert(ST_TOTAL == 12288, "tcnn SDF pack size (weights.py: pack_sdf_tcnn)");
 
 __device__ __forceinline__ half8 relu_half8(const f32x16& v, int base) {
   half8 r;
@@ -1657,6 +1658,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   out[t] = o;
 }
 
+extern int g_encoder_overlap;  // encode.hip
 int g_lattice_h64 = 0;  // 1: 64-evaluation tiles, 2 workgroups per CU (bnv_set_option); measured 4 % slower
 int g_lattice_pipe = 1; // 1: k_lattice_table_h (cross-tile / cross-layer pipelined); 0: k_decode<LATTICE, 1>
 
@@ -1761,6 +1763,10 @@ int bnv_set_option(const char* name, int value) {
   }
   if (!strcmp(name, "lattice_pipe")) {
     g_lattice_pipe = value;
+    return BNV_OK;
+  }
+  if (!strcmp(name, "encoder_overlap")) {
+    g_encoder_overlap = value;
     return BNV_OK;
   }
   return BNV_ERR_INVALID_ARGUMENT;
