@@ -990,6 +990,198 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_decode_pts_bwd_t: the same backward for the tiny-cuda-nn decoder (MLP mode 2; the reference's default
+// checkpoint).  32 | 64 | 64 | 64 | 16, no bias, f16 operands, fp32 accumulate: one wave carries 32
+// evaluations forward and backward in registers (waves 0..3 of the workgroup; no barriers inside).
+// PARITY UNPINNED like the forward (tcnn's CUDA arithmetic cannot run here).  tcnn back-propagates in fp16
+// with a loss scale; here the Jacobian d(alpha)/d(input) is propagated with a unit seed (f16 operands O(1),
+// fp32 accumulation) and multiplied by the incoming gradient in fp32, which cannot underflow.
+// Pack (halves): W2^T [2 mb][4 g][64][8] | W1^T [2 mb][4 g][64][8] | W0^T [4 g][64][8] | 128 halves holding
+// row 0 of the output layer as 64 floats.
+// ---------------------------------------------------------------------------------------------------
+constexpr int TB_W2T = 0;
+constexpr int TB_W1T = TB_W2T + 2 * 4 * 64 * 8;
+constexpr int TB_W0T = TB_W1T + 2 * 4 * 64 * 8;
+constexpr int TB_W3R = TB_W0T + 4 * 64 * 8;   // 64 floats
+constexpr int TB_TOTAL = TB_W3R + 128;        // 10,368 halves = 5,184 floats
+
+__device__ __forceinline__ uint32_t positive_bits32(const f32x16 (&a)[2]) {
+  uint32_t m = 0u;
+#pragma unroll
+  for (int mb = 1; mb >= 0; --mb) {
+#pragma unroll
+    for (int r = 15; r >= 0; --r) m = (m << 1) | (uint32_t)(a[mb][r] > 0.f);
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(512, 2) void k_decode_pts_bwd_t(DecodeBwdArgs B) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DecodeArgs& A = B.d;
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int* l_row = (int*)(lds + L_DELTA);
+  const int64_t n_tiles = (A.n + 15) / 16;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (threadIdx.x < DM) {
+      const int e = threadIdx.x;
+      float loc[3] = {0.f, 0.f, 0.f};
+      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float wtri = 0.f, wvol = 0.f;
+      int row = -1;
+      const int64_t q = tile * 16 + (e >> 3);
+      const int cb = kCornerCeilBits[e & 7];
+      if (q < A.n) {
+        float c[3], corner[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          c[a] = A.coords[q * 3 + a];
+          if (!A.is_coords) c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
+          corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
+          loc[a] = __fsub_rn(c[a], corner[a]);
+        }
+        wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
+        uint64_t key;
+        if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
+          row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
+        if (row >= A.row_limit) row = -1;
+        if (row >= 0) {
+          const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+          const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+          for (int f = 0; f < 4; ++f) {
+            feat[f] = f0[f];
+            feat[4 + f] = f1[f];
+          }
+          wvol = A.weights[row];
+        }
+      }
+      stage_input_t(lds, e, loc, feat);
+      lds[L_WTRI + e] = wtri;
+      lds[L_WVOL + e] = wvol;
+      l_row[e] = row;
+    }
+    __syncthreads();
+    float go = 0.f;
+    if (threadIdx.x < DM) {
+      const int e = threadIdx.x;
+      const int64_t q = tile * 16 + (e >> 3);
+      if (q < A.n) {
+        const int b = e & ~7;
+        float norm = 0.f, wmin = 3.4e38f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          norm = __fadd_rn(norm, lds[L_WTRI + b + k]);
+          wmin = fminf(wmin, lds[L_WVOL + b + k]);
+        }
+        if (wmin >= (float)A.grid.min_pts_in_grid)
+          go = B.grad_out[q] * voxel * __fdiv_rn(lds[L_WTRI + e], norm);
+      }
+      lds[L_ALPHA + e] = go;
+    }
+    if (!__syncthreads_or(go != 0.f)) continue;
+    if (w < 4) {
+      const _Float16* ph = (const _Float16*)A.pack;
+      const _Float16* pb = (const _Float16*)B.bwd_pack;
+      const int col = w * 32 + j;
+      // ---- forward, keeping the sign bits of the three hidden pre-activations -------------------------
+      f32x16 a0[2], a1[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a0[mb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const half8 b = *(const half8*)&lds[L_HL + ((ks * 2 + h) * DM + col) * 4];
+          a0[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&ph[ST_W0 + ((mb * 2 + ks) * 64 + lane) * 8],
+                                                          b, a0[mb], 0, 0, 0);
+        }
+      }
+      half8 s[4];
+      auto fill_relu = [&](const f32x16 (&in)[2]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          s[nb * 2] = relu_half8(in[nb], 0);
+          s[nb * 2 + 1] = relu_half8(in[nb], 8);
+        }
+      };
+      auto fill_masked = [&](const f32x16 (&in)[2], uint32_t m) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+          for (int ksl = 0; ksl < 2; ++ksl) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              s[nb * 2 + ksl][e] = (_Float16)(((m >> (nb * 16 + ksl * 8 + e)) & 1u) ? in[nb][ksl * 8 + e] : 0.f);
+          }
+        }
+      };
+      auto layer64 = [&](const _Float16* wp, f32x16 (&out)[2]) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[mb][r] = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wp[((mb * 4 + g) * 64 + lane) * 8], s[g],
+                                                            out[mb], 0, 0, 0);
+        }
+      };
+      const uint32_t m0 = positive_bits32(a0);
+      fill_relu(a0);
+      layer64(ph + ST_W1, a1);
+      const uint32_t m1 = positive_bits32(a1);
+      fill_relu(a1);
+      layer64(ph + ST_W2, a0);
+      const uint32_t m2 = positive_bits32(a0);
+      // ---- backward with a unit seed: delta_2 = W3[0, :] * [z2 > 0] ------------------------------------
+      {
+        const float* w3r = (const float*)(pb + TB_W3R);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 t = *(const f32x4*)&w3r[mb * 32 + 8 * qd + 4 * h];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a0[mb][4 * qd + i] = t[i];
+          }
+        }
+      }
+      fill_masked(a0, m2);
+      layer64(pb + TB_W2T, a1);
+      fill_masked(a1, m1);
+      layer64(pb + TB_W1T, a0);
+      fill_masked(a0, m0);
+      f32x16 g;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        g = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&pb[TB_W0T + (gq * 64 + lane) * 8], s[gq], g, 0, 0, 0);
+      const float sc = lds[L_ALPHA + col];
+      const int row = l_row[col];
+      if (sc != 0.f && row >= 0) {
+        float* gf = B.grad_features + (size_t)row * 8;
+        if (h == 0) {
+          unsafeAtomicAdd(gf + 0, g[5] * sc);
+          unsafeAtomicAdd(gf + 1, g[6] * sc);
+          unsafeAtomicAdd(gf + 2, g[7] * sc);
+          unsafeAtomicAdd(gf + 7, g[8] * sc);
+        } else {
+          unsafeAtomicAdd(gf + 3, g[4] * sc);
+          unsafeAtomicAdd(gf + 4, g[5] * sc);
+          unsafeAtomicAdd(gf + 5, g[6] * sc);
+          unsafeAtomicAdd(gf + 6, g[7] * sc);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_lattice_table_h: the hot kernel (lattice table, split-operand mode), software-pipelined ACROSS tiles
 // and layers.  Same arithmetic as k_decode<LATTICE, 1> (bit-identical tables); what changes is when
 // things are fetched (tools/phase_prof.py showed 5 % of a tile in the gather/stage front end, ~600 idle
@@ -1739,6 +1931,8 @@ int bnv_decode_init() {
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd_t, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    L_TOTAL * 4));
   return BNV_OK;
 }
 
@@ -1794,7 +1988,7 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
   return launch_decode(MODE_PTS, a, (n + 15) / 16, (hipStream_t)stream);
 }
 
-size_t bnv_sdfmlp_bwd_pack_floats(void) { return SB_PACK_FLOATS; }
+size_t bnv_sdfmlp_bwd_pack_floats(void) { return g_mlp_mode == 2 ? (size_t)(TB_TOTAL / 2) : (size_t)SB_PACK_FLOATS; }
 
 int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
                             const float* weights, int64_t row_limit, const float* sdfmlp_pack,
@@ -1803,7 +1997,6 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0)
     return BNV_ERR_INVALID_ARGUMENT;
-  if (g_mlp_mode == 2) return BNV_ERR_INVALID_ARGUMENT;  // fp32 decoder only
   if (n == 0) return BNV_OK;
   if (!coords || !grad_sdf || !grad_features) return BNV_ERR_INVALID_ARGUMENT;
   DecodeBwdArgs b = {};
@@ -1822,7 +2015,10 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
   int64_t nblk = (n + 15) / 16;
   if (nblk > g_num_cus) nblk = g_num_cus;
   ProfScope prof(PROF_DECODE_PTS, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
+  if (g_mlp_mode == 2)
+    hipLaunchKernelGGL(k_decode_pts_bwd_t, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
+  else
+    hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

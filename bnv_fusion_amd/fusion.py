@@ -94,9 +94,12 @@ class TcnnNeRFModel(nn.Module):
         super().__init__()
         self.model = _TcnnParams(64 * 32 + 64 * 64 * 2 + 16 * 64)
         self.register_buffer("sdf_pack", torch.zeros(12288 // 2), persistent=False)
+        self.register_buffer("sdf_bwd_pack", torch.zeros(5184), persistent=False)   # transposed layers (backward)
 
     def repack(self):
-        self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn(self.model.params.detach().cpu().numpy())))
+        p = self.model.params.detach().cpu().numpy()
+        self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn(p)))
+        self.sdf_bwd_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn_bwd(p)))
 
     xyz_encoding = staticmethod(LocalNeRFModel.xyz_encoding)
 

@@ -233,3 +233,28 @@ def pack_pointnet_tcnn(params):
 def pack_sdf_tcnn(params):
     """tcnnNeRFModel (modules.py:136-253): 32 | 64 | 64 | 64 | 16 -> ST_* layout of csrc/decode.hip."""
     return _pack_tcnn(_split_tcnn(params, 32))
+
+
+def pack_sdf_tcnn_bwd(params):
+    """Transposed layers of the tcnn SDF decoder for bnv_decode_pts_backward in MLP mode 2 -> float32 [5184]
+    (TB_* layout of csrc/decode.hip): W2^T, W1^T as hidden-layer packs, W0^T as an output-layer pack (32 rows =
+    the padded inputs), then row 0 of the output layer as 64 floats."""
+    W0, W1, W2, W3 = _split_tcnn(params, 32)
+    h16 = lambda W: W.astype(np.float16).astype(np.float32)     # the forward multiplies fp16 weights
+    lane = np.arange(64)
+    n, h = lane & 31, lane >> 5
+    sf = _slot_feature(np.arange(8)[None, :], h[:, None])
+    out = []
+    for W in (h16(W2).T, h16(W1).T):
+        o = np.zeros((2, 4, 64, 8), np.float16)
+        for mb in range(2):
+            for g in range(4):
+                o[mb, g] = W[(mb * 32 + n)[:, None], (g >> 1) * 32 + 16 * (g & 1) + sf]
+        out.append(o.ravel())
+    Wt = h16(W0).T                                                # [32, 64]
+    o = np.zeros((4, 64, 8), np.float16)
+    for g in range(4):
+        o[g] = Wt[n[:, None], (g >> 1) * 32 + 16 * (g & 1) + sf]
+    out.append(o.ravel())
+    halves = np.concatenate(out).view(np.float32)
+    return np.concatenate([halves, h16(W3)[0].astype(np.float32)])

@@ -217,7 +217,8 @@ int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, co
  * (sparse_volume.py:768-833).  grad_sdf [n] = d loss / d out_sdf; grad_features [row_limit, 8] is
  * ACCUMULATED into (the caller zeroes it).  The decoder weights are frozen and the points are data, so
  * nothing else receives gradient; sdf_delta is additive and does not enter.  sdfmlp_bwd_pack holds the
- * transposed layers (bnv_sdfmlp_bwd_pack_floats(); weights.py: pack_sdf_mlp_bwd).  fp32 decoder only. */
+ * transposed layers (bnv_sdfmlp_bwd_pack_floats() for the current MLP mode; weights.py: pack_sdf_mlp_bwd for
+ * the fp32 decoder, pack_sdf_tcnn_bwd for the tiny-cuda-nn decoder of MLP mode 2). */
 size_t bnv_sdfmlp_bwd_pack_floats(void);
 int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
                             const float* features, const float* weights, int64_t row_limit,

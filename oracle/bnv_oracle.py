@@ -389,13 +389,17 @@ def decode_feature_grid_w_pts(sd, voxel_coords, feat_grid, pts_weight, voxel_siz
 # --------------------------------------------------------------------------- #
 
 
-def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True):
+def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True, ste=False):
     """tiny-cuda-nn FullyFusedMLP restated: identity encoding pads the input to a multiple of 16
     with 1.0; ``n_hidden`` hidden layers of ``width`` with ReLU, no bias, output padded to 16;
     weights row-major [out, in] in one flat vector (call sites
     pointnet_utils.py:274-279, modules.py:171-176).  ``half`` rounds weights, inputs and every
     layer output to fp16 as the CUDA kernel stores them (fp32 accumulate)."""
     q = (lambda t: t.half().float()) if half else (lambda t: t)
+    if half and ste:
+        # for gradient checks: the fp16 rounding counts as identity in the backward pass (what autograd does
+        # for a dtype cast) WITHOUT rounding the gradient itself to fp16
+        q = lambda t: t + (t.half().float() - t).detach()
     n = x.shape[0]
     pad = torch.ones((n, n_in_padded - x.shape[1]), dtype=x.dtype)
     h = q(torch.cat([x, pad], dim=1))
@@ -416,11 +420,11 @@ def tcnn_point_encoder(params):
     return lambda x: tcnn_mlp(params, x[0].t(), 16, 8).t()[None]
 
 
-def tcnn_geo_forward(params):
+def tcnn_geo_forward(params, ste=False):
     """tcnnNeRFModel.geo_forward, modules.py:249-253: [..., 17] -> [..., 1]."""
     def f(x):
         shp = list(x.shape)
-        return tcnn_mlp(params, x.reshape(-1, shp[-1]), 32, 1).reshape(shp[:-1] + [1])
+        return tcnn_mlp(params, x.reshape(-1, shp[-1]), 32, 1, ste=ste).reshape(shp[:-1] + [1])
     return f
 
 

@@ -177,3 +177,62 @@ def test_neural_map_optimize_reduces_ray_loss(bnv):
     assert not vol.features.requires_grad and float((vol.features - f0).abs().max()) > 1e-4
     fq, _, _ = vol.query(vol.active_coordinates[:1000])
     assert torch.equal(fq, vol.features[:1000])                       # run_e2e.py:158-162 write-back
+
+
+def test_tcnn_decoder_backward_vs_oracle_autograd():
+    """decode_pts backward with the reference's default (tiny-cuda-nn, fp16) decoder: MLP mode 2.  PARITY
+    UNPINNED like the tcnn forward; checked against torch autograd through the oracle's fp16 restatement of the
+    FullyFusedMLP (rounding treated as identity in the backward pass), at fp16-level tolerance."""
+    import bnv_fusion_amd as bnv
+    from conftest import WEIGHTS_TCNN
+    from oracle import bnv_oracle as orc
+    model = bnv.load_pretrained(device=DEV, voxel_size=0.02, tiny_cuda=True)
+    params = torch.as_tensor(orc.load_weights(WEIGHTS_TCNN)["nerf.model.params"]).float()
+    geo = orc.tcnn_geo_forward(params, ste=True)
+    vol = _insertion_order_volume(bnv)
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    ovol = orc.OracleSparseVolume(8, 0.02, z["dims"], 8)
+    ovol.insert(vol.active_coordinates.cpu(), vol.features.cpu(), vol.weights.cpu(), vol.num_hits.cpu())
+    ovol.to_tensor()
+    g = torch.Generator().manual_seed(8)
+    rows = torch.randint(len(z["keys_insertion"]), (2400,), generator=g)
+    q = (torch.from_numpy(z["keys_insertion"])[rows].float() + (torch.rand(2400, 3, generator=g) - 0.5) * 1.2)
+    q = q.reshape(1, 300, 8, 3)
+    go = torch.randn(1, 300, 8, 1, generator=g)
+    ovol.features.requires_grad_(True)
+    ref_out = ovol.decode_pts(q, None, None, is_coords=True, query_tensor=True, geo=geo)
+    (ref_out * go).sum().backward()
+    try:
+        vol.features = torch.nn.Parameter(vol.features)
+        out = vol.decode_pts(q.to(DEV), model.nerf, None, is_coords=True, query_tensor=True)
+        (out * go.to(DEV)).sum().backward()
+    finally:
+        bnv.set_mlp_mode(1)
+    assert (out.detach().cpu() - ref_out.detach()).abs().max() <= 1e-4
+    ref, got = ovol.features.grad, vol.features.grad.cpu()
+    assert float((ref.abs().sum(-1) > 0).float().mean()) > 0.3
+    assert torch.equal(ref.abs().sum(-1) > 0, got.abs().sum(-1) > 0)
+    assert (got - ref).abs().max() <= 2e-2 * ref.abs().max(), (got - ref).abs().max() / ref.abs().max()
+
+
+def test_neural_map_optimize_runs_with_tcnn_checkpoint():
+    """The reference's default configuration end to end: tcnn encoder/decoder, fuse, a few optimiser steps."""
+    import bnv_fusion_amd as bnv
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    try:
+        model = bnv.load_pretrained(device=DEV, voxel_size=voxel, tiny_cuda=True)
+        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=200000, device=DEV, tsdf=True)
+        for t in range(0, 12, 2):
+            frame = {"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+                     "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)}
+            nm.integrate(frame)
+            nm.frames.append(frame)
+        nm.volume.to_tensor()
+        f0 = nm.volume.features.clone()
+        hist = nm.optimize(n_iters=5, sampling_size=1500, train_ray_splits=1000,
+                           generator=torch.Generator().manual_seed(2))
+        assert len(hist) == 5 and all(torch.isfinite(h) for h in hist)
+        assert float((nm.volume.features - f0).abs().max()) > 1e-5
+    finally:
+        bnv.set_mlp_mode(1)
