@@ -28,11 +28,13 @@ FLOP_PER_PAIR = 2 * (6 * 128 + 128 * 128 + 128 * 128 + 128 * 8)          # 69,12
 FLOP_PER_EVAL = 2 * (17 * 256 + 3 * 256 * 256 + 256)                      # 402,432 SDF MLP
 FLOP_PER_PAIR_TCNN = 2 * (16 * 64 + 2 * 64 * 64 + 64 * 16)                # 20,480  tcnn encoder
 FLOP_PER_EVAL_TCNN = 2 * (32 * 64 + 2 * 64 * 64 + 64 * 16)                # 22,528  tcnn decoder
-PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md: f32-in / f16-in
-MODE_NAME = {0: "fp32_exact", 1: "split_f16", 2: "tcnn_f16"}
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0, 3: 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md: f32-in / f16-in
+MODE_NAME = {0: "fp32_exact", 1: "split_f16", 2: "tcnn_f16", 3: "f16_operands"}
+MFMA_PER_PRODUCT = {0: 1, 1: 3, 2: 1, 3: 1}
 DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
-         2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate"}
+         2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
+         3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_32x32x16_f16, f32 accumulate"}
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -44,7 +46,7 @@ def pmc_traffic_bytes(kernel_substr):
         return None
     fetch = write = None
     for line in open(path):
-        if kernel_substr in line:
+        if kernel_substr in line and "k_lattice_table_h<1>" not in line:
             parts = line.strip().rsplit(",", 3)
             if parts[1] == "FETCH_SIZE":
                 fetch = float(parts[2])
@@ -113,7 +115,7 @@ def main():
                     help="frames fused (untimed setup) before warm-up so that voxel weights reach "
                          "min_pts_in_grid and the decode mask is live (SURVEY.md section 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1],
+    ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1, 3],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"],
@@ -276,23 +278,20 @@ def main():
 
     first = args.preroll + args.warmup
     main_run = timed(args.mlp_mode, first, args.steps, args.warmup)
-    alt = None
-    if not args.no_alt_mode and world == 1:
-        # the other arithmetic mode on a few of the same frames (volume state differs only by those fusions)
-        alt = timed(1 - args.mlp_mode, first, min(args.steps, 8), 1)
-        bnv.set_mlp_mode(args.mlp_mode)
     elapsed = main_run["elapsed"]
 
-    # parity spot check of the timed configuration against the oracle (40 voxels of the last frame)
-    parity = None
-    if (world == 1 or frame_parallel) and rank == 0 and main_run["coords"] is not None:
+    # parity spot check of a configuration against the oracle (40 voxels of its last frame): the SDF decoded by
+    # the GPU from the GPU's own volume vs the oracle's decode of the same volume values
+    def parity_check(run):
+        if not ((world == 1 or frame_parallel) and rank == 0 and run["coords"] is not None):
+            return None
         from oracle import bnv_oracle as orc           # checker only
         sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
         geo = None
         if tcnn:
             geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
                 ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
-        g = main_run["coords"]
+        g = run["coords"]
         pick = g[torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)].cpu()
         off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
         nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
@@ -303,9 +302,22 @@ def main():
         ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
                               geo=geo)[0, :, :, 0]
         got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
-        parity = {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
-                  "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
-                  "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}
+        return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
+                "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
+                "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}
+
+    parity = parity_check(main_run)
+    # the other arithmetic modes of the fp32 checkpoint on a few of the same frames (the volume state differs
+    # only by those fusions), each with its own parity spot check
+    alts = []
+    if not args.no_alt_mode and world == 1 and not tcnn:
+        for am in (0, 1, 3):
+            if am == args.mlp_mode:
+                continue
+            r = timed(am, first, min(args.steps, 8), 1)
+            r["mode"], r["parity"] = am, parity_check(r)
+            alts.append(r)
+        bnv.set_mlp_mode(args.mlp_mode)
 
     if rank == 0:
         fps = args.steps / elapsed
@@ -337,7 +349,7 @@ def main():
             # dominant kernel: the lattice-table SDF MLP.  achieved = algorithmic FLOPs (402,432 per MLP
             # evaluation x evaluations per launch; the split mode issues 3 MFMA products per algorithmic
             # product, which are NOT counted) / mean kernel time from HIP events on the launch stream
-            "roofline": {"bound": "mfma", "kernel": ("k_lattice_table_h" if m == 1 else f"k_decode<LATTICE,{MODE_NAME[m]}>") + " (SDF MLP 17-256x4-1)",
+            "roofline": {"bound": "mfma", "kernel": ("k_lattice_table_h" if m in (1, 3) else f"k_decode<LATTICE,{MODE_NAME[m]}>") + " (SDF MLP 17-256x4-1)",
                          "achieved": main_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
                          "frac": main_run["dec_tflops"] / peak,
                          "traffic": pmc_traffic_bytes("k_lattice_table_h") if (m == 1 and world == 1 and not tcnn) else None,
@@ -345,19 +357,17 @@ def main():
                                          "algorithmic bytes = 40 B x evaluations",
                          "avg_kernel_ms": main_run["dec_ms"], "flop_per_launch": main_run["dec_flop"],
                          "mlp_evals_per_launch": main_run["rows"],
-                         "mfma_issue_frac": main_run["dec_tflops"] * (3 if m == 1 else 1) / peak},
+                         "mfma_issue_frac": main_run["dec_tflops"] * MFMA_PER_PRODUCT[m] / peak},
             "kernels": {"pointnet_scatter": {"avg_ms": main_run["enc_ms"], "tflops": main_run["enc_tflops"],
                                              "frac_of_peak": main_run["enc_tflops"] / peak}},
             "parity": parity,
         }
-        if alt is not None:
-            am = 1 - m
-            out["other_mlp_mode"] = {"mlp_mode": MODE_NAME[am], "dtype": DTYPE[am], "value": alt["fps"],
-                                     "unit": "frames/s", "steps": alt["steps"],
-                                     "ms_per_step": 1e3 * alt["elapsed"] / alt["steps"],
-                                     "decode_kernel_ms": alt["dec_ms"], "decode_tflops": alt["dec_tflops"],
-                                     "decode_frac_of_peak": alt["dec_tflops"] / PEAK_TFLOPS[am],
-                                     "pointnet_kernel_ms": alt["enc_ms"], "pointnet_tflops": alt["enc_tflops"]}
+        out["other_mlp_modes"] = [
+            {"mlp_mode": MODE_NAME[a["mode"]], "dtype": DTYPE[a["mode"]], "value": a["fps"], "unit": "frames/s",
+             "steps": a["steps"], "ms_per_step": 1e3 * a["elapsed"] / a["steps"], "decode_kernel_ms": a["dec_ms"],
+             "decode_tflops": a["dec_tflops"], "decode_frac_of_peak": a["dec_tflops"] / PEAK_TFLOPS[a["mode"]],
+             "pointnet_kernel_ms": a["enc_ms"], "pointnet_tflops": a["enc_tflops"], "parity": a["parity"]}
+            for a in alts]
         if not args.no_cpu_baseline and world == 1 and not tcnn:
             out["cpu_baseline"] = cpu_baseline(depth_host[0], intr, synthetic.pose(0), args.grid)
             out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]

@@ -18,7 +18,7 @@ SYMBOLS = [
     "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_tsdf_integrate", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
-    "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_decode_pts_backward",
+    "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
     "bnv_mc_count", "bnv_mc_emit",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
@@ -88,6 +88,7 @@ def load():
         "bnv_decode_pts": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, C.c_int,
                                      C.POINTER(SdfDelta), vp, vp]),
         "bnv_sdfmlp_bwd_pack_floats": (sz, []),
+        "bnv_sdfmlp_tcnn_bwd_pack_floats": (sz, []),
         "bnv_decode_pts_backward": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, vp, i64,
                                               C.c_int, vp, vp, vp]),
         "bnv_mc_count": (C.c_int, [vp, i64, vp, C.c_float, vp, vp, vp]),

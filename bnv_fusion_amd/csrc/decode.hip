@@ -223,7 +223,8 @@ __device__ __forceinline__ float relu1(float x) { return relu_bits(x); }
 #ifndef BNV_A_AHEAD
 #define BNV_A_AHEAD 2
 #endif
-template <int NKS, bool BIAS = true>
+// NPROD = 3: split operands (al.bh + ah.bl + ah.bh); NPROD = 1: f16 operands (ah.bh only; MLP mode 3)
+template <int NKS, bool BIAS = true, int NPROD = 3>
 __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
                                             const float* __restrict__ lds, f32x16 (&acc)[4], int w, int lane,
                                             int j, int h) {
@@ -243,16 +244,16 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
   // from L2 kAhead steps ahead (register ring), activation fragments from LDS one step ahead
   constexpr int kAhead = BNV_A_AHEAD, kRing = kAhead + 1;
   half8 ah[kRing], al[kRing], bh[2][4], bl[2][4];
-#define BNV_LOAD_A(ks)                                              \
-  {                                                                 \
-    ah[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2) * 64 * 8);     \
-    al[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2 + 1) * 64 * 8); \
+#define BNV_LOAD_A(ks)                                                                  \
+  {                                                                                     \
+    ah[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2) * 64 * 8);                       \
+    if (NPROD == 3) al[(ks) % kRing] = *(const half8*)(wl + ((ks) * 2 + 1) * 64 * 8);   \
   }
 #define BNV_LOAD_B(ks)                                                                    \
   {                                                                                       \
     _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
       bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
-      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
+      if (NPROD == 3) bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4); \
     }                                                                                     \
   }
 #pragma unroll
@@ -263,29 +264,34 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
   for (int ks = 0; ks < NKS; ++ks) {
     if (ks + kAhead < NKS) BNV_LOAD_A(ks + kAhead);
     if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    const half8 a_hi = ah[ks % kRing], a_lo = al[ks % kRing];
+    const half8 a_hi = ah[ks % kRing];
+    if constexpr (NPROD == 3) {
+      const half8 a_lo = al[ks % kRing];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+      for (int pt = 0; pt < 4; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+      for (int pt = 0; pt < 4; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
       acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
     // Issue order inside the step: every prefetch goes into the shadow of an MFMA (one memory instruction
-    // behind each of the first ten MFMAs).  A wave then keeps the MFMA pipe busy on its own; with all ten
-    // loads clustered at the top of the step a lone wave reached only 55-70 % (tools/phase_prof.py).
+    // behind each MFMA).  A wave then keeps the MFMA pipe busy on its own; with all the loads clustered at
+    // the top of the step a lone wave reached only 55-70 % (tools/phase_prof.py).
+    constexpr int kDs = NPROD == 3 ? 8 : 4, kVm = NPROD == 3 ? 2 : 1;
     if (ks + 1 < NKS) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
+      for (int g = 0; g < (NPROD == 3 ? kDs : kDs - 1); ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
       }
+      if (NPROD == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     if (ks + kAhead < NKS) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < kVm; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
       }
@@ -296,6 +302,7 @@ __device__ __forceinline__ void mlp_layer_h(const _Float16* __restrict__ wp, con
 #undef BNV_LOAD_B
 }
 
+template <int NPROD = 3>
 __device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x16 (&acc)[4], int w, int j, int h) {
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) {
@@ -307,46 +314,47 @@ __device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x
         const float x = relu1(acc[pt][8 * ksl + e]);
         const _Float16 t = (_Float16)x;
         hi[e] = t;
-        lo[e] = (_Float16)(x - (float)t);
+        if (NPROD == 3) lo[e] = (_Float16)(x - (float)t);
       }
       const int o = (((2 * w + ksl) * 2 + h) * DM + pt * 32 + j) * 4;
       *(half8*)&lds[L_HL + o] = hi;
-      *(half8*)&lds[L_HLO + o] = lo;
+      if (NPROD == 3) *(half8*)&lds[L_HLO + o] = lo;
     }
   }
 }
 
+template <int NPROD = 3>
 __device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const float* __restrict__ pack) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
   const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
   f32x16 acc[4];
-  mlp_layer_h<2>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
+  mlp_layer_h<2, true, NPROD>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
   BNV_PH(1);
   __syncthreads();
   BNV_PH(2);
-  store_relu_h(lds, acc, w, j, h);
+  store_relu_h<NPROD>(lds, acc, w, j, h);
   BNV_PH(3);
   __syncthreads();
   BNV_PH(4);
-  mlp_layer_h<16>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+  mlp_layer_h<16, true, NPROD>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
   BNV_PH(5);
   __syncthreads();
   BNV_PH(6);
-  store_relu_h(lds, acc, w, j, h);
+  store_relu_h<NPROD>(lds, acc, w, j, h);
   BNV_PH(7);
   __syncthreads();
   BNV_PH(8);
-  mlp_layer_h<16>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+  mlp_layer_h<16, true, NPROD>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
   BNV_PH(9);
   __syncthreads();
   BNV_PH(10);
-  store_relu_h(lds, acc, w, j, h);
+  store_relu_h<NPROD>(lds, acc, w, j, h);
   BNV_PH(11);
   __syncthreads();
   BNV_PH(12);
-  mlp_layer_h<16>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+  mlp_layer_h<16, true, NPROD>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
   BNV_PH(13);
   const f32x16 wa = frag256(pack + SD_WA, w, h);
 #pragma unroll
@@ -370,6 +378,7 @@ __device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const fl
 }
 
 // inputs of evaluation j in the split layout: features 0..16 (+15 zero) over K-steps 0, 1
+template <int NPROD = 3>
 __device__ __forceinline__ void stage_input_h(float* __restrict__ lds, int j, const float (&loc)[3],
                                               const float (&feat)[8]) {
   float in[32];
@@ -390,11 +399,11 @@ __device__ __forceinline__ void stage_input_h(float* __restrict__ lds, int j, co
         const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
         const _Float16 t = (_Float16)x;
         hi[jj] = t;
-        lo[jj] = (_Float16)(x - (float)t);
+        if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
       }
       const int o = ((ks * 2 + hh) * DM + j) * 4;
       *(half8*)&lds[L_HL + o] = hi;
-      *(half8*)&lds[L_HLO + o] = lo;
+      if (NPROD == 3) *(half8*)&lds[L_HLO + o] = lo;
     }
   }
 }
@@ -609,7 +618,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
         }
       }
       if constexpr (PREC == 2) stage_input_t(lds, j, loc, feat);
-      else if constexpr (PREC == 1) stage_input_h(lds, j, loc, feat);
+      else if constexpr (PREC == 1) stage_input_h<3>(lds, j, loc, feat);
+      else if constexpr (PREC == 3) stage_input_h<1>(lds, j, loc, feat);
       else stage_input(hl, j, loc, feat);
       lds[L_WTRI + j] = wtri;
       lds[L_WVOL + j] = wvol;
@@ -637,7 +647,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
     }
     if (run_mlp) {
       if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
-      else if constexpr (PREC == 1) sdf_mlp_tile_h(lds, A.pack);
+      else if constexpr (PREC == 1) sdf_mlp_tile_h<3>(lds, A.pack);
+      else if constexpr (PREC == 3) sdf_mlp_tile_h<1>(lds, A.pack);
       else sdf_mlp_tile(lds, A.pack);
     }
     // ---------------- back end ------------------------------------------------------------
@@ -1207,7 +1218,7 @@ struct ARing {
 // One layer of the chain.  BASE = K-steps before this layer within the tile (ring phase); the ring holds
 // this layer's fragments 0 .. kTAhead-1 on entry; the last kTAhead steps request the NEXT layer's first
 // fragments from wp_next (its per-wave stride NEXT_NKS).
-template <int NKS, int BASE, int NEXT_NKS>
+template <int NKS, int BASE, int NEXT_NKS, int NPROD>
 __device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
                                             const float* __restrict__ bias, const float* __restrict__ hh,
                                             const float* __restrict__ hl, ARing& ring, f32x16 (&acc)[4], int w,
@@ -1225,7 +1236,7 @@ __device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rs, int voff,
   {                                                                                       \
     _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
       bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
-      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4);             \
+      if (NPROD == 3) bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4); \
     }                                                                                     \
   }
   BNV_LOAD_B(0);
@@ -1235,34 +1246,38 @@ __device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rs, int voff,
     bool loads_a = false;
     if (nx < NKS) {
       ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2) * 1024);
-      ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2 + 1) * 1024);
+      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2 + 1) * 1024);
       loads_a = true;
     } else if (nx - NKS < NEXT_NKS && nx - NKS < kTAhead) {
       ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2) * 1024);
-      ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2 + 1) * 1024);
+      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2 + 1) * 1024);
       loads_a = true;
     }
     if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    const half8 a_hi = ring.hi[(BASE + ks) % kTRing], a_lo = ring.lo[(BASE + ks) % kTRing];
+    const half8 a_hi = ring.hi[(BASE + ks) % kTRing];
+    if constexpr (NPROD == 3) {
+      const half8 a_lo = ring.lo[(BASE + ks) % kTRing];
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
+      for (int pt = 0; pt < 4; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+      for (int pt = 0; pt < 4; ++pt)
+        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
+    }
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
       acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
     if (ks + 1 < NKS) {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
+      for (int g = 0; g < (NPROD == 3 ? 8 : 3); ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
       }
+      if (NPROD == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     if (loads_a) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < (NPROD == 3 ? 2 : 1); ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
       }
@@ -1280,6 +1295,7 @@ __device__ __forceinline__ int lattice_entry(const DecodeArgs& A, int64_t e, int
   return (A.list[ci] << 5) | (int)(e - ci * 27);
 }
 
+template <int NPROD>
 __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const float voxel = A.grid.voxel_size;
@@ -1326,11 +1342,11 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
           const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
           const _Float16 t = (_Float16)x;
           hi[jj] = t;
-          lo[jj] = (_Float16)(x - (float)t);
+          if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
         }
         const int o = ((ks * 2 + hh) * DM + e) * 4;
         *(half8*)&lds[T_PARK_HI + o] = hi;
-        *(half8*)&lds[T_PARK_LO + o] = lo;
+        if (NPROD == 3) *(half8*)&lds[T_PARK_LO + o] = lo;
       }
     }
   };
@@ -1360,10 +1376,10 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {  // layer 0 has 2 K-steps; its third request slot belongs to layer 1
       ring.hi[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2) * 1024);
-      ring.lo[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2 + 1) * 1024);
+      if (NPROD == 3) ring.lo[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2 + 1) * 1024);
     }
     ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);
-    ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
+    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
   }
   __syncthreads();
 
@@ -1383,23 +1399,23 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
     }
     f32x16 acc[4];
     // layer 0 (B from PARK); K-steps 0, 1 of the tile; requests fragments 1, 2 of layer 1 (0 is in the ring)
-    chain_layer<2, 0, 16>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, w, h);
+    chain_layer<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, w, h);
     __syncthreads();
-    store_relu_h(lds, acc, w, j, h);
+    store_relu_h<NPROD>(lds, acc, w, j, h);
     if (gatherer) stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
     __syncthreads();
-    chain_layer<16, 2, 16>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, w, h);
+    chain_layer<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, w, h);
     __syncthreads();
-    store_relu_h(lds, acc, w, j, h);
+    store_relu_h<NPROD>(lds, acc, w, j, h);
     __syncthreads();
-    chain_layer<16, 18, 16>(rs, voff, O2, O3, pack + SD_B0 + 512, hl_hh, hl_hl, ring, acc, w, h);
+    chain_layer<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, hl_hh, hl_hl, ring, acc, w, h);
     __syncthreads();
-    store_relu_h(lds, acc, w, j, h);
+    store_relu_h<NPROD>(lds, acc, w, j, h);
     __syncthreads();
     // layer 3; its last steps request layer 0's two fragments and layer 1's first for the NEXT tile
-    chain_layer<16, 34, 2>(rs, voff, O3, O0, pack + SD_B0 + 768, hl_hh, hl_hl, ring, acc, w, h);
+    chain_layer<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, hl_hh, hl_hl, ring, acc, w, h);
     ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);  // (50 + 2) % 5: layer 1's fragment 0, next tile
-    ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
+    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
     // fc_alpha: 256 -> 1
     const f32x16 wa = frag256(pack + SD_WA, w, h);
 #pragma unroll
@@ -1861,7 +1877,7 @@ constexpr int kProfLds = 0;
 #endif
 
 static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
-  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_h64) {
+  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_h64) {  // (split mode only)
     int64_t grid = 2 * (int64_t)g_num_cus;
     if (2 * n_tiles_hint < grid) grid = 2 * n_tiles_hint;
     if (grid < 1) grid = 1;
@@ -1873,9 +1889,12 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   int64_t grid = g_num_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
-  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_pipe) {
+  if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
-    hipLaunchKernelGGL(k_lattice_table_h, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+    if (g_mlp_mode == 1)
+      hipLaunchKernelGGL(k_lattice_table_h<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+    else
+      hipLaunchKernelGGL(k_lattice_table_h<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
@@ -1891,6 +1910,10 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
     if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 1);
     else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
+  } else if (g_mlp_mode == 3) {
+    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 3);
+    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 3);
+    else BNV_LAUNCH_DECODE(MODE_DENSE, 3);
   } else {
     if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 0);
     else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 0);
@@ -1924,10 +1947,15 @@ int bnv_decode_init() {
   BNV_OPT_IN(MODE_PTS, 2);
   BNV_OPT_IN(MODE_LATTICE, 2);
   BNV_OPT_IN(MODE_DENSE, 2);
+  BNV_OPT_IN(MODE_PTS, 3);
+  BNV_OPT_IN(MODE_LATTICE, 3);
+  BNV_OPT_IN(MODE_DENSE, 3);
 #undef BNV_OPT_IN
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_lattice_h64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     Q_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h, hipFuncAttributeMaxDynamicSharedMemorySize,
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     L_TOTAL * 4));
@@ -1988,7 +2016,8 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
   return launch_decode(MODE_PTS, a, (n + 15) / 16, (hipStream_t)stream);
 }
 
-size_t bnv_sdfmlp_bwd_pack_floats(void) { return g_mlp_mode == 2 ? (size_t)(TB_TOTAL / 2) : (size_t)SB_PACK_FLOATS; }
+size_t bnv_sdfmlp_bwd_pack_floats(void) { return SB_PACK_FLOATS; }
+size_t bnv_sdfmlp_tcnn_bwd_pack_floats(void) { return TB_TOTAL / 2; }
 
 int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
                             const float* weights, int64_t row_limit, const float* sdfmlp_pack,

@@ -24,7 +24,7 @@ namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
-int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks
+int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
 bool g_prof_on = false;
@@ -459,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
 // ------------------------------------------------------------------------------------------
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+template <int NPROD = 3>
 __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, half8* hi, half8* lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -466,10 +467,11 @@ __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, hal
     if (relu) x = relu_bits(x);
     const _Float16 h = (_Float16)x;
     (*hi)[e] = h;
-    (*lo)[e] = (_Float16)(x - (float)h);
+    if (NPROD == 3) (*lo)[e] = (_Float16)(x - (float)h);
   }
 }
 
+template <int NPROD = 3>
 __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
                                            const half8 (&inh)[8], const half8 (&inl)[8], f32x16 (&out)[4],
                                            int lane, int h) {
@@ -483,7 +485,7 @@ __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, cons
   {                                                                                         \
     const _Float16* w = wp + (((((q) & 3) * 8 + ((q) >> 2)) * 2) * 64 + lane) * 8;           \
     ah[(q) & 1] = *(const half8*)w;                                                         \
-    al[(q) & 1] = *(const half8*)(w + 64 * 8);                                              \
+    if (NPROD == 3) al[(q) & 1] = *(const half8*)(w + 64 * 8);                              \
   }
   BNV_LOAD_W(0);
 #pragma unroll
@@ -491,8 +493,10 @@ __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, cons
     if (q + 1 < 32) BNV_LOAD_W(q + 1);
     __builtin_amdgcn_sched_barrier(0);
     const int g = q >> 2, mb = q & 3;
-    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q & 1], inh[g], out[mb], 0, 0, 0);
-    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inl[g], out[mb], 0, 0, 0);
+    if constexpr (NPROD == 3) {
+      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q & 1], inh[g], out[mb], 0, 0, 0);
+      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inl[g], out[mb], 0, 0, 0);
+    }
     out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inh[g], out[mb], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -587,7 +591,7 @@ constexpr int kEncProfLds = 0;
 // two waves take 652 together): the kernel is bound by MFMA cycles + VALU cycles, not by their maximum.
 int g_encoder_overlap = 0;
 
-template <bool OVERLAP>
+template <bool OVERLAP, int NPROD>
 __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
@@ -788,15 +792,17 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
         const float x = e < 4 ? in[e] : 0.f;
         const _Float16 hh = (_Float16)x;
         bh[e] = hh;
-        bl[e] = (_Float16)(x - (float)hh);
+        if (NPROD == 3) bl[e] = (_Float16)(x - (float)hh);
       }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
         const _Float16* w = wh + PH_W1 + ((mb * 2) * 64 + lane) * 8;
         const half8 ahi = *(const half8*)w, alo = *(const half8*)(w + 64 * 8);
         f32x16 c = bias_init(lb, mb, h);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
+        if constexpr (NPROD == 3) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
+        }
         ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh, c, 0, 0, 0);
       }
     }
@@ -804,24 +810,24 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
     half8 sh[8], sl[8];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+      split8<NPROD>(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8<NPROD>(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
     BNV_EPH(2);
-    layer128_h(wh + PH_W2, lb + 128, sh, sl, hb, lane, h);
+    layer128_h<NPROD>(wh + PH_W2, lb + 128, sh, sl, hb, lane, h);
     BNV_EPH(3);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      split8(hb[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+      split8<NPROD>(hb[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8<NPROD>(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
     BNV_EPH(4);
-    layer128_h(wh + PH_W3, lb + 256, sh, sl, ha, lane, h);
+    layer128_h<NPROD>(wh + PH_W3, lb + 256, sh, sl, ha, lane, h);
     BNV_EPH(5);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
-      split8(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
+      split8<NPROD>(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
+      split8<NPROD>(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
     BNV_EPH(6);
     // ---- layer 4: 128 -> 8 ------------------------------------------------------------------
@@ -851,8 +857,10 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int gq = gp * 2 + u;
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4l[gp & 1][u], sh[gq], o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sl[gq], o, 0, 0, 0);
+        if constexpr (NPROD == 3) {
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4l[gp & 1][u], sh[gq], o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sl[gq], o, 0, 0, 0);
+        }
         o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sh[gq], o, 0, 0, 0);
       }
     }
@@ -1127,9 +1135,11 @@ int bnv_init(int device) {
   g_num_cus = cus;
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<false>,
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<false, 3>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<true>,
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<true, 3>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<false, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
   extern int bnv_decode_init();
   return bnv_decode_init();
@@ -1153,7 +1163,7 @@ const char* bnv_status_string(int s) {
 size_t bnv_pointnet_pack_floats(void) { return PN_PACK_FLOATS; }
 
 int bnv_set_mlp_mode(int mode) {
-  if (mode < 0 || mode > 2) return BNV_ERR_INVALID_ARGUMENT;
+  if (mode < 0 || mode > 3) return BNV_ERR_INVALID_ARGUMENT;
   g_mlp_mode = mode;
   return BNV_OK;
 }
@@ -1239,11 +1249,14 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
                          ws.acc);
     else if (g_mlp_mode == 1) {
       if (g_encoder_overlap)
-        hipLaunchKernelGGL(k_pointnet_scatter_h<true>, dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+        hipLaunchKernelGGL((k_pointnet_scatter_h<true, 3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
                            input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
       else
-        hipLaunchKernelGGL(k_pointnet_scatter_h<false>, dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+        hipLaunchKernelGGL((k_pointnet_scatter_h<false, 3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
                            input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+    } else if (g_mlp_mode == 3) {
+      hipLaunchKernelGGL((k_pointnet_scatter_h<false, 1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     } else
       hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);

@@ -94,7 +94,8 @@ class TcnnNeRFModel(nn.Module):
         super().__init__()
         self.model = _TcnnParams(64 * 32 + 64 * 64 * 2 + 16 * 64)
         self.register_buffer("sdf_pack", torch.zeros(12288 // 2), persistent=False)
-        self.register_buffer("sdf_bwd_pack", torch.zeros(5184), persistent=False)   # transposed layers (backward)
+        self.register_buffer("sdf_bwd_pack", torch.zeros(int(_lib.load().bnv_sdfmlp_tcnn_bwd_pack_floats())),
+                             persistent=False)   # transposed layers (backward)
 
     def repack(self):
         p = self.model.params.detach().cpu().numpy()

@@ -93,7 +93,11 @@ int bnv_last_hip_error(void);
  *      fp32-class accuracy (differences at the level of fp32 summation order) at 16/3 the MFMA rate;
  *   2  the tiny-cuda-nn networks of the reference's default checkpoint (pointnet_tcnn.ckpt): inputs
  *      padded with 1.0, 64-wide, no bias, fp16 weights and activations, f16 MFMA with fp32
- *      accumulation.  The pack buffers then hold the tcnn layouts (weights.py: pack_*_tcnn). */
+ *      accumulation.  The pack buffers then hold the tcnn layouts (weights.py: pack_*_tcnn);
+ *   3  the fp32 checkpoint with weights and activations rounded to f16 (the hi halves of mode 1's packs),
+ *      ONE product per multiply-add on the f16 MFMA, fp32 accumulation: a third of mode 1's MFMAs and no lo
+ *      conversions; per-layer relative error ~2^-11, SDF error ~1e-5 against the 1e-4 bar (features ~1e-3).
+ *      The backward of decode_pts keeps the split arithmetic. */
 int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 
@@ -217,9 +221,10 @@ int bnv_decode_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, co
  * (sparse_volume.py:768-833).  grad_sdf [n] = d loss / d out_sdf; grad_features [row_limit, 8] is
  * ACCUMULATED into (the caller zeroes it).  The decoder weights are frozen and the points are data, so
  * nothing else receives gradient; sdf_delta is additive and does not enter.  sdfmlp_bwd_pack holds the
- * transposed layers (bnv_sdfmlp_bwd_pack_floats() for the current MLP mode; weights.py: pack_sdf_mlp_bwd for
- * the fp32 decoder, pack_sdf_tcnn_bwd for the tiny-cuda-nn decoder of MLP mode 2). */
+ * transposed layers: bnv_sdfmlp_bwd_pack_floats() floats for the fp32 decoder (weights.py: pack_sdf_mlp_bwd),
+ * bnv_sdfmlp_tcnn_bwd_pack_floats() for the tiny-cuda-nn decoder of MLP mode 2 (pack_sdf_tcnn_bwd). */
 size_t bnv_sdfmlp_bwd_pack_floats(void);
+size_t bnv_sdfmlp_tcnn_bwd_pack_floats(void);
 int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
                             const float* features, const float* weights, int64_t row_limit,
                             const float* sdfmlp_pack, const float* sdfmlp_bwd_pack, const float* coords,

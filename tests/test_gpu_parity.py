@@ -737,3 +737,41 @@ def test_meshlize_returns_mesh_like_the_reference(bnv, model, golden_volume, tmp
     n_before = len(mesh.vertices)
     mesh.merge_vertices()
     assert len(mesh.vertices) < n_before and mesh.faces.max() == len(mesh.vertices) - 1
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP mode 3: the fp32 checkpoint with f16 operands (one MFMA product).  Integer outputs stay bit-exact;
+# the float bars: SDF 1e-4 (north_star) END TO END against the reference's golden outputs, features 5e-3.
+# ---------------------------------------------------------------------------------------------
+def test_f16_operand_mode_end_to_end_vs_reference_golden():
+    import bnv_fusion_amd as bnv
+    try:
+        bnv.set_mlp_mode(bnv.MLP_MODE_F16)
+        model = bnv.load_pretrained(device=DEV, voxel_size=0.02)
+        z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+        vol = _vol(bnv, z)
+        f, c, ids, g, n = _encode(model, vol, torch.from_numpy(z["input_pts"]))
+        assert np.array_equal(ids.cpu().numpy(), z["flat_ids"]) and np.array_equal(c.cpu().numpy(), z["pcounts"])
+        ferr = np.abs(f.cpu().numpy() - z["feats"]).max()
+        assert 1e-6 < ferr <= 5e-3, ferr                                   # really the reduced-precision path
+        # the whole chain in this mode: 12 frames encoded + fused on the GPU, then decoded; compared with the
+        # reference's SDF of ITS fused volume (errors of the encoder, the running average and the decoder add up)
+        seq = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+        dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+        vol = _vol(bnv, seq)
+        for fr in seq["frames"]:
+            f, c, _, g, n = _encode(model, vol, torch.from_numpy(fr))
+            vol.track_n_pts(n)
+            model._integrate(vol, g, f, c)
+        vol.to_tensor()
+        assert np.array_equal(vol.active_coordinates.cpu().numpy(), seq["keys_insertion"])
+        v = np.float32(vol.voxel_size)
+        for key, coords in (("lattice_qt", dec["lattice_coords"]), ("random_qt", dec["random_coords"])):
+            out = vol.decode_pts(torch.from_numpy(coords).to(DEV), model.nerf, None, is_coords=True).cpu().numpy()
+            assert np.abs(out - dec[key]).max() <= SDF_TOL, (key, np.abs(out - dec[key]).max())
+            assert np.array_equal(out == v, dec[key] == v)
+        lat = vol.decode_lattice(torch.from_numpy(dec["origins"]).to(DEV), model.nerf, query_tensor=True).cpu().numpy()
+        err = np.abs(lat - dec["lattice_qt"][0, :, :, 0]).max()
+        assert 1e-8 < err <= SDF_TOL, err
+    finally:
+        bnv.set_mlp_mode(1)
