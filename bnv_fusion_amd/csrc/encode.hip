@@ -155,16 +155,28 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
   }
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
   const int lane = threadIdx.x & 63;
+  // the floor-z and ceil-z corners of an (x, y) column are neighbouring bits, nearly always of the same
+  // bitmap word: one visibility load and at most one atomicOr per column instead of two
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
+  for (int k = 0; k < 4; ++k) {
+    const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy;
     // duplicates (floor == ceil) would set the same bit again
-    const bool dup = ((k & 1) && cx == fx) || ((k & 2) && cy == fy) || ((k & 4) && cz == fz);
-    const int id = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + gz) : -1;
-    const int prev = __shfl_up(id, 1);
-    if (id >= 0 && !(lane > 0 && prev == id)) {
-      const uint32_t bit = 1u << (id & 31);
-      if (!(bitmap[id >> 5] & bit)) atomicOr(&bitmap[id >> 5], bit);
+    const bool dup = ((k & 1) && cx == fx) || ((k & 2) && cy == fy);
+    const int id0 = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + fz) : -1;
+    const int id1 = (id0 >= 0 && cz != fz) ? id0 + (cz - fz) : -1;
+    const int p0 = __shfl_up(id0, 1), p1 = __shfl_up(id1, 1);
+    if (id0 >= 0 && !(lane > 0 && p0 == id0 && p1 == id1)) {
+      const uint32_t bit0 = 1u << (id0 & 31);
+      if (id1 >= 0 && (id1 >> 5) == (id0 >> 5)) {
+        const uint32_t bits = bit0 | (1u << (id1 & 31));
+        if ((bitmap[id0 >> 5] & bits) != bits) atomicOr(&bitmap[id0 >> 5], bits);
+      } else {
+        if (!(bitmap[id0 >> 5] & bit0)) atomicOr(&bitmap[id0 >> 5], bit0);
+        if (id1 >= 0) {
+          const uint32_t bit1 = 1u << (id1 & 31);
+          if (!(bitmap[id1 >> 5] & bit1)) atomicOr(&bitmap[id1 >> 5], bit1);
+        }
+      }
     }
   }
   const unsigned long long b = __ballot(valid);
