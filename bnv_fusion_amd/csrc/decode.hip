@@ -720,6 +720,191 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Arbitrary query points (SparseVolume.decode_pts, sparse_volume.py:768-833) with LIVE-QUERY COMPACTION.
+// A query whose 8 corners are not all observed decodes to the constant voxel_size (:809, :818) without ever
+// reading its MLP outputs; the ray samples of the global optimiser are ~90 % such free-space points, but
+// spread so that nearly every run of 16 consecutive queries contains a live one.  The workgroup therefore
+// first CLASSIFIES a chunk of 128 queries (1,024 corner look-ups by all 512 threads; masked queries are
+// finished right there), compacts the live ones into an LDS list, and runs the MLP on tiles of 16 LIVE
+// queries.  Shared by the forward kernel and the two backward kernels.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PC_Q = 128;                         // queries per chunk
+constexpr int C_ROW = L_TOTAL;                    // [1024] int   row of every (query, corner) or -1
+constexpr int C_WN = C_ROW + PC_Q * 8;            // [1024] float trilinear weight / sum over the 8 corners
+constexpr int C_DLT = C_WN + PC_Q * 8;            // [1024] float sdf_delta sample of the corner
+constexpr int C_LIST = C_DLT + PC_Q * 8;          // [128]  int   chunk-local indices of the live queries
+constexpr int C_CNT = C_LIST + PC_Q;              // [4]    int   number of live queries
+constexpr int C_TOTAL = C_CNT + 4;                // 38,532 floats = 154,128 B
+
+// corner k of query point c (voxel units): corner coordinates, local offset, trilinear weight
+__device__ __forceinline__ float pts_corner(const DecodeArgs& A, int64_t q, int k, float (&corner)[3], float (&loc)[3]) {
+  const int cb = kCornerCeilBits[k];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float c = A.coords[q * 3 + a];
+    if (!A.is_coords) c = __fdiv_rn(__fsub_rn(c, A.grid.bound_min[a]), A.grid.voxel_size);  // (:793)
+    corner[a] = ((cb >> a) & 1) ? ceilf(c) : floorf(c);
+    loc[a] = __fsub_rn(c, corner[a]);
+  }
+  return __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
+}
+
+// Classifies chunk `chunk`; returns the number of live queries (uniform).  Masked queries get their final
+// value written to A.out when WRITE_MASKED (forward); live ones are listed in C_LIST in ascending order.
+template <bool WRITE_MASKED>
+__device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t chunk, float* __restrict__ lds) {
+  int* c_row = (int*)(lds + C_ROW);
+  int* c_list = (int*)(lds + C_LIST);
+  int* c_cnt = (int*)(lds + C_CNT);
+  const float voxel = A.grid.voxel_size;
+  if (threadIdx.x == 0) *c_cnt = 0;
+  __syncthreads();
+  unsigned live_bits = 0;  // lanes with k == 0: bit i set when this thread's i-th query is live
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ce = it * 512 + threadIdx.x;  // (query, corner) index within the chunk
+    const int64_t q = chunk * PC_Q + (ce >> 3);
+    const int k = ce & 7;
+    float wtri = 0.f, wvol = 0.f, dlt = 0.f;
+    int row = -1;
+    if (q < A.n) {
+      float corner[3], loc[3];
+      wtri = pts_corner(A, q, k, corner, loc);
+      uint64_t key;
+      if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
+        row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
+      if (row >= A.row_limit) row = -1;
+      if (row >= 0) wvol = A.weights[row];
+      if (A.delta.data) dlt = sample_delta(A.delta, A.grid, corner);
+    }
+    // the 8 corners of a query sit in 8 consecutive lanes: sums in corner order, like the reference's dim-1 sum
+    float norm = 0.f, wmin = 3.4e38f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      norm = __fadd_rn(norm, __shfl(wtri, (threadIdx.x & 56) + kk));
+      wmin = fminf(wmin, __shfl(wvol, (threadIdx.x & 56) + kk));
+    }
+    const float wn = __fdiv_rn(wtri, norm);
+    float dacc = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) dacc = __fadd_rn(dacc, __shfl(__fmul_rn(dlt, wn), (threadIdx.x & 56) + kk));
+    c_row[ce] = row;
+    lds[C_WN + ce] = wn;
+    lds[C_DLT + ce] = dlt;
+    const bool live = q < A.n && wmin >= (float)A.grid.min_pts_in_grid;
+    if (k == 0 && q < A.n) {
+      if (live) {
+        live_bits |= 1u << it;
+      } else if (WRITE_MASKED) {
+        float o = voxel;
+        if (A.delta.data) o = __fadd_rn(o, dacc);
+        A.out[q] = o;
+      }
+    }
+  }
+  // ordered compaction of the live queries (chunk-local index = ce >> 3): ballot per wave, wave offsets via LDS
+  __shared__ int wave_cnt[2][8];
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  unsigned long long b0 = __ballot(live_bits & 1u), b1 = __ballot(live_bits & 2u);
+  if (ln == 0) {
+    wave_cnt[0][wv] = __popcll(b0);
+    wave_cnt[1][wv] = __popcll(b1);
+  }
+  __syncthreads();
+  int base0 = 0, base1 = 0, tot0 = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < wv) {
+      base0 += wave_cnt[0][i];
+      base1 += wave_cnt[1][i];
+    }
+    tot0 += wave_cnt[0][i];
+  }
+  if (live_bits & 1u) c_list[base0 + __popcll(b0 & ((1ull << ln) - 1ull))] = threadIdx.x >> 3;
+  if (live_bits & 2u) c_list[tot0 + base1 + __popcll(b1 & ((1ull << ln) - 1ull))] = 64 + (threadIdx.x >> 3);
+  if (threadIdx.x == 511) {
+    int t1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t1 += wave_cnt[1][i];
+    *c_cnt = tot0 + t1;
+  }
+  __syncthreads();
+  return *c_cnt;
+}
+
+// front end of one tile of 16 live queries: thread e < 128 = (live query e >> 3, corner e & 7)
+template <int PREC>
+__device__ __forceinline__ void pts_stage_tile(const DecodeArgs& A, int64_t chunk, int tile, int n_live,
+                                               float* __restrict__ lds, int* __restrict__ row_out) {
+  const int e = threadIdx.x;
+  const int* c_row = (const int*)(lds + C_ROW);
+  const int* c_list = (const int*)(lds + C_LIST);
+  float loc[3] = {0.f, 0.f, 0.f};
+  float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float wn = 0.f, dlt = 0.f;
+  int row = -1;
+  const int li = tile * 16 + (e >> 3);
+  if (li < n_live) {
+    const int ql = c_list[li];
+    const int ce = ql * 8 + (e & 7);
+    float corner[3];
+    pts_corner(A, chunk * PC_Q + ql, e & 7, corner, loc);
+    row = c_row[ce];
+    wn = lds[C_WN + ce];
+    dlt = lds[C_DLT + ce];
+    if (row >= 0) {
+      const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+      const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        feat[f] = f0[f];
+        feat[4 + f] = f1[f];
+      }
+    }
+  }
+  if constexpr (PREC == 2) stage_input_t(lds, e, loc, feat);
+  else if constexpr (PREC == 1) stage_input_h<3>(lds, e, loc, feat);
+  else if constexpr (PREC == 3) stage_input_h<1>(lds, e, loc, feat);
+  else stage_input(lds + L_HL, e, loc, feat);
+  lds[L_WTRI + e] = wn;
+  lds[L_DELTA + e] = dlt;
+  if (row_out) row_out[e] = row;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(512, 2) void k_decode_pts(DecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const float voxel = A.grid.voxel_size;
+  const int64_t n_chunks = (A.n + PC_Q - 1) / PC_Q;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int n_live = pts_classify_chunk<true>(A, chunk, lds);
+    for (int tile = 0; tile * 16 < n_live; ++tile) {
+      if (threadIdx.x < DM) pts_stage_tile<PREC>(A, chunk, tile, n_live, lds, nullptr);
+      __syncthreads();
+      if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
+      else if constexpr (PREC == 1) sdf_mlp_tile_h<3>(lds, A.pack);
+      else if constexpr (PREC == 3) sdf_mlp_tile_h<1>(lds, A.pack);
+      else sdf_mlp_tile(lds, A.pack);
+      if (threadIdx.x < 16 && tile * 16 + threadIdx.x < n_live) {
+        const int b = threadIdx.x * 8;
+        float acc = 0.f, dacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float wk = lds[L_WTRI + b + k];
+          float a = __fmul_rn(lds[L_ALPHA + b + k], voxel);
+          if constexpr (PREC == 2) a = (float)(_Float16)a;  // half tensor * python float stays half (:813)
+          acc = __fadd_rn(acc, __fmul_rn(a, wk));
+          dacc = __fadd_rn(dacc, __fmul_rn(lds[L_DELTA + b + k], wk));
+        }
+        if (A.delta.data) acc = __fadd_rn(acc, dacc);
+        A.out[chunk * PC_Q + ((const int*)(lds + C_LIST))[tile * 16 + threadIdx.x]] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k_decode_pts_bwd: d(loss)/d(volume features) of k_decode<PTS> -- what the global optimiser needs
 // (run_e2e.py:111-162 makes volume.features an nn.Parameter and back-propagates the ray loss of
 // render_utils.py:461-560 through SparseVolume.decode_pts, sparse_volume.py:768-833).
@@ -849,68 +1034,22 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  int* l_row = (int*)(lds + L_DELTA);
-  const int64_t n_tiles = (A.n + 15) / 16;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    // ---------------- front end (as k_decode<PTS>), also remembers the row of every evaluation -------
+  int* l_row = (int*)(lds + L_WVOL);
+  const int64_t n_chunks = (A.n + PC_Q - 1) / PC_Q;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+   const int n_live = pts_classify_chunk<false>(A, chunk, lds);
+   for (int tile = 0; tile * 16 < n_live; ++tile) {
+    // front end: 16 LIVE queries of the chunk; masked queries carry no gradient and were dropped above
     if (threadIdx.x < DM) {
-      const int e = threadIdx.x;
-      float loc[3] = {0.f, 0.f, 0.f};
-      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float wtri = 0.f, wvol = 0.f;
-      int row = -1;
-      const int64_t q = tile * 16 + (e >> 3);
-      const int cb = kCornerCeilBits[e & 7];
-      if (q < A.n) {
-        float c[3], corner[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          c[a] = A.coords[q * 3 + a];
-          if (!A.is_coords) c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
-          corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
-          loc[a] = __fsub_rn(c[a], corner[a]);
-        }
-        wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
-        uint64_t key;
-        if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
-          row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
-        if (row >= A.row_limit) row = -1;
-        if (row >= 0) {
-          const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
-          const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            feat[f] = f0[f];
-            feat[4 + f] = f1[f];
-          }
-          wvol = A.weights[row];
-        }
-      }
-      stage_input_h(lds, e, loc, feat);
-      lds[L_WTRI + e] = wtri;
-      lds[L_WVOL + e] = wvol;
-      l_row[e] = row;
+      pts_stage_tile<1>(A, chunk, tile, n_live, lds, l_row);
+      // incoming gradient of every evaluation: d out_q / d alpha_k = voxel * w_k / sum(w)
+      const int li = tile * 16 + (threadIdx.x >> 3);
+      float go = 0.f;
+      if (li < n_live)
+        go = B.grad_out[chunk * PC_Q + ((const int*)(lds + C_LIST))[li]] * voxel * lds[L_WTRI + threadIdx.x];
+      lds[L_ALPHA + threadIdx.x] = go;
     }
     __syncthreads();
-    // incoming gradient of every evaluation: d out_q / d alpha_k = voxel * w_k / sum(w) under the mask
-    float go = 0.f;
-    if (threadIdx.x < DM) {
-      const int e = threadIdx.x;
-      const int64_t q = tile * 16 + (e >> 3);
-      if (q < A.n) {
-        const int b = e & ~7;
-        float norm = 0.f, wmin = 3.4e38f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          norm = __fadd_rn(norm, lds[L_WTRI + b + k]);
-          wmin = fminf(wmin, lds[L_WVOL + b + k]);
-        }
-        if (wmin >= (float)A.grid.min_pts_in_grid)
-          go = B.grad_out[q] * voxel * __fdiv_rn(lds[L_WTRI + e], norm);
-      }
-      lds[L_ALPHA + e] = go;
-    }
-    if (!__syncthreads_or(go != 0.f)) continue;  // every query of the tile is masked: no gradient
     // launder the weight pointers once per tile: otherwise the bias / fc_alpha fragments (80 VGPRs) are
     // hoisted out of the tile loop as loop invariants and the MLP spills
     const float* pack = A.pack;
@@ -997,6 +1136,7 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
       }
     }
     __syncthreads();
+   }
   }
 }
 
@@ -1033,66 +1173,22 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd_t(DecodeBwdArgs B) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  int* l_row = (int*)(lds + L_DELTA);
-  const int64_t n_tiles = (A.n + 15) / 16;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int* l_row = (int*)(lds + L_WVOL);
+  const int64_t n_chunks = (A.n + PC_Q - 1) / PC_Q;
+  for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+   const int n_live = pts_classify_chunk<false>(A, chunk, lds);
+   for (int tile = 0; tile * 16 < n_live; ++tile) {
+    // front end: 16 LIVE queries of the chunk; masked queries carry no gradient and were dropped above
     if (threadIdx.x < DM) {
-      const int e = threadIdx.x;
-      float loc[3] = {0.f, 0.f, 0.f};
-      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      float wtri = 0.f, wvol = 0.f;
-      int row = -1;
-      const int64_t q = tile * 16 + (e >> 3);
-      const int cb = kCornerCeilBits[e & 7];
-      if (q < A.n) {
-        float c[3], corner[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          c[a] = A.coords[q * 3 + a];
-          if (!A.is_coords) c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
-          corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
-          loc[a] = __fsub_rn(c[a], corner[a]);
-        }
-        wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
-        uint64_t key;
-        if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
-          row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
-        if (row >= A.row_limit) row = -1;
-        if (row >= 0) {
-          const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
-          const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
-#pragma unroll
-          for (int f = 0; f < 4; ++f) {
-            feat[f] = f0[f];
-            feat[4 + f] = f1[f];
-          }
-          wvol = A.weights[row];
-        }
-      }
-      stage_input_t(lds, e, loc, feat);
-      lds[L_WTRI + e] = wtri;
-      lds[L_WVOL + e] = wvol;
-      l_row[e] = row;
+      pts_stage_tile<2>(A, chunk, tile, n_live, lds, l_row);
+      // incoming gradient of every evaluation: d out_q / d alpha_k = voxel * w_k / sum(w)
+      const int li = tile * 16 + (threadIdx.x >> 3);
+      float go = 0.f;
+      if (li < n_live)
+        go = B.grad_out[chunk * PC_Q + ((const int*)(lds + C_LIST))[li]] * voxel * lds[L_WTRI + threadIdx.x];
+      lds[L_ALPHA + threadIdx.x] = go;
     }
     __syncthreads();
-    float go = 0.f;
-    if (threadIdx.x < DM) {
-      const int e = threadIdx.x;
-      const int64_t q = tile * 16 + (e >> 3);
-      if (q < A.n) {
-        const int b = e & ~7;
-        float norm = 0.f, wmin = 3.4e38f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          norm = __fadd_rn(norm, lds[L_WTRI + b + k]);
-          wmin = fminf(wmin, lds[L_WVOL + b + k]);
-        }
-        if (wmin >= (float)A.grid.min_pts_in_grid)
-          go = B.grad_out[q] * voxel * __fdiv_rn(lds[L_WTRI + e], norm);
-      }
-      lds[L_ALPHA + e] = go;
-    }
-    if (!__syncthreads_or(go != 0.f)) continue;
     if (w < 4) {
       const _Float16* ph = (const _Float16*)A.pack;
       const _Float16* pb = (const _Float16*)B.bwd_pack;
@@ -1189,6 +1285,7 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd_t(DecodeBwdArgs B) {
       }
     }
     __syncthreads();
+   }
   }
 }
 
@@ -1898,25 +1995,37 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
+  if (mode == MODE_PTS) {
+    int64_t gp = g_num_cus;
+    const int64_t chunks = (args.n + PC_Q - 1) / PC_Q;
+    if (chunks < gp) gp = chunks;
+    if (gp < 1) gp = 1;
+    ProfScope prof(PROF_DECODE_PTS, stream);
+#define BNV_LAUNCH_PTS(P) \
+  hipLaunchKernelGGL((k_decode_pts<P>), dim3((unsigned)gp), dim3(512), C_TOTAL * 4, stream, args)
+    if (g_mlp_mode == 2) BNV_LAUNCH_PTS(2);
+    else if (g_mlp_mode == 1) BNV_LAUNCH_PTS(1);
+    else if (g_mlp_mode == 3) BNV_LAUNCH_PTS(3);
+    else BNV_LAUNCH_PTS(0);
+#undef BNV_LAUNCH_PTS
+    BNV_LAUNCH_CHECK();
+    return BNV_OK;
+  }
   ProfScope prof(mode == MODE_PTS ? PROF_DECODE_PTS : mode == MODE_LATTICE ? PROF_DECODE_LATTICE : PROF_DECODE_DENSE,
                  stream);
 #define BNV_LAUNCH_DECODE(M, P) \
   hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4 + kProfLds, stream, args)
   if (g_mlp_mode == 2) {
-    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 2);
-    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
+    if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 2);
   } else if (g_mlp_mode == 1) {
-    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 1);
-    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
+    if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
   } else if (g_mlp_mode == 3) {
-    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 3);
-    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 3);
+    if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 3);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 3);
   } else {
-    if (mode == MODE_PTS) BNV_LAUNCH_DECODE(MODE_PTS, 0);
-    else if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 0);
+    if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 0);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 0);
   }
 #undef BNV_LAUNCH_DECODE
@@ -1938,16 +2047,12 @@ extern "C" {
 int bnv_decode_init() {
 #define BNV_OPT_IN(M, P) \
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4 + kProfLds))
-  BNV_OPT_IN(MODE_PTS, 0);
   BNV_OPT_IN(MODE_LATTICE, 0);
   BNV_OPT_IN(MODE_DENSE, 0);
-  BNV_OPT_IN(MODE_PTS, 1);
   BNV_OPT_IN(MODE_LATTICE, 1);
   BNV_OPT_IN(MODE_DENSE, 1);
-  BNV_OPT_IN(MODE_PTS, 2);
   BNV_OPT_IN(MODE_LATTICE, 2);
   BNV_OPT_IN(MODE_DENSE, 2);
-  BNV_OPT_IN(MODE_PTS, 3);
   BNV_OPT_IN(MODE_LATTICE, 3);
   BNV_OPT_IN(MODE_DENSE, 3);
 #undef BNV_OPT_IN
@@ -1958,9 +2063,13 @@ int bnv_decode_init() {
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L_TOTAL * 4));
+                                    C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd_t, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    L_TOTAL * 4));
+                                    C_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<3>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
   return BNV_OK;
 }
 
@@ -2041,13 +2150,13 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
   b.bwd_pack = sdfmlp_bwd_pack;
   b.grad_out = grad_sdf;
   b.grad_features = grad_features;
-  int64_t nblk = (n + 15) / 16;
+  int64_t nblk = (n + PC_Q - 1) / PC_Q;
   if (nblk > g_num_cus) nblk = g_num_cus;
   ProfScope prof(PROF_DECODE_PTS, (hipStream_t)stream);
   if (g_mlp_mode == 2)
-    hipLaunchKernelGGL(k_decode_pts_bwd_t, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(k_decode_pts_bwd_t, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
   else
-    hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), L_TOTAL * 4, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
