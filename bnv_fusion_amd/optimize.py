@@ -11,9 +11,13 @@ its backward into ``volume.features`` -- are the HIP kernels behind ``bnv_decode
 Randomness: pass ``generator=`` (a CPU or device ``torch.Generator``) for reproducible draws; a CPU
 generator reproduces the reference's CPU stream bit for bit (used by the parity tests).
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from .fusion import get_neighbors
 
 
@@ -155,14 +159,58 @@ def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generat
         "gt_pts": pts_map[idx].float().unsqueeze(0),
         "intr_mat": intr_mat.to(dev).float().reshape(1, 3, 3),
         "T_wc": T_wc.to(dev).float().reshape(1, 4, 4),
+        # host copies for the fused path (kernel arguments): free when the pose came from the host
+        "T_wc_host": T_wc.detach().cpu().numpy().astype(np.float32).reshape(4, 4),
+        "intr_host": intr_mat.detach().cpu().numpy().astype(np.float32).reshape(3, 3),
         "mask": mask.reshape(-1)[idx].float().unsqueeze(0),
         "neighbor_pts": pts_map[nidx].float().unsqueeze(0),
         "neighbor_masks": mask.reshape(-1)[nidx].float().unsqueeze(0),
     }
 
 
+def ray_split_step(volume, rays, nerf, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
+                   generator=None, grad=None):
+    """calculate_loss + backward of one ray split with the fused kernels (csrc/rays.hip + the decode_pts
+    forward / backward kernels): 6 launches instead of the ~180 of the torch formulation above, whose results
+    it reproduces (same uniforms in the same order: fine strata first, then coarse).  ``d loss / d features`` is
+    ACCUMULATED into ``grad`` ([M, 8], e.g. ``volume.features.grad``); returns (loss [1] device tensor, pts)."""
+    lib = _lib.load()
+    uv = rays["uv"][0].float().contiguous()
+    dev = uv.device
+    n = int(uv.shape[0])
+    n_fine, n_coarse = int(truncated_units * 2), int(ray_max_dist * 5)
+    S = n_fine + n_coarse
+    u_f = _rand((1, n, n_fine), dev, generator).contiguous()
+    u_c = _rand((1, n, n_coarse), dev, generator).contiguous()
+    T = rays["T_wc_host"] if rays.get("T_wc_host") is not None else rays["T_wc"].detach().cpu().numpy()
+    K = rays["intr_host"] if rays.get("intr_host") is not None else rays["intr_mat"].detach().cpu().numpy()
+    T = (C.c_float * 16)(*np.asarray(T, dtype=np.float32).reshape(-1)[:16].tolist())
+    K = (C.c_float * 9)(*np.asarray(K, dtype=np.float32).reshape(-1)[:9].tolist())
+    gt = rays["gt_pts"][0].float().contiguous()
+    rm = rays["mask"][0].float().contiguous()
+    nb = rays["neighbor_pts"][0].float().contiguous()
+    nbm = rays["neighbor_masks"][0].float().contiguous()
+    pts = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    target = torch.empty((n, S), dtype=torch.float32, device=dev)
+    weight = torch.empty((n, S), dtype=torch.float32, device=dev)
+    _lib.check(lib.bnv_ray_samples(_lib.ptr(uv), _lib.ptr(gt), _lib.ptr(rm), _lib.ptr(nb), _lib.ptr(nbm),
+                                   int(nb.shape[1]), T, K, _lib.ptr(u_f), _lib.ptr(u_c), n, n_fine, n_coarse,
+                                   float(truncated_dist), _lib.ptr(pts), _lib.ptr(target), _lib.ptr(weight),
+                                   _lib.stream_ptr()), "bnv_ray_samples")
+    volume.count_optim_pts(pts)
+    n_valid = (rm.sum() + 1e-4).reshape(1)
+    pred = volume._decode_pts_forward(pts, nerf, sdf_delta, False, True).reshape(-1).contiguous()
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    g = torch.empty_like(pred)
+    _lib.check(lib.bnv_ray_loss(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(weight), _lib.ptr(n_valid), n * S,
+                                _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()), "bnv_ray_loss")
+    if grad is not None:
+        volume.decode_pts_backward(pts, nerf, g, grad)
+    return loss, pts
+
+
 def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
-                    train_ray_splits=1000, lr=0.001, generator=None):
+                    train_ray_splits=1000, lr=0.001, generator=None, fused=True):
     """NeuralMap.optimize (run_e2e.py:111-162): Adam on ``volume.features`` over an iterable of ray
     batches, ``train_ray_splits`` rays per backward, then the optimised features are written back into the
     hash volume.  Returns the list of per-iteration losses (device scalars)."""
@@ -171,18 +219,28 @@ def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, 
     optimizer = torch.optim.Adam([volume.features], lr=lr)
     history = []
     for rays in ray_batches:
-        optimizer.zero_grad()
-        if torch.isnan(rays["T_wc"]).any():
+        optimizer.zero_grad(set_to_none=False)
+        if rays.get("T_wc_host") is not None:
+            if np.isnan(rays["T_wc_host"]).any():
+                continue
+        elif torch.isnan(rays["T_wc"]).any():
             continue
         n_rays = rays["uv"].shape[1]
         total = None
-        for indx in torch.split(torch.arange(n_rays, device=rays["uv"].device), train_ray_splits, dim=0):
-            part = {k: (torch.index_select(v, 1, indx) if k not in ("T_wc", "intr_mat") else v)
-                    for k, v in rays.items()}
-            out = calculate_loss(volume, part, nerf, truncated_units, truncated_dist, ray_max_dist,
-                                 sdf_delta=sdf_delta, generator=generator)
-            loss = sum(v for k, v in out.items() if k[0] != "_")
-            loss.backward()
+        if fused and volume.features.grad is None:
+            volume.features.grad = torch.zeros_like(volume.features)
+        whole = ("T_wc", "intr_mat", "T_wc_host", "intr_host")
+        for lo in range(0, n_rays, train_ray_splits):
+            part = {k: (v[:, lo: lo + train_ray_splits] if k not in whole else v) for k, v in rays.items()}
+            if fused:
+                loss, _ = ray_split_step(volume, part, nerf, truncated_units, truncated_dist, ray_max_dist,
+                                         sdf_delta=sdf_delta, generator=generator, grad=volume.features.grad)
+                loss = loss[0]
+            else:
+                out = calculate_loss(volume, part, nerf, truncated_units, truncated_dist, ray_max_dist,
+                                     sdf_delta=sdf_delta, generator=generator)
+                loss = sum(v for k, v in out.items() if k[0] != "_")
+                loss.backward()
             total = loss.detach() if total is None else total + loss.detach()
         optimizer.step()
         history.append(total)

@@ -262,6 +262,34 @@ class SparseVolume:
                                                     _lib.ptr(w), lim, _lib.ptr(self._stamp), self._epoch,
                                                     _lib.stream_ptr()), "bnv_volume_count_optim")
 
+    def count_optim_pts(self, pts, is_coords=False):
+        """count_optim on the 8 corner voxels of sample points [..., 3] (world units unless is_coords) -- what
+        render_utils.py:488-493 does via get_neighbors, without materialising the int64 keys."""
+        f, w, h, lim = self._snapshot()
+        p = pts.detach().reshape(-1, 3).float().contiguous()
+        if self._stamp is None or self._stamp.numel() < self._row_capacity:
+            self._stamp = torch.zeros(self._row_capacity, dtype=torch.int32, device=self._dev)
+        self._epoch += 1
+        _lib.check(self._lib.bnv_volume_count_optim_pts(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(p),
+                                                        int(p.shape[0]), 1 if is_coords else 0, _lib.ptr(w), lim,
+                                                        _lib.ptr(self._stamp), self._epoch, _lib.stream_ptr()),
+                   "bnv_volume_count_optim_pts")
+
+    def decode_pts_backward(self, coords, nerf, grad_sdf, grad_features, is_coords=False):
+        """Accumulates d(sum(grad_sdf * decode_pts(coords))) / d features into ``grad_features`` [M, 8] (the
+        to_tensor() snapshot rows).  The autograd edge of decode_pts calls this; the fused optimiser step too."""
+        if not hasattr(nerf, "sdf_bwd_pack"):
+            raise NotImplementedError("decode_pts backward needs a decoder with sdf_bwd_pack")
+        self._select_mode(nerf)
+        f, w, _, lim = self._snapshot()
+        c = coords.detach().reshape(-1, 3).float().contiguous()
+        g = grad_sdf.detach().reshape(-1).float().contiguous()
+        assert grad_features.shape == f.shape and grad_features.is_contiguous()
+        _lib.check(self._lib.bnv_decode_pts_backward(
+            C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+            _lib.ptr(nerf.sdf_pack), _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]),
+            1 if is_coords else 0, _lib.ptr(g), _lib.ptr(grad_features), _lib.stream_ptr()), "bnv_decode_pts_backward")
+
     # ---- decode ------------------------------------------------------------------------------------
     def _delta(self, sdf_delta):
         d = _lib.SdfDelta()

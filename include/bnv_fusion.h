@@ -231,6 +231,29 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid
                             int64_t n, int is_coords, const float* grad_sdf, float* grad_features,
                             bnv_stream_t stream);
 
+/* ---- global optimiser: ray sampling + SDF ray loss, fused ------------------------------------------ */
+
+/* One ray split of render_utils.py:461-549 up to the decode.  Per ray: the ray through pixel uv
+ * (get_camera_params / lift, :411-458; T_wc 4x4 and intr 3x3 row-major on the host), n_fine stratified
+ * samples within +-truncated_dist of the observed surface point gt_pts and n_coarse between the camera and
+ * it (hierarchical_sampling, :191-233; u_fine / u_coarse are the uniforms in [0,1) of the strata, supplied
+ * by the caller), merged by distance -> pts [n, S, 3] (S = n_fine + n_coarse <= 64).  Per sample the L1
+ * target of compute_sdf_loss (:508-549): +-distance to the nearest valid neighbour point (nb_pts
+ * [n, n_nb, 3], nb_mask [n, n_nb]) clipped to +-truncated_dist, and weight = valid * ray_mask. */
+int bnv_ray_samples(const float* uv, const float* gt_pts, const float* ray_mask, const float* nb_pts,
+                    const float* nb_mask, int n_nb, const float T_wc[16], const float intr[9],
+                    const float* u_fine, const float* u_coarse, int n, int n_fine, int n_coarse,
+                    float truncated_dist, float* pts, float* target, float* weight, bnv_stream_t stream);
+/* loss += sum_i weight_i |pred_i - target_i| / *n_valid (device scalars; loss is accumulated atomically)
+ * and grad_i = d loss / d pred_i. */
+int bnv_ray_loss(const float* pred, const float* target, const float* weight, const float* n_valid,
+                 int64_t m, float* loss, float* grad, bnv_stream_t stream);
+/* SparseVolume.count_optim on the 8 corner voxels of m sample points (render_utils.py:491-493,
+ * sparse_volume.py:602-622): weights[row] += 1 once per distinct row. */
+int bnv_volume_count_optim_pts(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* pts,
+                               int64_t m, int is_coords, float* weights, int64_t row_limit,
+                               int32_t* stamp, int32_t epoch, bnv_stream_t stream);
+
 /* ---- per-voxel marching cubes on decoded lattices -------------------------------------------- */
 
 /* SparseVolume.meshlize after the decode (sparse_volume.py:740-756): for every voxel whose 3x3x3

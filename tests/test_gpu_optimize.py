@@ -236,3 +236,33 @@ def test_neural_map_optimize_runs_with_tcnn_checkpoint():
         assert float((nm.volume.features - f0).abs().max()) > 1e-5
     finally:
         bnv.set_mlp_mode(1)
+
+
+def test_fused_ray_split_equals_the_torch_formulation(bnv, model):
+    """csrc/rays.hip (sampling + loss, fused) + decode forward/backward against optimize.calculate_loss + autograd
+    (itself pinned to the reference's golden vectors): same points, same loss, same gradient, same count_optim."""
+    from bnv_fusion_amd import optimize
+    dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    op = np.load(os.path.join(GOLDEN, "optimize_64.npz"))
+    rays = {k[5:]: torch.from_numpy(op[k]).to(DEV) for k in op.files if k.startswith("rays_")}
+    delta = torch.from_numpy(dec["sdf_delta"]).to(DEV)
+    args = (int(op["truncated_units"]), float(op["truncated_dist"]), int(op["ray_max_dist"]))
+    vol = _insertion_order_volume(bnv)
+    vol.features = torch.nn.Parameter(vol.features)
+    grad = torch.zeros_like(vol.features)
+    loss, pts = optimize.ray_split_step(vol, rays, model.nerf, *args, sdf_delta=delta,
+                                        generator=torch.Generator().manual_seed(int(op["seed"])), grad=grad)
+    assert np.abs(pts.cpu().numpy() - op["pts"][0]).max() <= 2e-6
+    assert (vol.weights.detach().cpu().numpy() != op["weights_after"]).mean() <= 2e-3
+    assert abs(float(loss) - float(op["depth_bce_loss"])) <= 1e-4 * float(op["depth_bce_loss"])
+    ref = op["grad_features"]
+    assert np.abs(grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max()
+    # and against the torch path of this package on a fresh volume, same generator state
+    vol2 = _insertion_order_volume(bnv)
+    vol2.features = torch.nn.Parameter(vol2.features)
+    l2 = optimize.calculate_loss(vol2, rays, model.nerf, *args, sdf_delta=delta,
+                                 generator=torch.Generator().manual_seed(int(op["seed"])))["depth_bce_loss"]
+    l2.backward()
+    assert abs(float(loss) - float(l2.detach())) <= 1e-5 * float(l2.detach())
+    assert (grad - vol2.features.grad).abs().max() <= 1e-4 * vol2.features.grad.abs().max()
+    assert torch.equal(vol.weights, vol2.weights)
