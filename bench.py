@@ -292,7 +292,8 @@ def main():
             geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
                 ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
         g = run["coords"]
-        pick = g[torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)].cpu()
+        sel = torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)
+        pick = g[sel].cpu()
         off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
         nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
         fo, wo, _ = nm.volume.query(nbr.to(dev))
@@ -301,7 +302,10 @@ def main():
         ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
         ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
                               geo=geo)[0, :, :, 0]
-        got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
+        if world == 1:
+            got = run["sdf"][sel].cpu()     # the very output of the last timed frame (no extra launch)
+        else:                               # replicated volume has moved on: decode again from the current state
+            got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
         return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
                 "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
                 "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}

@@ -290,13 +290,14 @@ class HipFrameBackend:
         return self.volume.decode_lattice(grid_ids, self.pointnet.nerf, None, query_tensor=False,
                                           n_dev=counters[2:3])
 
-    def account(self, headers, rows):
+    def account(self, headers, rows, n_rows_after=None):
         """Host bookkeeping once a batch's headers are on the host: n_avg_pts statistics
         (sparse_volume.py:508-523), the row reservation made for the capacity bound, overflow check."""
-        for h in headers:
+        for i, h in enumerate(headers):
             c = h[:4].view(torch.int32)
             n_valid, n_out, err = int(c[0]), int(c[2]), int(c[4])
-            self.volume._rows_upper -= rows - n_out
+            self.volume.settle(rows, n_rows_after if n_rows_after is not None else
+                               self.volume._rows_upper - self.volume._inflight)
             if err:
                 raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
             if n_valid:
@@ -307,6 +308,12 @@ class HipFrameBackend:
 
     def pinned(self, shape):
         return torch.empty(shape, dtype=torch.int64, pin_memory=True)
+
+    def rows_readback(self):
+        """Pinned copy of the volume's row count behind everything enqueued so far."""
+        h = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        h.copy_(self.volume._n_rows, non_blocking=True)
+        return h
 
     def event(self):
         ev = torch.cuda.Event()
@@ -322,8 +329,9 @@ class BatchHandle:
     """One batch of FrameParallelNeuralMap.  ``result()`` -> (coords [U', 3], sdf [U', 27]) of the frame
     THIS rank decoded, or (None, None); waits for that batch only."""
 
-    def __init__(self, fp, rec, sdf, host_hdr, event, n_frames):
+    def __init__(self, fp, rec, sdf, host_hdr, event, n_frames, host_rows=None):
         self._fp, self._rec, self._sdf, self._host, self._event, self._b = fp, rec, sdf, host_hdr, event, n_frames
+        self._host_rows = host_rows
         self._accounted = False
         self._done = None
 
@@ -331,7 +339,11 @@ class BatchHandle:
         if not self._accounted:
             if self._event is not None:
                 self._event.synchronize()
-            self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows)
+            n_after = int(self._host_rows[0]) if self._host_rows is not None else None
+            if n_after is not None:
+                self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows, n_after)
+            else:
+                self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows)
             self._accounted = True
 
     def result(self):
@@ -418,8 +430,9 @@ class FrameParallelNeuralMap:
                     sdf = be.decode_record(out[s], self.rows)
                 if s == self.rank:
                     mine = out[s]
+            host_rows = be.rows_readback() if hasattr(be, "rows_readback") else None
             ev = be.event()
-        self._last = BatchHandle(self, mine, sdf, host, ev, b)
+        self._last = BatchHandle(self, mine, sdf, host, ev, b, host_rows)
         return self._last
 
     def process_batch(self, frames, decode=True):

@@ -27,8 +27,9 @@ class FrameHandle:
     """A frame enqueued by NeuralMap.fuse_and_decode_async.  ``result()`` waits for THAT frame only (a HIP
     event recorded behind its last kernel) and returns (coords [U',3] i64, sdf [U',27] or None)."""
 
-    def __init__(self, nm, bufs, host_counters, event, cap, sdf):
+    def __init__(self, nm, bufs, host_counters, event, cap, sdf, host_rows=None):
         self._nm, self._bufs, self._host, self._event, self._cap, self._sdf = nm, bufs, host_counters, event, cap, sdf
+        self._host_rows = host_rows
         self._done = None
 
     def result(self):
@@ -38,7 +39,9 @@ class FrameHandle:
         h = self._host
         n_valid, n_out, err = int(h[0]), int(h[2]), int(h[4])
         vol = self._nm.volume
-        vol._rows_upper -= self._cap - n_out          # the reservation was made for the capacity bound
+        # the reservation was made for the capacity bound; the row count behind this frame's integrate came back
+        # with the counters, so the host-side bound stays exact and _reserve never has to synchronise
+        vol.settle(self._cap, int(self._host_rows[0]))
         if err:
             raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
         if n_valid == 0:
@@ -129,9 +132,11 @@ class NeuralMap:
                                    n_dev=n_dev) if decode else None
             host = torch.empty(8, dtype=torch.int32, pin_memory=True)
             host.copy_(counters, non_blocking=True)
+            host_rows = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host_rows.copy_(v._n_rows, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-        return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf)
+        return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
 
     def optimize(self, n_iters, last_frame=-1, sampling_size=5000, train_ray_splits=1000, ray_max_dist=3,
                  lr=0.001, generator=None):

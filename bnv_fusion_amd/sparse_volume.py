@@ -109,6 +109,7 @@ class SparseVolume:
         self._num_hits = torch.zeros(cap, dtype=torch.float32, device=d)
         self._n_rows = torch.zeros(1, dtype=torch.int32, device=d)
         self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
+        self._inflight = 0            # rows reserved by enqueued, not yet settled, device-count integrates
         self._lattice_ws = None
         self._stamp = None
         _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
@@ -135,9 +136,16 @@ class SparseVolume:
 
     def num_rows(self):
         """Exact number of active voxels (one device->host read)."""
-        n = int(self._n_rows.item())
-        self._rows_upper = n
+        n = int(self._n_rows.item())          # the stream is drained up to here: nothing is in flight any more
+        self._rows_upper = n + self._inflight
         return n
+
+    def settle(self, n_reserved, n_rows_after):
+        """Bookkeeping of an integrate that was enqueued with a device-side count: ``n_reserved`` rows had been
+        set aside for it; ``n_rows_after`` is the volume's row count read back (pinned copy) behind it.  Keeps
+        the host-side bound exact without ever synchronising: bound = last known count + what is in flight."""
+        self._inflight -= int(n_reserved)
+        self._rows_upper = int(n_rows_after) + self._inflight
 
     def _reserve(self, n_new):
         """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows)."""
@@ -189,6 +197,8 @@ class SparseVolume:
                                                   _lib.ptr(pcounts), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
                                                   _lib.stream_ptr()), "bnv_volume_integrate")
         self._rows_upper += n
+        if n_dev is not None:
+            self._inflight += n
 
     def insert(self, keys, new_feats, new_weights, new_num_hits):
         """sparse_volume.py:561-585 (upsert)."""
