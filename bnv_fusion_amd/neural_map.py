@@ -68,6 +68,10 @@ class NeuralMap:
         self.truncated_units = truncated_units
         self.truncated_dist = min(truncated_units * voxel_size * 0.5, 0.1)  # run_e2e.py:54
         self.frames = []                                                  # key frames for optimize() (run_e2e.py:73)
+        # fuse_and_decode_async: the encode of a frame depends only on the frame, so it is enqueued on a second
+        # HIP stream and overlaps the previous frame's integrate / decode kernels on the main stream
+        self.overlap_encode = True
+        self._enc_stream = None
         self.sdf_delta_weight = sdf_delta_weight                          # fusion_pointnet_model.yaml:44,47
         if tsdf:                                                          # run_e2e.py:60-71
             import numpy as np
@@ -122,9 +126,23 @@ class NeuralMap:
         ``.result()`` after enqueuing the NEXT frame to keep the GPU busy."""
         with torch.no_grad():
             v = self.volume
-            input_pts = frame_input_pts(frame)
-            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
-                input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+            main = torch.cuda.current_stream()
+            if self.overlap_encode:
+                if self._enc_stream is None:
+                    self._enc_stream = torch.cuda.Stream(device=v._dev)
+                with torch.cuda.stream(self._enc_stream):
+                    input_pts = frame_input_pts(frame)
+                    feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
+                        input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+                    done = torch.cuda.Event()
+                    done.record(self._enc_stream)
+                main.wait_event(done)
+                for t in (feats, pcounts, flat_ids, grid_ids, counters):
+                    t.record_stream(main)     # allocated on the encode stream, consumed on the main stream
+            else:
+                input_pts = frame_input_pts(frame)
+                feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
+                    input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
             n_dev = counters[2:3]
             v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
             self._integrate_tsdf(frame)
