@@ -775,3 +775,43 @@ def test_f16_operand_mode_end_to_end_vs_reference_golden():
         assert 1e-8 < err <= SDF_TOL, err
     finally:
         bnv.set_mlp_mode(1)
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 127, 128, 129, 1000])
+def test_decode_pts_ragged_sizes_and_all_masked_vs_oracle(bnv, model, golden_volume, orc, sd, n):
+    """The chunked / compacted arbitrary-point decode at sizes around its 128-query chunk and 16-query tile,
+    with live and masked queries mixed, all live, and all masked; world coordinates and sdf_delta included."""
+    vol = golden_volume
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    ovol = orc.OracleSparseVolume(8, vol.voxel_size, z["dims"], 8)
+    ovol.insert(vol.active_coordinates.cpu(), vol.features.cpu(), vol.weights.cpu(), vol.num_hits.cpu())
+    ovol.to_tensor()
+    delta = torch.from_numpy(dec["sdf_delta"])
+    g = torch.Generator().manual_seed(100 + n)
+    valid = vol.active_coordinates.cpu()[(vol.weights[:, 0] >= 8).cpu()]
+    for kind in ("mixed", "live", "masked"):
+        if n == 0:
+            q = torch.zeros(1, 0, 1, 3)
+        elif kind == "masked":
+            q = torch.rand(1, n, 1, 3, generator=g) * 3 + 1.0                 # a corner of the grid nobody observed
+        else:
+            base = valid[torch.randint(len(valid), (n,), generator=g)].float()
+            spread = 1.6 if kind == "mixed" else 0.0
+            q = (base + (torch.rand(n, 3, generator=g) - 0.5) * spread).reshape(1, n, 1, 3)
+        qw = q * vol.voxel_size + ovol.min_coords                                # world coordinates
+        out = vol.decode_pts(qw.to(DEV), model.nerf, delta.to(DEV), is_coords=False, query_tensor=True).cpu()
+        if n == 0:                    # the reference itself asserts on an empty query (torch.min of nothing)
+            assert tuple(out.shape) == (1, 0, 1, 1)
+            continue
+        ref = ovol.decode_pts(qw, sd, delta, is_coords=False, query_tensor=True)
+        assert out.shape == ref.shape
+        if n:
+            assert (out - ref).abs().max() <= SDF_TOL, (kind, float((out - ref).abs().max()))
+            ref0 = ovol.decode_pts(qw, sd, None, is_coords=False)
+            out0 = vol.decode_pts(qw.to(DEV), model.nerf, None, is_coords=False).cpu()
+            assert torch.equal(out0 == vol.voxel_size, ref0 == ovol.voxel_size)   # mask decisions
+            if kind == "masked":
+                assert bool((out0 == vol.voxel_size).all())
+            if kind == "live" and n >= 7:
+                assert float((out0 != vol.voxel_size).float().mean()) > 0.5
