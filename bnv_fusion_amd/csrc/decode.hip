@@ -60,7 +60,7 @@ constexpr int L_WVOL = L_WTRI + DM;           // [128] volume weight (or dense c
 constexpr int L_DELTA = L_WVOL + DM;          // [128] sdf_delta sample of its corner
 constexpr int L_TOTAL = L_DELTA + DM;         // 35,328 floats = 141,312 B
 
-enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2 };
+enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2 };  // MODE_PTS runs k_decode_pts, the others k_decode
 
 // Phase timing of the decode tile loop (development builds only: -DBNV_PHASE_PROF, tools/phase_prof.py).
 // Thread 0 of every workgroup accumulates shader-clock deltas per phase in LDS and adds them to
@@ -579,30 +579,11 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
             c[a] = A.coords[q * 3 + a];
-            if (MODE == MODE_PTS && !A.is_coords)  // (coords - min_coords) / voxel_size (:793)
-              c[a] = __fdiv_rn(__fsub_rn(c[a], A.grid.bound_min[a]), voxel);
             corner[a] = ((cb >> a) & 1) ? ceilf(c[a]) : floorf(c[a]);
             loc[a] = __fsub_rn(c[a], corner[a]);
           }
           wtri = __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
-          if constexpr (MODE == MODE_PTS) {
-            uint64_t key;
-            int row = -1;
-            if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
-              row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
-            if (row >= A.row_limit) row = -1;
-            if (row >= 0) {
-              const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
-              const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
-#pragma unroll
-              for (int f = 0; f < 4; ++f) {
-                feat[f] = f0[f];
-                feat[4 + f] = f1[f];
-              }
-              wvol = A.weights[row];
-            }
-            if (A.delta.data) dlt = sample_delta(A.delta, A.grid, corner);
-          } else {  // MODE_DENSE: nearest gather == direct index, zero outside (:296-310)
+          {  // MODE_DENSE: nearest gather == direct index, zero outside (:296-310)
             const int x = (int)corner[0], y = (int)corner[1], z = (int)corner[2];
             if (x >= 0 && y >= 0 && z >= 0 && x < A.dims[0] && y < A.dims[1] && z < A.dims[2]) {
               const size_t plane = (size_t)A.dims[0] * A.dims[1] * A.dims[2];
@@ -626,31 +607,13 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
       lds[L_DELTA + j] = dlt;
     }
     // ---------------- MLP -----------------------------------------------------------------
-    bool run_mlp = true;
-    if constexpr (MODE == MODE_PTS) {
-      // a query whose 8 corners are not all observed decodes to the constant voxel_size (:809,:818); ray
-      // samples of the global optimiser are mostly such free-space points and come in runs along the ray:
-      // a tile with no live query skips the MLP (its alpha values are never selected)
-      __syncthreads();
-      int live = 0;
-      if (threadIdx.x < 16 && tile * 16 + threadIdx.x < A.n) {
-        float wmin = 3.4e38f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) wmin = fminf(wmin, lds[L_WVOL + threadIdx.x * 8 + k]);
-        live = wmin >= (float)A.grid.min_pts_in_grid;
-      }
-      run_mlp = __syncthreads_or(live) != 0;
-    } else {
-      BNV_PH(0);
-      __syncthreads();
-      BNV_PH(18);
-    }
-    if (run_mlp) {
-      if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
-      else if constexpr (PREC == 1) sdf_mlp_tile_h<3>(lds, A.pack);
-      else if constexpr (PREC == 3) sdf_mlp_tile_h<1>(lds, A.pack);
-      else sdf_mlp_tile(lds, A.pack);
-    }
+    BNV_PH(0);
+    __syncthreads();
+    BNV_PH(18);
+    if constexpr (PREC == 2) sdf_mlp_tile_t(lds, A.pack);
+    else if constexpr (PREC == 1) sdf_mlp_tile_h<3>(lds, A.pack);
+    else if constexpr (PREC == 3) sdf_mlp_tile_h<1>(lds, A.pack);
+    else sdf_mlp_tile(lds, A.pack);
     // ---------------- back end ------------------------------------------------------------
     if constexpr (MODE == MODE_LATTICE) {
       if (threadIdx.x < DM) {
@@ -696,14 +659,9 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
             dacc = __fadd_rn(dacc, __fmul_rn(lds[L_DELTA + b + k], wk));
             wmin = fminf(wmin, wv);
           }
-          float out;
-          if constexpr (MODE == MODE_DENSE) {
-            out = (wsum > 0.f) ? acc : voxel;  // any corner valid (:328-329)
-          } else {
-            out = (wmin >= (float)A.grid.min_pts_in_grid) ? acc : voxel;  // all corners valid (:809,:818)
-            if (A.delta.data) out = __fadd_rn(out, dacc);
-          }
-          A.out[q] = out;
+          (void)dacc;
+          (void)wmin;
+          A.out[q] = (wsum > 0.f) ? acc : voxel;  // MODE_DENSE: any corner valid (:328-329)
         }
       }
     }
