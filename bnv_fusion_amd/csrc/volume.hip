@@ -18,8 +18,9 @@ struct VolWs {
   int32_t* slot_of;        // [n] slot index of each key (or -1: key out of range)
   int32_t* is_new;         // [n] 1 if this thread's CAS created the slot
   uint32_t* block_sums;    // [n_blocks + 1]
-  int32_t* total_new;      // [1]
-  int32_t* error;          // [1]
+  uint32_t* block_new;     // [ceil(n / 256) + 1] created keys per 256-key block (integrate)
+  int32_t* total_new;      // [1] workspace word 0: created keys (insert) / first new row (integrate)
+  int32_t* error;          // [1] workspace word 1: sticky error code (1 table full, 2 key range, 3 row capacity)
 };
 
 static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
@@ -31,14 +32,16 @@ static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
     off = (off + bytes + 255) / 256 * 256;
     return p;
   };
+  char* d = take(256);   // control words first: their offsets do not depend on n
   char* a = take(n * 4);
   char* b = take(n * 4);
   char* c = take((nb + 1) * 4);
-  char* d = take(256);
+  char* e = take(((n + 255) / 256 + 1) * 4);
   if (ws) {
     ws->slot_of = (int32_t*)a;
     ws->is_new = (int32_t*)b;
     ws->block_sums = (uint32_t*)c;
+    ws->block_new = (uint32_t*)e;
     ws->total_new = (int32_t*)d;
     ws->error = (int32_t*)d + 1;
   }
@@ -69,13 +72,15 @@ __global__ __launch_bounds__(256) void k_vol_probe_insert(bnv_volume_t v, const 
                                                           int64_t n, const int32_t* __restrict__ n_dev,
                                                           int32_t* __restrict__ slot_of,
                                                           int32_t* __restrict__ is_new,
-                                                          int32_t* __restrict__ error) {
+                                                          int32_t* __restrict__ error,
+                                                          uint32_t* __restrict__ block_new = nullptr) {
   n = dev_count(n, n_dev);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   uint64_t key;
   int32_t slot = -1, created = 0;
-  if (pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key)) {
+  if (i >= n) {
+    // (fall through to the block count with created = 0)
+  } else if (pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key)) {
     const uint32_t mask = (uint32_t)(v.n_slots - 1);
     uint32_t s = mix64(key) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
@@ -99,8 +104,17 @@ __global__ __launch_bounds__(256) void k_vol_probe_insert(bnv_volume_t v, const 
   } else {
     *error = 2;  // coordinate outside the 21-bit key range
   }
-  slot_of[i] = slot;
-  is_new[i] = created;
+  if (i < n) {
+    slot_of[i] = slot;
+    is_new[i] = created;
+  }
+  if (block_new) {  // created keys of this 256-key block (first level of the ordered numbering)
+    __shared__ uint32_t wave_new[4];
+    const unsigned long long b = __ballot(created);
+    if ((threadIdx.x & 63) == 0) wave_new[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_new[blockIdx.x] = wave_new[0] + wave_new[1] + wave_new[2] + wave_new[3];
+  }
 }
 
 __global__ __launch_bounds__(kVolThreads) void k_vol_scan_partial(const int32_t* __restrict__ is_new, int64_t n,
@@ -179,31 +193,90 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
   *n_rows += *total_new;
 }
 
-// _integrate/_update (local_point_fusion.py:647-673) on rows that now all exist
-__global__ __launch_bounds__(256) void k_vol_integrate_apply(bnv_volume_t v, const float* __restrict__ feats,
-                                                             const int64_t* __restrict__ pcounts, int64_t n,
-                                                             const int32_t* __restrict__ n_dev,
-                                                             const int32_t* __restrict__ slot_of) {
+// ---- fused upsert for _integrate: 3 launches instead of 7 (memset, probe, 2-level scan x2, assign, commit,
+// apply).  Every launch costs ~10 us of stream time whatever it does, and the frame-parallel multi-GPU mode
+// replays this upsert once per frame of a batch on every rank.  K1 = k_vol_probe_insert, which also counts
+// the created keys of each 256-key block.
+// K2: ONE workgroup turns the block counts into exclusive offsets and commits the row count; first_row_out
+// receives the old count.
+__global__ __launch_bounds__(1024) void k_vol_offsets_commit(uint32_t* __restrict__ block_new, int n_blocks,
+                                                             int32_t* __restrict__ n_rows,
+                                                             int32_t* __restrict__ first_row_out) {
+  __shared__ uint32_t wave_tot[16];
+  uint32_t carry = 0;
+  for (int base = 0; base < n_blocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const uint32_t val = (i < n_blocks) ? block_new[i] : 0;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan<1024>(val, wave_tot, &total);
+    if (i < n_blocks) block_new[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int32_t first = *n_rows;
+    *first_row_out = first;
+    *n_rows = first + (int32_t)carry;
+  }
+}
+
+// K3: creates the rows of the new keys and applies _integrate/_update (local_point_fusion.py:647-673) to every
+// key in one pass.  Keys are unique within a batch, so a row is touched by exactly one thread.
+__global__ __launch_bounds__(256) void k_vol_assign_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
+                                                              const float* __restrict__ feats,
+                                                              const int64_t* __restrict__ pcounts, int64_t n,
+                                                              const int32_t* __restrict__ n_dev,
+                                                              const int32_t* __restrict__ slot_of,
+                                                              const int32_t* __restrict__ is_new,
+                                                              const uint32_t* __restrict__ block_off,
+                                                              const int32_t* __restrict__ first_row,
+                                                              int32_t* __restrict__ error) {
   n = dev_count(n, n_dev);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // rank of a created key among the created keys of the batch, in batch order (= position of its new row)
+  __shared__ uint32_t wave_new[4];
+  const int created = (i < n) ? is_new[i] : 0;
+  const unsigned long long bal = __ballot(created);
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (ln == 0) wave_new[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  uint32_t before = block_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+  for (int k = 0; k < wv; ++k) before += wave_new[k];
   if (i >= n) return;
   const int32_t slot = slot_of[i];
   if (slot < 0) return;
-  const int64_t row = v.slot_rows[slot];
-  if (row < 0 || row >= v.row_capacity) return;
+  const int32_t r = created ? (int32_t)before + 1 : 0;
+  int64_t row;
+  float w_old = 0.f;
+  float fo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r > 0) {
+    row = (int64_t)*first_row + (r - 1);
+    if (row >= v.row_capacity) {
+      *error = 3;
+      return;
+    }
+    v.slot_rows[slot] = (int32_t)row;
+    v.row_coords[row * 3 + 0] = coords[i * 3 + 0];
+    v.row_coords[row * 3 + 1] = coords[i * 3 + 1];
+    v.row_coords[row * 3 + 2] = coords[i * 3 + 2];
+    v.num_hits[row] = 0.f;   // a fresh row reads as zeros (SparseVolume.query of an absent key, :677-679)
+  } else {
+    row = v.slot_rows[slot];
+    if (row < 0 || row >= v.row_capacity) return;
+    w_old = v.weights[row];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fo[f] = v.features[row * 8 + f];
+  }
   // fine_weights = clip(pcounts / 32, max=1)   (:660; int64 / 32 -> float32 true division)
   const float w = fminf(__fdiv_rn((float)pcounts[i], 32.0f), 1.0f);
-  const float w_old = v.weights[row];
   const float w_new = __fadd_rn(w_old, w);  // updated_weights = old + new (:649)
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
-    const float fo = v.features[row * 8 + f];
     const float fn = feats[i * 8 + f];
     // (old_feats * old_weights + new_feats * new_weights) / updated_weights (:650)
-    v.features[row * 8 + f] = __fdiv_rn(__fadd_rn(__fmul_rn(fo, w_old), __fmul_rn(fn, w)), w_new);
+    v.features[row * 8 + f] = __fdiv_rn(__fadd_rn(__fmul_rn(fo[f], w_old), __fmul_rn(fn, w)), w_new);
   }
   v.weights[row] = w_new;
-  // num_hits is carried through unchanged (:661-672)
 }
 
 __global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const float* __restrict__ feats,
@@ -338,10 +411,15 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   VolWs ws;
   if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  const int rc = vol_upsert_rows(*vol, coords, n, n_dev, ws, stream);
-  if (rc != BNV_OK) return rc;
-  hipLaunchKernelGGL(k_vol_integrate_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, feats,
-                     pcounts, n, n_dev, ws.slot_of);
+  const unsigned nb256 = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, *vol, coords, n, n_dev, ws.slot_of,
+                     ws.is_new, ws.error, ws.block_new);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(1024), 0, stream, ws.block_new, (int)nb256, vol->n_rows,
+                     ws.total_new);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_assign_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+                     ws.slot_of, ws.is_new, ws.block_new, ws.total_new, ws.error);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

@@ -348,8 +348,10 @@ class BatchHandle:
 
     def result(self):
         if self._done is None:
-            self._account()
             fp = self._fp
+            while fp._unsettled and not self._accounted:      # bookkeeping stays in batch order
+                fp._unsettled.pop(0)._account()
+            self._account()
             if self._rec is None:
                 self._done = (None, None)
             else:
@@ -389,6 +391,8 @@ class FrameParallelNeuralMap:
         self.volume = getattr(self.backend, "volume", None)
         self.rows = record_rows
         self._last = None
+        self._unsettled = []      # batches whose host bookkeeping has not been done yet (oldest first)
+        self.max_unsettled = 3    # the host may run this many batches ahead of the GPU before it waits
 
     def _agree_rows(self, frames):
         """One-time: the record capacity all ranks use (max over ranks of the local bound)."""
@@ -418,8 +422,11 @@ class FrameParallelNeuralMap:
         frames, out = ticket["frames"], ticket["out"]
         b = len(frames)
         ticket["work"].wait()
-        if self._last is not None:          # previous batch's headers are on the host by now: bookkeeping
-            self._last._account()
+        # host bookkeeping of earlier batches, in order, without waiting: only batches whose event has already
+        # fired (the host must be free to enqueue the N replayed integrates while the GPU still runs the encode)
+        while self._unsettled and (self._unsettled[0]._event is None or self._unsettled[0]._event.query()
+                                   or len(self._unsettled) >= self.max_unsettled):
+            self._unsettled.pop(0)._account()
         with torch.no_grad():
             host = be.pinned((self.world, REC_HDR))
             host.copy_(out[:, :REC_HDR], non_blocking=True)
@@ -433,6 +440,7 @@ class FrameParallelNeuralMap:
             host_rows = be.rows_readback() if hasattr(be, "rows_readback") else None
             ev = be.event()
         self._last = BatchHandle(self, mine, sdf, host, ev, b, host_rows)
+        self._unsettled.append(self._last)
         return self._last
 
     def process_batch(self, frames, decode=True):
@@ -450,8 +458,8 @@ class FrameParallelNeuralMap:
             ticket = nxt
 
     def flush(self):
-        if self._last is not None:
-            self._last._account()
+        while self._unsettled:
+            self._unsettled.pop(0)._account()
 
     def _dev(self):
         return getattr(self.backend, "dev", torch.device("cpu"))

@@ -110,6 +110,7 @@ class SparseVolume:
         self._n_rows = torch.zeros(1, dtype=torch.int32, device=d)
         self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
         self._inflight = 0            # rows reserved by enqueued, not yet settled, device-count integrates
+        self._rows_known = 0          # largest row count read back so far
         self._lattice_ws = None
         self._stamp = None
         _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
@@ -137,7 +138,13 @@ class SparseVolume:
     def num_rows(self):
         """Exact number of active voxels (one device->host read)."""
         n = int(self._n_rows.item())          # the stream is drained up to here: nothing is in flight any more
+        self._rows_known = max(self._rows_known, n)
         self._rows_upper = n + self._inflight
+        if self._ws is not None:              # sticky error word of the upsert kernels (csrc/volume.hip: VolWs)
+            err = int(self._ws[4:8].view(torch.int32).item())
+            if err:
+                raise _lib.BnvError({1: "hash table full", 2: "voxel coordinate outside the 21-bit key range",
+                                     3: "row capacity exceeded"}.get(err, f"upsert error {err}"))
         return n
 
     def settle(self, n_reserved, n_rows_after):
@@ -145,16 +152,20 @@ class SparseVolume:
         set aside for it; ``n_rows_after`` is the volume's row count read back (pinned copy) behind it.  Keeps
         the host-side bound exact without ever synchronising: bound = last known count + what is in flight."""
         self._inflight -= int(n_reserved)
-        self._rows_upper = int(n_rows_after) + self._inflight
+        self._rows_known = max(self._rows_known, int(n_rows_after))     # row counts only grow
+        self._rows_upper = self._rows_known + self._inflight
 
     def _reserve(self, n_new):
-        """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows)."""
+        """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows).  The test uses the
+        host-side BOUND (known rows + reservations of integrates still in flight), and growth provides for the
+        bound too -- otherwise every call would have to synchronise to learn that the real count still fits."""
         if self._rows_upper + n_new <= self._row_capacity:
             return
         n = self.num_rows()
-        if n + n_new <= self._row_capacity:
+        need = n + self._inflight + n_new
+        if need <= self._row_capacity:
             return
-        cap = max(2 * self._row_capacity, n + n_new)
+        cap = max(2 * self._row_capacity, need)
         d = self._dev
 
         def grow(t, shape):

@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
 from bnv_fusion_amd import synthetic
 from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); ap.add_argument("--replay", type=int, default=1); ap.add_argument("--ahead", type=int, default=3); args = ap.parse_args()
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -15,12 +15,22 @@ dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)} for t in range(30 + args.frames)]
 fp = FrameParallelNeuralMap(np.array([dims]*3), voxel, model, device="cuda:0", tsdf=True)
+fp.max_unsettled = args.ahead
 for h in fp.process_stream([[f] for f in frames[:30]], decode=False): pass
+if args.replay > 1:     # emulate the replicated part of an N-rank batch: N - 1 more integrates (+ TSDF) per batch
+    orig = fp.backend.integrate_record
+    def replayed(rec, rows, frame=None):
+        for _ in range(args.replay):
+            orig(rec, rows, frame)
+        fp.backend.volume._inflight -= (args.replay - 1) * rows      # keep the host-side row bound consistent
+        fp.backend.volume._rows_upper -= (args.replay - 1) * rows
+    fp.backend.integrate_record = replayed
 fp.flush(); torch.cuda.synchronize()
 for rep in range(2):
     t0 = time.perf_counter(); last = None
     for last in fp.process_stream([[f] for f in frames[30:]]): pass
     fp.flush(); c, sdf = last.result(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"one-rank frame-parallel over RCCL: {args.frames/dt:.1f} frames/s ({1e3*dt/args.frames:.3f} ms per batch of 1), last frame {len(c)} voxels")
+    print(f"ahead={args.ahead} one-rank frame-parallel over RCCL, {args.replay} integrates per batch: {1e3*dt/args.frames:.3f} ms per batch "
+          f"-> an {args.replay}-rank run would do {args.replay*args.frames/dt:.0f} frames/s if the exchange hides")
 dist.destroy_process_group()
