@@ -21,6 +21,7 @@ struct TsdfArgs {
   int im_h, im_w;
   const float* color_im;  // folded b*65536 + g*256 + r, or null
   const float* depth_im;  // metres, 0 = invalid
+  const uint16_t* depth_mm;  // alternative input: the dataset's uint16 millimetres (common.py:93: / 1000.)
 };
 
 __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
   const int px = (int)roundf(a.intr[0] * (cx / cz) + a.intr[2]);
   const int py = (int)roundf(a.intr[4] * (cy / cz) + a.intr[5]);
   if (px < 0 || px >= a.im_w || py < 0 || py >= a.im_h || cz < 0.f) return;
-  const float depth = a.depth_im[(size_t)py * a.im_w + px];
+  const float depth = a.depth_mm ? __fdiv_rn((float)a.depth_mm[(size_t)py * a.im_w + px], 1000.f)
+                                 : a.depth_im[(size_t)py * a.im_w + px];
   if (depth == 0.f) return;
   const float diff = depth - cz;
   if (diff < -a.trunc_margin) return;
@@ -69,12 +71,12 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
 
 using namespace bnv;
 
-extern "C" int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+static int tsdf_integrate_impl(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
                                   const float origin_host[3], float voxel_size, float trunc_margin,
-                                  const float* depth_im, const float* color_im, int im_h, int im_w,
+                                  const float* depth_im, const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                                   const float intr_host[9], const float pose_host[16], float obs_weight,
                                   bnv_stream_t stream) {
-  if (!tsdf || !weight || !dim_host || !origin_host || !depth_im || !intr_host || !pose_host || im_h <= 0 ||
+  if (!tsdf || !weight || !dim_host || !origin_host || (!depth_im && !depth_mm) || !intr_host || !pose_host || im_h <= 0 ||
       im_w <= 0)
     return BNV_ERR_INVALID_ARGUMENT;
   TsdfArgs a;
@@ -94,9 +96,28 @@ extern "C" int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, cons
   a.im_w = im_w;
   a.color_im = color_im;
   a.depth_im = depth_im;
+  a.depth_mm = depth_mm;
   const int64_t n = (int64_t)a.dim[0] * a.dim[1] * a.dim[2];
   if (n <= 0) return BNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_tsdf_integrate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+extern "C" int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+                                  const float origin_host[3], float voxel_size, float trunc_margin,
+                                  const float* depth_im, const float* color_im, int im_h, int im_w,
+                                  const float intr_host[9], const float pose_host[16], float obs_weight,
+                                  bnv_stream_t stream) {
+  return tsdf_integrate_impl(tsdf, weight, color, dim_host, origin_host, voxel_size, trunc_margin, depth_im, nullptr,
+                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, stream);
+}
+
+extern "C" int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+                                      const float origin_host[3], float voxel_size, float trunc_margin,
+                                      const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
+                                      const float intr_host[9], const float pose_host[16], float obs_weight,
+                                      bnv_stream_t stream) {
+  return tsdf_integrate_impl(tsdf, weight, color, dim_host, origin_host, voxel_size, trunc_margin, nullptr, depth_mm,
+                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, stream);
 }

@@ -280,10 +280,7 @@ class HipFrameBackend:
         counters, grid_ids, pcounts, feats = record_views(rec, rows)
         self.volume.integrate(grid_ids, feats, pcounts, n_dev=counters[2:3])
         if self.tsdf_vol is not None and frame is not None and "depth" in frame:
-            d = frame["depth"]
-            if d.dtype in (torch.uint16, torch.int16):
-                d = d.to(torch.float32) / 1000.0
-            self.tsdf_vol.integrate(frame.get("rgb"), d, frame["intr_mat"], frame["T_wc"], obs_weight=1.)
+            self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
 
     def decode_record(self, rec, rows):
         counters, grid_ids, _, _ = record_views(rec, rows)

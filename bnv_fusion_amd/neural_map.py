@@ -88,10 +88,8 @@ class NeuralMap:
         """run_e2e.py:99-109: TSDF side fusion of the same frame (depth in metres, no colour here)."""
         if self.tsdf_vol is None or "depth" not in frame:
             return
-        d = frame["depth"]
-        if d.dtype in (torch.uint16, torch.int16):
-            d = d.to(torch.float32) / 1000.0
-        self.tsdf_vol.integrate(frame.get("rgb"), d, frame["intr_mat"], frame["T_wc"], obs_weight=1.)
+        # uint16 millimetres go to the kernel as they are (converted per sample, no float copy of the frame)
+        self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
 
     def integrate(self, frame):
         """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU (or a depth frame, see

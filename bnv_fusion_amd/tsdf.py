@@ -31,7 +31,9 @@ class TSDFVolume:
 
     def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):
         """fusion.py:208-250.  depth_im [H, W] metres (numpy or tensor); color_im [H, W, 3] in [0, 255] or None."""
-        depth = torch.as_tensor(depth_im).to(self._dev, torch.float32).contiguous()
+        depth = torch.as_tensor(depth_im)
+        u16 = depth.dtype in (torch.uint16, torch.int16)     # the dataset's millimetres: converted in the kernel
+        depth = depth.to(self._dev).contiguous() if u16 else depth.to(self._dev, torch.float32).contiguous()
         im_h, im_w = int(depth.shape[0]), int(depth.shape[1])
         col = None
         if color_im is not None:
@@ -41,7 +43,8 @@ class TSDFVolume:
         org = (C.c_float * 3)(*self._vol_origin.tolist())
         intr = (C.c_float * 9)(*np.asarray(cam_intr, dtype=np.float64)[:3, :3].reshape(-1).astype(np.float32).tolist())
         pose = (C.c_float * 16)(*np.asarray(cam_pose, dtype=np.float64).reshape(-1).astype(np.float32).tolist())
-        _lib.check(self._lib.bnv_tsdf_integrate(
+        fn = self._lib.bnv_tsdf_integrate_u16 if u16 else self._lib.bnv_tsdf_integrate
+        _lib.check(fn(
             _lib.ptr(self.tsdf), _lib.ptr(self.weight), _lib.ptr(self.color if col is not None else None), dim, org,
             np.float32(self._voxel_size), np.float32(self._trunc_margin), _lib.ptr(depth), _lib.ptr(col), im_h, im_w,
             intr, pose, float(obs_weight), _lib.stream_ptr()), "bnv_tsdf_integrate")

@@ -133,6 +133,13 @@ int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t d
                        const float* depth_im, const float* color_im, int im_h, int im_w,
                        const float intr_host[9], const float pose_host[16], float obs_weight,
                        bnv_stream_t stream);
+/* The same with the depth image as the dataset stores it: uint16 millimetres, converted per sample as
+ * depth_mm / 1000 (common.py:93) inside the kernel -- no float copy of the frame. */
+int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+                       const float origin_host[3], float voxel_size, float trunc_margin,
+                       const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
+                       const float intr_host[9], const float pose_host[16], float obs_weight,
+                       bnv_stream_t stream);
 
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 

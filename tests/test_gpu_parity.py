@@ -819,3 +819,19 @@ def test_decode_pts_ragged_sizes_and_all_masked_vs_oracle(bnv, model, golden_vol
                 assert bool((out0 == vol.voxel_size).all())
             if kind == "live" and n >= 7:
                 assert float((out0 != vol.voxel_size).float().mean()) > 0.5
+
+
+def test_tsdf_uint16_depth_equals_float_metres(bnv):
+    """bnv_tsdf_integrate_u16 converts the dataset's millimetres inside the kernel (correctly rounded / 1000, what
+    cv2.imread(...) / 1000. -> float32 gives in the reference): same volume as feeding float32 metres."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.tsdf import TSDFVolume
+    bounds = np.array([[-1.27, 1.27]] * 3)
+    a, b = TSDFVolume(bounds, 0.025, device=DEV), TSDFVolume(bounds, 0.025, device=DEV)
+    for t in range(3):
+        d16 = synthetic.depth_u16(t, 240, 320)
+        metres = (d16.astype(np.float64) / 1000.0).astype(np.float32)
+        a.integrate(None, torch.from_numpy(d16).to(DEV), synthetic.intrinsics(240, 320), synthetic.pose(t))
+        b.integrate(None, torch.from_numpy(metres).to(DEV), synthetic.intrinsics(240, 320), synthetic.pose(t))
+    assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight)
+    assert float((a.weight > 0).float().mean()) > 0.01
