@@ -1413,13 +1413,23 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
     }
   };
 
+  // ---- tiles are handed out DYNAMICALLY (one atomic per tile on a counter in the workspace, fetched one tile
+  // ahead): when another stream's kernel still holds some CUs at launch (the next frame's encoder, an RCCL
+  // collective), the workgroups that start late simply take fewer tiles instead of stretching the kernel's tail
+  __shared__ int s_tile[3];
+  int* tile_ctr = (int*)A.n_list + 2;
+  if (threadIdx.x == 0) {
+    s_tile[0] = atomicAdd(tile_ctr, 1);
+    s_tile[1] = atomicAdd(tile_ctr, 1);
+  }
+  __syncthreads();
   // ---- prologue: inputs of the first tile into PARK, entry of the second tile, first weight fragments
-  int64_t tile = blockIdx.x;
+  int64_t tile = s_tile[0], tile_nx = s_tile[1];
   int ent_cur = -1, ent_nx = -1;
   f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
   if (gatherer) {
     if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
-    if (tile + gridDim.x < n_tiles) ent_nx = lattice_entry(A, (tile + gridDim.x) * DM + threadIdx.x, n_evals);
+    if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + threadIdx.x, n_evals);
     load_feats(ent_cur, f0, f1);
     stage_park(threadIdx.x, ent_cur, f0, f1);
   }
@@ -1442,22 +1452,26 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
   const float* park_hl = lds + T_PARK_LO + (h * DM + j) * 4;
   const float* hl_hh = lds + L_HL + (h * DM + j) * 4;
   const float* hl_hl = lds + L_HLO + (h * DM + j) * 4;
-  for (; tile < n_tiles; tile += gridDim.x) {
-    // ---- requests for the following tiles (gather lanes): features of tile+1, entry of tile+2 --------
+  while (tile < n_tiles) {
+    // ---- requests for the following tiles: the id of the tile after next (thread 0; everybody reads it behind
+    // the next barrier), features of the next tile (gather lanes) --------------------------------------------
+    if (threadIdx.x == 0) s_tile[2] = atomicAdd(tile_ctr, 1);
     int ent_nx2 = -1;
     if (gatherer) {
       f0 = f32x4{0.f, 0.f, 0.f, 0.f};
       f1 = f32x4{0.f, 0.f, 0.f, 0.f};
       load_feats(ent_nx, f0, f1);
-      const int64_t t2 = tile + 2 * (int64_t)gridDim.x;
-      if (t2 < n_tiles) ent_nx2 = lattice_entry(A, t2 * DM + threadIdx.x, n_evals);
     }
     f32x16 acc[4];
     // layer 0 (B from PARK); K-steps 0, 1 of the tile; requests fragments 1, 2 of layer 1 (0 is in the ring)
     chain_layer<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, w, h);
     __syncthreads();
+    const int64_t tile_nx2 = s_tile[2];
     store_relu_h<NPROD>(lds, acc, w, j, h);
-    if (gatherer) stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
+    if (gatherer) {
+      stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
+      if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + threadIdx.x, n_evals);
+    }
     __syncthreads();
     chain_layer<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, w, h);
     __syncthreads();
@@ -1493,6 +1507,8 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
       ent_cur = ent_nx;
       ent_nx = ent_nx2;
     }
+    tile = tile_nx;
+    tile_nx = tile_nx2;
   }
 }
 
@@ -2172,7 +2188,7 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  if (build_list) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 4, stream));
+  if (build_list) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 16, stream));  // rows listed, (entries), tile counter, spare
   if (n == 0) return BNV_OK;
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
@@ -2188,7 +2204,7 @@ int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, v
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 4, stream));
+  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));  // entries listed, tile counter of the table kernel, spare
   if (n == 0) return BNV_OK;
   hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
