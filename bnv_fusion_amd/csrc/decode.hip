@@ -1510,6 +1510,16 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
     tile = tile_nx;
     tile_nx = tile_nx2;
   }
+  // the last workgroup to leave resets the hand-out counter (word 2) and the exit count (word 3), so the kernel
+  // can be launched again without any host-side reset
+  if (threadIdx.x == 0) {
+    int* done = (int*)A.n_list + 3;
+    __threadfence();
+    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+      *tile_ctr = 0;
+      *done = 0;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -835,3 +835,34 @@ def test_tsdf_uint16_depth_equals_float_metres(bnv):
         b.integrate(None, torch.from_numpy(metres).to(DEV), synthetic.intrinsics(240, 320), synthetic.pose(t))
     assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight)
     assert float((a.weight > 0).float().mean()) > 0.01
+
+
+def test_lattice_table_stage_can_be_relaunched(bnv, model, golden_volume):
+    """The staged C API: the table kernel hands tiles out from a counter in the workspace and resets it itself, so
+    bnv_lattice_table can be called again (e.g. after changing features) without re-running the earlier stages."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib
+    vol = golden_volume
+    lib = _lib.load()
+    coords = vol.active_coordinates
+    ref = vol.decode_lattice(coords, model.nerf, None, query_tensor=True).clone()
+    n = int(coords.shape[0])
+    f, w, _, lim = vol._snapshot()
+    d, _keep = vol._delta(None)
+    ws = vol._lattice_ws
+    vol._lattice_epoch += 1
+    args = (C.byref(vol._struct()), C.byref(vol._grid))
+    _lib.check(lib.bnv_lattice_neighbors(*args, _lib.ptr(w), int(lim), _lib.ptr(coords.contiguous()), n, None, None, 0,
+                                         _lib.ptr(ws), ws.numel(), vol._lattice_epoch, _lib.stream_ptr()), "neighbors")
+    _lib.check(lib.bnv_lattice_mark(args[0], n, None, _lib.ptr(ws), ws.numel(), vol._lattice_epoch, _lib.stream_ptr()),
+               "mark")
+    out = torch.empty((n, 27), device=DEV)
+    for rep in range(3):      # the same entry list three times: every launch must do the full work again
+        if rep:
+            off = int(lib.bnv_decode_lattice_table_offset(vol._row_capacity))
+            ws[off: off + 4 * 27 * int(lim)].zero_()          # wipe the table: it has to be recomputed
+        _lib.check(lib.bnv_lattice_table(*args, _lib.ptr(f), _lib.ptr(model.nerf.sdf_pack), n, 1, _lib.ptr(ws),
+                                         ws.numel(), _lib.stream_ptr()), "table")
+        _lib.check(lib.bnv_lattice_blend(*args, _lib.ptr(coords.contiguous()), n, None, C.byref(d), _lib.ptr(ws),
+                                         ws.numel(), _lib.ptr(out), _lib.stream_ptr()), "blend")
+        assert torch.equal(out, ref), rep
