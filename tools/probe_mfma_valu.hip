@@ -26,6 +26,39 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
 #pragma unroll
       for (int u = 0; u < 12; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[u & 3], 0, 0, 0);
     }
+  } else if (role == 4) {   // v_mfma_f32_16x16x32_f16: 4 accumulator registers, 4 passes
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v c[4];
+    for (int a = 0; a < 4; ++a) c[a] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 24; ++u) c[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, c[u & 3], 0, 0, 0);
+    }
+    for (int a = 0; a < 4; ++a) acc[0][a] += c[a][0];
+  } else if (role == 5) {   // SAME wave: 12 MFMAs with 8 independent VALU ops behind each
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[u & 3], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_fmaf(v[q], 1.0001f, 0.5f);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (role == 6) {   // ... 16 behind each
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, acc[u & 3], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = __builtin_fmaf(v[q], 1.0001f, 0.5f);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else if (role == 2) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -70,6 +103,12 @@ int main() {
   run("VALU fma x96 alone (younger)", 0, 2);
   run("MFMA x12 (older) + VALU fma x96 (younger)", 1, 2);
   run("VALU fma x96 (older) + MFMA x12 (younger)", 2, 1);
+  run("MFMA 16x16x32 x24 alone (older)", 4, 0);
+  run("MFMA 16x16x32 x24 (older) + VALU fma x96 (younger)", 4, 2);
+  run("VALU fma x96 (older) + MFMA 16x16x32 x24 (younger)", 2, 4);
+  run("same wave: 12 x (MFMA + 8 VALU), alone", 5, 0);
+  run("same wave: 12 x (MFMA + 16 VALU), alone", 6, 0);
+  run("same wave: 12 x (MFMA + 8 VALU), both waves", 5, 5);
   run("cvt mix x24 alone (younger)", 0, 3);
   run("MFMA x12 (older) + cvt mix x24 (younger)", 1, 3);
   run("cvt mix x24 (older) + MFMA x12 (younger)", 3, 1);
