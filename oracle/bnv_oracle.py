@@ -9,13 +9,16 @@ fallback.
 
 Parity pin: the reference has no tests of its own, so the
 oracle is pinned against outputs of the reference itself, captured in the build
-container by ``tests/golden/make_golden.py`` (reference imported under the
+container by ``tests/golden/make_golden*.py`` (reference imported under the
 shims of ``tests/golden/ref_shims.py``) and committed as ``tests/golden/*.npz``;
 ``tests/test_oracle_golden.py`` checks this file against every one of them
-(voxel ids / counts bit-exact, floats to <= 1e-6).  The tcnn (fp16
-FullyFusedMLP) variant is the exception: its reference arithmetic is CUDA-only
-and cannot be executed here, so ``tcnn_*`` below is "parity unpinned" (layout
-verified statistically in SURVEY.md Appendix A only).
+(voxel ids / counts bit-exact, floats to <= 1e-6; gradients and the optimiser's
+ray loss from the reference's autograd; the TSDF side fusion from the
+reference's CPU fallback).  NOT pinned, and said so where they are defined:
+the tcnn (fp16 FullyFusedMLP) variant -- its reference arithmetic is CUDA-only
+(layout verified statistically in SURVEY.md Appendix A only); the Sobel
+normals of the depth front end (kornia absent); marching cubes (scikit-image
+absent).
 
 All file:line citations are relative to /root/reference.
 """
@@ -470,11 +473,18 @@ def depth_to_input_pts(depth, intr, T_wc, max_depth=10.0):
     return out[mask.reshape(-1)]
 
 
-def tsdf_integrate(tsdf, weight, vol_origin, voxel_size, depth_im, cam_intr, cam_pose, obs_weight=1.0):
-    """TSDFVolume.integrate as its inline CUDA kernel computes it (third_parties/fusion.py:68-126), in
-    numpy float32, un-fused multiply-adds.  PARITY UNPINNED: the kernel needs pycuda, its CPU twin needs
-    numba, neither exists here; anchored on the source and on the call site run_e2e.py:99-109.
-    tsdf / weight [X, Y, Z] float32 are updated in place; colour is not restated."""
+def tsdf_integrate(tsdf, weight, vol_origin, voxel_size, depth_im, cam_intr, cam_pose, obs_weight=1.0,
+                   cpu_path=False):
+    """TSDFVolume.integrate (third_parties/fusion.py).  tsdf / weight [X, Y, Z] float32 are updated in place;
+    colour is not restated.
+
+    Default: as the inline CUDA kernel computes it (:68-126) -- float32 throughout, un-fused multiply-adds,
+    transposed rotation, ``roundf`` (half away from zero) for the pixel; this is what the reference runs on a GPU
+    box and what csrc/tsdf.hip follows.  ``cpu_path=True``: as the reference's CPU fallback computes it
+    (:283-305) -- camera points through ``np.linalg.inv(cam_pose)`` in float64, ``np.round`` (half to even).
+    PIN: tests/golden/tsdf_40.npz was captured from that CPU fallback (make_golden_tsdf.py; numba shimmed as plain
+    Python); ``cpu_path=True`` reproduces it, and the default differs from it only in the ~1 % of voxels whose
+    projection falls within rounding distance of a pixel boundary."""
     f = np.float32
     X, Y, Z = tsdf.shape
     vx, vy, vz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
@@ -484,6 +494,29 @@ def tsdf_integrate(tsdf, weight, vol_origin, voxel_size, depth_im, cam_intr, cam
     K = np.asarray(cam_intr, dtype=np.float64)[:3, :3].astype(f)
     P = np.asarray(cam_pose, dtype=np.float64).astype(f)
     pt = [org[i] + v.astype(f) * vs for i, v in enumerate((vx, vy, vz))]
+    if cpu_path:
+        # vox2world (float32) -> rigid_transform with the inverted pose (float64) -> cam2pix (fusion.py:171-195)
+        Tinv = np.linalg.inv(np.asarray(cam_pose))
+        xyz = np.stack([p.astype(np.float32) for p in pt], -1).reshape(-1, 3)
+        cam_all = (Tinv @ np.hstack([xyz, np.ones((len(xyz), 1), dtype=np.float32)]).T).T[:, :3]
+        cam = [cam_all[:, i].reshape(X, Y, Z) for i in range(3)]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ux = cam[0] * K[0, 0] / cam[2] + K[0, 2]
+            uy = cam[1] * K[1, 1] / cam[2] + K[1, 2]
+        rnd = lambda a: np.where(np.isfinite(a), np.round(a), -1).astype(np.int64)
+        px, py = rnd(ux), rnd(uy)
+        H, W = depth_im.shape
+        ok = (px >= 0) & (px < W) & (py >= 0) & (py < H) & (cam[2] > 0)
+        d = np.zeros(cam[2].shape)
+        d[ok] = np.asarray(depth_im)[py[ok], px[ok]]
+        diff = d - cam[2]
+        ok = (d > 0) & (diff >= -float(trunc))
+        dist = np.minimum(1, diff / float(trunc))
+        w_old = weight[ok]
+        w_new = (w_old + f(obs_weight)).astype(f)
+        tsdf[ok] = ((w_old * tsdf[ok] + f(obs_weight) * dist[ok].astype(f)) / w_new).astype(f)
+        weight[ok] = w_new
+        return tsdf, weight
     t = [pt[i] - P[i, 3] for i in range(3)]
     cam = [(P[0, i] * t[0] + P[1, i] * t[1]) + P[2, i] * t[2] for i in range(3)]
     with np.errstate(divide="ignore", invalid="ignore"):

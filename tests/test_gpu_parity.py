@@ -866,3 +866,25 @@ def test_lattice_table_stage_can_be_relaunched(bnv, model, golden_volume):
         _lib.check(lib.bnv_lattice_blend(*args, _lib.ptr(coords.contiguous()), n, None, C.byref(d), _lib.ptr(ws),
                                          ws.numel(), _lib.ptr(out), _lib.stream_ptr()), "blend")
         assert torch.equal(out, ref), rep
+
+
+def test_tsdf_kernel_vs_reference_cpu_path_golden(bnv, orc):
+    """The HIP TSDF kernel against the volume the reference's CPU fallback produced (tests/golden/tsdf_40.npz): equal
+    to 1e-6 except in the ~1 % of voxels whose projection ties between two pixels (the kernel rounds like the
+    reference's CUDA kernel, the fallback like numpy), where it must equal the oracle's CUDA-kernel flavour."""
+    from bnv_fusion_amd.tsdf import TSDFVolume
+    z = np.load(os.path.join(GOLDEN, "tsdf_40.npz"))
+    vol = TSDFVolume(z["bounds"].copy(), float(z["voxel_size"]), device=DEV)
+    assert tuple(vol.tsdf.shape) == z["tsdf"].shape
+    dims = z["tsdf"].shape
+    o_tsdf = np.full(dims, -5 * 0.025, dtype=np.float32)
+    o_w = np.zeros(dims, dtype=np.float32)
+    for d, T in zip(z["depths"], z["poses"]):
+        vol.integrate(None, torch.from_numpy(d).to(DEV), z["intr"], T)
+        orc.tsdf_integrate(o_tsdf, o_w, z["origin"], float(z["voxel_size"]), d, z["intr"], T)
+    got, gw = vol.tsdf.cpu().numpy(), vol.weight.cpu().numpy()
+    observed = int((z["weight"] > 0).sum())
+    off = np.abs(got - z["tsdf"]) > 1e-6
+    assert off.sum() <= 0.015 * observed and np.abs(got - z["tsdf"])[~off].max() <= 1e-6
+    assert (gw != z["weight"]).sum() <= 0.002 * gw.size
+    assert np.abs(got - o_tsdf).max() <= 1e-6 and np.array_equal(gw, o_w)     # == the CUDA-kernel flavour everywhere

@@ -189,3 +189,24 @@ def test_calculate_loss_matches_reference(sd, insertion_volume):
     loss.backward()
     ref = op["grad_features"]
     assert np.abs(vol.features.grad.numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_tsdf_integrate_matches_reference_cpu_path():
+    """tests/golden/tsdf_40.npz: three frames through the reference's own CPU fallback of TSDFVolume.integrate
+    (make_golden_tsdf.py).  The oracle's cpu_path flavour reproduces it; the default (CUDA-kernel) flavour differs
+    only where the projection of a voxel centre falls within rounding distance of a pixel boundary."""
+    z = np.load(os.path.join(GOLDEN, "tsdf_40.npz"))
+    dims = z["tsdf"].shape
+    res = {}
+    for cpu in (True, False):
+        tsdf = np.full(dims, -5 * 0.025, dtype=np.float32)
+        w = np.zeros(dims, dtype=np.float32)
+        for d, T in zip(z["depths"], z["poses"]):
+            orc.tsdf_integrate(tsdf, w, z["origin"], float(z["voxel_size"]), d, z["intr"], T, cpu_path=cpu)
+        res[cpu] = (tsdf, w)
+    assert np.array_equal(res[True][1], z["weight"])
+    assert np.abs(res[True][0] - z["tsdf"]).max() <= 2e-7
+    observed = int((z["weight"] > 0).sum())
+    off = np.abs(res[False][0] - z["tsdf"]) > 1e-6
+    assert observed > 10000 and off.sum() <= 0.015 * observed          # pixel-boundary ties only
+    assert np.abs(res[False][0] - z["tsdf"])[~off].max() <= 1e-6
