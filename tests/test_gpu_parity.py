@@ -888,3 +888,15 @@ def test_tsdf_kernel_vs_reference_cpu_path_golden(bnv, orc):
     assert off.sum() <= 0.015 * observed and np.abs(got - z["tsdf"])[~off].max() <= 1e-6
     assert (gw != z["weight"]).sum() <= 0.002 * gw.size
     assert np.abs(got - o_tsdf).max() <= 1e-6 and np.array_equal(gw, o_w)     # == the CUDA-kernel flavour everywhere
+
+
+def test_depth_front_end_points_vs_reference_golden(bnv):
+    """The HIP front end against points produced by the reference's own functions (tests/golden/frontend_120.npz)."""
+    from bnv_fusion_amd.frontend import depth_to_input_pts
+    z = np.load(os.path.join(GOLDEN, "frontend_120.npz"))
+    pts = depth_to_input_pts(torch.from_numpy(z["depth"]).to(DEV), z["intr"], z["T_wc"],
+                             max_depth=float(z["max_depth"]))[0].cpu().numpy()
+    ref = z["pts_w"].astype(np.float32)
+    assert pts.shape == (int(z["n_valid"]), 6)
+    same = (pts[:, :3] == ref).all(1).mean()
+    assert same > 0.999 and np.abs(pts[:, :3] - ref).max() <= 2e-7        # float64 kernel, <= 1 ulp after the cast

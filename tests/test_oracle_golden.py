@@ -210,3 +210,14 @@ def test_tsdf_integrate_matches_reference_cpu_path():
     off = np.abs(res[False][0] - z["tsdf"]) > 1e-6
     assert observed > 10000 and off.sum() <= 0.015 * observed          # pixel-boundary ties only
     assert np.abs(res[False][0] - z["tsdf"])[~off].max() <= 1e-6
+
+
+def test_depth_front_end_points_match_reference_functions():
+    """tests/golden/frontend_120.npz: world points through the reference's geometry.depth2xyz + get_homogeneous as
+    FusionInferenceAbstractDataset.__getitem__ calls them (make_golden_frontend.py).  The normals stay unpinned
+    (kornia absent)."""
+    z = np.load(os.path.join(GOLDEN, "frontend_120.npz"))
+    p = orc.depth_to_input_pts(z["depth"], z["intr"], z["T_wc"], float(z["max_depth"]))
+    assert p.shape == (int(z["n_valid"]), 6)
+    assert np.abs(p[:, :3] - z["pts_w"]).max() <= 1e-15
+    assert np.array_equal(p[:, :3].astype(np.float32), z["pts_w"].astype(np.float32))   # what run_e2e.py:249 feeds on
