@@ -103,7 +103,13 @@ int bnv_get_mlp_mode(void);
 
 /* Tuning switches (A/B experiments; defaults are the measured-best):
  *   "lattice_h64"  0 (default): lattice-table MLP in split mode uses 128-evaluation tiles, 1 workgroup per CU;
- *                  1: 64-evaluation tiles, 2 workgroups per CU (measured about 4 % slower). */
+ *                  1: 64-evaluation tiles, 2 workgroups per CU (measured about 4 % slower);
+ *   "lattice_pipe"  1 (default): lattice-table MLP of modes 1 and 3 runs k_lattice_table_h (operands prefetched
+ *                  across tiles and layers, dynamic tile hand-out); 0: the generic k_decode<LATTICE> (bit-identical
+ *                  tables, 3-5 % slower);
+ *   "encoder_overlap"  0 (default); 1: point encoder with the output block in the outer loop (bit-identical
+ *                  features, no measurable gain: MFMA and VALU do not co-execute on a SIMD of this part).
+ * Unknown names return BNV_ERR_INVALID_ARGUMENT. */
 int bnv_set_option(const char* name, int value);
 
 /* Optional timing of the dominant kernels with HIP events recorded on their launch stream.
