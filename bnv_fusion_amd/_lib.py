@@ -19,7 +19,7 @@ SYMBOLS = [
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
-    "bnv_mc_count", "bnv_mc_emit", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
+    "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
 
@@ -91,6 +91,7 @@ def load():
         "bnv_sdfmlp_tcnn_bwd_pack_floats": (sz, []),
         "bnv_decode_pts_backward": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, vp, i64,
                                               C.c_int, vp, vp, vp]),
+        "bnv_png_unfilter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp]),
         "bnv_ray_samples": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp,
                                       C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
         "bnv_ray_loss": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp]),

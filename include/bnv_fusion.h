@@ -244,6 +244,13 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol_host, const bnv_grid_t* grid
                             int64_t n, int is_coords, const float* grad_sdf, float* grad_features,
                             bnv_stream_t stream);
 
+/* ---- dataset formats (host only) ----------------------------------------------------------------- */
+
+/* Reverses the PNG scanline filters of an inflated IDAT stream (the reference reads its 16-bit depth PNGs with
+ * cv2.imread(path, -1), src/utils/common.py:93; bnv_fusion_amd/datasets.py parses the container).  raw: height
+ * scanlines of 1 filter byte + row_bytes data bytes; bpp: bytes per pixel; out: height * row_bytes bytes. */
+int bnv_png_unfilter(const uint8_t* raw, int height, int row_bytes, int bpp, uint8_t* out);
+
 /* ---- global optimiser: ray sampling + SDF ray loss, fused ------------------------------------------ */
 
 /* One ray split of render_utils.py:461-549 up to the decode.  Per ray: the ray through pixel uv
