@@ -902,18 +902,26 @@ def test_depth_front_end_points_vs_reference_golden(bnv):
     assert same > 0.999 and np.abs(pts[:, :3] - ref).max() <= 2e-7        # float64 kernel, <= 1 ulp after the cast
 
 
-def test_run_e2e_example_on_a_written_sequence(tmp_path):
-    """examples/run_e2e.py (the reference's main loop: read the sequence directory, fuse, optimise, mesh, save) as a
-    child process on a small synthetic sequence written in the reference's on-disk layout."""
-    import subprocess
+def test_run_e2e_example_on_a_written_sequence(tmp_path, monkeypatch, capsys):
+    """examples/run_e2e.py (the reference's main loop: read the sequence directory, fuse, optimise, mesh, save) on a
+    small synthetic sequence written in the reference's on-disk layout.  Run in-process (no exec from a process that
+    has initialised the GPU)."""
+    import importlib.util
     import sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("run_e2e_example", os.path.join(root, "examples", "run_e2e.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
     out = tmp_path / "out"
-    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_e2e.py"), "--synthetic", "10", "--out",
-                        str(out), "--voxel-size", "0.02", "--height", "240", "--width", "320", "--mode", "demo",
-                        "--optim-interval", "5"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert "speed on local fusion" in r.stdout and "speed on global fusion" in r.stdout
+    monkeypatch.setattr(sys, "argv", ["run_e2e.py", "--synthetic", "10", "--out", str(out), "--voxel-size", "0.02",
+                                      "--height", "240", "--width", "320", "--mode", "demo", "--optim-interval", "5"])
+    try:
+        mod.main()
+    finally:
+        import bnv_fusion_amd
+        bnv_fusion_amd.set_mlp_mode(1)
+    printed = capsys.readouterr().out
+    assert "speed on local fusion" in printed and "speed on global fusion" in printed
     # (no 0.ply: after one frame no voxel has reached min_pts_in_grid yet, there is nothing to mesh)
     for f in ("before_optim.ply", "final.ply", "final_sparse_volume.pth", "scene0.npy", "5.ply"):
         assert (out / f).exists(), f
