@@ -1868,16 +1868,23 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     }
     // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
     // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
+    // An entry (corner row, local offset) belongs to exactly ONE lattice point, so a point that is handled once
+    // needs no de-duplication: this voxel is the owner (all offsets >= 0, floor(point) == voxel) -> plain append.
+    // Only a point whose owner voxel is NOT decoded in this call can be reached from several voxels; those few go
+    // through the need_mask atomics.
+    bool shared = false;
     if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
       const int owner = nbr_rows[b * 27 + ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
       if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
+      shared = true;
     }
     if (live) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         if (rowk[k] < 0) continue;
         const uint32_t bit = 1u << lk[k];
-        if (!(atomicOr(&need_mask[rowk[k]], bit) & bit)) s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];
+        if (shared && (atomicOr(&need_mask[rowk[k]], bit) & bit)) continue;
+        s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];
       }
     }
   }
