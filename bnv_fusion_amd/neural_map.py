@@ -1,10 +1,11 @@
-"""NeuralMap -- the per-frame driver of the reference (src/run_e2e.py:27-109, 164-167) reduced to
-the hot path: encode -> track_n_pts -> _integrate -> (decode of the voxels this frame touched).
+"""NeuralMap -- the driver object of the reference (src/run_e2e.py:27-194) on the HIP path:
 
-``integrate(frame)`` has the reference's contract (run_e2e.py:78-98; the TSDF side fusion of
-:99-109 is a "next" row).  ``fuse_and_decode`` is one unit of the benchmark metric
-("depth frames/sec fused+decoded"): it additionally decodes the 3x3x3 meshing
-lattice of every voxel the frame's encode returned.
+* ``integrate(frame)``            run_e2e.py:78-109: encode -> track_n_pts -> _integrate (+ TSDF side fusion);
+* ``fuse_and_decode[_async]``     one unit of the benchmark metric ("depth frames/sec fused+decoded", SURVEY.md
+                                  section 8d): integrate + the 3x3x3 meshing lattice of every voxel the frame's
+                                  encode returned; the async form never synchronises with the host;
+* ``optimize``                    run_e2e.py:111-162: the global optimiser over ``self.frames``;
+* ``extract_mesh`` / ``save``     run_e2e.py:164-194.
 """
 import torch
 
