@@ -4,12 +4,15 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-One step = one synthetic 640x480 frame: encode_pointcloud + _integrate into the persistent volume
-(fused) + SDF decode of the 3x3x3 lattice of every voxel that encode returned (decoded).  Inputs are
-resident in HBM before the timed region.  N > 1 is launched by torch.distributed.run, one rank per
-GPU: the active-voxel set is sharded by spatial hash and corner-voxel SDF tables are exchanged with
-one RCCL all-gather per frame (bnv_fusion_amd/distributed.py) -- strong scaling of one frame stream.
-Rank 0 prints ONE JSON line.
+One step = one synthetic 640x480 frame: uint16 depth image -> points + normals (GPU front end) ->
+encode_pointcloud + _integrate into the persistent volume (+ TSDF side fusion) (fused) + SDF decode of the
+3x3x3 lattice of every voxel that encode returned (decoded).  Inputs are resident in HBM before the timed
+region.  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL: by default frame-parallel
+(ranks encode / decode different frames of a batch, replicated volume, one all-gather of encoded voxels per
+batch); --parallelism spatial shards the active-voxel set by spatial hash and exchanges corner-voxel SDF tables
+per frame (bnv_fusion_amd/distributed.py).  Strong scaling of one frame stream.
+Rank 0 prints ONE JSON line: metric / value plus `roofline` (dominant kernel, timed alone), `kernels`,
+`parity` (spot check against the oracle), `other_mlp_modes`, `cpu_baseline` (the oracle on the host cores).
 """
 import argparse
 import ctypes as C
