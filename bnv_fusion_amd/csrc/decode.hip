@@ -1974,7 +1974,7 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
-  int64_t grid = g_num_cus;
+  int64_t grid = g_num_cus - g_reserve_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
   if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
@@ -2085,6 +2085,11 @@ int bnv_set_option(const char* name, int value) {
   }
   if (!strcmp(name, "lattice_pipe")) {
     g_lattice_pipe = value;
+    return BNV_OK;
+  }
+  if (!strcmp(name, "reserve_cus")) {
+    if (value < 0 || value >= g_num_cus) return BNV_ERR_INVALID_ARGUMENT;
+    g_reserve_cus = value;
     return BNV_OK;
   }
   if (!strcmp(name, "encoder_overlap")) {

@@ -24,6 +24,7 @@ namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
+int g_reserve_cus = 0;  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
 int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
@@ -1251,7 +1252,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   BNV_LAUNCH_CHECK();
   // point encoder + scatter
   const int n_tiles = ((n + 31) / 32) * 8;
-  int grid_pn = g_num_cus;
+  int grid_pn = g_num_cus - g_reserve_cus > 0 ? g_num_cus - g_reserve_cus : 1;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
   {
     ProfScope prof(PROF_POINTNET, stream);

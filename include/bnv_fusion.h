@@ -109,6 +109,10 @@ int bnv_get_mlp_mode(void);
  *                  tables, 3-5 % slower);
  *   "encoder_overlap"  0 (default); 1: point encoder with the output block in the outer loop (bit-identical
  *                  features, no measurable gain: MFMA and VALU do not co-execute on a SIMD of this part).
+ *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
+ *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
+ *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside
+ *                  the decode in the multi-GPU mode).
  * Unknown names return BNV_ERR_INVALID_ARGUMENT. */
 int bnv_set_option(const char* name, int value);
 
