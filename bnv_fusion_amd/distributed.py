@@ -388,6 +388,13 @@ class FrameParallelNeuralMap:
         self.volume = getattr(self.backend, "volume", None)
         self.rows = record_rows
         self._last = None
+        # The persistent MLP kernels fill every CU (1 workgroup each, most of the LDS and VGPRs), so an RCCL kernel
+        # that becomes ready while one of them runs would wait for its tail.  With more than one rank they leave a
+        # few CUs free for the collective (about 3 % of MFMA throughput).  NOT measured on a multi-GPU node from
+        # here (one GPU available); BNV_RESERVE_CUS overrides, 0 disables.
+        if self.world > 1 and getattr(getattr(self.backend, "dev", None), "type", "cpu") == "cuda":
+            import os
+            _lib.load().bnv_set_option(b"reserve_cus", int(os.environ.get("BNV_RESERVE_CUS", "8")))
         self._unsettled = []      # batches whose host bookkeeping has not been done yet (oldest first)
         self.max_unsettled = 3    # the host may run this many batches ahead of the GPU before it waits
 
