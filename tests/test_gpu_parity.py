@@ -926,3 +926,48 @@ def test_run_e2e_example_on_a_written_sequence(tmp_path, monkeypatch, capsys):
     for f in ("before_optim.ply", "final.ply", "final_sparse_volume.pth", "scene0.npy", "5.ply"):
         assert (out / f).exists(), f
     assert (out / "final.ply").stat().st_size > 100000
+
+
+def test_empty_frames_in_the_async_and_frame_parallel_pipelines(bnv):
+    """A frame with no valid depth (all zeros) in the middle of a sequence: the reference's integrate() returns early
+    (encode gives 5 x None, run_e2e.py:91-92); here the device-side counts are 0 and every later kernel is a no-op.
+    The frames around it must fuse and decode exactly as without it."""
+    import socket
+    import torch.distributed as dist
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+    dims, voxel = synthetic.GRID_DIMS[128]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    mk = lambda t: {"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+                    "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)}
+    good = [mk(t) for t in range(9)]
+    empty = {"depth": torch.zeros((240, 320), dtype=torch.uint16, device=DEV), "intr_mat": synthetic.intrinsics(240, 320),
+             "T_wc": synthetic.pose(4)}
+    seq = good[:4] + [empty] + good[4:]
+    ref_nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    ref = [ref_nm.fuse_and_decode(f) for f in good]
+    nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    handles = [nm.fuse_and_decode_async(f) for f in seq]
+    got = [h.result() for h in handles]
+    assert got[4] == (None, None)
+    for (c0, s0), (c1, s1) in zip(ref, got[:4] + got[5:]):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    assert nm.volume.num_rows() == ref_nm.volume.num_rows()
+    created = False
+    if not dist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        created = True
+    try:
+        fp = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+        out = [h.result() for h in fp.process_stream([[f] for f in seq])]
+        fp.flush()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert out[4] == (None, None)
+    for (c0, s0), (c1, s1) in zip(ref, out[:4] + out[5:]):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    assert np.allclose(fp.volume.n_pts_list, ref_nm.volume.n_pts_list)
