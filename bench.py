@@ -10,7 +10,8 @@ encode_pointcloud + _integrate into the persistent volume (+ TSDF side fusion) (
 region.  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL: by default frame-parallel
 (ranks encode / decode different frames of a batch, replicated volume, one all-gather of encoded voxels per
 batch); --parallelism spatial shards the active-voxel set by spatial hash and exchanges corner-voxel SDF tables
-per frame (bnv_fusion_amd/distributed.py).  Strong scaling of one frame stream.
+per frame (bnv_fusion_amd/distributed.py).  In frame-parallel mode one step is one batch
+of N consecutive frames of the same stream (one per rank; weak scaling), `value` counts all of them.
 Rank 0 prints ONE JSON line: metric / value plus `roofline` (dominant kernel, timed alone), `kernels`,
 `parity` (spot check against the oracle), `other_mlp_modes`, `cpu_baseline` (the oracle on the host cores).
 """
@@ -178,7 +179,10 @@ def main():
         nm.overlap_encode = not args.no_stream_overlap
 
     # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
-    n_frames = args.preroll + args.warmup + args.steps
+    # frames per step: one frame on one GPU; in frame-parallel mode a step is one batch = one frame PER RANK
+    # (weak scaling: per-GPU work per step is fixed, `value` counts the frames of all ranks)
+    fpu = world if frame_parallel else 1
+    n_frames = args.preroll + (args.warmup + args.steps) * fpu
     depth_host = [synthetic.depth_u16(t) for t in range(n_frames)]
     intr = synthetic.intrinsics()
     if args.input == "depth":
@@ -231,10 +235,11 @@ def main():
     lib = _lib.load()
 
     def timed(mode, first, steps, warm):
-        """`warm` untimed frames, then times exactly `steps` frames from index `first`, in MLP mode `mode`."""
+        """`warm` untimed steps, then times exactly `steps` steps (`fpu` frames each) from frame index `first`, in
+        MLP mode `mode`."""
         if mode != 2:
             bnv.set_mlp_mode(mode)
-        run_frames(first - warm, warm)
+        run_frames(first - warm * fpu, warm * fpu)
         lib.bnv_profile_enable(1)
         table_rows, n_vox = [], []
         if world > 1:
@@ -246,7 +251,7 @@ def main():
             n_vox.append(0 if c is None else int(c.shape[0]))
 
         if frame_parallel:
-            coords, sdf = run_frames(first, steps)
+            coords, sdf = run_frames(first, steps * fpu)
             table_rows.append(nm.volume.last_lattice_evals().clone() if coords is not None
                               else torch.zeros(1, dtype=torch.int32, device=dev))
             n_vox.append(0 if coords is None else int(coords.shape[0]))
@@ -276,13 +281,13 @@ def main():
         enc_ms = prof_ms[0] / max(prof_n[0], 1)
         dec_flop = float(rows.mean()) * (FLOP_PER_EVAL_TCNN if mode == 2 else FLOP_PER_EVAL)
         enc_flop = 8.0 * n_points * (FLOP_PER_PAIR_TCNN if mode == 2 else FLOP_PER_PAIR)
-        return {"elapsed": elapsed, "steps": steps, "fps": steps / elapsed, "rows": float(rows.mean()),
+        return {"elapsed": elapsed, "steps": steps, "fps": steps * fpu / elapsed, "rows": float(rows.mean()),
                 "n_vox": float(np.mean(n_vox)), "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
                 "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
                 "enc_tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0, "dec_flop": dec_flop,
                 "coords": coords, "sdf": sdf}
 
-    first = args.preroll + args.warmup
+    first = args.preroll + args.warmup * fpu
     main_run = timed(args.mlp_mode, first, args.steps, args.warmup)
     elapsed = main_run["elapsed"]
     # parity spot check of a configuration against the oracle (40 voxels of its last frame): the SDF decoded by
@@ -344,13 +349,14 @@ def main():
         bnv.set_mlp_mode(args.mlp_mode)
 
     if rank == 0:
-        fps = args.steps / elapsed
+        fps = args.steps * fpu / elapsed
         m = args.mlp_mode
         peak = PEAK_TFLOPS[m]
         out = {
             "metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if (frame_parallel or world == 1) else "strong",
             "vs_baseline": None, "dtype": DTYPE[m], "data": "synthetic",
             "config": {"workload": f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, "
                                    f"voxel {voxel}, {'pointnet_tcnn.ckpt (fp16 tcnn)' if tcnn else 'fp32 pointnet.ckpt'} weights; step = "
@@ -362,11 +368,13 @@ def main():
                                    + "decode of the 3x3x3 lattice of every "
                                      "touched voxel",
                        "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
+                       "frames_per_step": fpu,
                        "mlp_mode": MODE_NAME[m],
                        "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
                        "decode_live_fraction": main_run["live"],
                        "parallelism": ("1 GPU" if world == 1 else
-                                       f"frame-parallel x{world}: ranks encode/decode different frames of a batch, "
+                                       f"frame-parallel x{world}: one step = one batch of {world} consecutive frames, ranks encode/decode "
+                                       "different frames of the batch, "
                                        "replicated volume, one RCCL all-gather of encoded voxels per batch"
                                        if frame_parallel else
                                        f"spatial-hash voxel sharding x{world} + RCCL all-gather of SDF tables per frame")},

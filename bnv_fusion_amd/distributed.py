@@ -205,33 +205,46 @@ class ShardedNeuralMap:
 # =============================================================================================
 # Frame-parallel mode: throughput scaling of one frame stream
 # =============================================================================================
-# ---------------------------------------------------------------------------------------------------
-# frame-parallel mode
-# ---------------------------------------------------------------------------------------------------
-# One encoded frame travels as a fixed-size flat int64 RECORD, struct-of-arrays so that every section is a
-# contiguous view the kernels read in place:
-#   [0, 8)            header: word 0 = int32 counters[0:2] ... exactly the 8 int32 device counters of
-#                     bnv_encode_pointcloud in words 0..3 (n_valid, n_unique | n_out, n_avg bits | error, -)
-#   [8, 8 + 3R)       grid_ids  [R, 3] int64
-#   [8 + 3R, 8 + 4R)  pcounts   [R]    int64
-#   [8 + 4R, 8 + 8R)  feats     [R, 8] float32
-# R = the record capacity, equal on every rank.  Rows >= n_out are don't-care.
+# One encoded frame travels in two pieces:
+#   HEADER   8 int64 words = the 8 int32 device counters of bnv_encode_pointcloud in words 0..3
+#            (n_valid, n_unique | n_out, n_avg bits | error, -); all-gathered first (64 B per rank), read by the host
+#            while the GPU still works on the previous batch;
+#   PAYLOAD  flat int64 [8 * rows], struct-of-arrays so that every section is a contiguous view the kernels read
+#            in place:  [0, 3*rows) grid_ids [rows, 3] int64 | [3*rows, 4*rows) pcounts [rows] int64 |
+#            [4*rows, 8*rows) feats [rows, 8] float32.  (One packing launch + ONE all-gather: measured faster than
+#            all-gathering the encoder's three output arrays separately, every collective costs ~15 us.)
+# rows = the largest n_out of the batch (from the headers, rounded up to ROW_QUANTUM), equal on every rank, so the
+# payload all-gather moves what the batch really holds (64 B per emitted voxel) instead of the worst-case bound.
+# Rows >= a frame's n_out are don't-care.
 REC_HDR = 8
+ROW_QUANTUM = 1024
 
 
-def record_words(rows):
-    return REC_HDR + 8 * int(rows)
+def payload_words(rows):
+    return 8 * int(rows)
 
 
-def record_views(rec, rows):
-    """-> (counters int32 [8], grid_ids [R, 3] i64, pcounts [R] i64, feats [R, 8] f32): views, no copies."""
+def payload_views(p, rows):
+    """-> (grid_ids [R, 3] i64, pcounts [R] i64, feats [R, 8] f32): views of a payload, no copies."""
     R = int(rows)
-    return (rec[:4].view(torch.int32), rec[REC_HDR: REC_HDR + 3 * R].view(R, 3), rec[REC_HDR + 3 * R: REC_HDR + 4 * R],
-            rec[REC_HDR + 4 * R: REC_HDR + 8 * R].view(torch.float32).view(R, 8))
+    return p[: 3 * R].view(R, 3), p[3 * R: 4 * R], p[4 * R: 8 * R].view(torch.float32).view(R, 8)
+
+
+def header_counters(h):
+    """int64 [8] header -> the 8 int32 encoder counters (view)."""
+    return h[:4].view(torch.int32)
+
+
+class EncodedFrame:
+    """What encode_frame returns: the header and the encoder's capacity-sized output arrays."""
+
+    def __init__(self, hdr, grid_ids=None, pcounts=None, feats=None):
+        self.hdr, self.grid_ids, self.pcounts, self.feats = hdr, grid_ids, pcounts, feats
 
 
 class HipFrameBackend:
-    """Full (replicated) volume on one GPU; the per-frame phases as separate, host-sync-free calls."""
+    """Full (replicated) volume on one GPU; the per-frame phases as separate calls.  Nothing here waits for the
+    GPU; the one host wait of a batch (its headers) is in FrameParallelNeuralMap.exchange."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, capacity=1 << 20, device="cuda:0",
                  tsdf=False):
@@ -246,62 +259,89 @@ class HipFrameBackend:
             mn, mx, _ = get_world_range(dimensions, 0.025)
             self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
         self._scratch_ids = None
+        self._side = torch.cuda.Stream(device=self.dev)       # header / payload exchange: never behind the decode
 
     def record_rows(self, frame):
         """Upper bound of the voxels one frame can emit (every emitted voxel holds >= min_pts pairs)."""
-        from .neural_map import frame_input_pts
         if "input_pts" in frame:
             n = int(frame["input_pts"].shape[1])
         else:
             n = int(frame["depth"].shape[-2] * frame["depth"].shape[-1])
         return 8 * n // max(self.pointnet.min_pts_in_grid, 1) + 1
 
-    def encode_record(self, frame, rows):
-        """Encodes one frame straight into a new record (the encoder writes the record's sections)."""
+    def encode_frame(self, frame):
+        """Encodes one frame into capacity-sized arrays (the encoder's own outputs; nothing is copied)."""
         from .neural_map import frame_input_pts
         v = self.volume
         self.pointnet.shard = (0, 1, BLOCK_LOG2)
-        rec = torch.empty(record_words(rows), dtype=torch.int64, device=self.dev)
-        counters, grid_ids, pcounts, feats = record_views(rec, rows)
+        rows = self.record_rows(frame)
+        grid_ids = torch.empty((rows, 3), dtype=torch.int64, device=self.dev)
+        pcounts = torch.empty(rows, dtype=torch.int64, device=self.dev)
+        feats = torch.empty((rows, 8), dtype=torch.float32, device=self.dev)
+        hdr = torch.empty(REC_HDR, dtype=torch.int64, device=self.dev)        # words 4..7 are never read
         if self._scratch_ids is None or self._scratch_ids.numel() < rows:
             self._scratch_ids = torch.empty(rows, dtype=torch.int64, device=self.dev)
         _, _, _, _, cnt, _ = self.pointnet.encode_pointcloud_async(
             frame_input_pts(frame), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size,
             out=(feats, pcounts, self._scratch_ids, grid_ids))
-        counters.copy_(cnt)
-        return rec
+        header_counters(hdr).copy_(cnt)
+        return EncodedFrame(hdr, grid_ids, pcounts, feats)
 
-    def empty_record(self, rows):
-        rec = torch.empty(record_words(rows), dtype=torch.int64, device=self.dev)
-        rec[:REC_HDR] = 0
-        return rec
+    def empty_frame(self):
+        return EncodedFrame(torch.zeros(REC_HDR, dtype=torch.int64, device=self.dev))
 
-    def integrate_record(self, rec, rows, frame=None):
-        counters, grid_ids, pcounts, feats = record_views(rec, rows)
-        self.volume.integrate(grid_ids, feats, pcounts, n_dev=counters[2:3])
+    def pack(self, enc, rows):
+        """The first ``rows`` rows of an encoded frame as one payload (one launch)."""
+        if enc.grid_ids is None:                 # this rank has no frame in the batch
+            return torch.zeros(payload_words(rows), dtype=torch.int64, device=self.dev)
+        for t in (enc.grid_ids, enc.pcounts, enc.feats):
+            t.record_stream(torch.cuda.current_stream())
+        have = int(enc.pcounts.shape[0])
+        if rows <= have:
+            return torch.cat([enc.grid_ids[:rows].reshape(-1), enc.pcounts[:rows],
+                              enc.feats[:rows].reshape(-1).view(torch.int64)])
+        p = torch.zeros(payload_words(rows), dtype=torch.int64, device=self.dev)   # another rank's frame is larger
+        g, c, f = payload_views(p, rows)
+        g[:have], c[:have], f[:have] = enc.grid_ids, enc.pcounts, enc.feats
+        return p
+
+    def side(self, after_main):
+        """Context: the exchange stream.  ``after_main``: it first waits for what the main stream holds now."""
+        import os, contextlib
+        if os.environ.get("BNV_X_MAIN"):
+            return contextlib.nullcontext()
+        if after_main:
+            self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def adopt(self, *tensors):
+        """Tensors allocated on the exchange stream that main-stream kernels are about to read."""
+        for t in tensors:
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream())
+
+    def integrate_record(self, hdr, payload, rows, n_out, frame=None):
+        if n_out:
+            grid_ids, pcounts, feats = payload_views(payload, rows)
+            self.volume.integrate(grid_ids[:n_out], feats[:n_out], pcounts[:n_out], n_dev=header_counters(hdr)[2:3])
         if self.tsdf_vol is not None and frame is not None and "depth" in frame:
             self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
 
-    def decode_record(self, rec, rows):
-        counters, grid_ids, _, _ = record_views(rec, rows)
-        return self.volume.decode_lattice(grid_ids, self.pointnet.nerf, None, query_tensor=False,
-                                          n_dev=counters[2:3])
+    def decode_record(self, hdr, payload, rows, n_out):
+        grid_ids, _, _ = payload_views(payload, rows)
+        return self.volume.decode_lattice(grid_ids[:n_out], self.pointnet.nerf, None, query_tensor=False)
 
-    def account(self, headers, rows, n_rows_after=None):
-        """Host bookkeeping once a batch's headers are on the host: n_avg_pts statistics
-        (sparse_volume.py:508-523), the row reservation made for the capacity bound, overflow check."""
-        for i, h in enumerate(headers):
-            c = h[:4].view(torch.int32)
-            n_valid, n_out, err = int(c[0]), int(c[2]), int(c[4])
-            self.volume.settle(rows, n_rows_after if n_rows_after is not None else
-                               self.volume._rows_upper - self.volume._inflight)
-            if err:
-                raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+    def account(self, headers, n_rows_after=None):
+        """Host bookkeeping of a batch: n_avg_pts statistics (sparse_volume.py:508-523) and the row reservations
+        made for the capacity bound (the volume's row count behind the batch comes from a pinned read-back)."""
+        for h in headers:
+            c = header_counters(h)
+            n_valid, n_out = int(c[0]), int(c[2])
+            if n_out:
+                self.volume.settle(n_out, n_rows_after if n_rows_after is not None else
+                                   self.volume._rows_upper - self.volume._inflight)
             if n_valid:
                 self.volume.track_n_pts(float(c[3:4].view(torch.float32)[0]))
-
-    def unaccounted(self, rows):
-        """A frame that was skipped (fewer frames than ranks): undo nothing, nothing was reserved."""
 
     def pinned(self, shape):
         return torch.empty(shape, dtype=torch.int64, pin_memory=True)
@@ -317,8 +357,8 @@ class HipFrameBackend:
         ev.record()
         return ev
 
-    def slice_result(self, rec, rows, sdf, n_out):
-        _, grid_ids, _, _ = record_views(rec, rows)
+    def slice_result(self, payload, rows, sdf, n_out):
+        grid_ids, _, _ = payload_views(payload, rows)
         return grid_ids[:n_out], None if sdf is None else sdf[:n_out]
 
 
@@ -326,9 +366,9 @@ class BatchHandle:
     """One batch of FrameParallelNeuralMap.  ``result()`` -> (coords [U', 3], sdf [U', 27]) of the frame
     THIS rank decoded, or (None, None); waits for that batch only."""
 
-    def __init__(self, fp, rec, sdf, host_hdr, event, n_frames, host_rows=None):
-        self._fp, self._rec, self._sdf, self._host, self._event, self._b = fp, rec, sdf, host_hdr, event, n_frames
-        self._host_rows = host_rows
+    def __init__(self, fp, payload, rows, sdf, host_hdr, event, n_frames, host_rows=None):
+        self._fp, self._payload, self._rows, self._sdf = fp, payload, rows, sdf
+        self._host, self._event, self._b, self._host_rows = host_hdr, event, n_frames, host_rows
         self._accounted = False
         self._done = None
 
@@ -337,10 +377,7 @@ class BatchHandle:
             if self._event is not None:
                 self._event.synchronize()
             n_after = int(self._host_rows[0]) if self._host_rows is not None else None
-            if n_after is not None:
-                self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows, n_after)
-            else:
-                self._fp.backend.account([self._host[s] for s in range(self._b)], self._fp.rows)
+            self._fp.backend.account([self._host[s] for s in range(self._b)], n_after)
             self._accounted = True
 
     def result(self):
@@ -349,36 +386,33 @@ class BatchHandle:
             while fp._unsettled and not self._accounted:      # bookkeeping stays in batch order
                 fp._unsettled.pop(0)._account()
             self._account()
-            if self._rec is None:
+            c = header_counters(self._host[fp.rank])
+            if self._payload is None or int(c[0]) == 0 or int(c[2]) == 0:
                 self._done = (None, None)
             else:
-                c = self._host[fp.rank][:4].view(torch.int32)
-                if int(c[0]) == 0:
-                    self._done = (None, None)
-                else:
-                    self._done = fp.backend.slice_result(self._rec, fp.rows, self._sdf, int(c[2]))
-            self._rec = self._sdf = None
+                self._done = fp.backend.slice_result(self._payload, self._rows, self._sdf, int(c[2]))
+            self._payload = self._sdf = None
         return self._done
 
 
 class FrameParallelNeuralMap:
     """N ranks process a batch of up to N consecutive frames together:
 
-      1. rank r encodes frame r of the batch (encode_pointcloud is a pure function of the frame) straight
-         into a fixed-size record;
-      2. ONE all-gather of the records (64 B per voxel slot; sizes are fixed, so no size exchange and no
-         host synchronisation -- element counts travel in the record header and are read on the device);
+      1. rank r encodes frame r of the batch (encode_pointcloud is a pure function of the frame);
+      2. the 64-byte headers are all-gathered and copied to the host on a side stream; the host reads them while
+         the GPU is still busy with the previous batch, sizes ONE all-gather of the payloads by the largest frame of
+         the batch (64 B per emitted voxel) and starts it on the side stream;
       3. every rank replays _integrate (and the TSDF side fusion) for all frames of the batch IN FRAME
          ORDER on its replicated volume, and decodes the lattice of frame r right after integrating frame r.
 
     Every volume goes through exactly the single-GPU sequence of states, so all outputs equal the
     one-GPU run; decode (the largest kernel) and encode are spread over the ranks, only the cheap
     upserts are replicated.  ``process_stream`` software-pipelines the batches: batch k+1 is encoded and
-    its all-gather started (RCCL's own stream) BEFORE batch k is integrated and decoded, so the exchange
-    overlaps the decode kernels."""
+    its exchange started (side stream + RCCL's own stream) BEFORE batch k is integrated and decoded, so the
+    exchange overlaps the decode kernels."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None, tsdf=False, record_rows=None):
+                 group=None, tsdf=False):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
@@ -386,8 +420,8 @@ class FrameParallelNeuralMap:
         self.backend = backend or HipFrameBackend(dimensions, voxel_size, pointnet, min_pts_in_grid, device=device,
                                                   tsdf=tsdf)
         self.volume = getattr(self.backend, "volume", None)
-        self.rows = record_rows
         self._last = None
+        self.exchanged_bytes = 0   # payload bytes this rank has received in all-gathers (statistics)
         # The persistent MLP kernels fill every CU (1 workgroup each, most of the LDS and VGPRs), so an RCCL kernel
         # that becomes ready while one of them runs would wait for its tail.  With more than one rank they leave a
         # few CUs free for the collective (about 3 % of MFMA throughput).  NOT measured on a multi-GPU node from
@@ -398,52 +432,73 @@ class FrameParallelNeuralMap:
         self._unsettled = []      # batches whose host bookkeeping has not been done yet (oldest first)
         self.max_unsettled = 3    # the host may run this many batches ahead of the GPU before it waits
 
-    def _agree_rows(self, frames):
-        """One-time: the record capacity all ranks use (max over ranks of the local bound)."""
-        import torch.distributed as dist
-        local = max(self.backend.record_rows(f) for f in frames)
-        t = torch.tensor([local], dtype=torch.int64, device=self.backend.dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        self.rows = int(t.item())
-
     def submit(self, frames):
-        """Encode this rank's frame of the batch and start the all-gather; returns a ticket."""
+        """Encode this rank's frame of the batch and start the header exchange; returns a ticket."""
         import torch.distributed as dist
         b = len(frames)
         assert 1 <= b <= self.world
-        if self.rows is None:
-            self._agree_rows(frames)
         be = self.backend
         with torch.no_grad():
-            rec = be.encode_record(frames[self.rank], self.rows) if self.rank < b else be.empty_record(self.rows)
-            out = torch.empty((self.world, record_words(self.rows)), dtype=torch.int64, device=rec.device)
-            work = dist.all_gather_into_tensor(out.view(-1), rec, group=self.group, async_op=True)
-        return {"frames": frames, "out": out, "work": work, "rec": rec}
+            enc = be.encode_frame(frames[self.rank]) if self.rank < b else be.empty_frame()
+            with be.side(after_main=True):
+                hdr_all = torch.empty((self.world, REC_HDR), dtype=torch.int64, device=enc.hdr.device)
+                dist.all_gather_into_tensor(hdr_all.view(-1), enc.hdr, group=self.group)
+                host = be.pinned((self.world, REC_HDR))
+                host.copy_(hdr_all, non_blocking=True)
+                ev = be.event()
+        return {"frames": frames, "enc": enc, "hdr": hdr_all, "host": host, "event": ev}
+
+    def exchange(self, ticket):
+        """Waits for the batch's headers (the only host wait of a batch), then starts the payload all-gather."""
+        import torch.distributed as dist
+        if "rows" in ticket:
+            return ticket
+        be = self.backend
+        if ticket["event"] is not None:
+            ticket["event"].synchronize()
+        b = len(ticket["frames"])
+        n_out = []
+        for s in range(b):
+            c = header_counters(ticket["host"][s])
+            if int(c[4]):
+                raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {int(c[4])})")
+            n_out.append(int(c[2]) if int(c[0]) else 0)
+        rows = -(-max(n_out) // ROW_QUANTUM) * ROW_QUANTUM
+        out = work = None
+        if rows:
+            with torch.no_grad(), be.side(after_main=False):
+                send = be.pack(ticket["enc"], rows)
+                out = torch.empty((self.world, payload_words(rows)), dtype=torch.int64, device=send.device)
+                work = dist.all_gather_into_tensor(out.view(-1), send, group=self.group, async_op=True)
+            self.exchanged_bytes += 8 * out.numel()
+        ticket.update(rows=rows, n_out=n_out, out=out, work=work)
+        return ticket
 
     def finish(self, ticket, decode=True):
         """Integrate the whole batch in frame order, decode this rank's frame; returns a BatchHandle."""
         be = self.backend
-        frames, out = ticket["frames"], ticket["out"]
+        self.exchange(ticket)
+        frames, out, rows, n_out, hdr = ticket["frames"], ticket["out"], ticket["rows"], ticket["n_out"], ticket["hdr"]
         b = len(frames)
-        ticket["work"].wait()
+        if ticket["work"] is not None:
+            ticket["work"].wait()
+        be.adopt(out, hdr)
         # host bookkeeping of earlier batches, in order, without waiting: only batches whose event has already
         # fired (the host must be free to enqueue the N replayed integrates while the GPU still runs the encode)
         while self._unsettled and (self._unsettled[0]._event is None or self._unsettled[0]._event.query()
                                    or len(self._unsettled) >= self.max_unsettled):
             self._unsettled.pop(0)._account()
         with torch.no_grad():
-            host = be.pinned((self.world, REC_HDR))
-            host.copy_(out[:, :REC_HDR], non_blocking=True)
             sdf = mine = None
             for s in range(b):
-                be.integrate_record(out[s], self.rows, frames[s])
-                if decode and s == self.rank:
-                    sdf = be.decode_record(out[s], self.rows)
-                if s == self.rank:
+                be.integrate_record(hdr[s], None if out is None else out[s], rows, n_out[s], frames[s])
+                if s == self.rank and n_out[s]:
                     mine = out[s]
+                    if decode:
+                        sdf = be.decode_record(hdr[s], out[s], rows, n_out[s])
             host_rows = be.rows_readback() if hasattr(be, "rows_readback") else None
             ev = be.event()
-        self._last = BatchHandle(self, mine, sdf, host, ev, b, host_rows)
+        self._last = BatchHandle(self, mine, rows, sdf, ticket["host"], ev, b, host_rows)
         self._unsettled.append(self._last)
         return self._last
 
@@ -454,11 +509,15 @@ class FrameParallelNeuralMap:
 
     def process_stream(self, batches, decode=True):
         """batches: list of frame lists (each up to `world` long, the same on every rank).  Yields one
-        BatchHandle per batch; batch k+1's encode + exchange are enqueued before batch k's integrate + decode."""
-        ticket = self.submit(batches[0]) if batches else None
+        BatchHandle per batch; batch k+1's encode is enqueued before batch k's integrate + decode, and its
+        payload exchange is started right after them, as soon as its headers have reached the host."""
+        ticket = self.exchange(self.submit(batches[0])) if batches else None
         for i in range(len(batches)):
             nxt = self.submit(batches[i + 1]) if i + 1 < len(batches) else None
-            yield self.finish(ticket, decode)
+            handle = self.finish(ticket, decode)
+            if nxt is not None:
+                self.exchange(nxt)
+            yield handle
             ticket = nxt
 
     def flush(self):

@@ -144,7 +144,7 @@ def test_owner_hash_is_balanced_and_blocked():
 # frame-parallel mode
 # ---------------------------------------------------------------------------------------------
 class OracleFrameBackend:
-    """The frame-backend protocol of bnv_fusion_amd.distributed (fixed-size records) on top of the oracle."""
+    """The frame-backend protocol of bnv_fusion_amd.distributed (headers + sized payloads) on top of the oracle."""
 
     def __init__(self, dims, voxel):
         from oracle import bnv_oracle as orc
@@ -152,47 +152,68 @@ class OracleFrameBackend:
         self.sd = orc.load_weights(WEIGHTS_FP32)
         self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
         self.dev = torch.device("cpu")
+        self.payload_rows = []
 
-    def record_rows(self, frame):
-        return 8 * int(frame["input_pts"].shape[1]) // 8 + 1
-
-    def empty_record(self, rows):
-        from bnv_fusion_amd.distributed import record_words
-        return torch.zeros(record_words(rows), dtype=torch.int64)
-
-    def encode_record(self, frame, rows):
-        from bnv_fusion_amd.distributed import record_views
+    def encode_frame(self, frame):
+        from bnv_fusion_amd.distributed import EncodedFrame, header_counters
         v = self.vol
         f, c, _, g, n = self.orc.encode_pointcloud(self.sd, frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
                                                    v.voxel_size)
-        rec = self.empty_record(rows)
-        rec[8:] = 0x7ff8dead                      # rows beyond n_out are don't-care: poison them
-        counters, grid_ids, pcounts, feats = record_views(rec, rows)
         k = len(g)
+        cap = k + 37                               # capacity-sized outputs; rows beyond n_out are don't-care: poison
+        hdr = torch.zeros(8, dtype=torch.int64)
+        counters = header_counters(hdr)
         counters[0], counters[2] = 1, k
         counters[3:4] = torch.tensor([float(n)]).view(torch.int32)
+        grid_ids = torch.full((cap, 3), 0x7ff8dead, dtype=torch.int64)
+        pcounts = torch.full((cap,), 0x7ff8dead, dtype=torch.int64)
+        feats = torch.full((cap, 8), float("nan"))
         grid_ids[:k], pcounts[:k], feats[:k] = g, c.reshape(-1), f
-        return rec
+        return EncodedFrame(hdr, grid_ids, pcounts, feats)
 
-    def _valid(self, rec, rows):
-        from bnv_fusion_amd.distributed import record_views
-        counters, grid_ids, pcounts, feats = record_views(rec, rows)
-        k = int(counters[2])
+    def empty_frame(self):
+        from bnv_fusion_amd.distributed import EncodedFrame
+        return EncodedFrame(torch.zeros(8, dtype=torch.int64))
+
+    def pack(self, enc, rows):
+        from bnv_fusion_amd.distributed import payload_views, payload_words
+        p = torch.full((payload_words(rows),), 0x7ff8dead, dtype=torch.int64)
+        if enc.grid_ids is not None:
+            g, c, f = payload_views(p, rows)
+            m = min(rows, len(enc.pcounts))
+            g[:m], c[:m], f[:m] = enc.grid_ids[:m], enc.pcounts[:m], enc.feats[:m]
+        self.payload_rows.append(rows)
+        return p
+
+    def side(self, after_main):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def adopt(self, *tensors):
+        pass
+
+    def _valid(self, payload, rows, k):
+        from bnv_fusion_amd.distributed import payload_views
+        grid_ids, pcounts, feats = payload_views(payload, rows)
         return grid_ids[:k], pcounts[:k], feats[:k]
 
-    def integrate_record(self, rec, rows, frame=None):
-        g, c, f = self._valid(rec, rows)
-        self.orc.integrate(self.vol, g, f, c.reshape(-1, 1))
+    def integrate_record(self, hdr, payload, rows, n_out, frame=None):
+        from bnv_fusion_amd.distributed import header_counters
+        assert int(header_counters(hdr)[2]) == n_out
+        if n_out:
+            g, c, f = self._valid(payload, rows, n_out)
+            self.orc.integrate(self.vol, g, f, c.reshape(-1, 1))
 
-    def decode_record(self, rec, rows):
-        g, _, _ = self._valid(rec, rows)
+    def decode_record(self, hdr, payload, rows, n_out):
+        g, _, _ = self._valid(payload, rows, n_out)
         o = self.orc      # a sample of the voxels keeps the CPU suite fast; the exchange logic is what is tested
         return self.vol.decode_pts(o.lattice_coords(g.numpy()[::12]), self.sd, None, is_coords=True,
                                    query_tensor=False)[0, :, :, 0]
 
-    def account(self, headers, rows):
+    def account(self, headers, n_rows_after=None):
+        from bnv_fusion_amd.distributed import header_counters
         for h in headers:
-            c = h[:4].view(torch.int32)
+            c = header_counters(h)
             if int(c[0]):
                 self.vol.track_n_pts(float(c[3:4].view(torch.float32)[0]))
 
@@ -202,8 +223,8 @@ class OracleFrameBackend:
     def event(self):
         return None
 
-    def slice_result(self, rec, rows, sdf, n_out):
-        return self._valid(rec, rows)[0], sdf
+    def slice_result(self, payload, rows, sdf, n_out):
+        return self._valid(payload, rows, n_out)[0], sdf
 
 
 def _fp_worker(rank, world, port, frames, dims, voxel, ret):
@@ -225,7 +246,7 @@ def _fp_worker(rank, world, port, frames, dims, voxel, ret):
         if c is not None:
             outs.append((i * world + rank, c.numpy(), sdf.numpy()))
     nm.flush()
-    ret[rank] = (outs, np.asarray(nm.backend.vol.n_pts_list), len(nm.backend.vol._keys))
+    ret[rank] = (outs, np.asarray(nm.backend.vol.n_pts_list), len(nm.backend.vol._keys), list(nm.backend.payload_rows))
     dist.destroy_process_group()
 
 
@@ -240,9 +261,15 @@ def test_frame_parallel_equals_single_process():
         got = {t: (c, s) for r in (0, 1) for t, c, s in ret[r][0]}
         npts = [ret[r][1] for r in (0, 1)]
         nkeys = [ret[r][2] for r in (0, 1)]
+        prow = [ret[r][3] for r in (0, 1)]
     sd = orc.load_weights(WEIGHTS_FP32)
     vol = orc.OracleSparseVolume(8, voxel, dims, 8)
     assert sorted(got) == list(range(11))            # every frame decoded exactly once
+    # payloads are sized by the largest frame of the batch (from the exchanged headers), the same on both ranks
+    assert prow[0] == prow[1] and len(prow[0]) == 6
+    for b, rows in enumerate(prow[0]):
+        biggest = max(len(got[t][0]) for t in range(2 * b, min(2 * b + 2, 11)))
+        assert rows % 1024 == 0 and biggest <= rows < biggest + 1024
     for t, fr in enumerate(frames):
         f, c, _, g, n = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
         vol.track_n_pts(n)

@@ -646,7 +646,7 @@ def test_non_cubic_volume_and_save_load(bnv, orc, sd, tmp_path):
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_frame_parallel_record_path_equals_neural_map(bnv, backend):
     """The frame-parallel multi-GPU mode (distributed.FrameParallelNeuralMap) on its HIP backend, run here as a
-    one-rank group: encode straight into the fixed-size record, all-gather, device-side counts, pipelined
+    one-rank group: encode, header all-gather read by the host, payload all-gather sized by the batch, pipelined
     stream (batch k+1 encoded before batch k is integrated) -- bit-identical to the sequential NeuralMap.
     (World-2 exchange logic: tests/test_distributed_cpu.py on gloo.)"""
     import socket
@@ -665,7 +665,7 @@ def test_frame_parallel_record_path_equals_neural_map(bnv, backend):
             s.bind(("127.0.0.1", 0))
             port = s.getsockname()[1]
         # "nccl" = RCCL: a one-rank communicator still goes through the real collective calls the multi-GPU bench
-        # makes (all_gather_into_tensor async + wait, all_reduce MAX, int64 payloads)
+        # makes (all_gather_into_tensor of headers and of int64 payloads on the side stream, async + wait)
         kw = {"device_id": torch.device(DEV)} if backend == "nccl" else {}
         dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, **kw)
         created = True

@@ -21,12 +21,14 @@ def wrap(obj, name, key):
 be = fp.backend
 R = 8
 orig_int = be.integrate_record
-def replayed(rec, rows, frame=None):
-    for _ in range(R): orig_int(rec, rows, frame)
-    be.volume._inflight -= (R - 1) * rows; be.volume._rows_upper -= (R - 1) * rows
+def replayed(hdr, payload, rows, n_out, frame=None):
+    for _ in range(R): orig_int(hdr, payload, rows, n_out, frame)
+    be.volume._inflight -= (R - 1) * n_out; be.volume._rows_upper -= (R - 1) * n_out
 be.integrate_record = replayed
 wrap(be, "integrate_record", "integrate x8 (host)")
-wrap(be, "encode_record", "encode_record (host)")
+wrap(be, "encode_frame", "encode_frame (host)")
+wrap(be, "pack", "pack (host)")
+wrap(fp, "exchange", "exchange total (incl. the header wait)")
 wrap(be, "decode_record", "decode_record (host)")
 wrap(fp, "submit", "submit total")
 wrap(fp, "finish", "finish total")

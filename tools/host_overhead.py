@@ -15,12 +15,16 @@ torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"fuse_and_decode_async: host enqueue {1e3*(t1-t0)/40:.3f} ms/frame; GPU drained after {1e3*(t2-t0)/40:.3f} ms/frame")
 for h in hs: h.result()
 be = HipFrameBackend(np.array([dims]*3), voxel, model, device="cuda:0", tsdf=True)
-rows = be.record_rows(frames[0])
-recs = [be.encode_record(frames[t], rows) for t in range(8)]
+from bnv_fusion_amd.distributed import header_counters
+encs = [be.encode_frame(frames[t]) for t in range(8)]
 torch.cuda.synchronize()
-for name, fn in (("encode_record", lambda i: be.encode_record(frames[30 + i], rows)),
-                 ("integrate_record(+tsdf)", lambda i: be.integrate_record(recs[i % 8], rows, frames[i % 8])),
-                 ("decode_record", lambda i: be.decode_record(recs[i % 8], rows))):
+n_out = [int(header_counters(e.hdr.cpu())[2]) for e in encs]
+rows = -(-max(n_out) // 1024) * 1024
+pay = [be.pack(e, rows) for e in encs]
+for name, fn in (("encode_frame", lambda i: be.encode_frame(frames[30 + i])),
+                 ("pack", lambda i: be.pack(encs[i % 8], rows)),
+                 ("integrate_record(+tsdf)", lambda i: be.integrate_record(encs[i % 8].hdr, pay[i % 8], rows, n_out[i % 8], frames[i % 8])),
+                 ("decode_record", lambda i: be.decode_record(encs[i % 8].hdr, pay[i % 8], rows, n_out[i % 8]))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(40): fn(i)
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
