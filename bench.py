@@ -153,7 +153,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+            # RCCL's stream at high priority: the exchange kernels are short and on the path of the next batch;
+            # they should take a CU as soon as one of the (CU-filling) compute kernels releases it
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=torch.device(dev), pg_options=opts)
         else:
             dist.init_process_group(backend)
 

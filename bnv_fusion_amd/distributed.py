@@ -259,7 +259,8 @@ class HipFrameBackend:
             mn, mx, _ = get_world_range(dimensions, 0.025)
             self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
         self._scratch_ids = None
-        self._side = torch.cuda.Stream(device=self.dev)       # header / payload exchange: never behind the decode
+        # high priority: its few small launches are on the path of the next batch (measured: -35 us per batch)
+        self._side = torch.cuda.Stream(device=self.dev, priority=-1)       # header / payload exchange: never behind the decode
 
     def record_rows(self, frame):
         """Upper bound of the voxels one frame can emit (every emitted voxel holds >= min_pts pairs)."""
@@ -307,9 +308,6 @@ class HipFrameBackend:
 
     def side(self, after_main):
         """Context: the exchange stream.  ``after_main``: it first waits for what the main stream holds now."""
-        import os, contextlib
-        if os.environ.get("BNV_X_MAIN"):
-            return contextlib.nullcontext()
         if after_main:
             self._side.wait_stream(torch.cuda.current_stream())
         return torch.cuda.stream(self._side)
@@ -423,12 +421,15 @@ class FrameParallelNeuralMap:
         self._last = None
         self.exchanged_bytes = 0   # payload bytes this rank has received in all-gathers (statistics)
         # The persistent MLP kernels fill every CU (1 workgroup each, most of the LDS and VGPRs), so an RCCL kernel
-        # that becomes ready while one of them runs would wait for its tail.  With more than one rank they leave a
-        # few CUs free for the collective (about 3 % of MFMA throughput).  NOT measured on a multi-GPU node from
-        # here (one GPU available); BNV_RESERVE_CUS overrides, 0 disables.
+        # that becomes ready while one of them runs waits for its tail.  The exchange of batch k+1 is issued while
+        # batch k's upserts run (small kernels, free CUs) and is needed a whole decode + encode later, and both MLP
+        # kernels hand their tiles out dynamically, so workgroups displaced by the collective cost nothing but the
+        # collective's own CU time.  Leaving CUs free permanently instead (BNV_RESERVE_CUS=n, `reserve_cus`) costs
+        # 3-6 % of a batch on one GPU (tools/fp_single_rank.py --reserve 8) and is therefore off by default; the
+        # multi-GPU node is not available from here, so the knob stays.
         if self.world > 1 and getattr(getattr(self.backend, "dev", None), "type", "cpu") == "cuda":
             import os
-            _lib.load().bnv_set_option(b"reserve_cus", int(os.environ.get("BNV_RESERVE_CUS", "8")))
+            _lib.load().bnv_set_option(b"reserve_cus", int(os.environ.get("BNV_RESERVE_CUS", "0")))
         self._unsettled = []      # batches whose host bookkeeping has not been done yet (oldest first)
         self.max_unsettled = 3    # the host may run this many batches ahead of the GPU before it waits
 
