@@ -14,8 +14,9 @@ SYMBOLS = [
     "bnv_encode_workspace_bytes", "bnv_encode_workspace_reset", "bnv_pointnet_pack_floats",
     "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_voxelize_pairs",
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
+    "bnv_volume_integrate_batch",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
-    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
+    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_tsdf_integrate_batch_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
@@ -82,6 +83,7 @@ def load():
         "bnv_volume_rehash": (C.c_int, [C.POINTER(Volume), vp]),
         "bnv_volume_workspace_bytes": (sz, [i64]),
         "bnv_volume_integrate": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, vp, sz, vp]),
+        "bnv_volume_integrate_batch": (C.c_int, [C.POINTER(Volume), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
         "bnv_volume_insert": (C.c_int, [C.POINTER(Volume), vp, vp, vp, vp, i64, vp, sz, vp]),
         "bnv_volume_query": (C.c_int, [C.POINTER(Volume), vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         "bnv_volume_count_optim": (C.c_int, [C.POINTER(Volume), vp, i64, vp, i64, vp, i32, vp]),
@@ -116,6 +118,9 @@ def load():
                                          C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, vp]),
         "bnv_tsdf_integrate_u16": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float, vp, vp,
                                          C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, vp]),
+        "bnv_tsdf_integrate_batch_u16": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                                   C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                                   C.POINTER(C.c_float), C.c_float, vp]),
         "bnv_set_mlp_mode": (C.c_int, [C.c_int]),
         "bnv_get_mlp_mode": (C.c_int, []),
         "bnv_set_option": (C.c_int, [C.c_char_p, C.c_int]),

@@ -67,6 +67,63 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
   }
 }
 
+// Several consecutive frames in one launch (the replay loop of the frame-parallel multi-GPU mode): the voxel's
+// tsdf / weight stay in registers between frames, every frame applies exactly the single-frame arithmetic above,
+// in frame order -> identical results to one launch per frame.  Depth only (no colour volume).
+constexpr int kTsdfBatchMax = BNV_TSDF_BATCH_MAX;
+struct TsdfBatchArgs {
+  float* tsdf;
+  float* weight;
+  int dim[3];
+  float origin[3];
+  float voxel_size, trunc_margin, obs_weight;
+  int im_h, im_w, n_frames;
+  const uint16_t* depth_mm[kTsdfBatchMax];
+  float intr[kTsdfBatchMax][4];    // fx, cx, fy, cy
+  float pose[kTsdfBatchMax][12];   // rows 0..2 of the camera-to-world matrix
+};
+
+__global__ __launch_bounds__(256) void k_tsdf_integrate_batch(TsdfBatchArgs a) {
+  const int64_t n = (int64_t)a.dim[0] * a.dim[1] * a.dim[2];
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int yz = a.dim[1] * a.dim[2];
+  const int vx = (int)(idx / yz), vy = (int)((idx - (int64_t)vx * yz) / a.dim[2]);
+  const int vz = (int)(idx - (int64_t)vx * yz - (int64_t)vy * a.dim[2]);
+  const float pt_x = a.origin[0] + (float)vx * a.voxel_size;
+  const float pt_y = a.origin[1] + (float)vy * a.voxel_size;
+  const float pt_z = a.origin[2] + (float)vz * a.voxel_size;
+  bool loaded = false;
+  float w_cur = 0.f, t_cur = 0.f;
+  for (int f = 0; f < a.n_frames; ++f) {
+    const float* P = a.pose[f];
+    const float tx = pt_x - P[3], ty = pt_y - P[7], tz = pt_z - P[11];
+    const float cx = P[0] * tx + P[4] * ty + P[8] * tz;
+    const float cy = P[1] * tx + P[5] * ty + P[9] * tz;
+    const float cz = P[2] * tx + P[6] * ty + P[10] * tz;
+    const int px = (int)roundf(a.intr[f][0] * (cx / cz) + a.intr[f][1]);
+    const int py = (int)roundf(a.intr[f][2] * (cy / cz) + a.intr[f][3]);
+    if (px < 0 || px >= a.im_w || py < 0 || py >= a.im_h || cz < 0.f) continue;
+    const float depth = __fdiv_rn((float)a.depth_mm[f][(size_t)py * a.im_w + px], 1000.f);
+    if (depth == 0.f) continue;
+    const float diff = depth - cz;
+    if (diff < -a.trunc_margin) continue;
+    const float dist = fminf(1.0f, diff / a.trunc_margin);
+    if (!loaded) {
+      w_cur = a.weight[idx];
+      t_cur = a.tsdf[idx];
+      loaded = true;
+    }
+    const float w_new = w_cur + a.obs_weight;
+    t_cur = (t_cur * w_cur + a.obs_weight * dist) / w_new;
+    w_cur = w_new;
+  }
+  if (loaded) {
+    a.weight[idx] = w_cur;
+    a.tsdf[idx] = t_cur;
+  }
+}
+
 }  // namespace bnv
 
 using namespace bnv;
@@ -120,4 +177,43 @@ extern "C" int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, 
                                       bnv_stream_t stream) {
   return tsdf_integrate_impl(tsdf, weight, color, dim_host, origin_host, voxel_size, trunc_margin, nullptr, depth_mm,
                              color_im, im_h, im_w, intr_host, pose_host, obs_weight, stream);
+}
+
+extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3],
+                                            const float origin_host[3], float voxel_size, float trunc_margin,
+                                            int n_frames, const uint16_t* const* depth_mm, int im_h, int im_w,
+                                            const float* intr_host, const float* pose_host, float obs_weight,
+                                            bnv_stream_t stream) {
+  if (!tsdf || !weight || !dim_host || !origin_host || !depth_mm || !intr_host || !pose_host || im_h <= 0 || im_w <= 0 ||
+      n_frames < 0 || n_frames > kTsdfBatchMax)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (n_frames == 0) return BNV_OK;
+  TsdfBatchArgs a = {};
+  a.tsdf = tsdf;
+  a.weight = weight;
+  for (int i = 0; i < 3; ++i) {
+    a.dim[i] = dim_host[i];
+    a.origin[i] = origin_host[i];
+  }
+  a.voxel_size = voxel_size;
+  a.trunc_margin = trunc_margin;
+  a.obs_weight = obs_weight;
+  a.im_h = im_h;
+  a.im_w = im_w;
+  a.n_frames = n_frames;
+  for (int f = 0; f < n_frames; ++f) {
+    if (!depth_mm[f]) return BNV_ERR_INVALID_ARGUMENT;
+    a.depth_mm[f] = depth_mm[f];
+    const float* K = intr_host + 9 * f;
+    a.intr[f][0] = K[0];
+    a.intr[f][1] = K[2];
+    a.intr[f][2] = K[4];
+    a.intr[f][3] = K[5];
+    for (int i = 0; i < 12; ++i) a.pose[f][i] = pose_host[16 * f + i];
+  }
+  const int64_t n = (int64_t)a.dim[0] * a.dim[1] * a.dim[2];
+  if (n <= 0) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_tsdf_integrate_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
 }

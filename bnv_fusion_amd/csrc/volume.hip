@@ -279,6 +279,155 @@ __global__ __launch_bounds__(256) void k_vol_assign_integrate(bnv_volume_t v, co
   v.weights[row] = w_new;
 }
 
+// ---- batched _integrate: up to kVolBatchMax consecutive frames in 4 launches, results identical to integrating
+// them one after the other (the frame-parallel multi-GPU mode replays a whole batch of frames on every rank, and a
+// launch costs ~10 us of stream time whatever it does).  Items are (frame s, index i); the grid is frame-major,
+// every frame padded to whole 256-item blocks.  Two per-SLOT side tables that belong to the volume:
+//   slot_mask [n_slots]                bit s set <=> frame s of the batch holds the slot's key (zero between calls)
+//   slot_items[n_slots * kVolBatchMax] the index i of that key in frame s (valid where the bit is set)
+// B1 probes / CAS-inserts every key and fills the two tables.  B2 flags the creators -- the FIRST frame of a key that
+// was not in the volume before the batch, exactly the frame whose sequential upsert would have created the row --
+// and counts them per block; k_vol_offsets_commit (one workgroup) turns the counts into offsets and commits the row
+// count.  (A last-block-done variant of B2 that did the scan itself was slower: 3,200 tickets on one address.)
+// B3: the thread of a key's first occurrence creates the row if needed, then applies the running average of every
+// frame that holds the key, in frame order, in registers: one read and one write of the row.
+constexpr int kVolBatchMax = BNV_VOLUME_BATCH_MAX;
+
+struct VolBatch {
+  const int64_t* coords[kVolBatchMax];
+  const float* feats[kVolBatchMax];
+  const int64_t* pcounts[kVolBatchMax];
+  const int32_t* n_dev[kVolBatchMax];
+  int64_t n[kVolBatchMax];
+  int32_t block_start[kVolBatchMax + 1];   // first block of each frame; [n_frames] = total blocks
+  int32_t n_frames;
+};
+
+__device__ __forceinline__ int batch_frame_of(const VolBatch& b, int block) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < kVolBatchMax; ++k) s += (k < b.n_frames && block >= b.block_start[k]) ? 1 : 0;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_vol_batch_probe(bnv_volume_t v, VolBatch b, int32_t* __restrict__ slot_of,
+                                                         uint32_t* __restrict__ slot_mask,
+                                                         int32_t* __restrict__ slot_items,
+                                                         int32_t* __restrict__ error) {
+  const int s = batch_frame_of(b, blockIdx.x);
+  const int64_t n = dev_count(b.n[s], b.n_dev[s]);
+  const int64_t i = (int64_t)(blockIdx.x - b.block_start[s]) * 256 + threadIdx.x;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int32_t slot = -1;
+  if (i < n) {
+    const int64_t* c = b.coords[s] + i * 3;
+    uint64_t key;
+    if (pack_key(c[0], c[1], c[2], &key)) {
+      const uint32_t mask = (uint32_t)(v.n_slots - 1);
+      uint32_t p = mix64(key) & mask;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint64_t k = v.slot_keys[p];
+        if (k == kEmptyKey)
+          k = atomicCAS((unsigned long long*)&v.slot_keys[p], (unsigned long long)kEmptyKey, (unsigned long long)key);
+        if (k == kEmptyKey || k == key) {
+          slot = (int32_t)p;
+          break;
+        }
+        p = (p + 1) & mask;
+      }
+      if (slot < 0) {
+        *error = 1;  // table full
+      } else {
+        atomicOr(&slot_mask[slot], 1u << s);
+        slot_items[(int64_t)slot * kVolBatchMax + s] = (int32_t)i;
+      }
+    } else {
+      *error = 2;  // coordinate outside the 21-bit key range
+    }
+  }
+  slot_of[item] = slot;
+}
+
+__global__ __launch_bounds__(256) void k_vol_batch_count(bnv_volume_t v, VolBatch b,
+                                                         const int32_t* __restrict__ slot_of,
+                                                         const uint32_t* __restrict__ slot_mask,
+                                                         int32_t* __restrict__ is_new,
+                                                         uint32_t* __restrict__ block_new) {
+  const int s = batch_frame_of(b, blockIdx.x);
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t slot = slot_of[item];
+  int created = 0;
+  if (slot >= 0 && v.slot_rows[slot] < 0) created = (__ffs(slot_mask[slot]) - 1) == s;
+  is_new[item] = created;
+  __shared__ uint32_t wave_tot[4];
+  const unsigned long long bal = __ballot(created);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) block_new[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+__global__ __launch_bounds__(256) void k_vol_batch_apply(bnv_volume_t v, VolBatch b,
+                                                         const int32_t* __restrict__ slot_of,
+                                                         const int32_t* __restrict__ is_new,
+                                                         const uint32_t* __restrict__ block_off,
+                                                         const int32_t* __restrict__ first_row,
+                                                         uint32_t* __restrict__ slot_mask,
+                                                         const int32_t* __restrict__ slot_items,
+                                                         int32_t* __restrict__ error) {
+  const int s = batch_frame_of(b, blockIdx.x);
+  const int64_t i = (int64_t)(blockIdx.x - b.block_start[s]) * 256 + threadIdx.x;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint32_t wave_new[4];
+  const int created = is_new[item];
+  const unsigned long long bal = __ballot(created);
+  const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (ln == 0) wave_new[wv] = (uint32_t)__popcll(bal);
+  __syncthreads();
+  uint32_t before = block_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+  for (int k = 0; k < wv; ++k) before += wave_new[k];
+  const int32_t slot = slot_of[item];
+  if (slot < 0) return;
+  uint32_t frames = slot_mask[slot];
+  if ((__ffs(frames) - 1) != s) return;   // a later occurrence: the first one does the work (0: already done)
+  int64_t row;
+  float w_acc = 0.f;
+  float fo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (created) {
+    row = (int64_t)*first_row + before;
+    if (row >= v.row_capacity) {
+      *error = 3;
+      return;
+    }
+    const int64_t* c = b.coords[s] + i * 3;
+    v.slot_rows[slot] = (int32_t)row;
+    v.row_coords[row * 3 + 0] = c[0];
+    v.row_coords[row * 3 + 1] = c[1];
+    v.row_coords[row * 3 + 2] = c[2];
+    v.num_hits[row] = 0.f;
+  } else {
+    row = v.slot_rows[slot];
+    if (row < 0 || row >= v.row_capacity) return;
+    w_acc = v.weights[row];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fo[f] = v.features[row * 8 + f];
+  }
+  slot_mask[slot] = 0;   // the table is all zeros again when the launch ends
+  while (frames) {
+    const int t = __ffs(frames) - 1;
+    frames &= frames - 1;
+    const int64_t it = (t == s) ? i : (int64_t)slot_items[(int64_t)slot * kVolBatchMax + t];
+    const float w = fminf(__fdiv_rn((float)b.pcounts[t][it], 32.0f), 1.0f);
+    const float w_new = __fadd_rn(w_acc, w);
+    const float* fn = b.feats[t] + it * 8;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) fo[f] = __fdiv_rn(__fadd_rn(__fmul_rn(fo[f], w_acc), __fmul_rn(fn[f], w)), w_new);
+    w_acc = w_new;
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) v.features[row * 8 + f] = fo[f];
+  v.weights[row] = w_acc;
+}
+
 __global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const float* __restrict__ feats,
                                                           const float* __restrict__ weights,
                                                           const float* __restrict__ hits, int64_t n,
@@ -420,6 +569,47 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_assign_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
                      ws.slot_of, ws.is_new, ws.block_new, ws.total_new, ws.error);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_integrate_batch(const bnv_volume_t* vol, int n_frames, const int64_t* const* coords,
+                               const float* const* feats, const int64_t* const* pcounts, const int64_t* n,
+                               const int32_t* const* n_dev, uint32_t* slot_mask, int32_t* slot_items, void* ws_ptr,
+                               size_t ws_bytes, bnv_stream_t stream_) {
+  if (!vol_ok(vol) || n_frames < 0 || n_frames > kVolBatchMax) return BNV_ERR_INVALID_ARGUMENT;
+  if (n_frames == 0) return BNV_OK;
+  if (!coords || !feats || !pcounts || !n || !slot_mask || !slot_items || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  VolBatch b = {};
+  int64_t blocks = 0;
+  for (int s = 0; s < n_frames; ++s) {
+    if (n[s] < 0 || (n[s] > 0 && (!coords[s] || !feats[s] || !pcounts[s]))) return BNV_ERR_INVALID_ARGUMENT;
+    b.coords[s] = coords[s];
+    b.feats[s] = feats[s];
+    b.pcounts[s] = pcounts[s];
+    b.n_dev[s] = n_dev ? n_dev[s] : nullptr;
+    b.n[s] = n[s];
+    b.block_start[s] = (int32_t)blocks;
+    blocks += (n[s] + 255) / 256;
+  }
+  for (int s = n_frames; s <= kVolBatchMax; ++s) b.block_start[s] = (int32_t)blocks;
+  b.n_frames = n_frames;
+  if (blocks == 0) return BNV_OK;
+  if (blocks > 0x7fffffff / 256) return BNV_ERR_INVALID_ARGUMENT;
+  VolWs ws;
+  if (vol_ws_layout(blocks * 256, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  hipLaunchKernelGGL(k_vol_batch_probe, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
+                     slot_items, ws.error);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_batch_count, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
+                     ws.is_new, ws.block_new);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(1024), 0, stream, ws.block_new, (int)blocks, vol->n_rows,
+                     ws.total_new);
+  BNV_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_vol_batch_apply, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, ws.is_new,
+                     ws.block_new, ws.total_new, slot_mask, slot_items, ws.error);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

@@ -325,6 +325,29 @@ class HipFrameBackend:
         if self.tsdf_vol is not None and frame is not None and "depth" in frame:
             self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
 
+    def integrate_records(self, hdr_all, out, rows, n_out, s0, s1):
+        """_integrate of frames [s0, s1) of a gathered batch, in frame order, as ONE batched upsert (4 launches)."""
+        items = []
+        for s in range(s0, s1):
+            if n_out[s]:
+                grid_ids, pcounts, feats = payload_views(out[s], rows)
+                k = n_out[s]
+                items.append((grid_ids[:k], feats[:k], pcounts[:k], header_counters(hdr_all[s])[2:3]))
+        if items:
+            self.volume.integrate_batch(items)
+
+    def integrate_tsdf(self, frames):
+        """TSDF side fusion of all frames of a batch (one launch per 8 frames; nothing reads it before the batch ends)."""
+        if self.tsdf_vol is None:
+            return
+        fr = [f for f in frames if "depth" in f]
+        if any(f.get("rgb") is not None for f in fr):
+            for f in fr:
+                self.tsdf_vol.integrate(f.get("rgb"), f["depth"], f["intr_mat"], f["T_wc"], obs_weight=1.)
+        elif fr:
+            self.tsdf_vol.integrate_batch([f["depth"] for f in fr], [f["intr_mat"] for f in fr],
+                                          [f["T_wc"] for f in fr], obs_weight=1.)
+
     def decode_record(self, hdr, payload, rows, n_out):
         grid_ids, _, _ = payload_views(payload, rows)
         return self.volume.decode_lattice(grid_ids[:n_out], self.pointnet.nerf, None, query_tensor=False)
@@ -401,7 +424,8 @@ class FrameParallelNeuralMap:
          the GPU is still busy with the previous batch, sizes ONE all-gather of the payloads by the largest frame of
          the batch (64 B per emitted voxel) and starts it on the side stream;
       3. every rank replays _integrate (and the TSDF side fusion) for all frames of the batch IN FRAME
-         ORDER on its replicated volume, and decodes the lattice of frame r right after integrating frame r.
+         ORDER on its replicated volume -- as batched upserts: frames 0..r, then the decode of frame r, then frames
+         r+1.. (bnv_volume_integrate_batch: identical results to one upsert per frame).
 
     Every volume goes through exactly the single-GPU sequence of states, so all outputs equal the
     one-GPU run; decode (the largest kernel) and encode are spread over the ranks, only the cheap
@@ -491,12 +515,16 @@ class FrameParallelNeuralMap:
             self._unsettled.pop(0)._account()
         with torch.no_grad():
             sdf = mine = None
-            for s in range(b):
-                be.integrate_record(hdr[s], None if out is None else out[s], rows, n_out[s], frames[s])
-                if s == self.rank and n_out[s]:
-                    mine = out[s]
-                    if decode:
-                        sdf = be.decode_record(hdr[s], out[s], rows, n_out[s])
+            # frames up to and including this rank's own, then its decode (the state the single-GPU run decodes
+            # from), then the rest of the batch: two batched upserts instead of one per frame
+            own = min(self.rank + 1, b)
+            be.integrate_records(hdr, out, rows, n_out, 0, own)
+            if self.rank < b and n_out[self.rank]:
+                mine = out[self.rank]
+                if decode:
+                    sdf = be.decode_record(hdr[self.rank], mine, rows, n_out[self.rank])
+            be.integrate_records(hdr, out, rows, n_out, own, b)
+            be.integrate_tsdf(frames)
             host_rows = be.rows_readback() if hasattr(be, "rows_readback") else None
             ev = be.event()
         self._last = BatchHandle(self, mine, rows, sdf, ticket["host"], ev, b, host_rows)

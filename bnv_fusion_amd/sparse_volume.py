@@ -67,6 +67,8 @@ class SparseVolume:
         self.shard = (0, 1, 3)
         self._grid = make_grid(n_xyz, min_coords, max_coords, voxel_size, min_pts_in_grid, self.shard)
         self._ws = None
+        self._slot_mask = None        # side tables of integrate_batch (per slot; re-made with the slot table)
+        self._slot_items = None
         self._lattice_ws = None
         self._stamp = None
         self._epoch = 0
@@ -210,6 +212,36 @@ class SparseVolume:
         self._rows_upper += n
         if n_dev is not None:
             self._inflight += n
+
+    BATCH_MAX = 8     # BNV_VOLUME_BATCH_MAX
+
+    def integrate_batch(self, frames):
+        """``integrate`` for several consecutive frames at once: ``frames`` is a list of (coords, feats, pcounts,
+        n_dev) tuples in frame order (n_dev as in ``integrate``, may be None).  Four launches per BATCH_MAX frames;
+        rows, features and weights come out exactly as from one ``integrate`` call per frame."""
+        items = []
+        for coords, feats, pcounts, n_dev in frames:
+            n = int(coords.shape[0])
+            if n:
+                items.append((coords.reshape(-1, 3).long().contiguous(), feats.float().contiguous(),
+                              pcounts.reshape(-1).long().contiguous(), n_dev, n))
+        for g0 in range(0, len(items), self.BATCH_MAX):
+            grp = items[g0: g0 + self.BATCH_MAX]
+            total = sum(it[4] for it in grp)
+            self._reserve(total)                       # may re-make the slot table: side tables after it
+            if self._slot_mask is None or self._slot_mask.numel() != self._n_slots:
+                self._slot_mask = torch.zeros(self._n_slots, dtype=torch.int32, device=self._dev)
+                self._slot_items = torch.empty(self._n_slots * self.BATCH_MAX, dtype=torch.int32, device=self._dev)
+            ws = self._workspace(sum((it[4] + 255) // 256 * 256 for it in grp))
+            k = len(grp)
+            arr = lambda j: (C.c_void_p * k)(*[it[j].data_ptr() for it in grp])
+            nd = (C.c_void_p * k)(*[(it[3].data_ptr() if it[3] is not None else 0) for it in grp])
+            ns = (C.c_int64 * k)(*[it[4] for it in grp])
+            _lib.check(self._lib.bnv_volume_integrate_batch(
+                C.byref(self._struct()), k, arr(0), arr(1), arr(2), ns, nd, _lib.ptr(self._slot_mask),
+                _lib.ptr(self._slot_items), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), "bnv_volume_integrate_batch")
+            self._rows_upper += total
+            self._inflight += sum(it[4] for it in grp if it[3] is not None)
 
     def insert(self, keys, new_feats, new_weights, new_num_hits):
         """sparse_volume.py:561-585 (upsert)."""

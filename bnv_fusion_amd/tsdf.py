@@ -49,6 +49,35 @@ class TSDFVolume:
             np.float32(self._voxel_size), np.float32(self._trunc_margin), _lib.ptr(depth), _lib.ptr(col), im_h, im_w,
             intr, pose, float(obs_weight), _lib.stream_ptr()), "bnv_tsdf_integrate")
 
+    BATCH_MAX = 8     # BNV_TSDF_BATCH_MAX
+
+    def integrate_batch(self, depth_ims, cam_intrs, cam_poses, obs_weight=1.):
+        """``integrate`` (without colour) for several consecutive uint16-millimetre depth frames of one size, one
+        launch per BATCH_MAX frames; results identical to one call per frame in order."""
+        ims = [torch.as_tensor(d) for d in depth_ims]
+        if not ims:
+            return
+        if any(d.dtype not in (torch.uint16, torch.int16) or d.shape != ims[0].shape for d in ims):
+            for d, k, p in zip(ims, cam_intrs, cam_poses):
+                self.integrate(None, d, k, p, obs_weight)
+            return
+        ims = [d.to(self._dev).contiguous() for d in ims]
+        im_h, im_w = int(ims[0].shape[0]), int(ims[0].shape[1])
+        dim = (C.c_int32 * 3)(*[int(v) for v in self._vol_dim])
+        org = (C.c_float * 3)(*self._vol_origin.tolist())
+        for g0 in range(0, len(ims), self.BATCH_MAX):
+            grp = ims[g0: g0 + self.BATCH_MAX]
+            k = len(grp)
+            intr = np.stack([np.asarray(c, dtype=np.float64)[:3, :3].reshape(-1).astype(np.float32)
+                             for c in cam_intrs[g0: g0 + k]]).reshape(-1)
+            pose = np.stack([np.asarray(p, dtype=np.float64).reshape(-1).astype(np.float32)
+                             for p in cam_poses[g0: g0 + k]]).reshape(-1)
+            _lib.check(self._lib.bnv_tsdf_integrate_batch_u16(
+                _lib.ptr(self.tsdf), _lib.ptr(self.weight), dim, org, np.float32(self._voxel_size),
+                np.float32(self._trunc_margin), k, (C.c_void_p * k)(*[d.data_ptr() for d in grp]), im_h, im_w,
+                (C.c_float * (9 * k))(*intr.tolist()), (C.c_float * (16 * k))(*pose.tolist()), float(obs_weight),
+                _lib.stream_ptr()), "bnv_tsdf_integrate_batch_u16")
+
     def get_volume(self):
         return self.tsdf.cpu().numpy(), self.color.cpu().numpy()
 

@@ -150,6 +150,14 @@ int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32
                        const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                        const float intr_host[9], const float pose_host[16], float obs_weight,
                        bnv_stream_t stream);
+/* n_frames (<= BNV_TSDF_BATCH_MAX) consecutive uint16 depth frames in ONE launch, depth only (no colour volume):
+ * identical to n_frames calls of bnv_tsdf_integrate_u16 in order.  depth_mm: HOST array of device pointers;
+ * intr_host [n_frames, 9] and pose_host [n_frames, 16] row-major f32 on the host. */
+#define BNV_TSDF_BATCH_MAX 8
+int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3], const float origin_host[3],
+                                 float voxel_size, float trunc_margin, int n_frames,
+                                 const uint16_t* const* depth_mm, int im_h, int im_w, const float* intr_host,
+                                 const float* pose_host, float obs_weight, bnv_stream_t stream);
 
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
@@ -201,6 +209,20 @@ size_t bnv_volume_workspace_bytes(int64_t max_keys);
 int bnv_volume_integrate(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
                          const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws,
                          size_t ws_bytes, bnv_stream_t stream);
+
+/* The same for up to BNV_VOLUME_BATCH_MAX consecutive frames in ONE call (4 launches): the result -- row order, row
+ * count, features, weights -- is identical to calling bnv_volume_integrate once per frame in order (the replay loop of
+ * the frame-parallel multi-GPU mode, and any caller that holds several encoded frames; the reference integrates one
+ * frame per call, local_point_fusion.py:647-673).  coords / feats / pcounts / n / n_dev: HOST arrays of n_frames
+ * device pointers / counts (n_dev may be NULL, or hold NULLs).  slot_mask [n_slots] u32 and slot_items
+ * [n_slots * BNV_VOLUME_BATCH_MAX] i32 are side tables that belong to the volume: slot_mask must be all zeros
+ * before the first call (it is all zeros again after every call) and both must be re-made when the slot table is.
+ * Workspace: bnv_volume_workspace_bytes(sum over frames of n rounded up to 256). */
+#define BNV_VOLUME_BATCH_MAX 8
+int bnv_volume_integrate_batch(const bnv_volume_t* vol_host, int n_frames, const int64_t* const* coords,
+                               const float* const* feats, const int64_t* const* pcounts, const int64_t* n,
+                               const int32_t* const* n_dev, uint32_t* slot_mask, int32_t* slot_items,
+                               void* workspace, size_t workspace_bytes, bnv_stream_t stream);
 /* SparseVolume.insert (upsert with explicit values), sparse_volume.py:561-585. */
 int bnv_volume_insert(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
                       const float* weights, const float* num_hits, int64_t n, void* ws,

@@ -204,6 +204,13 @@ class OracleFrameBackend:
             g, c, f = self._valid(payload, rows, n_out)
             self.orc.integrate(self.vol, g, f, c.reshape(-1, 1))
 
+    def integrate_records(self, hdr_all, out, rows, n_out, s0, s1):
+        for s in range(s0, s1):
+            self.integrate_record(hdr_all[s], None if out is None else out[s], rows, n_out[s])
+
+    def integrate_tsdf(self, frames):
+        pass
+
     def decode_record(self, hdr, payload, rows, n_out):
         g, _, _ = self._valid(payload, rows, n_out)
         o = self.orc      # a sample of the voxels keeps the CPU suite fast; the exchange logic is what is tested

@@ -157,6 +157,47 @@ def test_full_chain_sequence_vs_reference_golden(bnv, model):
     assert np.allclose(nm.volume.n_pts_list, z["n_pts_list"])
 
 
+def test_integrate_batch_equals_frame_by_frame(bnv):
+    """bnv_volume_integrate_batch (several consecutive frames in 4 launches) against one bnv_volume_integrate per
+    frame: row order, row count, features and weights must be identical bit for bit.  Frames overlap heavily, keys
+    first appear in different frames, one frame is empty, device-side counts smaller than the buffers, 19 frames
+    (> 2 groups of 8), small initial capacity (the tables grow between groups)."""
+    g = torch.Generator().manual_seed(3)
+    pool = torch.unique(torch.randint(0, 60, (9000, 3), generator=g), dim=0)
+    frames = []
+    for t in range(19):
+        if t == 5:
+            k = pool[:0]
+        else:
+            lo = (t * 211) % (len(pool) // 2)
+            sel = pool[lo: lo + len(pool) // 2]
+            k = sel[torch.randperm(len(sel), generator=g)[: 1500 + 97 * t]]
+        n = len(k)
+        cap = n + 300                                   # buffers larger than the device-side count
+        coords = torch.full((cap, 3), 7_000_000, dtype=torch.int64)   # poison beyond n: would be a key-range error
+        coords[:n] = k
+        feats = torch.randn(cap, 8, generator=g)
+        pc = torch.randint(1, 80, (cap,), generator=g)
+        nd = torch.tensor([n], dtype=torch.int32)
+        frames.append(tuple(x.to(DEV) for x in (coords, feats, pc, nd)))
+    mk = lambda: bnv.SparseVolume(8, 0.02, np.array([1.24] * 3), 8, capacity=2048, device=DEV)
+    seq, bat = mk(), mk()
+    for c, f, p, nd in frames:
+        seq.integrate(c, f, p, n_dev=nd)
+    bat.integrate_batch(frames[:3])
+    bat.integrate_batch(frames[3:])
+    n_rows = seq.num_rows()
+    assert bat.num_rows() == n_rows and n_rows > 3000
+    for a, b in zip(seq.to_tensor(), bat.to_tensor()):
+        assert torch.equal(a, b)
+    assert int(bat._slot_mask.abs().sum()) == 0          # the side table cleans itself
+    # host-side counts (n_dev = None) take the same path
+    hs = mk()
+    hs.integrate_batch([(c[: int(nd)], f[: int(nd)], p[: int(nd)], None) for c, f, p, nd in frames])
+    for a, b in zip(seq.to_tensor(), hs.to_tensor()):
+        assert torch.equal(a, b)
+
+
 def test_volume_query_insert_grow(bnv):
     vol = bnv.SparseVolume(8, 0.02, np.array([1.24] * 3), 8, capacity=1024, device=DEV)
     g = torch.Generator().manual_seed(0)
@@ -835,6 +876,24 @@ def test_tsdf_uint16_depth_equals_float_metres(bnv):
         b.integrate(None, torch.from_numpy(metres).to(DEV), synthetic.intrinsics(240, 320), synthetic.pose(t))
     assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight)
     assert float((a.weight > 0).float().mean()) > 0.01
+
+
+def test_tsdf_batch_equals_frame_by_frame(bnv):
+    """bnv_tsdf_integrate_batch_u16: 11 frames (two launches) against one bnv_tsdf_integrate_u16 per frame, bit
+    for bit; an all-zero depth frame in the middle."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.tsdf import TSDFVolume
+    bounds = np.array([[-1.27, 1.27]] * 3)
+    a, b = TSDFVolume(bounds, 0.025, device=DEV), TSDFVolume(bounds, 0.025, device=DEV)
+    depth = [torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV) for t in range(11)]
+    depth[4] = torch.zeros_like(depth[4])
+    K = [synthetic.intrinsics(240, 320)] * 11
+    T = [synthetic.pose(3 * t) for t in range(11)]
+    for d, k, p in zip(depth, K, T):
+        a.integrate(None, d, k, p)
+    b.integrate_batch(depth, K, T)
+    assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight)
+    assert float(a.weight.max()) >= 8
 
 
 def test_lattice_table_stage_can_be_relaunched(bnv, model, golden_volume):

@@ -20,20 +20,21 @@ def wrap(obj, name, key):
     setattr(obj, name, f)
 be = fp.backend
 R = 8
-orig_int = be.integrate_record
-def replayed(hdr, payload, rows, n_out, frame=None):
-    for _ in range(R): orig_int(hdr, payload, rows, n_out, frame)
-    be.volume._inflight -= (R - 1) * n_out; be.volume._rows_upper -= (R - 1) * n_out
-be.integrate_record = replayed
-wrap(be, "integrate_record", "integrate x8 (host)")
+orig_v, orig_t = be.volume.integrate_batch, be.tsdf_vol.integrate_batch
+def replayed(items):
+    orig_v(items * R)
+    extra = (R - 1) * sum(int(it[0].shape[0]) for it in items)
+    be.volume._inflight -= extra; be.volume._rows_upper -= extra
+be.volume.integrate_batch = replayed
+be.tsdf_vol.integrate_batch = lambda d, k, p, obs_weight=1.: orig_t(d * R, k * R, p * R, obs_weight)
+wrap(be, "integrate_records", "integrate_records x8 (host)")
+wrap(be, "integrate_tsdf", "integrate_tsdf x8 (host)")
 wrap(be, "encode_frame", "encode_frame (host)")
 wrap(be, "pack", "pack (host)")
 wrap(fp, "exchange", "exchange total (incl. the header wait)")
 wrap(be, "decode_record", "decode_record (host)")
 wrap(fp, "submit", "submit total")
 wrap(fp, "finish", "finish total")
-wrap(be.volume, "integrate", " volume.integrate")
-wrap(be.tsdf_vol, "integrate", " tsdf.integrate")
 n = 60
 t0 = time.perf_counter()
 for last in fp.process_stream([[f] for f in frames[30:30+n]]): pass

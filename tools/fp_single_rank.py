@@ -7,7 +7,7 @@ sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
 from bnv_fusion_amd import synthetic
 from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); ap.add_argument("--replay", type=int, default=1); ap.add_argument("--ahead", type=int, default=3); ap.add_argument("--reserve", type=int, default=0); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); ap.add_argument("--replay", type=int, default=1); ap.add_argument("--ahead", type=int, default=3); ap.add_argument("--reserve", type=int, default=0); ap.add_argument("--split", action="store_true"); args = ap.parse_args()
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -21,13 +21,21 @@ if args.reserve:
     _lib.load().bnv_set_option(b"reserve_cus", args.reserve)
 for h in fp.process_stream([[f] for f in frames[:30]], decode=False): pass
 if args.replay > 1:     # emulate the replicated part of an N-rank batch: N - 1 more integrates (+ TSDF) per batch
-    orig = fp.backend.integrate_record
-    def replayed(hdr, payload, rows, n_out, frame=None):
-        for _ in range(args.replay):
-            orig(hdr, payload, rows, n_out, frame)
-        fp.backend.volume._inflight -= (args.replay - 1) * n_out     # keep the host-side row bound consistent
-        fp.backend.volume._rows_upper -= (args.replay - 1) * n_out
-    fp.backend.integrate_record = replayed
+    vol, tv = fp.backend.volume, fp.backend.tsdf_vol
+    orig_v, orig_t = vol.integrate_batch, tv.integrate_batch
+    if args.split:      # the rank's own frame sits in the middle of the batch: two batched upserts
+        fp.rank_pos = args.replay // 2
+    def replayed(items):
+        k = len(items)
+        if args.split:
+            orig_v(items * (args.replay // 2)); orig_v(items * (args.replay - args.replay // 2))
+        else:
+            orig_v(items * args.replay)
+        extra = (args.replay - 1) * sum(int(it[0].shape[0]) for it in items)
+        vol._inflight -= extra; vol._rows_upper -= extra          # keep the host-side row bound consistent
+    def replayed_t(d, k, p, obs_weight=1.):
+        orig_t(d * args.replay, k * args.replay, p * args.replay, obs_weight)
+    vol.integrate_batch, tv.integrate_batch = replayed, replayed_t
 fp.flush(); torch.cuda.synchronize()
 import ctypes as C
 for rep in range(2):
