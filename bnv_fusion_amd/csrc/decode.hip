@@ -1796,6 +1796,9 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;  // count from device memory; n = grid capacity
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // without a row list to build, the control words of the stages behind this one (entries listed, tile counter of
+  // the table kernel, spare) are cleared here: saves bnv_decode_lattice a memset launch per call
+  if (!list && t == 0) n_list[1] = n_list[2] = n_list[3] = 0;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
   const int nb = (int)(t - b * 27);
@@ -2220,19 +2223,25 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   return BNV_OK;
 }
 
-int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
-                     int32_t epoch, bnv_stream_t stream_) {
+static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
+                             int32_t epoch, bool clear, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
-  BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));  // entries listed, tile counter of the table kernel, spare
+  // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
+  if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
   hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
                      ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
+                     int32_t epoch, bnv_stream_t stream) {
+  return lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, true, stream);
 }
 
 int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
@@ -2284,7 +2293,7 @@ int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const fl
   int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
                                  epoch, stream);
   if (rc != BNV_OK) return rc;
-  rc = bnv_lattice_mark(vol, n, n_dev, ws_ptr, ws_bytes, epoch, stream);
+  rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
   if (rc != BNV_OK) return rc;
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;

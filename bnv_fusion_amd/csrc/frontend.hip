@@ -76,8 +76,12 @@ __global__ __launch_bounds__(1024) void k_front_top(uint32_t* __restrict__ block
   if (threadIdx.x == 0) *total_out = (int32_t)carry;
 }
 
+// pad_total: when not null (= the valid-pixel count written by k_front_top), the rows behind the valid ones are
+// filled with NaN here -- invalid pixel i goes to row n_valid + (i - valid pixels before i) -- so that the caller
+// needs no separate fill of the H*W-row buffer.
 __global__ __launch_bounds__(kFrontThreads) void k_front_points(FrontArgs a, const uint32_t* __restrict__ block_sums,
-                                                                float* __restrict__ out) {
+                                                                float* __restrict__ out,
+                                                                const int32_t* __restrict__ pad_total) {
   __shared__ uint32_t wave_tot[kFrontThreads / 64];
   const int64_t n = (int64_t)a.H * a.W;
   const int64_t base = (int64_t)blockIdx.x * kFrontTile + (int64_t)threadIdx.x * kFrontItems;
@@ -93,8 +97,15 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_points(FrontArgs a, con
   uint32_t run = block_exclusive_scan<kFrontThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
 #pragma unroll
   for (int e = 0; e < kFrontItems; ++e) {
-    if (!(dd[e] > 0.0)) continue;
     const int64_t i = base + e;
+    if (!(dd[e] > 0.0)) {
+      if (pad_total && i < n) {
+        float* o = out + ((size_t)*pad_total + (size_t)(i - run)) * 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) o[r] = __builtin_nanf("");
+      }
+      continue;
+    }
     const int y = (int)(i / a.W), x = (int)(i % a.W);
     const double d = dd[e];
     // ---- normal: Sobel/8 of the xyz map, cross product, L2 normalise (kornia depth_to_normals) ----
@@ -137,9 +148,9 @@ size_t bnv_depth_workspace_bytes(int H, int W) {
   return (size_t)(((n + kFrontTile - 1) / kFrontTile + 1) * 4 + 256);
 }
 
-int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
-                        const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes, float* out_pts,
-                        int32_t* n_out, bnv_stream_t stream_) {
+static int depth_to_points_impl(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                                const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes, float* out_pts,
+                                int32_t* n_out, bool pad, bnv_stream_t stream_) {
   if (!depth || !intr_host || !T_wc_host || !ws || !out_pts || !n_out || H <= 0 || W <= 0 || depth_dtype < 0 ||
       depth_dtype > 2 || (int64_t)H * W >= (1LL << 31))
     return BNV_ERR_INVALID_ARGUMENT;
@@ -166,9 +177,24 @@ int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const 
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_front_top, dim3(1), dim3(1024), 0, stream, sums, nb, n_out);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_front_points, dim3(nb), dim3(kFrontThreads), 0, stream, a, sums, out_pts);
+  hipLaunchKernelGGL(k_front_points, dim3(nb), dim3(kFrontThreads), 0, stream, a, sums, out_pts,
+                     pad ? (const int32_t*)n_out : (const int32_t*)nullptr);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                        const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes, float* out_pts,
+                        int32_t* n_out, bnv_stream_t stream) {
+  return depth_to_points_impl(depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth, ws, ws_bytes, out_pts, n_out,
+                              false, stream);
+}
+
+int bnv_depth_to_points_padded(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                               const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes, float* out_pts,
+                               int32_t* n_out, bnv_stream_t stream) {
+  return depth_to_points_impl(depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth, ws, ws_bytes, out_pts, n_out,
+                              true, stream);
 }
 
 }  // extern "C"

@@ -29,12 +29,10 @@ def depth_to_input_pts(depth, intr_mat, T_wc, max_depth=10.0, compact=True):
     K = (C.c_double * 9)(*np.asarray(intr_mat, dtype=np.float64)[:3, :3].reshape(-1))
     T = (C.c_double * 16)(*np.asarray(T_wc, dtype=np.float64).reshape(-1))
     ws = torch.empty(int(lib.bnv_depth_workspace_bytes(H, W)), dtype=torch.uint8, device=d.device)
-    if compact:
-        out = torch.empty((H * W, 6), dtype=torch.float32, device=d.device)
-    else:
-        out = torch.full((H * W, 6), float("nan"), dtype=torch.float32, device=d.device)
-    n = torch.zeros(1, dtype=torch.int32, device=d.device)
-    _lib.check(lib.bnv_depth_to_points(_lib.ptr(d), dt, H, W, K, T, float(max_depth), _lib.ptr(ws), ws.numel(),
+    out = torch.empty((H * W, 6), dtype=torch.float32, device=d.device)
+    n = torch.empty(1, dtype=torch.int32, device=d.device)           # written by the scan kernel
+    fn = lib.bnv_depth_to_points if compact else lib.bnv_depth_to_points_padded   # padded: NaN rows behind n
+    _lib.check(fn(_lib.ptr(d), dt, H, W, K, T, float(max_depth), _lib.ptr(ws), ws.numel(),
                                        _lib.ptr(out), _lib.ptr(n), _lib.stream_ptr()), "bnv_depth_to_points")
     if not compact:
         return out.unsqueeze(0), n

@@ -249,7 +249,7 @@ class LitFusionPointNet(nn.Module):
             pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
             flat_ids = torch.empty(cap, dtype=torch.int64, device=dev)
             grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
-        counters = torch.zeros(8, dtype=torch.int32, device=dev)
+        counters = torch.empty(8, dtype=torch.int32, device=dev)    # cleared by bnv_encode_pointcloud itself
         _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
                                              _lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points,
                                              _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids),

@@ -133,6 +133,11 @@ size_t bnv_depth_workspace_bytes(int H, int W);
 int bnv_depth_to_points(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
                         const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes,
                         float* out_pts, int32_t* n_out, bnv_stream_t stream);
+/* The same, and the rows [n_out, H*W) of out_pts are set to NaN by the same launch (a caller that hands the whole
+ * H*W-row buffer on without reading n_out -- the encoder's bounds mask drops NaN rows -- needs no separate fill). */
+int bnv_depth_to_points_padded(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                               const double* T_wc_host, double max_depth, void* ws, size_t ws_bytes,
+                               float* out_pts, int32_t* n_out, bnv_stream_t stream);
 
 /* ---- TSDF side fusion: TSDFVolume.integrate (third_parties/fusion.py:68-141, called per frame from
  * run_e2e.py:99-109).  tsdf / weight / color [dx,dy,dz] f32 (color may be NULL); depth_im [h,w] f32 metres
