@@ -29,6 +29,32 @@ __device__ __forceinline__ float relu_bits(float x) {
   return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 
+// hi/lo f16 split of fp32 values for the split-operand MFMA modes: hi = rn16(x), lo = rn16(x - hi).  Written with
+// v_cvt_pk_f16_f32 + v_fma_mixlo/mixhi_f16 (x - hi is formed in fp32 straight from the packed f16 hi and rounded once
+// into the destination half): 1.5 VALU ops per value where the plain C++ form compiles to ~2.9 (cvt, cvt back, sub,
+// cvt, pack).  Bit-identical to that form, subnormals and overflow included (tools/probe_split_mix.hip).  Plain asm
+// (not volatile): the compiler still schedules and dead-code-eliminates it; its inputs come out of a v_max_i32 or a
+// plain move, so no MFMA-result hazard is hidden from it.
+typedef _Float16 bnv_half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_pair_f16(float a, float b, unsigned& hi, unsigned& lo) {
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(b));
+}
+__device__ __forceinline__ void split8_f16(const float (&x)[8], bnv_half8& hi, bnv_half8& lo) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t h, l;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    unsigned hh, ll;
+    split_pair_f16(x[2 * p], x[2 * p + 1], hh, ll);
+    h[p] = hh;
+    l[p] = ll;
+  }
+  hi = __builtin_bit_cast(bnv_half8, h);
+  lo = __builtin_bit_cast(bnv_half8, l);
+}
+
 struct ProfScope {
   int kind;
   hipStream_t stream;

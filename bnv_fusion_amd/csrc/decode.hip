@@ -309,12 +309,14 @@ __device__ __forceinline__ void store_relu_h(float* __restrict__ lds, const f32x
 #pragma unroll
     for (int ksl = 0; ksl < 2; ++ksl) {
       half8 hi, lo;
+      if (NPROD == 3) {
+        float x[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = relu1(acc[pt][8 * ksl + e]);
-        const _Float16 t = (_Float16)x;
-        hi[e] = t;
-        if (NPROD == 3) lo[e] = (_Float16)(x - (float)t);
+        for (int e = 0; e < 8; ++e) x[e] = relu1(acc[pt][8 * ksl + e]);
+        split8_f16(x, hi, lo);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hi[e] = (_Float16)relu1(acc[pt][8 * ksl + e]);
       }
       const int o = (((2 * w + ksl) * 2 + h) * DM + pt * 32 + j) * 4;
       *(half8*)&lds[L_HL + o] = hi;
@@ -1620,13 +1622,10 @@ __device__ __forceinline__ void store_relu_q(float* __restrict__ lds, const f32x
 #pragma unroll
       for (int ksl = 0; ksl < 2; ++ksl) {
         half8 hi, lo;
+        float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = relu1(acc[nb][pt][8 * ksl + e]);
-          const _Float16 t = (_Float16)x;
-          hi[e] = t;
-          lo[e] = (_Float16)(x - (float)t);
-        }
+        for (int e = 0; e < 8; ++e) x[e] = relu1(acc[nb][pt][8 * ksl + e]);
+        split8_f16(x, hi, lo);
         const int o = (((2 * (2 * w + nb) + ksl) * 2 + h) * DQ + pt * 32 + j) * 4;
         *(half8*)&lds[Q_HL + o] = hi;
         *(half8*)&lds[Q_HLO + o] = lo;

@@ -474,13 +474,14 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 template <int NPROD = 3>
 __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, half8* hi, half8* lo) {
+  float x[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float x = v[base + e];
-    if (relu) x = relu_bits(x);
-    const _Float16 h = (_Float16)x;
-    (*hi)[e] = h;
-    if (NPROD == 3) (*lo)[e] = (_Float16)(x - (float)h);
+  for (int e = 0; e < 8; ++e) x[e] = relu ? relu_bits(v[base + e]) : v[base + e];
+  if (NPROD == 3) {
+    split8_f16(x, *hi, *lo);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) (*hi)[e] = (_Float16)x[e];
   }
 }
 
