@@ -52,7 +52,7 @@ for i in ORDER:
     print(f"  {NAMES[i]:28s}" + "".join(f"{v[w, i] / tiles:8.0f}" for w in range(8)) + f"   {100 * v[0, i] / tot:5.1f} % (w0)")
 mf = v[:, [1, 5, 9, 13]].sum(1)
 print("  MFMA phases total %          " + "".join(f"{100 * mf[w] / tot:8.1f}" for w in range(8)))
-print("  ideal MFMA-bound tile = 600 MFMA x 32 cyc x 2 waves/SIMD = 38400 cyc")
+print("  MFMA-bound tile = 600 MFMA x 2 waves/SIMD x 24.5 cyc (two waves of a SIMD issue one MFMA per ~24.5 cycles, probe_lds_mfma.hip) = 29400 cyc")
 
 # ---- point encoder (k_pointnet_scatter_h): per-wave phase cycles per 32-pair tile ----
 lib.bnv_dev_enc_phase_read.argtypes = [C.POINTER(C.c_ulonglong)]
@@ -65,6 +65,6 @@ e = np.array(list(eb), dtype=np.float64).reshape(8, 16)
 n_tiles = n * (307200 // 32) * 8 / 8.0          # tiles per wave index (8 waves share them evenly)
 EN = ["voxelise/stage", "L1 6->128", "split 1", "L2 128->128", "split 2", "L3 128->128", "split 3", "L4 128->8", "scatter"]
 etot = e[:, :9].sum(1)
-print(f"encoder: {etot.mean() / n_tiles:.0f} cycles per tile per wave; ideal MFMA-bound = 228 MFMA x 32 cyc x 2 waves/SIMD = 14592")
+print(f"encoder: {etot.mean() / n_tiles:.0f} cycles per tile per wave; MFMA-bound = 228 MFMA x 2 waves/SIMD x 24.5 cyc = 11200")
 for i, name in enumerate(EN):
     print(f"  {name:16s}" + "".join(f"{e[w, i] / n_tiles:8.0f}" for w in range(8)) + f"   {100 * e[:, i].sum() / etot.sum():5.1f} %")
