@@ -507,7 +507,6 @@ static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t
                            const VolWs& ws, hipStream_t stream) {
   const unsigned nb256 = (unsigned)((n + 255) / 256);
   const int nbt = (int)((n + kVolTile - 1) / kVolTile);
-  BNV_HIP_CHECK(hipMemsetAsync(ws.total_new, 0, 8, stream));
   hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, n_dev, ws.slot_of,
                      ws.is_new, ws.error);
   BNV_LAUNCH_CHECK();

@@ -57,3 +57,43 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f
+
+
+def test_argument_validation_without_a_gpu():
+    """Invalid arguments are refused before any HIP call (status codes of include/bnv_fusion.h), so this runs on CPU."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib
+    lib = _lib.load()
+    INVALID = -1
+    v = _lib.Volume()                                   # all-null volume
+    assert lib.bnv_volume_integrate(C.byref(v), None, None, None, 4, None, None, 0, None) == INVALID
+    assert lib.bnv_volume_integrate_batch(C.byref(v), 1, None, None, None, None, None, None, None, None, 0, None) == INVALID
+    assert lib.bnv_volume_clear(C.byref(v), None) == INVALID
+    assert lib.bnv_tsdf_integrate_u16(None, None, None, None, None, 0.025, 0.125, None, None, 480, 640, None, None, 1.0,
+                                      None) == INVALID
+    assert lib.bnv_tsdf_integrate_batch_u16(C.c_void_p(8), C.c_void_p(8), (C.c_int32 * 3)(4, 4, 4),
+                                            (C.c_float * 3)(), 0.025, 0.125, 9, C.c_void_p(8), 4, 4,
+                                            (C.c_float * 9)(), (C.c_float * 16)(), 1.0, None) == INVALID   # > 8 frames
+    assert lib.bnv_depth_to_points(None, 0, 480, 640, None, None, 10.0, None, 0, None, None, None) == INVALID
+    assert lib.bnv_png_unfilter(None, 1, 1, 2, None) != 0
+    assert lib.bnv_set_option(b"no_such_option", 1) == INVALID
+    assert lib.bnv_set_mlp_mode(7) == INVALID
+    for code in (0, -1, -2, -3, -4, -5):
+        assert len(lib.bnv_status_string(code)) > 0
+    assert int(lib.bnv_volume_workspace_bytes(1000)) > 8000
+    assert int(lib.bnv_depth_workspace_bytes(480, 640)) > 0
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """No library -> ImportError naming the build command; nothing falls back to a CPU path."""
+    import subprocess
+    import sys
+    code = ("import bnv_fusion_amd as b, torch\n"
+            "try:\n"
+            "    b.load_pretrained(device='cpu').encode_pointcloud(torch.zeros((1, 4, 6)), [8, 8, 8], [0.] * 3, [1.] * 3, 0.125)\n"
+            "except ImportError as e:\n"
+            "    assert 'no CPU fallback' in str(e), e\n"
+            "    print('LOUD')\n")
+    env = dict(os.environ, BNV_FUSION_LIB=str(tmp_path / "absent.so"), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "LOUD" in out.stdout, out.stdout + out.stderr

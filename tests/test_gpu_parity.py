@@ -1030,3 +1030,50 @@ def test_empty_frames_in_the_async_and_frame_parallel_pipelines(bnv):
     for (c0, s0), (c1, s1) in zip(ref, out[:4] + out[5:]):
         assert torch.equal(c0, c1) and torch.equal(s0, s1)
     assert np.allclose(fp.volume.n_pts_list, ref_nm.volume.n_pts_list)
+
+
+# ---------------------------------------------------------------------------------------------
+# error behaviour: device-side failures are sticky and surface as exceptions, never as silent wrong data
+# ---------------------------------------------------------------------------------------------
+def test_volume_errors_are_sticky_and_loud(bnv):
+    from bnv_fusion_amd._lib import BnvError
+    vol = bnv.SparseVolume(8, 0.02, np.array([1.24] * 3), 8, capacity=2048, device=DEV)
+    good = torch.tensor([[1, 2, 3], [4, 5, 6]], device=DEV)
+    vol.integrate(good, torch.ones(2, 8, device=DEV), torch.full((2,), 16, device=DEV))
+    assert vol.num_rows() == 2
+    bad = torch.tensor([[1, 2, 3_000_000]], device=DEV)            # outside the 21-bit key range
+    vol.integrate(bad, torch.ones(1, 8, device=DEV), torch.full((1,), 16, device=DEV))
+    with pytest.raises(BnvError, match="21-bit"):
+        vol.num_rows()
+    # a later, valid call does not wipe the error (the host may read it late: nothing synchronises per call)
+    vol.insert(good, torch.ones(2, 8, device=DEV), torch.ones(2, 1, device=DEV), torch.zeros(2, 1, device=DEV))
+    vol.integrate_batch([(good, torch.ones(2, 8, device=DEV), torch.full((2,), 16, device=DEV), None)])
+    with pytest.raises(BnvError, match="21-bit"):
+        vol.num_rows()
+    # the batched upsert reports the same way
+    v2 = bnv.SparseVolume(8, 0.02, np.array([1.24] * 3), 8, capacity=2048, device=DEV)
+    v2.integrate_batch([(good, torch.ones(2, 8, device=DEV), torch.full((2,), 16, device=DEV), None),
+                        (bad, torch.ones(1, 8, device=DEV), torch.full((1,), 16, device=DEV), None)])
+    with pytest.raises(BnvError, match="21-bit"):
+        v2.num_rows()
+
+
+def test_encode_capacity_overflow_is_reported(bnv, model):
+    """Caller-provided output buffers that are too small: the encoder keeps inside them and flags the frame
+    (counters[4]); encode_pointcloud / the pipelines turn that flag into an exception."""
+    from bnv_fusion_amd import synthetic
+    pts = torch.from_numpy(synthetic.frame(0, 120, 160)).to(DEV)
+    dims, voxel = synthetic.GRID_DIMS[64]
+    vol = bnv.SparseVolume(8, voxel, np.array([dims] * 3), 8, capacity=4096, device=DEV)
+    args = (pts, vol.n_xyz, vol.min_coords, vol.max_coords, vol.voxel_size)
+    _, _, _, _, counters, _ = model.encode_pointcloud_async(*args)
+    n_out = int(counters[2])
+    assert n_out > 64 and int(counters[4]) == 0
+    cap = 32
+    out = (torch.full((cap + 8, 8), -7.0, device=DEV)[:cap], torch.empty(cap, dtype=torch.int64, device=DEV),
+           torch.empty(cap, dtype=torch.int64, device=DEV), torch.empty((cap, 3), dtype=torch.int64, device=DEV))
+    guard = out[0]._base if out[0]._base is not None else None
+    _, _, _, _, counters, _ = model.encode_pointcloud_async(*args, out=out)
+    assert int(counters[4]) != 0                                  # flagged
+    if guard is not None:
+        assert bool((guard[cap:] == -7.0).all())                  # nothing written past the capacity
