@@ -107,6 +107,9 @@ int bnv_get_mlp_mode(void);
  *   "lattice_pipe"  1 (default): lattice-table MLP of modes 1 and 3 runs k_lattice_table_h (operands prefetched
  *                  across tiles and layers, dynamic tile hand-out); 0: the generic k_decode<LATTICE> (bit-identical
  *                  tables, 3-5 % slower);
+ *   "lattice_quad"  0 (default); 1: k_lattice_table_q, the same kernel with 64 features x 64 evaluations per wave
+ *                  (half the LDS operand reads, twice the weight reads from L2; bit-identical tables; measured 3 %
+ *                  slower in mode 1 and 12 % slower in mode 3 -- tools/ab_quad.py);
  *   "encoder_overlap"  0 (default); 1: point encoder with the output block in the outer loop (bit-identical
  *                  features, no measurable gain: MFMA and VALU do not co-execute on a SIMD of this part).
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
