@@ -261,6 +261,12 @@ class HipFrameBackend:
         self._scratch_ids = None
         # high priority: its few small launches are on the path of the next batch (measured: -35 us per batch)
         self._side = torch.cuda.Stream(device=self.dev, priority=-1)       # header / payload exchange: never behind the decode
+        # the encode of batch k+1 depends on its frame only: on its own stream it runs beside batch k's upserts and
+        # decode (its latency-bound kernels fill the decode's tail), as in NeuralMap.fuse_and_decode_async
+        import os
+        self.overlap_encode = os.environ.get("BNV_FP_ENCODE_STREAM", "1") != "0"
+        self._enc = torch.cuda.Stream(device=self.dev)
+        self._enc_src = None
 
     def record_rows(self, frame):
         """Upper bound of the voxels one frame can emit (every emitted voxel holds >= min_pts pairs)."""
@@ -272,6 +278,12 @@ class HipFrameBackend:
 
     def encode_frame(self, frame):
         """Encodes one frame into capacity-sized arrays (the encoder's own outputs; nothing is copied)."""
+        if self.overlap_encode and torch.cuda.current_stream() != self._enc:
+            self._enc_src = self._enc
+            with torch.cuda.stream(self._enc):
+                return self.encode_frame(frame)
+        if not self.overlap_encode:
+            self._enc_src = None
         from .neural_map import frame_input_pts
         v = self.volume
         self.pointnet.shard = (0, 1, BLOCK_LOG2)
@@ -308,8 +320,8 @@ class HipFrameBackend:
 
     def side(self, after_main):
         """Context: the exchange stream.  ``after_main``: it first waits for what the main stream holds now."""
-        if after_main:
-            self._side.wait_stream(torch.cuda.current_stream())
+        if after_main:     # ... or the encode stream, when the encode was enqueued there
+            self._side.wait_stream(self._enc_src if self._enc_src is not None else torch.cuda.current_stream())
         return torch.cuda.stream(self._side)
 
     def adopt(self, *tensors):
