@@ -227,15 +227,17 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_partial(F f, const int32_
 }
 
 // one block of 1024 threads: exclusive scan of block_sums[0:n_blocks) in place, total appended
-__global__ __launch_bounds__(1024) void k_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
+// (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
+// workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
                                                    int32_t* __restrict__ total_out) {
   __shared__ uint32_t wave_tot[16];
   uint32_t carry = 0;
-  for (int base = 0; base < n_blocks; base += 1024) {
+  for (int base = 0; base < n_blocks; base += 256) {
     const int i = base + threadIdx.x;
     const uint32_t v = (i < n_blocks) ? block_sums[i] : 0;
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<1024>(v, wave_tot, &total);
+    const uint32_t ex = block_exclusive_scan<256>(v, wave_tot, &total);
     if (i < n_blocks) block_sums[i] = carry + ex;
     carry += total;
   }
@@ -1244,7 +1246,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   hipLaunchKernelGGL(k_scan_partial<PopcWords>, dim3(nb_words), dim3(kScanThreads), 0, stream,
                      PopcWords{ws.bitmap}, (const int32_t*)nullptr, ws.n_words, ws.block_sums);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_set_unique, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_words, counters);
   BNV_LAUNCH_CHECK();
@@ -1282,7 +1284,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   hipLaunchKernelGGL(k_scan_partial<ValidFlags>, dim3(nb_u), dim3(kScanThreads), 0, stream,
                      ValidFlags{ws.counts, ws.ids, g, emit_all}, &counters->n_unique, (int64_t)0, ws.block_sums);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_finalize_counters, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_u, counters);
   BNV_LAUNCH_CHECK();

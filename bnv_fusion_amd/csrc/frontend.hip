@@ -61,15 +61,17 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_count(FrontArgs a, uint
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_front_top(uint32_t* __restrict__ block_sums, int n_blocks,
+// (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
+// workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
+__global__ __launch_bounds__(256) void k_front_top(uint32_t* __restrict__ block_sums, int n_blocks,
                                                     int32_t* __restrict__ total_out) {
   __shared__ uint32_t wave_tot[16];
   uint32_t carry = 0;
-  for (int base = 0; base < n_blocks; base += 1024) {
+  for (int base = 0; base < n_blocks; base += 256) {
     const int i = base + threadIdx.x;
     const uint32_t v = (i < n_blocks) ? block_sums[i] : 0;
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<1024>(v, wave_tot, &total);
+    const uint32_t ex = block_exclusive_scan<256>(v, wave_tot, &total);
     if (i < n_blocks) block_sums[i] = carry + ex;
     carry += total;
   }
@@ -175,7 +177,7 @@ static int depth_to_points_impl(const void* depth, int depth_dtype, int H, int W
   uint32_t* sums = (uint32_t*)ws;
   hipLaunchKernelGGL(k_front_count, dim3(nb), dim3(kFrontThreads), 0, stream, a, sums);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_front_top, dim3(1), dim3(1024), 0, stream, sums, nb, n_out);
+  hipLaunchKernelGGL(k_front_top, dim3(1), dim3(256), 0, stream, sums, nb, n_out);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_front_points, dim3(nb), dim3(kFrontThreads), 0, stream, a, sums, out_pts,
                      pad ? (const int32_t*)n_out : (const int32_t*)nullptr);

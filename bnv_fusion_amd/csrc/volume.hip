@@ -199,16 +199,18 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
 // the created keys of each 256-key block.
 // K2: ONE workgroup turns the block counts into exclusive offsets and commits the row count; first_row_out
 // receives the old count.
-__global__ __launch_bounds__(1024) void k_vol_offsets_commit(uint32_t* __restrict__ block_new, int n_blocks,
+// (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
+// workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
+__global__ __launch_bounds__(256) void k_vol_offsets_commit(uint32_t* __restrict__ block_new, int n_blocks,
                                                              int32_t* __restrict__ n_rows,
                                                              int32_t* __restrict__ first_row_out) {
   __shared__ uint32_t wave_tot[16];
   uint32_t carry = 0;
-  for (int base = 0; base < n_blocks; base += 1024) {
+  for (int base = 0; base < n_blocks; base += 256) {
     const int i = base + threadIdx.x;
     const uint32_t val = (i < n_blocks) ? block_new[i] : 0;
     uint32_t total;
-    const uint32_t ex = block_exclusive_scan<1024>(val, wave_tot, &total);
+    const uint32_t ex = block_exclusive_scan<256>(val, wave_tot, &total);
     if (i < n_blocks) block_new[i] = carry + ex;
     carry += total;
     __syncthreads();
@@ -563,7 +565,7 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, *vol, coords, n, n_dev, ws.slot_of,
                      ws.is_new, ws.error, ws.block_new);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(1024), 0, stream, ws.block_new, (int)nb256, vol->n_rows,
+  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(256), 0, stream, ws.block_new, (int)nb256, vol->n_rows,
                      ws.total_new);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_assign_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
@@ -604,7 +606,7 @@ int bnv_volume_integrate_batch(const bnv_volume_t* vol, int n_frames, const int6
   hipLaunchKernelGGL(k_vol_batch_count, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
                      ws.is_new, ws.block_new);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(1024), 0, stream, ws.block_new, (int)blocks, vol->n_rows,
+  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(256), 0, stream, ws.block_new, (int)blocks, vol->n_rows,
                      ws.total_new);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_batch_apply, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, ws.is_new,

@@ -73,6 +73,17 @@ class NeuralMap:
         # HIP stream and overlaps the previous frame's integrate / decode kernels on the main stream
         self.overlap_encode = True
         self._enc_stream = None
+        # Optional (off: measured 7 % SLOWER, tools/ab_prep.py): the frame's upsert, TSDF fusion and the first decode
+        # stage (feature snapshot, neighbour rows) on a third, high-priority stream, beside the previous frame's
+        # persistent SDF-MLP kernel, which then reads a snapshot of the features.  The kernel trace shows the small
+        # kernels do run beside the MLP kernel, but the two MLP kernels then pair up (encoder, encoder, decoder,
+        # decoder) because the front-end kernel of the next frame (40 VGPRs) does not fit beside the decoder
+        # (32 VGPRs per SIMD lane free) and holds its stream back; see DESIGN.md section 5.
+        self.overlap_prep = False
+        self._prep_stream = None
+        self._vol_ev = None            # behind the last enqueued modification of the volume (any stream)
+        self._slot_ev = [None, None]   # behind the last reader of each staged-decode workspace
+        self._frame_no = 0
         self.sdf_delta_weight = sdf_delta_weight                          # fusion_pointnet_model.yaml:44,47
         if tsdf:                                                          # run_e2e.py:60-71
             import numpy as np
@@ -99,6 +110,7 @@ class NeuralMap:
         input_pts = frame_input_pts(frame)
         if len(input_pts) == 0:
             return None
+        self._join()
         with torch.no_grad():
             fine_feats, fine_weights, _, fine_coords, fine_n_pts = self.pointnet.encode_pointcloud(
                 input_pts, self.volume.n_xyz, self.volume.min_coords, self.volume.max_coords,
@@ -108,7 +120,21 @@ class NeuralMap:
             self.volume.track_n_pts(fine_n_pts)
             self.pointnet._integrate(self.volume, fine_coords, fine_feats, fine_weights)
             self._integrate_tsdf(frame)
+            self._mark_volume_update()
         return fine_coords
+
+    def _mark_volume_update(self):
+        """An event behind a volume update enqueued on the current stream (the side stream of a later
+        fuse_and_decode_async waits for it)."""
+        if self._prep_stream is not None:
+            self._vol_ev = torch.cuda.Event()
+            self._vol_ev.record()
+
+    def _join(self):
+        """The current stream waits for volume updates that fuse_and_decode_async enqueued on its side stream."""
+        if self._vol_ev is not None:
+            torch.cuda.current_stream().wait_event(self._vol_ev)
+            self._vol_ev = None
 
     def fuse_and_decode(self, frame):
         """One benchmark work unit: integrate + SDF lattice [U', 27] of the touched voxels (live
@@ -143,16 +169,46 @@ class NeuralMap:
                 feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
                     input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
             n_dev = counters[2:3]
+            host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+            host_rows = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            if decode and self.overlap_encode and self.overlap_prep:
+                if self._prep_stream is None:
+                    self._prep_stream = torch.cuda.Stream(device=v._dev, priority=-1)
+                prep, slot = self._prep_stream, self._frame_no & 1
+                self._frame_no += 1
+                prep.wait_event(done)                                   # the encode's outputs
+                if self._vol_ev is not None:
+                    prep.wait_event(self._vol_ev)                       # earlier volume updates (any stream)
+                if self._slot_ev[slot] is not None:
+                    prep.wait_event(self._slot_ev[slot])                # the frame before last is done with this workspace
+                with torch.cuda.stream(prep):
+                    for t in (feats, pcounts, flat_ids, grid_ids, counters):
+                        t.record_stream(prep)
+                    v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
+                    self._integrate_tsdf(frame)
+                    v.lattice_stage_a(grid_ids, n_dev, slot)
+                    host.copy_(counters, non_blocking=True)
+                    host_rows.copy_(v._n_rows, non_blocking=True)
+                    ready = torch.cuda.Event()
+                    ready.record(prep)
+                self._vol_ev = ready
+                main.wait_event(ready)
+                sdf = v.lattice_stage_b(self.pointnet.nerf, slot, self.sdf_delta)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._slot_ev[slot] = ev
+                return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
+            self._join()
             v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
             self._integrate_tsdf(frame)
             sdf = v.decode_lattice(grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False,
                                    n_dev=n_dev) if decode else None
-            host = torch.empty(8, dtype=torch.int32, pin_memory=True)
             host.copy_(counters, non_blocking=True)
-            host_rows = torch.empty(1, dtype=torch.int32, pin_memory=True)
             host_rows.copy_(v._n_rows, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
+            if self._prep_stream is not None:
+                self._vol_ev = ev
         return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
 
     def optimize(self, n_iters, last_frame=-1, sampling_size=5000, train_ray_splits=1000, ray_max_dist=3,
@@ -163,6 +219,7 @@ class NeuralMap:
         png in DataLoader workers, fusion_inference_dataset.py:329-420).  Defaults are the values of
         fusion_pointnet_model.yaml / fusion_inference_dataset.yaml."""
         from .optimize import optimize_volume, sample_key_frame
+        self._join()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         lo = 0 if last_frame == -1 else last_frame
         cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
@@ -181,12 +238,14 @@ class NeuralMap:
 
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""
+        self._join()
         self.volume.to_tensor()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         return self.volume.meshlize_sdf(self.pointnet.nerf, delta)
 
     def extract_mesh(self, path=None):
         """run_e2e.py:164-167: mesh of the whole volume (TSDF prior included when enabled) -> TriMesh or None."""
+        self._join()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         self.volume.to_tensor()
         out = self.volume.meshlize(self.pointnet.nerf, delta, path)
@@ -197,6 +256,7 @@ class NeuralMap:
         final_sparse_volume.pth (sparse_volume.py:835-860)."""
         import os
         import numpy as np
+        self._join()
         if self.tsdf_vol is not None:
             tsdf, _ = self.tsdf_vol.get_volume()
             np.save(os.path.join(working_dir, scan_id + ".npy"), tsdf * (self.tsdf_voxel_size * 5))

@@ -70,6 +70,9 @@ class SparseVolume:
         self._slot_mask = None        # side tables of integrate_batch (per slot; re-made with the slot table)
         self._slot_items = None
         self._lattice_ws = None
+        self._stages = None           # double-buffered lattice workspaces of the staged decode
+        self._stages_capacity = 0
+        self._last_stage = None
         self._stamp = None
         self._epoch = 0
         self.reset(capacity)
@@ -411,6 +414,7 @@ class SparseVolume:
             self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
             self._lattice_epoch = 0
         self._lattice_epoch += 1
+        self._last_stage = None
         _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
                                                 _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
@@ -418,6 +422,62 @@ class SparseVolume:
                                                 self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_decode_lattice")
         return out
+
+    # ---- the lattice decode in two stages, on double-buffered workspaces ----------------------------------------
+    # NeuralMap's frame pipeline runs stage A of frame t (feature snapshot + neighbour rows) on a side stream while
+    # the SDF-MLP kernel of frame t-1 is still running: the small kernels fit beside the persistent MLP kernel, and
+    # the next integrate may then modify the live features at once, because the MLP reads the snapshot.
+    def lattice_stage_a(self, origins, n_dev, slot):
+        """Snapshot of the live features + neighbour rows of ``origins`` into workspace ``slot`` (0 / 1)."""
+        o = origins.detach().reshape(-1, 3).long().contiguous()
+        n = int(o.shape[0])
+        st = self._stage_state(n, slot)
+        rows = min(self._rows_upper, self._row_capacity)
+        st["feat"][:rows].copy_(self._features[:rows])
+        st["epoch"] += 1
+        st["o"], st["n"], st["n_dev"] = o, n, n_dev
+        if n:
+            _lib.check(self._lib.bnv_lattice_neighbors(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(self._weights),
+                                                       self._row_capacity, _lib.ptr(o), n, _lib.ptr(n_dev), None, 0,
+                                                       _lib.ptr(st["ws"]), st["ws"].numel(), st["epoch"], _lib.stream_ptr()),
+                       "bnv_lattice_neighbors")
+        return st
+
+    def lattice_stage_b(self, nerf, slot, sdf_delta=None):
+        """Live-entry marking, SDF MLP on the snapshot, blend -> [n, 27] for the origins of stage A."""
+        self._select_mode(nerf)
+        st = self._stages[slot]
+        o, n, n_dev, ws = st["o"], st["n"], st["n_dev"], st["ws"]
+        out = torch.empty((n, 27), dtype=torch.float32, device=self._dev)
+        if n == 0:
+            return out
+        d, keep = self._delta(sdf_delta)
+        vol = self._struct()
+        _lib.check(self._lib.bnv_lattice_mark(C.byref(vol), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(), st["epoch"],
+                                              _lib.stream_ptr()), "bnv_lattice_mark")
+        _lib.check(self._lib.bnv_lattice_table(C.byref(vol), C.byref(self._grid), _lib.ptr(st["feat"]),
+                                               _lib.ptr(nerf.sdf_pack), n, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                   "bnv_lattice_table")
+        _lib.check(self._lib.bnv_lattice_blend(C.byref(vol), C.byref(self._grid), _lib.ptr(o), n, _lib.ptr(n_dev),
+                                               C.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
+                   "bnv_lattice_blend")
+        self._last_stage = slot
+        return out
+
+    def _stage_state(self, n, slot):
+        if self._stages is None or self._stages_capacity != self._row_capacity:
+            if self._stages is not None:
+                torch.cuda.synchronize(self._dev)      # the tables were re-made: nothing may still read the old buffers
+            self._stages = [{"ws": None, "feat": None, "epoch": 0} for _ in range(2)]
+            self._stages_capacity = self._row_capacity
+        st = self._stages[slot]
+        need = int(self._lib.bnv_decode_lattice_workspace_bytes(max(n, 1), self._row_capacity))
+        if st["ws"] is None or st["ws"].numel() < need:
+            st["ws"] = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            st["epoch"] = 0
+        if st["feat"] is None:
+            st["feat"] = torch.empty((self._row_capacity, 8), dtype=torch.float32, device=self._dev)
+        return st
 
     def last_lattice_table_rows(self):
         """Device int32 tensor [1]: rows listed by the last bnv_lattice_neighbors(build_list) (sharded
@@ -429,7 +489,8 @@ class SparseVolume:
         """Device int32 tensor [1]: SDF-MLP evaluations of the last decode_lattice call (table entries
         read by live lattice points)."""
         off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
-        return self._lattice_ws[off + 4: off + 8].view(torch.int32)
+        ws = self._stages[self._last_stage]["ws"] if self._last_stage is not None else self._lattice_ws
+        return ws[off + 4: off + 8].view(torch.int32)
 
     def meshlize(self, nerf, sdf_delta=None, path=None):
         """sparse_volume.py:697-766: decode the 3x3x3 lattice of every active voxel and run per-voxel

@@ -596,21 +596,30 @@ def test_volume_list_wrapper(bnv, model, golden_volume):
     assert np.abs(sdf.reshape(-1, 27).cpu().numpy() - d["lattice_q"][0, :, :, 0]).max() <= SDF_TOL
 
 
-def test_async_frames_equal_sync_frames(bnv):
+@pytest.mark.parametrize("prep", [False, True])
+def test_async_frames_equal_sync_frames(bnv, prep):
     """fuse_and_decode_async (device-side counts, no mid-frame sync, results collected one frame late)
-    produces exactly what the synchronous API produces."""
+    produces exactly what the synchronous API produces -- also with the optional three-stream pipeline
+    (overlap_prep: upsert + first decode stage beside the previous frame's MLP kernel, which reads a snapshot),
+    mixed with fuse-only and synchronous calls."""
     from bnv_fusion_amd import synthetic
     dims, voxel = synthetic.GRID_DIMS[128]
     model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     a = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
     b = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
+    b.overlap_prep = prep
     frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
                "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)} for t in range(12)]
     sync_out = [a.fuse_and_decode(f) for f in frames]
     handles, async_out = [], []
-    for f in frames:
+    for i, f in enumerate(frames):
+        if i == 7:                                   # a synchronous frame in the middle of the asynchronous ones
+            async_out.append(handles[-1].result())
+            handles.append(None)
+            async_out.append(b.fuse_and_decode(f))
+            continue
         handles.append(b.fuse_and_decode_async(f))
-        if len(handles) > 1:
+        if len(handles) > 1 and handles[-2] is not None:
             async_out.append(handles[-2].result())
     async_out.append(handles[-1].result())
     for (c0, s0), (c1, s1) in zip(sync_out, async_out):
