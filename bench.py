@@ -17,6 +17,7 @@ Rank 0 prints ONE JSON line: metric / value plus `roofline` (dominant kernel, ti
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -39,6 +40,14 @@ DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
          2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
          3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_32x32x16_f16, f32 accumulate"}
+
+
+# Row capacity of the volume.  The tables grow on demand like the reference's Open3D map, but a growth step (sync +
+# re-allocation + re-hash, ~40 ms) is a one-off that must not land in a 70 ms timed region: the host-side bound that
+# triggers it counts the worst-case reservations of the frames in flight (up to 3 x 307,201 rows at 640x480 on top of
+# ~350,000 known rows), so 2^20 rows were sometimes not enough -- and whether the step fell into the timed region
+# depended on how far the host happened to run ahead.
+CAPACITY = 1 << 22
 
 
 def pmc_traffic_bytes(kernel_substr):
@@ -172,12 +181,13 @@ def main():
     frame_parallel = world > 1 and args.parallelism == "frame"
     if frame_parallel:
         from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev, tsdf=(args.input == "depth"))
+        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev, tsdf=(args.input == "depth"),
+                                    capacity=CAPACITY)
     elif world > 1:
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
     else:
-        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=1 << 20, device=dev,
+        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=CAPACITY, device=dev,
                            tsdf=(args.input == "depth"))
         nm.overlap_encode = not args.no_stream_overlap
 
@@ -216,14 +226,20 @@ def main():
             # software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU
             # never waits for the host (each result() waits on that frame's own event only)
             pending = None
+            _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
             for t in range(first, first + count):
+                _a = time.perf_counter()
                 h = nm.fuse_and_decode_async(frames[t], decode=decode)
+                if _dbg is not None:
+                    _dbg.append(time.perf_counter() - _a)
                 if pending is not None:
                     r = pending.result()
                     if collect is not None:
                         collect(r)
                 pending = h
             last = pending.result()
+            if _dbg:
+                print("enqueue ms:", " ".join(f"{1e3*x:.2f}" for x in _dbg), file=sys.stderr)
             if collect is not None:
                 collect(last)
         else:
@@ -248,6 +264,12 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        # the cyclic garbage collector stays out of the timed region (as timeit does): with torch imported a full
+        # collection takes ~40 ms, and one landed on the third timed frame of every process but the first on a box
+        # (350 instead of 540 frames/s over 40 frames; found with per-frame enqueue times, BNV_BENCH_DEBUG=1)
+        gc.collect()
+        gc.disable()
+        _ms0 = torch.cuda.memory_stats() if os.environ.get("BNV_BENCH_DEBUG") else None
         t0 = time.perf_counter()
         def collect(res):
             c, _ = res
@@ -270,6 +292,12 @@ def main():
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        gc.enable()
+        if _ms0 is not None:
+            _ms1 = torch.cuda.memory_stats()
+            print("timed region: device allocs", _ms1["num_device_alloc"] - _ms0["num_device_alloc"], "device frees",
+                  _ms1["num_device_free"] - _ms0["num_device_free"], "reserved MB",
+                  _ms1["reserved_bytes.all.current"] >> 20, "retries", _ms1["num_alloc_retries"], file=sys.stderr)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

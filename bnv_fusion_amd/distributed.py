@@ -446,13 +446,13 @@ class FrameParallelNeuralMap:
     exchange overlaps the decode kernels."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None, tsdf=False):
+                 group=None, tsdf=False, capacity=1 << 20):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend or HipFrameBackend(dimensions, voxel_size, pointnet, min_pts_in_grid, device=device,
-                                                  tsdf=tsdf)
+                                                  tsdf=tsdf, capacity=capacity)
         self.volume = getattr(self.backend, "volume", None)
         self._last = None
         self.exchanged_bytes = 0   # payload bytes this rank has received in all-gathers (statistics)
