@@ -2109,67 +2109,55 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
     list[atomicAdd(n_list, 1)] = row;
 }
 
-// Per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is LIVE), the 8 (row, l)
-// table entries it reads go to the MLP work list.  Entries of masked points are never evaluated.
-// A workgroup of 256 threads handles 1024 consecutive points in two passes: pass 1 decides, per point, which entries
-// it appends (an 8-bit mask kept in a register) and counts them; ONE global atomic per workgroup reserves the space;
-// pass 2 recomputes the entries of the set bits (the neighbour rows are L1/L2 hits by then) and writes them straight
-// to the list.  No LDS buffer and 32 VGPRs, so the kernel runs beside the persistent MLP kernels of the other
-// streams (an earlier version collected the entries in a 32 KB LDS buffer with 1024 threads and had to wait for them).
-constexpr int kMarkThreads = 256, kMarkItems = 4;
-
-// corner k of lattice offset d: index of its voxel among the 27 neighbours, its local offset l, and whether it
-// duplicates the floor corner (ceil == floor on an axis with d == 0)
-__device__ __forceinline__ void mark_corner(const int (&d)[3], int k, int& nbi, int& li, bool& dup) {
-  nbi = 0;
-  li = 0;
-  dup = false;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int nb_a = 0, loc2 = 0;
-    if (d[a] != 0) {
-      if ((k >> a) & 1) {
-        nb_a = (d[a] + 1) / 2;
-        loc2 = -1;
-      } else {
-        nb_a = (d[a] - 1) / 2;
-        loc2 = 1;
-      }
-    } else if ((k >> a) & 1) {
-      dup = true;
-    }
-    nbi = nbi * 3 + (nb_a + 1);
-    li = li * 3 + (loc2 + 1);
-  }
-}
-
-__global__ __launch_bounds__(kMarkThreads) __attribute__((amdgpu_num_vgpr(16))) void k_lattice_mark(
-    const int32_t* __restrict__ nbr_rows, int64_t n, const int32_t* __restrict__ origin_stamp, int32_t epoch,
-    uint32_t* __restrict__ need_mask, int32_t* __restrict__ entries, int32_t* __restrict__ n_entries,
-    int64_t entry_capacity, const int32_t* __restrict__ n_dev) {
+// One thread per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is
+// LIVE), flags the 8 (row, l) table entries it reads; the first thread to flag an entry appends it to
+// the MLP work list.  Entries of masked points are never evaluated.
+constexpr int kMarkThreads = 1024;
+__global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
+                                                               const int32_t* __restrict__ origin_stamp, int32_t epoch,
+                                                               uint32_t* __restrict__ need_mask,
+                                                               int32_t* __restrict__ entries,
+                                                               int32_t* __restrict__ n_entries,
+                                                               int64_t entry_capacity,
+                                                               const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
+  // new entries are collected per block in LDS and appended with ONE global atomic per block
+  __shared__ int s_buf[kMarkThreads * 8];
   __shared__ int s_count, s_base;
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  const int64_t t0 = (int64_t)blockIdx.x * (kMarkThreads * kMarkItems) + threadIdx.x;
-  uint32_t masks = 0;  // 8 bits per item: the corners whose entry this thread appends
-  int total = 0;
-#pragma unroll 1
-  for (int c = 0; c < kMarkItems; ++c) {
-    const int64_t t = t0 + (int64_t)c * kMarkThreads;
-    if (t >= n * 27) break;
+  const int64_t t = (int64_t)blockIdx.x * kMarkThreads + threadIdx.x;
+  if (t < n * 27) {
     const int64_t b = t / 27;
     const int p = (int)(t - b * 27);
     const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    int rowk[8], lk[8];
     bool live = true;
-    uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      int nbi, li;
-      bool dup;
-      mark_corner(d, k, nbi, li, dup);
-      if (nbr_rows[b * 27 + nbi] < 0) live = false;
-      if (!dup) m |= 1u << k;
+      int nbi = 0, li = 0;
+      bool dup = false;  // ceil == floor on an axis with d == 0: same entry as the floor corner
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int nb_a = 0, loc2 = 0;
+        if (d[a] != 0) {
+          if ((k >> a) & 1) {
+            nb_a = (d[a] + 1) / 2;
+            loc2 = -1;
+          } else {
+            nb_a = (d[a] - 1) / 2;
+            loc2 = 1;
+          }
+        } else if ((k >> a) & 1) {
+          dup = true;
+        }
+        nbi = nbi * 3 + (nb_a + 1);
+        li = li * 3 + (loc2 + 1);
+      }
+      const int row = nbr_rows[b * 27 + nbi];
+      if (row < 0) live = false;
+      rowk[k] = dup ? -1 : row;
+      lk[k] = li;
     }
     // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
     // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
@@ -2183,48 +2171,27 @@ __global__ __launch_bounds__(kMarkThreads) __attribute__((amdgpu_num_vgpr(16))) 
       if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
       shared = true;
     }
-    if (!live) continue;
-    if (shared) {
+    if (live) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (!((m >> k) & 1)) continue;
-        int nbi, li;
-        bool dup;
-        mark_corner(d, k, nbi, li, dup);
-        const uint32_t bit = 1u << li;
-        if (atomicOr(&need_mask[nbr_rows[b * 27 + nbi]], bit) & bit) m &= ~(1u << k);
+        if (rowk[k] < 0) continue;
+        const uint32_t bit = 1u << lk[k];
+        if (shared && (atomicOr(&need_mask[rowk[k]], bit) & bit)) continue;
+        s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];
       }
     }
-    masks |= m << (8 * c);
-    total += __popc(m);
   }
-  const int off = total ? atomicAdd(&s_count, total) : 0;
   __syncthreads();
-  if (threadIdx.x == 0 && s_count) s_base = atomicAdd(n_entries, s_count);
+  const int cnt = s_count;
+  if (cnt == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(n_entries, cnt);
   __syncthreads();
-  if (!total) return;
-  int64_t pos = (int64_t)s_base + off;
-#pragma unroll 1
-  for (int c = 0; c < kMarkItems; ++c) {
-    const uint32_t m = (masks >> (8 * c)) & 255u;
-    if (!m) continue;
-    const int64_t t = t0 + (int64_t)c * kMarkThreads;
-    const int64_t b = t / 27;
-    const int p = (int)(t - b * 27);
-    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (!((m >> k) & 1)) continue;
-      int nbi, li;
-      bool dup;
-      mark_corner(d, k, nbi, li, dup);
-      if (pos < entry_capacity) entries[pos] = (nbr_rows[b * 27 + nbi] << 5) | li;
-      ++pos;
-    }
-  }
+  const int base = s_base;
+  for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
+    if (base + i < entry_capacity) entries[base + i] = s_buf[i];
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
+__global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                        const float* __restrict__ table, bnv_grid_t g,
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
                                                        float* __restrict__ out, const int32_t* __restrict__ n_dev) {
@@ -2234,19 +2201,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_la
   const int64_t b = t / 27;
   const int p = (int)(t - b * 27);
   const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};  // lattice point = origin + 0.5 * d
-  // Every corner has the same weight 0.5^m (m = axes with a half-voxel offset) and the reference's normaliser, the
-  // sequential sum of the 8 weights, is exactly 8 * 0.5^m -- so one pass over the corners suffices and nothing is
-  // kept in arrays (24 VGPRs instead of 48: the kernel then fits beside the persistent MLP kernels of other streams).
-  const int m = (d[0] != 0) + (d[1] != 0) + (d[2] != 0);
-  const float wc = m == 0 ? 1.f : (m == 1 ? 0.5f : (m == 2 ? 0.25f : 0.125f));
-  const float w = __fdiv_rn(wc, 8.f * wc);
-  bool ok = true;
-  float acc = 0.f, dacc = 0.f;
+  float wk[8];
+  int rowk[8], lk[8];
+  float ck[8][3];
+  float norm = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int cb = kCornerCeilBits[k];
     int nbi = 0, li = 0;
-    float ck[3];
+    float w = 1.f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       int nb_a = 0, loc2 = 0;  // neighbour offset of the corner voxel, 2 * local coordinate
@@ -2258,16 +2221,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(16))) void k_la
           nb_a = (d[a] - 1) / 2;
           loc2 = 1;
         }
+        w = __fmul_rn(w, 0.5f);
       }
       nbi = nbi * 3 + (nb_a + 1);
       li = li * 3 + (loc2 + 1);
-      if (delta.data) ck[a] = (float)(origins[b * 3 + a] + nb_a);
+      ck[k][a] = (float)(origins[b * 3 + a] + nb_a);
     }
-    const int row = nbr_rows[b * 27 + nbi];
-    if (row < 0) ok = false;
-    const float a = row >= 0 ? table[(size_t)row * 27 + li] : 0.f;
+    wk[k] = w;
+    lk[k] = li;
+    rowk[k] = nbr_rows[b * 27 + nbi];
+    norm = __fadd_rn(norm, w);
+  }
+  bool ok = true;
+  float acc = 0.f, dacc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = __fdiv_rn(wk[k], norm);
+    if (rowk[k] < 0) ok = false;
+    const float a = rowk[k] >= 0 ? table[(size_t)rowk[k] * 27 + lk[k]] : 0.f;
     acc = __fadd_rn(acc, __fmul_rn(a, w));
-    if (delta.data) dacc = __fadd_rn(dacc, __fmul_rn(sample_delta(delta, g, ck), w));
+    if (delta.data) dacc = __fadd_rn(dacc, __fmul_rn(sample_delta(delta, g, ck[k]), w));
   }
   float o = ok ? acc : g.voxel_size;
   if (delta.data) o = __fadd_rn(o, dacc);
@@ -2563,8 +2536,7 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark,
-                     dim3((unsigned)((n * 27 + kMarkThreads * kMarkItems - 1) / (kMarkThreads * kMarkItems))),
+  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
                      ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
   BNV_LAUNCH_CHECK();

@@ -608,7 +608,7 @@ constexpr int kEncProfLds = 0;
 int g_encoder_overlap = 0;
 
 template <bool OVERLAP, int NPROD>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
+__global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
     int32_t* __restrict__ counts, long long* __restrict__ acc) {

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_front_top(uint32_t* __restrict__ block_
 // pad_total: when not null (= the valid-pixel count written by k_front_top), the rows behind the valid ones are
 // filled with NaN here -- invalid pixel i goes to row n_valid + (i - valid pixels before i) -- so that the caller
 // needs no separate fill of the H*W-row buffer.
-__global__ __launch_bounds__(kFrontThreads) __attribute__((amdgpu_num_vgpr(16))) void k_front_points(FrontArgs a, const uint32_t* __restrict__ block_sums,
+__global__ __launch_bounds__(kFrontThreads) void k_front_points(FrontArgs a, const uint32_t* __restrict__ block_sums,
                                                                 float* __restrict__ out,
                                                                 const int32_t* __restrict__ pad_total) {
   __shared__ uint32_t wave_tot[kFrontThreads / 64];
