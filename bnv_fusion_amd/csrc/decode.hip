@@ -2191,6 +2191,9 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     if (base + i < entry_capacity) entries[base + i] = s_buf[i];
 }
 
+// DELTA = false: the streaming case (no TSDF prior): 8 table reads and a weighted sum, few registers -- it runs
+// beside the persistent MLP kernels of the other streams.
+template <bool DELTA>
 __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                        const float* __restrict__ table, bnv_grid_t g,
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
@@ -2201,6 +2204,41 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   const int64_t b = t / 27;
   const int p = (int)(t - b * 27);
   const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};  // lattice point = origin + 0.5 * d
+  if constexpr (!DELTA) {
+    // Every corner has the same weight 0.5^m (m = axes with a half-voxel offset) and the reference's normaliser, the
+    // sequential sum of the 8 weights, is exactly 8 * 0.5^m: one pass, nothing kept in arrays (<= 32 VGPRs).
+    const int m = (d[0] != 0) + (d[1] != 0) + (d[2] != 0);
+    const float wc = m == 0 ? 1.f : (m == 1 ? 0.5f : (m == 2 ? 0.25f : 0.125f));
+    const float w = __fdiv_rn(wc, 8.f * wc);
+    bool ok = true;
+    float acc = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+      const int cb = kCornerCeilBits[k];
+      int nbi = 0, li = 0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        int nb_a = 0, loc2 = 0;
+        if (d[a] != 0) {
+          if ((cb >> a) & 1) {
+            nb_a = (d[a] + 1) / 2;
+            loc2 = -1;
+          } else {
+            nb_a = (d[a] - 1) / 2;
+            loc2 = 1;
+          }
+        }
+        nbi = nbi * 3 + (nb_a + 1);
+        li = li * 3 + (loc2 + 1);
+      }
+      const int row = nbr_rows[b * 27 + nbi];
+      if (row < 0) ok = false;
+      const float a = row >= 0 ? table[(size_t)row * 27 + li] : 0.f;
+      acc = __fadd_rn(acc, __fmul_rn(a, w));
+    }
+    out[t] = ok ? acc : g.voxel_size;
+    return;
+  }
   float wk[8];
   int rowk[8], lk[8];
   float ck[8][3];
@@ -2225,7 +2263,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
       }
       nbi = nbi * 3 + (nb_a + 1);
       li = li * 3 + (loc2 + 1);
-      ck[k][a] = (float)(origins[b * 3 + a] + nb_a);
+      if (DELTA) ck[k][a] = (float)(origins[b * 3 + a] + nb_a);
     }
     wk[k] = w;
     lk[k] = li;
@@ -2240,10 +2278,10 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
     if (rowk[k] < 0) ok = false;
     const float a = rowk[k] >= 0 ? table[(size_t)rowk[k] * 27 + lk[k]] : 0.f;
     acc = __fadd_rn(acc, __fmul_rn(a, w));
-    if (delta.data) dacc = __fadd_rn(dacc, __fmul_rn(sample_delta(delta, g, ck[k]), w));
+    if (DELTA) dacc = __fadd_rn(dacc, __fmul_rn(sample_delta(delta, g, ck[k]), w));
   }
   float o = ok ? acc : g.voxel_size;
-  if (delta.data) o = __fadd_rn(o, dacc);
+  if (DELTA) o = __fadd_rn(o, dacc);
   out[t] = o;
 }
 
@@ -2580,8 +2618,12 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   bnv_sdf_delta_t d = {};
   if (delta) d = *delta;
-  hipLaunchKernelGGL(k_lattice_blend, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
+  if (d.data)
+    hipLaunchKernelGGL(k_lattice_blend<true>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
+  else
+    hipLaunchKernelGGL(k_lattice_blend<false>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

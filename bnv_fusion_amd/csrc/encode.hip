@@ -607,8 +607,12 @@ constexpr int kEncProfLds = 0;
 // two waves take 652 together): the kernel is bound by MFMA cycles + VALU cycles, not by their maximum.
 int g_encoder_overlap = 0;
 
+// amdgpu_num_vgpr(120) = 240 of the unified register file (the attribute counts half of it on this target): at 241
+// the two waves of a SIMD leave 16 VGPRs per lane to kernels of other streams, at 240 they leave 32 -- enough for the
+// frame's small kernels (upsert, TSDF, neighbour rows, blend) to run BESIDE this kernel instead of behind it
+// (tools/probe_coresidency.py).  No spills.
 template <bool OVERLAP, int NPROD>
-__global__ __launch_bounds__(512, 2) void k_pointnet_scatter_h(
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
     int32_t* __restrict__ counts, long long* __restrict__ acc) {
