@@ -12,6 +12,8 @@ region.  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL:
 batch); --parallelism spatial shards the active-voxel set by spatial hash and exchanges corner-voxel SDF tables
 per frame (bnv_fusion_amd/distributed.py).  In frame-parallel mode one step is one batch
 of N consecutive frames of the same stream (one per rank; weak scaling), `value` counts all of them.
+The timed region runs with the cyclic garbage collector disabled and a volume that does not grow inside it
+(timing hygiene); BNV_BENCH_DEBUG=1 prints per-frame enqueue times to stderr.
 Rank 0 prints ONE JSON line: metric / value plus `roofline` (dominant kernel, timed alone), `kernels`,
 `parity` (spot check against the oracle), `other_mlp_modes`, `cpu_baseline` (the oracle on the host cores).
 """
