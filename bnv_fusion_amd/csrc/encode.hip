@@ -229,8 +229,11 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_partial(F f, const int32_
 // one block of 1024 threads: exclusive scan of block_sums[0:n_blocks) in place, total appended
 // (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
 // workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
+// what: 0 nothing more; 1 the total is the frame's number of touched voxels (counters->n_unique); 2 the total is
+// the number of emitted voxels and the frame's counters are completed (these were two single-thread launches).
 __global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
-                                                   int32_t* __restrict__ total_out) {
+                                                   int32_t* __restrict__ total_out,
+                                                   bnv_encode_counters_t* __restrict__ counters = nullptr, int what = 0) {
   __shared__ uint32_t wave_tot[16];
   uint32_t carry = 0;
   for (int base = 0; base < n_blocks; base += 256) {
@@ -244,6 +247,15 @@ __global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ block_s
   if (threadIdx.x == 0) {
     block_sums[n_blocks] = carry;
     if (total_out) *total_out = (int32_t)carry;
+    if (what == 1) {
+      counters->n_unique = (int32_t)carry;
+    } else if (what == 2) {
+      // n_avg_pts = mean over ALL U voxels of the pair count (local_point_fusion.py:143); every valid
+      // point contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid.
+      const int U = counters->n_unique;
+      counters->n_out = (int32_t)carry;
+      counters->n_avg_pts = (U > 0) ? __fdiv_rn((float)(8 * counters->n_valid_points), (float)U) : 0.f;
+    }
   }
 }
 
@@ -1076,20 +1088,6 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
   }
 }
 
-__global__ void k_finalize_counters(const uint32_t* __restrict__ block_sums, int n_blocks,
-                                    bnv_encode_counters_t* __restrict__ counters) {
-  // n_avg_pts = mean over ALL U voxels of the pair count (local_point_fusion.py:143); every valid
-  // point contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid.
-  const int U = counters->n_unique;
-  counters->n_out = (int32_t)block_sums[n_blocks];
-  counters->n_avg_pts = (U > 0) ? __fdiv_rn((float)(8 * counters->n_valid_points), (float)U) : 0.f;
-}
-
-__global__ void k_set_unique(const uint32_t* __restrict__ block_sums, int n_blocks,
-                             bnv_encode_counters_t* __restrict__ counters) {
-  counters->n_unique = (int32_t)block_sums[n_blocks];
-}
-
 // ------------------------------------------------------------------------------------------
 // k_voxelize_pairs (dense path + tests)
 // ------------------------------------------------------------------------------------------
@@ -1250,9 +1248,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   hipLaunchKernelGGL(k_scan_partial<PopcWords>, dim3(nb_words), dim3(kScanThreads), 0, stream,
                      PopcWords{ws.bitmap}, (const int32_t*)nullptr, ws.n_words, ws.block_sums);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_set_unique, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_words, counters);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr, counters, 1);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scan_apply_bitmap, dim3(nb_words), dim3(kScanThreads), 0, stream, ws.bitmap, ws.n_words,
                      ws.block_sums, ws.word_prefix, ws.ids, ws.max_unique, counters);
@@ -1288,9 +1284,7 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
   hipLaunchKernelGGL(k_scan_partial<ValidFlags>, dim3(nb_u), dim3(kScanThreads), 0, stream,
                      ValidFlags{ws.counts, ws.ids, g, emit_all}, &counters->n_unique, (int64_t)0, ws.block_sums);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_finalize_counters, dim3(1), dim3(1), 0, stream, ws.block_sums, nb_u, counters);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr, counters, 2);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
                      ws.counts, ws.acc, ws.block_sums, out_feats, out_pcounts, out_flat_ids, out_grid_ids,

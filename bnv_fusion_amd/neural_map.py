@@ -126,7 +126,7 @@ class NeuralMap:
     def _mark_volume_update(self):
         """An event behind a volume update enqueued on the current stream (the side stream of a later
         fuse_and_decode_async waits for it)."""
-        if self._prep_stream is not None:
+        if self._prep_stream is not None or self._enc_stream is not None:
             self._vol_ev = torch.cuda.Event()
             self._vol_ev.record()
 
@@ -152,10 +152,17 @@ class NeuralMap:
         with torch.no_grad():
             v = self.volume
             main = torch.cuda.current_stream()
+            tsdf_done = False
             if self.overlap_encode:
                 if self._enc_stream is None:
                     self._enc_stream = torch.cuda.Stream(device=v._dev)
                 with torch.cuda.stream(self._enc_stream):
+                    # the TSDF side fusion depends on the frame only as well: ahead of the encode on this stream it
+                    # runs beside the previous frame's decode instead of between this frame's encoder and decoder
+                    if self._vol_ev is not None:      # a synchronous integrate() on the main stream came before
+                        self._enc_stream.wait_event(self._vol_ev)
+                    self._integrate_tsdf(frame)
+                    tsdf_done = True
                     input_pts = frame_input_pts(frame)
                     feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
                         input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
@@ -185,7 +192,8 @@ class NeuralMap:
                     for t in (feats, pcounts, flat_ids, grid_ids, counters):
                         t.record_stream(prep)
                     v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
-                    self._integrate_tsdf(frame)
+                    if not tsdf_done:
+                        self._integrate_tsdf(frame)
                     v.lattice_stage_a(grid_ids, n_dev, slot)
                     host.copy_(counters, non_blocking=True)
                     host_rows.copy_(v._n_rows, non_blocking=True)
@@ -200,7 +208,8 @@ class NeuralMap:
                 return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
             self._join()
             v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
-            self._integrate_tsdf(frame)
+            if not tsdf_done:
+                self._integrate_tsdf(frame)
             sdf = v.decode_lattice(grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False,
                                    n_dev=n_dev) if decode else None
             host.copy_(counters, non_blocking=True)

@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung GPU call or rendezvous must fail ONE test with a stack dump, not stall the whole run: every test gets a
+    generous per-test limit when pytest-timeout is installed (thread method: it also fires inside a blocked C call)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
