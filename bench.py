@@ -7,22 +7,37 @@
 One step = one synthetic 640x480 frame: uint16 depth image -> points + normals (GPU front end) ->
 encode_pointcloud + _integrate into the persistent volume (+ TSDF side fusion) (fused) + SDF decode of the
 3x3x3 lattice of every voxel that encode returned (decoded).  Inputs are resident in HBM before the timed
-region.  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL: by default frame-parallel
-(ranks encode / decode different frames of a batch, replicated volume, one all-gather of encoded voxels per
-batch); --parallelism spatial shards the active-voxel set by spatial hash and exchanges corner-voxel SDF tables
-per frame (bnv_fusion_amd/distributed.py).  In frame-parallel mode one step is one batch
-of N consecutive frames of the same stream (one per rank; weak scaling), `value` counts all of them.
+region.
+
+N > 1: one rank per GPU over RCCL.  Started either by `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or as plain `python bench.py --gpus N`, which
+starts the N ranks itself as a child `torch.distributed.run` BEFORE this process makes any GPU call and exits with
+the child's code.  Default decomposition: frame-parallel (ranks encode / decode different frames of a batch,
+replicated volume, one all-gather of encoded voxels per batch; one step = one batch of N consecutive frames of
+the same stream, weak scaling, `value` counts all of them); --parallelism spatial shards the active-voxel set by
+spatial hash and exchanges boundary records per frame (bnv_fusion_amd/distributed.py).
+
 The timed region runs with the cyclic garbage collector disabled and a volume that does not grow inside it
 (timing hygiene); BNV_BENCH_DEBUG=1 prints per-frame enqueue times to stderr.
-Rank 0 prints ONE JSON line: metric / value plus `roofline` (dominant kernel, timed alone), `kernels`,
-`parity` (spot check against the oracle), `other_mlp_modes`, `cpu_baseline` (the oracle on the host cores).
+Rank 0 prints ONE JSON line: metric / value plus
+  roofline         dominant kernel of the headline arithmetic mode, timed alone (HIP events on its stream);
+  fp32_exact       the same --steps in IEEE-fp32 MFMA arithmetic (the reference's precision to the letter), with its
+                   own kernel-alone roofline and parity check;
+  sustained        >= 1,000 frames back to back (frames/s, shader clock and package power while it ran);
+  growth           frames/s from an empty volume of the reference's initial capacity (100,000 rows), growing on demand;
+  parity           GPU outputs of the last timed frame against the oracle (>= 2,000 voxels);
+  other_mlp_modes  the f16-operand mode (lower precision, never the headline);
+  cpu_baseline     the oracle on the host cores.
 """
 import argparse
 import ctypes as C
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -42,34 +57,92 @@ DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
          2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
          3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_32x32x16_f16, f32 accumulate"}
+DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_h<3>", 2: "k_decode<LATTICE, tcnn>",
+                 3: "k_lattice_table_h<1>"}
+PARITY_VOXELS = 2048
 
-
-# Row capacity of the volume.  The tables grow on demand like the reference's Open3D map, but a growth step (sync +
-# re-allocation + re-hash, ~40 ms) is a one-off that must not land in a 70 ms timed region: the host-side bound that
-# triggers it counts the worst-case reservations of the frames in flight (up to 3 x 307,201 rows at 640x480 on top of
-# ~350,000 known rows), so 2^20 rows were sometimes not enough -- and whether the step fell into the timed region
-# depended on how far the host happened to run ahead.
+# Row capacity of the volume in the timed runs.  The tables grow on demand like the reference's Open3D map, but a
+# growth step (sync + re-allocation + re-hash, ~40 ms) is a one-off that must not land in a 100 ms timed region: the
+# host-side bound that triggers it counts the worst-case reservations of the frames in flight (up to 3 x 307,201 rows
+# at 640x480 on top of ~350,000 known rows).  What growing from the reference's 100,000 rows costs is reported
+# separately (`growth`).
 CAPACITY = 1 << 22
+PROFILE_TAG = "r02"
 
 
-def pmc_traffic_bytes(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_summary.csv; separate --pmc runs): 2 x FETCH_SIZE + WRITE_SIZE, in KB
-    units, FETCH doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.csv")
-    if not os.path.exists(path):
-        return None
+def pmc_traffic(kernel_substr, evals_now):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<tag>_pmc_summary.csv; separate --pmc runs): 2 x FETCH_SIZE + WRITE_SIZE in KB units, FETCH doubled
+    as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  The counters cannot be collected from
+    inside this process, so the figure is the profile's -- it is only emitted when this run's evaluations per
+    launch are within 10 % of the profiled run's, and its source is named next to it."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_summary.csv")
+    meta_path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_meta.json")
+    if not (os.path.exists(path) and os.path.exists(meta_path)):
+        return None, None
+    meta = json.load(open(meta_path))
     fetch = write = None
     for line in open(path):
-        if kernel_substr in line and "k_lattice_table_h<1>" not in line:
+        if kernel_substr in line:
             parts = line.strip().rsplit(",", 3)
             if parts[1] == "FETCH_SIZE":
                 fetch = float(parts[2])
             elif parts[1] == "WRITE_SIZE":
                 write = float(parts[2])
     if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+        return None, None
+    prof_evals = float(meta.get("mlp_evals_per_launch", 0.0))
+    src = {"file": f"profiles/{PROFILE_TAG}_pmc_summary.csv", "source_commit": meta.get("commit"),
+           "mlp_evals_per_launch_in_profile": prof_evals,
+           "algorithmic_bytes": "40 B x evaluations (32 B feature row + 4 B entry id read, 4 B table entry written)"}
+    if not prof_evals or abs(evals_now - prof_evals) > 0.10 * prof_evals:
+        src["dropped"] = "evaluations per launch of this run differ from the profiled run's by more than 10 %"
+        return None, src
+    return (2.0 * fetch + write) * 1024.0, src
+
+
+class SmiSampler:
+    """Samples shader clock and package power with rocm-smi from a host thread while a pass runs."""
+
+    def __init__(self, period=0.25):
+        self.period, self.samples, self._stop, self._th = period, [], False, None
+
+    def _loop(self):
+        while not self._stop:
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True,
+                                   text=True, timeout=5).stdout
+                card = next(iter(json.loads(o).values()))
+                sclk = pwr = None
+                for k, v in card.items():
+                    kl = k.lower()
+                    if "sclk" in kl and "mhz" in str(v).lower():
+                        sclk = float(str(v).lower().replace("(", " ").replace("mhz", " ").split()[0])
+                    elif "power" in kl and "(w)" in kl:
+                        try:
+                            pwr = float(v)
+                        except ValueError:
+                            pass
+                self.samples.append((time.perf_counter(), sclk, pwr))
+            except Exception:
+                return
+            time.sleep(self.period)
+
+    def __enter__(self):
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self._th.join(timeout=10)
+
+    def summary(self, t0, t1):
+        inside = [(c, p) for (t, c, p) in self.samples if t0 <= t <= t1]
+        clk = [c for c, _ in inside if c]
+        pw = [p for _, p in inside if p]
+        return {"smi_samples": len(inside), "mean_sclk_mhz": float(np.mean(clk)) if clk else None,
+                "mean_package_power_w": float(np.mean(pw)) if pw else None}
 
 
 def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
@@ -120,10 +193,25 @@ def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
             "front_end_s": t_front, "encode_s": t_enc, "integrate_s": t_int, "decode_s_scaled": t_dec}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (a fresh
+    process tree; this process has not touched the GPU and never will) and leave with the child's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["BNV_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=256, choices=[128, 256, 512])
     ap.add_argument("--preroll", type=int, default=30,
@@ -132,7 +220,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1, 3],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
-    ap.add_argument("--no-alt-mode", action="store_true", help="skip the short run in the other MLP mode")
+    ap.add_argument("--no-alt-mode", action="store_true",
+                    help="skip the fp32_exact run, the f16-operand run, the sustained pass and the growth run")
+    ap.add_argument("--sustained-frames", type=int, default=1000,
+                    help="frames of the sustained pass (1 GPU; 0 = skip)")
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"],
                     help="fp32: pointnet.ckpt networks (oracle-pinned; the headline); tcnn: the reference's default "
                          "tiny-cuda-nn fp16 networks (pointnet_tcnn.ckpt)")
@@ -147,20 +238,36 @@ def main():
     ap.add_argument("--parallelism", default="frame", choices=["frame", "spatial"],
                     help="N > 1: 'frame' = ranks encode/decode different frames of a batch, replicated volume, one "
                          "all-gather per batch (throughput scaling); 'spatial' = voxels sharded by spatial hash, "
-                         "table all-gather per frame")
+                         "boundary exchange per frame")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="launcher test (no GPU needed): every rank checks RANK / WORLD_SIZE against --gpus, rank 0 "
+                         "prints them, all exit before any GPU call")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.dry_run_launch:
+        if rank == 0:
+            print(json.dumps({"dry_run_launch": True, "world": world, "gpus": args.gpus,
+                              "self_launched": os.environ.get("BNV_BENCH_SELF_LAUNCHED") == "1"}))
+        return
     # one rank per GPU; BNV_DIST_BACKEND=gloo lets several ranks share a GPU for functional testing
     backend = os.environ.get("BNV_DIST_BACKEND", "nccl")
-    local_dev = local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = torch.cuda.device_count()              # (does not initialise the GPU)
+    if backend == "nccl" and world > 1 and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPUs visible -- RCCL needs one GPU "
+                         "per rank (BNV_DIST_BACKEND=gloo lets ranks share a GPU for functional tests)")
+    local_dev = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_dev)
     dev = f"cuda:{local_dev}"
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
@@ -175,29 +282,34 @@ def main():
     from bnv_fusion_amd import synthetic, _lib
 
     dims, voxel = synthetic.GRID_DIMS[args.grid]
+    dims3 = np.array([dims] * 3)
     tcnn = args.checkpoint == "tcnn"
     model = bnv.load_pretrained(device=dev, voxel_size=voxel, tiny_cuda=tcnn)
     if tcnn:
         args.no_alt_mode = True
         args.mlp_mode = 2
     frame_parallel = world > 1 and args.parallelism == "frame"
+    with_tsdf = args.input == "depth"
     if frame_parallel:
         from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-        nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device=dev, tsdf=(args.input == "depth"),
-                                    capacity=CAPACITY)
+        nm = FrameParallelNeuralMap(dims3, voxel, model, device=dev, tsdf=with_tsdf, capacity=CAPACITY)
+        nm.backend.inputs_resident = True
     elif world > 1:
         from bnv_fusion_amd.distributed import ShardedNeuralMap
-        nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device=dev)
+        nm = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY)
     else:
-        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=CAPACITY, device=dev,
-                           tsdf=(args.input == "depth"))
+        nm = bnv.NeuralMap(dims3, voxel, model, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
         nm.overlap_encode = not args.no_stream_overlap
+        nm.inputs_resident = True      # every frame is uploaded (and synchronised) before anything is timed
 
     # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
     # frames per step: one frame on one GPU; in frame-parallel mode a step is one batch = one frame PER RANK
     # (weak scaling: per-GPU work per step is fixed, `value` counts the frames of all ranks)
     fpu = world if frame_parallel else 1
     n_frames = args.preroll + (args.warmup + args.steps) * fpu
+    POOL = 64                      # two pan periods (synthetic.yaw_deg): the sustained pass cycles over them
+    if world == 1 and not args.no_alt_mode and args.sustained_frames:
+        n_frames = max(n_frames, args.preroll + POOL)
     depth_host = [synthetic.depth_u16(t) for t in range(n_frames)]
     intr = synthetic.intrinsics()
     if args.input == "depth":
@@ -208,18 +320,20 @@ def main():
             d.astype(np.float64) / 1000.0, intr, synthetic.pose(t)).astype(np.float32)[None]).to(dev)}
             for t, d in enumerate(depth_host)]
     n_points = int((depth_host[0] > 0).sum())
+    torch.cuda.synchronize()
 
-    def run_frames(first, count, decode=True, collect=None):
-        """Processes frames [first, first+count) in order; returns this rank's last (coords, sdf)."""
+    def run_frames(idx, decode=True, collect=None, m=None):
+        """Processes the frames with indices ``idx`` in order on map ``m``; returns this rank's last (coords, sdf)."""
+        m = m or nm
         last = (None, None)
         if frame_parallel:
             # batches of `world` consecutive frames, software-pipelined (batch k+1's encode + all-gather are
             # enqueued before batch k's integrate + decode); only the last handle is read back on the host
-            batches = [frames[t0: min(t0 + world, first + count)] for t0 in range(first, first + count, world)]
+            batches = [[frames[t] for t in idx[b0: b0 + world]] for b0 in range(0, len(idx), world)]
             handle = None
-            for handle in nm.process_stream(batches, decode=decode):
+            for handle in m.process_stream(batches, decode=decode):
                 pass
-            nm.flush()
+            m.flush()
             if handle is not None:
                 out = handle.result()
                 if out[0] is not None:
@@ -229,9 +343,9 @@ def main():
             # never waits for the host (each result() waits on that frame's own event only)
             pending = None
             _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
-            for t in range(first, first + count):
+            for t in idx:
                 _a = time.perf_counter()
-                h = nm.fuse_and_decode_async(frames[t], decode=decode)
+                h = m.fuse_and_decode_async(frames[t], decode=decode)
                 if _dbg is not None:
                     _dbg.append(time.perf_counter() - _a)
                 if pending is not None:
@@ -239,28 +353,29 @@ def main():
                     if collect is not None:
                         collect(r)
                 pending = h
-            last = pending.result()
+            if pending is not None:
+                last = pending.result()
+                if collect is not None:
+                    collect(last)
             if _dbg:
                 print("enqueue ms:", " ".join(f"{1e3*x:.2f}" for x in _dbg), file=sys.stderr)
-            if collect is not None:
-                collect(last)
         else:
-            for t in range(first, first + count):
-                last = nm.fuse_and_decode(frames[t]) if decode else (nm.integrate(frames[t]), None)
+            for t in idx:
+                last = m.fuse_and_decode(frames[t]) if decode else (m.integrate(frames[t]), None)
                 if collect is not None:
                     collect(last)
         return last
 
-    run_frames(0, args.preroll, decode=False)           # setup: make the decode mask live
+    run_frames(list(range(args.preroll)), decode=False)           # setup: make the decode mask live
 
     lib = _lib.load()
 
-    def timed(mode, first, steps, warm):
-        """`warm` untimed steps, then times exactly `steps` steps (`fpu` frames each) from frame index `first`, in
-        MLP mode `mode`."""
+    def timed(mode, idx, warm_idx):
+        """Untimed warm-up over ``warm_idx``, then times exactly the steps ``idx`` (a multiple of `fpu` frame
+        indices), in MLP mode ``mode``."""
         if mode != 2:
             bnv.set_mlp_mode(mode)
-        run_frames(first - warm * fpu, warm * fpu)
+        run_frames(warm_idx)
         lib.bnv_profile_enable(1)
         table_rows, n_vox = [], []
         if world > 1:
@@ -271,35 +386,30 @@ def main():
         # (350 instead of 540 frames/s over 40 frames; found with per-frame enqueue times, BNV_BENCH_DEBUG=1)
         gc.collect()
         gc.disable()
-        _ms0 = torch.cuda.memory_stats() if os.environ.get("BNV_BENCH_DEBUG") else None
         t0 = time.perf_counter()
+
         def collect(res):
             c, _ = res
             n_vox.append(0 if c is None else int(c.shape[0]))
 
         if frame_parallel:
-            coords, sdf = run_frames(first, steps * fpu)
+            coords, sdf = run_frames(idx)
             table_rows.append(nm.volume.last_lattice_evals().clone() if coords is not None
                               else torch.zeros(1, dtype=torch.int32, device=dev))
             n_vox.append(0 if coords is None else int(coords.shape[0]))
         elif world > 1:
-            for t in range(first, first + steps):
+            for t in idx:
                 coords, sdf = nm.fuse_and_decode(frames[t])
-                table_rows.append((nm.volume.last_lattice_table_rows() * 27).clone())
+                table_rows.append(nm.last_mlp_evals().clone())
                 n_vox.append(0 if coords is None else int(coords.shape[0]))
         else:
-            coords, sdf = run_frames(first, steps, collect=collect)
+            coords, sdf = run_frames(idx, collect=collect)
             table_rows.append(nm.volume.last_lattice_evals().clone())
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         gc.enable()
-        if _ms0 is not None:
-            _ms1 = torch.cuda.memory_stats()
-            print("timed region: device allocs", _ms1["num_device_alloc"] - _ms0["num_device_alloc"], "device frees",
-                  _ms1["num_device_free"] - _ms0["num_device_free"], "reserved MB",
-                  _ms1["reserved_bytes.all.current"] >> 20, "retries", _ms1["num_alloc_retries"], file=sys.stderr)
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -314,17 +424,20 @@ def main():
         enc_ms = prof_ms[0] / max(prof_n[0], 1)
         dec_flop = float(rows.mean()) * (FLOP_PER_EVAL_TCNN if mode == 2 else FLOP_PER_EVAL)
         enc_flop = 8.0 * n_points * (FLOP_PER_PAIR_TCNN if mode == 2 else FLOP_PER_PAIR)
-        return {"elapsed": elapsed, "steps": steps, "fps": steps * fpu / elapsed, "rows": float(rows.mean()),
+        steps = len(idx) // fpu
+        return {"elapsed": elapsed, "steps": steps, "fps": len(idx) / elapsed, "rows": float(rows.mean()),
                 "n_vox": float(np.mean(n_vox)), "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
                 "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
                 "enc_tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0, "dec_flop": dec_flop,
-                "coords": coords, "sdf": sdf}
+                "coords": coords, "sdf": sdf, "frames_this_rank": len(n_vox) if world == 1 else
+                (len(idx) // world if frame_parallel else len(idx))}
 
     first = args.preroll + args.warmup * fpu
-    main_run = timed(args.mlp_mode, first, args.steps, args.warmup)
-    elapsed = main_run["elapsed"]
-    # parity spot check of a configuration against the oracle (40 voxels of its last frame): the SDF decoded by
-    # the GPU from the GPU's own volume vs the oracle's decode of the same volume values
+    warm_idx = list(range(args.preroll, first))
+    step_idx = list(range(first, first + args.steps * fpu))
+
+    # parity check of a configuration against the oracle (PARITY_VOXELS voxels of its last frame): the SDF lattice
+    # decoded by the GPU from the GPU's own volume vs the oracle's decode of the same volume values
     def parity_check(run):
         if not ((world == 1 or frame_parallel) and rank == 0 and run["coords"] is not None):
             return None
@@ -335,52 +448,126 @@ def main():
             geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
                 ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
         g = run["coords"]
-        sel = torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:40].to(g.device)
+        sel = torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:PARITY_VOXELS].to(g.device)
         pick = g[sel].cpu()
         off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
         nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
         fo, wo, _ = nm.volume.query(nbr.to(dev))
-        ovol = orc.OracleSparseVolume(8, voxel, np.array([dims] * 3), 8)
+        ovol = orc.OracleSparseVolume(8, voxel, dims3, 8)
         present = wo[:, 0].cpu() > 0
         ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
-        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
-                              geo=geo)[0, :, :, 0]
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        with torch.no_grad():
+            ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
+                                  geo=geo)[0, :, :, 0]
         if world == 1:
             got = run["sdf"][sel].cpu()     # the very output of the last timed frame (no extra launch)
         else:                               # replicated volume has moved on: decode again from the current state
             got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
         return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
                 "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
-                "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)), "voxels_checked": 40}
+                "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)),
+                "live_fraction_checked": float((ref != voxel).float().mean()),
+                "voxels_checked": int(len(pick)), "sdf_values_checked": int(ref.numel())}
 
-    parity = parity_check(main_run)          # right after the timed region: the volume is in that run's final state
-    # Kernel-alone pass for the roofline: with the encode on a second stream the two MLP kernels of consecutive
-    # frames share the GPU, so their event-to-event durations overlap.  A roofline needs the kernel's own
-    # duration: a few of the same frames are run again with everything on one stream (and that is how the
-    # committed rocprofv3 summaries are taken: --no-stream-overlap).
-    kern_run, kern_note = main_run, "timed region"
-    if world == 1 and getattr(nm, "overlap_encode", False):
-        nm.overlap_encode = False
-        # (the CPU-side parity check above left the GPU idle for seconds: same cold start + warm-up as the timed region)
-        kern_run = timed(args.mlp_mode, first, args.steps, args.warmup)
-        nm.overlap_encode = True
-        kern_note = (f"the same {kern_run['steps']} frames (+{args.warmup} warm-up) re-run from an idle GPU with the "
-                     "encode on the main stream, so that each kernel has the GPU to itself (in the timed region the "
-                     "two MLP kernels of consecutive frames overlap); that pass ran at "
-                     f"{kern_run['fps']:.1f} frames/s")
+    def measure(mode):
+        """Timed region + parity + kernel-alone pass in MLP mode ``mode`` -> (timed run, kernel-alone run, note)."""
+        run = timed(mode, step_idx, warm_idx)
+        run["parity"] = parity_check(run)  # right after the timed region: the volume is in that run's final state
+        # Kernel-alone pass for the roofline: with the encode on a second stream the two MLP kernels of consecutive
+        # frames share the GPU, so their event-to-event durations overlap.  A roofline needs the kernel's own
+        # duration: the same frames are run again with everything on one stream (and that is how the committed
+        # rocprofv3 summaries are taken: --no-stream-overlap).
+        kern, note = run, "timed region"
+        if world == 1 and getattr(nm, "overlap_encode", False):
+            nm.overlap_encode = False
+            kern = timed(mode, step_idx, warm_idx)
+            nm.overlap_encode = True
+            note = (f"the same {kern['steps']} frames (+{args.warmup} warm-up) re-run from an idle GPU with the encode "
+                    "on the main stream, so that each kernel has the GPU to itself (in the timed region the two MLP "
+                    f"kernels of consecutive frames overlap); that pass ran at {kern['fps']:.1f} frames/s")
+        return run, kern, note
 
-    # the other arithmetic modes of the fp32 checkpoint on a few of the same frames (the volume state differs
-    # only by those fusions), each with its own parity spot check
+    def roofline_of(mode, kern, note):
+        peak = PEAK_TFLOPS[mode]
+        traffic, src = (None, None)
+        if mode == 1 and world == 1 and not tcnn:
+            traffic, src = pmc_traffic("k_lattice_table_h<3>", kern["rows"])
+        # achieved = algorithmic FLOPs (402,432 per MLP evaluation x evaluations per launch; the split mode issues 3
+        # MFMA products per algorithmic product, which are NOT counted) / mean kernel time from HIP events recorded
+        # on the launch stream
+        return {"bound": "mfma", "kernel": DECODE_KERNEL[mode] + " (SDF MLP 17-256x4-1)",
+                "achieved": kern["dec_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kern["dec_tflops"] / peak,
+                "traffic": traffic, "traffic_source": src,
+                "avg_kernel_ms": kern["dec_ms"], "flop_per_launch": kern["dec_flop"],
+                "mlp_evals_per_launch": kern["rows"],
+                "mfma_issue_frac": kern["dec_tflops"] * MFMA_PER_PRODUCT[mode] / peak, "timing": note}
+
+    main_run, kern_run, kern_note = measure(args.mlp_mode)
+    elapsed = main_run["elapsed"]
+
+    extras = {}
     alts = []
     if not args.no_alt_mode and world == 1 and not tcnn:
-        for am in (0, 1, 3):
+        # ---- the reference's precision to the letter: IEEE fp32 MFMA, the full --steps, its own roofline -------
+        if args.mlp_mode != 0:
+            r0, k0, n0 = measure(0)
+            extras["fp32_exact"] = {
+                "dtype": DTYPE[0], "value": r0["fps"], "unit": "frames/s", "steps": r0["steps"],
+                "ms_per_step": 1e3 * r0["elapsed"] / r0["steps"], "roofline": roofline_of(0, k0, n0),
+                "kernels": {"pointnet_scatter": {"avg_ms": k0["enc_ms"], "tflops": k0["enc_tflops"],
+                                                 "frac_of_peak": k0["enc_tflops"] / PEAK_TFLOPS[0]}},
+                "parity": r0["parity"]}
+        # ---- lower precision, reported for completeness (never the headline) ------------------------------------
+        for am in (1, 3):
             if am == args.mlp_mode:
                 continue
-            r = timed(am, first, min(args.steps, 8), max(args.warmup, 3))
+            r = timed(am, step_idx[: 8], warm_idx[-3:])
             r["mode"], r["parity"] = am, parity_check(r)
             alts.append(r)
         bnv.set_mlp_mode(args.mlp_mode)
 
+        # ---- sustained pass: >= 1,000 frames back to back in the headline mode -----------------------------------
+        if args.sustained_frames:
+            pool = list(range(args.preroll, args.preroll + POOL))      # 2 pan periods: cycling continues the pan
+            idx = [pool[i % POOL] for i in range(args.sustained_frames)]
+            run_frames(pool[:8])
+            torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()
+            with SmiSampler() as smi:
+                t0 = time.perf_counter()
+                run_frames(idx)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            gc.enable()
+            extras["sustained"] = {"frames": len(idx), "value": len(idx) / (t1 - t0), "unit": "frames/s",
+                                   "ms_per_frame": 1e3 * (t1 - t0) / len(idx), "mlp_mode": MODE_NAME[args.mlp_mode],
+                                   "frames_note": f"the {POOL} frames after the pre-roll (two periods of the +-4 degree "
+                                                  "pan), cycled; the volume keeps accumulating",
+                                   **smi.summary(t0, t1)}
+
+        # ---- growth: from an EMPTY volume of the reference's initial capacity (sparse_volume.py:486: 100,000) ---
+        nm2 = bnv.NeuralMap(dims3, voxel, model, capacity=100000, device=dev, tsdf=with_tsdf)
+        nm2.overlap_encode, nm2.inputs_resident = nm.overlap_encode, True
+        cap0 = nm2.volume._row_capacity
+        n_g = min(60, n_frames)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_frames(list(range(n_g)), m=nm2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        extras["growth"] = {"frames": n_g, "value": n_g / (t1 - t0), "unit": "frames/s",
+                            "row_capacity_start": cap0, "row_capacity_end": nm2.volume._row_capacity,
+                            "rows_end": nm2.volume.num_rows(),
+                            "note": "fuse+decode from an empty volume that grows on demand (sync + re-allocation + "
+                                    "re-hash per doubling); early frames decode to the masked constant (weights < "
+                                    "min_pts), so this prices the growth steps, not the steady state"}
+        del nm2
+
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, int(main_run["frames_this_rank"]))
     if rank == 0:
         fps = args.steps * fpu / elapsed
         m = args.mlp_mode
@@ -410,24 +597,19 @@ def main():
                                        "different frames of the batch, "
                                        "replicated volume, one RCCL all-gather of encoded voxels per batch"
                                        if frame_parallel else
-                                       f"spatial-hash voxel sharding x{world} + RCCL all-gather of SDF tables per frame")},
-            # dominant kernel: the lattice-table SDF MLP.  achieved = algorithmic FLOPs (402,432 per MLP
-            # evaluation x evaluations per launch; the split mode issues 3 MFMA products per algorithmic
-            # product, which are NOT counted) / mean kernel time from HIP events on the launch stream
-            "roofline": {"bound": "mfma", "kernel": ("k_lattice_table_h" if m in (1, 3) else f"k_decode<LATTICE,{MODE_NAME[m]}>") + " (SDF MLP 17-256x4-1)",
-                         "achieved": kern_run["dec_tflops"], "peak": peak, "unit": "TFLOP/s",
-                         "frac": kern_run["dec_tflops"] / peak,
-                         "traffic": pmc_traffic_bytes("k_lattice_table_h") if (m == 1 and world == 1 and not tcnn) else None,
-                         "traffic_note": "HBM bytes/launch, rocprofv3 PMC (profiles/r01_pmc_summary.csv); "
-                                         "algorithmic bytes = 40 B x evaluations",
-                         "avg_kernel_ms": kern_run["dec_ms"], "flop_per_launch": kern_run["dec_flop"],
-                         "mlp_evals_per_launch": kern_run["rows"],
-                         "mfma_issue_frac": kern_run["dec_tflops"] * MFMA_PER_PRODUCT[m] / peak,
-                         "timing": kern_note},
+                                       f"spatial-hash voxel sharding x{world} + one RCCL all-gather of boundary records per frame")},
+            "roofline": roofline_of(m, kern_run, kern_note),
             "kernels": {"pointnet_scatter": {"avg_ms": kern_run["enc_ms"], "tflops": kern_run["enc_tflops"],
                                              "frac_of_peak": kern_run["enc_tflops"] / peak}},
-            "parity": parity,
+            "parity": main_run["parity"],
         }
+        if world > 1:
+            out["distributed"] = {"backend": "rccl" if backend == "nccl" else backend, "world_size": world,
+                                  "frames_per_rank": per_rank,
+                                  "launcher": ("bench.py started torch.distributed.run itself"
+                                               if os.environ.get("BNV_BENCH_SELF_LAUNCHED") == "1"
+                                               else "external torch.distributed.run")}
+        out.update(extras)
         out["other_mlp_modes"] = [
             {"mlp_mode": MODE_NAME[a["mode"]], "dtype": DTYPE[a["mode"]], "value": a["fps"], "unit": "frames/s",
              "steps": a["steps"], "ms_per_step": 1e3 * a["elapsed"] / a["steps"], "decode_kernel_ms": a["dec_ms"],

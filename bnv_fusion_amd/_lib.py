@@ -117,12 +117,14 @@ def load():
         "bnv_depth_to_points_padded": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.c_double, vp, sz, vp, vp, vp]),
         "bnv_tsdf_integrate": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float, vp, vp,
-                                         C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, vp]),
+                                         C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                         vp, vp]),
         "bnv_tsdf_integrate_u16": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float, vp, vp,
-                                         C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, vp]),
+                                         C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                         vp, vp]),
         "bnv_tsdf_integrate_batch_u16": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
                                                    C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_float),
-                                                   C.POINTER(C.c_float), C.c_float, vp]),
+                                                   C.POINTER(C.c_float), C.c_float, C.c_float, vp]),
         "bnv_set_mlp_mode": (C.c_int, [C.c_int]),
         "bnv_get_mlp_mode": (C.c_int, []),
         "bnv_set_option": (C.c_int, [C.c_char_p, C.c_int]),

@@ -1524,507 +1524,6 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// k_lattice_table_q: k_lattice_table_h with 64 x 64 register blocking.  There every wave owns 32 output features for
-// all 128 evaluations of the tile, so each of the 8 waves reads the WHOLE activation tile from LDS in every layer
-// (67 % of the LDS bandwidth in split mode, 100 % in f16-operand mode: tools/probe_lds_mfma.hip).  Here wave w owns
-// feature blocks 2*(w>>1), 2*(w>>1)+1 and evaluation blocks 2*(w&1), 2*(w&1)+1: per K-step 2 B fragments per plane
-// from LDS instead of 4, and 2 weight fragments per plane from L2 instead of 1 (twice the weight traffic, half the
-// LDS operand reads; the part is power-bound, and an LDS read costs more than a coalesced L2 read that two waves of
-// the workgroup share through the vector L1).  Same tiles, same work list, same LDS layout, the same accumulation
-// order per output element and the same 16 partial sums of the last layer: tables bit-identical to k_lattice_table_h.
-// ---------------------------------------------------------------------------------------------------
-struct ARingQ {
-  half8 hi[kTRing][2], lo[kTRing][2];
-};
-
-template <int NKS, int BASE, int NEXT_NKS, int NPROD>
-__device__ __forceinline__ void chain_layer_q(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
-                                              const float* __restrict__ bias, const float* __restrict__ hh,
-                                              const float* __restrict__ hl, ARingQ& ring, f32x16 (&acc)[2][2],
-                                              int fg, int h) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const f32x16 b0 = frag256(bias, 2 * fg + a, h);
-    acc[a][0] = b0;
-    acc[a][1] = b0;
-  }
-  const int sl = off + 2 * fg * NKS * 2 * 1024;            // feature block 2*fg; block 2*fg+1 is NKS*2 KB further
-  const int sn = off_next + 2 * fg * NEXT_NKS * 2 * 1024;
-  half8 bh[2][2], bl[2][2];
-#define BNV_LOAD_BQ(ks)                                                                  \
-  {                                                                                      \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                      \
-      bh[(ks) & 1][b] = *(const half8*)(hh + ((ks) * 2 * DM + b * 32) * 4);              \
-      if (NPROD == 3) bl[(ks) & 1][b] = *(const half8*)(hl + ((ks) * 2 * DM + b * 32) * 4); \
-    }                                                                                    \
-  }
-  BNV_LOAD_BQ(0);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int nx = ks + kTAhead;  // the fragments requested during this step
-    bool loads_a = false;
-    if (nx < NKS) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        ring.hi[(BASE + nx) % kTRing][a] = load_frag(rs, voff, sl + (a * NKS * 2 + nx * 2) * 1024);
-        if (NPROD == 3) ring.lo[(BASE + nx) % kTRing][a] = load_frag(rs, voff, sl + (a * NKS * 2 + nx * 2 + 1) * 1024);
-      }
-      loads_a = true;
-    } else if (nx - NKS < NEXT_NKS && nx - NKS < kTAhead) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        ring.hi[(BASE + nx) % kTRing][a] = load_frag(rs, voff, sn + (a * NEXT_NKS * 2 + (nx - NKS) * 2) * 1024);
-        if (NPROD == 3)
-          ring.lo[(BASE + nx) % kTRing][a] = load_frag(rs, voff, sn + (a * NEXT_NKS * 2 + (nx - NKS) * 2 + 1) * 1024);
-      }
-      loads_a = true;
-    }
-    if (ks + 1 < NKS) BNV_LOAD_BQ(ks + 1);
-    if constexpr (NPROD == 3) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring.lo[(BASE + ks) % kTRing][a], bh[ks & 1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring.hi[(BASE + ks) % kTRing][a], bl[ks & 1][b], acc[a][b], 0, 0, 0);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring.hi[(BASE + ks) % kTRing][a], bh[ks & 1][b], acc[a][b], 0, 0, 0);
-    if (ks + 1 < NKS) {
-#pragma unroll
-      for (int g = 0; g < (NPROD == 3 ? 4 : 2); ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-      }
-    }
-    if (loads_a) {
-#pragma unroll
-      for (int g = 0; g < (NPROD == 3 ? 4 : 2); ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef BNV_LOAD_BQ
-}
-
-// ReLU + split + store of a wave's 64 x 64 block in the layout the next layer's B fetch expects
-template <int NPROD>
-__device__ __forceinline__ void store_relu_q(float* __restrict__ lds, const f32x16 (&acc)[2][2], int fg, int eh, int j,
-                                             int h) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int ksl = 0; ksl < 2; ++ksl) {
-        half8 hi, lo;
-        if (NPROD == 3) {
-          float x[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = relu1(acc[a][b][8 * ksl + e]);
-          split8_f16(x, hi, lo);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) hi[e] = (_Float16)relu1(acc[a][b][8 * ksl + e]);
-        }
-        const int o = (((2 * (2 * fg + a) + ksl) * 2 + h) * DM + (2 * eh + b) * 32 + j) * 4;
-        *(half8*)&lds[L_HL + o] = hi;
-        if (NPROD == 3) *(half8*)&lds[L_HLO + o] = lo;
-      }
-    }
-  }
-}
-
-template <int NPROD>
-__global__ __launch_bounds__(512, 2) void k_lattice_table_q(DecodeArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const float voxel = A.grid.voxel_size;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int fg = w >> 1, eh = w & 1;
-  const int j = lane & 31, h = lane >> 5;
-  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
-  const int64_t n_tiles = (n_evals + DM - 1) / DM;
-  const float* pack = A.pack;
-  const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
-  const float s5 = sinf(0.5f), c5 = cosf(0.5f);
-  const bool gatherer = threadIdx.x < DM;
-
-  auto stage_park = [&](int e, int ent, const f32x4& f0, const f32x4& f1) {
-    float in[32];
-#pragma unroll
-    for (int f = 0; f < 32; ++f) in[f] = 0.f;
-    if (ent >= 0) {
-      const int l = ent & 31;
-      const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
-      const int li[3] = {lx, ly, lz};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        in[a] = (float)li[a] * 0.5f;
-        in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
-        in[6 + a] = li[a] == 0 ? 1.f : c5;
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        in[9 + f] = f0[f];
-        in[13 + f] = f1[f];
-      }
-    } else {
-      in[6] = in[7] = in[8] = 1.f;
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        half8 hi, lo;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
-          const _Float16 t = (_Float16)x;
-          hi[jj] = t;
-          if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
-        }
-        const int o = ((ks * 2 + hh) * DM + e) * 4;
-        *(half8*)&lds[T_PARK_HI + o] = hi;
-        if (NPROD == 3) *(half8*)&lds[T_PARK_LO + o] = lo;
-      }
-    }
-  };
-  auto load_feats = [&](int ent, f32x4& f0, f32x4& f1) {
-    if (ent >= 0) {
-      const size_t row = (size_t)(ent >> 5);
-      f0 = *(const f32x4*)&A.features[row * 8];
-      f1 = *(const f32x4*)&A.features[row * 8 + 4];
-    }
-  };
-
-  __shared__ int s_tile[3];
-  int* tile_ctr = (int*)A.n_list + 2;
-  if (threadIdx.x == 0) {
-    s_tile[0] = atomicAdd(tile_ctr, 1);
-    s_tile[1] = atomicAdd(tile_ctr, 1);
-  }
-  __syncthreads();
-  int64_t tile = s_tile[0], tile_nx = s_tile[1];
-  int ent_cur = -1, ent_nx = -1;
-  f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
-  if (gatherer) {
-    if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
-    if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + threadIdx.x, n_evals);
-    load_feats(ent_cur, f0, f1);
-    stage_park(threadIdx.x, ent_cur, f0, f1);
-  }
-  ARingQ ring;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph, 0, SH_TOTAL * 2, 0x00020000);
-  const int voff = lane * 16;
-  constexpr int O0 = SH_W0 * 2, O1 = SH_W1 * 2, O2 = SH_W2 * 2, O3 = SH_W3 * 2;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      ring.hi[p][a] = load_frag(rs, voff, O0 + ((2 * fg + a) * 2 * 2 + p * 2) * 1024);
-      if (NPROD == 3) ring.lo[p][a] = load_frag(rs, voff, O0 + ((2 * fg + a) * 2 * 2 + p * 2 + 1) * 1024);
-    }
-    ring.hi[2][a] = load_frag(rs, voff, O1 + ((2 * fg + a) * 16 * 2) * 1024);
-    if (NPROD == 3) ring.lo[2][a] = load_frag(rs, voff, O1 + ((2 * fg + a) * 16 * 2 + 1) * 1024);
-  }
-  __syncthreads();
-
-  const int col = 64 * eh + j;   // the wave's first evaluation block
-  const float* park_hh = lds + T_PARK_HI + (h * DM + col) * 4;
-  const float* park_hl = lds + T_PARK_LO + (h * DM + col) * 4;
-  const float* hl_hh = lds + L_HL + (h * DM + col) * 4;
-  const float* hl_hl = lds + L_HLO + (h * DM + col) * 4;
-  while (tile < n_tiles) {
-    if (threadIdx.x == 0) s_tile[2] = atomicAdd(tile_ctr, 1);
-    int ent_nx2 = -1;
-    if (gatherer) {
-      f0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_feats(ent_nx, f0, f1);
-    }
-    f32x16 acc[2][2];
-    chain_layer_q<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, fg, h);
-    __syncthreads();
-    const int64_t tile_nx2 = s_tile[2];
-    store_relu_q<NPROD>(lds, acc, fg, eh, j, h);
-    if (gatherer) {
-      stage_park(threadIdx.x, ent_nx, f0, f1);
-      if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + threadIdx.x, n_evals);
-    }
-    __syncthreads();
-    chain_layer_q<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, fg, h);
-    __syncthreads();
-    store_relu_q<NPROD>(lds, acc, fg, eh, j, h);
-    __syncthreads();
-    chain_layer_q<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, hl_hh, hl_hl, ring, acc, fg, h);
-    __syncthreads();
-    store_relu_q<NPROD>(lds, acc, fg, eh, j, h);
-    __syncthreads();
-    chain_layer_q<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, hl_hh, hl_hl, ring, acc, fg, h);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      ring.hi[2][a] = load_frag(rs, voff, O1 + ((2 * fg + a) * 16 * 2) * 1024);  // (50 + 2) % 5, next tile
-      if (NPROD == 3) ring.lo[2][a] = load_frag(rs, voff, O1 + ((2 * fg + a) * 16 * 2 + 1) * 1024);
-    }
-    // fc_alpha: 256 -> 1; one partial per (feature block, lane half), as in k_lattice_table_h
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const f32x16 wa = frag256(pack + SD_WA, 2 * fg + a, h);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum = fmaf(wa[r], relu_bits(acc[a][b][r]), sum);
-        lds[L_PART + ((2 * fg + a) * 2 + h) * DM + (2 * eh + b) * 32 + j] = sum;
-      }
-    }
-    __syncthreads();
-    if (gatherer) {
-      if (ent_cur >= 0) {
-        float sum = pack[SD_BA];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + threadIdx.x];
-        const int row = ent_cur >> 5;
-        A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
-        if (A.entries) A.need_mask[row] = 0u;
-      }
-      ent_cur = ent_nx;
-      ent_nx = ent_nx2;
-    }
-    tile = tile_nx;
-    tile_nx = tile_nx2;
-  }
-  if (threadIdx.x == 0) {
-    int* done = (int*)A.n_list + 3;
-    __threadfence();
-    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
-      *tile_ctr = 0;
-      *done = 0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// k_decode_lattice_h64: the hot case (lattice table, split-operand mode) with 64-evaluation tiles and
-// 4-wave workgroups, two workgroups per CU.  The two waves that share a SIMD then belong to different
-// workgroups and run out of phase, so one wave's barrier / convert / store phase overlaps the other's
-// MFMAs (the 128-evaluation kernel moves all 8 waves of a CU in lock step: MFMA pipe 61 % busy).
-// MEASURED (tools/ab_h64.py, interleaved A/B, 4 rounds): 1.32-1.45 ms vs 1.19-1.41 ms for the 128-evaluation
-// kernel -- the doubled L2 weight traffic cancels the overlap.  Kept as an option, off by default.
-// Wave w owns output features [64w, 64w+64) (two 32-row blocks) for the tile's 64 evaluations (two
-// 32-column tiles): each weight fragment feeds 2 column tiles instead of 4, i.e. twice the L2 weight traffic.
-// ---------------------------------------------------------------------------------------------------
-constexpr int DQ = 64;
-constexpr int Q_HL = 0;                              // hi plane [16 ks][2 h][64 j][8 halves] = 32 KB
-constexpr int Q_HLO = Q_HL + 16 * 2 * DQ * 4;        // lo plane
-constexpr int Q_PART = Q_HLO + 16 * 2 * DQ * 4;      // [4 w][2 nb][2 h][64]
-constexpr int Q_ALPHA = Q_PART + 16 * DQ;
-constexpr int Q_TOTAL = Q_ALPHA + DQ;                // 17,472 floats = 69,888 B
-
-template <int NKS>
-__device__ __forceinline__ void mlp_layer_q(const _Float16* __restrict__ wp, const float* __restrict__ bias,
-                                            const float* __restrict__ lds, f32x16 (&acc)[2][2], int w, int lane,
-                                            int j, int h) {
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const f32x16 b0 = frag256(bias, 2 * w + nb, h);
-    acc[nb][0] = b0;
-    acc[nb][1] = b0;
-  }
-  const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, 8 * NKS * 2 * 64 * 8 * 2, 0x00020000);
-  const int voff = lane * 16;
-  const int sbase = (2 * w) * NKS * 2 * 1024;  // bytes; this wave's two 32-row blocks are contiguous
-  const float* hh = lds + Q_HL + (h * DQ + j) * 4;
-  const float* hl = lds + Q_HLO + (h * DQ + j) * 4;
-  half8 ah[3][2], al[3][2], bh[2][2], bl[2][2];
-#define BNV_LOAD_A(ks)                                                                  \
-  {                                                                                     \
-    ah[(ks) % 3][0] = load_frag(rs, voff, sbase + ((ks) * 2) * 1024);                    \
-    al[(ks) % 3][0] = load_frag(rs, voff, sbase + ((ks) * 2 + 1) * 1024);                \
-    ah[(ks) % 3][1] = load_frag(rs, voff, sbase + (NKS * 2 + (ks) * 2) * 1024);          \
-    al[(ks) % 3][1] = load_frag(rs, voff, sbase + (NKS * 2 + (ks) * 2 + 1) * 1024);      \
-  }
-#define BNV_LOAD_B(ks)                                                                   \
-  {                                                                                      \
-    _Pragma("unroll") for (int pt = 0; pt < 2; ++pt) {                                   \
-      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DQ + pt * 32) * 4);            \
-      bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DQ + pt * 32) * 4);            \
-    }                                                                                    \
-  }
-  BNV_LOAD_A(0);
-  if (NKS > 1) BNV_LOAD_A(1);
-  BNV_LOAD_B(0);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    if (ks + 2 < NKS) BNV_LOAD_A(ks + 2);
-    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks % 3][nb], bh[ks & 1][pt], acc[nb][pt], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks % 3][nb], bl[ks & 1][pt], acc[nb][pt], 0, 0, 0);
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt)
-        acc[nb][pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks % 3][nb], bh[ks & 1][pt], acc[nb][pt], 0, 0, 0);
-    if (ks + 1 < NKS) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-    if (ks + 2 < NKS) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef BNV_LOAD_A
-#undef BNV_LOAD_B
-}
-
-__device__ __forceinline__ void store_relu_q(float* __restrict__ lds, const f32x16 (&acc)[2][2], int w, int j, int h) {
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-      for (int ksl = 0; ksl < 2; ++ksl) {
-        half8 hi, lo;
-        float x[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = relu1(acc[nb][pt][8 * ksl + e]);
-        split8_f16(x, hi, lo);
-        const int o = (((2 * (2 * w + nb) + ksl) * 2 + h) * DQ + pt * 32 + j) * 4;
-        *(half8*)&lds[Q_HL + o] = hi;
-        *(half8*)&lds[Q_HLO + o] = lo;
-      }
-}
-
-__global__ __launch_bounds__(256, 2) void k_decode_lattice_h64(DecodeArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const float voxel = A.grid.voxel_size;
-  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
-  const int64_t n_tiles = (n_evals + DQ - 1) / DQ;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const _Float16* ph = (const _Float16*)(A.pack + SD_TOTAL);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    int row = -1, l = 0;
-    if (threadIdx.x < DQ) {
-      const int64_t e = tile * DQ + threadIdx.x;
-      float loc[3] = {0.f, 0.f, 0.f};
-      float feat[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (e < n_evals) {
-        if (A.entries) {
-          const int ent = A.entries[e];
-          row = ent >> 5;
-          l = ent & 31;
-        } else {
-          const int64_t ci = e / 27;
-          l = (int)(e - ci * 27);
-          row = A.list[ci];
-        }
-        loc[0] = (float)(l / 9 - 1) * 0.5f;
-        loc[1] = (float)((l / 3) % 3 - 1) * 0.5f;
-        loc[2] = (float)(l % 3 - 1) * 0.5f;
-        const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
-        const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-          feat[f] = f0[f];
-          feat[4 + f] = f1[f];
-        }
-      }
-      // inputs in the split layout (features 0..16, zero padded to 32), DQ columns
-      float in[32];
-#pragma unroll
-      for (int f = 0; f < 32; ++f) in[f] = 0.f;
-      in[0] = loc[0]; in[1] = loc[1]; in[2] = loc[2];
-      in[3] = sinf(loc[0]); in[4] = sinf(loc[1]); in[5] = sinf(loc[2]);
-      in[6] = cosf(loc[0]); in[7] = cosf(loc[1]); in[8] = cosf(loc[2]);
-#pragma unroll
-      for (int f = 0; f < 8; ++f) in[9 + f] = feat[f];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          half8 hi, lo;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
-            const _Float16 t = (_Float16)x;
-            hi[jj] = t;
-            lo[jj] = (_Float16)(x - (float)t);
-          }
-          const int o = ((ks * 2 + hh) * DQ + threadIdx.x) * 4;
-          *(half8*)&lds[Q_HL + o] = hi;
-          *(half8*)&lds[Q_HLO + o] = lo;
-        }
-    }
-    __syncthreads();
-    f32x16 acc[2][2];
-    mlp_layer_q<2>(ph + SH_W0, A.pack + SD_B0, lds, acc, w, lane, j, h);
-    __syncthreads();
-    store_relu_q(lds, acc, w, j, h);
-    __syncthreads();
-    mlp_layer_q<16>(ph + SH_W1, A.pack + SD_B0 + 256, lds, acc, w, lane, j, h);
-    __syncthreads();
-    store_relu_q(lds, acc, w, j, h);
-    __syncthreads();
-    mlp_layer_q<16>(ph + SH_W2, A.pack + SD_B0 + 512, lds, acc, w, lane, j, h);
-    __syncthreads();
-    store_relu_q(lds, acc, w, j, h);
-    __syncthreads();
-    mlp_layer_q<16>(ph + SH_W3, A.pack + SD_B0 + 768, lds, acc, w, lane, j, h);
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      const f32x16 wa = frag256(A.pack + SD_WA, 2 * w + nb, h);
-#pragma unroll
-      for (int pt = 0; pt < 2; ++pt) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc = fmaf(wa[r], relu1(acc[nb][pt][r]), sacc);
-        lds[Q_PART + (((w * 2 + nb) * 2) + h) * DQ + pt * 32 + j] = sacc;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < DQ) {
-      float sacc = A.pack[SD_BA];
-#pragma unroll
-      for (int p = 0; p < 16; ++p) sacc += lds[Q_PART + p * DQ + threadIdx.x];
-      if (row >= 0) {
-        if (A.entries) A.need_mask[row] = 0u;
-        A.table[(size_t)row * 27 + l] = __fmul_rn(sacc, voxel);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // ---- lattice decode: neighbour lookup + blend ------------------------------------------------
 struct LatticeWs {
   int32_t* nbr_rows;  // [n][27]
@@ -2286,9 +1785,6 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   out[t] = o;
 }
 
-extern int g_encoder_overlap;  // encode.hip
-int g_lattice_h64 = 0;  // 1: 64-evaluation tiles, 2 workgroups per CU (bnv_set_option); measured 4 % slower
-int g_lattice_quad = 0; // 1: k_lattice_table_q (64 x 64 register blocking) instead of k_lattice_table_h
 int g_lattice_pipe = 1; // 1: k_lattice_table_h (cross-tile / cross-layer pipelined); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
@@ -2298,26 +1794,12 @@ constexpr int kProfLds = 0;
 #endif
 
 static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
-  if (mode == MODE_LATTICE && g_mlp_mode == 1 && g_lattice_h64) {  // (split mode only)
-    int64_t grid = 2 * (int64_t)g_num_cus;
-    if (2 * n_tiles_hint < grid) grid = 2 * n_tiles_hint;
-    if (grid < 1) grid = 1;
-    ProfScope prof(PROF_DECODE_LATTICE, stream);
-    hipLaunchKernelGGL(k_decode_lattice_h64, dim3((unsigned)grid), dim3(256), Q_TOTAL * 4, stream, args);
-    BNV_LAUNCH_CHECK();
-    return BNV_OK;
-  }
   int64_t grid = g_num_cus - g_reserve_cus;
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
   if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
-    if (g_lattice_quad) {
-      if (g_mlp_mode == 1)
-        hipLaunchKernelGGL(k_lattice_table_q<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
-      else
-        hipLaunchKernelGGL(k_lattice_table_q<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
-    } else if (g_mlp_mode == 1)
+    if (g_mlp_mode == 1)
       hipLaunchKernelGGL(k_lattice_table_h<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
     else
       hipLaunchKernelGGL(k_lattice_table_h<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
@@ -2385,15 +1867,9 @@ int bnv_decode_init() {
   BNV_OPT_IN(MODE_LATTICE, 3);
   BNV_OPT_IN(MODE_DENSE, 3);
 #undef BNV_OPT_IN
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_lattice_h64, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    Q_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_q<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_q<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     C_TOTAL * 4));
@@ -2421,14 +1897,6 @@ int bnv_dev_phase_read(unsigned long long* out256) {
 
 int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;
-  if (!strcmp(name, "lattice_h64")) {
-    g_lattice_h64 = value;
-    return BNV_OK;
-  }
-  if (!strcmp(name, "lattice_quad")) {
-    g_lattice_quad = value;
-    return BNV_OK;
-  }
   if (!strcmp(name, "lattice_pipe")) {
     g_lattice_pipe = value;
     return BNV_OK;
@@ -2436,10 +1904,6 @@ int bnv_set_option(const char* name, int value) {
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value >= g_num_cus) return BNV_ERR_INVALID_ARGUMENT;
     g_reserve_cus = value;
-    return BNV_OK;
-  }
-  if (!strcmp(name, "encoder_overlap")) {
-    g_encoder_overlap = value;
     return BNV_OK;
   }
   return BNV_ERR_INVALID_ARGUMENT;

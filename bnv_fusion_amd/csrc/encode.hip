@@ -531,71 +531,6 @@ __device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, cons
 #undef BNV_LOAD_W
 }
 
-// ------------------------------------------------------------------------------------------
-// The point-encoder MLP with the OUTPUT block in the outer loop (split mode).  A wave's own
-// instruction stream used to be the bottleneck: 228 MFMAs (7.3 k cycles) + ~200 ReLU/split VALU ops per
-// layer that could only start once all four accumulators of a layer were complete (tools/phase_prof.py:
-// MFMA pipe 52 % busy).  Here block mb of a layer is finished first (24 accumulate-chained MFMAs --
-// tools/probe_mfma_issue.hip: a dependent chain issues at the full rate), and its ReLU + hi/lo split runs
-// in the shadow of block mb+1's MFMAs; the last block of a layer is converted under the first MFMAs of the
-// next layer, whose K-steps need the blocks in order.  Arithmetic and summation order are unchanged.
-// ------------------------------------------------------------------------------------------
-struct SplitBlock {   // the two K-steps an output block feeds in the next layer
-  half8 h0, l0, h1, l1;
-};
-
-__device__ __forceinline__ SplitBlock split_block(const f32x16& v) {
-  SplitBlock s;
-  split8(v, 0, true, &s.h0, &s.l0);
-  split8(v, 8, true, &s.h1, &s.l1);
-  return s;
-}
-
-// one output block of a 128 -> 128 layer: acc = b + sum_g W[mb][g] x[g]; `pending` (the previous block's
-// accumulator) is converted into (nh, nl)[2 pmb], [2 pmb + 1] inside the same scheduling region
-template <bool HAS_PENDING>
-__device__ __forceinline__ f32x16 block128_h(const _Float16* __restrict__ wp, const float* __restrict__ bias, int mb,
-                                             const half8 (&inh)[8], const half8 (&inl)[8], const f32x16& pending,
-                                             int pmb, half8 (&nh)[8], half8 (&nl)[8], int lane, int h) {
-  f32x16 acc = bias_init(bias, mb, h);
-  half8 ah[2], al[2];
-#define BNV_LOAD_W(g)                                                         \
-  {                                                                           \
-    const _Float16* w = wp + ((((mb) * 8 + (g)) * 2) * 64 + lane) * 8;        \
-    ah[(g) & 1] = *(const half8*)w;                                           \
-    al[(g) & 1] = *(const half8*)(w + 64 * 8);                                \
-  }
-  BNV_LOAD_W(0);
-  if (HAS_PENDING) {
-    const SplitBlock sb = split_block(pending);
-    nh[2 * pmb] = sb.h0;
-    nl[2 * pmb] = sb.l0;
-    nh[2 * pmb + 1] = sb.h1;
-    nl[2 * pmb + 1] = sb.l1;
-  }
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    if (g + 1 < 8) BNV_LOAD_W(g + 1);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[g & 1], inh[g], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g & 1], inl[g], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[g & 1], inh[g], acc, 0, 0, 0);
-  }
-  // issue order of the region: behind every MFMA a few conversion ops, the next step's two weight reads
-  // behind the first two MFMAs of a step
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
-      if (HAS_PENDING) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // 3 VALU
-      if (u < 2 && g + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#undef BNV_LOAD_W
-  return acc;
-}
-
 #ifdef BNV_PHASE_PROF
 __device__ unsigned long long g_enc_phase[8 * 16];
 #define BNV_EPH(i)                                                                          \
@@ -613,17 +548,11 @@ constexpr int kEncProfLds = 8 * 16 * 8;
 constexpr int kEncProfLds = 0;
 #endif
 
-// bnv_set_option("encoder_overlap", 1): output-block-outer MLP.  MEASURED (tools/ab_enc.py): bit-identical
-// features, 0.525 vs 0.523 ms -- no gain, because VALU work of one wave does not overlap the MFMAs of the
-// other wave on the SIMD at all (tools/probe_mfma_valu.hip: 385 cycles of MFMAs + 268 cycles of VALU from
-// two waves take 652 together): the kernel is bound by MFMA cycles + VALU cycles, not by their maximum.
-int g_encoder_overlap = 0;
-
 // amdgpu_num_vgpr(120) = 240 of the unified register file (the attribute counts half of it on this target): at 241
 // the two waves of a SIMD leave 16 VGPRs per lane to kernels of other streams, at 240 they leave 32 -- enough for the
 // frame's small kernels (upsert, TSDF, neighbour rows, blend) to run BESIDE this kernel instead of behind it
 // (tools/probe_coresidency.py).  No spills.
-template <bool OVERLAP, int NPROD>
+template <int NPROD>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
@@ -731,90 +660,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     if (__ballot(slot >= 0) == 0ULL) continue;
 
     f32x16 o;
-    if constexpr (OVERLAP) {
-      // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots); blocks converted one behind -----------
-      half8 xh[8], xl[8], yh[8], yl[8];
-      {
-        half8 bh, bl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = e < 4 ? in[e] : 0.f;
-          const _Float16 hh = (_Float16)x;
-          bh[e] = hh;
-          bl[e] = (_Float16)(x - (float)hh);
-        }
-        f32x16 prev;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-          const _Float16* w = wh + PH_W1 + ((mb * 2) * 64 + lane) * 8;
-          const half8 ahi = *(const half8*)w, alo = *(const half8*)(w + 64 * 8);
-          f32x16 c = bias_init(lb, mb, h);
-          if (mb > 0) {
-            const SplitBlock sb = split_block(prev);
-            xh[2 * (mb - 1)] = sb.h0;
-            xl[2 * (mb - 1)] = sb.l0;
-            xh[2 * (mb - 1) + 1] = sb.h1;
-            xl[2 * (mb - 1) + 1] = sb.l1;
-          }
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
-          prev = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh, c, 0, 0, 0);
-        }
-        BNV_EPH(1);
-        // ---- layer 2 (reads x, writes y); block 0 converts layer 1's last block ------------------------
-        f32x16 cur = block128_h<true>(wh + PH_W2, lb + 128, 0, xh, xl, prev, 3, xh, xl, lane, h);
-        prev = cur;
-#pragma unroll
-        for (int mb = 1; mb < 4; ++mb) {
-          cur = block128_h<true>(wh + PH_W2, lb + 128, mb, xh, xl, prev, mb - 1, yh, yl, lane, h);
-          prev = cur;
-        }
-        BNV_EPH(3);
-        // ---- layer 3 (reads y, writes x) ----------------------------------------------------------------
-        cur = block128_h<true>(wh + PH_W3, lb + 256, 0, yh, yl, prev, 3, yh, yl, lane, h);
-        prev = cur;
-#pragma unroll
-        for (int mb = 1; mb < 4; ++mb) {
-          cur = block128_h<true>(wh + PH_W3, lb + 256, mb, yh, yl, prev, mb - 1, xh, xl, lane, h);
-          prev = cur;
-        }
-        BNV_EPH(5);
-        // ---- layer 4: 128 -> 8; converts layer 3's last block under its first MFMAs --------------------
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        {
-          const f32x4 b4 = *(const f32x4*)&lb[384 + 4 * h];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = b4[r];
-        }
-        half8 w4h[8], w4l[8];
-#pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {
-          const _Float16* w = wh + PH_W4 + ((((gq * 2) * 2 + h) * 8) + (j & 7)) * 8;
-          w4h[gq] = *(const half8*)w;
-          w4l[gq] = *(const half8*)(w + 2 * 8 * 8);
-        }
-        {
-          const SplitBlock sb = split_block(prev);
-          xh[6] = sb.h0;
-          xl[6] = sb.l0;
-          xh[7] = sb.h1;
-          xl[7] = sb.l1;
-        }
-#pragma unroll
-        for (int gq = 0; gq < 8; ++gq) {
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4l[gq], xh[gq], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gq], xl[gq], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gq], xh[gq], o, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 18; ++u) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
     // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots) -----------------------------
     f32x16 ha[4], hb[4];
     {
@@ -897,7 +742,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
       }
     }
 #undef BNV_LOAD_W4
-    }
     BNV_EPH(7);
     scatter_tile(o, slot, j, h, counts, acc);
     BNV_EPH(8);
@@ -1153,11 +997,9 @@ int bnv_init(int device) {
   g_num_cus = cus;
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<false, 3>,
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<3>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<true, 3>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<false, 1>,
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
   extern int bnv_decode_init();
   return bnv_decode_init();
@@ -1264,14 +1106,10 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
                          ws.acc);
     else if (g_mlp_mode == 1) {
-      if (g_encoder_overlap)
-        hipLaunchKernelGGL((k_pointnet_scatter_h<true, 3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                           input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
-      else
-        hipLaunchKernelGGL((k_pointnet_scatter_h<false, 3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                           input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+      hipLaunchKernelGGL((k_pointnet_scatter_h<3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     } else if (g_mlp_mode == 3) {
-      hipLaunchKernelGGL((k_pointnet_scatter_h<false, 1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+      hipLaunchKernelGGL((k_pointnet_scatter_h<1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
                          input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     } else
       hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,

@@ -22,12 +22,16 @@ struct TsdfArgs {
   const float* color_im;  // folded b*65536 + g*256 + r, or null
   const float* depth_im;  // metres, 0 = invalid
   const uint16_t* depth_mm;  // alternative input: the dataset's uint16 millimetres (common.py:93: / 1000.)
+  float max_depth;           // > 0: samples with depth >= max_depth are invalid (common.py:110-113: depth * mask)
+  const int32_t* gate;       // device int32 or null: *gate == 0 -> the launch does nothing (the reference returns from
+                             // NeuralMap.integrate before the TSDF fusion when the encode found no point, run_e2e.py:91-92)
 };
 
 __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
   const int64_t n = (int64_t)a.dim[0] * a.dim[1] * a.dim[2];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= n) return;
+  if (a.gate && *a.gate == 0) return;
   const int yz = a.dim[1] * a.dim[2];
   const int vx = (int)(idx / yz), vy = (int)((idx - (int64_t)vx * yz) / a.dim[2]);
   const int vz = (int)(idx - (int64_t)vx * yz - (int64_t)vy * a.dim[2]);
@@ -45,7 +49,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
   if (px < 0 || px >= a.im_w || py < 0 || py >= a.im_h || cz < 0.f) return;
   const float depth = a.depth_mm ? __fdiv_rn((float)a.depth_mm[(size_t)py * a.im_w + px], 1000.f)
                                  : a.depth_im[(size_t)py * a.im_w + px];
-  if (depth == 0.f) return;
+  if (depth == 0.f || (a.max_depth > 0.f && !(depth < a.max_depth))) return;
   const float diff = depth - cz;
   if (diff < -a.trunc_margin) return;
   const float dist = fminf(1.0f, diff / a.trunc_margin);
@@ -76,7 +80,7 @@ struct TsdfBatchArgs {
   float* weight;
   int dim[3];
   float origin[3];
-  float voxel_size, trunc_margin, obs_weight;
+  float voxel_size, trunc_margin, obs_weight, max_depth;
   int im_h, im_w, n_frames;
   const uint16_t* depth_mm[kTsdfBatchMax];
   float intr[kTsdfBatchMax][4];    // fx, cx, fy, cy
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_batch(TsdfBatchArgs a) {
     const int py = (int)roundf(a.intr[f][2] * (cy / cz) + a.intr[f][3]);
     if (px < 0 || px >= a.im_w || py < 0 || py >= a.im_h || cz < 0.f) continue;
     const float depth = __fdiv_rn((float)a.depth_mm[f][(size_t)py * a.im_w + px], 1000.f);
-    if (depth == 0.f) continue;
+    if (depth == 0.f || (a.max_depth > 0.f && !(depth < a.max_depth))) continue;
     const float diff = depth - cz;
     if (diff < -a.trunc_margin) continue;
     const float dist = fminf(1.0f, diff / a.trunc_margin);
@@ -132,7 +136,7 @@ static int tsdf_integrate_impl(float* tsdf, float* weight, float* color, const i
                                   const float origin_host[3], float voxel_size, float trunc_margin,
                                   const float* depth_im, const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                                   const float intr_host[9], const float pose_host[16], float obs_weight,
-                                  bnv_stream_t stream) {
+                                  float max_depth, const int32_t* gate, bnv_stream_t stream) {
   if (!tsdf || !weight || !dim_host || !origin_host || (!depth_im && !depth_mm) || !intr_host || !pose_host || im_h <= 0 ||
       im_w <= 0)
     return BNV_ERR_INVALID_ARGUMENT;
@@ -154,6 +158,8 @@ static int tsdf_integrate_impl(float* tsdf, float* weight, float* color, const i
   a.color_im = color_im;
   a.depth_im = depth_im;
   a.depth_mm = depth_mm;
+  a.max_depth = max_depth;
+  a.gate = gate;
   const int64_t n = (int64_t)a.dim[0] * a.dim[1] * a.dim[2];
   if (n <= 0) return BNV_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_tsdf_integrate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
@@ -165,25 +171,25 @@ extern "C" int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, cons
                                   const float origin_host[3], float voxel_size, float trunc_margin,
                                   const float* depth_im, const float* color_im, int im_h, int im_w,
                                   const float intr_host[9], const float pose_host[16], float obs_weight,
-                                  bnv_stream_t stream) {
+                                  float max_depth, const int32_t* gate, bnv_stream_t stream) {
   return tsdf_integrate_impl(tsdf, weight, color, dim_host, origin_host, voxel_size, trunc_margin, depth_im, nullptr,
-                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, stream);
+                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, max_depth, gate, stream);
 }
 
 extern "C" int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
                                       const float origin_host[3], float voxel_size, float trunc_margin,
                                       const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                                       const float intr_host[9], const float pose_host[16], float obs_weight,
-                                      bnv_stream_t stream) {
+                                      float max_depth, const int32_t* gate, bnv_stream_t stream) {
   return tsdf_integrate_impl(tsdf, weight, color, dim_host, origin_host, voxel_size, trunc_margin, nullptr, depth_mm,
-                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, stream);
+                             color_im, im_h, im_w, intr_host, pose_host, obs_weight, max_depth, gate, stream);
 }
 
 extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3],
                                             const float origin_host[3], float voxel_size, float trunc_margin,
                                             int n_frames, const uint16_t* const* depth_mm, int im_h, int im_w,
                                             const float* intr_host, const float* pose_host, float obs_weight,
-                                            bnv_stream_t stream) {
+                                            float max_depth, bnv_stream_t stream) {
   if (!tsdf || !weight || !dim_host || !origin_host || !depth_mm || !intr_host || !pose_host || im_h <= 0 || im_w <= 0 ||
       n_frames < 0 || n_frames > kTsdfBatchMax)
     return BNV_ERR_INVALID_ARGUMENT;
@@ -198,6 +204,7 @@ extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const in
   a.voxel_size = voxel_size;
   a.trunc_margin = trunc_margin;
   a.obs_weight = obs_weight;
+  a.max_depth = max_depth;
   a.im_h = im_h;
   a.im_w = im_w;
   a.n_frames = n_frames;

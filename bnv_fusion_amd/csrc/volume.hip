@@ -20,7 +20,7 @@ struct VolWs {
   uint32_t* block_sums;    // [n_blocks + 1]
   uint32_t* block_new;     // [ceil(n / 256) + 1] created keys per 256-key block (integrate)
   int32_t* total_new;      // [1] workspace word 0: created keys (insert) / first new row (integrate)
-  int32_t* error;          // [1] workspace word 1: sticky error code (1 table full, 2 key range, 3 row capacity)
+  int32_t* error;          // [1] = vol.n_rows + 1: sticky error code (1 table full, 2 key range, 3 row capacity)
 };
 
 static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
@@ -43,7 +43,7 @@ static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
     ws->block_sums = (uint32_t*)c;
     ws->block_new = (uint32_t*)e;
     ws->total_new = (int32_t*)d;
-    ws->error = (int32_t*)d + 1;
+    ws->error = nullptr;   // set by the entry points: the word behind the volume's row counter
   }
   return off;
 }
@@ -56,7 +56,10 @@ __global__ __launch_bounds__(256) void k_vol_clear(uint64_t* __restrict__ slot_k
     slot_keys[i] = kEmptyKey;
     slot_rows[i] = -1;
   }
-  if (i == 0 && n_rows) *n_rows = 0;
+  if (i == 0 && n_rows) {
+    n_rows[0] = 0;
+    n_rows[1] = 0;  // sticky error word
+  }
 }
 
 // probe / CAS-insert one key per thread; records the slot and whether this thread created it
@@ -547,7 +550,7 @@ int bnv_volume_rehash(const bnv_volume_t* vol, bnv_stream_t stream) {
                      vol->slot_keys, vol->slot_rows, vol->n_slots, (int32_t*)nullptr);
   BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_vol_rehash, dim3((unsigned)((vol->row_capacity + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, *vol, (int32_t*)nullptr);
+                     (hipStream_t)stream, *vol, vol->n_rows + 1);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -560,6 +563,7 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   if (!coords || !feats || !pcounts || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
   if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned nb256 = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, *vol, coords, n, n_dev, ws.slot_of,
@@ -599,6 +603,7 @@ int bnv_volume_integrate_batch(const bnv_volume_t* vol, int n_frames, const int6
   if (blocks > 0x7fffffff / 256) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
   if (vol_ws_layout(blocks * 256, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(k_vol_batch_probe, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
                      slot_items, ws.error);
@@ -623,6 +628,7 @@ int bnv_volume_insert(const bnv_volume_t* vol, const int64_t* coords, const floa
   if (!coords || !feats || !weights || !num_hits || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
   if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = vol_upsert_rows(*vol, coords, n, nullptr, ws, stream);
   if (rc != BNV_OK) return rc;

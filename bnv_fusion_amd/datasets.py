@@ -113,8 +113,11 @@ def _read_matrix(path):
 class FusionInferenceDataset:
     """fusion_inference_dataset.py:105-146 for the per-frame path: ``dimensions`` and frames in order."""
 
-    def __init__(self, data_dir, scan_id, skip_images=1, downsample_scale=1.0, max_depth=10.0, device="cuda:0",
+    def __init__(self, data_dir, scan_id, skip_images=1, downsample_scale=1.0, max_depth=3.0, device="cuda:0",
                  num_images=None):
+        # max_depth: cfg.model.ray_tracer.ray_max_dist (fusion_inference_dataset.py:28; 3 m in
+        # fusion_pointnet_model.yaml:43).  The frames carry the raw depth image; the cut-off is applied by the
+        # kernels (NeuralMap(max_depth=dataset.max_depth)), where the reference's load_depth zeroes the image.
         self.root = os.path.join(data_dir, scan_id)
         self.scan_id = scan_id
         self.device = device
@@ -143,7 +146,7 @@ class FusionInferenceDataset:
             depth = depth[ys][:, xs]
             intr[:2, :3] *= self.downsample_scale
         return {
-            "frame_id": i, "scene_id": self.scan_id,
+            "frame_id": i, "scene_id": self.scan_id, "max_depth": self.max_depth,
             "depth": torch.from_numpy(depth).to(self.device),
             "depth_path": os.path.join(self.root, "depth", f"{i}.png"),
             "intr_mat": intr.astype(np.float64),

@@ -177,19 +177,23 @@ class ShardedNeuralMap:
     """Per-frame driver over one shard; every rank calls the same methods with the same frame."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None):
+                 group=None, capacity=1 << 20):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend or HipShardBackend(dimensions, voxel_size, pointnet, self.rank, self.world,
-                                                  min_pts_in_grid, device=device)
+                                                  min_pts_in_grid, capacity=capacity, device=device)
         self.volume = getattr(self.backend, "volume", None)
         self.voxel_size = voxel_size
 
     def integrate(self, frame):
         with torch.no_grad():
             return self.backend.encode_integrate(frame)
+
+    def last_mlp_evals(self):
+        """Device int32 [1]: SDF-MLP evaluations this rank ran for the last frame."""
+        return self.volume.last_lattice_table_rows() * 27
 
     def fuse_and_decode(self, frame):
         with torch.no_grad():
@@ -247,11 +251,13 @@ class HipFrameBackend:
     GPU; the one host wait of a batch (its headers) is in FrameParallelNeuralMap.exchange."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, capacity=1 << 20, device="cuda:0",
-                 tsdf=False):
+                 tsdf=False, max_depth=3.0):
         from .sparse_volume import SparseVolume
         self.pointnet = pointnet
         self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
         self.dev = self.volume._dev
+        self.max_depth = max_depth          # the loader's depth cut-off (NeuralMap.max_depth)
+        self.inputs_resident = False        # as NeuralMap.inputs_resident
         self.tsdf_vol = None
         if tsdf:                                               # run_e2e.py:60-71, as NeuralMap does
             from .sparse_volume import get_world_range
@@ -280,6 +286,8 @@ class HipFrameBackend:
         """Encodes one frame into capacity-sized arrays (the encoder's own outputs; nothing is copied)."""
         if self.overlap_encode and torch.cuda.current_stream() != self._enc:
             self._enc_src = self._enc
+            if not self.inputs_resident:      # the frame's tensors may still be in production on the caller's stream
+                self._enc.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._enc):
                 return self.encode_frame(frame)
         if not self.overlap_encode:
@@ -295,7 +303,7 @@ class HipFrameBackend:
         if self._scratch_ids is None or self._scratch_ids.numel() < rows:
             self._scratch_ids = torch.empty(rows, dtype=torch.int64, device=self.dev)
         _, _, _, _, cnt, _ = self.pointnet.encode_pointcloud_async(
-            frame_input_pts(frame), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size,
+            frame_input_pts(frame, self.max_depth), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size,
             out=(feats, pcounts, self._scratch_ids, grid_ids))
         header_counters(hdr).copy_(cnt)
         return EncodedFrame(hdr, grid_ids, pcounts, feats)
@@ -335,7 +343,8 @@ class HipFrameBackend:
             grid_ids, pcounts, feats = payload_views(payload, rows)
             self.volume.integrate(grid_ids[:n_out], feats[:n_out], pcounts[:n_out], n_dev=header_counters(hdr)[2:3])
         if self.tsdf_vol is not None and frame is not None and "depth" in frame:
-            self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
+            self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.,
+                                    max_depth=self.max_depth)
 
     def integrate_records(self, hdr_all, out, rows, n_out, s0, s1):
         """_integrate of frames [s0, s1) of a gathered batch, in frame order, as ONE batched upsert (4 launches)."""
@@ -348,17 +357,20 @@ class HipFrameBackend:
         if items:
             self.volume.integrate_batch(items)
 
-    def integrate_tsdf(self, frames):
-        """TSDF side fusion of all frames of a batch (one launch per 8 frames; nothing reads it before the batch ends)."""
+    def integrate_tsdf(self, frames, n_valid=None):
+        """TSDF side fusion of all frames of a batch (one launch per 8 frames; nothing reads it before the batch ends).
+        ``n_valid``: the frames' in-bounds point counts (from the headers): frames without any are skipped, as the
+        reference returns from NeuralMap.integrate before the TSDF fusion then (run_e2e.py:91-92)."""
         if self.tsdf_vol is None:
             return
-        fr = [f for f in frames if "depth" in f]
+        fr = [f for i, f in enumerate(frames) if "depth" in f and (n_valid is None or n_valid[i])]
         if any(f.get("rgb") is not None for f in fr):
             for f in fr:
-                self.tsdf_vol.integrate(f.get("rgb"), f["depth"], f["intr_mat"], f["T_wc"], obs_weight=1.)
+                self.tsdf_vol.integrate(f.get("rgb"), f["depth"], f["intr_mat"], f["T_wc"], obs_weight=1.,
+                                        max_depth=self.max_depth)
         elif fr:
             self.tsdf_vol.integrate_batch([f["depth"] for f in fr], [f["intr_mat"] for f in fr],
-                                          [f["T_wc"] for f in fr], obs_weight=1.)
+                                          [f["T_wc"] for f in fr], obs_weight=1., max_depth=self.max_depth)
 
     def decode_record(self, hdr, payload, rows, n_out):
         grid_ids, _, _ = payload_views(payload, rows)
@@ -380,10 +392,8 @@ class HipFrameBackend:
         return torch.empty(shape, dtype=torch.int64, pin_memory=True)
 
     def rows_readback(self):
-        """Pinned copy of the volume's row count behind everything enqueued so far."""
-        h = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        h.copy_(self.volume._n_rows, non_blocking=True)
-        return h
+        """Pinned copy of {row count, sticky upsert error} behind everything enqueued so far."""
+        return self.volume.status_readback()
 
     def event(self):
         ev = torch.cuda.Event()
@@ -412,6 +422,8 @@ class BatchHandle:
             n_after = int(self._host_rows[0]) if self._host_rows is not None else None
             self._fp.backend.account([self._host[s] for s in range(self._b)], n_after)
             self._accounted = True
+            if self._host_rows is not None and len(self._host_rows) > 1 and int(self._host_rows[1]):
+                self._fp.backend.volume.check_status(self._host_rows[1])   # device-side upsert failure: raise
 
     def result(self):
         if self._done is None:
@@ -494,12 +506,13 @@ class FrameParallelNeuralMap:
         if ticket["event"] is not None:
             ticket["event"].synchronize()
         b = len(ticket["frames"])
-        n_out = []
+        n_out, n_valid = [], []
         for s in range(b):
             c = header_counters(ticket["host"][s])
             if int(c[4]):
                 raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {int(c[4])})")
             n_out.append(int(c[2]) if int(c[0]) else 0)
+            n_valid.append(int(c[0]))
         rows = -(-max(n_out) // ROW_QUANTUM) * ROW_QUANTUM
         out = work = None
         if rows:
@@ -508,7 +521,7 @@ class FrameParallelNeuralMap:
                 out = torch.empty((self.world, payload_words(rows)), dtype=torch.int64, device=send.device)
                 work = dist.all_gather_into_tensor(out.view(-1), send, group=self.group, async_op=True)
             self.exchanged_bytes += 8 * out.numel()
-        ticket.update(rows=rows, n_out=n_out, out=out, work=work)
+        ticket.update(rows=rows, n_out=n_out, n_valid=n_valid, out=out, work=work)
         return ticket
 
     def finish(self, ticket, decode=True):
@@ -536,7 +549,7 @@ class FrameParallelNeuralMap:
                 if decode:
                     sdf = be.decode_record(hdr[self.rank], mine, rows, n_out[self.rank])
             be.integrate_records(hdr, out, rows, n_out, own, b)
-            be.integrate_tsdf(frames)
+            be.integrate_tsdf(frames, ticket["n_valid"])
             host_rows = be.rows_readback() if hasattr(be, "rows_readback") else None
             ev = be.event()
         self._last = BatchHandle(self, mine, rows, sdf, ticket["host"], ev, b, host_rows)

@@ -12,7 +12,7 @@ import torch
 from .sparse_volume import SparseVolume
 
 
-def frame_input_pts(frame, max_depth=10.0):
+def frame_input_pts(frame, max_depth=3.0):
     """``frame['input_pts']`` if present (the reference's dataset output), else built on the GPU from
     ``frame['depth']`` (uint16 mm or float metres), ``frame['intr_mat']`` and ``frame['T_wc']`` by the
     front-end kernel (csrc/frontend.hip) -- without a host read: invalid pixels are NaN rows that the
@@ -32,6 +32,15 @@ class FrameHandle:
         self._nm, self._bufs, self._host, self._event, self._cap, self._sdf = nm, bufs, host_counters, event, cap, sdf
         self._host_rows = host_rows
         self._done = None
+        self._settled = False
+
+    def __del__(self):
+        # a handle dropped without result(): give its row reservation back (the bound stays an upper bound)
+        if not self._settled and self._host_rows is not None:
+            try:
+                self._nm.volume.release(self._cap)
+            except Exception:
+                pass
 
     def result(self):
         if self._done is not None:
@@ -43,6 +52,8 @@ class FrameHandle:
         # the reservation was made for the capacity bound; the row count behind this frame's integrate came back
         # with the counters, so the host-side bound stays exact and _reserve never has to synchronise
         vol.settle(self._cap, int(self._host_rows[0]))
+        self._settled = True
+        vol.check_status(self._host_rows[1])      # sticky error word of the upsert kernels, read back with the rows
         if err:
             raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
         if n_valid == 0:
@@ -57,8 +68,13 @@ class FrameHandle:
 
 class NeuralMap:
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
-                 capacity=100000, device="cuda:0", tsdf=False, truncated_units=10, sdf_delta_weight=0.1):
+                 capacity=100000, device="cuda:0", tsdf=False, truncated_units=10, sdf_delta_weight=0.1,
+                 max_depth=3.0):
         self.pointnet = pointnet
+        # depth cut-off of the reference's loader (model.ray_tracer.ray_max_dist, fusion_pointnet_model.yaml:43 ->
+        # fusion_inference_dataset.py:28 -> common.py:110-113): applies to input_pts AND to the TSDF side fusion,
+        # both of which see ``depth * mask`` in the reference (run_e2e.py:100-109 reads frame['rgbd'])
+        self.max_depth = max_depth
         self.volume = SparseVolume(feature_vector_size, voxel_size, dimensions, min_pts_in_grid,
                                    capacity=capacity, device=device)
         self.voxel_size = voxel_size
@@ -73,17 +89,10 @@ class NeuralMap:
         # HIP stream and overlaps the previous frame's integrate / decode kernels on the main stream
         self.overlap_encode = True
         self._enc_stream = None
-        # Optional (off: measured 7 % SLOWER, tools/ab_prep.py): the frame's upsert, TSDF fusion and the first decode
-        # stage (feature snapshot, neighbour rows) on a third, high-priority stream, beside the previous frame's
-        # persistent SDF-MLP kernel, which then reads a snapshot of the features.  The kernel trace shows the small
-        # kernels do run beside the MLP kernel, but the two MLP kernels then pair up (encoder, encoder, decoder,
-        # decoder) because the front-end kernel of the next frame (40 VGPRs) does not fit beside the decoder
-        # (32 VGPRs per SIMD lane free) and holds its stream back; see DESIGN.md section 5.
-        self.overlap_prep = False
-        self._prep_stream = None
-        self._vol_ev = None            # behind the last enqueued modification of the volume (any stream)
-        self._slot_ev = [None, None]   # behind the last reader of each staged-decode workspace
-        self._frame_no = 0
+        # True: the caller guarantees that a frame's tensors are complete in device memory when it is passed in
+        # (uploaded / produced and synchronised earlier), so the encode stream need not wait for the caller's stream
+        self.inputs_resident = False
+        self._vol_ev = None            # behind the last TSDF update a synchronous integrate() enqueued (main stream)
         self.sdf_delta_weight = sdf_delta_weight                          # fusion_pointnet_model.yaml:44,47
         if tsdf:                                                          # run_e2e.py:60-71
             import numpy as np
@@ -96,21 +105,22 @@ class NeuralMap:
         """run_e2e.py:169-186 -> sdf_delta [1, 1, X, Y, Z] for decode_pts / meshlize."""
         return self.tsdf_vol.sdf_delta(self.truncated_dist, self.sdf_delta_weight)
 
-    def _integrate_tsdf(self, frame):
-        """run_e2e.py:99-109: TSDF side fusion of the same frame (depth in metres, no colour here)."""
+    def _integrate_tsdf(self, frame, gate=None):
+        """run_e2e.py:99-109: TSDF side fusion of the same frame.  ``gate``: device int32 (the frame's in-bounds
+        point count): nothing happens when it is 0, as in the reference, which returns before this call then."""
         if self.tsdf_vol is None or "depth" not in frame:
             return
         # uint16 millimetres go to the kernel as they are (converted per sample, no float copy of the frame)
-        self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.)
+        self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.,
+                                max_depth=self.max_depth, gate=gate)
 
     def integrate(self, frame):
         """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU (or a depth frame, see
         frame_input_pts).
         Returns the voxel coordinates the frame touched ([U', 3] int64) or None."""
-        input_pts = frame_input_pts(frame)
+        input_pts = frame_input_pts(frame, self.max_depth)
         if len(input_pts) == 0:
             return None
-        self._join()
         with torch.no_grad():
             fine_feats, fine_weights, _, fine_coords, fine_n_pts = self.pointnet.encode_pointcloud(
                 input_pts, self.volume.n_xyz, self.volume.min_coords, self.volume.max_coords,
@@ -124,17 +134,11 @@ class NeuralMap:
         return fine_coords
 
     def _mark_volume_update(self):
-        """An event behind a volume update enqueued on the current stream (the side stream of a later
-        fuse_and_decode_async waits for it)."""
-        if self._prep_stream is not None or self._enc_stream is not None:
+        """An event behind a TSDF update enqueued on the current stream: the encode stream of a later
+        fuse_and_decode_async (which also updates the TSDF volume) waits for it."""
+        if self.tsdf_vol is not None:
             self._vol_ev = torch.cuda.Event()
             self._vol_ev.record()
-
-    def _join(self):
-        """The current stream waits for volume updates that fuse_and_decode_async enqueued on its side stream."""
-        if self._vol_ev is not None:
-            torch.cuda.current_stream().wait_event(self._vol_ev)
-            self._vol_ev = None
 
     def fuse_and_decode(self, frame):
         """One benchmark work unit: integrate + SDF lattice [U', 27] of the touched voxels (live
@@ -148,76 +152,57 @@ class NeuralMap:
     def fuse_and_decode_async(self, frame, decode=True):
         """The same work as fuse_and_decode, enqueued without any host synchronisation: integrate and the
         lattice decode read the frame's voxel count from device memory.  Returns a FrameHandle; call
-        ``.result()`` after enqueuing the NEXT frame to keep the GPU busy."""
+        ``.result()`` after enqueuing the NEXT frame to keep the GPU busy (``result()`` also settles the frame's
+        row reservation and raises on a device-side upsert error)."""
         with torch.no_grad():
             v = self.volume
             main = torch.cuda.current_stream()
-            tsdf_done = False
             if self.overlap_encode:
                 if self._enc_stream is None:
                     self._enc_stream = torch.cuda.Stream(device=v._dev)
-                with torch.cuda.stream(self._enc_stream):
-                    # the TSDF side fusion depends on the frame only as well: ahead of the encode on this stream it
-                    # runs beside the previous frame's decode instead of between this frame's encoder and decoder
-                    if self._vol_ev is not None:      # a synchronous integrate() on the main stream came before
-                        self._enc_stream.wait_event(self._vol_ev)
-                    self._integrate_tsdf(frame)
-                    tsdf_done = True
-                    input_pts = frame_input_pts(frame)
+                enc = self._enc_stream
+                if self.inputs_resident:
+                    # only a synchronous integrate() on the caller's stream can still hold the TSDF volume
+                    if self._vol_ev is not None:
+                        enc.wait_event(self._vol_ev)
+                        self._vol_ev = None
+                else:
+                    # everything the caller's stream holds now is ordered before the side stream's work: a depth /
+                    # input_pts tensor a GPU op on that stream is still producing, the TSDF update of a synchronous
+                    # integrate().  (It also holds the previous frame's decode, so this frame's encode no longer
+                    # overlaps it: callers whose frames are complete in device memory set inputs_resident.)
+                    enc.wait_stream(main)
+                with torch.cuda.stream(enc):
+                    input_pts = frame_input_pts(frame, self.max_depth)
                     feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
                         input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
                     done = torch.cuda.Event()
-                    done.record(self._enc_stream)
+                    done.record(enc)
+                    # the TSDF side fusion depends on the frame only as well (gated on the device by the encode's
+                    # point count): behind the encode on this stream it runs beside this frame's upsert / decode
+                    # instead of between its encoder and decoder
+                    self._integrate_tsdf(frame, gate=counters[0:1])
+                    tsdf_ev = torch.cuda.Event()
+                    tsdf_ev.record(enc)
                 main.wait_event(done)
                 for t in (feats, pcounts, flat_ids, grid_ids, counters):
                     t.record_stream(main)     # allocated on the encode stream, consumed on the main stream
             else:
-                input_pts = frame_input_pts(frame)
+                input_pts = frame_input_pts(frame, self.max_depth)
                 feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
                     input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+                self._integrate_tsdf(frame, gate=counters[0:1])
             n_dev = counters[2:3]
             host = torch.empty(8, dtype=torch.int32, pin_memory=True)
-            host_rows = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            if decode and self.overlap_encode and self.overlap_prep:
-                if self._prep_stream is None:
-                    self._prep_stream = torch.cuda.Stream(device=v._dev, priority=-1)
-                prep, slot = self._prep_stream, self._frame_no & 1
-                self._frame_no += 1
-                prep.wait_event(done)                                   # the encode's outputs
-                if self._vol_ev is not None:
-                    prep.wait_event(self._vol_ev)                       # earlier volume updates (any stream)
-                if self._slot_ev[slot] is not None:
-                    prep.wait_event(self._slot_ev[slot])                # the frame before last is done with this workspace
-                with torch.cuda.stream(prep):
-                    for t in (feats, pcounts, flat_ids, grid_ids, counters):
-                        t.record_stream(prep)
-                    v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
-                    if not tsdf_done:
-                        self._integrate_tsdf(frame)
-                    v.lattice_stage_a(grid_ids, n_dev, slot)
-                    host.copy_(counters, non_blocking=True)
-                    host_rows.copy_(v._n_rows, non_blocking=True)
-                    ready = torch.cuda.Event()
-                    ready.record(prep)
-                self._vol_ev = ready
-                main.wait_event(ready)
-                sdf = v.lattice_stage_b(self.pointnet.nerf, slot, self.sdf_delta)
-                ev = torch.cuda.Event()
-                ev.record()
-                self._slot_ev[slot] = ev
-                return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
-            self._join()
             v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
-            if not tsdf_done:
-                self._integrate_tsdf(frame)
             sdf = v.decode_lattice(grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False,
                                    n_dev=n_dev) if decode else None
             host.copy_(counters, non_blocking=True)
-            host_rows.copy_(v._n_rows, non_blocking=True)
+            host_rows = v.status_readback()
+            if self.overlap_encode:
+                main.wait_event(tsdf_ev)      # long finished by now: the frame's event covers its TSDF update too
             ev = torch.cuda.Event()
             ev.record()
-            if self._prep_stream is not None:
-                self._vol_ev = ev
         return FrameHandle(self, (feats, pcounts, flat_ids, grid_ids), host, ev, cap, sdf, host_rows)
 
     def optimize(self, n_iters, last_frame=-1, sampling_size=5000, train_ray_splits=1000, ray_max_dist=3,
@@ -228,7 +213,6 @@ class NeuralMap:
         png in DataLoader workers, fusion_inference_dataset.py:329-420).  Defaults are the values of
         fusion_pointnet_model.yaml / fusion_inference_dataset.yaml."""
         from .optimize import optimize_volume, sample_key_frame
-        self._join()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         lo = 0 if last_frame == -1 else last_frame
         cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
@@ -247,14 +231,12 @@ class NeuralMap:
 
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""
-        self._join()
         self.volume.to_tensor()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         return self.volume.meshlize_sdf(self.pointnet.nerf, delta)
 
     def extract_mesh(self, path=None):
         """run_e2e.py:164-167: mesh of the whole volume (TSDF prior included when enabled) -> TriMesh or None."""
-        self._join()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         self.volume.to_tensor()
         out = self.volume.meshlize(self.pointnet.nerf, delta, path)
@@ -265,7 +247,6 @@ class NeuralMap:
         final_sparse_volume.pth (sparse_volume.py:835-860)."""
         import os
         import numpy as np
-        self._join()
         if self.tsdf_vol is not None:
             tsdf, _ = self.tsdf_vol.get_volume()
             np.save(os.path.join(working_dir, scan_id + ".npy"), tsdf * (self.tsdf_voxel_size * 5))

@@ -70,9 +70,6 @@ class SparseVolume:
         self._slot_mask = None        # side tables of integrate_batch (per slot; re-made with the slot table)
         self._slot_items = None
         self._lattice_ws = None
-        self._stages = None           # double-buffered lattice workspaces of the staged decode
-        self._stages_capacity = 0
-        self._last_stage = None
         self._stamp = None
         self._epoch = 0
         self.reset(capacity)
@@ -112,7 +109,8 @@ class SparseVolume:
         self._features = torch.zeros((cap, 8), dtype=torch.float32, device=d)
         self._weights = torch.zeros(cap, dtype=torch.float32, device=d)
         self._num_hits = torch.zeros(cap, dtype=torch.float32, device=d)
-        self._n_rows = torch.zeros(1, dtype=torch.int32, device=d)
+        self._status = torch.zeros(2, dtype=torch.int32, device=d)   # {rows in use, sticky upsert error}
+        self._n_rows = self._status[:1]
         self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
         self._inflight = 0            # rows reserved by enqueued, not yet settled, device-count integrates
         self._rows_known = 0          # largest row count read back so far
@@ -142,15 +140,28 @@ class SparseVolume:
 
     def num_rows(self):
         """Exact number of active voxels (one device->host read)."""
-        n = int(self._n_rows.item())          # the stream is drained up to here: nothing is in flight any more
+        st = self._status.tolist()            # the stream is drained up to here: nothing is in flight any more
+        n = int(st[0])
         self._rows_known = max(self._rows_known, n)
         self._rows_upper = n + self._inflight
-        if self._ws is not None:              # sticky error word of the upsert kernels (csrc/volume.hip: VolWs)
-            err = int(self._ws[4:8].view(torch.int32).item())
-            if err:
-                raise _lib.BnvError({1: "hash table full", 2: "voxel coordinate outside the 21-bit key range",
-                                     3: "row capacity exceeded"}.get(err, f"upsert error {err}"))
+        self.check_status(st[1])
         return n
+
+    UPSERT_ERRORS = {1: "hash table full", 2: "voxel coordinate outside the 21-bit key range",
+                     3: "row capacity exceeded"}
+
+    def check_status(self, err):
+        """Raises on the sticky error word of the upsert kernels (device int32 next to the row counter; the
+        asynchronous pipelines read it back with the row count, see status_readback)."""
+        err = int(err)
+        if err:
+            raise _lib.BnvError("volume upsert failed: " + self.UPSERT_ERRORS.get(err, f"error {err}"))
+
+    def status_readback(self):
+        """Pinned int32 [2] = {row count, sticky upsert error} behind everything enqueued so far (async copy)."""
+        h = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        h.copy_(self._status, non_blocking=True)
+        return h
 
     def settle(self, n_reserved, n_rows_after):
         """Bookkeeping of an integrate that was enqueued with a device-side count: ``n_reserved`` rows had been
@@ -159,6 +170,11 @@ class SparseVolume:
         self._inflight -= int(n_reserved)
         self._rows_known = max(self._rows_known, int(n_rows_after))     # row counts only grow
         self._rows_upper = self._rows_known + self._inflight
+
+    def release(self, n_reserved):
+        """Gives back the reservation of an enqueued integrate whose result was never collected."""
+        self._inflight -= int(n_reserved)
+        self._rows_upper = max(self._rows_known, self._rows_upper - int(n_reserved))
 
     def _reserve(self, n_new):
         """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows).  The test uses the
@@ -414,7 +430,6 @@ class SparseVolume:
             self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
             self._lattice_epoch = 0
         self._lattice_epoch += 1
-        self._last_stage = None
         _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
                                                 _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
@@ -422,62 +437,6 @@ class SparseVolume:
                                                 self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_decode_lattice")
         return out
-
-    # ---- the lattice decode in two stages, on double-buffered workspaces ----------------------------------------
-    # NeuralMap's frame pipeline runs stage A of frame t (feature snapshot + neighbour rows) on a side stream while
-    # the SDF-MLP kernel of frame t-1 is still running: the small kernels fit beside the persistent MLP kernel, and
-    # the next integrate may then modify the live features at once, because the MLP reads the snapshot.
-    def lattice_stage_a(self, origins, n_dev, slot):
-        """Snapshot of the live features + neighbour rows of ``origins`` into workspace ``slot`` (0 / 1)."""
-        o = origins.detach().reshape(-1, 3).long().contiguous()
-        n = int(o.shape[0])
-        st = self._stage_state(n, slot)
-        rows = min(self._rows_upper, self._row_capacity)
-        st["feat"][:rows].copy_(self._features[:rows])
-        st["epoch"] += 1
-        st["o"], st["n"], st["n_dev"] = o, n, n_dev
-        if n:
-            _lib.check(self._lib.bnv_lattice_neighbors(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(self._weights),
-                                                       self._row_capacity, _lib.ptr(o), n, _lib.ptr(n_dev), None, 0,
-                                                       _lib.ptr(st["ws"]), st["ws"].numel(), st["epoch"], _lib.stream_ptr()),
-                       "bnv_lattice_neighbors")
-        return st
-
-    def lattice_stage_b(self, nerf, slot, sdf_delta=None):
-        """Live-entry marking, SDF MLP on the snapshot, blend -> [n, 27] for the origins of stage A."""
-        self._select_mode(nerf)
-        st = self._stages[slot]
-        o, n, n_dev, ws = st["o"], st["n"], st["n_dev"], st["ws"]
-        out = torch.empty((n, 27), dtype=torch.float32, device=self._dev)
-        if n == 0:
-            return out
-        d, keep = self._delta(sdf_delta)
-        vol = self._struct()
-        _lib.check(self._lib.bnv_lattice_mark(C.byref(vol), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(), st["epoch"],
-                                              _lib.stream_ptr()), "bnv_lattice_mark")
-        _lib.check(self._lib.bnv_lattice_table(C.byref(vol), C.byref(self._grid), _lib.ptr(st["feat"]),
-                                               _lib.ptr(nerf.sdf_pack), n, 1, _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
-                   "bnv_lattice_table")
-        _lib.check(self._lib.bnv_lattice_blend(C.byref(vol), C.byref(self._grid), _lib.ptr(o), n, _lib.ptr(n_dev),
-                                               C.byref(d), _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
-                   "bnv_lattice_blend")
-        self._last_stage = slot
-        return out
-
-    def _stage_state(self, n, slot):
-        if self._stages is None or self._stages_capacity != self._row_capacity:
-            if self._stages is not None:
-                torch.cuda.synchronize(self._dev)      # the tables were re-made: nothing may still read the old buffers
-            self._stages = [{"ws": None, "feat": None, "epoch": 0} for _ in range(2)]
-            self._stages_capacity = self._row_capacity
-        st = self._stages[slot]
-        need = int(self._lib.bnv_decode_lattice_workspace_bytes(max(n, 1), self._row_capacity))
-        if st["ws"] is None or st["ws"].numel() < need:
-            st["ws"] = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
-            st["epoch"] = 0
-        if st["feat"] is None:
-            st["feat"] = torch.empty((self._row_capacity, 8), dtype=torch.float32, device=self._dev)
-        return st
 
     def last_lattice_table_rows(self):
         """Device int32 tensor [1]: rows listed by the last bnv_lattice_neighbors(build_list) (sharded
@@ -489,8 +448,7 @@ class SparseVolume:
         """Device int32 tensor [1]: SDF-MLP evaluations of the last decode_lattice call (table entries
         read by live lattice points)."""
         off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
-        ws = self._stages[self._last_stage]["ws"] if self._last_stage is not None else self._lattice_ws
-        return ws[off + 4: off + 8].view(torch.int32)
+        return self._lattice_ws[off + 4: off + 8].view(torch.int32)
 
     def meshlize(self, nerf, sdf_delta=None, path=None):
         """sparse_volume.py:697-766: decode the 3x3x3 lattice of every active voxel and run per-voxel

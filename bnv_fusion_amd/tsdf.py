@@ -29,8 +29,12 @@ class TSDFVolume:
         self.color = torch.zeros(dims, dtype=torch.float32, device=self._dev)
         self.gpu_mode = True
 
-    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):
-        """fusion.py:208-250.  depth_im [H, W] metres (numpy or tensor); color_im [H, W, 3] in [0, 255] or None."""
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1., max_depth=None, gate=None):
+        """fusion.py:208-250.  depth_im [H, W] metres (numpy or tensor); color_im [H, W, 3] in [0, 255] or None.
+        ``max_depth``: samples at or beyond it are invalid -- the reference's loader has already zeroed them when
+        the frame reaches this call (common.py:110-113); here the raw image is passed and masked in the kernel.
+        ``gate``: device int32 tensor; the launch does nothing when it holds 0 (pipelined NeuralMap: the frame's
+        in-bounds point count, which the reference tests on the host before this call, run_e2e.py:91-92)."""
         depth = torch.as_tensor(depth_im)
         u16 = depth.dtype in (torch.uint16, torch.int16)     # the dataset's millimetres: converted in the kernel
         depth = depth.to(self._dev).contiguous() if u16 else depth.to(self._dev, torch.float32).contiguous()
@@ -47,11 +51,11 @@ class TSDFVolume:
         _lib.check(fn(
             _lib.ptr(self.tsdf), _lib.ptr(self.weight), _lib.ptr(self.color if col is not None else None), dim, org,
             np.float32(self._voxel_size), np.float32(self._trunc_margin), _lib.ptr(depth), _lib.ptr(col), im_h, im_w,
-            intr, pose, float(obs_weight), _lib.stream_ptr()), "bnv_tsdf_integrate")
+            intr, pose, float(obs_weight), float(max_depth or 0.0), _lib.ptr(gate), _lib.stream_ptr()), "bnv_tsdf_integrate")
 
     BATCH_MAX = 8     # BNV_TSDF_BATCH_MAX
 
-    def integrate_batch(self, depth_ims, cam_intrs, cam_poses, obs_weight=1.):
+    def integrate_batch(self, depth_ims, cam_intrs, cam_poses, obs_weight=1., max_depth=None):
         """``integrate`` (without colour) for several consecutive uint16-millimetre depth frames of one size, one
         launch per BATCH_MAX frames; results identical to one call per frame in order."""
         ims = [torch.as_tensor(d) for d in depth_ims]
@@ -59,7 +63,7 @@ class TSDFVolume:
             return
         if any(d.dtype not in (torch.uint16, torch.int16) or d.shape != ims[0].shape for d in ims):
             for d, k, p in zip(ims, cam_intrs, cam_poses):
-                self.integrate(None, d, k, p, obs_weight)
+                self.integrate(None, d, k, p, obs_weight, max_depth)
             return
         ims = [d.to(self._dev).contiguous() for d in ims]
         im_h, im_w = int(ims[0].shape[0]), int(ims[0].shape[1])
@@ -76,7 +80,7 @@ class TSDFVolume:
                 _lib.ptr(self.tsdf), _lib.ptr(self.weight), dim, org, np.float32(self._voxel_size),
                 np.float32(self._trunc_margin), k, (C.c_void_p * k)(*[d.data_ptr() for d in grp]), im_h, im_w,
                 (C.c_float * (9 * k))(*intr.tolist()), (C.c_float * (16 * k))(*pose.tolist()), float(obs_weight),
-                _lib.stream_ptr()), "bnv_tsdf_integrate_batch_u16")
+                float(max_depth or 0.0), _lib.stream_ptr()), "bnv_tsdf_integrate_batch_u16")
 
     def get_volume(self):
         return self.tsdf.cpu().numpy(), self.color.cpu().numpy()

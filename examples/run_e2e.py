@@ -49,7 +49,8 @@ def main():
                                 [dims] * 3)
     data = datasets.FusionInferenceDataset(args.data_dir, args.scan_id, skip_images=args.skip_images, device=dev)
     model = bnv.load_pretrained(device=dev, voxel_size=args.voxel_size, tiny_cuda=args.tiny_cuda)
-    nm = bnv.NeuralMap(data.dimensions, args.voxel_size, model, capacity=1 << 20, device=dev, tsdf=True)
+    nm = bnv.NeuralMap(data.dimensions, args.voxel_size, model, capacity=1 << 20, device=dev, tsdf=True,
+                       max_depth=data.max_depth)
     t_local = t_global = 0.0
     for idx, frame in enumerate(data):                                   # run_e2e.py:243-279
         t0 = time.perf_counter()
@@ -63,7 +64,7 @@ def main():
             last = max(0, len(nm.frames) - args.optim_interval)
             n_iters = min(len(nm.frames), args.optim_interval) * args.skip_images
             t0 = time.perf_counter()
-            nm.optimize(n_iters=n_iters, last_frame=last)
+            nm.optimize(n_iters=n_iters, last_frame=last, ray_max_dist=data.max_depth)
             torch.cuda.synchronize()
             t_global += time.perf_counter() - t0
             mesh = nm.extract_mesh(os.path.join(args.out, f"{idx}.ply"))
@@ -71,7 +72,7 @@ def main():
     steps = int(len(nm.frames) * args.skip_images) * (1 if args.mode == "demo" else 2)   # :283-284
     if not args.no_optimize:
         t0 = time.perf_counter()
-        nm.optimize(n_iters=steps, last_frame=-1)
+        nm.optimize(n_iters=steps, last_frame=-1, ray_max_dist=data.max_depth)
         torch.cuda.synchronize()
         t_global += time.perf_counter() - t0
     print(f"speed on local fusion: {len(nm.frames) / max(t_local, 1e-9):.1f} fps"

@@ -75,7 +75,9 @@ typedef struct bnv_volume {
   float* weights;        /* [row_capacity]                                    */
   float* num_hits;       /* [row_capacity]                                    */
   int64_t row_capacity;
-  int32_t* n_rows;       /* device scalar: number of rows in use              */
+  int32_t* n_rows;       /* device int32[2]: {rows in use, sticky error of the upsert kernels: 0 ok, 1 slot table
+                            full, 2 voxel coordinate outside the 21-bit key range, 3 row capacity exceeded};
+                            bnv_volume_clear zeroes both                      */
   int32_t n_feats;       /* 8                                                 */
 } bnv_volume_t;
 
@@ -102,16 +104,9 @@ int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 
 /* Tuning switches (A/B experiments; defaults are the measured-best):
- *   "lattice_h64"  0 (default): lattice-table MLP in split mode uses 128-evaluation tiles, 1 workgroup per CU;
- *                  1: 64-evaluation tiles, 2 workgroups per CU (measured about 4 % slower);
  *   "lattice_pipe"  1 (default): lattice-table MLP of modes 1 and 3 runs k_lattice_table_h (operands prefetched
  *                  across tiles and layers, dynamic tile hand-out); 0: the generic k_decode<LATTICE> (bit-identical
  *                  tables, 3-5 % slower);
- *   "lattice_quad"  0 (default); 1: k_lattice_table_q, the same kernel with 64 features x 64 evaluations per wave
- *                  (half the LDS operand reads, twice the weight reads from L2; bit-identical tables; measured 3 %
- *                  slower in mode 1 and 12 % slower in mode 3 -- tools/ab_quad.py);
- *   "encoder_overlap"  0 (default); 1: point encoder with the output block in the outer loop (bit-identical
- *                  features, no measurable gain: MFMA and VALU do not co-execute on a SIMD of this part).
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside
@@ -145,19 +140,23 @@ int bnv_depth_to_points_padded(const void* depth, int depth_dtype, int H, int W,
 /* ---- TSDF side fusion: TSDFVolume.integrate (third_parties/fusion.py:68-141, called per frame from
  * run_e2e.py:99-109).  tsdf / weight / color [dx,dy,dz] f32 (color may be NULL); depth_im [h,w] f32 metres
  * (0 = invalid); color_im [h,w] f32 folded b*65536+g*256+r or NULL; intr 3x3 and pose 4x4 row-major f32 on
- * the HOST; trunc_margin = 5 * voxel_size in the reference. */
+ * the HOST; trunc_margin = 5 * voxel_size in the reference.  max_depth > 0: samples with depth >= max_depth are
+ * invalid too -- the reference's loader zeroes them before the frame reaches either fusion (common.py:110-113 with
+ * max_depth = model.ray_tracer.ray_max_dist, fusion_inference_dataset.py:28); <= 0: no cut.  gate: device int32 or
+ * NULL; when *gate == 0 the launch does nothing -- NeuralMap.integrate returns before the TSDF fusion when the
+ * encode found no in-bounds point (run_e2e.py:91-92), and the pipelined host does not know that count yet. */
 int bnv_tsdf_integrate(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
                        const float origin_host[3], float voxel_size, float trunc_margin,
                        const float* depth_im, const float* color_im, int im_h, int im_w,
                        const float intr_host[9], const float pose_host[16], float obs_weight,
-                       bnv_stream_t stream);
+                       float max_depth, const int32_t* gate, bnv_stream_t stream);
 /* The same with the depth image as the dataset stores it: uint16 millimetres, converted per sample as
  * depth_mm / 1000 (common.py:93) inside the kernel -- no float copy of the frame. */
 int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
                        const float origin_host[3], float voxel_size, float trunc_margin,
                        const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                        const float intr_host[9], const float pose_host[16], float obs_weight,
-                       bnv_stream_t stream);
+                       float max_depth, const int32_t* gate, bnv_stream_t stream);
 /* n_frames (<= BNV_TSDF_BATCH_MAX) consecutive uint16 depth frames in ONE launch, depth only (no colour volume):
  * identical to n_frames calls of bnv_tsdf_integrate_u16 in order.  depth_mm: HOST array of device pointers;
  * intr_host [n_frames, 9] and pose_host [n_frames, 16] row-major f32 on the host. */
@@ -165,7 +164,7 @@ int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32
 int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3], const float origin_host[3],
                                  float voxel_size, float trunc_margin, int n_frames,
                                  const uint16_t* const* depth_mm, int im_h, int im_w, const float* intr_host,
-                                 const float* pose_host, float obs_weight, bnv_stream_t stream);
+                                 const float* pose_host, float obs_weight, float max_depth, bnv_stream_t stream);
 
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 

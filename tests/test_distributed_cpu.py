@@ -208,7 +208,7 @@ class OracleFrameBackend:
         for s in range(s0, s1):
             self.integrate_record(hdr_all[s], None if out is None else out[s], rows, n_out[s])
 
-    def integrate_tsdf(self, frames):
+    def integrate_tsdf(self, frames, n_valid=None):
         pass
 
     def decode_record(self, hdr, payload, rows, n_out):
@@ -287,3 +287,21 @@ def test_frame_parallel_equals_single_process():
         assert np.array_equal(got[t][1], ref.numpy())           # same ops in the same order: bit-identical
     assert nkeys[0] == nkeys[1] == len(vol._keys)               # replicated volumes stay in lock step
     assert np.allclose(npts[0], vol.n_pts_list) and np.allclose(npts[1], vol.n_pts_list)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (a child torch.distributed.run, before
+    any GPU call) and leaves with the child's exit code; a WORLD_SIZE that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"dry_run_launch": True, "world": 2, "gpus": 2, "self_launched": True}
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch"],
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "does not match" in bad.stderr

@@ -596,18 +596,17 @@ def test_volume_list_wrapper(bnv, model, golden_volume):
     assert np.abs(sdf.reshape(-1, 27).cpu().numpy() - d["lattice_q"][0, :, :, 0]).max() <= SDF_TOL
 
 
-@pytest.mark.parametrize("prep", [False, True])
-def test_async_frames_equal_sync_frames(bnv, prep):
-    """fuse_and_decode_async (device-side counts, no mid-frame sync, results collected one frame late)
-    produces exactly what the synchronous API produces -- also with the optional three-stream pipeline
-    (overlap_prep: upsert + first decode stage beside the previous frame's MLP kernel, which reads a snapshot),
-    mixed with fuse-only and synchronous calls."""
+@pytest.mark.parametrize("resident", [False, True])
+def test_async_frames_equal_sync_frames(bnv, resident):
+    """fuse_and_decode_async (device-side counts, no mid-frame sync, results collected one frame late; the encode
+    and the TSDF side fusion on a second stream) produces exactly what the synchronous API produces, mixed with
+    synchronous calls -- with and without the caller's guarantee that frames are complete in device memory."""
     from bnv_fusion_amd import synthetic
     dims, voxel = synthetic.GRID_DIMS[128]
     model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     a = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
     b = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
-    b.overlap_prep = prep
+    b.inputs_resident = resident
     frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
                "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)} for t in range(12)]
     sync_out = [a.fuse_and_decode(f) for f in frames]
