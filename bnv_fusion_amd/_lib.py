@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("BNV_FUSION_LIB") or os.path.join(_HERE, "libbnv_fusio
 SYMBOLS = [
     "bnv_init", "bnv_num_compute_units", "bnv_status_string", "bnv_last_hip_error",
     "bnv_encode_workspace_bytes", "bnv_encode_workspace_reset", "bnv_pointnet_pack_floats",
-    "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_voxelize_pairs",
+    "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_encode_begin", "bnv_encode_begin_depth",
+    "bnv_encode_finish", "bnv_encode_shard_counts_offset", "bnv_voxelize_pairs",
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_integrate_batch",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
@@ -78,6 +79,12 @@ def load():
         "bnv_sdfmlp_pack_floats": (sz, []),
         "bnv_encode_pointcloud": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64, C.c_int,
                                             vp, vp]),
+        "bnv_encode_begin": (C.c_int, [vp, i64, C.POINTER(Grid), vp, sz, i64, vp]),
+        "bnv_encode_begin_depth": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.c_double, C.POINTER(Grid), vp, sz, i64, vp, vp]),
+        "bnv_encode_finish": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64, C.c_int,
+                                        vp, vp]),
+        "bnv_encode_shard_counts_offset": (sz, []),
         "bnv_voxelize_pairs": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, vp, vp, vp]),
         "bnv_volume_clear": (C.c_int, [C.POINTER(Volume), vp]),
         "bnv_volume_rehash": (C.c_int, [C.POINTER(Volume), vp]),

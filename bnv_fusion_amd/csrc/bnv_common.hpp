@@ -112,6 +112,35 @@ __device__ __forceinline__ int voxel_owner(int x, int y, int z, const bnv_grid_t
   return (int)(mix64(b) % (uint32_t)g.shard_world);
 }
 
+// Is the voxel a BOUNDARY voxel of the sharding: does any voxel of its 3x3x3 neighbourhood belong to another
+// rank?  (Purely a function of the coordinates: only voxels on the faces of their block can qualify.)  The decode of
+// a voxel reads the rows of that neighbourhood, so boundary voxels are the ones whose rows other ranks need.
+__device__ __forceinline__ bool shard_is_boundary(int x, int y, int z, const bnv_grid_t& g) {
+  if (g.shard_world <= 1) return false;
+  const int m = (1 << g.shard_block_log2) - 1;
+  const int bx = x & m, by = y & m, bz = z & m;
+  if (bx != 0 && bx != m && by != 0 && by != m && bz != 0 && bz != m) return false;  // interior of its block
+  const int me = voxel_owner(x, y, z, g);
+  for (int dx = (bx == 0 ? -1 : 0); dx <= (bx == m ? 1 : 0); ++dx)
+    for (int dy = (by == 0 ? -1 : 0); dy <= (by == m ? 1 : 0); ++dy)
+      for (int dz = (bz == 0 ? -1 : 0); dz <= (bz == m ? 1 : 0); ++dz)
+        if ((dx | dy | dz) != 0 && voxel_owner(x + dx, y + dy, z + dz, g) != me) return true;
+  return false;
+}
+
+// Does rank `rank` own a voxel of the 3x3x3 neighbourhood of (x, y, z) (the voxel itself included)?  Then it
+// reads this voxel's row when it decodes, and keeps a copy of it (a ghost row) if the voxel is somebody else's.
+__device__ __forceinline__ bool shard_adjacent_to(int x, int y, int z, const bnv_grid_t& g, int rank) {
+  if (g.shard_world <= 1) return rank == 0;
+  const int m = (1 << g.shard_block_log2) - 1;
+  const int bx = x & m, by = y & m, bz = z & m;
+  for (int dx = (bx == 0 ? -1 : 0); dx <= (bx == m ? 1 : 0); ++dx)
+    for (int dy = (by == 0 ? -1 : 0); dy <= (by == m ? 1 : 0); ++dy)
+      for (int dz = (bz == 0 ? -1 : 0); dz <= (bz == m ? 1 : 0); ++dz)
+        if (voxel_owner(x + dx, y + dy, z + dz, g) == rank) return true;
+  return false;
+}
+
 // ---- packed volume keys -------------------------------------------------------------------
 constexpr uint64_t kEmptyKey = ~0ULL;
 constexpr int64_t kKeyOffset = 1 << 20;
@@ -160,6 +189,52 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
   __syncthreads();
   *block_total = total;
   return base + incl - v;
+}
+
+// ---- single-pass ordered prefix over the workgroups of ONE launch (decoupled look-back) -------------------------
+// Replaces the three launches of a two-level scan (partial sums, top-level scan, apply).  state[tile] is ONE 64-bit
+// word: bits 63..34 launch epoch | 33..32 flag (1 = this tile's aggregate, 2 = inclusive prefix up to and including
+// this tile) | 31..0 value.  Words left behind by earlier launches carry older epochs and read as "not published
+// yet", so the array is never cleared; every launch takes a fresh epoch from next_epoch().  Workgroups are
+// dispatched in index order, so a predecessor is always resident or finished when a tile waits for it.
+// lookback_exclusive is called by ALL lanes of the first wave of the block with the tile's aggregate (wave-uniform);
+// `seed` is added to tile 0's prefix (e.g. the first free row).  Returns the exclusive prefix, in every lane.
+uint32_t next_epoch();
+
+__device__ __forceinline__ uint64_t lb_word(uint32_t epoch, uint32_t flag, uint32_t v) {
+  return ((uint64_t)(epoch & 0x3fffffffu) << 34) | ((uint64_t)flag << 32) | (uint64_t)v;
+}
+
+__device__ __forceinline__ uint32_t lookback_exclusive(uint64_t* __restrict__ state, int tile, uint32_t agg,
+                                                       uint32_t epoch, uint32_t seed = 0) {
+  const int lane = threadIdx.x & 63;
+  if (tile == 0) {
+    if (lane == 0) __hip_atomic_store(&state[0], lb_word(epoch, 2, seed + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return seed;
+  }
+  if (lane == 0) __hip_atomic_store(&state[tile], lb_word(epoch, 1, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t want = epoch & 0x3fffffffu;
+  uint32_t excl = 0;
+  for (int hi = tile - 1;; hi -= 64) {
+    const int p = hi - lane;   // lane 0 looks at the nearest predecessor
+    uint64_t w = 0;
+    if (p >= 0) {
+      do {
+        w = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((uint32_t)(w >> 34) != want);
+    }
+    const bool incl = p >= 0 && ((uint32_t)(w >> 32) & 3u) == 2u;
+    const unsigned long long m = __ballot(incl);
+    const int first = m ? (int)__ffsll((long long)m) - 1 : 64;   // lane of the nearest inclusive prefix
+    uint32_t v = (p >= 0 && lane <= first) ? (uint32_t)w : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    excl += v;
+    if (m) break;   // (tile 0 always publishes an inclusive prefix, so the walk ends at the latest there)
+  }
+  if (lane == 0)
+    __hip_atomic_store(&state[tile], lb_word(epoch, 2, excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return excl;
 }
 
 }  // namespace bnv

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["encode.hip", "volume.hip", "decode.hip", "frontend.hip", "tsdf.hip", "mesh.hip", "rays.hip", "io.hip"]
-HEADERS = ["bnv_common.hpp", os.path.join("..", "..", "include", "bnv_fusion.h")]
+HEADERS = ["bnv_common.hpp", "frontend.hpp", os.path.join("..", "..", "include", "bnv_fusion.h")]
 OUT = os.path.join(HERE, "..", "libbnv_fusion_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off",   # one rounding per float op, like the reference's ATen CPU ops

@@ -15,10 +15,12 @@
 // pair j, so the K-step that consumes D[r] as its B operand contracts features
 // {f0(r), f0(r)+4}; the packed A operands (weights) are pre-permuted on the host to match
 // (bnv_fusion_amd/weights.py: pack_pointnet).
+#include <stddef.h>
+
 #include <utility>
 #include <vector>
 
-#include "bnv_common.hpp"
+#include "frontend.hpp"
 
 namespace bnv {
 
@@ -74,77 +76,92 @@ constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exac
 // ------------------------------------------------------------------------------------------
 // workspace layout
 // ------------------------------------------------------------------------------------------
+// Control block: the first 512 bytes of the workspace.  All-zero between frames (k_finalize's closing workgroup
+// leaves it so), so no kernel of a frame needs a memset in front of it.
+struct EncCtl {
+  int32_t n_valid;             // points that passed the bounds mask (k_mark / k_front_mark)
+  int32_t n_unique;            // U: touched voxels (k_rank)
+  int32_t error;               // != 0: a capacity was exceeded
+  int32_t pad[13];
+  int32_t shard_boundary[64];  // sharded encode: touched BOUNDARY voxels owned by each rank (k_rank) -- an upper
+                               // bound of the boundary records that rank will exchange for this frame, known on
+                               // every rank (the voxelisation is replicated) before the encoder MLP starts
+};
+static_assert(sizeof(EncCtl) <= 512, "control block");
+
 struct EncodeWs {
+  EncCtl* ctl;
+  uint64_t* tile_state;   // [n_tiles] look-back state of k_rank / k_finalize (epoch-tagged, never cleared)
   uint32_t* bitmap;       // [n_words]
   uint32_t* word_prefix;  // [n_words]
-  uint32_t* block_sums;   // [n_scan_blocks + 1]
   int32_t* ids;           // [max_unique] flat voxel id of slot s (ascending)
   int32_t* counts;        // [max_unique]
   long long* acc;         // [max_unique][8] fixed-point feature sums
   int64_t n_words;
   int64_t max_unique;
-  int64_t n_scan_blocks;
+  int64_t n_tiles;
 };
 
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 elements per block
+constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 slots per workgroup (k_finalize)
+constexpr int kRankItems = 4;
+constexpr int kRankTile = kScanThreads * kRankItems;  // 1024 bitmap words per workgroup (k_rank)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char* base, EncodeWs* ws) {
   const int64_t nvox = (int64_t)n_xyz[0] * n_xyz[1] * n_xyz[2];
-  const int64_t n_words = (nvox + 31) / 32;
+  const int64_t n_words = align_up((size_t)((nvox + 31) / 32), 4);
   int64_t max_unique = 8 * max_points;
   if (max_unique > nvox) max_unique = nvox;
   if (max_unique < 1) max_unique = 1;
-  const int64_t nb_words = (n_words + kScanTile - 1) / kScanTile;
+  const int64_t nb_words = (n_words + kRankTile - 1) / kRankTile;
   const int64_t nb_unique = (max_unique + kScanTile - 1) / kScanTile;
-  const int64_t n_scan_blocks = nb_words > nb_unique ? nb_words : nb_unique;
+  const int64_t n_tiles = nb_words > nb_unique ? nb_words : nb_unique;
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = base ? base + off : nullptr;
     off = align_up(off + bytes, 256);
     return p;
   };
+  char* p_ctl = take(512);   // control block first: its offset does not depend on the sizes
+  char* p_state = take(n_tiles * 8);
   char* p_bitmap = take(n_words * 4);
   char* p_prefix = take(n_words * 4);
-  char* p_sums = take((n_scan_blocks + 1) * 4);
   char* p_ids = take(max_unique * 4);
   char* p_counts = take(max_unique * 4);
   char* p_acc = take(max_unique * 8 * 8);
   if (ws) {
+    ws->ctl = (EncCtl*)p_ctl;
+    ws->tile_state = (uint64_t*)p_state;
     ws->bitmap = (uint32_t*)p_bitmap;
     ws->word_prefix = (uint32_t*)p_prefix;
-    ws->block_sums = (uint32_t*)p_sums;
     ws->ids = (int32_t*)p_ids;
     ws->counts = (int32_t*)p_counts;
     ws->acc = (long long*)p_acc;
     ws->n_words = n_words;
     ws->max_unique = max_unique;
-    ws->n_scan_blocks = n_scan_blocks;
+    ws->n_tiles = n_tiles;
   }
   return off;
 }
 
+// every launch of a look-back kernel takes a fresh epoch (bnv_common.hpp: lookback_exclusive)
+static uint32_t g_epoch = 0;
+uint32_t next_epoch() { return ++g_epoch; }
+
 // ------------------------------------------------------------------------------------------
-// k_mark: one thread per point
+// mark: one thread per point; sets the bits of its 8 corner voxels in the grid bitmap
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
-                                              uint32_t* __restrict__ bitmap,
-                                              bnv_encode_counters_t* __restrict__ counters) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  bool valid = false;
-  float x = 0.f, y = 0.f, z = 0.f;
-  if (i < n_points) {
-    x = pts[(size_t)i * 6 + 0];
-    y = pts[(size_t)i * 6 + 1];
-    z = pts[(size_t)i * 6 + 2];
-    valid = in_bounds(x, y, z, g);
-  }
-  // ~20 pairs fall into each voxel and neighbouring pixels (= neighbouring lanes) mostly share it, so
-  // an atomic is issued only when the previous lane targets a different voxel AND the bit is not
-  // already visible (a stale read only costs a redundant atomicOr, never a missed one).
+// ~20 pairs fall into each voxel and neighbouring pixels (= neighbouring lanes) mostly share it, so an atomic is
+// issued only when the previous lane targets a different voxel AND the bit is not already visible (a stale read
+// only costs a redundant atomicOr, never a missed one).  The floor-z and ceil-z corners of an (x, y) column are
+// neighbouring bits, nearly always of the same bitmap word: one visibility load and at most one atomicOr per
+// column instead of two.  The four columns' visibility loads are issued together (independent addresses), then
+// the atomics: one L2 round trip per point instead of four.  Every lane of the wave must call this.
+__device__ __forceinline__ void mark_point(bool valid, float x, float y, float z, const bnv_grid_t& g,
+                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ n_valid) {
   int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
     const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
@@ -156,41 +173,141 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
   }
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
   const int lane = threadIdx.x & 63;
-  // the floor-z and ceil-z corners of an (x, y) column are neighbouring bits, nearly always of the same
-  // bitmap word: one visibility load and at most one atomicOr per column instead of two
+  int id0[4], id1[4];
+  uint32_t w0[4], w1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy;
     // duplicates (floor == ceil) would set the same bit again
     const bool dup = ((k & 1) && cx == fx) || ((k & 2) && cy == fy);
-    const int id0 = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + fz) : -1;
-    const int id1 = (id0 >= 0 && cz != fz) ? id0 + (cz - fz) : -1;
-    const int p0 = __shfl_up(id0, 1), p1 = __shfl_up(id1, 1);
-    if (id0 >= 0 && !(lane > 0 && p0 == id0 && p1 == id1)) {
-      const uint32_t bit0 = 1u << (id0 & 31);
-      if (id1 >= 0 && (id1 >> 5) == (id0 >> 5)) {
-        const uint32_t bits = bit0 | (1u << (id1 & 31));
-        if ((bitmap[id0 >> 5] & bits) != bits) atomicOr(&bitmap[id0 >> 5], bits);
-      } else {
-        if (!(bitmap[id0 >> 5] & bit0)) atomicOr(&bitmap[id0 >> 5], bit0);
-        if (id1 >= 0) {
-          const uint32_t bit1 = 1u << (id1 & 31);
-          if (!(bitmap[id1 >> 5] & bit1)) atomicOr(&bitmap[id1 >> 5], bit1);
-        }
+    int a = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + fz) : -1;
+    int b = (a >= 0 && cz != fz) ? a + (cz - fz) : -1;
+    const int p0 = __shfl_up(a, 1), p1 = __shfl_up(b, 1);
+    if (lane > 0 && p0 == a && p1 == b) a = b = -1;   // the previous lane sets the very same bits
+    id0[k] = a;
+    id1[k] = b;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    w0[k] = id0[k] >= 0 ? bitmap[id0[k] >> 5] : 0u;
+    w1[k] = (id1[k] >= 0 && (id1[k] >> 5) != (id0[k] >> 5)) ? bitmap[id1[k] >> 5] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (id0[k] < 0) continue;
+    const uint32_t bit0 = 1u << (id0[k] & 31);
+    if (id1[k] >= 0 && (id1[k] >> 5) == (id0[k] >> 5)) {
+      const uint32_t bits = bit0 | (1u << (id1[k] & 31));
+      if ((w0[k] & bits) != bits) atomicOr(&bitmap[id0[k] >> 5], bits);
+    } else {
+      if (!(w0[k] & bit0)) atomicOr(&bitmap[id0[k] >> 5], bit0);
+      if (id1[k] >= 0) {
+        const uint32_t bit1 = 1u << (id1[k] & 31);
+        if (!(w1[k] & bit1)) atomicOr(&bitmap[id1[k] >> 5], bit1);
       }
     }
   }
   const unsigned long long b = __ballot(valid);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters->n_valid_points, (int)__popcll(b));
+  if (lane == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
+}
+
+__global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
+                                              uint32_t* __restrict__ bitmap, EncCtl* __restrict__ ctl) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool valid = false;
+  float x = 0.f, y = 0.f, z = 0.f;
+  if (i < n_points) {
+    x = pts[(size_t)i * 6 + 0];
+    y = pts[(size_t)i * 6 + 1];
+    z = pts[(size_t)i * 6 + 2];
+    valid = in_bounds(x, y, z, g);
+  }
+  mark_point(valid, x, y, z, g, bitmap, &ctl->n_valid);
+}
+
+// The same, fused behind the depth front end (frontend.hpp): one thread per PIXEL computes the pixel's world point
+// and normal in float64 as the reference's loader does, writes the float32 row of input_pts (NaN for an invalid
+// pixel: rows stay in pixel order, nothing is compacted -- the encoder's bounds mask drops NaN rows wherever they
+// are) and marks the point's voxels from the registers: the 7.4 MB of points are not read back, one launch less.
+__global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restrict__ out_pts, bnv_grid_t g,
+                                                    uint32_t* __restrict__ bitmap, EncCtl* __restrict__ ctl) {
+  const int64_t n = (int64_t)a.H * a.W;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float p[6];
+  bool have = false;
+  if (i < n) have = front_point(a, (int)(i / a.W), (int)(i % a.W), p);
+  if (i < n) {
+    float* o = out_pts + (size_t)i * 6;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      f32x2 v;
+      v[0] = have ? p[2 * r] : __builtin_nanf("");
+      v[1] = have ? p[2 * r + 1] : __builtin_nanf("");
+      *(f32x2*)(o + 2 * r) = v;
+    }
+  }
+  const bool valid = have && in_bounds(p[0], p[1], p[2], g);
+  mark_point(valid, p[0], p[1], p[2], g, bitmap, &ctl->n_valid);
 }
 
 // ------------------------------------------------------------------------------------------
-// three-phase device-wide exclusive scan over f(idx)
+// rank: sorted-unique without a sort.  One pass over the bitmap (decoupled look-back over the workgroups):
+// word_prefix[w] = set bits before word w, ids[] = the set bits in ascending order (= torch.unique's output),
+// ctl->n_unique = their number.
 // ------------------------------------------------------------------------------------------
-struct PopcWords {
-  const uint32_t* words;
-  __device__ uint32_t operator()(int64_t i) const { return __popc(words[i]); }
-};
+__global__ __launch_bounds__(kScanThreads) void k_rank(const uint32_t* __restrict__ bitmap, int64_t n_words,
+                                                       uint64_t* __restrict__ tile_state, uint32_t epoch,
+                                                       uint32_t* __restrict__ word_prefix,
+                                                       int32_t* __restrict__ ids, int64_t max_unique,
+                                                       EncCtl* __restrict__ ctl, bnv_grid_t g) {
+  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  __shared__ uint32_t s_excl;
+  __shared__ int s_hist[64];
+  const int64_t base = (int64_t)blockIdx.x * kRankTile + (int64_t)threadIdx.x * kRankItems;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 w = {0u, 0u, 0u, 0u};
+  if (base < n_words) w = *(const u32x4*)&bitmap[base];   // n_words is a multiple of 4
+  const uint32_t s = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+  if (g.shard_world > 1 && threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+  uint32_t total;
+  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
+  if (threadIdx.x < 64) {
+    const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch);
+    if (threadIdx.x == 0) {
+      s_excl = excl;
+      if (blockIdx.x == gridDim.x - 1) ctl->n_unique = (int32_t)(excl + total);
+    }
+  }
+  __syncthreads();
+  if (total == 0) return;  // nothing set in this tile: prefixes are never read for clear words
+  run += s_excl;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+#pragma unroll
+  for (int e = 0; e < kRankItems; ++e) {
+    uint32_t bits = w[e];
+    if (!bits) continue;
+    word_prefix[base + e] = run;
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      const int id = (int)((base + e) * 32 + b);
+      if (run < max_unique) ids[run] = id;
+      else ctl->error = 1;
+      ++run;
+      if (g.shard_world > 1) {
+        const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+        if (shard_is_boundary(x, y, z, g)) atomicAdd(&s_hist[voxel_owner(x, y, z, g) & 63], 1);
+      }
+    }
+  }
+  if (g.shard_world > 1) {
+    __syncthreads();
+    if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
+      atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
+  }
+}
+
 struct ValidFlags {  // 1 where the voxel in slot s is emitted
   const int32_t* counts;
   const int32_t* ids;
@@ -207,96 +324,6 @@ struct ValidFlags {  // 1 where the voxel in slot s is emitted
     return 1;
   }
 };
-
-template <class F>
-__global__ __launch_bounds__(kScanThreads) void k_scan_partial(F f, const int32_t* __restrict__ n_dev,
-                                                               int64_t n_static,
-                                                               uint32_t* __restrict__ block_sums) {
-  __shared__ uint32_t wave_tot[kScanThreads / 64];
-  const int64_t n = n_dev ? (int64_t)*n_dev : n_static;
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-  uint32_t s = 0;
-  if (base < n) {
-#pragma unroll
-    for (int e = 0; e < kScanItems; ++e)
-      if (base + e < n) s += f(base + e);
-  }
-  uint32_t total;
-  block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// one block of 1024 threads: exclusive scan of block_sums[0:n_blocks) in place, total appended
-// (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
-// workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
-// what: 0 nothing more; 1 the total is the frame's number of touched voxels (counters->n_unique); 2 the total is
-// the number of emitted voxels and the frame's counters are completed (these were two single-thread launches).
-__global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ block_sums, int n_blocks,
-                                                   int32_t* __restrict__ total_out,
-                                                   bnv_encode_counters_t* __restrict__ counters = nullptr, int what = 0) {
-  __shared__ uint32_t wave_tot[16];
-  uint32_t carry = 0;
-  for (int base = 0; base < n_blocks; base += 256) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = (i < n_blocks) ? block_sums[i] : 0;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<256>(v, wave_tot, &total);
-    if (i < n_blocks) block_sums[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) {
-    block_sums[n_blocks] = carry;
-    if (total_out) *total_out = (int32_t)carry;
-    if (what == 1) {
-      counters->n_unique = (int32_t)carry;
-    } else if (what == 2) {
-      // n_avg_pts = mean over ALL U voxels of the pair count (local_point_fusion.py:143); every valid
-      // point contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid.
-      const int U = counters->n_unique;
-      counters->n_out = (int32_t)carry;
-      counters->n_avg_pts = (U > 0) ? __fdiv_rn((float)(8 * counters->n_valid_points), (float)U) : 0.f;
-    }
-  }
-}
-
-// apply phase for the bitmap: word_prefix + expansion of set bits into ids[]
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply_bitmap(const uint32_t* __restrict__ bitmap,
-                                                                   int64_t n_words,
-                                                                   const uint32_t* __restrict__ block_sums,
-                                                                   uint32_t* __restrict__ word_prefix,
-                                                                   int32_t* __restrict__ ids, int64_t max_unique,
-                                                                   bnv_encode_counters_t* __restrict__ counters) {
-  __shared__ uint32_t wave_tot[kScanThreads / 64];
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-  uint32_t w[kScanItems];
-  uint32_t s = 0;
-#pragma unroll
-  for (int e = 0; e < kScanItems; ++e) {
-    w[e] = (base + e < n_words) ? bitmap[base + e] : 0u;
-    s += __popc(w[e]);
-  }
-  uint32_t total;
-  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
-  if (total == 0) {  // nothing set in this tile: prefixes are never read for clear words
-    return;
-  }
-#pragma unroll
-  for (int e = 0; e < kScanItems; ++e) {
-    if (base + e < n_words) {
-      uint32_t bits = w[e];
-      if (bits) {
-        word_prefix[base + e] = run;
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (run < max_unique) ids[run] = (int32_t)((base + e) * 32 + b);
-          else counters->error = 1;
-          ++run;
-        }
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // k_pointnet_scatter
@@ -875,15 +902,34 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
 }
 
 // ------------------------------------------------------------------------------------------
-// finalize: ordered compaction of the emitted voxels + cleanup of the per-frame scratch
+// finalize: mean, min-points filter, ORDERED compaction of the emitted voxels (one pass: decoupled look-back over the
+// workgroups), unflatten, cleanup of the per-frame scratch; the workgroup of the last tile completes the frame's
+// counters and clears the control block.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanThreads) void k_finalize(
     bnv_grid_t g, int emit_all, uint32_t* __restrict__ bitmap, int32_t* __restrict__ ids,
-    int32_t* __restrict__ counts, long long* __restrict__ acc, const uint32_t* __restrict__ block_sums,
-    float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts, int64_t* __restrict__ out_flat,
-    int64_t* __restrict__ out_grid, int64_t out_capacity, bnv_encode_counters_t* __restrict__ counters) {
+    int32_t* __restrict__ counts, long long* __restrict__ acc, uint64_t* __restrict__ tile_state, uint32_t epoch,
+    EncCtl* __restrict__ ctl, float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts,
+    int64_t* __restrict__ out_flat, int64_t* __restrict__ out_grid, int64_t out_capacity,
+    bnv_encode_counters_t* __restrict__ counters) {
   __shared__ uint32_t wave_tot[kScanThreads / 64];
-  const int64_t n = counters->n_unique;
+  __shared__ uint32_t s_excl;
+  const int64_t n = ctl->n_unique;
+  if (n == 0) {
+    // no voxel touched (no point passed the bounds mask): workgroup 0 reports the empty frame
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      counters->n_valid_points = ctl->n_valid;
+      counters->n_unique = 0;
+      counters->n_out = 0;
+      counters->n_avg_pts = 0.f;
+      counters->error = ctl->error;
+      counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
+      ctl->n_valid = 0;
+      ctl->error = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) ctl->shard_boundary[threadIdx.x] = 0;
+    return;
+  }
   const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
   if ((int64_t)blockIdx.x * kScanTile >= n) return;
   ValidFlags flags{counts, ids, g, emit_all};
@@ -895,7 +941,34 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     s += fl[e];
   }
   uint32_t total;
-  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total) + block_sums[blockIdx.x];
+  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
+  const bool last_tile = (int64_t)(blockIdx.x + 1) * kScanTile >= n;
+  if (threadIdx.x < 64) {
+    const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch);
+    if (threadIdx.x == 0) s_excl = excl;
+    if (last_tile) {
+      // every other tile has published (so it has read ctl->n_unique): complete the counters, leave the
+      // control block clean for the next frame
+      if (threadIdx.x == 0) {
+        const int32_t n_out = (int32_t)(excl + total);
+        const int32_t nv = ctl->n_valid;
+        counters->n_valid_points = nv;
+        counters->n_unique = (int32_t)n;
+        counters->n_out = n_out;
+        // n_avg_pts = mean over ALL U voxels of the pair count (local_point_fusion.py:143); every valid point
+        // contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid
+        counters->n_avg_pts = __fdiv_rn((float)(8 * nv), (float)n);
+        counters->error = ctl->error ? ctl->error : ((int64_t)n_out > out_capacity ? 2 : 0);
+        counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
+        ctl->n_valid = 0;
+        ctl->n_unique = 0;
+        ctl->error = 0;
+      }
+      ctl->shard_boundary[threadIdx.x] = 0;
+    }
+  }
+  __syncthreads();
+  run += s_excl;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
 #pragma unroll
   for (int e = 0; e < kScanItems; ++e) {
@@ -919,8 +992,6 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
         out_grid[(size_t)run * 3 + 0] = x;
         out_grid[(size_t)run * 3 + 1] = y;
         out_grid[(size_t)run * 3 + 2] = z;
-      } else {
-        counters->error = 2;
       }
       ++run;
     }
@@ -1061,40 +1132,83 @@ int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream) {
   return BNV_OK;
 }
 
-int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
-                          const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
-                          float* out_feats,
-                          int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
-                          int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
-                          bnv_stream_t stream_) {
+// ---- encode in two halves.  begin = voxelise (bounds mask, 8 corner voxels, bitmap) + sorted-unique (rank);
+// finish = PointNet + scatter-mean + min-points filter + ordered compaction.  Everything between the two lives in
+// the workspace; bnv_encode_pointcloud is begin + finish.
+static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, hipStream_t stream) {
+  const int nb_words = (int)((ws.n_words + kRankTile - 1) / kRankTile);
+  hipLaunchKernelGGL(k_rank, dim3(nb_words), dim3(kScanThreads), 0, stream, ws.bitmap, ws.n_words, ws.tile_state,
+                     next_epoch(), ws.word_prefix, ws.ids, ws.max_unique, ws.ctl, g);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+static bool grid_ok(const bnv_grid_t& g) {
+  return (int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] < (1LL << 31) && g.n_xyz[0] > 0 && g.n_xyz[1] > 0 &&
+         g.n_xyz[2] > 0 && g.shard_world >= 1 && g.shard_world <= 64 && g.shard_rank >= 0 &&
+         g.shard_rank < g.shard_world;
+}
+
+size_t bnv_encode_shard_counts_offset(void) { return offsetof(EncCtl, shard_boundary); }
+
+int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host, void* ws_ptr,
+                     size_t ws_bytes, int64_t ws_max_points, bnv_stream_t stream_) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!input_pts || !grid_host || !ws_ptr || n_points < 0 || n_points > (1 << 27) || ws_max_points < n_points)
+    return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_grid_t g = *grid_host;
+  if (!grid_ok(g)) return BNV_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  EncodeWs ws;
+  // the layout is a function of the workspace's capacity, not of this frame's point count, so
+  // the scratch the previous frame left clean stays where this frame expects it
+  if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (n_points == 0) return BNV_OK;
+  const int n = (int)n_points;
+  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.ctl);
+  BNV_LAUNCH_CHECK();
+  return encode_rank(ws, g, stream);
+}
+
+int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                           const double* T_wc_host, double max_depth, const bnv_grid_t* grid_host, void* ws_ptr,
+                           size_t ws_bytes, int64_t ws_max_points, float* out_pts, bnv_stream_t stream_) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!depth || !intr_host || !T_wc_host || !grid_host || !ws_ptr || !out_pts || H <= 0 || W <= 0 || depth_dtype < 0 ||
+      depth_dtype > 2 || (int64_t)H * W > (1 << 27) || ws_max_points < (int64_t)H * W)
+    return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_grid_t g = *grid_host;
+  if (!grid_ok(g)) return BNV_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  EncodeWs ws;
+  if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  FrontArgs a;
+  front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
+  const int64_t n = (int64_t)H * W;
+  hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bitmap,
+                     ws.ctl);
+  BNV_LAUNCH_CHECK();
+  return encode_rank(ws, g, stream);
+}
+
+int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                      const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
+                      float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                      int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
       n_points > (1 << 27) || ws_max_points < n_points)
     return BNV_ERR_INVALID_ARGUMENT;
   const bnv_grid_t g = *grid_host;
-  if ((int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] >= (1LL << 31)) return BNV_ERR_INVALID_ARGUMENT;
+  if (!grid_ok(g)) return BNV_ERR_INVALID_ARGUMENT;
   hipStream_t stream = (hipStream_t)stream_;
   EncodeWs ws;
-  // the layout is a function of the workspace's capacity, not of this frame's point count, so
-  // the scratch the previous frame left clean stays where this frame expects it
-  const size_t need = encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws);
-  if (need > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
-  BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
-  if (n_points == 0) return BNV_OK;
+  if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (n_points == 0) {
+    BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
+    return BNV_OK;
+  }
   const int n = (int)n_points;
-
-  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, counters);
-  BNV_LAUNCH_CHECK();
-  // sorted-unique via bitmap rank
-  const int nb_words = (int)((ws.n_words + kScanTile - 1) / kScanTile);
-  hipLaunchKernelGGL(k_scan_partial<PopcWords>, dim3(nb_words), dim3(kScanThreads), 0, stream,
-                     PopcWords{ws.bitmap}, (const int32_t*)nullptr, ws.n_words, ws.block_sums);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_words, (int32_t*)nullptr, counters, 1);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_apply_bitmap, dim3(nb_words), dim3(kScanThreads), 0, stream, ws.bitmap, ws.n_words,
-                     ws.block_sums, ws.word_prefix, ws.ids, ws.max_unique, counters);
-  BNV_LAUNCH_CHECK();
   // point encoder + scatter
   const int n_tiles = ((n + 31) / 32) * 8;
   int grid_pn = g_num_cus - g_reserve_cus > 0 ? g_num_cus - g_reserve_cus : 1;
@@ -1116,19 +1230,27 @@ int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_gr
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
   }
   BNV_LAUNCH_CHECK();
-  // ordered compaction of the emitted voxels; the number of slots is only known on the device,
-  // so the scan grids cover max_unique and blocks past n_unique exit at once
+  // ordered compaction of the emitted voxels; the number of slots is only known on the device, so the grid covers
+  // max_unique and workgroups past n_unique exit at once
   const int nb_u = (int)((ws.max_unique + kScanTile - 1) / kScanTile);
-  hipLaunchKernelGGL(k_scan_partial<ValidFlags>, dim3(nb_u), dim3(kScanThreads), 0, stream,
-                     ValidFlags{ws.counts, ws.ids, g, emit_all}, &counters->n_unique, (int64_t)0, ws.block_sums);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, stream, ws.block_sums, nb_u, (int32_t*)nullptr, counters, 2);
-  BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
-                     ws.counts, ws.acc, ws.block_sums, out_feats, out_pcounts, out_flat_ids, out_grid_ids,
-                     out_capacity, counters);
+                     ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, out_feats, out_pcounts, out_flat_ids,
+                     out_grid_ids, out_capacity, counters);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_encode_pointcloud(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                          const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
+                          float* out_feats,
+                          int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                          int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
+                          bnv_stream_t stream) {
+  if (!pointnet_pack || !counters) return BNV_ERR_INVALID_ARGUMENT;
+  const int rc = bnv_encode_begin(input_pts, n_points, grid_host, ws_ptr, ws_bytes, ws_max_points, stream);
+  if (rc != BNV_OK) return rc;
+  return bnv_encode_finish(input_pts, n_points, grid_host, pointnet_pack, ws_ptr, ws_bytes, ws_max_points, out_feats,
+                           out_pcounts, out_flat_ids, out_grid_ids, out_capacity, emit_all, counters, stream);
 }
 
 int bnv_voxelize_pairs(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,

@@ -7,44 +7,13 @@
 // pixel, float64 arithmetic in the reference's operation order (compiled with -ffp-contract=off), one
 // rounding to float32 at the end, rows compacted by the validity mask in row-major pixel order with an
 // ordered prefix sum.  HBM-bound and tiny: 0.6 MB of depth in, 7.4 MB of points out per 640x480 frame.
-#include "bnv_common.hpp"
+#include "frontend.hpp"
 
 namespace bnv {
 
 constexpr int kFrontThreads = 256;
 constexpr int kFrontItems = 4;
 constexpr int kFrontTile = kFrontThreads * kFrontItems;
-
-struct FrontArgs {
-  const void* depth;
-  int dtype;  // 0: uint16 millimetres (cv2.imread(...)/1000., common.py:93), 1: float32 metres, 2: float64 metres
-  int H, W;
-  double fx, fy, cx, cy;
-  double T[12];  // rows 0..2 of T_wc
-  double max_depth;
-  float fxf, fyf, cxf, cyf;  // depth2xyz builds its pixel rays in float32 (geometry.py:163-168)
-};
-
-__device__ __forceinline__ double depth_at(const FrontArgs& a, int y, int x) {
-  y = y < 0 ? 0 : (y >= a.H ? a.H - 1 : y);  // replicate padding of the Sobel filter
-  x = x < 0 ? 0 : (x >= a.W ? a.W - 1 : x);
-  const size_t i = (size_t)y * a.W + x;
-  double d;
-  if (a.dtype == 0) d = (double)((const uint16_t*)a.depth)[i] / 1000.0;
-  else if (a.dtype == 1) d = (double)((const float*)a.depth)[i];
-  else d = ((const double*)a.depth)[i];
-  // mask = depth > 0 (& depth < max_depth); depth = depth * mask   (common.py:107-110)
-  return (d > 0.0 && d < a.max_depth) ? d : 0.0;
-}
-
-__device__ __forceinline__ void xyz_at(const FrontArgs& a, int y, int x, double (&p)[3]) {
-  const int yc = y < 0 ? 0 : (y >= a.H ? a.H - 1 : y);
-  const int xc = x < 0 ? 0 : (x >= a.W ? a.W - 1 : x);
-  const double d = depth_at(a, yc, xc);
-  p[0] = ((double)xc - a.cx) / a.fx * d;
-  p[1] = ((double)yc - a.cy) / a.fy * d;
-  p[2] = d;
-}
 
 __global__ __launch_bounds__(kFrontThreads) void k_front_count(FrontArgs a, uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wave_tot[kFrontThreads / 64];
@@ -108,33 +77,11 @@ __global__ __launch_bounds__(kFrontThreads) void k_front_points(FrontArgs a, con
       }
       continue;
     }
-    const int y = (int)(i / a.W), x = (int)(i % a.W);
-    const double d = dd[e];
-    // ---- normal: Sobel/8 of the xyz map, cross product, L2 normalise (kornia depth_to_normals) ----
-    double A[3], B[3], C[3], D[3], E[3], F[3], gx[3], gy[3];
-    xyz_at(a, y - 1, x + 1, A); xyz_at(a, y, x + 1, B); xyz_at(a, y + 1, x + 1, C);
-    xyz_at(a, y - 1, x - 1, D); xyz_at(a, y, x - 1, E); xyz_at(a, y + 1, x - 1, F);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gx[c] = (((((A[c] + 2.0 * B[c]) + C[c]) - D[c]) - 2.0 * E[c]) - F[c]) / 8.0;
-    xyz_at(a, y + 1, x - 1, A); xyz_at(a, y + 1, x, B); xyz_at(a, y + 1, x + 1, C);
-    xyz_at(a, y - 1, x - 1, D); xyz_at(a, y - 1, x, E); xyz_at(a, y - 1, x + 1, F);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gy[c] = (((((A[c] + 2.0 * B[c]) + C[c]) - D[c]) - 2.0 * E[c]) - F[c]) / 8.0;
-    double nrm[3] = {gx[1] * gy[2] - gx[2] * gy[1], gx[2] * gy[0] - gx[0] * gy[2], gx[0] * gy[1] - gx[1] * gy[0]};
-    const double len = sqrt((nrm[0] * nrm[0] + nrm[1] * nrm[1]) + nrm[2] * nrm[2]);
-    const double den = len > 1e-12 ? len : 1e-12;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nrm[c] = nrm[c] / den;
-    // ---- point: depth2xyz with float32 pixel rays, then T_wc ----
-    const double ur = (double)__fdiv_rn(__fsub_rn((float)x, a.cxf), a.fxf);
-    const double vr = (double)__fdiv_rn(__fsub_rn((float)y, a.cyf), a.fyf);
-    const double pc[3] = {ur * d, vr * d, d};
+    float p[6];
+    front_point(a, (int)(i / a.W), (int)(i % a.W), p);
     float* o = out + (size_t)run * 6;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      o[r] = (float)(((a.T[r * 4 + 0] * pc[0] + a.T[r * 4 + 1] * pc[1]) + a.T[r * 4 + 2] * pc[2]) + a.T[r * 4 + 3]);
-      o[3 + r] = (float)((a.T[r * 4 + 0] * nrm[0] + a.T[r * 4 + 1] * nrm[1]) + a.T[r * 4 + 2] * nrm[2]);
-    }
+    for (int r = 0; r < 6; ++r) o[r] = p[r];
     ++run;
   }
 }
@@ -158,20 +105,7 @@ static int depth_to_points_impl(const void* depth, int depth_dtype, int H, int W
     return BNV_ERR_INVALID_ARGUMENT;
   if (ws_bytes < bnv_depth_workspace_bytes(H, W)) return BNV_ERR_WORKSPACE_TOO_SMALL;
   FrontArgs a;
-  a.depth = depth;
-  a.dtype = depth_dtype;
-  a.H = H;
-  a.W = W;
-  a.fx = intr_host[0];
-  a.fy = intr_host[4];
-  a.cx = intr_host[2];
-  a.cy = intr_host[5];
-  for (int i = 0; i < 12; ++i) a.T[i] = T_wc_host[i];
-  a.max_depth = max_depth;
-  a.fxf = (float)a.fx;
-  a.fyf = (float)a.fy;
-  a.cxf = (float)a.cx;
-  a.cyf = (float)a.cy;
+  front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   hipStream_t stream = (hipStream_t)stream_;
   const int nb = (int)(((int64_t)H * W + kFrontTile - 1) / kFrontTile);
   uint32_t* sums = (uint32_t*)ws;

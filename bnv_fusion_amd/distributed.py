@@ -302,9 +302,13 @@ class HipFrameBackend:
         hdr = torch.empty(REC_HDR, dtype=torch.int64, device=self.dev)        # words 4..7 are never read
         if self._scratch_ids is None or self._scratch_ids.numel() < rows:
             self._scratch_ids = torch.empty(rows, dtype=torch.int64, device=self.dev)
-        _, _, _, _, cnt, _ = self.pointnet.encode_pointcloud_async(
-            frame_input_pts(frame, self.max_depth), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size,
-            out=(feats, pcounts, self._scratch_ids, grid_ids))
+        outs = (feats, pcounts, self._scratch_ids, grid_ids)
+        if "input_pts" in frame:
+            cnt = self.pointnet.encode_pointcloud_async(frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
+                                                        v.voxel_size, out=outs)[4]
+        else:      # straight from the depth image: front end fused into the voxelisation
+            cnt = self.pointnet.encode_depth_async(frame["depth"], frame["intr_mat"], frame["T_wc"], self.max_depth,
+                                                   v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, out=outs)[4]
         header_counters(hdr).copy_(cnt)
         return EncodedFrame(hdr, grid_ids, pcounts, feats)
 

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-_DTYPES = {torch.uint16: 0, torch.int16: 0, torch.float32: 1, torch.float64: 2}
+DEPTH_DTYPES = {torch.uint16: 0, torch.int16: 0, torch.float32: 1, torch.float64: 2}
 
 
 def depth_to_input_pts(depth, intr_mat, T_wc, max_depth=10.0, compact=True):
@@ -25,7 +25,7 @@ def depth_to_input_pts(depth, intr_mat, T_wc, max_depth=10.0, compact=True):
     lib = _lib.require_device(depth.device.index or 0)
     d = depth.contiguous()
     H, W = int(d.shape[-2]), int(d.shape[-1])
-    dt = _DTYPES[d.dtype]
+    dt = DEPTH_DTYPES[d.dtype]
     K = (C.c_double * 9)(*np.asarray(intr_mat, dtype=np.float64)[:3, :3].reshape(-1))
     T = (C.c_double * 16)(*np.asarray(T_wc, dtype=np.float64).reshape(-1))
     ws = torch.empty(int(lib.bnv_depth_workspace_bytes(H, W)), dtype=torch.uint8, device=d.device)

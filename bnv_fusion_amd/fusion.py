@@ -214,19 +214,8 @@ class LitFusionPointNet(nn.Module):
         return grid, res
 
     # ---- encode (local_point_fusion.py:81-165) ----------------------------------------------------
-    def encode_pointcloud_async(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=False, out=None):
-        """Enqueues the encode and returns WITHOUT synchronising: capacity-sized output buffers
-        (feats [cap,8], pcounts [cap] i64, flat_ids [cap] i64, grid_ids [cap,3] i64) and the device
-        counters (int32 [8]: n_valid, n_unique, n_out, n_avg_pts as float bits, error).  Downstream kernels
-        read n_out from ``counters[2:3]`` on the device.  ``out``: caller-provided contiguous buffers
-        (feats, pcounts, flat_ids, grid_ids) to write into; their row count is the capacity."""
-        lib = self._lib_for(self.pointnet_pack)
-        self._select_mode(lib)
-        assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
-        pts = input_pts[0].detach().float().contiguous()
-        dev = pts.device
-        n = int(pts.shape[0])
-        grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
+    def _encode_buffers(self, lib, dev, n, res, emit_all, out):
+        """Workspace (kept across frames, zero-filled = clean) and output buffers of one encode of up to n points."""
         nvox = res[0] * res[1] * res[2]
         n_arr = (C.c_int32 * 3)(*res)
         key = (tuple(res), dev)
@@ -249,13 +238,72 @@ class LitFusionPointNet(nn.Module):
             pcounts = torch.empty(cap, dtype=torch.int64, device=dev)
             flat_ids = torch.empty(cap, dtype=torch.int64, device=dev)
             grid_ids = torch.empty((cap, 3), dtype=torch.int64, device=dev)
-        counters = torch.empty(8, dtype=torch.int32, device=dev)    # cleared by bnv_encode_pointcloud itself
-        _lib.check(lib.bnv_encode_pointcloud(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack),
-                                             _lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points,
-                                             _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids),
-                                             _lib.ptr(grid_ids), cap, 1 if emit_all else 0, _lib.ptr(counters),
-                                             _lib.stream_ptr()), "bnv_encode_pointcloud")
+        counters = torch.empty(8, dtype=torch.int32, device=dev)    # written in full by the encode's last kernel
         return feats, pcounts, flat_ids, grid_ids, counters, cap
+
+    def shard_boundary_counts(self):
+        """Device int32 [shard_world] view into the encode workspace: touched boundary voxels owned by each rank,
+        valid between the two halves of a sharded encode (include/bnv_fusion.h: bnv_encode_begin)."""
+        off = int(_lib.load().bnv_encode_shard_counts_offset())
+        return self._enc_ws[off: off + 4 * self.shard[1]].view(torch.int32)
+
+    def encode_pointcloud_async(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, emit_all=False, out=None,
+                                between=None):
+        """Enqueues the encode and returns WITHOUT synchronising: capacity-sized output buffers
+        (feats [cap,8], pcounts [cap] i64, flat_ids [cap] i64, grid_ids [cap,3] i64) and the device
+        counters (int32 [8]: n_valid, n_unique, n_out, n_avg_pts as float bits, error).  Downstream kernels
+        read n_out from ``counters[2:3]`` on the device.  ``out``: caller-provided contiguous buffers
+        (feats, pcounts, flat_ids, grid_ids) to write into; their row count is the capacity.  ``between``: called
+        between the two halves of the encode (voxelise + sorted-unique | PointNet + reduction), e.g. to enqueue a
+        read-back of shard_boundary_counts()."""
+        lib = self._lib_for(self.pointnet_pack)
+        self._select_mode(lib)
+        assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
+        pts = input_pts[0].detach().float().contiguous()
+        n = int(pts.shape[0])
+        grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
+        feats, pcounts, flat_ids, grid_ids, counters, cap = self._encode_buffers(lib, pts.device, n, res, emit_all, out)
+        ws = (_lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points)
+        _lib.check(lib.bnv_encode_begin(_lib.ptr(pts), n, C.byref(grid), *ws, _lib.stream_ptr()), "bnv_encode_begin")
+        if between is not None:
+            between()
+        _lib.check(lib.bnv_encode_finish(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack), *ws,
+                                         _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids),
+                                         cap, 1 if emit_all else 0, _lib.ptr(counters), _lib.stream_ptr()),
+                   "bnv_encode_finish")
+        return feats, pcounts, flat_ids, grid_ids, counters, cap
+
+    def encode_depth_async(self, depth, intr_mat, T_wc, max_depth, n_xyz, bound_min, bound_max, voxel_size, out=None,
+                           between=None):
+        """encode_pointcloud_async straight from a depth image [H, W] on the GPU (uint16/int16 millimetres, or
+        float32/float64 metres): the front end (FusionInferenceAbstractDataset.__getitem__,
+        fusion_inference_dataset.py:40-90) is fused in front of the voxelisation -- one kernel computes every pixel's
+        world point + normal in float64, writes its float32 input_pts row (pixel order, NaN rows for invalid pixels)
+        and marks its voxels.  Returns the same tuple as encode_pointcloud_async plus the input_pts tensor
+        [1, H*W, 6]."""
+        from .frontend import DEPTH_DTYPES
+        lib = self._lib_for(self.pointnet_pack)
+        self._select_mode(lib)
+        if not depth.is_cuda:
+            raise _lib.BnvError("encode_depth_async runs on the GPU only")
+        d = depth.contiguous()
+        H, W = int(d.shape[-2]), int(d.shape[-1])
+        n = H * W
+        grid, res = self._grid(n_xyz, bound_min, bound_max, voxel_size)
+        feats, pcounts, flat_ids, grid_ids, counters, cap = self._encode_buffers(lib, d.device, n, res, False, out)
+        pts = torch.empty((n, 6), dtype=torch.float32, device=d.device)
+        K = (C.c_double * 9)(*np.asarray(intr_mat, dtype=np.float64)[:3, :3].reshape(-1))
+        T = (C.c_double * 16)(*np.asarray(T_wc, dtype=np.float64).reshape(-1))
+        ws = (_lib.ptr(self._enc_ws), self._enc_ws.numel(), self._enc_ws_points)
+        _lib.check(lib.bnv_encode_begin_depth(_lib.ptr(d), DEPTH_DTYPES[d.dtype], H, W, K, T, float(max_depth),
+                                              C.byref(grid), *ws, _lib.ptr(pts), _lib.stream_ptr()),
+                   "bnv_encode_begin_depth")
+        if between is not None:
+            between()
+        _lib.check(lib.bnv_encode_finish(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack), *ws,
+                                         _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids),
+                                         cap, 0, _lib.ptr(counters), _lib.stream_ptr()), "bnv_encode_finish")
+        return feats, pcounts, flat_ids, grid_ids, counters, cap, pts.unsqueeze(0)
 
     def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):
         lib = self._lib_for(self.pointnet_pack)

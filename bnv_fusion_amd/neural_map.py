@@ -149,6 +149,16 @@ class NeuralMap:
         sdf = self.volume.decode_lattice(coords, self.pointnet.nerf, self.sdf_delta, query_tensor=False)
         return coords, sdf
 
+    def _encode_frame_async(self, frame):
+        """encode_pointcloud of a frame without a host sync: from ``input_pts`` if the frame carries them (the
+        reference's dataset output), else straight from its depth image (front end fused into the voxelisation)."""
+        v = self.volume
+        if "input_pts" in frame:
+            return self.pointnet.encode_pointcloud_async(frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
+                                                         v.voxel_size)
+        return self.pointnet.encode_depth_async(frame["depth"], frame["intr_mat"], frame["T_wc"], self.max_depth,
+                                                v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)[:6]
+
     def fuse_and_decode_async(self, frame, decode=True):
         """The same work as fuse_and_decode, enqueued without any host synchronisation: integrate and the
         lattice decode read the frame's voxel count from device memory.  Returns a FrameHandle; call
@@ -173,9 +183,7 @@ class NeuralMap:
                     # overlaps it: callers whose frames are complete in device memory set inputs_resident.)
                     enc.wait_stream(main)
                 with torch.cuda.stream(enc):
-                    input_pts = frame_input_pts(frame, self.max_depth)
-                    feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
-                        input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+                    feats, pcounts, flat_ids, grid_ids, counters, cap = self._encode_frame_async(frame)
                     done = torch.cuda.Event()
                     done.record(enc)
                     # the TSDF side fusion depends on the frame only as well (gated on the device by the encode's
@@ -188,9 +196,7 @@ class NeuralMap:
                 for t in (feats, pcounts, flat_ids, grid_ids, counters):
                     t.record_stream(main)     # allocated on the encode stream, consumed on the main stream
             else:
-                input_pts = frame_input_pts(frame, self.max_depth)
-                feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
-                    input_pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+                feats, pcounts, flat_ids, grid_ids, counters, cap = self._encode_frame_async(frame)
                 self._integrate_tsdf(frame, gate=counters[0:1])
             n_dev = counters[2:3]
             host = torch.empty(8, dtype=torch.int32, pin_memory=True)

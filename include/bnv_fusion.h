@@ -178,6 +178,31 @@ int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream);
 size_t bnv_pointnet_pack_floats(void);
 size_t bnv_sdfmlp_pack_floats(void);
 
+/* The encode in two halves (bnv_encode_pointcloud below = begin + finish on the same arguments; everything between
+ * the halves lives in the workspace):
+ *   begin   bounds mask (local_point_fusion.py:94-104), 8-corner voxelisation (:153-165, modules.py:586-655) into a
+ *           grid bitmap, sorted-unique of the touched voxels by bitmap rank (torch.unique, :118-119);
+ *   finish  the point encoder on every (point, corner) pair, per-voxel mean, min-points filter, ordered repack.
+ * bnv_encode_begin_depth fuses the depth front end in front of `begin` (depth arguments as bnv_depth_to_points): it
+ * writes input_pts rows IN PIXEL ORDER into out_pts [H*W, 6] (NaN rows for invalid pixels -- nothing is compacted; the
+ * bounds mask drops NaN rows wherever they are) and marks the voxels from registers; n_points of the matching
+ * finish call is H*W.
+ * With spatial sharding (grid.shard_world > 1) `begin` also leaves, at byte offset bnv_encode_shard_counts_offset()
+ * of the workspace, int32[shard_world]: the number of touched BOUNDARY voxels each rank owns (voxels with a foreign
+ * voxel in their 3x3x3 neighbourhood).  The voxelisation is replicated, so every rank holds the same numbers: an
+ * upper bound, known before the encoder runs, of the boundary records each rank exchanges for the frame
+ * (bnv_shard_pack).  `finish` clears them. */
+int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host, void* ws, size_t ws_bytes,
+                     int64_t ws_max_points, bnv_stream_t stream);
+int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
+                           const double* T_wc_host, double max_depth, const bnv_grid_t* grid_host, void* ws,
+                           size_t ws_bytes, int64_t ws_max_points, float* out_pts, bnv_stream_t stream);
+int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
+                      const float* pointnet_pack, void* ws, size_t ws_bytes, int64_t ws_max_points,
+                      float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                      int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream);
+size_t bnv_encode_shard_counts_offset(void);
+
 /* input_pts [n_points, 6] f32 (world xyz, world normal).
  * Runs: bounds mask (:94-104), 8-corner voxelisation (:153-165, modules.py:586-655), the point
  * encoder on every (point, corner) pair (pointnet_utils.py:246-266, BatchNorm folded), sorted

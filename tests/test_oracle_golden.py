@@ -221,3 +221,46 @@ def test_depth_front_end_points_match_reference_functions():
     assert p.shape == (int(z["n_valid"]), 6)
     assert np.abs(p[:, :3] - z["pts_w"]).max() <= 1e-15
     assert np.array_equal(p[:, :3].astype(np.float32), z["pts_w"].astype(np.float32))   # what run_e2e.py:249 feeds on
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_headline_config_oracle_vs_reference_golden():
+    """The oracle at the configuration the metric is quoted on (256^3, voxel 0.01, full 640x480 frame) against what
+    the reference itself produced there (tests/golden/headline_256.npz, make_golden_256.py): encode of frame 0
+    (every voxel id and count through SHA-256, features of every 16th voxel), and the lattice decode of 2,048 voxels
+    from the reference's own fused volume values after 20 frames."""
+    from bnv_fusion_amd import synthetic
+    z = np.load(os.path.join(GOLDEN, "headline_256.npz"))
+    voxel, dims = float(z["voxel_size"]), z["dims"]
+    sd = orc.load_weights(WEIGHTS_FP32)
+    torch.set_num_threads(8)
+    # inputs are regenerated, not stored: they must be the very frames the reference saw
+    assert _sha(synthetic.depth_u16(0)) == str(z["depth_sha256"][0])
+    pts = synthetic.frame(0)
+    assert _sha(pts) == str(z["input_pts_sha256"][0])
+    vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    assert vol.n_xyz.tolist() == [256, 256, 256]
+    with torch.no_grad():
+        f, c, ids, g, n = orc.encode_pointcloud(sd, torch.from_numpy(pts), vol.n_xyz, vol.min_coords, vol.max_coords,
+                                                voxel)
+    assert np.array_equal(ids.numpy(), np.cumsum(z["flat_ids_delta_0"].astype(np.int64)))
+    assert np.array_equal(c.numpy().reshape(-1), z["pcounts_0"].astype(np.int64))
+    assert _sha(ids.numpy().astype(np.int64)) + _sha(c.numpy().reshape(-1).astype(np.int64)) == \
+        str(z["ids_counts_sha256"][0])
+    assert float(n) == float(z["n_avg_pts"][0])
+    assert np.abs(f.numpy()[::16] - z["feats16_0"]).max() <= 2e-6
+    # decode from the reference's fused values
+    keys = torch.from_numpy(z["nbr_keys"].astype(np.int64))
+    vol.insert(keys, torch.from_numpy(z["nbr_feats"]), torch.from_numpy(z["nbr_weights"])[:, None],
+               torch.zeros(len(keys), 1))
+    origins = z["decode_origins"].astype(np.int64)
+    with torch.no_grad():
+        got = vol.decode_pts(orc.lattice_coords(origins), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+    ref = z["decode_sdf"]
+    assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
+    assert np.abs(got.numpy() - ref).max() <= 2e-6
+    assert (ref != np.float32(voxel)).mean() > 0.3
