@@ -166,6 +166,30 @@ __device__ __forceinline__ int volume_find(const uint64_t* __restrict__ slot_key
   return -1;
 }
 
+// ---- dense row index of the grid (bnv_volume_t::brick) -----------------------------------------------------------
+__device__ __forceinline__ bool brick_index(const bnv_volume_t& v, int64_t x, int64_t y, int64_t z, int64_t* idx) {
+  if ((uint64_t)x >= (uint64_t)v.brick_dims[0] || (uint64_t)y >= (uint64_t)v.brick_dims[1] ||
+      (uint64_t)z >= (uint64_t)v.brick_dims[2])
+    return false;
+  *idx = (x * v.brick_dims[1] + y) * v.brick_dims[2] + z;
+  return true;
+}
+
+// a row was created for voxel (x, y, z)
+__device__ __forceinline__ void brick_set(const bnv_volume_t& v, int64_t x, int64_t y, int64_t z, int32_t row) {
+  int64_t idx;
+  if (v.brick && brick_index(v, x, y, z, &idx)) v.brick[idx] = row;
+}
+
+// Row of voxel (x, y, z) or -1: from the brick when it is kept and the voxel is inside the grid, else from the hash.
+__device__ __forceinline__ int volume_row(const bnv_volume_t& v, int64_t x, int64_t y, int64_t z) {
+  int64_t idx;
+  if (v.brick && brick_index(v, x, y, z, &idx)) return v.brick[idx];
+  uint64_t key;
+  if (!pack_key(x, y, z, &key)) return -1;
+  return volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+}
+
 // ---- block-wide exclusive scan of one uint32 per thread (256 or 1024 threads) ---------------
 template <int THREADS>
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_totals,

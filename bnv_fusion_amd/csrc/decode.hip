@@ -1534,6 +1534,7 @@ struct LatticeWs {
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
   int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
+  uint64_t* tile_state;  // [ceil(27 n / 1024) + 1] look-back state of k_lattice_mark (epoch-tagged, never cleared)
   int64_t list_capacity;
   int64_t entry_capacity;
 };
@@ -1559,7 +1560,9 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   int64_t ecap = 27 * cap;
   if (ecap > 216 * n) ecap = 216 * n;
   char* en = take(ecap * 4);
+  char* ts = take(((27 * n + 1023) / 1024 + 1) * 8);
   if (ws) {
+    ws->tile_state = (uint64_t*)ts;
     ws->need_mask = (uint32_t*)nm;
     ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
@@ -1594,9 +1597,9 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   const int64_t x = origins[b * 3 + 0] + (nb / 9 - 1);
   const int64_t y = origins[b * 3 + 1] + ((nb / 3) % 3 - 1);
   const int64_t z = origins[b * 3 + 2] + (nb % 3 - 1);
-  uint64_t key;
-  int row = -1;
-  if (pack_key(x, y, z, &key)) row = volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+  // (from the dense row index when the volume keeps one: the 27 look-ups of a voxel are 9 runs of 3 neighbouring
+  // words, and neighbouring voxels share them -- against 27 hash probes that each pull a line of their own)
+  int row = volume_row(v, x, y, z);
   if (row >= row_limit) row = -1;
   bool usable = false;
   if (row >= 0) usable = weights[row] >= min_pts;
@@ -1618,9 +1621,13 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
                                                                int64_t entry_capacity,
-                                                               const int32_t* __restrict__ n_dev) {
+                                                               const int32_t* __restrict__ n_dev,
+                                                               uint64_t* __restrict__ tile_state, uint32_t lb_epoch) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
-  // new entries are collected per block in LDS and appended with ONE global atomic per block
+  if ((int64_t)blockIdx.x * kMarkThreads >= n * 27) return;
+  // new entries are collected per block in LDS; the block's place in the list comes from a decoupled look-back over
+  // the blocks (entries in block order: the list is the same from run to run).  One atomicAdd per block on a single
+  // counter serialised at ~11 ns each in the memory-side atomic unit: 2,600 of them were most of this kernel's time.
   __shared__ int s_buf[kMarkThreads * 8];
   __shared__ int s_count, s_base;
   if (threadIdx.x == 0) s_count = 0;
@@ -1682,8 +1689,13 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   }
   __syncthreads();
   const int cnt = s_count;
-  if (cnt == 0) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(n_entries, cnt);
+  if (threadIdx.x < 64) {
+    const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, (uint32_t)cnt, lb_epoch);
+    if (threadIdx.x == 0) {
+      s_base = (int)excl;
+      if ((int64_t)(blockIdx.x + 1) * kMarkThreads >= n * 27) *n_entries = (int32_t)(excl + (uint32_t)cnt);  // last block
+    }
+  }
   __syncthreads();
   const int base = s_base;
   for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
@@ -2041,7 +2053,7 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   if (n == 0) return BNV_OK;
   hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, ws.tile_state, next_epoch());
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

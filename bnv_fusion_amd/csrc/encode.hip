@@ -79,7 +79,7 @@ constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exac
 // Control block: the first 512 bytes of the workspace.  All-zero between frames (k_finalize's closing workgroup
 // leaves it so), so no kernel of a frame needs a memset in front of it.
 struct EncCtl {
-  int32_t n_valid;             // points that passed the bounds mask (k_mark / k_front_mark)
+  int32_t spare;
   int32_t n_unique;            // U: touched voxels (k_rank)
   int32_t error;               // != 0: a capacity was exceeded
   int32_t pad[13];
@@ -92,6 +92,7 @@ static_assert(sizeof(EncCtl) <= 512, "control block");
 struct EncodeWs {
   EncCtl* ctl;
   uint64_t* tile_state;   // [n_tiles] look-back state of k_rank / k_finalize (epoch-tagged, never cleared)
+  int32_t* valid_blocks;  // [ceil(max_points / 256)] points that passed the bounds mask, per workgroup of the mark kernel
   uint32_t* bitmap;       // [n_words]
   uint32_t* word_prefix;  // [n_words]
   int32_t* ids;           // [max_unique] flat voxel id of slot s (ascending)
@@ -127,6 +128,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   };
   char* p_ctl = take(512);   // control block first: its offset does not depend on the sizes
   char* p_state = take(n_tiles * 8);
+  char* p_valid = take(((max_points + 255) / 256 + 1) * 4);
   char* p_bitmap = take(n_words * 4);
   char* p_prefix = take(n_words * 4);
   char* p_ids = take(max_unique * 4);
@@ -135,6 +137,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   if (ws) {
     ws->ctl = (EncCtl*)p_ctl;
     ws->tile_state = (uint64_t*)p_state;
+    ws->valid_blocks = (int32_t*)p_valid;
     ws->bitmap = (uint32_t*)p_bitmap;
     ws->word_prefix = (uint32_t*)p_prefix;
     ws->ids = (int32_t*)p_ids;
@@ -159,9 +162,12 @@ uint32_t next_epoch() { return ++g_epoch; }
 // only costs a redundant atomicOr, never a missed one).  The floor-z and ceil-z corners of an (x, y) column are
 // neighbouring bits, nearly always of the same bitmap word: one visibility load and at most one atomicOr per
 // column instead of two.  The four columns' visibility loads are issued together (independent addresses), then
-// the atomics: one L2 round trip per point instead of four.  Every lane of the wave must call this.
+// the atomics: one L2 round trip per point instead of four.  Every thread of the (256-thread) workgroup must call
+// this.  The number of valid points goes to valid_blocks[blockIdx.x] as a plain store: one atomicAdd per wave on a
+// single counter serialises in the memory-side atomic unit at ~11 ns each -- 4,800 of them were 52 of this kernel's
+// 77 us (tools/probe_mark.hip).
 __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z, const bnv_grid_t& g,
-                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ n_valid) {
+                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks) {
   int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
     const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
@@ -207,12 +213,15 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
       }
     }
   }
+  __shared__ int s_valid[4];
   const unsigned long long b = __ballot(valid);
-  if (lane == 0 && b) atomicAdd(n_valid, (int)__popcll(b));
+  if (lane == 0) s_valid[threadIdx.x >> 6] = (int)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) valid_blocks[blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
 }
 
 __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
-                                              uint32_t* __restrict__ bitmap, EncCtl* __restrict__ ctl) {
+                                              uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool valid = false;
   float x = 0.f, y = 0.f, z = 0.f;
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
     z = pts[(size_t)i * 6 + 2];
     valid = in_bounds(x, y, z, g);
   }
-  mark_point(valid, x, y, z, g, bitmap, &ctl->n_valid);
+  mark_point(valid, x, y, z, g, bitmap, valid_blocks);
 }
 
 // The same, fused behind the depth front end (frontend.hpp): one thread per PIXEL computes the pixel's world point
@@ -230,7 +239,8 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
 // pixel: rows stay in pixel order, nothing is compacted -- the encoder's bounds mask drops NaN rows wherever they
 // are) and marks the point's voxels from the registers: the 7.4 MB of points are not read back, one launch less.
 __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restrict__ out_pts, bnv_grid_t g,
-                                                    uint32_t* __restrict__ bitmap, EncCtl* __restrict__ ctl) {
+                                                    uint32_t* __restrict__ bitmap,
+                                                    int32_t* __restrict__ valid_blocks) {
   const int64_t n = (int64_t)a.H * a.W;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float p[6];
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restri
     }
   }
   const bool valid = have && in_bounds(p[0], p[1], p[2], g);
-  mark_point(valid, p[0], p[1], p[2], g, bitmap, &ctl->n_valid);
+  mark_point(valid, p[0], p[1], p[2], g, bitmap, valid_blocks);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -909,7 +919,8 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
 __global__ __launch_bounds__(kScanThreads) void k_finalize(
     bnv_grid_t g, int emit_all, uint32_t* __restrict__ bitmap, int32_t* __restrict__ ids,
     int32_t* __restrict__ counts, long long* __restrict__ acc, uint64_t* __restrict__ tile_state, uint32_t epoch,
-    EncCtl* __restrict__ ctl, float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts,
+    EncCtl* __restrict__ ctl, const int32_t* __restrict__ valid_blocks, int n_mark_blocks,
+    float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts,
     int64_t* __restrict__ out_flat, int64_t* __restrict__ out_grid, int64_t out_capacity,
     bnv_encode_counters_t* __restrict__ counters) {
   __shared__ uint32_t wave_tot[kScanThreads / 64];
@@ -918,13 +929,12 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
   if (n == 0) {
     // no voxel touched (no point passed the bounds mask): workgroup 0 reports the empty frame
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      counters->n_valid_points = ctl->n_valid;
+      counters->n_valid_points = 0;
       counters->n_unique = 0;
       counters->n_out = 0;
       counters->n_avg_pts = 0.f;
       counters->error = ctl->error;
       counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
-      ctl->n_valid = 0;
       ctl->error = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) ctl->shard_boundary[threadIdx.x] = 0;
@@ -949,9 +959,12 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     if (last_tile) {
       // every other tile has published (so it has read ctl->n_unique): complete the counters, leave the
       // control block clean for the next frame
+      int nv = 0;
+      for (int b = threadIdx.x; b < n_mark_blocks; b += 64) nv += valid_blocks[b];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) nv += __shfl_xor(nv, d, 64);
       if (threadIdx.x == 0) {
         const int32_t n_out = (int32_t)(excl + total);
-        const int32_t nv = ctl->n_valid;
         counters->n_valid_points = nv;
         counters->n_unique = (int32_t)n;
         counters->n_out = n_out;
@@ -960,7 +973,6 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
         counters->n_avg_pts = __fdiv_rn((float)(8 * nv), (float)n);
         counters->error = ctl->error ? ctl->error : ((int64_t)n_out > out_capacity ? 2 : 0);
         counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
-        ctl->n_valid = 0;
         ctl->n_unique = 0;
         ctl->error = 0;
       }
@@ -1165,7 +1177,7 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   if (n_points == 0) return BNV_OK;
   const int n = (int)n_points;
-  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.ctl);
+  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.valid_blocks);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1186,7 +1198,7 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bitmap,
-                     ws.ctl);
+                     ws.valid_blocks);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1234,8 +1246,8 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
   // max_unique and workgroups past n_unique exit at once
   const int nb_u = (int)((ws.max_unique + kScanTile - 1) / kScanTile);
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
-                     ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, out_feats, out_pcounts, out_flat_ids,
-                     out_grid_ids, out_capacity, counters);
+                     ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, ws.valid_blocks, (n + 255) / 256, out_feats,
+                     out_pcounts, out_flat_ids, out_grid_ids, out_capacity, counters);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

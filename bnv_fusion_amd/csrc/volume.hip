@@ -19,6 +19,7 @@ struct VolWs {
   int32_t* is_new;         // [n] 1 if this thread's CAS created the slot
   uint32_t* block_sums;    // [n_blocks + 1]
   uint32_t* block_new;     // [ceil(n / 256) + 1] created keys per 256-key block (integrate)
+  uint64_t* tile_state;    // [ceil(n / 256) + 1] look-back state of k_vol_integrate (epoch-tagged, never cleared)
   int32_t* total_new;      // [1] workspace word 0: created keys (insert) / first new row (integrate)
   int32_t* error;          // [1] = vol.n_rows + 1: sticky error code (1 table full, 2 key range, 3 row capacity)
 };
@@ -37,7 +38,9 @@ static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
   char* b = take(n * 4);
   char* c = take((nb + 1) * 4);
   char* e = take(((n + 255) / 256 + 1) * 4);
+  char* t = take(((n + 255) / 256 + 1) * 8);
   if (ws) {
+    ws->tile_state = (uint64_t*)t;
     ws->slot_of = (int32_t*)a;
     ws->is_new = (int32_t*)b;
     ws->block_sums = (uint32_t*)c;
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(kVolThreads) void k_vol_assign_rows(bnv_volume_t v,
         v.row_coords[row * 3 + 0] = coords[i * 3 + 0];
         v.row_coords[row * 3 + 1] = coords[i * 3 + 1];
         v.row_coords[row * 3 + 2] = coords[i * 3 + 2];
+        brick_set(v, coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], (int32_t)row);
         // a fresh row reads as zeros (SparseVolume.query of an absent key, sparse_volume.py:677-679)
         for (int f = 0; f < v.n_feats; ++f) v.features[row * v.n_feats + f] = 0.f;
         v.weights[row] = 0.f;
@@ -196,12 +200,8 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
   *n_rows += *total_new;
 }
 
-// ---- fused upsert for _integrate: 3 launches instead of 7 (memset, probe, 2-level scan x2, assign, commit,
-// apply).  Every launch costs ~10 us of stream time whatever it does, and the frame-parallel multi-GPU mode
-// replays this upsert once per frame of a batch on every rank.  K1 = k_vol_probe_insert, which also counts
-// the created keys of each 256-key block.
-// K2: ONE workgroup turns the block counts into exclusive offsets and commits the row count; first_row_out
-// receives the old count.
+// ONE workgroup turns per-block counts of created keys into exclusive offsets and commits the row count;
+// first_row_out receives the old count (the batched upsert below; the per-frame upsert is k_vol_integrate).
 // (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
 // workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
 __global__ __launch_bounds__(256) void k_vol_offsets_commit(uint32_t* __restrict__ block_new, int n_blocks,
@@ -225,37 +225,86 @@ __global__ __launch_bounds__(256) void k_vol_offsets_commit(uint32_t* __restrict
   }
 }
 
-// K3: creates the rows of the new keys and applies _integrate/_update (local_point_fusion.py:647-673) to every
-// key in one pass.  Keys are unique within a batch, so a row is touched by exactly one thread.
-__global__ __launch_bounds__(256) void k_vol_assign_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
-                                                              const float* __restrict__ feats,
-                                                              const int64_t* __restrict__ pcounts, int64_t n,
-                                                              const int32_t* __restrict__ n_dev,
-                                                              const int32_t* __restrict__ slot_of,
-                                                              const int32_t* __restrict__ is_new,
-                                                              const uint32_t* __restrict__ block_off,
-                                                              const int32_t* __restrict__ first_row,
-                                                              int32_t* __restrict__ error) {
+// ---- _integrate in ONE launch.  Every workgroup (256 keys) probes / CAS-inserts its keys, counts the keys it
+// created, obtains the first row of its new keys by decoupled look-back over the workgroups (rows are numbered in
+// batch order: the reference's insertion order; tile 0 seeds the chain with the volume's row count, the last tile
+// commits the new count), creates the rows and applies the running average.  Keys are unique within a batch, so a
+// slot / row is touched by exactly one thread; the look-back state is epoch-tagged and needs no clearing.
+__global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
+                                                       const float* __restrict__ feats,
+                                                       const int64_t* __restrict__ pcounts, int64_t n,
+                                                       const int32_t* __restrict__ n_dev,
+                                                       uint64_t* __restrict__ tile_state, uint32_t epoch,
+                                                       int32_t* __restrict__ error) {
   n = dev_count(n, n_dev);
+  if ((int64_t)blockIdx.x * 256 >= n) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // rank of a created key among the created keys of the batch, in batch order (= position of its new row)
+  uint64_t key;
+  int32_t slot = -1, created = 0;
+  if (i < n) {
+    if (pack_key(coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], &key)) {
+      const uint32_t mask = (uint32_t)(v.n_slots - 1);
+      uint32_t s = mix64(key) & mask;
+      for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint64_t k = v.slot_keys[s];
+        if (k == kEmptyKey) {
+          k = atomicCAS((unsigned long long*)&v.slot_keys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
+          if (k == kEmptyKey) {
+            slot = (int32_t)s;
+            created = 1;
+            break;
+          }
+        }
+        if (k == key) {
+          slot = (int32_t)s;
+          break;
+        }
+        s = (s + 1) & mask;
+      }
+      if (slot < 0) *error = 1;  // table full
+    } else {
+      *error = 2;  // coordinate outside the 21-bit key range
+    }
+  }
+  // the values of an existing row are requested before the look-back, which then waits on other workgroups
+  float w_old = 0.f;
+  float fo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int64_t row = -1;
+  if (slot >= 0 && !created) {
+    row = v.slot_rows[slot];
+    if (row >= 0 && row < v.row_capacity) {
+      w_old = v.weights[row];
+      const f32x4 a = *(const f32x4*)&v.features[row * 8], b = *(const f32x4*)&v.features[row * 8 + 4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fo[f] = a[f];
+        fo[4 + f] = b[f];
+      }
+    } else {
+      row = -1;
+    }
+  }
   __shared__ uint32_t wave_new[4];
-  const int created = (i < n) ? is_new[i] : 0;
+  __shared__ uint32_t s_first;
   const unsigned long long bal = __ballot(created);
   const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (ln == 0) wave_new[wv] = (uint32_t)__popcll(bal);
   __syncthreads();
-  uint32_t before = block_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
-  for (int k = 0; k < wv; ++k) before += wave_new[k];
-  if (i >= n) return;
-  const int32_t slot = slot_of[i];
-  if (slot < 0) return;
-  const int32_t r = created ? (int32_t)before + 1 : 0;
-  int64_t row;
-  float w_old = 0.f;
-  float fo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (r > 0) {
-    row = (int64_t)*first_row + (r - 1);
+  if (threadIdx.x < 64) {
+    const uint32_t total = wave_new[0] + wave_new[1] + wave_new[2] + wave_new[3];
+    const uint32_t seed = blockIdx.x == 0 ? (uint32_t)v.n_rows[0] : 0u;
+    const uint32_t first = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch, seed);
+    if (threadIdx.x == 0) {
+      s_first = first;
+      if ((int64_t)(blockIdx.x + 1) * 256 >= n) v.n_rows[0] = (int32_t)(first + total);   // last tile: commit
+    }
+  }
+  __syncthreads();
+  if (i >= n || slot < 0) return;
+  if (created) {
+    uint32_t before = s_first + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+    for (int k = 0; k < wv; ++k) before += wave_new[k];
+    row = (int64_t)before;
     if (row >= v.row_capacity) {
       *error = 3;
       return;
@@ -264,23 +313,23 @@ __global__ __launch_bounds__(256) void k_vol_assign_integrate(bnv_volume_t v, co
     v.row_coords[row * 3 + 0] = coords[i * 3 + 0];
     v.row_coords[row * 3 + 1] = coords[i * 3 + 1];
     v.row_coords[row * 3 + 2] = coords[i * 3 + 2];
+    brick_set(v, coords[i * 3 + 0], coords[i * 3 + 1], coords[i * 3 + 2], (int32_t)row);
     v.num_hits[row] = 0.f;   // a fresh row reads as zeros (SparseVolume.query of an absent key, :677-679)
-  } else {
-    row = v.slot_rows[slot];
-    if (row < 0 || row >= v.row_capacity) return;
-    w_old = v.weights[row];
-#pragma unroll
-    for (int f = 0; f < 8; ++f) fo[f] = v.features[row * 8 + f];
+  } else if (row < 0) {
+    return;
   }
   // fine_weights = clip(pcounts / 32, max=1)   (:660; int64 / 32 -> float32 true division)
   const float w = fminf(__fdiv_rn((float)pcounts[i], 32.0f), 1.0f);
   const float w_new = __fadd_rn(w_old, w);  // updated_weights = old + new (:649)
+  f32x4 o[2];
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
     const float fn = feats[i * 8 + f];
     // (old_feats * old_weights + new_feats * new_weights) / updated_weights (:650)
-    v.features[row * 8 + f] = __fdiv_rn(__fadd_rn(__fmul_rn(fo[f], w_old), __fmul_rn(fn, w)), w_new);
+    o[f >> 2][f & 3] = __fdiv_rn(__fadd_rn(__fmul_rn(fo[f], w_old), __fmul_rn(fn, w)), w_new);
   }
+  *(f32x4*)&v.features[row * 8] = o[0];
+  *(f32x4*)&v.features[row * 8 + 4] = o[1];
   v.weights[row] = w_new;
 }
 
@@ -408,6 +457,7 @@ __global__ __launch_bounds__(256) void k_vol_batch_apply(bnv_volume_t v, VolBatc
     v.row_coords[row * 3 + 0] = c[0];
     v.row_coords[row * 3 + 1] = c[1];
     v.row_coords[row * 3 + 2] = c[2];
+    brick_set(v, c[0], c[1], c[2], (int32_t)row);
     v.num_hits[row] = 0.f;
   } else {
     row = v.slot_rows[slot];
@@ -505,7 +555,8 @@ __global__ __launch_bounds__(256) void k_vol_rehash(bnv_volume_t v, int32_t* __r
 static bool vol_ok(const bnv_volume_t* v) {
   return v && v->slot_keys && v->slot_rows && v->row_coords && v->features && v->weights && v->num_hits &&
          v->n_rows && v->n_slots > 0 && (v->n_slots & (v->n_slots - 1)) == 0 && v->n_slots <= (1LL << 31) &&
-         v->row_capacity > 0 && v->n_feats == 8;
+         v->row_capacity > 0 && v->n_feats == 8 &&
+         (!v->brick || (v->brick_dims[0] > 0 && v->brick_dims[1] > 0 && v->brick_dims[2] > 0));
 }
 
 static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const int32_t* n_dev,
@@ -538,6 +589,10 @@ size_t bnv_volume_workspace_bytes(int64_t max_keys) { return vol_ws_layout(max_k
 
 int bnv_volume_clear(const bnv_volume_t* vol, bnv_stream_t stream) {
   if (!vol_ok(vol)) return BNV_ERR_INVALID_ARGUMENT;
+  if (vol->brick) {
+    const size_t nvox = (size_t)vol->brick_dims[0] * vol->brick_dims[1] * vol->brick_dims[2];
+    BNV_HIP_CHECK(hipMemsetAsync(vol->brick, 0xff, nvox * 4, (hipStream_t)stream));   // every word -1
+  }
   hipLaunchKernelGGL(k_vol_clear, dim3((unsigned)((vol->n_slots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      vol->slot_keys, vol->slot_rows, vol->n_slots, vol->n_rows);
   BNV_LAUNCH_CHECK();
@@ -566,14 +621,8 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned nb256 = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, *vol, coords, n, n_dev, ws.slot_of,
-                     ws.is_new, ws.error, ws.block_new);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(256), 0, stream, ws.block_new, (int)nb256, vol->n_rows,
-                     ws.total_new);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_assign_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
-                     ws.slot_of, ws.is_new, ws.block_new, ws.total_new, ws.error);
+  hipLaunchKernelGGL(k_vol_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+                     ws.tile_state, next_epoch(), ws.error);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

@@ -109,6 +109,10 @@ class SparseVolume:
         self._features = torch.zeros((cap, 8), dtype=torch.float32, device=d)
         self._weights = torch.zeros(cap, dtype=torch.float32, device=d)
         self._num_hits = torch.zeros(cap, dtype=torch.float32, device=d)
+        # dense row index of the grid (include/bnv_fusion.h: bnv_volume_t.brick): 4 B per voxel of the grid -- 64 MB
+        # at 256^3, 512 MB at 512^3 -- filled with -1 by bnv_volume_clear below; kept for grids up to 2^30 voxels
+        nvox = self._n_xyz_host[0] * self._n_xyz_host[1] * self._n_xyz_host[2]
+        self._brick = torch.empty(nvox, dtype=torch.int32, device=d) if nvox <= (1 << 30) else None
         self._status = torch.zeros(2, dtype=torch.int32, device=d)   # {rows in use, sticky upsert error}
         self._n_rows = self._status[:1]
         self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
@@ -136,6 +140,9 @@ class SparseVolume:
         v.row_capacity = self._row_capacity
         v.n_rows = self._n_rows.data_ptr()
         v.n_feats = 8
+        v.brick = self._brick.data_ptr() if self._brick is not None else None
+        for a in range(3):
+            v.brick_dims[a] = self._n_xyz_host[a]
         return v
 
     def num_rows(self):

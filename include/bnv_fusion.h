@@ -79,6 +79,12 @@ typedef struct bnv_volume {
                             full, 2 voxel coordinate outside the 21-bit key range, 3 row capacity exceeded};
                             bnv_volume_clear zeroes both                      */
   int32_t n_feats;       /* 8                                                 */
+  /* Optional dense index of the volume's grid ("brick"): brick[(x * dims[1] + y) * dims[2] + z] = row of voxel
+   * (x, y, z), or -1.  Maintained by every kernel that creates rows, for keys inside [0, dims); read by the decode
+   * kernels in place of 27 hash probes per voxel (neighbouring voxels are neighbouring words: one cache line serves
+   * a whole z-run, where every hash probe pulls a line of its own).  NULL: not kept (the hash is always complete). */
+  int32_t* brick;
+  int32_t brick_dims[3];
 } bnv_volume_t;
 
 /* ------------------------------------------------------------------------------------------ */

@@ -739,7 +739,7 @@ def test_other_baseline_grids(bnv, orc, sd, grid):
     keep = cnt >= 8
     assert torch.equal(ids.cpu(), u[keep]) and torch.equal(c.cpu()[:, 0], cnt[keep])
     # a sample of the frame's voxels with their whole neighbourhoods: the oracle encodes just the points that
-    # reach those voxels (the per-voxel mean only depends on a voxel's own pairs), fuses them 12 times like the GPU
+    # reach those voxels (the per-voxel mean only depends on a voxel's own pairs), fuses them 16 times like the GPU
     # fuses the frame, and decodes
     sel = torch.arange(len(g))[:: max(1, len(g) // 1536)][:1536]
     pick = g.cpu()[sel]
@@ -755,7 +755,7 @@ def test_other_baseline_grids(bnv, orc, sd, grid):
     with torch.no_grad():
         fo, co, ido, go, _ = orc.encode_pointcloud(sd, sub, ovol.n_xyz, ovol.min_coords, ovol.max_coords, voxel)
     in_nbr = torch.isin(ido, nbr_flat)
-    for _ in range(12):
+    for _ in range(16):
         model._integrate(nm.volume, g, f, c)
         orc.integrate(ovol, go[in_nbr], fo[in_nbr], co[in_nbr])
     # fused volume values of the neighbourhood rows
@@ -767,7 +767,7 @@ def test_other_baseline_grids(bnv, orc, sd, grid):
     sdf = nm.volume.decode_lattice(pick.to(DEV), model.nerf, query_tensor=False).cpu()
     assert torch.equal(sdf == voxel, ref == voxel)                       # mask decisions
     assert (sdf - ref).abs().max() <= SDF_TOL
-    assert float((ref != voxel).float().mean()) > 0.2
+    assert float((ref != voxel).float().mean()) > 0.15
 
 
 def test_non_cubic_volume_and_save_load(bnv, orc, sd, tmp_path):
@@ -1077,8 +1077,7 @@ def test_depth_front_end_points_vs_reference_golden(bnv):
                              max_depth=float(z["max_depth"]))[0].cpu().numpy()
     ref = z["pts_w"].astype(np.float32)
     assert pts.shape == (int(z["n_valid"]), 6)
-    same = (pts[:, :3] == ref).all(1).mean()
-    assert same > 0.999 and np.abs(pts[:, :3] - ref).max() <= 2e-7        # float64 kernel, <= 1 ulp after the cast
+    assert np.array_equal(pts[:, :3], ref)            # float64 kernel in the reference's operation order: bit-exact
 
 
 def test_run_e2e_example_on_a_written_sequence(tmp_path, monkeypatch, capsys):
