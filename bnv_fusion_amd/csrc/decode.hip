@@ -1534,7 +1534,6 @@ struct LatticeWs {
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
   int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
-  uint64_t* tile_state;  // [ceil(27 n / 1024) + 1] look-back state of k_lattice_mark (epoch-tagged, never cleared)
   int64_t list_capacity;
   int64_t entry_capacity;
 };
@@ -1560,9 +1559,7 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   int64_t ecap = 27 * cap;
   if (ecap > 216 * n) ecap = 216 * n;
   char* en = take(ecap * 4);
-  char* ts = take(((27 * n + 1023) / 1024 + 1) * 8);
   if (ws) {
-    ws->tile_state = (uint64_t*)ts;
     ws->need_mask = (uint32_t*)nm;
     ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
@@ -1614,92 +1611,118 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
 // One thread per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is
 // LIVE), flags the 8 (row, l) table entries it reads; the first thread to flag an entry appends it to
 // the MLP work list.  Entries of masked points are never evaluated.
+// A workgroup walks kMarkChunks chunks of 1,024 lattice points and collects the new entries in LDS; they go to the
+// global list with ONE atomicAdd on the list counter per flush -- normally one per workgroup.  (Same-address
+// atomics serialise in the memory-side atomic unit at ~11 ns each, tools/probe_mark.hip: one per 1,024 points was
+// 29 us of serial time per frame; a decoupled look-back in its place was slower still, 57-78 us, because every
+// workgroup then ends with two or three dependent memory round trips.)
 constexpr int kMarkThreads = 1024;
+constexpr int kMarkChunks = 4;
+constexpr int kMarkOrigins = kMarkThreads / 27 + 2;   // origins a chunk's lattice points can belong to
+constexpr int kMarkBuf = 16384;                       // LDS entry buffer; a chunk appends at most 8 * 1024
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
                                                                int64_t entry_capacity,
-                                                               const int32_t* __restrict__ n_dev,
-                                                               uint64_t* __restrict__ tile_state, uint32_t lb_epoch) {
+                                                               const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
-  if ((int64_t)blockIdx.x * kMarkThreads >= n * 27) return;
-  // new entries are collected per block in LDS; the block's place in the list comes from a decoupled look-back over
-  // the blocks (entries in block order: the list is the same from run to run).  One atomicAdd per block on a single
-  // counter serialised at ~11 ns each in the memory-side atomic unit: 2,600 of them were most of this kernel's time.
-  __shared__ int s_buf[kMarkThreads * 8];
+  if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
+  __shared__ int s_buf[kMarkBuf];
+  __shared__ int s_nbr[kMarkOrigins * 27];
   __shared__ int s_count, s_base;
   if (threadIdx.x == 0) s_count = 0;
-  __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * kMarkThreads + threadIdx.x;
-  if (t < n * 27) {
-    const int64_t b = t / 27;
-    const int p = (int)(t - b * 27);
-    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
-    int rowk[8], lk[8];
-    bool live = true;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      int nbi = 0, li = 0;
-      bool dup = false;  // ceil == floor on an axis with d == 0: same entry as the floor corner
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        int nb_a = 0, loc2 = 0;
-        if (d[a] != 0) {
-          if ((k >> a) & 1) {
-            nb_a = (d[a] + 1) / 2;
-            loc2 = -1;
-          } else {
-            nb_a = (d[a] - 1) / 2;
-            loc2 = 1;
-          }
-        } else if ((k >> a) & 1) {
-          dup = true;
-        }
-        nbi = nbi * 3 + (nb_a + 1);
-        li = li * 3 + (loc2 + 1);
-      }
-      const int row = nbr_rows[b * 27 + nbi];
-      if (row < 0) live = false;
-      rowk[k] = dup ? -1 : row;
-      lk[k] = li;
+  for (int ch = 0; ch < kMarkChunks; ++ch) {
+    const int64_t t0 = ((int64_t)blockIdx.x * kMarkChunks + ch) * kMarkThreads;
+    const bool last = ch == kMarkChunks - 1 || t0 + kMarkThreads >= n * 27;
+    // the neighbour rows of the chunk's origins: one coalesced read, then 8 LDS reads per lattice point
+    const int64_t b0 = t0 / 27;
+    for (int i = threadIdx.x; i < kMarkOrigins * 27; i += kMarkThreads) {
+      const int64_t g = b0 * 27 + i;
+      s_nbr[i] = g < n * 27 ? nbr_rows[g] : -1;
     }
-    // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
-    // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
-    // An entry (corner row, local offset) belongs to exactly ONE lattice point, so a point that is handled once
-    // needs no de-duplication: this voxel is the owner (all offsets >= 0, floor(point) == voxel) -> plain append.
-    // Only a point whose owner voxel is NOT decoded in this call can be reached from several voxels; those few go
-    // through the need_mask atomics.
-    bool shared = false;
-    if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
-      const int owner = nbr_rows[b * 27 + ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
-      if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
-      shared = true;
-    }
-    if (live) {
+    __syncthreads();
+    const int64_t t = t0 + threadIdx.x;
+    if (t < n * 27) {
+      const int64_t b = t / 27;
+      const int p = (int)(t - b * 27);
+      const int* nb27 = s_nbr + (int)(b - b0) * 27;
+      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+      int rowk[8], lk[8];
+      bool live = true;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        if (rowk[k] < 0) continue;
-        const uint32_t bit = 1u << lk[k];
-        if (shared && (atomicOr(&need_mask[rowk[k]], bit) & bit)) continue;
-        s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];
+        int nbi = 0, li = 0;
+        bool dup = false;  // ceil == floor on an axis with d == 0: same entry as the floor corner
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          int nb_a = 0, loc2 = 0;
+          if (d[a] != 0) {
+            if ((k >> a) & 1) {
+              nb_a = (d[a] + 1) / 2;
+              loc2 = -1;
+            } else {
+              nb_a = (d[a] - 1) / 2;
+              loc2 = 1;
+            }
+          } else if ((k >> a) & 1) {
+            dup = true;
+          }
+          nbi = nbi * 3 + (nb_a + 1);
+          li = li * 3 + (loc2 + 1);
+        }
+        const int row = nb27[nbi];
+        if (row < 0) live = false;
+        rowk[k] = dup ? -1 : row;
+        lk[k] = li;
+      }
+      // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
+      // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
+      // An entry (corner row, local offset) belongs to exactly ONE lattice point, so a point that is handled once
+      // needs no de-duplication: this voxel is the owner (all offsets >= 0, floor(point) == voxel) -> plain append.
+      // Only a point whose owner voxel is NOT decoded in this call can be reached from several voxels; those few go
+      // through the need_mask atomics.
+      bool shared = false;
+      if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
+        const int owner = nb27[((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
+        if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
+        shared = true;
+      }
+      // append, wave-aggregated: one LDS atomic per wave and corner (64 lanes adding 1 to the same LDS word
+      // serialise 64-fold: that was this kernel's time)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        bool add = live && rowk[k] >= 0;
+        if (add && shared) {
+          const uint32_t bit = 1u << lk[k];
+          add = !(atomicOr(&need_mask[rowk[k]], bit) & bit);
+        }
+        const unsigned long long m = __ballot(add);
+        if (m) {
+          const int lane = threadIdx.x & 63;
+          int base = 0;
+          if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&s_count, (int)__popcll(m));
+          base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
+          if (add) s_buf[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (rowk[k] << 5) | lk[k];
+        }
       }
     }
-  }
-  __syncthreads();
-  const int cnt = s_count;
-  if (threadIdx.x < 64) {
-    const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, (uint32_t)cnt, lb_epoch);
-    if (threadIdx.x == 0) {
-      s_base = (int)excl;
-      if ((int64_t)(blockIdx.x + 1) * kMarkThreads >= n * 27) *n_entries = (int32_t)(excl + (uint32_t)cnt);  // last block
+    __syncthreads();
+    const int cnt = s_count;
+    if (cnt > 0 && (last || cnt > kMarkBuf - 8 * kMarkThreads)) {   // flush (block-uniform)
+      if (threadIdx.x == 0) {
+        s_base = atomicAdd(n_entries, cnt);
+        s_count = 0;
+      }
+      __syncthreads();
+      const int base = s_base;
+      for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
+        if (base + i < entry_capacity) entries[base + i] = s_buf[i];
+      __syncthreads();
     }
+    if (last) break;
   }
-  __syncthreads();
-  const int base = s_base;
-  for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
-    if (base + i < entry_capacity) entries[base + i] = s_buf[i];
 }
 
 // DELTA = false: the streaming case (no TSDF prior): 8 table reads and a weighted sum, few registers -- it runs
@@ -1710,10 +1733,20 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
                                                        float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
+  if ((int64_t)blockIdx.x * 256 >= n * 27) return;
+  // the neighbour rows of the block's origins: one coalesced read, then 8 LDS reads per lattice point
+  __shared__ int s_nbr[(256 / 27 + 2) * 27];
+  const int64_t b0 = ((int64_t)blockIdx.x * 256) / 27;
+  for (int i = threadIdx.x; i < (256 / 27 + 2) * 27; i += 256) {
+    const int64_t gidx = b0 * 27 + i;
+    s_nbr[i] = gidx < n * 27 ? nbr_rows[gidx] : -1;
+  }
+  __syncthreads();
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
   const int p = (int)(t - b * 27);
+  const int* nb27 = s_nbr + (int)(b - b0) * 27;
   const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};  // lattice point = origin + 0.5 * d
   if constexpr (!DELTA) {
     // Every corner has the same weight 0.5^m (m = axes with a half-voxel offset) and the reference's normaliser, the
@@ -1723,7 +1756,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
     const float wc = m == 0 ? 1.f : (m == 1 ? 0.5f : (m == 2 ? 0.25f : 0.125f));
     const float w = __fdiv_rn(wc, 8.f * wc);
     bool ok = true;
-    float acc = 0.f;
+    int rowk[8], lk[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int cb = kCornerCeilBits[k];
@@ -1743,12 +1776,18 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
         nbi = nbi * 3 + (nb_a + 1);
         li = li * 3 + (loc2 + 1);
       }
-      const int row = nbr_rows[b * 27 + nbi];
-      if (row < 0) ok = false;
-      const float a = row >= 0 ? table[(size_t)row * 27 + li] : 0.f;
-      acc = __fadd_rn(acc, __fmul_rn(a, w));
+      rowk[k] = nb27[nbi];
+      lk[k] = li;
+      if (rowk[k] < 0) ok = false;
     }
-    out[t] = ok ? acc : g.voxel_size;
+    if (!ok) {   // masked point (about half of them on a thin sheet): the constant, no table reads
+      out[t] = g.voxel_size;
+      return;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = __fadd_rn(acc, __fmul_rn(table[(size_t)rowk[k] * 27 + lk[k]], w));
+    out[t] = acc;
     return;
   }
   float wk[8];
@@ -1779,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
     }
     wk[k] = w;
     lk[k] = li;
-    rowk[k] = nbr_rows[b * 27 + nbi];
+    rowk[k] = nb27[nbi];
     norm = __fadd_rn(norm, w);
   }
   bool ok = true;
@@ -2051,9 +2090,9 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads - 1) / kMarkThreads)),
+  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, ws.tile_state, next_epoch());
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

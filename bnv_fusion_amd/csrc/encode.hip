@@ -104,8 +104,7 @@ struct EncodeWs {
 };
 
 constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 slots per workgroup (k_finalize)
+constexpr int kFinTile = kScanThreads;                 // 256 slots per workgroup (k_finalize: one per thread)
 constexpr int kRankItems = 4;
 constexpr int kRankTile = kScanThreads * kRankItems;  // 1024 bitmap words per workgroup (k_rank)
 
@@ -118,7 +117,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   if (max_unique > nvox) max_unique = nvox;
   if (max_unique < 1) max_unique = 1;
   const int64_t nb_words = (n_words + kRankTile - 1) / kRankTile;
-  const int64_t nb_unique = (max_unique + kScanTile - 1) / kScanTile;
+  const int64_t nb_unique = (max_unique + kFinTile - 1) / kFinTile;
   const int64_t n_tiles = nb_words > nb_unique ? nb_words : nb_unique;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -940,19 +939,28 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     if (blockIdx.x == 0 && threadIdx.x < 64) ctl->shard_boundary[threadIdx.x] = 0;
     return;
   }
-  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-  if ((int64_t)blockIdx.x * kScanTile >= n) return;
+  // ONE slot per thread: consecutive threads read consecutive 64-byte accumulator rows (with 8 slots per thread
+  // every thread walked its own 512-byte stretch and the kernel was latency-bound at 34 us for 25 MB)
+  const int64_t sl = (int64_t)blockIdx.x * kFinTile + threadIdx.x;
+  if ((int64_t)blockIdx.x * kFinTile >= n) return;
   ValidFlags flags{counts, ids, g, emit_all};
-  uint32_t fl[kScanItems];
-  uint32_t s = 0;
+  const uint32_t fl = sl < n ? flags(sl) : 0u;
+  int id = 0, c = 0;
+  long long a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (sl < n) {
+    id = ids[sl];
+    c = counts[sl];
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int e = 0; e < kScanItems; ++e) {
-    fl[e] = (base + e < n) ? flags(base + e) : 0u;
-    s += fl[e];
+    for (int q = 0; q < 4; ++q) {
+      const i64x2 v = *(const i64x2*)&acc[sl * 8 + 2 * q];
+      a8[2 * q] = v[0];
+      a8[2 * q + 1] = v[1];
+    }
   }
   uint32_t total;
-  uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
-  const bool last_tile = (int64_t)(blockIdx.x + 1) * kScanTile >= n;
+  uint32_t run = block_exclusive_scan<kScanThreads>(fl, wave_tot, &total);
+  const bool last_tile = (int64_t)(blockIdx.x + 1) * kFinTile >= n;
   if (threadIdx.x < 64) {
     const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch);
     if (threadIdx.x == 0) s_excl = excl;
@@ -980,39 +988,37 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     }
   }
   __syncthreads();
+  if (sl >= n) return;
   run += s_excl;
-  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  if (fl && (int64_t)run < out_capacity) {
+    const bool keep = c >= g.min_pts_in_grid;  // emit_all: features zeroed below min_pts (:126)
+    const float inv_scale = 1.0f / kFixedScale;
+    f32x4 o[2];
 #pragma unroll
-  for (int e = 0; e < kScanItems; ++e) {
-    const int64_t sl = base + e;
-    if (sl >= n) break;
-    const int id = ids[sl];
-    const int c = counts[sl];
-    if (fl[e]) {
-      if ((int64_t)run < out_capacity) {
-        const bool keep = c >= g.min_pts_in_grid;  // emit_all: features zeroed below min_pts (:126)
-        const float inv_scale = 1.0f / kFixedScale;
-#pragma unroll
-        for (int f = 0; f < 8; ++f) {
-          // mean = sum / max(count, 1) (torch_scatter.scatter_mean); the fixed-point sum is exact
-          const double sum = (double)acc[sl * 8 + f] * (double)inv_scale;
-          out_feats[(size_t)run * 8 + f] = keep ? (float)(sum / (double)(c > 1 ? c : 1)) : 0.f;
-        }
-        out_pcounts[run] = c;
-        out_flat[run] = id;
-        const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
-        out_grid[(size_t)run * 3 + 0] = x;
-        out_grid[(size_t)run * 3 + 1] = y;
-        out_grid[(size_t)run * 3 + 2] = z;
-      }
-      ++run;
+    for (int f = 0; f < 8; ++f) {
+      // mean = sum / max(count, 1) (torch_scatter.scatter_mean); the fixed-point sum is exact
+      const double sum = (double)a8[f] * (double)inv_scale;
+      o[f >> 2][f & 3] = keep ? (float)(sum / (double)(c > 1 ? c : 1)) : 0.f;
     }
-    // leave the scratch clean for the next frame
-    counts[sl] = 0;
-#pragma unroll
-    for (int f = 0; f < 8; ++f) acc[sl * 8 + f] = 0;
-    bitmap[id >> 5] = 0u;
+    *(f32x4*)&out_feats[(size_t)run * 8] = o[0];
+    *(f32x4*)&out_feats[(size_t)run * 8 + 4] = o[1];
+    out_pcounts[run] = c;
+    out_flat[run] = id;
+    const int nyz = g.n_xyz[1] * g.n_xyz[2];
+    const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+    out_grid[(size_t)run * 3 + 0] = x;
+    out_grid[(size_t)run * 3 + 1] = y;
+    out_grid[(size_t)run * 3 + 2] = z;
   }
+  // leave the scratch clean for the next frame
+  counts[sl] = 0;
+  {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 z2 = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(i64x2*)&acc[sl * 8 + 2 * q] = z2;
+  }
+  bitmap[id >> 5] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1244,7 +1250,7 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
   BNV_LAUNCH_CHECK();
   // ordered compaction of the emitted voxels; the number of slots is only known on the device, so the grid covers
   // max_unique and workgroups past n_unique exit at once
-  const int nb_u = (int)((ws.max_unique + kScanTile - 1) / kScanTile);
+  const int nb_u = (int)((ws.max_unique + kFinTile - 1) / kFinTile);
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
                      ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, ws.valid_blocks, (n + 255) / 256, out_feats,
                      out_pcounts, out_flat_ids, out_grid_ids, out_capacity, counters);

@@ -1,22 +1,29 @@
-"""Multi-GPU local fusion + decode: the active-voxel set sharded by spatial hash, one process per
-GPU, RCCL over xGMI (SURVEY.md section 8e -- new design; the reference is single-GPU).
+"""Multi-GPU local fusion + decode, one process per GPU, RCCL over xGMI (SURVEY.md section 8e -- new design; the
+reference is single-GPU).  Two decompositions, both producing exactly the single-GPU outputs:
 
-Ownership   owner(voxel) = mix64(block coordinate) % world, blocks of 8^3 voxels (same function in
-            csrc/bnv_common.hpp: voxel_owner).  A (point, corner) pair contributes to exactly one
-            voxel, so every rank voxelises the whole frame (cheap, replicated) but runs the point
-            encoder only on pairs whose voxel it owns: per-voxel sums are complete locally, NO
-            reduction collective, results identical to one GPU.
-Exchange    decode of a touched voxel reads the 27-entry SDF tables and weights of its 3x3x3
-            neighbour voxels, some owned elsewhere.  Per frame: (1) all-gather of the touched voxel
-            coordinates (each rank contributes the ones it owns), (2) every rank evaluates the SDF
-            MLP for the rows IT owns among the neighbours of all touched voxels, (3) one all-gather
-            of those records (coords 24 B + weight 4 B + table 108 B), installed on every rank as
-            halo rows, (4) each rank blends the lattice of the touched voxels it owns.  Outputs
-            stay sharded.  Both all-gathers are variable-size (sizes first, then padded payload).
+SPATIAL SHARDING (the north-star decomposition; ``ShardedNeuralMap``)
+  Ownership   owner(voxel) = mix64(block coordinate) % world, blocks of 8^3 voxels (same function in
+              csrc/bnv_common.hpp: voxel_owner).  A (point, corner) pair contributes to exactly one voxel, so every
+              rank voxelises the whole frame (cheap, replicated) but runs the point encoder only on pairs whose voxel
+              it owns and upserts only its own voxels: per-voxel sums are complete locally, NO reduction collective.
+  Exchange    the decode of a voxel reads the rows of its 3x3x3 neighbourhood, some owned elsewhere: GHOST rows.
+              A row changes only when a frame's encode emits its voxel, so per frame every rank sends the rows it has
+              just updated that are BOUNDARY voxels (a voxel of their 3x3x3 neighbourhood has another owner: a function
+              of the coordinates alone) -- 48-byte records {key, weight, 8 features} -- in ONE all-gather; every rank
+              installs the records adjacent to voxels it owns.  Then its local volume (own + ghost rows) decodes the
+              voxels it owns exactly as the single-GPU volume would.  Outputs stay sharded.
+  Sizes       the all-gather is padded to the largest block.  Its size comes from a bound every rank computes for
+              ALL ranks without talking to anybody: the voxelisation is replicated, so the number of touched boundary
+              voxels each rank owns is known on every GPU right after the frame's voxels are ranked, BEFORE the
+              encoder runs (bnv_encode_begin).  The host reads those few integers while the encoder runs: the one
+              host wait of a frame.  The real record counts travel in the blocks' headers and stay on the device.
+  Bytes       per frame and rank ~0.58 x U'/world records of 48 B at 8^3 blocks (U' ~ 1e5 emitted voxels at
+              640x480): ~2.8 MB gathered per frame in total, ~0.35 MB sent per rank at world 8.
 
-The frame logic lives in ``ShardedNeuralMap`` and talks to a backend; ``HipShardBackend`` is the
-product backend (HIP kernels).  The phases are exposed separately so that tests can drive several
-shards in one process.
+FRAME-PARALLEL (throughput of one frame stream; ``FrameParallelNeuralMap``, below)
+
+The frame logic talks to a backend; ``HipShardBackend`` / ``HipFrameBackend`` are the product backends (HIP kernels).
+tests/test_distributed_cpu.py drives the same logic over gloo with oracle-backed backends.
 """
 import ctypes as C
 
@@ -26,6 +33,8 @@ import torch
 from . import _lib
 
 BLOCK_LOG2 = 3
+REC_WORDS = 12          # BNV_SHARD_RECORD_BYTES / 4: {x, y, z, weight bits, 8 feature bits}
+REC_QUANTUM = 512       # the per-rank block capacity is rounded up to this many records
 
 
 def mix64(k):
@@ -49,8 +58,32 @@ def voxel_owner(coords, world, block_log2=BLOCK_LOG2):
     return (mix64(key) % np.uint64(world)).astype(np.int64)
 
 
+_OFF27 = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)], dtype=np.int64)
+
+
+def shard_is_boundary(coords, world, block_log2=BLOCK_LOG2):
+    """Host restatement of csrc/bnv_common.hpp shard_is_boundary: does a voxel of the 3x3x3 neighbourhood belong to
+    another rank?  coords [n, 3] -> bool [n]."""
+    c = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
+    me = voxel_owner(c, world, block_log2)
+    out = np.zeros(len(c), dtype=bool)
+    for d in _OFF27:
+        out |= voxel_owner(c + d, world, block_log2) != me
+    return out
+
+
+def shard_adjacent_to(coords, world, rank, block_log2=BLOCK_LOG2):
+    """Host restatement of shard_adjacent_to: does ``rank`` own a voxel of the 3x3x3 neighbourhood (itself included)?"""
+    c = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
+    out = np.zeros(len(c), dtype=bool)
+    for d in _OFF27:
+        out |= voxel_owner(c + d, world, block_log2) == rank
+    return out
+
+
 def all_gather_var(t, group=None):
-    """All-gather of tensors whose first dimension differs per rank -> concatenation in rank order."""
+    """All-gather of tensors whose first dimension differs per rank -> concatenation in rank order (host-synchronous;
+    used by tests and tools to collect sharded OUTPUTS, not on the per-frame path)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
@@ -65,145 +98,187 @@ def all_gather_var(t, group=None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
 
 
+class ShardFrame:
+    """One frame on its way through a shard backend (everything a later phase needs)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
 class HipShardBackend:
-    """One shard of the volume on one GPU, HIP kernels."""
+    """One shard of the volume on one GPU, HIP kernels.  Nothing here waits for the GPU except ``bound`` (the
+    frame's one host wait) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0"):
-        from .sparse_volume import SparseVolume
+                 device="cuda:0", tsdf=False, max_depth=3.0):
+        from .sparse_volume import SparseVolume, make_grid
         self.pointnet = pointnet
         self.rank, self.world = rank, world
         pointnet.shard = (rank, world, BLOCK_LOG2)
         self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
-        self.dev = self.volume._dev
-        self._ghost = torch.zeros(self.volume._row_capacity, dtype=torch.uint8, device=self.dev)
-        self._epoch = 0
-
-    # ---- helpers --------------------------------------------------------------------------------
-    def _ws(self, n):
         v = self.volume
-        need = int(v._lib.bnv_decode_lattice_workspace_bytes(max(int(n), 1), v._row_capacity))
-        if v._lattice_ws is None or v._lattice_ws.numel() < need:
-            v._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self.dev)
-            self._epoch = 0
-        if self._ghost.numel() < v._row_capacity:
-            g = torch.zeros(v._row_capacity, dtype=torch.uint8, device=self.dev)
-            g[: self._ghost.numel()] = self._ghost
-            self._ghost = g
-        return v._lattice_ws
-
-    def _table(self):
-        v = self.volume
-        off = int(v._lib.bnv_decode_lattice_table_offset(v._row_capacity))
-        return v._lattice_ws[off: off + v._row_capacity * 27 * 4].view(torch.float32).view(v._row_capacity, 27)
-
-    def rows_of(self, keys):
-        v = self.volume
-        k = keys.reshape(-1, 3).long().contiguous()
-        rows = torch.empty(k.shape[0], dtype=torch.int32, device=self.dev)
-        _lib.check(v._lib.bnv_volume_query(C.byref(v._struct()), _lib.ptr(k), int(k.shape[0]), _lib.ptr(v._features),
-                                           _lib.ptr(v._weights), _lib.ptr(v._num_hits), v._row_capacity, None, None,
-                                           None, _lib.ptr(rows), _lib.stream_ptr()), "bnv_volume_query")
-        return rows.long()
+        v.shard = (rank, world, BLOCK_LOG2)
+        v._grid = make_grid(v._n_xyz_host, v.min_coords, v.max_coords, voxel_size, min_pts_in_grid, v.shard)
+        self.dev = v._dev
+        self.max_depth = max_depth
+        self.sdf_delta = None
+        self.tsdf_vol = None
+        if tsdf:            # the TSDF side volume (0.025 m, dense) is small: every rank keeps the whole of it
+            from .sparse_volume import get_world_range
+            from .tsdf import TSDFVolume
+            mn, mx, _ = get_world_range(dimensions, 0.025)
+            self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
+        self._lib = v._lib
 
     # ---- phases ---------------------------------------------------------------------------------
-    def encode_integrate(self, frame):
+    def encode(self, frame):
+        """Voxelise the whole frame, encode + upsert the voxels this rank owns; the per-rank bounds of the
+        exchange are copied to pinned memory between the two halves of the encode (before the encoder MLP)."""
         v = self.volume
         self.pointnet.shard = (self.rank, self.world, BLOCK_LOG2)
-        from .neural_map import frame_input_pts
-        f, c, _, coords, n_avg = self.pointnet.encode_pointcloud(
-            frame_input_pts(frame), v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, return_dense=False)
-        if f is None:
-            return torch.zeros((0, 3), dtype=torch.int64, device=self.dev)
-        v.track_n_pts(n_avg)
-        v.integrate(coords, f, c)
-        return coords
+        bound_host = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
+        ev = torch.cuda.Event()
 
-    def tables_for(self, touched):
-        """Records (coords [m,3] i64, weights [m], table [m,27]) of the rows this shard owns among the
-        neighbours of ``touched`` (the global touched set)."""
-        v = self.volume
-        n = int(touched.shape[0])
-        ws = self._ws(n)
-        self._epoch += 1
-        t = touched.reshape(-1, 3).long().contiguous()
-        _lib.check(v._lib.bnv_lattice_neighbors(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._weights),
-                                                v._row_capacity, _lib.ptr(t), n, None, _lib.ptr(self._ghost), 1,
-                                                _lib.ptr(ws), ws.numel(), self._epoch, _lib.stream_ptr()),
-                   "bnv_lattice_neighbors")
-        _lib.check(v._lib.bnv_lattice_table(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._features),
-                                            _lib.ptr(self.pointnet.nerf.sdf_pack), n, 0, _lib.ptr(ws), ws.numel(),
-                                            _lib.stream_ptr()), "bnv_lattice_table")
-        m = int(v.last_lattice_table_rows().item())
-        off = int(v._lib.bnv_decode_lattice_list_offset(max(n, 1), v._row_capacity))
-        rows = ws[off: off + 4 * m].view(torch.int32).long()
-        return v._row_coords[rows], v._weights[rows], self._table()[rows]
+        def between():
+            bound_host.copy_(self.pointnet.shard_boundary_counts(), non_blocking=True)
+            ev.record()
 
-    def install_and_blend(self, owned_touched, rec_coords, rec_weights, rec_tables):
-        """Installs all exchanged records (halo rows for foreign ones) and blends the lattice of the
-        touched voxels this shard owns -> [n, 27]."""
+        if "input_pts" in frame:
+            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
+                frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, between=between)
+        else:
+            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_depth_async(
+                frame["depth"], frame["intr_mat"], frame["T_wc"], self.max_depth, v.n_xyz, v.min_coords,
+                v.max_coords, v.voxel_size, between=between)[:6]
+        n_dev = counters[2:3]
+        v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
+        if self.tsdf_vol is not None and "depth" in frame:
+            self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.,
+                                    max_depth=self.max_depth, gate=counters[0:1])
+        return ShardFrame(grid_ids=grid_ids, counters=counters, n_dev=n_dev, cap=cap, bound_host=bound_host,
+                          bound_event=ev)
+
+    def bound(self, fr):
+        """Largest number of boundary records any rank can send for this frame (the same number on every rank)."""
+        fr.bound_event.synchronize()
+        return int(fr.bound_host.max()) if self.world > 1 else 0
+
+    def pack(self, fr, capacity):
+        """This rank's block: header + ``capacity`` records, int32 words."""
         v = self.volume
-        n = int(owned_touched.shape[0])
-        out = torch.empty((n, 27), dtype=torch.float32, device=self.dev)
-        mine = torch.from_numpy(voxel_owner(rec_coords.cpu().numpy(), self.world) == self.rank).to(self.dev)
-        foreign = ~mine
-        if bool(foreign.any()):
-            fk = rec_coords[foreign]
-            z = torch.zeros((fk.shape[0], 8), dtype=torch.float32, device=self.dev)
-            v.insert(fk, z, rec_weights[foreign], torch.zeros(fk.shape[0], device=self.dev))
-        ws = self._ws(max(n, 1))
-        rows = self.rows_of(rec_coords)
-        self._table()[rows] = rec_tables
-        self._ghost[rows[foreign]] = 1
-        if n == 0:
-            return out
-        self._epoch += 1
-        o = owned_touched.reshape(-1, 3).long().contiguous()
-        _lib.check(v._lib.bnv_lattice_neighbors(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(v._weights),
-                                                v._row_capacity, _lib.ptr(o), n, None, None, 0, _lib.ptr(ws), ws.numel(),
-                                                self._epoch, _lib.stream_ptr()), "bnv_lattice_neighbors")
-        d = _lib.SdfDelta()
-        _lib.check(v._lib.bnv_lattice_blend(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(o), n, None, C.byref(d),
-                                            _lib.ptr(ws), ws.numel(), _lib.ptr(out), _lib.stream_ptr()),
-                   "bnv_lattice_blend")
-        return out
+        block = torch.empty((capacity + 1) * REC_WORDS, dtype=torch.int32, device=self.dev)
+        _lib.check(self._lib.bnv_shard_pack(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(fr.grid_ids), fr.cap,
+                                            _lib.ptr(fr.n_dev), _lib.ptr(block), capacity, _lib.stream_ptr()),
+                   "bnv_shard_pack")
+        return block
+
+    def install(self, blocks, capacity):
+        """blocks: [world, (capacity + 1) * REC_WORDS] int32 -- the all-gather's output."""
+        v = self.volume
+        bound = (self.world - 1) * capacity          # ghost rows this call can create at most
+        v._reserve(bound)
+        _lib.check(self._lib.bnv_shard_install(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(blocks), self.world,
+                                               capacity, _lib.stream_ptr()), "bnv_shard_install")
+        v._rows_upper += bound
+        v._inflight += bound
+        return bound
+
+    def decode(self, fr):
+        v = self.volume
+        return v.decode_lattice(fr.grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False, n_dev=fr.n_dev)
+
+    def finish(self, fr, sdf, reserved):
+        """Read-backs of the frame (async) -> what ``result`` needs."""
+        host = torch.empty(8, dtype=torch.int32, pin_memory=True)
+        host.copy_(fr.counters, non_blocking=True)
+        fr.host, fr.host_rows, fr.sdf, fr.reserved = host, self.volume.status_readback(), sdf, reserved + fr.cap
+        fr.event = torch.cuda.Event()
+        fr.event.record()
+        return fr
+
+    def result(self, fr):
+        """-> (coords [U'_r, 3] of the voxels this rank owns among the frame's, sdf [U'_r, 27]) or (None, None)."""
+        fr.event.synchronize()
+        v = self.volume
+        v.settle(fr.reserved, int(fr.host_rows[0]))
+        v.check_status(fr.host_rows[1])
+        h = fr.host
+        if int(h[4]):
+            raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {int(h[4])})")
+        if int(h[0]) == 0:
+            return None, None
+        v.track_n_pts(float(h[3:4].view(torch.float32)[0]))
+        n_out = int(h[2])
+        return fr.grid_ids[:n_out], None if fr.sdf is None else fr.sdf[:n_out]
 
     def owned_rows_mask(self):
+        """bool [rows]: rows this rank owns (the others are ghost rows)."""
         n = self.volume.num_rows()
-        return self._ghost[:n] == 0
+        c = self.volume._row_coords[:n].cpu().numpy()
+        return torch.from_numpy(voxel_owner(c, self.world) == self.rank).to(self.dev)
+
+    def last_mlp_evals(self):
+        return self.volume.last_lattice_evals()
+
+
+class ShardHandle:
+    def __init__(self, nm, fr):
+        self._nm, self._fr, self._done = nm, fr, None
+
+    def result(self):
+        if self._done is None:
+            self._done = self._nm.backend.result(self._fr)
+            self._fr = None
+        return self._done
 
 
 class ShardedNeuralMap:
-    """Per-frame driver over one shard; every rank calls the same methods with the same frame."""
+    """Per-frame driver over one shard; every rank calls the same methods with the same frame.
+
+    fuse_and_decode_async enqueues: encode (whole frame voxelised, owned voxels encoded) -> upsert -> pack boundary
+    records -> ONE all-gather -> install ghost rows -> lattice decode of the owned voxels.  One host wait (the
+    exchange bound, read while the encoder runs); the outputs are collected through the returned handle."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None, capacity=1 << 20):
+                 group=None, capacity=1 << 20, tsdf=False):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend or HipShardBackend(dimensions, voxel_size, pointnet, self.rank, self.world,
-                                                  min_pts_in_grid, capacity=capacity, device=device)
+                                                  min_pts_in_grid, capacity=capacity, device=device, tsdf=tsdf)
         self.volume = getattr(self.backend, "volume", None)
         self.voxel_size = voxel_size
+        self.exchanged_bytes = 0          # bytes this rank has received in all-gathers (statistics)
+        self.host_waits = 0
+
+    def fuse_and_decode_async(self, frame, decode=True):
+        import torch.distributed as dist
+        be = self.backend
+        with torch.no_grad():
+            fr = be.encode(frame)
+            bound = be.bound(fr)                       # the frame's one host wait (the encoder is running)
+            self.host_waits += 1
+            reserved = 0
+            if bound > 0:
+                capacity = -(-bound // REC_QUANTUM) * REC_QUANTUM
+                send = be.pack(fr, capacity)
+                recv = torch.empty((self.world, send.numel()), dtype=send.dtype, device=send.device)
+                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)      # THE collective of the frame
+                self.exchanged_bytes += recv.numel() * 4
+                reserved = be.install(recv, capacity)
+            sdf = be.decode(fr) if decode else None
+            return ShardHandle(self, be.finish(fr, sdf, reserved))
+
+    def fuse_and_decode(self, frame):
+        return self.fuse_and_decode_async(frame).result()
 
     def integrate(self, frame):
-        with torch.no_grad():
-            return self.backend.encode_integrate(frame)
+        return self.fuse_and_decode_async(frame, decode=False).result()[0]
 
     def last_mlp_evals(self):
         """Device int32 [1]: SDF-MLP evaluations this rank ran for the last frame."""
-        return self.volume.last_lattice_table_rows() * 27
-
-    def fuse_and_decode(self, frame):
-        with torch.no_grad():
-            owned = self.backend.encode_integrate(frame)
-            touched = all_gather_var(owned, self.group)                      # collective 1: coordinates
-            rc, rw, rt = self.backend.tables_for(touched)
-            rec = all_gather_var(torch.cat([rw.reshape(-1, 1), rt], dim=1), self.group)   # collective 2: tables
-            rec_c = all_gather_var(rc, self.group)
-            sdf = self.backend.install_and_blend(owned, rec_c, rec[:, 0].contiguous(), rec[:, 1:].contiguous())
-        return owned, sdf
+        return self.backend.last_mlp_evals()
 
 
 # =============================================================================================

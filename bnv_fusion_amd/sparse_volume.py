@@ -155,7 +155,7 @@ class SparseVolume:
         return n
 
     UPSERT_ERRORS = {1: "hash table full", 2: "voxel coordinate outside the 21-bit key range",
-                     3: "row capacity exceeded"}
+                     3: "row capacity exceeded", 4: "a rank's boundary-record block overflowed (sharded exchange)"}
 
     def check_status(self, err):
         """Raises on the sticky error word of the upsert kernels (device int32 next to the row counter; the

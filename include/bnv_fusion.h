@@ -172,6 +172,23 @@ int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_h
                                  const uint16_t* const* depth_mm, int im_h, int im_w, const float* intr_host,
                                  const float* pose_host, float obs_weight, float max_depth, bnv_stream_t stream);
 
+/* ---- spatially sharded volume: the exchange step (new design; bnv_fusion_amd/distributed.py).
+ * Voxels are owned by hash(block coordinate) % shard_world (bnv_grid_t).  Per frame every rank sends the rows it has
+ * just updated that are BOUNDARY voxels (a voxel of their 3x3x3 neighbourhood belongs to another rank), one
+ * all-gather moves the blocks, every rank installs the records adjacent to voxels it owns as ghost rows.
+ * A block is (1 + capacity) records of BNV_SHARD_RECORD_BYTES: record 0 is the header {int32 count, int32 sender
+ * rank, int32 overflow flag}; a record is {int32 x, y, z; float weight; float feature[8]}.
+ *   bnv_shard_pack     coords [n, 3] i64 = this frame's emitted voxels (n_dev: device count or NULL), values read
+ *                      from the volume AFTER the frame's upsert; capacity >= the bound bnv_encode_begin leaves in the
+ *                      workspace for this rank;
+ *   bnv_shard_install  blocks = world blocks back to back (the all-gather's output); the own block is skipped; a
+ *                      sender's overflow flag sets the volume's sticky error word to 4. */
+#define BNV_SHARD_RECORD_BYTES 48
+int bnv_shard_pack(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* coords, int64_t n,
+                   const int32_t* n_dev, void* block, int64_t capacity, bnv_stream_t stream);
+int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
+                      int64_t capacity, bnv_stream_t stream);
+
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
 /* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points.  The scratch is

@@ -1,7 +1,8 @@
-"""World-size-2 gloo test (CPU) of the sharded frame logic in bnv_fusion_amd/distributed.py:
-ownership partition, the two variable-size all-gathers and the halo assembly.  The compute of each
-shard is done by an oracle-backed backend (test infrastructure); the union of the shards' SDF
-lattices must equal the single-process oracle decode of the same frames."""
+"""World-size-2 gloo tests (CPU) of the multi-GPU frame logic in bnv_fusion_amd/distributed.py: the spatial
+sharding (ownership partition, the exchange bound every rank computes by itself, the ONE padded all-gather of
+boundary records per frame, ghost rows) and the frame-parallel mode.  The compute of each rank is done by an
+oracle-backed backend (test infrastructure); the union of the shards' SDF lattices must equal the single-process
+oracle decode of the same frames."""
 import os
 import socket
 
@@ -12,70 +13,87 @@ import torch.multiprocessing as mp
 
 from conftest import GOLDEN, WEIGHTS_FP32
 
-_OFF27 = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
-_CEIL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1))
 
 
 class OracleShardBackend:
+    """The shard protocol of bnv_fusion_amd.distributed.ShardedNeuralMap on the CPU oracle: same phases, same record
+    layout (12 int32 words: x, y, z, weight bits, 8 feature bits; block = header record + capacity records)."""
+
     def __init__(self, dims, voxel, rank, world):
         from oracle import bnv_oracle as orc
-        from bnv_fusion_amd.distributed import voxel_owner
-        self.orc, self.owner = orc, voxel_owner
+        from bnv_fusion_amd import distributed as D
+        self.orc, self.D = orc, D
         self.sd = orc.load_weights(WEIGHTS_FP32)
         self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
         self.rank, self.world, self.voxel = rank, world, voxel
+        self.installed = 0
 
-    def encode_integrate(self, frame):
-        o, v = self.orc, self.vol
-        f, c, ids, g, n = o.encode_pointcloud(self.sd, frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords,
-                                              v.voxel_size)
-        own = torch.from_numpy(self.owner(g.numpy(), self.world) == self.rank)
+    def encode(self, frame):
+        o, v, D = self.orc, self.vol, self.D
+        pts = frame["input_pts"]
+        f, c, ids, g, n = o.encode_pointcloud(self.sd, pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+        # the bound: touched BOUNDARY voxels per owner over ALL touched voxels (no min-points filter), replicated
+        xyz = pts[0, :, :3]
+        inb = ((xyz < (v.max_coords - v.voxel_size)) & (xyz > (v.min_coords + v.voxel_size))).all(-1)
+        _, gid = o.get_relative_xyz(xyz[inb][None], v.min_coords, v.voxel_size)
+        touched = torch.unique(gid.reshape(-1, 3).long(), dim=0).numpy()
+        bnd = D.shard_is_boundary(touched, self.world)
+        counts = np.bincount(D.voxel_owner(touched[bnd], self.world), minlength=self.world)
+        own = torch.from_numpy(D.voxel_owner(g.numpy(), self.world) == self.rank)
         o.integrate(v, g[own], f[own], c[own])
-        return g[own]
+        return D.ShardFrame(grid_ids=g[own], counts=counts, n_avg=n)
 
-    def tables_for(self, touched):
-        o, v = self.orc, self.vol
-        nb = np.unique((touched.numpy()[:, None, :] + _OFF27[None]).reshape(-1, 3), axis=0)
-        keep = [k for k in map(tuple, nb.tolist()) if k in v._map and float(v._w[v._map[k]]) >= v.min_pts_in_grid]
-        if not keep:
-            return torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0), torch.zeros((0, 27))
-        rows = [v._map[k] for k in keep]
-        feats = torch.stack([v._feats[r] for r in rows])                       # [m, 8]
-        loc = torch.tensor(_OFF27, dtype=torch.float32) * 0.5                  # l index = (lx+1)*9+(ly+1)*3+(lz+1)
-        x = torch.cat([o.xyz_encoding(loc)[None].expand(len(rows), 27, 9), feats[:, None, :].expand(-1, 27, 8)], -1)
-        table = o.geo_forward(self.sd, x)[..., 0] * self.voxel
-        w = torch.stack([v._w[r].reshape(()) for r in rows])
-        return torch.tensor(keep, dtype=torch.int64), w, table
+    def bound(self, fr):
+        return int(fr.counts.max()) if self.world > 1 else 0
 
-    def install_and_blend(self, owned, rec_c, rec_w, rec_t):
-        halo = {tuple(k): i for i, k in enumerate(rec_c.tolist())}
-        out = torch.full((len(owned), 27), float(np.float32(self.voxel)))
-        for b, o3 in enumerate(owned.tolist()):
-            for p, d in enumerate(_OFF27.tolist()):
-                acc, ok, ws = 0.0, True, []
-                terms = []
-                for cx in _CEIL:
-                    key, l, w = [], 0, 1.0
-                    for a in range(3):
-                        if d[a] == 0:
-                            nb_a, loc2 = 0, 0
-                        elif cx[a]:
-                            nb_a, loc2 = (d[a] + 1) // 2, -1
-                        else:
-                            nb_a, loc2 = (d[a] - 1) // 2, 1
-                        if d[a] != 0:
-                            w *= 0.5
-                        key.append(o3[a] + nb_a)
-                        l = l * 3 + (loc2 + 1)
-                    i = halo.get(tuple(key))
-                    if i is None:
-                        ok = False
-                        break
-                    terms.append((float(rec_t[i, l]), w))
-                if ok:
-                    norm = sum(w for _, w in terms)
-                    out[b, p] = float(sum(np.float32(t) * np.float32(w / norm) for t, w in terms))
-        return out
+    def pack(self, fr, capacity):
+        D, v = self.D, self.vol
+        g = fr.grid_ids.numpy()
+        send = g[D.shard_is_boundary(g, self.world)] if len(g) else g.reshape(0, 3)
+        assert len(send) <= fr.counts[self.rank] <= capacity       # the bound bounds
+        block = torch.zeros((capacity + 1, D.REC_WORDS), dtype=torch.int32)
+        block[0, 0], block[0, 1] = len(send), self.rank
+        if len(send):
+            f, w, _ = v.query(torch.from_numpy(send))
+            block[1: 1 + len(send), :3] = torch.from_numpy(send).int()
+            block[1: 1 + len(send), 3] = w[:, 0].contiguous().view(torch.int32)
+            block[1: 1 + len(send), 4:] = f.contiguous().view(torch.int32)
+        return block.reshape(-1)
+
+    def install(self, blocks, capacity):
+        D, v = self.D, self.vol
+        blocks = blocks.reshape(self.world, capacity + 1, D.REC_WORDS)
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            n = int(blocks[r, 0, 0])
+            assert int(blocks[r, 0, 1]) == r and int(blocks[r, 0, 2]) == 0 and n <= capacity
+            rec = blocks[r, 1: 1 + n]
+            keys = rec[:, :3].long()
+            mine = torch.from_numpy(D.shard_adjacent_to(keys.numpy(), self.world, self.rank)) if n else torch.zeros(0, dtype=torch.bool)
+            if mine.any():
+                k = keys[mine]
+                v.insert(k, rec[mine, 4:].contiguous().view(torch.float32),
+                         rec[mine, 3:4].contiguous().view(torch.float32), torch.zeros(len(k), 1))
+                self.installed += len(k)
+        return 0
+
+    def decode(self, fr):
+        o = self.orc
+        if len(fr.grid_ids) == 0:
+            return torch.zeros((0, 27))
+        return self.vol.decode_pts(o.lattice_coords(fr.grid_ids.numpy()), self.sd, None, is_coords=True,
+                                   query_tensor=False)[0, :, :, 0]
+
+    def finish(self, fr, sdf, reserved):
+        fr.sdf = sdf
+        return fr
+
+    def result(self, fr):
+        return fr.grid_ids, fr.sdf
+
+    def last_mlp_evals(self):
+        return torch.zeros(1, dtype=torch.int32)
 
 
 def _free_port():
@@ -93,10 +111,12 @@ def _worker(rank, world, port, frames, dims, voxel, ret):
     nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world))
     for fr in frames:
         owned, sdf = nm.fuse_and_decode({"input_pts": torch.from_numpy(fr)})
+    assert nm.host_waits == len(frames) and nm.backend.installed > 0      # one host wait per frame; ghosts installed
     allc = all_gather_var(owned)
     alls = all_gather_var(sdf)
     if rank == 0:
         ret["coords"], ret["sdf"], ret["n0"] = allc.numpy(), alls.numpy(), len(owned)
+        ret["bytes"] = nm.exchanged_bytes
     dist.destroy_process_group()
 
 
@@ -125,6 +145,25 @@ def test_two_shards_equal_single_process():
     assert np.abs(sdf[order] - ref.numpy()).max() < 2e-6
     assert np.array_equal(sdf[order] == np.float32(voxel), ref.numpy() == np.float32(voxel))
     assert (ref != voxel).float().mean() > 0.05          # the decode mask is live in this test
+
+
+def test_boundary_predicates():
+    """shard_is_boundary / shard_adjacent_to (host restatements of the device predicates): a voxel is a boundary
+    voxel iff some OTHER rank is adjacent to it; interior voxels of a block are never boundary voxels; every voxel is
+    adjacent to its owner."""
+    from bnv_fusion_amd.distributed import shard_adjacent_to, shard_is_boundary, voxel_owner
+    g = np.stack(np.meshgrid(np.arange(8, 40), np.arange(8, 40), np.arange(8, 24), indexing="ij"), -1).reshape(-1, 3)
+    for world in (2, 4, 8):
+        own = voxel_owner(g, world)
+        bnd = shard_is_boundary(g, world)
+        adj = np.stack([shard_adjacent_to(g, world, r) for r in range(world)], 1)
+        assert adj[np.arange(len(g)), own].all()
+        others = adj.copy()
+        others[np.arange(len(g)), own] = False
+        assert np.array_equal(bnd, others.any(1))
+        interior = ((g & 7) > 0).all(1) & ((g & 7) < 7).all(1)
+        assert not bnd[interior].any() and 0.2 < bnd.mean() < 0.8
+    assert not shard_is_boundary(g, 1).any()
 
 
 def test_owner_hash_is_balanced_and_blocked():

@@ -387,39 +387,62 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
 
 
 # ---------------------------------------------------------------------------------------------
-# sharded volume: two shards driven phase by phase on ONE GPU (no process group needed)
+# sharded volume: several shards driven phase by phase on ONE GPU (no process group needed)
 # ---------------------------------------------------------------------------------------------
-def test_two_hip_shards_equal_single_volume(bnv, model):
-    from bnv_fusion_amd.distributed import HipShardBackend, voxel_owner
+@pytest.mark.parametrize("world", [2, 3])
+def test_hip_shards_equal_single_volume(bnv, model, world):
+    """``world`` shards of the spatially sharded volume driven phase by phase in ONE process (the all-gather is a
+    torch.stack): encode with ownership, upsert, pack boundary records, install ghost rows, decode -- the union of
+    the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements."""
+    from bnv_fusion_amd import distributed as D
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     dims, voxel = z["dims"], float(z["voxel_size"])
-    shards = [HipShardBackend(dims, voxel, model, r, 2, capacity=4096, device=DEV) for r in range(2)]
+    shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=4096, device=DEV) for r in range(world)]
     model.shard = (0, 1, 3)
     single = bnv.NeuralMap(dims, voxel, model, device=DEV)
     for fr in z["frames"]:
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
         model.shard = (0, 1, 3)
         ref_coords, ref_sdf = single.fuse_and_decode(frame)
-        owned = [b.encode_integrate(frame) for b in shards]
-        touched = torch.cat(owned)
-        recs = [b.tables_for(touched) for b in shards]
-        rc, rw, rt = (torch.cat([r[i] for r in recs]) for i in range(3))
-        outs = [b.install_and_blend(o, rc, rw, rt) for b, o in zip(shards, owned)]
+        frs = [b.encode(frame) for b in shards]
+        bounds = [b.bound(f) for b, f in zip(shards, frs)]
+        assert len(set(bounds)) == 1 and bounds[0] > 0                   # every rank computes the same bound
+        counts = [f.bound_host.clone() for f in frs]
+        assert all(torch.equal(c, counts[0]) for c in counts)
+        cap = -(-bounds[0] // D.REC_QUANTUM) * D.REC_QUANTUM
+        blocks = torch.stack([b.pack(f, cap) for b, f in zip(shards, frs)])
+        hdr = blocks.view(world, cap + 1, D.REC_WORDS)[:, 0, :3].cpu()
+        for r in range(world):
+            assert int(hdr[r, 1]) == r and int(hdr[r, 2]) == 0 and int(hdr[r, 0]) <= int(counts[0][r])
+        outs = []
+        for b, f in zip(shards, frs):
+            res = b.install(blocks, cap)
+            outs.append(b.result(b.finish(f, b.decode(f), res)))
     model.shard = (0, 1, 3)
-    for r in range(2):
-        assert np.all(voxel_owner(owned[r].cpu().numpy(), 2) == r)      # HIP ownership hash == host restatement
+    owned = [o[0] for o in outs]
+    for r in range(world):
+        assert np.all(D.voxel_owner(owned[r].cpu().numpy(), world) == r)   # HIP ownership hash == host restatement
+        # the records a rank sent are exactly its emitted boundary voxels (device predicate == host restatement)
+        n = int(hdr[r, 0])
+        sent = blocks.view(world, cap + 1, D.REC_WORDS)[r, 1: 1 + n, :3].cpu().numpy()
+        want = owned[r].cpu().numpy()[D.shard_is_boundary(owned[r].cpu().numpy(), world)]
+        assert np.array_equal(sent[np.lexsort(sent.T[::-1])], want[np.lexsort(want.T[::-1])])
     coords = torch.cat(owned).cpu().numpy()
-    sdf = torch.cat(outs).cpu().numpy()
+    sdf = torch.cat([o[1] for o in outs]).cpu().numpy()
     order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
     assert np.array_equal(coords[order], ref_coords.cpu().numpy())
-    assert np.abs(sdf[order] - ref_sdf.cpu().numpy()).max() <= 1e-6
+    assert np.array_equal(sdf[order], ref_sdf.cpu().numpy())               # bit-identical to the single volume
     assert float((ref_sdf != voxel).float().mean()) > 0.05
-    # every shard's volume holds its own rows + halo rows only
+    # every shard's volume holds its own rows + ghost rows adjacent to it, with the owner's values
+    single.volume.to_tensor()
     for r, b in enumerate(shards):
         b.volume.to_tensor()
         own = b.owned_rows_mask().cpu().numpy()
         k = b.volume.active_coordinates.cpu().numpy()
-        assert np.all(voxel_owner(k[own], 2) == r) and np.all(voxel_owner(k[~own], 2) != r)
+        assert np.all(D.voxel_owner(k[own], world) == r) and np.all(D.voxel_owner(k[~own], world) != r)
+        assert D.shard_adjacent_to(k[~own], world, r).all() and (~own).sum() > 0
+        f1, w1, _ = single.volume.query(b.volume.active_coordinates)
+        assert torch.equal(f1, b.volume.features) and torch.equal(w1, b.volume.weights)
 
 
 # ---------------------------------------------------------------------------------------------
