@@ -5,6 +5,7 @@ from .fusion import LitFusionPointNet, LocalNeRFModel, get_neighbors, load_pretr
 from .sparse_volume import SparseVolume, VolumeList, get_world_range  # noqa: F401
 from .neural_map import NeuralMap  # noqa: F401
 from . import optimize  # noqa: F401
+from ._lib import BnvError  # noqa: F401
 
 
 MLP_MODE_FP32_EXACT = 0     # v_mfma_f32_32x32x2_f32

@@ -30,7 +30,7 @@ constexpr int SD_W2 = SD_W1 + 65536;
 constexpr int SD_W3 = SD_W2 + 65536;
 constexpr int SD_B0 = SD_W3 + 65536;          // [256] x 4
 constexpr int SD_WA = SD_B0 + 4 * 256;        // fc_alpha weight [256]
-constexpr int SD_BA = SD_WA + 256;            // fc_alpha bias, padded to 4
+constexpr int SD_BA = SD_WA + 256;            // fc_alpha bias, padded to 4; [1] = certified |feature| bound (below)
 constexpr int SD_TOTAL = SD_BA + 4;
 // split-operand variant, appended to the same pack (units: 16-bit halves from float offset SD_TOTAL)
 constexpr int SH_W0 = 0;                          // [8 w][2 ks][2 hi/lo][64 lane][8]
@@ -379,6 +379,22 @@ __device__ __forceinline__ void sdf_mlp_tile_h(float* __restrict__ lds, const fl
   BNV_PH(16);
 }
 
+// Range certificate of the f16-split arithmetic (MLP modes 1 and 3; weights.py: certified_input_bound): with the
+// local coordinates and their sin / cos in [-1, 1] and |feature| <= pack[SD_BA + 1], no value of any layer can
+// reach the f16 overflow threshold (65,520), where fp32 -- the reference's arithmetic -- would still be fine.  A
+// feature row beyond the bound (or NaN) sets the volume's sticky error word to 5 instead of silently producing
+// inf / NaN: the caller then switches to exact fp32 (bnv_set_mlp_mode(0)).  8 compares per EVALUATION, not per
+// activation: free.
+__device__ __forceinline__ void check_feature_range(const float (&feat)[8], float bound, int32_t* __restrict__ status) {
+  float m = fmaxf(fabsf(feat[0]), fabsf(feat[1]));
+#pragma unroll
+  for (int f = 2; f < 8; ++f) m = fmaxf(m, fabsf(feat[f]));
+  bool bad = !(m <= bound);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) bad = bad || (feat[f] != feat[f]);   // fmaxf drops NaNs
+  if (bad && status) status[1] = 5;
+}
+
 // inputs of evaluation j in the split layout: features 0..16 (+15 zero) over K-steps 0, 1
 template <int NPROD = 3>
 __device__ __forceinline__ void stage_input_h(float* __restrict__ lds, int j, const float (&loc)[3],
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
           }
         }
       }
+      if constexpr (PREC == 1 || PREC == 3) check_feature_range(feat, A.pack[SD_BA + 1], A.vol.n_rows);
       if constexpr (PREC == 2) stage_input_t(lds, j, loc, feat);
       else if constexpr (PREC == 1) stage_input_h<3>(lds, j, loc, feat);
       else if constexpr (PREC == 3) stage_input_h<1>(lds, j, loc, feat);
@@ -822,6 +839,7 @@ __device__ __forceinline__ void pts_stage_tile(const DecodeArgs& A, int64_t chun
       }
     }
   }
+  if constexpr (PREC == 1 || PREC == 3) check_feature_range(feat, A.pack[SD_BA + 1], A.vol.n_rows);
   if constexpr (PREC == 2) stage_input_t(lds, e, loc, feat);
   else if constexpr (PREC == 1) stage_input_h<3>(lds, e, loc, feat);
   else if constexpr (PREC == 3) stage_input_h<1>(lds, e, loc, feat);
@@ -1372,6 +1390,10 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
 #pragma unroll
     for (int f = 0; f < 32; ++f) in[f] = 0.f;
     if (ent >= 0) {
+      {
+        const float fe[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        check_feature_range(fe, pack[SD_BA + 1], A.vol.n_rows);
+      }
       const int l = ent & 31;
       const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
       const int li[3] = {lx, ly, lz};

@@ -68,7 +68,8 @@ constexpr int PH_W2 = PH_W1 + 4 * 2 * 64 * 8;   // [4 mb][4 nb][2 ksl][2 hi/lo][
 constexpr int PH_W3 = PH_W2 + 4 * 4 * 2 * 2 * 64 * 8;
 constexpr int PH_W4 = PH_W3 + 4 * 4 * 2 * 2 * 64 * 8;   // [4 nb][2 ksl][2 hi/lo][2 h][8 n][8]
 constexpr int PH_TOTAL = PH_W4 + 4 * 2 * 2 * 2 * 8 * 8; // 71,680 halves = 143,360 B
-constexpr int PN_PACK_FLOATS = PN_TOTAL + PH_TOTAL / 2;
+constexpr int PN_CERT = PN_TOTAL + PH_TOTAL / 2;   // [4]: certified bound on |normal component| of the split modes
+constexpr int PN_PACK_FLOATS = PN_CERT + 4;
 constexpr int PH_LDS_BYTES = PH_TOTAL * 2 + (128 * 3 + 8) * 4 + 16;  // halves + fp32 biases + tile counter = 144,944 B
 
 constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exact integers
@@ -592,8 +593,12 @@ template <int NPROD>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
-    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+    int32_t* __restrict__ counts, long long* __restrict__ acc, int32_t* __restrict__ error) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // Range certificate of the f16-split arithmetic (weights.py: certified_input_bound): with the relative
+  // coordinates in [-1, 1] and |normal components| <= n_cert no value of any layer can reach the f16 overflow
+  // threshold.  A normal beyond that bound (or NaN) raises the frame's error word instead of silently becoming inf.
+  const float n_cert = wpack[PN_CERT];
   _Float16* wh = (_Float16*)lds;                       // PH_TOTAL halves
   float* lb = lds + PH_TOTAL / 2;                      // b1 b2 b3 b4
   for (int i = threadIdx.x * 4; i < PH_TOTAL / 2; i += 512 * 4)
@@ -669,6 +674,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
         nin[0] = raw[4];
         nin[1] = raw[5];
       }
+      if (!(fmaxf(fmaxf(fabsf(raw[3]), fabsf(raw[4])), fabsf(raw[5])) <= n_cert)) *error = 3;
     }
   };
   int t = grab();
@@ -1239,10 +1245,10 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
                          ws.acc);
     else if (g_mlp_mode == 1) {
       hipLaunchKernelGGL((k_pointnet_scatter_h<3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error);
     } else if (g_mlp_mode == 3) {
       hipLaunchKernelGGL((k_pointnet_scatter_h<1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error);
     } else
       hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);

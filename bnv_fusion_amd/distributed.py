@@ -23,7 +23,7 @@ SPATIAL SHARDING (the north-star decomposition; ``ShardedNeuralMap``)
 FRAME-PARALLEL (throughput of one frame stream; ``FrameParallelNeuralMap``, below)
 
 The frame logic talks to a backend; ``HipShardBackend`` / ``HipFrameBackend`` are the product backends (HIP kernels).
-tests/test_distributed_cpu.py drives the same logic over gloo with oracle-backed backends.
+tests/test_distributed_cpu.py drives the same logic over gloo with CPU backends of its own.
 """
 import ctypes as C
 
@@ -204,7 +204,8 @@ class HipShardBackend:
         v.check_status(fr.host_rows[1])
         h = fr.host
         if int(h[4]):
-            raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {int(h[4])})")
+            from .fusion import encode_error_message
+            raise _lib.BnvError(encode_error_message(int(h[4])))
         if int(h[0]) == 0:
             return None, None
         v.track_n_pts(float(h[3:4].view(torch.float32)[0]))
@@ -589,7 +590,8 @@ class FrameParallelNeuralMap:
         for s in range(b):
             c = header_counters(ticket["host"][s])
             if int(c[4]):
-                raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {int(c[4])})")
+                from .fusion import encode_error_message
+                raise _lib.BnvError(encode_error_message(int(c[4])))
             n_out.append(int(c[2]) if int(c[0]) else 0)
             n_valid.append(int(c[0]))
         rows = -(-max(n_out) // ROW_QUANTUM) * ROW_QUANTUM

@@ -23,6 +23,15 @@ from .sparse_volume import make_grid
 _CORNER_IS_CEIL = ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1))
 
 
+def encode_error_message(code):
+    """bnv_encode_counters_t.error -> text."""
+    return "bnv_encode_pointcloud: " + {
+        1: "more touched voxels than the workspace was sized for",
+        2: "output capacity exceeded",
+        3: "a normal beyond the range certified for the f16-split point encoder (or NaN): encode in exact fp32 -- "
+           "bnv_fusion_amd.set_mlp_mode(0)"}.get(int(code), f"error {int(code)}")
+
+
 def _get(cfg, name, default=None):
     if isinstance(cfg, dict):
         return cfg.get(name, default)
@@ -316,7 +325,7 @@ class LitFusionPointNet(nn.Module):
         host = counters.cpu()                       # the one device->host sync of the frame
         n_valid, n_unique, n_out, err = int(host[0]), int(host[1]), int(host[2]), int(host[4])
         if err:
-            raise _lib.BnvError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+            raise _lib.BnvError(encode_error_message(err))
         if n_valid == 0:                            # local_point_fusion.py:101-102
             return None, None, None, None, None
         if not return_dense:

@@ -9,6 +9,7 @@
 """
 import torch
 
+from ._lib import BnvError as _lib_error
 from .sparse_volume import SparseVolume
 
 
@@ -55,7 +56,8 @@ class FrameHandle:
         self._settled = True
         vol.check_status(self._host_rows[1])      # sticky error word of the upsert kernels, read back with the rows
         if err:
-            raise RuntimeError(f"bnv_encode_pointcloud: output capacity exceeded (code {err})")
+            from .fusion import encode_error_message
+            raise _lib_error(encode_error_message(err))
         if n_valid == 0:
             self._done = (None, None)
         else:

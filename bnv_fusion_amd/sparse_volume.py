@@ -155,14 +155,16 @@ class SparseVolume:
         return n
 
     UPSERT_ERRORS = {1: "hash table full", 2: "voxel coordinate outside the 21-bit key range",
-                     3: "row capacity exceeded", 4: "a rank's boundary-record block overflowed (sharded exchange)"}
+                     3: "row capacity exceeded", 4: "a rank's boundary-record block overflowed (sharded exchange)",
+                     5: "feature values beyond the range certified for the f16-split SDF decoder (or NaN): "
+                        "decode in exact fp32 -- bnv_fusion_amd.set_mlp_mode(0)"}
 
     def check_status(self, err):
         """Raises on the sticky error word of the upsert kernels (device int32 next to the row counter; the
         asynchronous pipelines read it back with the row count, see status_readback)."""
         err = int(err)
         if err:
-            raise _lib.BnvError("volume upsert failed: " + self.UPSERT_ERRORS.get(err, f"error {err}"))
+            raise _lib.BnvError("volume status: " + self.UPSERT_ERRORS.get(err, f"error {err}"))
 
     def status_readback(self):
         """Pinned int32 [2] = {row count, sticky upsert error} behind everything enqueued so far (async copy)."""

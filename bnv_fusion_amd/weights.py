@@ -41,8 +41,51 @@ def fold_pointnet(sd):
     return out
 
 
+F16_MAX = 65504.0
+
+
+def certified_input_bound(layers, fixed, n_free, limit=0.98 * F16_MAX):
+    """Range certificate of the f16-split arithmetic (MLP modes 1 and 3): every value a layer hands to the next one
+    is rounded to an f16 ``hi`` part, which overflows at 65,520 -- IEEE fp32, the reference's arithmetic, does not.
+    Interval bound: with |input_j| <= fixed_j for the first inputs and <= B for the last ``n_free`` ones, the
+    pre-activations of layer l are bounded per neuron by a_l + B c_l with a_0 = |W_0| fixed + |b_0|,
+    c_0 = |W_0| 1_free, a_l = |W_l| a_{l-1} + |b_l|, c_l = |W_l| c_{l-1} (ReLU only shrinks magnitudes).  Returns
+    the largest B for which every layer passed in stays below ``limit``: inputs within that bound CANNOT overflow.
+    ``layers``: the (W, b) pairs whose outputs are converted to f16 (all but the last layer of a network)."""
+    W0 = np.abs(np.asarray(layers[0][0], dtype=np.float64))
+    fixed = np.asarray(fixed, dtype=np.float64)
+    k = len(fixed)
+    assert W0.shape[1] == k + n_free
+    a = W0[:, :k] @ fixed + np.abs(np.asarray(layers[0][1], dtype=np.float64))
+    c = W0[:, k:].sum(1)
+    best = np.inf
+    for i, (W, b) in enumerate(layers):
+        if i:
+            Wa = np.abs(np.asarray(W, dtype=np.float64))
+            a, c = Wa @ a + np.abs(np.asarray(b, dtype=np.float64)), Wa @ c
+        if (a >= limit).any():
+            return 0.0
+        with np.errstate(divide="ignore"):
+            best = min(best, float(np.min(np.where(c > 0, (limit - a) / c, np.inf))))
+    return best
+
+
+def pointnet_normal_bound(sd):
+    """Largest |normal component| for which the split-mode point encoder provably cannot overflow (the three
+    relative coordinates are within [-1, 1] by construction, local_point_fusion.py:60-61)."""
+    return certified_input_bound(fold_pointnet(sd)[:3], [1.0, 1.0, 1.0], 3)
+
+
+def sdf_feature_bound(sd):
+    """Largest |feature| for which the split-mode SDF decoder provably cannot overflow (local coordinates within
+    [-1, 1], sin / cos within [-1, 1]; the last hidden layer's output is consumed in fp32)."""
+    layers = [(_np(sd[f"nerf.geo_layer{i}.weight"]), _np(sd[f"nerf.geo_layer{i}.bias"])) for i in range(3)]
+    return certified_input_bound(layers, [1.0] * 9, 8)
+
+
 def pack_pointnet(sd):
-    """-> float32 [34952] in the PN_* layout of csrc/encode.hip.
+    """-> float32 [34952 + split pack + 4] in the PN_* layout of csrc/encode.hip; the trailing 4 floats hold the
+    certified bound on |normal| of the split modes (pointnet_normal_bound) and padding.
 
     MFMA tile: lane l = (n = l & 31, h = l >> 5).  A K-step that consumes D register r of input
     block nb contracts input features nb*32 + f0(r) + 4h with f0(r) = (r & 3) + 8 (r >> 2); for
@@ -73,7 +116,9 @@ def pack_pointnet(sd):
                     w4p[nb, rq, hh, :, i] = W4[:, nb * 32 + 8 * rq + i + 4 * hh]
     fp32_part = np.concatenate([w1p.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4p.ravel(),
                                 b1, b2, b3, b4]).astype(np.float32)
-    return np.concatenate([fp32_part, _pack_pointnet_split(W1, W2, W3, W4)])
+    trailer = np.zeros(4, np.float32)
+    trailer[0] = min(pointnet_normal_bound(sd), 3.0e38)
+    return np.concatenate([fp32_part, _pack_pointnet_split(W1, W2, W3, W4), trailer])
 
 
 def split_f16(x):
@@ -171,6 +216,7 @@ def pack_sdf_mlp(sd):
     wa = _np(sd["nerf.fc_alpha.weight"]).astype(np.float32).reshape(256)
     ba = np.zeros(4, np.float32)
     ba[0] = _np(sd["nerf.fc_alpha.bias"]).reshape(-1)[0]
+    ba[1] = min(sdf_feature_bound(sd), 3.0e38)     # certified |feature| bound of the split modes (SD_BA + 1)
     fp32_part = np.concatenate([pack(Ws[0], 3), pack(Ws[1], 32), pack(Ws[2], 32), pack(Ws[3], 32),
                                 bs[0], bs[1], bs[2], bs[3], wa, ba]).astype(np.float32)
 

@@ -35,7 +35,7 @@ def test_pointnet_pack_matches_direct_mlp():
     PN_W4 = PN_W3 + 16384
     PN_B1 = PN_W4 + 1024
     PN_B2, PN_B3, PN_B4 = PN_B1 + 128, PN_B1 + 256, PN_B1 + 384
-    assert PN_B4 + 8 == 34952 and pack.size == 34952 + 71680 // 2
+    assert PN_B4 + 8 == 34952 and pack.size == 34952 + 71680 // 2 + 4      # + certified-range trailer
     rng = np.random.default_rng(0)
     x = rng.uniform(-1, 1, size=(32, 6))  # 32 pairs
 
@@ -170,7 +170,7 @@ def _mfma3(ah, al, bh, bl, c):
 def test_pointnet_split_pack_matches_direct_mlp():
     sd = W.load_npz(WEIGHTS_FP32)
     pack = W.pack_pointnet(sd)
-    halves = pack[34952:].view(np.float16).astype(np.float64)
+    halves = pack[34952: 34952 + 71680 // 2].view(np.float16).astype(np.float64)
     fp = pack[:34952].astype(np.float64)
     PH_W1, PH_W2 = 0, 4096
     PH_W3, PH_W4 = PH_W2 + 32768, PH_W2 + 65536
