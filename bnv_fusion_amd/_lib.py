@@ -21,7 +21,7 @@ SYMBOLS = [
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
-    "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
+    "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
 ]
 
@@ -110,6 +110,9 @@ def load():
                                                  vp]),
         "bnv_mc_count": (C.c_int, [vp, i64, vp, C.c_float, vp, vp, vp]),
         "bnv_mc_emit": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp, vp, vp, vp]),
+        "bnv_mc_count_indexed": (C.c_int, [vp, i64, vp, C.c_float, vp, vp, vp, vp]),
+        "bnv_mc_emit_indexed": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp, vp, vp, vp, vp,
+                                          vp]),
         "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
         "bnv_decode_lattice_count_offset": (sz, [i64]),
         "bnv_decode_lattice_table_offset": (sz, [i64]),

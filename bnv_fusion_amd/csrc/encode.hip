@@ -406,6 +406,9 @@ __device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, i
       closed |= fo;
     }
   }
+#ifdef BNV_PROBE_NO_SCATTER   // development probe (tools/): what do the scatter atomics cost?  keeps 1 of 64 tiles' atomics
+  if ((blockIdx.x & 63) != 0) return;
+#endif
   if (slot >= 0 && (j == 31 || next != slot)) {
     long long* dst = acc + (size_t)slot * 8 + 4 * h;
 #pragma unroll

@@ -1,6 +1,10 @@
 """Mesh extraction from decoded SDF lattices: per-voxel marching cubes on the GPU (csrc/mesh.hip), the
 last stage of SparseVolume.meshlize (src/models/sparse_volume.py:740-766).
 
+``marching_cubes_lattice_indexed`` produces what the reference's loop produces: per voxel a vertex list without
+duplicates and faces indexing it, concatenated with ``faces + last_face_id`` / ``last_face_id += max(faces) + 1``
+(:748-751).  ``marching_cubes_lattice`` is the older triangle-soup form (3 vertices per face).
+
 ``TriMesh`` stands in for the ``trimesh.Trimesh(vertices, faces, process=False)`` the reference returns:
 ``.vertices`` [V, 3] float32, ``.faces`` [T, 3] int64 (numpy, like trimesh), ``.export(path)`` (binary PLY).
 """
@@ -79,3 +83,36 @@ def marching_cubes_lattice(sdf, origins, voxel_size, min_coords, level=0.0, n_de
                                    _lib.stream_ptr()), "bnv_mc_emit")
     faces = torch.arange(3 * total, dtype=torch.int64, device=dev).reshape(-1, 3)
     return verts, faces
+
+
+def marching_cubes_lattice_indexed(sdf, origins, voxel_size, min_coords, level=0.0, n_dev=None):
+    """sdf [n, 27] (or [n, 3, 3, 3]) float32 on the GPU; origins [n, 3] int64.  -> (vertices [V, 3] f32 world
+    coordinates, faces [T, 3] i64, n_verts [n] i32, n_tris [n] i32) on the device: the concatenation
+    SparseVolume.meshlize builds (sparse_volume.py:740-756) -- voxels that fail the gate contribute nothing, a voxel's
+    faces index its own vertices offset by the vertex counts of the voxels before it."""
+    lib = _lib.load()
+    sdf = sdf.detach().reshape(-1, 27).float().contiguous()
+    origins = origins.detach().reshape(-1, 3).long().contiguous()
+    n = int(sdf.shape[0])
+    dev = sdf.device
+    assert origins.shape[0] == n
+    if n == 0:
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return torch.zeros((0, 3), device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev), z, z
+    table = _table(dev)
+    nv = torch.empty(n, dtype=torch.int32, device=dev)
+    nt = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(lib.bnv_mc_count_indexed(_lib.ptr(sdf), n, _lib.ptr(n_dev), float(level), _lib.ptr(table),
+                                        _lib.ptr(nv), _lib.ptr(nt), _lib.stream_ptr()), "bnv_mc_count_indexed")
+    ve, te = torch.cumsum(nv.long(), 0), torch.cumsum(nt.long(), 0)
+    totals = torch.stack([ve[-1], te[-1]]).tolist()         # the one host read: the mesh has to be allocated
+    V, T = int(totals[0]), int(totals[1])
+    verts = torch.empty((V, 3), dtype=torch.float32, device=dev)
+    faces = torch.empty((T, 3), dtype=torch.int64, device=dev)
+    if T:
+        mn = (C.c_float * 3)(*[float(x) for x in torch.as_tensor(min_coords).reshape(-1)[:3].tolist()])
+        voff, toff = (ve - nv.long()).contiguous(), (te - nt.long()).contiguous()
+        _lib.check(lib.bnv_mc_emit_indexed(_lib.ptr(sdf), _lib.ptr(origins), n, _lib.ptr(n_dev), float(level),
+                                           float(voxel_size), mn, _lib.ptr(table), _lib.ptr(voff), _lib.ptr(toff),
+                                           _lib.ptr(verts), _lib.ptr(faces), _lib.stream_ptr()), "bnv_mc_emit_indexed")
+    return verts, faces, nv, nt

@@ -464,11 +464,13 @@ class SparseVolume:
         marching cubes -- both on the GPU.  Returns (active_pts, mesh) like the reference (None when no
         voxel straddles the surface); ``mesh`` is a bnv_fusion_amd.mesh.TriMesh (vertices / faces /
         export), standing in for trimesh.Trimesh(process=False)."""
-        from .mesh import TriMesh, marching_cubes_lattice
+        from .mesh import TriMesh, marching_cubes_lattice_indexed
         assert self.active_coordinates is not None, "call self.to_tensor() first."
         active_pts = self.active_coordinates * self.voxel_size + self.min_coords
         sdf = self.decode_lattice(self.active_coordinates, nerf, sdf_delta, query_tensor=True)
-        verts, faces = marching_cubes_lattice(sdf, self.active_coordinates, self.voxel_size, self.min_coords)
+        # per voxel (verts, faces) with shared vertices, concatenated as the reference does (:740-756)
+        verts, faces, _, _ = marching_cubes_lattice_indexed(sdf, self.active_coordinates, self.voxel_size,
+                                                            self.min_coords)
         if faces.shape[0] == 0:
             return None
         mesh = TriMesh(verts.cpu().numpy(), faces.cpu().numpy())

@@ -370,6 +370,17 @@ int bnv_mc_count(const float* sdf, int64_t n, const int32_t* n_dev, float level,
 int bnv_mc_emit(const float* sdf, const int64_t* origins, int64_t n, const int32_t* n_dev, float level,
                 float voxel_size, const float min_coords[3], const int8_t* tri_table,
                 const int64_t* tri_offsets, float* vertices, bnv_stream_t stream);
+/* The same meshes with shared vertices, laid out as SparseVolume.meshlize concatenates them
+ * (sparse_volume.py:740-756): per voxel one vertex per sign-changing edge of its 3x3x3 lattice (ascending lattice-edge
+ * order: x edges, y edges, z edges, node-major) and faces that index them, offset by the vertex counts of the voxels
+ * before it (the reference's `faces + last_face_id; last_face_id += max(faces) + 1`).  count -> the caller's
+ * exclusive prefix sums (vert_offsets, tri_offsets [n] i64) -> emit into vertices [V, 3] f32, faces [T, 3] i64. */
+int bnv_mc_count_indexed(const float* sdf, int64_t n, const int32_t* n_dev, float level, const int8_t* tri_table,
+                         int32_t* n_verts, int32_t* n_tris, bnv_stream_t stream);
+int bnv_mc_emit_indexed(const float* sdf, const int64_t* origins, int64_t n, const int32_t* n_dev, float level,
+                        float voxel_size, const float min_coords[3], const int8_t* tri_table,
+                        const int64_t* vert_offsets, const int64_t* tri_offsets, float* vertices, int64_t* faces,
+                        bnv_stream_t stream);
 
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
 /* Byte offset, inside that workspace, of two int32 device counters: [0] rows listed by

@@ -715,6 +715,81 @@ def marching_cubes_voxels(sdf, origins, voxel_size, min_coords, level=0.0):
     return verts, np.arange(len(verts), dtype=np.int64).reshape(-1, 3)
 
 
+def _mc_lattice_edge(pa, axis):
+    """Id of the lattice edge pa -> pa + e_axis of a 3x3x3 node lattice (18 per axis; csrc/mesh.hip)."""
+    if axis == 0:
+        return pa[0] * 9 + pa[1] * 3 + pa[2]
+    if axis == 1:
+        return 18 + pa[0] * 6 + pa[1] * 3 + pa[2]
+    return 36 + pa[0] * 6 + pa[1] * 2 + pa[2]
+
+
+def marching_cubes_voxel_indexed(s, level=0.0):
+    """One voxel's 3x3x3 lattice -> (verts [v, 3] in lattice-index units, faces [t, 3] local indices): what
+    skimage.measure.marching_cubes(sdf[j], level) returns for it up to (i) the order of the vertices -- here ascending
+    lattice-edge id --, (ii) the order / starting corner / diagonal choice of the triangles of a cell and (iii) the
+    triangulation inside AMBIGUOUS cells (Lewiner's MC33 topology tests; scikit-image absent -> unpinned).  Shared
+    with every variant: one vertex per sign-changing lattice edge at the linear-interpolation point, and in a
+    non-ambiguous cell the polygon(s) the triangles span."""
+    s = np.asarray(s, dtype=np.float32)
+    tri_edges, pos = [], {}
+    for cx in range(2):
+        for cy in range(2):
+            for cz in range(2):
+                cc = (cx, cy, cz)
+                val = [s[cx + dx, cy + dy, cz + dz] for dx, dy, dz in _MC_CORNERS]
+                inside = [x < level for x in val]
+                if all(inside) or not any(inside):
+                    continue
+                lat = {}
+                for e, (a, b) in enumerate(_MC_EDGES):
+                    if inside[a] != inside[b]:
+                        pa = [cc[d] + _MC_CORNERS[a][d] for d in range(3)]
+                        pb = [cc[d] + _MC_CORNERS[b][d] for d in range(3)]
+                        axis = [d for d in range(3) if pa[d] != pb[d]][0]
+                        lid = _mc_lattice_edge(pa, axis)
+                        lat[e] = lid
+                        t = np.float32(level - val[a]) / np.float32(val[b] - val[a])
+                        pos[lid] = np.array(pa, np.float32) + t * (np.array(pb, np.float32) - np.array(pa, np.float32))
+                for loop in _mc_cell_loops(inside):
+                    mid = {e: (np.array(_MC_CORNERS[_MC_EDGES[e][0]], float)
+                               + np.array(_MC_CORNERS[_MC_EDGES[e][1]], float)) / 2 for e in loop}
+                    nrm = sum(np.cross(mid[loop[k]], mid[loop[(k + 1) % len(loop)]]) for k in range(len(loop)))
+                    g = sum((np.array(_MC_CORNERS[_MC_EDGES[e][1]], float) - np.array(_MC_CORNERS[_MC_EDGES[e][0]], float))
+                            * (1 if inside[_MC_EDGES[e][0]] else -1) for e in loop)
+                    if np.dot(nrm, g) < 0:
+                        loop = loop[::-1]
+                    for k in range(1, len(loop) - 1):
+                        tri_edges.append((lat[loop[0]], lat[loop[k]], lat[loop[k + 1]]))
+    ids = sorted(pos)
+    rank = {e: i for i, e in enumerate(ids)}
+    verts = np.stack([pos[e] for e in ids]).astype(np.float32) if ids else np.zeros((0, 3), np.float32)
+    faces = np.array([[rank[e] for e in t] for t in tri_edges], dtype=np.int64).reshape(-1, 3)
+    return verts, faces
+
+
+def meshlize_concat(sdf, origins, voxel_size, min_coords, level=0.0):
+    """The mesh assembly of SparseVolume.meshlize (sparse_volume.py:740-756) around the per-voxel mesher above:
+    gate, spacing 0.5, ``verts += origin - 0.5``, ``faces + last_face_id``, ``last_face_id += max(faces) + 1``,
+    ``* voxel_size + min_coords``.  -> (vertices [V, 3] f32, faces [T, 3] i64)."""
+    sdf = np.asarray(sdf, dtype=np.float32).reshape(-1, 3, 3, 3)
+    origins = np.asarray(origins)
+    mn = np.asarray(min_coords, dtype=np.float32)
+    all_v, all_f, last_face_id = [], [], 0
+    for j in range(len(sdf)):
+        if np.max(sdf[j]) > level and np.min(sdf[j]) < level:                      # :742
+            verts, faces = marching_cubes_voxel_indexed(sdf[j], level)
+            verts = verts * np.float32(0.5)                                          # spacing (:719, :746)
+            verts = verts + (origins[j].astype(np.float32) - np.float32(0.5))       # :749
+            all_v.append(verts)
+            all_f.append(faces + last_face_id)                                      # :751
+            last_face_id += int(np.max(faces)) + 1                                  # :752
+    if not all_v:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int64)
+    v = np.concatenate(all_v, 0) * np.float32(voxel_size) + mn                      # :756
+    return v.astype(np.float32), np.concatenate(all_f, 0)
+
+
 def synthetic_depth(t, H=480, W=640, seed=0):
     """depth(u,v) = 1.5 + 0.2 sin(u/40) cos(v/30) + N(0, 0.002) m,
     quantised to uint16 millimetres as the datasets store it (common.py:93)."""

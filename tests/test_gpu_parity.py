@@ -909,6 +909,20 @@ def test_marching_cubes_vs_oracle_and_properties(bnv, model, golden_volume, orc)
     # (4) nothing to mesh -> empty; meshlize end to end + PLY export
     e_v, e_f = marching_cubes_lattice(torch.full((4, 27), 0.02, device=DEV), o[:4].to(DEV), 1.0, torch.zeros(3))
     assert e_v.shape == (0, 3) and e_f.shape == (0, 3)
+    # (5) the reference's output structure: per voxel shared vertices + faces, concatenated with
+    # `faces + last_face_id; last_face_id += max(faces) + 1` (sparse_volume.py:740-756) -- against the oracle's
+    # restatement of that loop, and consistent with the triangle soup above
+    from bnv_fusion_amd.mesh import marching_cubes_lattice_indexed
+    iv, jf, nv, nt = marching_cubes_lattice_indexed(sdf, coords, vol.voxel_size, vol.min_coords)
+    ov, of_ = orc.meshlize_concat(sdf.cpu().numpy(), coords.cpu().numpy(), vol.voxel_size, vol.min_coords.cpu().numpy())
+    assert np.array_equal(jf.cpu().numpy(), of_) and np.abs(iv.cpu().numpy() - ov).max() <= 1e-6
+    assert int(jf.max()) + 1 == iv.shape[0] == int(nv.sum()) and jf.shape[0] == int(nt.sum()) == faces.shape[0]
+    assert torch.equal(iv[jf].reshape(-1, 3), verts)                  # same triangles as the soup, vertices shared
+    assert iv.shape[0] < 0.5 * verts.shape[0]
+    siv, sjf, _, _ = marching_cubes_lattice_indexed(s.to(DEV), o.to(DEV), 1.0, torch.zeros(3))
+    assert torch.equal(siv[sjf].reshape(-1, 3), sv)
+    e = marching_cubes_lattice_indexed(torch.full((4, 27), 0.02, device=DEV), o[:4].to(DEV), 1.0, torch.zeros(3))
+    assert e[0].shape == (0, 3) and e[1].shape == (0, 3) and int(e[2].sum()) == 0
 
 
 def test_meshlize_returns_mesh_like_the_reference(bnv, model, golden_volume, tmp_path):
@@ -917,7 +931,9 @@ def test_meshlize_returns_mesh_like_the_reference(bnv, model, golden_volume, tmp
     assert out is not None
     active_pts, mesh = out
     assert active_pts.shape == (vol.active_coordinates.shape[0], 3)
-    assert mesh.faces.shape[1] == 3 and mesh.vertices.shape[0] == 3 * mesh.faces.shape[0]
+    # per-voxel shared vertices, every vertex used, indices in range (sparse_volume.py:748-752)
+    assert mesh.faces.shape[1] == 3 and mesh.faces.max() + 1 == mesh.vertices.shape[0] < 1.5 * mesh.faces.shape[0]
+    assert len(np.unique(mesh.faces)) == mesh.vertices.shape[0]
     lo, hi = vol.min_coords.cpu().numpy(), vol.max_coords.cpu().numpy()
     assert (mesh.vertices >= lo - 1e-5).all() and (mesh.vertices <= hi + vol.voxel_size).all()
     data = open(tmp_path / "m.ply", "rb").read()
