@@ -48,11 +48,12 @@ class TriMesh:
         return path
 
     def merge_vertices(self):
-        """Weld coincident vertices (trimesh's ``merge_vertices``): the kernel emits a triangle soup."""
-        u, inv = np.unique(self.vertices.view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1),
+        """Weld coincident vertices (trimesh's ``merge_vertices``): meshlize shares vertices inside a voxel only,
+        neighbouring voxels repeat the vertices on their common lattice edges."""
+        u, inv = np.unique(np.ascontiguousarray(self.vertices).view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1),
                            return_inverse=True)
         self.vertices = u.view(np.float32).reshape(-1, 3).copy()
-        self.faces = inv.reshape(-1, 3).astype(np.int64)
+        self.faces = inv.reshape(-1)[self.faces].astype(np.int64)
         return self
 
 
