@@ -80,7 +80,7 @@ constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exac
 // Control block: the first 512 bytes of the workspace.  All-zero between frames (k_finalize's closing workgroup
 // leaves it so), so no kernel of a frame needs a memset in front of it.
 struct EncCtl {
-  int32_t spare;
+  int32_t n_pairs;             // sharded encode: (point, corner) pairs whose voxel this rank owns (mark kernel)
   int32_t n_unique;            // U: touched voxels (k_rank)
   int32_t error;               // != 0: a capacity was exceeded
   int32_t pad[13];
@@ -94,6 +94,7 @@ struct EncodeWs {
   EncCtl* ctl;
   uint64_t* tile_state;   // [n_tiles] look-back state of k_rank / k_finalize (epoch-tagged, never cleared)
   int32_t* valid_blocks;  // [ceil(max_points / 256)] points that passed the bounds mask, per workgroup of the mark kernel
+  int32_t* pair_list;     // [8 * max_points] sharded encode: (point << 3 | corner) of the pairs this rank owns
   uint32_t* bitmap;       // [n_words]
   uint32_t* word_prefix;  // [n_words]
   int32_t* ids;           // [max_unique] flat voxel id of slot s (ascending)
@@ -129,6 +130,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   char* p_ctl = take(512);   // control block first: its offset does not depend on the sizes
   char* p_state = take(n_tiles * 8);
   char* p_valid = take(((max_points + 255) / 256 + 1) * 4);
+  char* p_pairs = take((size_t)(max_points > 0 ? max_points : 1) * 8 * 4);
   char* p_bitmap = take(n_words * 4);
   char* p_prefix = take(n_words * 4);
   char* p_ids = take(max_unique * 4);
@@ -138,6 +140,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
     ws->ctl = (EncCtl*)p_ctl;
     ws->tile_state = (uint64_t*)p_state;
     ws->valid_blocks = (int32_t*)p_valid;
+    ws->pair_list = (int32_t*)p_pairs;
     ws->bitmap = (uint32_t*)p_bitmap;
     ws->word_prefix = (uint32_t*)p_prefix;
     ws->ids = (int32_t*)p_ids;
@@ -166,8 +169,16 @@ uint32_t next_epoch() { return ++g_epoch; }
 // this.  The number of valid points goes to valid_blocks[blockIdx.x] as a plain store: one atomicAdd per wave on a
 // single counter serialises in the memory-side atomic unit at ~11 ns each -- 4,800 of them were 52 of this kernel's
 // 77 us (tools/probe_mark.hip).
+//
+// Spatial sharding (g.shard_world > 1, pair_list set): the (point, corner) pairs whose voxel THIS rank owns are also
+// listed -- (point << 3 | corner), corners of a workgroup's points in (corner, point) order so that neighbouring
+// pixels stay neighbours and the encoder's wave-level run reduction keeps working -- and the encoder then forms
+// its tiles from the list: 1 / world of the pairs instead of every tile that holds at least one owned pair
+// (with 8^3-voxel blocks that was ~60 % of the tiles at world 8).  One atomicAdd per WORKGROUP on the list counter.
 __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z, const bnv_grid_t& g,
-                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks) {
+                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks,
+                                           int point_index = 0, int32_t* __restrict__ pair_list = nullptr,
+                                           int32_t* __restrict__ n_pairs = nullptr) {
   int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
     const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
@@ -216,12 +227,45 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
   __shared__ int s_valid[4];
   const unsigned long long b = __ballot(valid);
   if (lane == 0) s_valid[threadIdx.x >> 6] = (int)__popcll(b);
-  __syncthreads();
+  if (pair_list) {   // (workgroup-uniform)
+    __shared__ int s_cnt[32];   // [corner][wave] owned pairs
+    unsigned long long own[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
+      own[k] = __ballot(valid && voxel_owner(gx, gy, gz, g) == g.shard_rank);
+      if (lane == 0) s_cnt[k * 4 + (threadIdx.x >> 6)] = (int)__popcll(own[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // exclusive prefix of the 32 counts (first wave), then the workgroup's place in the list
+      const int c = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0;
+      int incl = c;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((int)threadIdx.x >= d) incl += o;
+      }
+      const int total = __shfl(incl, 31, 64);
+      int base = 0;
+      if (threadIdx.x == 0 && total) base = atomicAdd(n_pairs, total);
+      base = __shfl(base, 0, 64);
+      if (threadIdx.x < 32) s_cnt[threadIdx.x] = base + incl - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((own[k] >> lane) & 1ull)
+        pair_list[s_cnt[k * 4 + (threadIdx.x >> 6)] + (int)__popcll(own[k] & ((1ull << lane) - 1ull))] =
+            (point_index << 3) | k;
+  } else {
+    __syncthreads();
+  }
   if (threadIdx.x == 0) valid_blocks[blockIdx.x] = s_valid[0] + s_valid[1] + s_valid[2] + s_valid[3];
 }
 
 __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
-                                              uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks) {
+                                              uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks,
+                                              int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool valid = false;
   float x = 0.f, y = 0.f, z = 0.f;
@@ -231,7 +275,7 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
     z = pts[(size_t)i * 6 + 2];
     valid = in_bounds(x, y, z, g);
   }
-  mark_point(valid, x, y, z, g, bitmap, valid_blocks);
+  mark_point(valid, x, y, z, g, bitmap, valid_blocks, i, pair_list, n_pairs);
 }
 
 // The same, fused behind the depth front end (frontend.hpp): one thread per PIXEL computes the pixel's world point
@@ -240,7 +284,8 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
 // are) and marks the point's voxels from the registers: the 7.4 MB of points are not read back, one launch less.
 __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restrict__ out_pts, bnv_grid_t g,
                                                     uint32_t* __restrict__ bitmap,
-                                                    int32_t* __restrict__ valid_blocks) {
+                                                    int32_t* __restrict__ valid_blocks,
+                                                    int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
   const int64_t n = (int64_t)a.H * a.W;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float p[6];
@@ -258,7 +303,7 @@ __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restri
     }
   }
   const bool valid = have && in_bounds(p[0], p[1], p[2], g);
-  mark_point(valid, p[0], p[1], p[2], g, bitmap, valid_blocks);
+  mark_point(valid, p[0], p[1], p[2], g, bitmap, valid_blocks, (int)i, pair_list, n_pairs);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -334,6 +379,37 @@ struct ValidFlags {  // 1 where the voxel in slot s is emitted
     return 1;
   }
 };
+
+// Tiles of the point encoder: 32 (point, corner) pairs.  Unsharded: tile t = corner t / n_pblocks of the 32 consecutive
+// points of block t % n_pblocks.  Sharded: 32 consecutive entries of the owned-pair list the mark kernel built.
+struct PairTiles {
+  const int32_t* list;   // null: unsharded
+  int n_pairs, n_points, n_pblocks, n_tiles;
+};
+__device__ __forceinline__ PairTiles pair_tiles(int n_points, const int32_t* __restrict__ pair_list,
+                                                const int32_t* __restrict__ n_pairs) {
+  PairTiles T;
+  T.list = pair_list;
+  T.n_points = n_points;
+  T.n_pblocks = (n_points + 31) >> 5;
+  T.n_pairs = pair_list ? *n_pairs : 0;
+  T.n_tiles = pair_list ? (T.n_pairs + 31) >> 5 : T.n_pblocks * 8;
+  return T;
+}
+// pair j of tile t -> point index and corner; false past the end
+__device__ __forceinline__ bool tile_pair(const PairTiles& T, int t, int j, int* i, int* k) {
+  if (T.list) {
+    const int e = t * 32 + j;
+    if (e >= T.n_pairs) return false;
+    const int p = T.list[e];
+    *i = p >> 3;
+    *k = p & 7;
+    return true;
+  }
+  *k = t / T.n_pblocks;
+  *i = (t - *k * T.n_pblocks) * 32 + j;
+  return *i < T.n_points;
+}
 
 // ------------------------------------------------------------------------------------------
 // k_pointnet_scatter
@@ -420,7 +496,8 @@ __device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, i
 __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
-    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+    int32_t* __restrict__ counts, long long* __restrict__ acc, const int32_t* __restrict__ pair_list,
+    const int32_t* __restrict__ n_pairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // stage all packed weights into LDS once per workgroup (persistent grid)
   for (int i = threadIdx.x * 4; i < PN_TOTAL; i += 512 * 4)
@@ -430,18 +507,17 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int n_pblocks = (n_points + 31) >> 5;
-  const int n_tiles = n_pblocks * 8;
+  const PairTiles T = pair_tiles(n_points, pair_list, n_pairs);
+  const int n_tiles = T.n_tiles;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
 
   for (int t = blockIdx.x * 8 + wave; t < n_tiles; t += gridDim.x * 8) {
-    const int k = t / n_pblocks;           // corner, uniform over the tile
-    const int pb = t - k * n_pblocks;
-    const int i = pb * 32 + j;
+    int i = 0, k = 0;
+    const bool have = tile_pair(T, t, j, &i, &k);
     float in0 = 0.f, in1 = 0.f, in2 = 0.f;  // this lane's half of the 6 inputs: features 2s + h
     int slot = -1;
     bool valid = false;
-    if (i < n_points) {
+    if (have) {
       const float* p = pts + (size_t)i * 6;
       const float x = p[0], y = p[1], z = p[2];
       valid = in_bounds(x, y, z, g);
@@ -596,7 +672,8 @@ template <int NPROD>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
-    int32_t* __restrict__ counts, long long* __restrict__ acc, int32_t* __restrict__ error) {
+    int32_t* __restrict__ counts, long long* __restrict__ acc, int32_t* __restrict__ error,
+    const int32_t* __restrict__ pair_list, const int32_t* __restrict__ n_pairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // Range certificate of the f16-split arithmetic (weights.py: certified_input_bound): with the relative
   // coordinates in [-1, 1] and |normal components| <= n_cert no value of any layer can reach the f16 overflow
@@ -614,8 +691,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int n_pblocks = (n_points + 31) >> 5;
-  const int n_tiles = n_pblocks * 8;
+  const PairTiles T = pair_tiles(n_points, pair_list, n_pairs);
+  const int n_tiles = T.n_tiles;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
 
   // Software pipeline over this wave's tiles: while tile t runs its MLP, the point of tile t+2 and the
@@ -632,7 +709,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
     c = __builtin_amdgcn_readfirstlane(c);
     return blockIdx.x * 8 + (c & 7) + (c >> 3) * tstep;
   };
-  float raw[6];                 // stage 1 (tile t+2): the raw point
+  float raw[6];                 // stage 1 (tile t+2): the raw point and its corner
+  int raw_k = 0;
   bool raw_ok = false;
   float nin[4];                 // stage 2 (tile t+1): network inputs, voxel id, its bitmap/prefix words
   uint32_t n_id = 0, n_word = 0, n_pref = 0;
@@ -640,9 +718,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   auto stage1 = [&](int t) {
     raw_ok = false;
     if (t < n_tiles) {
-      const int k = t / n_pblocks;
-      const int i = (t - k * n_pblocks) * 32 + j;
-      if (i < n_points) {
+      int i = 0;
+      if (tile_pair(T, t, j, &i, &raw_k)) {
         const float* p = pts + (size_t)i * 6;
 #pragma unroll
         for (int c = 0; c < 6; ++c) raw[c] = p[c];
@@ -655,7 +732,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
 #pragma unroll
     for (int c = 0; c < 4; ++c) nin[c] = 0.f;
     if (raw_ok && in_bounds(raw[0], raw[1], raw[2], g)) {
-      const int k = t / n_pblocks;
+      const int k = raw_k;
       const float xn = voxel_coord(raw[0], g.bound_min[0], g.voxel_size);
       const float yn = voxel_coord(raw[1], g.bound_min[1], g.voxel_size);
       const float zn = voxel_coord(raw[2], g.bound_min[2], g.voxel_size);
@@ -831,7 +908,8 @@ __device__ __forceinline__ f32x16 zero16() {
 __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
-    int32_t* __restrict__ counts, long long* __restrict__ acc) {
+    int32_t* __restrict__ counts, long long* __restrict__ acc, const int32_t* __restrict__ pair_list,
+    const int32_t* __restrict__ n_pairs) {
   __shared__ __attribute__((aligned(16))) _Float16 wh[PT_TOTAL];
   for (int i = threadIdx.x * 4; i < PT_TOTAL / 2; i += 256 * 4)
     *(f32x4*)&((float*)wh)[i] = *(const f32x4*)&wpack[i];
@@ -839,19 +917,19 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int n_pblocks = (n_points + 31) >> 5;
-  const int n_tiles = n_pblocks * 8;
+  const PairTiles T = pair_tiles(n_points, pair_list, n_pairs);
+  const int n_tiles = T.n_tiles;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
   for (int t = blockIdx.x * 4 + wave; t < n_tiles; t += gridDim.x * 4) {
-    const int k = t / n_pblocks;
-    const int i = (t - k * n_pblocks) * 32 + j;
+    int i = 0, k = 0;
+    const bool have = tile_pair(T, t, j, &i, &k);
     // operand slots of this lane half: features 8 (jj >> 2) + 4 h + (jj & 3); inputs 0..5, the rest 1.0
     half8 b;
 #pragma unroll
     for (int e = 0; e < 8; ++e) b[e] = (_Float16)1.0f;
     int slot = -1;
     bool valid = false;
-    if (i < n_points) {
+    if (have) {
       const float* p = pts + (size_t)i * 6;
       const float x = p[0], y = p[1], z = p[2];
       if (in_bounds(x, y, z, g)) {
@@ -944,6 +1022,7 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
       counters->error = ctl->error;
       counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
       ctl->error = 0;
+      ctl->n_pairs = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) ctl->shard_boundary[threadIdx.x] = 0;
     return;
@@ -992,6 +1071,7 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
         counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
         ctl->n_unique = 0;
         ctl->error = 0;
+        ctl->n_pairs = 0;
       }
       ctl->shard_boundary[threadIdx.x] = 0;
     }
@@ -1192,7 +1272,8 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   if (n_points == 0) return BNV_OK;
   const int n = (int)n_points;
-  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.valid_blocks);
+  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.valid_blocks,
+                     g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1213,7 +1294,7 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bitmap,
-                     ws.valid_blocks);
+                     ws.valid_blocks, g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1240,21 +1321,24 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
   const int n_tiles = ((n + 31) / 32) * 8;
   int grid_pn = g_num_cus - g_reserve_cus > 0 ? g_num_cus - g_reserve_cus : 1;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
+  const int32_t* plist = g.shard_world > 1 ? ws.pair_list : (const int32_t*)nullptr;   // sharded: owned pairs only
   {
     ProfScope prof(PROF_POINTNET, stream);
     if (g_mlp_mode == 2)
       hipLaunchKernelGGL(k_pointnet_scatter_t, dim3(g_num_cus * 4 < (n_tiles + 3) / 4 ? g_num_cus * 4 : (n_tiles + 3) / 4),
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
-                         ws.acc);
+                         ws.acc, plist, &ws.ctl->n_pairs);
     else if (g_mlp_mode == 1) {
       hipLaunchKernelGGL((k_pointnet_scatter_h<3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error);
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
+                         plist, &ws.ctl->n_pairs);
     } else if (g_mlp_mode == 3) {
       hipLaunchKernelGGL((k_pointnet_scatter_h<1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
-                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error);
+                         input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
+                         plist, &ws.ctl->n_pairs);
     } else
       hipLaunchKernelGGL(k_pointnet_scatter, dim3(grid_pn), dim3(512), PN_TOTAL * 4, stream, input_pts, n, g,
-                         pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+                         pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, plist, &ws.ctl->n_pairs);
   }
   BNV_LAUNCH_CHECK();
   // ordered compaction of the emitted voxels; the number of slots is only known on the device, so the grid covers
