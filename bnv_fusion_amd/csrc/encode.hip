@@ -95,12 +95,17 @@ struct EncodeWs {
   uint64_t* tile_state;   // [n_tiles] look-back state of k_rank / k_finalize (epoch-tagged, never cleared)
   int32_t* valid_blocks;  // [ceil(max_points / 256)] points that passed the bounds mask, per workgroup of the mark kernel
   int32_t* pair_list;     // [8 * max_points] sharded encode: (point << 3 | corner) of the pairs this rank owns
-  uint32_t* bitmap;       // [n_words]
+  uint8_t* bytemap;       // [n_words * 32] one byte per voxel: set by the mark kernel (plain stores), consumed and
+                          // cleared by k_rank
+  uint8_t* chunk_flag;    // [n_chunks] one byte per 64 voxels (2 bitmap words): any byte of the chunk set
+  uint32_t* bitmap;       // [n_words] one bit per touched voxel: written by k_rank, read by the encoder, cleared by
+                          // k_finalize
   uint32_t* word_prefix;  // [n_words]
   int32_t* ids;           // [max_unique] flat voxel id of slot s (ascending)
   int32_t* counts;        // [max_unique]
   long long* acc;         // [max_unique][8] fixed-point feature sums
   int64_t n_words;
+  int64_t n_chunks;       // n_words / 2
   int64_t max_unique;
   int64_t n_tiles;
 };
@@ -108,17 +113,18 @@ struct EncodeWs {
 constexpr int kScanThreads = 256;
 constexpr int kFinTile = kScanThreads;                 // 256 slots per workgroup (k_finalize: one per thread)
 constexpr int kRankItems = 4;
-constexpr int kRankTile = kScanThreads * kRankItems;  // 1024 bitmap words per workgroup (k_rank)
+constexpr int kRankTile = kScanThreads * kRankItems;  // 1024 chunks (of 64 voxels = 2 bitmap words) per workgroup (k_rank)
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char* base, EncodeWs* ws) {
   const int64_t nvox = (int64_t)n_xyz[0] * n_xyz[1] * n_xyz[2];
-  const int64_t n_words = align_up((size_t)((nvox + 31) / 32), 4);
+  const int64_t n_words = align_up((size_t)((nvox + 31) / 32), 8);   // whole chunks, whole u32x4 of chunk flags
+  const int64_t n_chunks = n_words / 2;
   int64_t max_unique = 8 * max_points;
   if (max_unique > nvox) max_unique = nvox;
   if (max_unique < 1) max_unique = 1;
-  const int64_t nb_words = (n_words + kRankTile - 1) / kRankTile;
+  const int64_t nb_words = (n_chunks + kRankTile - 1) / kRankTile;
   const int64_t nb_unique = (max_unique + kFinTile - 1) / kFinTile;
   const int64_t n_tiles = nb_words > nb_unique ? nb_words : nb_unique;
   size_t off = 0;
@@ -131,6 +137,8 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   char* p_state = take(n_tiles * 8);
   char* p_valid = take(((max_points + 255) / 256 + 1) * 4);
   char* p_pairs = take((size_t)(max_points > 0 ? max_points : 1) * 8 * 4);
+  char* p_bytes = take(n_words * 32);
+  char* p_chunks = take(n_chunks);
   char* p_bitmap = take(n_words * 4);
   char* p_prefix = take(n_words * 4);
   char* p_ids = take(max_unique * 4);
@@ -141,6 +149,9 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
     ws->tile_state = (uint64_t*)p_state;
     ws->valid_blocks = (int32_t*)p_valid;
     ws->pair_list = (int32_t*)p_pairs;
+    ws->bytemap = (uint8_t*)p_bytes;
+    ws->chunk_flag = (uint8_t*)p_chunks;
+    ws->n_chunks = n_chunks;
     ws->bitmap = (uint32_t*)p_bitmap;
     ws->word_prefix = (uint32_t*)p_prefix;
     ws->ids = (int32_t*)p_ids;
@@ -158,17 +169,16 @@ static uint32_t g_epoch = 0;
 uint32_t next_epoch() { return ++g_epoch; }
 
 // ------------------------------------------------------------------------------------------
-// mark: one thread per point; sets the bits of its 8 corner voxels in the grid bitmap
+// mark: one thread per point; flags its 8 corner voxels in the grid byte map
 // ------------------------------------------------------------------------------------------
-// ~20 pairs fall into each voxel and neighbouring pixels (= neighbouring lanes) mostly share it, so an atomic is
-// issued only when the previous lane targets a different voxel AND the bit is not already visible (a stale read
-// only costs a redundant atomicOr, never a missed one).  The floor-z and ceil-z corners of an (x, y) column are
-// neighbouring bits, nearly always of the same bitmap word: one visibility load and at most one atomicOr per
-// column instead of two.  The four columns' visibility loads are issued together (independent addresses), then
-// the atomics: one L2 round trip per point instead of four.  Every thread of the (256-thread) workgroup must call
-// this.  The number of valid points goes to valid_blocks[blockIdx.x] as a plain store: one atomicAdd per wave on a
-// single counter serialises in the memory-side atomic unit at ~11 ns each -- 4,800 of them were 52 of this kernel's
-// 77 us (tools/probe_mark.hip).
+// One BYTE per voxel, written with plain stores: setting a flag is idempotent, so no atomic is needed, nothing is
+// read back and nothing waits -- where the former bit map cost one visibility load + one device-scope atomicOr per
+// (point, column): 32 us of a 42 us kernel (tools/probe_mark.hip: 4 us with byte stores).  A second byte per 64-voxel
+// chunk lets k_rank find the touched chunks without reading the whole map (134 MB at 512^3).  ~20 pairs fall into each
+// voxel and neighbouring pixels (= neighbouring lanes) mostly share it: a lane skips a column its predecessor writes.
+// The number of valid points goes to valid_blocks[blockIdx.x] as a plain store: one atomicAdd per wave on a single
+// counter serialises in the memory-side atomic unit at ~11 ns each -- 4,800 of them were 52 us per frame.
+// Every thread of the (256-thread) workgroup must call this.
 //
 // Spatial sharding (g.shard_world > 1, pair_list set): the (point, corner) pairs whose voxel THIS rank owns are also
 // listed -- (point << 3 | corner), corners of a workgroup's points in (corner, point) order so that neighbouring
@@ -176,8 +186,9 @@ uint32_t next_epoch() { return ++g_epoch; }
 // its tiles from the list: 1 / world of the pairs instead of every tile that holds at least one owned pair
 // (with 8^3-voxel blocks that was ~60 % of the tiles at world 8).  One atomicAdd per WORKGROUP on the list counter.
 __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z, const bnv_grid_t& g,
-                                           uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks,
-                                           int point_index = 0, int32_t* __restrict__ pair_list = nullptr,
+                                           uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
+                                           int32_t* __restrict__ valid_blocks, int point_index = 0,
+                                           int32_t* __restrict__ pair_list = nullptr,
                                            int32_t* __restrict__ n_pairs = nullptr) {
   int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
@@ -190,38 +201,19 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
   }
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
   const int lane = threadIdx.x & 63;
-  int id0[4], id1[4];
-  uint32_t w0[4], w1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy;
-    // duplicates (floor == ceil) would set the same bit again
-    const bool dup = ((k & 1) && cx == fx) || ((k & 2) && cy == fy);
-    int a = (valid && !dup) ? (gx * nyz + gy * g.n_xyz[2] + fz) : -1;
-    int b = (a >= 0 && cz != fz) ? a + (cz - fz) : -1;
+    int a = valid ? (gx * nyz + gy * g.n_xyz[2] + fz) : -1;   // (floor == ceil duplicates just set the flag again)
+    int b = valid ? a + (cz - fz) : -1;
     const int p0 = __shfl_up(a, 1), p1 = __shfl_up(b, 1);
-    if (lane > 0 && p0 == a && p1 == b) a = b = -1;   // the previous lane sets the very same bits
-    id0[k] = a;
-    id1[k] = b;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    w0[k] = id0[k] >= 0 ? bitmap[id0[k] >> 5] : 0u;
-    w1[k] = (id1[k] >= 0 && (id1[k] >> 5) != (id0[k] >> 5)) ? bitmap[id1[k] >> 5] : 0u;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (id0[k] < 0) continue;
-    const uint32_t bit0 = 1u << (id0[k] & 31);
-    if (id1[k] >= 0 && (id1[k] >> 5) == (id0[k] >> 5)) {
-      const uint32_t bits = bit0 | (1u << (id1[k] & 31));
-      if ((w0[k] & bits) != bits) atomicOr(&bitmap[id0[k] >> 5], bits);
-    } else {
-      if (!(w0[k] & bit0)) atomicOr(&bitmap[id0[k] >> 5], bit0);
-      if (id1[k] >= 0) {
-        const uint32_t bit1 = 1u << (id1[k] & 31);
-        if (!(w1[k] & bit1)) atomicOr(&bitmap[id1[k] >> 5], bit1);
-      }
+    if (lane > 0 && p0 == a && p1 == b) continue;   // the previous lane flags the very same voxels
+    if (a < 0) continue;
+    bytemap[a] = 1;
+    chunk_flag[a >> 6] = 1;
+    if (b != a) {
+      bytemap[b] = 1;
+      if ((b >> 6) != (a >> 6)) chunk_flag[b >> 6] = 1;
     }
   }
   __shared__ int s_valid[4];
@@ -264,7 +256,8 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
 }
 
 __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
-                                              uint32_t* __restrict__ bitmap, int32_t* __restrict__ valid_blocks,
+                                              uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
+                                              int32_t* __restrict__ valid_blocks,
                                               int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool valid = false;
@@ -275,7 +268,7 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
     z = pts[(size_t)i * 6 + 2];
     valid = in_bounds(x, y, z, g);
   }
-  mark_point(valid, x, y, z, g, bitmap, valid_blocks, i, pair_list, n_pairs);
+  mark_point(valid, x, y, z, g, bytemap, chunk_flag, valid_blocks, i, pair_list, n_pairs);
 }
 
 // The same, fused behind the depth front end (frontend.hpp): one thread per PIXEL computes the pixel's world point
@@ -283,7 +276,7 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
 // pixel: rows stay in pixel order, nothing is compacted -- the encoder's bounds mask drops NaN rows wherever they
 // are) and marks the point's voxels from the registers: the 7.4 MB of points are not read back, one launch less.
 __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restrict__ out_pts, bnv_grid_t g,
-                                                    uint32_t* __restrict__ bitmap,
+                                                    uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
                                                     int32_t* __restrict__ valid_blocks,
                                                     int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
   const int64_t n = (int64_t)a.H * a.W;
@@ -303,27 +296,56 @@ __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restri
     }
   }
   const bool valid = have && in_bounds(p[0], p[1], p[2], g);
-  mark_point(valid, p[0], p[1], p[2], g, bitmap, valid_blocks, (int)i, pair_list, n_pairs);
+  mark_point(valid, p[0], p[1], p[2], g, bytemap, chunk_flag, valid_blocks, (int)i, pair_list, n_pairs);
 }
 
 // ------------------------------------------------------------------------------------------
-// rank: sorted-unique without a sort.  One pass over the bitmap (decoupled look-back over the workgroups):
-// word_prefix[w] = set bits before word w, ids[] = the set bits in ascending order (= torch.unique's output),
-// ctl->n_unique = their number.
+// rank: sorted-unique without a sort.  One pass over the chunk flags (decoupled look-back over the workgroups); a
+// flagged chunk's 64 voxel bytes become two bitmap words (and are cleared, with the flag, for the next frame):
+// bitmap = one bit per touched voxel, word_prefix[w] = set bits before word w, ids[] = the set bits in ascending
+// order (= torch.unique's output), ctl->n_unique = their number.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanThreads) void k_rank(const uint32_t* __restrict__ bitmap, int64_t n_words,
-                                                       uint64_t* __restrict__ tile_state, uint32_t epoch,
+__device__ __forceinline__ uint32_t bytes_to_bits16(const uint32_t (&v)[4]) {
+  // 16 flag bytes (0 / 1) -> 16 bits: (b0 | b1 << 8 | b2 << 16 | b3 << 24) * 0x01020408 has b0..b3 in bits 24..27
+  uint32_t r = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) r |= (((v[q] * 0x01020408u) >> 24) & 0xFu) << (4 * q);
+  return r;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
+                                                       int64_t n_chunks, uint64_t* __restrict__ tile_state,
+                                                       uint32_t epoch, uint32_t* __restrict__ bitmap,
                                                        uint32_t* __restrict__ word_prefix,
                                                        int32_t* __restrict__ ids, int64_t max_unique,
                                                        EncCtl* __restrict__ ctl, bnv_grid_t g) {
   __shared__ uint32_t wave_tot[kScanThreads / 64];
   __shared__ uint32_t s_excl;
   __shared__ int s_hist[64];
-  const int64_t base = (int64_t)blockIdx.x * kRankTile + (int64_t)threadIdx.x * kRankItems;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 w = {0u, 0u, 0u, 0u};
-  if (base < n_words) w = *(const u32x4*)&bitmap[base];   // n_words is a multiple of 4
-  const uint32_t s = __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+  const int64_t base = (int64_t)blockIdx.x * kRankTile + (int64_t)threadIdx.x * kRankItems;   // first chunk
+  uint32_t flags = 0;
+  if (base < n_chunks) flags = *(const uint32_t*)&chunk_flag[base];   // 4 chunk flags (n_chunks is a multiple of 4)
+  uint32_t w[2 * kRankItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int e = 0; e < kRankItems; ++e) {
+    w[2 * e] = w[2 * e + 1] = 0u;
+    if ((flags >> (8 * e)) & 0xffu) {
+      u32x4* src = (u32x4*)&bytemap[(base + e) * 64];
+      const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int hw = 0; hw < 2; ++hw) {
+        const u32x4 lo = src[2 * hw], hi = src[2 * hw + 1];
+        const uint32_t l4[4] = {lo[0], lo[1], lo[2], lo[3]}, h4[4] = {hi[0], hi[1], hi[2], hi[3]};
+        w[2 * e + hw] = bytes_to_bits16(l4) | (bytes_to_bits16(h4) << 16);
+        src[2 * hw] = z;       // consumed: clean for the next frame
+        src[2 * hw + 1] = z;
+      }
+      s += __popc(w[2 * e]) + __popc(w[2 * e + 1]);
+    }
+  }
+  if (flags) *(uint32_t*)&chunk_flag[base] = 0u;
   if (g.shard_world > 1 && threadIdx.x < 64) s_hist[threadIdx.x] = 0;
   uint32_t total;
   uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
@@ -339,14 +361,16 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(const uint32_t* __restric
   run += s_excl;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
 #pragma unroll
-  for (int e = 0; e < kRankItems; ++e) {
+  for (int e = 0; e < 2 * kRankItems; ++e) {
     uint32_t bits = w[e];
     if (!bits) continue;
-    word_prefix[base + e] = run;
+    const int64_t word = base * 2 + e;
+    bitmap[word] = bits;
+    word_prefix[word] = run;
     while (bits) {
       const int b = __ffs(bits) - 1;
       bits &= bits - 1;
-      const int id = (int)((base + e) * 32 + b);
+      const int id = (int)(word * 32 + b);
       if (run < max_unique) ids[run] = id;
       else ctl->error = 1;
       ++run;
@@ -1243,9 +1267,9 @@ int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream) {
 // finish = PointNet + scatter-mean + min-points filter + ordered compaction.  Everything between the two lives in
 // the workspace; bnv_encode_pointcloud is begin + finish.
 static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, hipStream_t stream) {
-  const int nb_words = (int)((ws.n_words + kRankTile - 1) / kRankTile);
-  hipLaunchKernelGGL(k_rank, dim3(nb_words), dim3(kScanThreads), 0, stream, ws.bitmap, ws.n_words, ws.tile_state,
-                     next_epoch(), ws.word_prefix, ws.ids, ws.max_unique, ws.ctl, g);
+  const int nb_chunks = (int)((ws.n_chunks + kRankTile - 1) / kRankTile);
+  hipLaunchKernelGGL(k_rank, dim3(nb_chunks), dim3(kScanThreads), 0, stream, ws.bytemap, ws.chunk_flag, ws.n_chunks,
+                     ws.tile_state, next_epoch(), ws.bitmap, ws.word_prefix, ws.ids, ws.max_unique, ws.ctl, g);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -1272,7 +1296,8 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   if (n_points == 0) return BNV_OK;
   const int n = (int)n_points;
-  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bitmap, ws.valid_blocks,
+  hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bytemap, ws.chunk_flag,
+                     ws.valid_blocks,
                      g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
@@ -1293,8 +1318,8 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   FrontArgs a;
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
-  hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bitmap,
-                     ws.valid_blocks, g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+  hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bytemap,
+                     ws.chunk_flag, ws.valid_blocks, g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
