@@ -1596,6 +1596,23 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   return off;
 }
 
+constexpr int kOriginBit = 1 << 30;   // flag in nbr_rows entries (rows are < 2^30)
+
+// origin_stamp[row of origin b] = epoch: which rows are decoded origins of this call
+__global__ __launch_bounds__(256) void k_lattice_stamp(bnv_volume_t v, const int64_t* __restrict__ origins, int64_t n,
+                                                       int64_t row_limit, int32_t* __restrict__ origin_stamp,
+                                                       int32_t epoch, const int32_t* __restrict__ n_dev,
+                                                       int32_t* __restrict__ n_list) {
+  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the control words of the stages behind (entries listed, tile counter of the table kernel, spare) are cleared
+  // here: saves bnv_decode_lattice a memset launch per call
+  if (n_list && b == 0) n_list[1] = n_list[2] = n_list[3] = 0;
+  if (b >= n) return;
+  const int row = volume_row(v, origins[b * 3 + 0], origins[b * 3 + 1], origins[b * 3 + 2]);
+  if (row >= 0 && row < row_limit) origin_stamp[row] = epoch;
+}
+
 __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const int64_t* __restrict__ origins,
                                                            int64_t n, const float* __restrict__ weights,
                                                            int64_t row_limit, float min_pts,
@@ -1607,9 +1624,6 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;  // count from device memory; n = grid capacity
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // without a row list to build, the control words of the stages behind this one (entries listed, tile counter of
-  // the table kernel, spare) are cleared here: saves bnv_decode_lattice a memset launch per call
-  if (!list && t == 0) n_list[1] = n_list[2] = n_list[3] = 0;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
   const int nb = (int)(t - b * 27);
@@ -1622,9 +1636,12 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   if (row >= row_limit) row = -1;
   bool usable = false;
   if (row >= 0) usable = weights[row] >= min_pts;
-  // rows below min_pts can only ever appear under a false mask: mark them as unusable corners
-  nbr_rows[t] = usable ? row : -1;
-  if (nb == 13 && row >= 0 && origin_stamp) origin_stamp[row] = epoch;  // this row is a decoded origin of this call
+  // rows below min_pts can only ever appear under a false mask: mark them as unusable corners.  Bit 30 of a usable
+  // row: its voxel is itself a decoded origin of this call (k_lattice_stamp ran first), which the live-entry marking
+  // needs for the owner test -- read here next to the row's weight instead of a dependent gather per lattice point
+  // there (~1 M scattered loads per frame).
+  const bool is_origin = usable && origin_stamp && origin_stamp[row] == epoch;
+  nbr_rows[t] = usable ? (row | (is_origin ? kOriginBit : 0)) : -1;
   // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
   if (usable && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
     list[atomicAdd(n_list, 1)] = row;
@@ -1696,7 +1713,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         }
         const int row = nb27[nbi];
         if (row < 0) live = false;
-        rowk[k] = dup ? -1 : row;
+        rowk[k] = dup ? -1 : (row & ~kOriginBit);
         lk[k] = li;
       }
       // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
@@ -1708,25 +1725,16 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
       bool shared = false;
       if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
         const int owner = nb27[((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
-        if (owner >= 0 && origin_stamp[owner] == epoch) live = false;
+        if (owner >= 0 && (owner & kOriginBit)) live = false;
         shared = true;
       }
-      // append, wave-aggregated: one LDS atomic per wave and corner (64 lanes adding 1 to the same LDS word
-      // serialise 64-fold: that was this kernel's time)
+      if (live) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        bool add = live && rowk[k] >= 0;
-        if (add && shared) {
+        for (int k = 0; k < 8; ++k) {
+          if (rowk[k] < 0) continue;
           const uint32_t bit = 1u << lk[k];
-          add = !(atomicOr(&need_mask[rowk[k]], bit) & bit);
-        }
-        const unsigned long long m = __ballot(add);
-        if (m) {
-          const int lane = threadIdx.x & 63;
-          int base = 0;
-          if (lane == (int)__ffsll((long long)m) - 1) base = atomicAdd(&s_count, (int)__popcll(m));
-          base = __shfl(base, (int)__ffsll((long long)m) - 1, 64);
-          if (add) s_buf[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (rowk[k] << 5) | lk[k];
+          if (shared && (atomicOr(&need_mask[rowk[k]], bit) & bit)) continue;
+          s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];   // (a wave-aggregated append was slower: 50 vs 41 us)
         }
       }
     }
@@ -1801,6 +1809,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
       rowk[k] = nb27[nbi];
       lk[k] = li;
       if (rowk[k] < 0) ok = false;
+      rowk[k] &= ~kOriginBit;
     }
     if (!ok) {   // masked point (about half of them on a thin sheet): the constant, no table reads
       out[t] = g.voxel_size;
@@ -1840,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
     }
     wk[k] = w;
     lk[k] = li;
-    rowk[k] = nb27[nbi];
+    rowk[k] = nb27[nbi] < 0 ? -1 : (nb27[nbi] & ~kOriginBit);
     norm = __fadd_rn(norm, w);
   }
   bool ok = true;
@@ -2096,6 +2105,9 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   if (build_list) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 16, stream));  // rows listed, (entries), tile counter, spare
   if (n == 0) return BNV_OK;
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_lattice_stamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, origins, n,
+                     row_limit, ws.origin_stamp, epoch, n_dev, build_list ? (int32_t*)nullptr : ws.n_list);
+  BNV_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
                      n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
                      build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp, n_dev);
