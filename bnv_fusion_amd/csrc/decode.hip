@@ -1655,10 +1655,19 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
 // atomics serialise in the memory-side atomic unit at ~11 ns each, tools/probe_mark.hip: one per 1,024 points was
 // 29 us of serial time per frame; a decoupled look-back in its place was slower still, 57-78 us, because every
 // workgroup then ends with two or three dependent memory round trips.)
-constexpr int kMarkThreads = 1024;
-constexpr int kMarkChunks = 4;
+#ifndef BNV_MARK_THREADS
+#define BNV_MARK_THREADS 1024
+#endif
+#ifndef BNV_MARK_CHUNKS
+#define BNV_MARK_CHUNKS 2
+#endif
+#ifndef BNV_MARK_SCAN
+#define BNV_MARK_SCAN 0
+#endif
+constexpr int kMarkThreads = BNV_MARK_THREADS;
+constexpr int kMarkChunks = BNV_MARK_CHUNKS;
 constexpr int kMarkOrigins = kMarkThreads / 27 + 2;   // origins a chunk's lattice points can belong to
-constexpr int kMarkBuf = 16384;                       // LDS entry buffer; a chunk appends at most 8 * 1024
+constexpr int kMarkBuf = kMarkChunks > 1 ? 16 * kMarkThreads : 8 * kMarkThreads;   // LDS entry buffer; a chunk appends at most 8 per thread
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
@@ -1670,8 +1679,42 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
   __shared__ int s_buf[kMarkBuf];
   __shared__ int s_nbr[kMarkOrigins * 27];
+  __shared__ int s_corner[216 + 27];
+#if BNV_MARK_SCAN
+  __shared__ uint32_t s_wave[kMarkThreads / 64];
+#endif
   __shared__ int s_count, s_base;
   if (threadIdx.x == 0) s_count = 0;
+  if (threadIdx.x < 216 + 27) {
+    if (threadIdx.x < 216) {
+      const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
+      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+      int nbi = 0, li = 0, dup = 0;   // ceil == floor on an axis with d == 0: same entry as the floor corner
+      for (int a = 0; a < 3; ++a) {
+        int nb_a = 0, loc2 = 0;
+        if (d[a] != 0) {
+          if ((k >> a) & 1) {
+            nb_a = (d[a] + 1) / 2;
+            loc2 = -1;
+          } else {
+            nb_a = (d[a] - 1) / 2;
+            loc2 = 1;
+          }
+        } else if ((k >> a) & 1) {
+          dup = 1;
+        }
+        nbi = nbi * 3 + (nb_a + 1);
+        li = li * 3 + (loc2 + 1);
+      }
+      s_corner[threadIdx.x] = nbi | (li << 5) | (dup << 10);
+    } else {
+      const int p = threadIdx.x - 216;
+      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+      s_corner[threadIdx.x] = (d[0] < 0 || d[1] < 0 || d[2] < 0)
+                                  ? ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)
+                                  : -1;
+    }
+  }
   for (int ch = 0; ch < kMarkChunks; ++ch) {
     const int64_t t0 = ((int64_t)blockIdx.x * kMarkChunks + ch) * kMarkThreads;
     const bool last = ch == kMarkChunks - 1 || t0 + kMarkThreads >= n * 27;
@@ -1683,38 +1726,23 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     }
     __syncthreads();
     const int64_t t = t0 + threadIdx.x;
+    int ent[8];
+    uint32_t keep = 0;    // bit k: corner k's entry is appended by this thread
     if (t < n * 27) {
       const int64_t b = t / 27;
       const int p = (int)(t - b * 27);
       const int* nb27 = s_nbr + (int)(b - b0) * 27;
-      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+      // corner k of lattice point p: neighbour index, local-offset index and the duplicate flag from a 216-entry
+      // table (the index arithmetic was most of this kernel's time)
       int rowk[8], lk[8];
       bool live = true;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        int nbi = 0, li = 0;
-        bool dup = false;  // ceil == floor on an axis with d == 0: same entry as the floor corner
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          int nb_a = 0, loc2 = 0;
-          if (d[a] != 0) {
-            if ((k >> a) & 1) {
-              nb_a = (d[a] + 1) / 2;
-              loc2 = -1;
-            } else {
-              nb_a = (d[a] - 1) / 2;
-              loc2 = 1;
-            }
-          } else if ((k >> a) & 1) {
-            dup = true;
-          }
-          nbi = nbi * 3 + (nb_a + 1);
-          li = li * 3 + (loc2 + 1);
-        }
-        const int row = nb27[nbi];
+        const int c = s_corner[p * 8 + k];     // nbi | li << 5 | dup << 10
+        const int row = nb27[c & 31];
         if (row < 0) live = false;
-        rowk[k] = dup ? -1 : (row & ~kOriginBit);
-        lk[k] = li;
+        rowk[k] = (c >> 10) ? -1 : (row & ~kOriginBit);
+        lk[k] = (c >> 5) & 31;
       }
       // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
       // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
@@ -1722,23 +1750,48 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
       // needs no de-duplication: this voxel is the owner (all offsets >= 0, floor(point) == voxel) -> plain append.
       // Only a point whose owner voxel is NOT decoded in this call can be reached from several voxels; those few go
       // through the need_mask atomics.
+      const int dneg = s_corner[216 + p];        // owner's neighbour index if some offset is negative, else -1
       bool shared = false;
-      if (live && (d[0] < 0 || d[1] < 0 || d[2] < 0)) {
-        const int owner = nb27[((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)];
+      if (live && dneg >= 0) {
+        const int owner = nb27[dneg];
         if (owner >= 0 && (owner & kOriginBit)) live = false;
         shared = true;
       }
       if (live) {
+        // the (few) shared points: all 8 atomics are issued before any result is looked at -- one memory round
+        // trip instead of eight dependent ones (every 1,024-thread workgroup holds some shared point, and a
+        // workgroup is as slow as its slowest thread)
+        uint32_t seen[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          seen[k] = (shared && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          if (rowk[k] < 0) continue;
-          const uint32_t bit = 1u << lk[k];
-          if (shared && (atomicOr(&need_mask[rowk[k]], bit) & bit)) continue;
-          s_buf[atomicAdd(&s_count, 1)] = (rowk[k] << 5) | lk[k];   // (a wave-aggregated append was slower: 50 vs 41 us)
+          ent[k] = (rowk[k] << 5) | lk[k];
+          if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) keep |= 1u << k;
         }
       }
     }
+#if BNV_MARK_SCAN
+    // the threads' places in the LDS buffer: one block-wide scan of the counts (no LDS atomics)
+    uint32_t tot;
+    const uint32_t off = block_exclusive_scan<kMarkThreads>((uint32_t)__popc(keep), s_wave, &tot);
+    const int at = s_count + (int)off;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((keep >> k) & 1u) s_buf[at + __popc(keep & ((1u << k) - 1u))] = ent[k];
     __syncthreads();
+    if (threadIdx.x == 0) s_count += (int)tot;
+    __syncthreads();
+#else
+    if (keep) {
+      const int at = atomicAdd(&s_count, __popc(keep));
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if ((keep >> k) & 1u) s_buf[at + __popc(keep & ((1u << k) - 1u))] = ent[k];
+    }
+    __syncthreads();
+#endif
     const int cnt = s_count;
     if (cnt > 0 && (last || cnt > kMarkBuf - 8 * kMarkThreads)) {   // flush (block-uniform)
       if (threadIdx.x == 0) {

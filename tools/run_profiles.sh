@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects everything profiles/<round>_* is built from (run on the GPU box through gpurun; tools/make_profiles.py then
+# builds the committed summaries from gpurun_out/).  Kernel trace and PMC passes are separate runs, as the pool requires.
+set -u
+R=${1:-r02}
+O=gpurun_out/$R
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt-mode --no-stream-overlap"
+python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
+python3 bench.py --checkpoint tcnn --no-cpu-baseline > $O/bench_line_tcnn.json 2> $O/bench_line_tcnn.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $BENCH > $O/trace_stdout.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc1 -o p -- $BENCH > $O/pmc1.log 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc2 -o p -- $BENCH > $O/pmc2.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc3 -o p -- $BENCH > $O/pmc3.log 2>&1
+python3 tools/spatial_single_rank.py --world 8 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids" > $O/spatial_world8.txt
+python3 tools/spatial_single_rank.py --world 2 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids" > $O/spatial_world2.txt
+python3 tools/fp_single_rank.py --replay 8 > $O/fp_replay8.txt 2>&1
+ls -la $O
