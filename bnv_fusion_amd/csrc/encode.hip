@@ -1,14 +1,17 @@
 // encode.hip -- LitFusionPointNet.encode_pointcloud (reference local_point_fusion.py:81-165)
-// as five gfx950 kernels:
+// as four gfx950 kernels (bnv_encode_begin = the first two, bnv_encode_finish = the last two):
 //
-//   k_mark            points -> 8 corner voxels -> atomicOr into a grid bitmap            (HBM/L2)
-//   k_scan_*          popcount prefix over the bitmap: the rank of a voxel's bit IS its
-//                     position in torch.unique's ascending output (replaces sort+unique)  (HBM/L2)
-//   k_pointnet_scatter  per (point, corner) pair: 6->128->128->128->8 MLP on fp32 MFMA
-//                     (v_mfma_f32_32x32x2_f32, transposed chaining: layer L's D registers are
-//                     layer L+1's B operands, no cross-lane traffic), then order-independent
-//                     64-bit fixed-point atomics into per-voxel accumulators               (MFMA)
-//   k_finalize_*      mean, min-points filter, ordered compaction, unflatten, cleanup      (HBM)
+//   k_mark / k_front_mark  points (or depth pixels: front end fused in, frontend.hpp) -> 8 corner voxels ->
+//                     flag bytes in a grid byte map, plain stores, no atomics                 (HBM)
+//   k_rank            one pass over the flagged chunks (decoupled look-back): bitmap words + popcount prefix --
+//                     the rank of a voxel's bit IS its position in torch.unique's ascending output
+//                     (replaces sort+unique)                                                   (HBM/L2)
+//   k_pointnet_scatter[_h|_t]  per (point, corner) pair: 6->128->128->128->8 MLP on MFMA
+//                     (transposed chaining: layer L's D registers are layer L+1's B operands, no
+//                     cross-lane traffic), then order-independent 64-bit fixed-point atomics into
+//                     per-voxel accumulators                                                   (MFMA)
+//   k_finalize        mean, min-points filter, ordered compaction in one pass (look-back), unflatten,
+//                     scratch cleanup, the frame's counters                                    (HBM)
 //
 // Layout of one MFMA tile: 32 pairs = 32 consecutive points x one corner; lane l = (j = l & 31:
 // pair, h = l >> 5).  D register r of a 32-feature block holds feature (r&3) + 8*(r>>2) + 4*h of
