@@ -134,8 +134,8 @@ def load():
         "bnv_tsdf_integrate_u16": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float, vp, vp,
                                          C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
                                          vp, vp]),
-        "bnv_tsdf_integrate_batch_u16": (C.c_int, [vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
-                                                   C.c_int, vp, C.c_int, C.c_int, C.POINTER(C.c_float),
+        "bnv_tsdf_integrate_batch_u16": (C.c_int, [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                                   C.c_int, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                    C.POINTER(C.c_float), C.c_float, C.c_float, vp]),
         "bnv_set_mlp_mode": (C.c_int, [C.c_int]),
         "bnv_get_mlp_mode": (C.c_int, []),

@@ -73,11 +73,13 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate(TsdfArgs a) {
 
 // Several consecutive frames in one launch (the replay loop of the frame-parallel multi-GPU mode): the voxel's
 // tsdf / weight stay in registers between frames, every frame applies exactly the single-frame arithmetic above,
-// in frame order -> identical results to one launch per frame.  Depth only (no colour volume).
+// in frame order -> identical results to one launch per frame.  Colour (optional, per frame) follows the same rule.
 constexpr int kTsdfBatchMax = BNV_TSDF_BATCH_MAX;
 struct TsdfBatchArgs {
   float* tsdf;
   float* weight;
+  float* color;                            // may be null
+  const float* color_im[kTsdfBatchMax];    // folded b*65536 + g*256 + r per frame, or null
   int dim[3];
   float origin[3];
   float voxel_size, trunc_margin, obs_weight, max_depth;
@@ -97,8 +99,8 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_batch(TsdfBatchArgs a) {
   const float pt_x = a.origin[0] + (float)vx * a.voxel_size;
   const float pt_y = a.origin[1] + (float)vy * a.voxel_size;
   const float pt_z = a.origin[2] + (float)vz * a.voxel_size;
-  bool loaded = false;
-  float w_cur = 0.f, t_cur = 0.f;
+  bool loaded = false, c_dirty = false;
+  float w_cur = 0.f, t_cur = 0.f, c_cur = 0.f;
   for (int f = 0; f < a.n_frames; ++f) {
     const float* P = a.pose[f];
     const float tx = pt_x - P[3], ty = pt_y - P[7], tz = pt_z - P[11];
@@ -116,15 +118,29 @@ __global__ __launch_bounds__(256) void k_tsdf_integrate_batch(TsdfBatchArgs a) {
     if (!loaded) {
       w_cur = a.weight[idx];
       t_cur = a.tsdf[idx];
+      if (a.color) c_cur = a.color[idx];
       loaded = true;
     }
     const float w_new = w_cur + a.obs_weight;
     t_cur = (t_cur * w_cur + a.obs_weight * dist) / w_new;
+    if (a.color && a.color_im[f]) {  // fusion.py:127-139, as k_tsdf_integrate
+      const float ob = floorf(c_cur / 65536.f), og = floorf((c_cur - ob * 65536.f) / 256.f);
+      const float orr = c_cur - ob * 65536.f - og * 256.f;
+      const float nc = a.color_im[f][(size_t)py * a.im_w + px];
+      float nb = floorf(nc / 65536.f), ng = floorf((nc - nb * 65536.f) / 256.f);
+      float nr = nc - nb * 65536.f - ng * 256.f;
+      nb = fminf(roundf((ob * w_cur + a.obs_weight * nb) / w_new), 255.0f);
+      ng = fminf(roundf((og * w_cur + a.obs_weight * ng) / w_new), 255.0f);
+      nr = fminf(roundf((orr * w_cur + a.obs_weight * nr) / w_new), 255.0f);
+      c_cur = nb * 65536.f + ng * 256.f + nr;
+      c_dirty = true;
+    }
     w_cur = w_new;
   }
   if (loaded) {
     a.weight[idx] = w_cur;
     a.tsdf[idx] = t_cur;
+    if (c_dirty) a.color[idx] = c_cur;
   }
 }
 
@@ -185,9 +201,10 @@ extern "C" int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, 
                              color_im, im_h, im_w, intr_host, pose_host, obs_weight, max_depth, gate, stream);
 }
 
-extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3],
+extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
                                             const float origin_host[3], float voxel_size, float trunc_margin,
-                                            int n_frames, const uint16_t* const* depth_mm, int im_h, int im_w,
+                                            int n_frames, const uint16_t* const* depth_mm,
+                                            const float* const* color_im, int im_h, int im_w,
                                             const float* intr_host, const float* pose_host, float obs_weight,
                                             float max_depth, bnv_stream_t stream) {
   if (!tsdf || !weight || !dim_host || !origin_host || !depth_mm || !intr_host || !pose_host || im_h <= 0 || im_w <= 0 ||
@@ -197,6 +214,7 @@ extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const in
   TsdfBatchArgs a = {};
   a.tsdf = tsdf;
   a.weight = weight;
+  a.color = (color && color_im) ? color : nullptr;
   for (int i = 0; i < 3; ++i) {
     a.dim[i] = dim_host[i];
     a.origin[i] = origin_host[i];
@@ -211,6 +229,7 @@ extern "C" int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const in
   for (int f = 0; f < n_frames; ++f) {
     if (!depth_mm[f]) return BNV_ERR_INVALID_ARGUMENT;
     a.depth_mm[f] = depth_mm[f];
+    a.color_im[f] = a.color ? color_im[f] : nullptr;
     const float* K = intr_host + 9 * f;
     a.intr[f][0] = K[0];
     a.intr[f][1] = K[2];

@@ -444,13 +444,10 @@ class HipFrameBackend:
         if self.tsdf_vol is None:
             return
         fr = [f for i, f in enumerate(frames) if "depth" in f and (n_valid is None or n_valid[i])]
-        if any(f.get("rgb") is not None for f in fr):
-            for f in fr:
-                self.tsdf_vol.integrate(f.get("rgb"), f["depth"], f["intr_mat"], f["T_wc"], obs_weight=1.,
-                                        max_depth=self.max_depth)
-        elif fr:
+        if fr:
             self.tsdf_vol.integrate_batch([f["depth"] for f in fr], [f["intr_mat"] for f in fr],
-                                          [f["T_wc"] for f in fr], obs_weight=1., max_depth=self.max_depth)
+                                          [f["T_wc"] for f in fr], obs_weight=1., max_depth=self.max_depth,
+                                          color_ims=[f.get("rgb") for f in fr])
 
     def decode_record(self, hdr, payload, rows, n_out):
         grid_ids, _, _ = payload_views(payload, rows)

@@ -39,10 +39,7 @@ class TSDFVolume:
         u16 = depth.dtype in (torch.uint16, torch.int16)     # the dataset's millimetres: converted in the kernel
         depth = depth.to(self._dev).contiguous() if u16 else depth.to(self._dev, torch.float32).contiguous()
         im_h, im_w = int(depth.shape[0]), int(depth.shape[1])
-        col = None
-        if color_im is not None:
-            c = torch.as_tensor(color_im).to(self._dev, torch.float32)
-            col = torch.floor(c[..., 2] * self._color_const + c[..., 1] * 256 + c[..., 0]).contiguous()  # :223-224
+        col = self._fold_color(color_im)
         dim = (C.c_int32 * 3)(*[int(v) for v in self._vol_dim])
         org = (C.c_float * 3)(*self._vol_origin.tolist())
         intr = (C.c_float * 9)(*np.asarray(cam_intr, dtype=np.float64)[:3, :3].reshape(-1).astype(np.float32).tolist())
@@ -53,18 +50,28 @@ class TSDFVolume:
             np.float32(self._voxel_size), np.float32(self._trunc_margin), _lib.ptr(depth), _lib.ptr(col), im_h, im_w,
             intr, pose, float(obs_weight), float(max_depth or 0.0), _lib.ptr(gate), _lib.stream_ptr()), "bnv_tsdf_integrate")
 
+    def _fold_color(self, color_im):
+        """[H, W, 3] colour in [0, 255] -> the folded b*65536 + g*256 + r image of fusion.py:223-224 (or None)."""
+        if color_im is None:
+            return None
+        c = torch.as_tensor(color_im).to(self._dev, torch.float32)
+        return torch.floor(c[..., 2] * self._color_const + c[..., 1] * 256 + c[..., 0]).contiguous()
+
     BATCH_MAX = 8     # BNV_TSDF_BATCH_MAX
 
-    def integrate_batch(self, depth_ims, cam_intrs, cam_poses, obs_weight=1., max_depth=None):
-        """``integrate`` (without colour) for several consecutive uint16-millimetre depth frames of one size, one
-        launch per BATCH_MAX frames; results identical to one call per frame in order."""
+    def integrate_batch(self, depth_ims, cam_intrs, cam_poses, obs_weight=1., max_depth=None, color_ims=None):
+        """``integrate`` for several consecutive uint16-millimetre depth frames of one size (``color_ims``: their colour
+        images or None, per frame), one launch per BATCH_MAX frames; results identical to one call per frame in order."""
         ims = [torch.as_tensor(d) for d in depth_ims]
         if not ims:
             return
+        cols = list(color_ims) if color_ims is not None else [None] * len(ims)
         if any(d.dtype not in (torch.uint16, torch.int16) or d.shape != ims[0].shape for d in ims):
-            for d, k, p in zip(ims, cam_intrs, cam_poses):
-                self.integrate(None, d, k, p, obs_weight, max_depth)
+            for d, k, p, c in zip(ims, cam_intrs, cam_poses, cols):
+                self.integrate(c, d, k, p, obs_weight, max_depth)
             return
+        cols = [self._fold_color(c) for c in cols]
+        have_col = any(c is not None for c in cols)
         ims = [d.to(self._dev).contiguous() for d in ims]
         im_h, im_w = int(ims[0].shape[0]), int(ims[0].shape[1])
         dim = (C.c_int32 * 3)(*[int(v) for v in self._vol_dim])
@@ -76,9 +83,13 @@ class TSDFVolume:
                              for c in cam_intrs[g0: g0 + k]]).reshape(-1)
             pose = np.stack([np.asarray(p, dtype=np.float64).reshape(-1).astype(np.float32)
                              for p in cam_poses[g0: g0 + k]]).reshape(-1)
+            cg = cols[g0: g0 + k]
             _lib.check(self._lib.bnv_tsdf_integrate_batch_u16(
-                _lib.ptr(self.tsdf), _lib.ptr(self.weight), dim, org, np.float32(self._voxel_size),
-                np.float32(self._trunc_margin), k, (C.c_void_p * k)(*[d.data_ptr() for d in grp]), im_h, im_w,
+                _lib.ptr(self.tsdf), _lib.ptr(self.weight), _lib.ptr(self.color if have_col else None), dim, org,
+                np.float32(self._voxel_size), np.float32(self._trunc_margin), k,
+                (C.c_void_p * k)(*[d.data_ptr() for d in grp]),
+                (C.c_void_p * k)(*[(c.data_ptr() if c is not None else 0) for c in cg]) if have_col else None,
+                im_h, im_w,
                 (C.c_float * (9 * k))(*intr.tolist()), (C.c_float * (16 * k))(*pose.tolist()), float(obs_weight),
                 float(max_depth or 0.0), _lib.stream_ptr()), "bnv_tsdf_integrate_batch_u16")
 

@@ -163,13 +163,15 @@ int bnv_tsdf_integrate_u16(float* tsdf, float* weight, float* color, const int32
                        const uint16_t* depth_mm, const float* color_im, int im_h, int im_w,
                        const float intr_host[9], const float pose_host[16], float obs_weight,
                        float max_depth, const int32_t* gate, bnv_stream_t stream);
-/* n_frames (<= BNV_TSDF_BATCH_MAX) consecutive uint16 depth frames in ONE launch, depth only (no colour volume):
- * identical to n_frames calls of bnv_tsdf_integrate_u16 in order.  depth_mm: HOST array of device pointers;
+/* n_frames (<= BNV_TSDF_BATCH_MAX) consecutive uint16 depth frames in ONE launch: identical to n_frames calls of
+ * bnv_tsdf_integrate_u16 in order.  depth_mm: HOST array of device pointers; color / color_im: the colour volume and a
+ * HOST array of device pointers to the frames' folded colour images (entries may be NULL), or both NULL;
  * intr_host [n_frames, 9] and pose_host [n_frames, 16] row-major f32 on the host. */
 #define BNV_TSDF_BATCH_MAX 8
-int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, const int32_t dim_host[3], const float origin_host[3],
-                                 float voxel_size, float trunc_margin, int n_frames,
-                                 const uint16_t* const* depth_mm, int im_h, int im_w, const float* intr_host,
+int bnv_tsdf_integrate_batch_u16(float* tsdf, float* weight, float* color, const int32_t dim_host[3],
+                                 const float origin_host[3], float voxel_size, float trunc_margin, int n_frames,
+                                 const uint16_t* const* depth_mm, const float* const* color_im, int im_h, int im_w,
+                                 const float* intr_host,
                                  const float* pose_host, float obs_weight, float max_depth, bnv_stream_t stream);
 
 /* ---- spatially sharded volume: the exchange step (new design; bnv_fusion_amd/distributed.py).

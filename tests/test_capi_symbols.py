@@ -71,8 +71,8 @@ def test_argument_validation_without_a_gpu():
     assert lib.bnv_volume_clear(C.byref(v), None) == INVALID
     assert lib.bnv_tsdf_integrate_u16(None, None, None, None, None, 0.025, 0.125, None, None, 480, 640, None, None, 1.0,
                                       3.0, None, None) == INVALID
-    assert lib.bnv_tsdf_integrate_batch_u16(C.c_void_p(8), C.c_void_p(8), (C.c_int32 * 3)(4, 4, 4),
-                                            (C.c_float * 3)(), 0.025, 0.125, 9, C.c_void_p(8), 4, 4,
+    assert lib.bnv_tsdf_integrate_batch_u16(C.c_void_p(8), C.c_void_p(8), None, (C.c_int32 * 3)(4, 4, 4),
+                                            (C.c_float * 3)(), 0.025, 0.125, 9, C.c_void_p(8), None, 4, 4,
                                             (C.c_float * 9)(), (C.c_float * 16)(), 1.0, 3.0, None) == INVALID   # > 8 frames
     assert lib.bnv_depth_to_points(None, 0, 480, 640, None, None, 10.0, None, 0, None, None, None) == INVALID
     assert lib.bnv_png_unfilter(None, 1, 1, 2, None) != 0

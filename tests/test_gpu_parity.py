@@ -1053,6 +1053,15 @@ def test_tsdf_batch_equals_frame_by_frame(bnv):
     b.integrate_batch(depth, K, T)
     assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight)
     assert float(a.weight.max()) >= 8
+    # with colour images (some frames without), and the depth cut-off of the loader
+    a, b = TSDFVolume(bounds, 0.025, device=DEV), TSDFVolume(bounds, 0.025, device=DEV)
+    g = torch.Generator().manual_seed(1)
+    rgb = [torch.randint(0, 256, (240, 320, 3), generator=g).float().to(DEV) if t % 4 else None for t in range(11)]
+    for d, k, p, c in zip(depth, K, T, rgb):
+        a.integrate(c, d, k, p, max_depth=1.55)
+    b.integrate_batch(depth, K, T, max_depth=1.55, color_ims=rgb)
+    assert torch.equal(a.tsdf, b.tsdf) and torch.equal(a.weight, b.weight) and torch.equal(a.color, b.color)
+    assert float(a.color.max()) > 65536 and float((a.weight > 0).float().mean()) > 0.005
 
 
 def test_lattice_table_stage_can_be_relaunched(bnv, model, golden_volume):
