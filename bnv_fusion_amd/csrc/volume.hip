@@ -200,31 +200,6 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
   *n_rows += *total_new;
 }
 
-// ONE workgroup turns per-block counts of created keys into exclusive offsets and commits the row count;
-// first_row_out receives the old count (the batched upsert below; the per-frame upsert is k_vol_integrate).
-// (256 threads: one wave per SIMD and 24 VGPRs fit beside the persistent MLP kernels of another stream; a 1024-thread
-// workgroup does not, and stalled its stream until the MLP kernel had finished -- rocprofv3 kernel trace)
-__global__ __launch_bounds__(256) void k_vol_offsets_commit(uint32_t* __restrict__ block_new, int n_blocks,
-                                                             int32_t* __restrict__ n_rows,
-                                                             int32_t* __restrict__ first_row_out) {
-  __shared__ uint32_t wave_tot[16];
-  uint32_t carry = 0;
-  for (int base = 0; base < n_blocks; base += 256) {
-    const int i = base + threadIdx.x;
-    const uint32_t val = (i < n_blocks) ? block_new[i] : 0;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan<256>(val, wave_tot, &total);
-    if (i < n_blocks) block_new[i] = carry + ex;
-    carry += total;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const int32_t first = *n_rows;
-    *first_row_out = first;
-    *n_rows = first + (int32_t)carry;
-  }
-}
-
 // ---- _integrate in ONE launch.  Every workgroup (256 keys) probes / CAS-inserts its keys, counts the keys it
 // created, obtains the first row of its new keys by decoupled look-back over the workgroups (rows are numbered in
 // batch order: the reference's insertion order; tile 0 seeds the chain with the volume's row count, the last tile
@@ -333,18 +308,14 @@ __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int
   v.weights[row] = w_new;
 }
 
-// ---- batched _integrate: up to kVolBatchMax consecutive frames in 4 launches, results identical to integrating
+// ---- batched _integrate: up to kVolBatchMax consecutive frames in 2 launches, results identical to integrating
 // them one after the other (the frame-parallel multi-GPU mode replays a whole batch of frames on every rank, and a
 // launch costs ~10 us of stream time whatever it does).  Items are (frame s, index i); the grid is frame-major,
 // every frame padded to whole 256-item blocks.  Two per-SLOT side tables that belong to the volume:
 //   slot_mask [n_slots]                bit s set <=> frame s of the batch holds the slot's key (zero between calls)
 //   slot_items[n_slots * kVolBatchMax] the index i of that key in frame s (valid where the bit is set)
-// B1 probes / CAS-inserts every key and fills the two tables.  B2 flags the creators -- the FIRST frame of a key that
-// was not in the volume before the batch, exactly the frame whose sequential upsert would have created the row --
-// and counts them per block; k_vol_offsets_commit (one workgroup) turns the counts into offsets and commits the row
-// count.  (A last-block-done variant of B2 that did the scan itself was slower: 3,200 tickets on one address.)
-// B3: the thread of a key's first occurrence creates the row if needed, then applies the running average of every
-// frame that holds the key, in frame order, in registers: one read and one write of the row.
+// B1 (k_vol_batch_probe) probes / CAS-inserts every key and fills the two tables -- it must be complete for ALL items
+// before a key's creator can be told, hence a launch of its own.  B2 (k_vol_batch_integrate) does the rest.
 constexpr int kVolBatchMax = BNV_VOLUME_BATCH_MAX;
 
 struct VolBatch {
@@ -402,52 +373,55 @@ __global__ __launch_bounds__(256) void k_vol_batch_probe(bnv_volume_t v, VolBatc
   slot_of[item] = slot;
 }
 
-__global__ __launch_bounds__(256) void k_vol_batch_count(bnv_volume_t v, VolBatch b,
-                                                         const int32_t* __restrict__ slot_of,
-                                                         const uint32_t* __restrict__ slot_mask,
-                                                         int32_t* __restrict__ is_new,
-                                                         uint32_t* __restrict__ block_new) {
-  const int s = batch_frame_of(b, blockIdx.x);
-  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int32_t slot = slot_of[item];
-  int created = 0;
-  if (slot >= 0 && v.slot_rows[slot] < 0) created = (__ffs(slot_mask[slot]) - 1) == s;
-  is_new[item] = created;
-  __shared__ uint32_t wave_tot[4];
-  const unsigned long long bal = __ballot(created);
-  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = (uint32_t)__popcll(bal);
-  __syncthreads();
-  if (threadIdx.x == 0) block_new[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-}
-
-__global__ __launch_bounds__(256) void k_vol_batch_apply(bnv_volume_t v, VolBatch b,
-                                                         const int32_t* __restrict__ slot_of,
-                                                         const int32_t* __restrict__ is_new,
-                                                         const uint32_t* __restrict__ block_off,
-                                                         const int32_t* __restrict__ first_row,
-                                                         uint32_t* __restrict__ slot_mask,
-                                                         const int32_t* __restrict__ slot_items,
-                                                         int32_t* __restrict__ error) {
+// B2 (one launch for what were three: creator count, offsets + commit, apply): the creator of a key -- the FIRST frame
+// of a key that was not in the volume before the batch, exactly the frame whose sequential upsert would have created
+// the row -- gets its row by decoupled look-back over the workgroups (rows numbered in (frame, index) order; tile 0 seeds
+// the chain with the volume's row count, the last tile commits the new count); then the thread of a key's first
+// occurrence creates the row if needed and applies the running average of every frame that holds the key, in frame
+// order, in registers: one read and one write of the row.  Safe in one launch: only the first-occurrence thread of a
+// key ever writes its slot / row / mask, and every other occurrence leaves at once whatever it reads there.
+__global__ __launch_bounds__(256) void k_vol_batch_integrate(bnv_volume_t v, VolBatch b,
+                                                             const int32_t* __restrict__ slot_of,
+                                                             uint32_t* __restrict__ slot_mask,
+                                                             const int32_t* __restrict__ slot_items,
+                                                             uint64_t* __restrict__ tile_state, uint32_t epoch,
+                                                             int32_t* __restrict__ error) {
   const int s = batch_frame_of(b, blockIdx.x);
   const int64_t i = (int64_t)(blockIdx.x - b.block_start[s]) * 256 + threadIdx.x;
   const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int32_t slot = slot_of[item];
+  uint32_t frames = 0;
+  bool first = false;
+  int created = 0;
+  if (slot >= 0) {
+    frames = slot_mask[slot];
+    first = (__ffs(frames) - 1) == s;   // a later occurrence: the first one does the work (mask 0: already done)
+    created = first && v.slot_rows[slot] < 0;
+  }
   __shared__ uint32_t wave_new[4];
-  const int created = is_new[item];
+  __shared__ uint32_t s_first;
   const unsigned long long bal = __ballot(created);
   const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (ln == 0) wave_new[wv] = (uint32_t)__popcll(bal);
   __syncthreads();
-  uint32_t before = block_off[blockIdx.x] + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
-  for (int k = 0; k < wv; ++k) before += wave_new[k];
-  const int32_t slot = slot_of[item];
-  if (slot < 0) return;
-  uint32_t frames = slot_mask[slot];
-  if ((__ffs(frames) - 1) != s) return;   // a later occurrence: the first one does the work (0: already done)
+  if (threadIdx.x < 64) {
+    const uint32_t total = wave_new[0] + wave_new[1] + wave_new[2] + wave_new[3];
+    const uint32_t seed = blockIdx.x == 0 ? (uint32_t)v.n_rows[0] : 0u;
+    const uint32_t fr = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch, seed);
+    if (threadIdx.x == 0) {
+      s_first = fr;
+      if (blockIdx.x == gridDim.x - 1) v.n_rows[0] = (int32_t)(fr + total);   // last tile: commit
+    }
+  }
+  __syncthreads();
+  if (!first) return;
   int64_t row;
   float w_acc = 0.f;
   float fo[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (created) {
-    row = (int64_t)*first_row + before;
+    uint32_t before = s_first + (uint32_t)__popcll(bal & ((1ull << ln) - 1ull));
+    for (int k = 0; k < wv; ++k) before += wave_new[k];
+    row = (int64_t)before;
     if (row >= v.row_capacity) {
       *error = 3;
       return;
@@ -657,14 +631,8 @@ int bnv_volume_integrate_batch(const bnv_volume_t* vol, int n_frames, const int6
   hipLaunchKernelGGL(k_vol_batch_probe, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
                      slot_items, ws.error);
   BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_batch_count, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
-                     ws.is_new, ws.block_new);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_offsets_commit, dim3(1), dim3(256), 0, stream, ws.block_new, (int)blocks, vol->n_rows,
-                     ws.total_new);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_vol_batch_apply, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, ws.is_new,
-                     ws.block_new, ws.total_new, slot_mask, slot_items, ws.error);
+  hipLaunchKernelGGL(k_vol_batch_integrate, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of,
+                     slot_mask, slot_items, ws.tile_state, next_epoch(), ws.error);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -28,7 +29,7 @@ def main():
     from bnv_fusion_amd import synthetic
     from bnv_fusion_amd.distributed import FrameParallelNeuralMap, ShardedNeuralMap
     dims, voxel = synthetic.GRID_DIMS[args.grid]
-    model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
+    model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.checkpoint == "tcnn")
     H, W = args.height, args.width
     frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, H, W)).cuda(), "intr_mat": synthetic.intrinsics(H, W),
                "T_wc": synthetic.pose(t)} for t in range(args.frames)]

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-def _launch(world, mode, grid, frames, out, hw):
+def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32"):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -28,18 +28,18 @@ def _launch(world, mode, grid, frames, out, hw):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
            "--mode", mode, "--grid", str(grid), "--frames", str(frames), "--height", str(hw[0]), "--width", str(hw[1]),
-           "--out", str(out)]
+           "--checkpoint", checkpoint, "--out", str(out)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load(os.path.join(out, f"rank{k}.pt"), weights_only=False) for k in range(world)]
 
 
-def _single(grid, frames, hw):
+def _single(grid, frames, hw, checkpoint="fp32"):
     import bnv_fusion_amd as bnv
     from bnv_fusion_amd import synthetic
     bnv.set_mlp_mode(1)
     dims, voxel = synthetic.GRID_DIMS[grid]
-    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel, tiny_cuda=checkpoint == "tcnn")
     nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True)
     outs = []
     for t in range(frames):
@@ -97,3 +97,18 @@ def test_frame_parallel_processes_equal_single_gpu(tmp_path, single_256, world):
         assert torch.equal(c, rc) and torch.equal(s, rs), t
     for r in ranks:
         assert r["meta"]["rows"] == rows and torch.equal(r["meta"]["tsdf"], tsdf)
+
+
+def test_tcnn_checkpoint_sharded_over_processes(tmp_path):
+    """BASELINE config 4 in miniature: the reference's default tiny-cuda-nn (fp16) networks, 512^3 grid, the volume
+    sharded over 2 processes -- bit-identical to the single-GPU run in the same arithmetic."""
+    ref, rows, tsdf, voxel = _single(512, 9, (240, 320), checkpoint="tcnn")
+    ranks = _launch(2, "spatial", 512, len(ref), tmp_path, (240, 320), checkpoint="tcnn")
+    for t, (rc, rs) in enumerate(ref):
+        parts = [r["out"][t] for r in ranks]
+        coords = torch.cat([p[0] for p in parts])
+        sdf = torch.cat([p[1] for p in parts])
+        order = torch.argsort((coords[:, 0] * 512 + coords[:, 1]) * 512 + coords[:, 2])
+        assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
+    import bnv_fusion_amd as bnv
+    bnv.set_mlp_mode(1)
