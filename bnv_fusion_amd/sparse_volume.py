@@ -245,7 +245,7 @@ class SparseVolume:
 
     def integrate_batch(self, frames):
         """``integrate`` for several consecutive frames at once: ``frames`` is a list of (coords, feats, pcounts,
-        n_dev) tuples in frame order (n_dev as in ``integrate``, may be None).  Four launches per BATCH_MAX frames;
+        n_dev) tuples in frame order (n_dev as in ``integrate``, may be None).  Two launches per BATCH_MAX frames;
         rows, features and weights come out exactly as from one ``integrate`` call per frame."""
         items = []
         for coords, feats, pcounts, n_dev in frames:

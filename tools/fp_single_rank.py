@@ -33,8 +33,9 @@ if args.replay > 1:     # emulate the replicated part of an N-rank batch: N - 1 
             orig_v(items * args.replay)
         extra = (args.replay - 1) * sum(int(it[0].shape[0]) for it in items)
         vol._inflight -= extra; vol._rows_upper -= extra          # keep the host-side row bound consistent
-    def replayed_t(d, k, p, obs_weight=1., max_depth=None):
-        orig_t(d * args.replay, k * args.replay, p * args.replay, obs_weight, max_depth)
+    def replayed_t(d, k, p, obs_weight=1., max_depth=None, color_ims=None):
+        orig_t(d * args.replay, k * args.replay, p * args.replay, obs_weight, max_depth,
+               None if color_ims is None else list(color_ims) * args.replay)
     vol.integrate_batch, tv.integrate_batch = replayed, replayed_t
 fp.flush(); torch.cuda.synchronize()
 import ctypes as C
