@@ -297,7 +297,6 @@ def main():
     elif world > 1:
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY, tsdf=with_tsdf)
-        nm.backend.inputs_resident = True
     else:
         nm = bnv.NeuralMap(dims3, voxel, model, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
         nm.overlap_encode = not args.no_stream_overlap
@@ -568,7 +567,6 @@ def main():
         from bnv_fusion_amd.distributed import ShardedNeuralMap
         nm_fp = nm
         nm = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY, tsdf=with_tsdf)
-        nm.backend.inputs_resident = True
         frame_parallel = False
         run_frames(list(range(args.preroll)), decode=False)
         sp_idx = list(range(args.preroll + args.warmup, args.preroll + args.warmup + args.steps))

@@ -122,9 +122,6 @@ class HipShardBackend:
         self.dev = v._dev
         self.max_depth = max_depth
         self.sdf_delta = None
-        self.overlap_encode = True
-        self.inputs_resident = False          # as NeuralMap.inputs_resident
-        self._enc_stream = None
         self.tsdf_vol = None
         if tsdf:            # the TSDF side volume (0.025 m, dense) is small: every rank keeps the whole of it
             from .sparse_volume import get_world_range
@@ -136,12 +133,7 @@ class HipShardBackend:
     # ---- phases ---------------------------------------------------------------------------------
     def encode(self, frame):
         """Voxelise the whole frame, encode + upsert the voxels this rank owns; the per-rank bounds of the
-        exchange are copied to pinned memory between the two halves of the encode (before the encoder MLP).
-
-        The encode depends on the frame only, so it is enqueued on a second HIP stream (``overlap_encode``) and runs
-        beside the PREVIOUS frame's exchange / decode on the caller's stream -- in this mode a frame is short (0.5 ms at
-        world 8) and the replicated voxelisation + the launch gaps of the encode are a third of it.  The upsert, which
-        changes what that decode reads, stays on the caller's stream."""
+        exchange are copied to pinned memory between the two halves of the encode (before the encoder MLP)."""
         v = self.volume
         self.pointnet.shard = (self.rank, self.world, BLOCK_LOG2)
         bound_host = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
@@ -151,30 +143,13 @@ class HipShardBackend:
             bound_host.copy_(self.pointnet.shard_boundary_counts(), non_blocking=True)
             ev.record()
 
-        def run():
-            if "input_pts" in frame:
-                return self.pointnet.encode_pointcloud_async(
-                    frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, between=between)
-            return self.pointnet.encode_depth_async(
+        if "input_pts" in frame:
+            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
+                frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, between=between)
+        else:
+            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_depth_async(
                 frame["depth"], frame["intr_mat"], frame["T_wc"], self.max_depth, v.n_xyz, v.min_coords,
                 v.max_coords, v.voxel_size, between=between)[:6]
-
-        main = torch.cuda.current_stream()
-        if self.overlap_encode:
-            if self._enc_stream is None:
-                self._enc_stream = torch.cuda.Stream(device=self.dev)
-            enc = self._enc_stream
-            if not self.inputs_resident:
-                enc.wait_stream(main)         # the frame's tensors may still be in production on the caller's stream
-            with torch.cuda.stream(enc):
-                feats, pcounts, flat_ids, grid_ids, counters, cap = run()
-                done = torch.cuda.Event()
-                done.record(enc)
-            main.wait_event(done)
-            for t in (feats, pcounts, flat_ids, grid_ids, counters):
-                t.record_stream(main)
-        else:
-            feats, pcounts, flat_ids, grid_ids, counters, cap = run()
         n_dev = counters[2:3]
         v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
         if self.tsdf_vol is not None and "depth" in frame:

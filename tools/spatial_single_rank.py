@@ -28,9 +28,7 @@ dims, voxel = synthetic.GRID_DIMS[args.grid]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
           for t in range(30 + args.frames)]
-ap_overlap = os.environ.get("BNV_SPATIAL_OVERLAP", "1") != "0"
 be = D.HipShardBackend(np.array([dims] * 3), voxel, model, 0, W, capacity=1 << 21, device="cuda:0", tsdf=True)
-be.overlap_encode, be.inputs_resident = ap_overlap, True
 PH = ("encode+upsert", "pack", "all_gather", "install", "decode")
 acc = {k: 0.0 for k in PH}
 waits = recv_bytes = own = evals = 0
