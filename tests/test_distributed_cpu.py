@@ -32,6 +32,9 @@ class OracleShardBackend:
         o, v, D = self.orc, self.vol, self.D
         pts = frame["input_pts"]
         f, c, ids, g, n = o.encode_pointcloud(self.sd, pts, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+        if f is None:          # no point inside the volume (local_point_fusion.py:101-102)
+            return D.ShardFrame(grid_ids=torch.zeros((0, 3), dtype=torch.int64), counts=np.zeros(self.world, int),
+                                n_avg=None)
         # the bound: touched BOUNDARY voxels per owner over ALL touched voxels (no min-points filter), replicated
         xyz = pts[0, :, :3]
         inb = ((xyz < (v.max_coords - v.voxel_size)) & (xyz > (v.min_coords + v.voxel_size))).all(-1)
@@ -109,9 +112,14 @@ def _worker(rank, world, port, frames, dims, voxel, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bnv_fusion_amd.distributed import ShardedNeuralMap, all_gather_var
     nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world))
+    # an empty frame first (no point inside the volume): bound 0 on every rank -> no collective, (empty, empty) out
+    far = torch.from_numpy(frames[0]).clone()
+    far[..., :3] += 50.0
+    e_owned, e_sdf = nm.fuse_and_decode({"input_pts": far})
+    assert len(e_owned) == 0 and nm.exchanged_bytes == 0
     for fr in frames:
         owned, sdf = nm.fuse_and_decode({"input_pts": torch.from_numpy(fr)})
-    assert nm.host_waits == len(frames) and nm.backend.installed > 0      # one host wait per frame; ghosts installed
+    assert nm.host_waits == len(frames) + 1 and nm.backend.installed > 0  # one host wait per frame; ghosts installed
     allc = all_gather_var(owned)
     alls = all_gather_var(sdf)
     if rank == 0:

@@ -400,6 +400,12 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
     shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=4096, device=DEV) for r in range(world)]
     model.shard = (0, 1, 3)
     single = bnv.NeuralMap(dims, voxel, model, device=DEV)
+    # an empty frame (no point inside the volume): bound 0 on every shard, nothing to exchange, (None, None) out
+    far = {"input_pts": torch.from_numpy(z["frames"][0]).to(DEV) + 50.0}
+    for b in shards:
+        f = b.encode(far)
+        assert b.bound(f) == 0 and b.result(b.finish(f, b.decode(f), 0)) == (None, None)
+        assert b.volume.num_rows() == 0
     for fr in z["frames"]:
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
         model.shard = (0, 1, 3)
