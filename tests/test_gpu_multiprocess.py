@@ -112,3 +112,25 @@ def test_tcnn_checkpoint_sharded_over_processes(tmp_path):
         assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
     import bnv_fusion_amd as bnv
     bnv.set_mlp_mode(1)
+
+
+def test_eight_ranks_both_modes(tmp_path, single_256):
+    """The driver's scaling run uses 8 ranks: both modes as 8 processes (sharing this box's GPU), 256^3, 320x240
+    frames -- frame-parallel batches of exactly BATCH_MAX frames plus a ragged last batch, and the 8-way sharded
+    volume -- bit-identical to the single-GPU run."""
+    ref, rows, tsdf, voxel = single_256
+    (tmp_path / "fp").mkdir()
+    (tmp_path / "sp").mkdir()
+    ranks = _launch(8, "frame", 256, len(ref), tmp_path / "fp", (240, 320))
+    for t, (rc, rs) in enumerate(ref):
+        c, s = ranks[t % 8]["out"][t]
+        assert torch.equal(c, rc) and torch.equal(s, rs), t
+    assert all(r["meta"]["rows"] == rows and torch.equal(r["meta"]["tsdf"], tsdf) for r in ranks)
+    ranks = _launch(8, "spatial", 256, len(ref), tmp_path / "sp", (240, 320))
+    for t, (rc, rs) in enumerate(ref):
+        parts = [r["out"][t] for r in ranks if r["out"][t][0] is not None]
+        coords = torch.cat([p[0] for p in parts])
+        sdf = torch.cat([p[1] for p in parts])
+        order = torch.argsort((coords[:, 0] * 256 + coords[:, 1]) * 256 + coords[:, 2])
+        assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
+    assert all(r["meta"]["host_waits"] == len(ref) and torch.equal(r["meta"]["tsdf"], tsdf) for r in ranks)
