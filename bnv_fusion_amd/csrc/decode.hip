@@ -1668,24 +1668,13 @@ constexpr int kMarkThreads = BNV_MARK_THREADS;
 constexpr int kMarkChunks = BNV_MARK_CHUNKS;
 constexpr int kMarkOrigins = kMarkThreads / 27 + 2;   // origins a chunk's lattice points can belong to
 constexpr int kMarkBuf = kMarkChunks > 1 ? 16 * kMarkThreads : 8 * kMarkThreads;   // LDS entry buffer; a chunk appends at most 8 per thread
-// LOOKUP = true (bnv_decode_lattice): the neighbour rows are looked up HERE (k_lattice_neighbors' job: dense row index,
-// usable weight, is-origin stamp) while they are staged into LDS, and written out for the blend kernel -- one launch
-// and one pass over the 10 MB neighbour array less.  LOOKUP = false: they come from a k_lattice_neighbors call.
-struct MarkLookup {
-  bnv_volume_t v;
-  const int64_t* origins;
-  const float* weights;
-  int64_t row_limit;
-  float min_pts;
-};
-template <bool LOOKUP>
-__global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(int32_t* __restrict__ nbr_rows, int64_t n,
+__global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
                                                                int64_t entry_capacity,
-                                                               const int32_t* __restrict__ n_dev, MarkLookup L) {
+                                                               const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
   if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
   __shared__ int s_buf[kMarkBuf];
@@ -1733,22 +1722,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(int32_t* __restri
     const int64_t b0 = t0 / 27;
     for (int i = threadIdx.x; i < kMarkOrigins * 27; i += kMarkThreads) {
       const int64_t g = b0 * 27 + i;
-      int val = -1;
-      if (g < n * 27) {
-        if constexpr (LOOKUP) {
-          const int64_t b = g / 27;
-          const int nb = (int)(g - b * 27);
-          int row = volume_row(L.v, L.origins[b * 3 + 0] + (nb / 9 - 1), L.origins[b * 3 + 1] + ((nb / 3) % 3 - 1),
-                               L.origins[b * 3 + 2] + (nb % 3 - 1));
-          if (row >= L.row_limit) row = -1;
-          if (row >= 0 && L.weights[row] >= L.min_pts)
-            val = row | (origin_stamp[row] == epoch ? kOriginBit : 0);
-          nbr_rows[g] = val;     // (the chunks' origin ranges overlap by one origin: the same value twice)
-        } else {
-          val = nbr_rows[g];
-        }
-      }
-      s_nbr[i] = val;
+      s_nbr[i] = g < n * 27 ? nbr_rows[g] : -1;
     }
     __syncthreads();
     const int64_t t = t0 + threadIdx.x;
@@ -2203,9 +2177,9 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark<false>, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
+  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, MarkLookup{});
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -2264,21 +2238,13 @@ int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const fl
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
-  // origin stamps -> neighbour rows + entries read by live lattice points (one kernel) -> MLP on those entries only
-  // -> blend
-  if (!vol_ok_ro(vol) || !grid || !weights || !origins || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
-  LatticeWs ws;
-  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
-  hipLaunchKernelGGL(k_lattice_stamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *vol,
-                     origins, n, row_limit, ws.origin_stamp, epoch, n_dev, ws.n_list);
-  BNV_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_lattice_mark<true>,
-                     dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
-                     dim3(kMarkThreads), 0, (hipStream_t)stream, ws.nbr_rows, n, ws.origin_stamp, epoch, ws.need_mask,
-                     ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev,
-                     MarkLookup{*vol, origins, weights, row_limit, (float)grid->min_pts_in_grid});
-  BNV_LAUNCH_CHECK();
-  int rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
+  // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend
+  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
+                                 epoch, stream);
+  if (rc != BNV_OK) return rc;
+  rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
+  if (rc != BNV_OK) return rc;
+  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;
   return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
