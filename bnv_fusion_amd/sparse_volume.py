@@ -181,9 +181,10 @@ class SparseVolume:
         self._rows_upper = self._rows_known + self._inflight
 
     def release(self, n_reserved):
-        """Gives back the reservation of an enqueued integrate whose result was never collected."""
+        """An enqueued integrate whose result was never collected: its reservation is no longer "in flight", but
+        how many rows it created is unknown, so the host-side bound keeps the whole reservation until the next exact
+        read (num_rows()) -- the bound must stay an upper bound."""
         self._inflight -= int(n_reserved)
-        self._rows_upper = max(self._rows_known, self._rows_upper - int(n_reserved))
 
     def _reserve(self, n_new):
         """Grow rows / slot table so that n_new more keys fit (the Open3D map auto-grows).  The test uses the
