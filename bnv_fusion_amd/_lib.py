@@ -144,7 +144,7 @@ def load():
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
-        "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, vp, vp]),
+        "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -60,7 +60,9 @@ constexpr int L_WVOL = L_WTRI + DM;           // [128] volume weight (or dense c
 constexpr int L_DELTA = L_WVOL + DM;          // [128] sdf_delta sample of its corner
 constexpr int L_TOTAL = L_DELTA + DM;         // 35,328 floats = 141,312 B
 
-enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2 };  // MODE_PTS runs k_decode_pts, the others k_decode
+// MODE_PTS runs k_decode_pts, the others k_decode.  MODE_DENSE1: the two one-evaluation-per-query branches of
+// decode_feature_grid_w_pts (DecodeArgs::variant).
+enum { MODE_PTS = 0, MODE_LATTICE = 1, MODE_DENSE = 2, MODE_DENSE1 = 3 };
 
 // Phase timing of the decode tile loop (development builds only: -DBNV_PHASE_PROF, tools/phase_prof.py).
 // Thread 0 of every workgroup accumulates shader-clock deltas per phase in LDS and adds them to
@@ -103,6 +105,10 @@ struct DecodeArgs {
   const float* feat_grid;
   const float* pts_weight;
   int32_t dims[3];
+  // DENSE1: 0 = nearest voxel (interpolate_decode=False), 1 = global coordinates (trilinear features)
+  int32_t variant;
+  float* nf_out;     // optional [n, 8]: the features the evaluation used
+  int32_t* status;   // optional: [1] = 5 when a feature leaves the certified range of the split arithmetic
 };
 
 __device__ __forceinline__ f32x16 frag256(const float* __restrict__ b, int w, int h) {
@@ -550,6 +556,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
   if constexpr (MODE == MODE_LATTICE) {
     n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
     n_tiles = (n_evals + DM - 1) / DM;
+  } else if constexpr (MODE == MODE_DENSE1) {
+    n_tiles = (A.n + DM - 1) / DM;
   } else {
     n_tiles = (A.n + 15) / 16;
   }
@@ -589,6 +597,71 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
             feat[4 + f] = f1[f];
           }
         }
+      } else if constexpr (MODE == MODE_DENSE1) {
+        const int64_t q = tile * DM + j;
+        if (q < A.n) {
+          const size_t plane = (size_t)A.dims[0] * A.dims[1] * A.dims[2];
+          float c[3];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) c[a] = A.coords[q * 3 + a];
+          if (A.variant == 0) {
+            // nearest voxel, one evaluation (local_point_fusion.py:288-292, 331-343): torch.round = half to even
+            int v[3];
+            bool in = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float r = rintf(c[a]);
+              // relative_xyz = rel * voxel; decode_implicit divides it by voxel again (:335,:374)
+              loc[a] = __fdiv_rn(__fmul_rn(__fsub_rn(c[a], r), voxel), voxel);
+              in = in && r >= 0.f && r <= (float)(A.dims[a] - 1);
+              v[a] = (int)r;
+            }
+            if (in) {
+              const size_t o = ((size_t)v[0] * A.dims[1] + v[1]) * A.dims[2] + v[2];
+#pragma unroll
+              for (int f = 0; f < 8; ++f) feat[f] = A.feat_grid[f * plane + o];
+              wvol = A.pts_weight[o];
+            }
+          } else {
+            // global coordinates (:345-367): features by trilinear grid_sample (align_corners, zero padding: the
+            // order of torch's grid_sampler_3d, x = last axis), weight by nearest; the MLP sees coords / (res - 1)
+            float u[3], fl[3];
+            bool near_in = true;
+            int nr[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+              const float t = __fdiv_rn(c[a], (float)(A.dims[a] - 1));
+              loc[a] = t;
+              const float gs = __fsub_rn(__fmul_rn(t, 2.f), 1.f);
+              u[a] = __fmul_rn(__fdiv_rn(__fadd_rn(gs, 1.f), 2.f), (float)(A.dims[a] - 1));
+              fl[a] = floorf(u[a]);
+              const float r = nearbyintf(u[a]);
+              near_in = near_in && r >= 0.f && r <= (float)(A.dims[a] - 1);
+              nr[a] = (int)r;
+            }
+            if (near_in) wvol = A.pts_weight[((size_t)nr[0] * A.dims[1] + nr[1]) * A.dims[2] + nr[2]];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {   // tnw, tne, tsw, tse, bnw, bne, bsw, bse: bit 0 = x (axis 2), 1 = y, 2 = z (axis 0)
+              const int d0 = (k >> 2) & 1, d1 = (k >> 1) & 1, d2 = k & 1;
+              const float p0 = fl[0] + (float)d0, p1 = fl[1] + (float)d1, p2 = fl[2] + (float)d2;
+              // weight of a corner = product over axes of (opposite corner - u) or (u - opposite corner)
+              const float w2 = d2 ? __fsub_rn(u[2], fl[2]) : __fsub_rn(fl[2] + 1.f, u[2]);
+              const float w1 = d1 ? __fsub_rn(u[1], fl[1]) : __fsub_rn(fl[1] + 1.f, u[1]);
+              const float w0 = d0 ? __fsub_rn(u[0], fl[0]) : __fsub_rn(fl[0] + 1.f, u[0]);
+              const float wk = __fmul_rn(__fmul_rn(w2, w1), w0);
+              if (p0 >= 0.f && p1 >= 0.f && p2 >= 0.f && p0 <= (float)(A.dims[0] - 1) &&
+                  p1 <= (float)(A.dims[1] - 1) && p2 <= (float)(A.dims[2] - 1)) {
+                const size_t o = ((size_t)(int)p0 * A.dims[1] + (int)p1) * A.dims[2] + (int)p2;
+#pragma unroll
+                for (int f = 0; f < 8; ++f) feat[f] = __fadd_rn(feat[f], __fmul_rn(A.feat_grid[f * plane + o], wk));
+              }
+            }
+          }
+          if (A.nf_out) {
+#pragma unroll
+            for (int f = 0; f < 8; ++f) A.nf_out[q * 8 + f] = feat[f];
+          }
+        }
       } else {
         const int64_t q = tile * 16 + (j >> 3);
         const int cb = kCornerCeilBits[j & 7];
@@ -616,7 +689,8 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
           }
         }
       }
-      if constexpr (PREC == 1 || PREC == 3) check_feature_range(feat, A.pack[SD_BA + 1], A.vol.n_rows);
+      if constexpr (PREC == 1 || PREC == 3)
+        check_feature_range(feat, A.pack[SD_BA + 1], (MODE == MODE_DENSE || MODE == MODE_DENSE1) ? A.status : A.vol.n_rows);
       if constexpr (PREC == 2) stage_input_t(lds, j, loc, feat);
       else if constexpr (PREC == 1) stage_input_h<3>(lds, j, loc, feat);
       else if constexpr (PREC == 3) stage_input_h<1>(lds, j, loc, feat);
@@ -652,6 +726,21 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
           float av = __fmul_rn(lds[L_ALPHA + threadIdx.x], voxel);
           if constexpr (PREC == 2) av = (float)(_Float16)av;  // half tensor * python float stays half (sparse_volume.py:813)
           A.table[(size_t)row * 27 + l] = av;
+        }
+      }
+    } else if constexpr (MODE == MODE_DENSE1) {
+      if (threadIdx.x < DM) {
+        const int64_t q = tile * DM + threadIdx.x;
+        if (q < A.n) {
+          const float wv = lds[L_WVOL + threadIdx.x];
+          const bool ok = wv >= (float)A.grid.min_pts_in_grid;
+          float a = lds[L_ALPHA + threadIdx.x];
+          // nearest: decode_implicit(normalize=True) scales by voxel; global: normalize=False, the raw prediction
+          if (A.variant == 0) {
+            a = __fmul_rn(a, voxel);
+            if constexpr (PREC == 2) a = (float)(_Float16)a;
+          }
+          A.out[q] = ok ? a : voxel;   // forward_with_mask zero + valid_mask (:340-343) / valid_mask (:365-366)
         }
       }
     } else {
@@ -1963,15 +2052,19 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4 + kProfLds, stream, args)
   if (g_mlp_mode == 2) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
+    else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 2);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 2);
   } else if (g_mlp_mode == 1) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
+    else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 1);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
   } else if (g_mlp_mode == 3) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 3);
+    else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 3);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 3);
   } else {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 0);
+    else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 0);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 0);
   }
 #undef BNV_LAUNCH_DECODE
@@ -1995,12 +2088,16 @@ int bnv_decode_init() {
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode<M, P>, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL * 4 + kProfLds))
   BNV_OPT_IN(MODE_LATTICE, 0);
   BNV_OPT_IN(MODE_DENSE, 0);
+  BNV_OPT_IN(MODE_DENSE1, 0);
   BNV_OPT_IN(MODE_LATTICE, 1);
   BNV_OPT_IN(MODE_DENSE, 1);
+  BNV_OPT_IN(MODE_DENSE1, 1);
   BNV_OPT_IN(MODE_LATTICE, 2);
   BNV_OPT_IN(MODE_DENSE, 2);
+  BNV_OPT_IN(MODE_DENSE1, 2);
   BNV_OPT_IN(MODE_LATTICE, 3);
   BNV_OPT_IN(MODE_DENSE, 3);
+  BNV_OPT_IN(MODE_DENSE1, 3);
 #undef BNV_OPT_IN
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
@@ -2104,12 +2201,18 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
 
 int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims[3], float voxel_size,
                      int32_t min_pts_in_grid, const float* sdfmlp_pack, const float* voxel_coords, int64_t n,
-                     float* out_sdf, bnv_stream_t stream) {
+                     int32_t variant, float* out_sdf, float* out_feats, int32_t* status, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!feat_grid || !pts_weight || !dims || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (variant < BNV_DENSE_CORNERS || variant > BNV_DENSE_GLOBAL) return BNV_ERR_INVALID_ARGUMENT;
+  if (variant == BNV_DENSE_CORNERS && out_feats) return BNV_ERR_INVALID_ARGUMENT;
+  if (dims[0] < 2 || dims[1] < 2 || dims[2] < 2) return BNV_ERR_INVALID_ARGUMENT;   // coords / (res - 1)
   if (n == 0) return BNV_OK;
   if (!voxel_coords || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
   DecodeArgs a = {};
+  a.status = status;
+  a.nf_out = out_feats;
+  a.variant = variant == BNV_DENSE_GLOBAL ? 1 : 0;
   a.grid.voxel_size = voxel_size;
   a.grid.min_pts_in_grid = min_pts_in_grid;
   a.pack = sdfmlp_pack;
@@ -2122,6 +2225,7 @@ int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int3
   a.dims[0] = dims[0];
   a.dims[1] = dims[1];
   a.dims[2] = dims[2];
+  if (variant != BNV_DENSE_CORNERS) return launch_decode(MODE_DENSE1, a, (n + DM - 1) / DM, (hipStream_t)stream);
   return launch_decode(MODE_DENSE, a, (n + 15) / 16, (hipStream_t)stream);
 }
 

@@ -367,9 +367,16 @@ class LitFusionPointNet(nn.Module):
     # ---- dense decode (local_point_fusion.py:265-379) ---------------------------------------------
     def decode_feature_grid_w_pts(self, voxel_coords, feat_grid, pts_weight, voxel_size, bound_min,
                                   gradient=False, global_coords=True):
-        if global_coords or not self.interpolate_decode or gradient:
-            raise NotImplementedError("only global_coords=False / interpolate_decode=True / gradient=False "
-                                      "(the fusion_pointnet_model.yaml configuration) runs on the HIP path")
+        """All three branches of the reference (local_point_fusion.py:265-367), one launch each: global_coords=True
+        (the signature default: trilinear features, one evaluation at coords / (res - 1), unscaled); else
+        interpolate_decode=True (8 corner evaluations, the yaml configuration) or False (one evaluation at the nearest
+        voxel).  Returns (sdf [1, Q], neighbor_feats) like the reference: [1, 8, Q, F] for the corner branch,
+        [1, Q, F] for the other two."""
+        if gradient:
+            # the reference's own branch (:367-369) reads the undefined name `mask` and raises NameError
+            raise NotImplementedError("decode_feature_grid_w_pts(gradient=True): the reference's branch cannot run "
+                                      "(local_point_fusion.py:368 uses an undefined name); use SparseVolume.decode_pts "
+                                      "for gradients")
         lib = self._lib_for(voxel_coords)
         self._select_mode(lib)
         q = voxel_coords.detach().reshape(-1, 3).float().contiguous()
@@ -378,9 +385,18 @@ class LitFusionPointNet(nn.Module):
         pw = pts_weight.detach().float().contiguous()
         dims = (C.c_int32 * 3)(*[int(v) for v in fg.shape[-3:]])
         out = torch.empty(n, dtype=torch.float32, device=q.device)
+        variant = 2 if global_coords else (0 if self.interpolate_decode else 1)
+        nf1 = torch.empty((n, 8), dtype=torch.float32, device=q.device) if variant else None
+        status = torch.zeros(2, dtype=torch.int32, device=q.device)
         _lib.check(lib.bnv_decode_dense(_lib.ptr(fg), _lib.ptr(pw), dims, float(np.float32(voxel_size)),
-                                        self.min_pts_in_grid, _lib.ptr(self.nerf.sdf_pack), _lib.ptr(q), n,
-                                        _lib.ptr(out), _lib.stream_ptr()), "bnv_decode_dense")
+                                        self.min_pts_in_grid, _lib.ptr(self.nerf.sdf_pack), _lib.ptr(q), n, variant,
+                                        _lib.ptr(out), _lib.ptr(nf1) if variant else None, _lib.ptr(status),
+                                        _lib.stream_ptr()), "bnv_decode_dense")
+        if int(status[1]) == 5:
+            raise RuntimeError("decode_feature_grid_w_pts: a feature is outside the range the split-f16 MLP arithmetic "
+                               "is certified for (or not finite); call bnv_set_mlp_mode(0) (exact fp32) for this grid")
+        if variant:
+            return out.reshape(1, n), nf1.reshape(1, n, 8)
         # the reference also returns the gathered neighbour features [1, 8, Q, F]
         nb = get_neighbors(voxel_coords.unsqueeze(1), as_int=True).squeeze(2).long()
         X, Y, Z = [int(v) for v in fg.shape[-3:]]

@@ -77,10 +77,13 @@ def pointnet_normal_bound(sd):
 
 
 def sdf_feature_bound(sd):
-    """Largest |feature| for which the split-mode SDF decoder provably cannot overflow (local coordinates within
-    [-1, 1], sin / cos within [-1, 1]; the last hidden layer's output is consumed in fp32)."""
+    """Largest |feature| for which the split-mode SDF decoder provably cannot overflow.  Position inputs: local
+    coordinates are within [-1, 1]; the global-coordinate branch of decode_feature_grid_w_pts feeds coords / (res - 1),
+    at most 1 + 0.5 / (res - 1) <= 1.5 for a query whose nearest voxel is inside the grid (any other query is masked
+    to voxel_size whatever the MLP returns) -- the certificate uses 1.5; sin / cos within [-1, 1]; the last hidden
+    layer's output is consumed in fp32."""
     layers = [(_np(sd[f"nerf.geo_layer{i}.weight"]), _np(sd[f"nerf.geo_layer{i}.bias"])) for i in range(3)]
-    return certified_input_bound(layers, [1.0] * 9, 8)
+    return certified_input_bound(layers, [1.5] * 3 + [1.0] * 6, 8)
 
 
 def pack_pointnet(sd):

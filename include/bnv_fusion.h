@@ -425,12 +425,25 @@ int bnv_lattice_blend(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
 size_t bnv_decode_lattice_table_offset(int64_t row_capacity);
 size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity);
 
-/* LitFusionPointNet.decode_feature_grid_w_pts, global_coords=False / interpolate_decode=True
- * (local_point_fusion.py:265-329): dense feat_grid [8,X,Y,Z], pts_weight [X,Y,Z];
- * voxel_coords [n,3] f32 -> out [n]. */
+/* LitFusionPointNet.decode_feature_grid_w_pts (local_point_fusion.py:265-370) on dense grids feat_grid [8,X,Y,Z],
+ * pts_weight [X,Y,Z]; voxel_coords [n,3] f32 (voxel units) -> out_sdf [n].  `variant` selects the reference's branch:
+ *   BNV_DENSE_CORNERS  global_coords=False, interpolate_decode=True (:281-329, the yaml configuration): 8 corner
+ *                      evaluations per query, blended; a corner counts when its weight >= min_pts_in_grid, the query is
+ *                      valid when ANY corner counts, otherwise out = voxel_size.  out_feats must be NULL.
+ *   BNV_DENSE_NEAREST  global_coords=False, interpolate_decode=False (:288-292, 331-343): ONE evaluation at the
+ *                      nearest voxel (torch.round, half to even), valid when that voxel's weight >= min_pts_in_grid.
+ *   BNV_DENSE_GLOBAL   global_coords=True, the signature default (:345-367): features by trilinear grid_sample
+ *                      (align_corners=True, zero padding), weight by nearest; the MLP sees voxel_coords / (res - 1),
+ *                      the prediction is NOT scaled by voxel_size; valid when the nearest weight >= min_pts_in_grid.
+ * out_feats (optional, NEAREST / GLOBAL) [n,8]: the features the evaluation used (the reference's second return value).
+ * status (optional, device int32[2]): status[1] = 5 when a feature leaves the certified range of the split arithmetic
+ * (the range guard of bnv_decode_pts, which reports through the volume's error word).
+ * gradient=True is not offered: the reference's branch (:367-369) reads an undefined name and cannot run. */
+enum { BNV_DENSE_CORNERS = 0, BNV_DENSE_NEAREST = 1, BNV_DENSE_GLOBAL = 2 };
 int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims_host[3],
                      float voxel_size, int32_t min_pts_in_grid, const float* sdfmlp_pack,
-                     const float* voxel_coords, int64_t n, float* out_sdf, bnv_stream_t stream);
+                     const float* voxel_coords, int64_t n, int32_t variant, float* out_sdf, float* out_feats,
+                     int32_t* status, bnv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -360,12 +360,40 @@ def lattice_coords(origins, step_size=0.5):
     return torch.from_numpy(vc).float().reshape(1, len(origin), -1, 3)
 
 
-def decode_feature_grid_w_pts(sd, voxel_coords, feat_grid, pts_weight, voxel_size, min_pts_in_grid=8):
-    """LitFusionPointNet.decode_feature_grid_w_pts with global_coords=False and
-    interpolate_decode=True, local_point_fusion.py:265-329 (+ decode_implicit :372-379,
-    LocalNeRFModel.forward(test=True) modules.py:941-960).  voxel_coords [1, Q, 3] -> sdf [1, Q]."""
+def decode_feature_grid_w_pts(sd, voxel_coords, feat_grid, pts_weight, voxel_size, min_pts_in_grid=8,
+                              global_coords=False, interpolate_decode=True):
+    """LitFusionPointNet.decode_feature_grid_w_pts, local_point_fusion.py:265-367 (+ decode_implicit :372-379,
+    LocalNeRFModel.forward(test=True) modules.py:941-960).  voxel_coords [1, Q, 3] -> sdf [1, Q], neighbor_feats.
+    Defaults = the yaml configuration (global_coords=False, interpolate_decode=True, :281-329); the other two
+    branches: nearest voxel (:288-292, 331-343) and global coordinates (:345-367, the signature default)."""
     h, w, d = feat_grid.shape[-3:]
     res = torch.tensor([h, w, d])
+    if global_coords:
+        g = voxel_coords / (res - 1)
+        g = (g * 2 - 1)[..., [2, 1, 0]].unsqueeze(0).unsqueeze(0)           # [1, 1, 1, Q, 3]
+        nf = F.grid_sample(feat_grid, g, mode="bilinear", padding_mode="zeros", align_corners=True)
+        nf = nf.squeeze(2).squeeze(2).permute(0, 2, 1)                     # [1, Q, F]
+        pw = F.grid_sample(pts_weight, g, mode="nearest", padding_mode="zeros", align_corners=True)
+        pw = pw.squeeze(2).squeeze(2).permute(0, 2, 1)[..., 0]             # [1, Q]
+        pts = voxel_coords / (res - 1)                                     # decode_implicit(normalize=False)
+        sdf = geo_forward(sd, torch.cat([xyz_encoding(pts[..., :3]), nf], dim=-1))[..., 0]
+        sdf = torch.where(pw >= min_pts_in_grid, sdf, torch.ones_like(sdf) * voxel_size)
+        return sdf, nf
+    if not interpolate_decode:
+        nc = torch.round(voxel_coords)
+        g = nc / (res - 1)
+        g = (g * 2 - 1)[..., [2, 1, 0]].unsqueeze(0).unsqueeze(0)
+        nf = F.grid_sample(feat_grid, g, mode="nearest", padding_mode="zeros", align_corners=True)
+        pw = F.grid_sample(pts_weight, g, mode="nearest", padding_mode="zeros", align_corners=True)
+        pw = pw * (pw >= min_pts_in_grid)
+        nf = nf.squeeze(2).squeeze(2).permute(0, 2, 1)                     # [1, Q, F]
+        pw = pw.squeeze(2).squeeze(2).permute(0, 2, 1)[..., 0]             # [1, Q]
+        rel_xyz = (voxel_coords - nc) * voxel_size
+        pts = rel_xyz / voxel_size                                         # decode_implicit(normalize=True)
+        geo_in = torch.cat([xyz_encoding(pts[..., :3]), nf], dim=-1)
+        sdf = (forward_with_mask(sd, geo_in, pw >= min_pts_in_grid) * voxel_size)[..., 0]
+        sdf = torch.where(pw > 0, sdf, torch.ones_like(sdf) * voxel_size)
+        return sdf, nf
     neighbor_coords = get_neighbors(voxel_coords.unsqueeze(1), as_int=True).squeeze(2)  # [1, 8, Q, 3] i32
     g = neighbor_coords / (res - 1)
     g = (g * 2 - 1)[..., [2, 1, 0]].unsqueeze(0)

@@ -309,6 +309,41 @@ def test_dense_decode_vs_reference_golden(bnv, model):
     assert np.array_equal(out == v, z["sdf"] == v)
 
 
+@pytest.mark.parametrize("branch", ["global", "nearest"])
+def test_dense_decode_other_branches_vs_reference_golden(bnv, model, branch):
+    """The two one-evaluation branches of decode_feature_grid_w_pts (local_point_fusion.py:288-292, 331-367):
+    global_coords=True -- the signature default -- and interpolate_decode=False."""
+    z0 = np.load(os.path.join(GOLDEN, "dense_decode_64.npz"))
+    z = np.load(os.path.join(GOLDEN, "dense_modes_64.npz"))
+    vol = _vol(bnv, z0)
+    fg, mask, _, _ = _encode(model, vol, torch.from_numpy(z0["input_pts"]), dense=True)
+    q = torch.from_numpy(z["queries"]).to(DEV)
+    assert model.interpolate_decode
+
+    def run(qq):
+        try:
+            model.interpolate_decode = branch != "nearest"
+            return model.decode_feature_grid_w_pts(qq, fg, mask, vol.voxel_size, vol.min_coords,
+                                                   global_coords=branch == "global")
+        finally:
+            model.interpolate_decode = True
+
+    sdf, nf = run(q)
+    out, ref = sdf.cpu().numpy(), z[f"sdf_{branch}"]
+    assert out.shape == ref.shape and tuple(nf.shape) == z[f"feats_{branch}"].shape
+    v = np.float32(vol.voxel_size)
+    assert np.array_equal(out == v, ref == v)
+    # the global branch returns the UNSCALED prediction (|value| up to 1): the same absolute tolerance is 50x tighter
+    assert np.abs(out - ref).max() <= SDF_TOL, np.abs(out - ref).max()
+    assert np.abs(nf.cpu().numpy() - z[f"feats_{branch}"]).max() <= 2e-6
+    for n in (0, 1, 127, 129):   # ragged tiles, empty input
+        s2, f2 = run(q[:, :n])
+        assert tuple(s2.shape) == (1, n) and tuple(f2.shape) == (1, n, 8)
+        assert torch.equal(s2, sdf[:, :n]) and torch.equal(f2, nf[:, :n])
+    with pytest.raises(NotImplementedError):
+        model.decode_feature_grid_w_pts(q, fg, mask, vol.voxel_size, vol.min_coords, gradient=True)
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size properties (BASELINE configs: 640x480 depth, 256^3 grid, voxel 0.01)
 # ---------------------------------------------------------------------------------------------

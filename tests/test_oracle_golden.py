@@ -124,6 +124,25 @@ def test_dense_decode_matches_reference(sd):
     assert 0 < (z["sdf"] == np.float32(vol.voxel_size)).sum() < z["sdf"].size
 
 
+def test_dense_decode_other_branches_match_reference(sd):
+    """global_coords=True (the signature default) and interpolate_decode=False, local_point_fusion.py:288-292, 331-367."""
+    z0 = np.load(os.path.join(GOLDEN, "dense_decode_64.npz"))
+    z = np.load(os.path.join(GOLDEN, "dense_modes_64.npz"))
+    vol = _vol(z0)
+    fg, mask, _, _ = orc.encode_pointcloud(sd, torch.from_numpy(z0["input_pts"]), vol.n_xyz, vol.min_coords,
+                                           vol.max_coords, vol.voxel_size, return_dense=True)
+    q = torch.from_numpy(z["queries"])
+    v = np.float32(vol.voxel_size)
+    for name, kw in (("global", dict(global_coords=True)), ("nearest", dict(interpolate_decode=False))):
+        sdf, nf = orc.decode_feature_grid_w_pts(sd, q, fg, mask, vol.voxel_size, **kw)
+        ref = z[f"sdf_{name}"]
+        assert sdf.shape == ref.shape and nf.shape == z[f"feats_{name}"].shape
+        assert np.array_equal(sdf.numpy() == v, ref == v)
+        assert np.abs(sdf.numpy() - ref).max() <= FLOAT_TOL
+        assert np.abs(nf.numpy() - z[f"feats_{name}"]).max() <= FLOAT_TOL
+        assert 0.05 < (ref == v).mean() < 0.5
+
+
 def test_known_answers(sd, fused_volume):
     """SURVEY.md section 8c known-answer properties (no reference import needed)."""
     vol, z = fused_volume
