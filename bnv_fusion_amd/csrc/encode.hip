@@ -482,41 +482,75 @@ __device__ __forceinline__ void layer128(const float* __restrict__ wp, const flo
 }
 
 // Scatter of one tile: lane (j, h) holds output features 4h .. 4h+3 of pair j.  Consecutive pairs are
-// neighbouring pixels and mostly fall into the same voxel, so the values are first converted to 2^32
-// fixed point (exact), summed over each run of equal slots with a segmented scan across the 32 pairs
-// (integer adds: associative, so the result is bit-identical to per-pair atomics), and only the last
-// lane of a run issues the atomics.
+// neighbouring pixels and mostly fall into the same voxel, so the tile's values are summed per RUN of equal slots
+// and only the last lane of a run issues the atomics (bit-identical to per-pair atomics: the sums are integers).
+// The kernel is bound by instruction issue, not by the MFMA pipe (tools/phase_prof.py), so
+// this is written for instruction count:
+//  * 2^32 fixed point in 8 VALU ops per value: r = rndne(f * 2^32) is an integer-valued float, hi = floor(r /
+//    2^32), lo = r - hi * 2^32 (both exact) -- the same integer llrintf gives, without the generic f32 -> i64
+//    conversion sequence;
+//  * ONE unsegmented inclusive prefix sum P over the 32 lanes of a half (5 DPP steps: row_shr 1, 2, 4, 8 and
+//    row_bcast:15; an add / add-with-carry pair per 64-bit value and step, no LDS crossbar traffic), then
+//    run [s, e] = P[e] - P[s - 1] in modular arithmetic: lanes of other runs -- invalid ones included, whatever
+//    they hold -- cancel exactly, so nothing is masked; one ds_bpermute per register fetches P[s - 1];
+//  * the run's pair count is its length.
+// (Round 1's segmented Hillis-Steele scan over ds_bpermute took ~300 instructions per tile; this takes ~110.)
 __device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, int h, int32_t* __restrict__ counts,
                                              long long* __restrict__ acc) {
-  long long v[4];
+  uint32_t lo[4], hi[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = slot >= 0 ? __float2ll_rn(o[q] * kFixedScale) : 0LL;
-  int cnt = slot >= 0 ? 1 : 0;
-  const int prev = __shfl_up(slot, 1, 32);
-  const int next = __shfl_down(slot, 1, 32);
-  int closed = (j == 0 || prev != slot) ? 1 : 0;  // run head: takes nothing from lower lanes
+  for (int q = 0; q < 4; ++q) {
+    const float r = __builtin_rintf(o[q] * kFixedScale);          // integer-valued; |r| < 2^63 for |feature| < 2^31
+    const float hf = __builtin_floorf(r * (1.0f / kFixedScale));  // exact: a power-of-two scaling, then floor
+    hi[q] = (uint32_t)(int)hf;
+    lo[q] = (uint32_t)__builtin_fmaf(hf, -kFixedScale, r);        // exact, in [0, 2^32)
+  }
+  // inclusive prefix over the 32 lanes of each half.  DPP reads need two wait states behind the VALU write of
+  // their source: every register is re-read eight instructions after it was written; s_nop 1 covers the entry.
+#define BNV_SCAN_STEP(ctrl)                                                      \
+  "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %4, vcc, %4, %4 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %6, vcc, %6, %6 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " ctrl "\n"
+  asm volatile("s_nop 1\n"
+               BNV_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])
+               :
+               : "vcc");
+#undef BNV_SCAN_STEP
+  // run geometry from the heads mask of the half: head = first lane of a run
+  const int prev = __builtin_amdgcn_update_dpp(0, slot, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  const unsigned long long heads64 = __ballot(j == 0 || prev != slot);
+  const uint32_t heads = h ? (uint32_t)(heads64 >> 32) : (uint32_t)heads64;
+  const int s = 31 - __clz((int)(heads & (0xffffffffu >> (31 - j))));   // head of this lane's run (bit 0 is set)
+  const bool is_end = j == 31 || ((heads >> (j + 1)) & 1u);
+  const int src = (h * 32 + (s > 0 ? s - 1 : 0)) * 4;                      // lane holding P[s - 1]
+  uint32_t plo[4], phi[4];
 #pragma unroll
-  for (int d = 1; d < 32; d <<= 1) {
-    long long vo[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vo[q] = __shfl_up(v[q], d, 32);
-    const int co = __shfl_up(cnt, d, 32);
-    const int fo = __shfl_up(closed, d, 32);
-    if (j >= d && !closed) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += vo[q];
-      cnt += co;
-      closed |= fo;
-    }
+  for (int q = 0; q < 4; ++q) {
+    plo[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[q]);
+    phi[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[q]);
   }
 #ifdef BNV_PROBE_NO_SCATTER   // development probe (tools/): what do the scatter atomics cost?  keeps 1 of 64 tiles' atomics
   if ((blockIdx.x & 63) != 0) return;
 #endif
-  if (slot >= 0 && (j == 31 || next != slot)) {
-    long long* dst = acc + (size_t)slot * 8 + 4 * h;
+  if (slot >= 0 && is_end) {
+    unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)h);   // 32-bit index: no loop-invariant 64-bit VGPR pair
 #pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd((unsigned long long*)(dst + q), (unsigned long long)v[q]);
-    if (h == 0) atomicAdd(&counts[slot], cnt);
+    for (int q = 0; q < 4; ++q) {
+      unsigned long long v = ((unsigned long long)hi[q] << 32) | lo[q];
+      if (s > 0) v -= ((unsigned long long)phi[q] << 32) | plo[q];
+      atomicAdd(dst + q, v);
+    }
+    if (h == 0) atomicAdd(&counts[slot], j - s + 1);
   }
 }
 
@@ -642,38 +676,77 @@ __device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, hal
   }
 }
 
-template <int NPROD = 3>
-__device__ __forceinline__ void layer128_h(const _Float16* __restrict__ wp, const float* __restrict__ bias,
-                                           const half8 (&inh)[8], const half8 (&inl)[8], f32x16 (&out)[4],
-                                           int lane, int h) {
+// LDS reads of the split-operand encoder go through a handful of OPAQUE 32-bit base addresses plus compile-time
+// byte offsets that fit the 16-bit immediate of ds_read_b128.  Written as plain pointer arithmetic on the 143 KB
+// weight image the compiler kept ~40 VGPRs of pre-added addresses alive across the tile loop (and spilled the
+// staged point of the next tile for them); with three weight bases (lane * 16 + 0 / 60 KB / 120 KB), one for the
+// last layer's rows and one for the biases it keeps five.
+#ifndef BNV_ENC_AHEAD
+#define BNV_ENC_AHEAD 1
+#endif
+typedef __attribute__((address_space(3))) const half8 lds_half8_t;
+typedef __attribute__((address_space(3))) const f32x4 lds_f32x4_t;
+constexpr int kLdsWin = 61440;   // span of one weight base (< 64 KB immediate range, multiple of 1024)
+struct EncLds {
+  uint32_t w[3];   // lane * 16 + kLdsWin * {0, 1, 2}
+  uint32_t w4;     // layer 4: row (j & 7) of lane half h
+  uint32_t b;      // biases: 4 * h floats into the bias block
+};
+__device__ __forceinline__ half8 lds_wfrag(const EncLds& L, int byte_off) {
+  const int b = byte_off / kLdsWin;
+  return *(lds_half8_t*)((b == 0 ? L.w[0] : (b == 1 ? L.w[1] : L.w[2])) + (uint32_t)(byte_off - b * kLdsWin));
+}
+__device__ __forceinline__ f32x16 lds_bias_init(const EncLds& L, int layer, int mb) {
+  f32x16 v;
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) out[mb] = bias_init(bias, mb, h);
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *(lds_f32x4_t*)(L.b + (uint32_t)((layer * 128 + mb * 32 + 8 * q) * 4));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[4 * q + i] = t[i];
+  }
+  return v;
+}
+
+// W_OFF: half offset of the layer's weights in the LDS image (PH_W2 / PH_W3); layer = index of its bias block
+template <int NPROD = 3>
+__device__ __forceinline__ void layer128_h(const EncLds& L, int w_off, int layer, const half8 (&inh)[8],
+                                           const half8 (&inl)[8], f32x16 (&out)[4]) {
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb) out[mb] = lds_bias_init(L, layer, mb);
   // 32 steps q = (K-step g = (nb, ksl), output block mb): three accumulate-chained products per step
   // (chained MFMAs on one accumulator issue back to back); the weight fragments of step q+1 are
   // fetched from LDS before the MFMAs of step q.
-  half8 ah[2], al[2];
-#define BNV_LOAD_W(q)                                                                       \
-  {                                                                                         \
-    const _Float16* w = wp + (((((q) & 3) * 8 + ((q) >> 2)) * 2) * 64 + lane) * 8;           \
-    ah[(q) & 1] = *(const half8*)w;                                                         \
-    if (NPROD == 3) al[(q) & 1] = *(const half8*)(w + 64 * 8);                              \
+  // BNV_ENC_AHEAD steps of look-ahead on the weight fragments (register ring of BNV_ENC_AHEAD + 1)
+  constexpr int kAhead = BNV_ENC_AHEAD, kRing = kAhead + 1;
+  half8 ah[kRing], al[kRing];
+#define BNV_LOAD_W(q)                                                                          \
+  {                                                                                            \
+    const int wb = (w_off + ((((q) & 3) * 8 + ((q) >> 2)) * 2) * 64 * 8) * 2;                   \
+    ah[(q) % kRing] = lds_wfrag(L, wb);                                                        \
+    if (NPROD == 3) al[(q) % kRing] = lds_wfrag(L, wb + 1024);                                 \
   }
-  BNV_LOAD_W(0);
+#pragma unroll
+  for (int p = 0; p < kAhead; ++p) BNV_LOAD_W(p);
 #pragma unroll
   for (int q = 0; q < 32; ++q) {
-    if (q + 1 < 32) BNV_LOAD_W(q + 1);
+    if (q + kAhead < 32) BNV_LOAD_W(q + kAhead);
     __builtin_amdgcn_sched_barrier(0);
     const int g = q >> 2, mb = q & 3;
     if constexpr (NPROD == 3) {
-      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q & 1], inh[g], out[mb], 0, 0, 0);
-      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inl[g], out[mb], 0, 0, 0);
+      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q % kRing], inh[g], out[mb], 0, 0, 0);
+      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q % kRing], inl[g], out[mb], 0, 0, 0);
     }
-    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q & 1], inh[g], out[mb], 0, 0, 0);
+    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q % kRing], inh[g], out[mb], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef BNV_LOAD_W
 }
 
+// Rows 8..31 of the last layer's A operand feed output rows nobody reads.  They used to be replicas of rows 0..7
+// (every lane loads row j & 7: no predication); lanes j >= 8 now read a 4 KB block of zeros instead: the kernel runs
+// at the package power limit (tools/power_probe.py: 0.447 ms with the real weights, 0.363 ms with zeroed ones, same
+// instruction stream) and zero operands are what an MFMA spends least energy on: -1.6 % kernel time.
+constexpr int kEncZeroLds = 4096;
 #ifdef BNV_PHASE_PROF
 __device__ unsigned long long g_enc_phase[8 * 16];
 #define BNV_EPH(i)                                                                          \
@@ -685,10 +758,10 @@ __device__ unsigned long long g_enc_phase[8 * 16];
       _p[15] = _t;                                                                          \
     }                                                                                       \
   } while (0)
-constexpr int kEncProfLds = 8 * 16 * 8;
+constexpr int kEncProfLds = 8 * 16 * 8 + kEncZeroLds;
 #else
 #define BNV_EPH(i)
-constexpr int kEncProfLds = 0;
+constexpr int kEncProfLds = kEncZeroLds;
 #endif
 
 // amdgpu_num_vgpr(120) = 240 of the unified register file (the attribute counts half of it on this target): at 241
@@ -721,6 +794,22 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   const PairTiles T = pair_tiles(n_points, pair_list, n_pairs);
   const int n_tiles = T.n_tiles;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  EncLds L;
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    L.w[0] = lds0 + lane * 16;
+    L.w[1] = L.w[0] + kLdsWin;
+    L.w[2] = L.w[0] + 2 * kLdsWin;
+    L.w4 = lds0 + PH_W4 * 2 + (h * 8 + (j & 7)) * 16;
+    {
+      const uint32_t zero0 = lds0 + PH_LDS_BYTES + (kEncProfLds - kEncZeroLds);
+      for (int i = threadIdx.x; i < kEncZeroLds / 4; i += 512) lds[(PH_LDS_BYTES + (kEncProfLds - kEncZeroLds)) / 4 + i] = 0.f;
+      if (j >= 8) L.w4 = zero0;
+      __syncthreads();
+    }
+    L.b = lds0 + PH_TOTAL * 2 + h * 16;
+    asm volatile("" : "+v"(L.w[0]), "+v"(L.w[1]), "+v"(L.w[2]), "+v"(L.w4), "+v"(L.b));
+  }
 
   // Software pipeline over this wave's tiles: while tile t runs its MLP, the point of tile t+2 and the
   // bitmap / prefix words of tile t+1 are in flight (three dependent memory latencies per tile).
@@ -822,9 +911,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
       }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) {
-        const _Float16* w = wh + PH_W1 + ((mb * 2) * 64 + lane) * 8;
-        const half8 ahi = *(const half8*)w, alo = *(const half8*)(w + 64 * 8);
-        f32x16 c = bias_init(lb, mb, h);
+        const half8 ahi = lds_wfrag(L, (PH_W1 + mb * 2 * 64 * 8) * 2), alo = lds_wfrag(L, (PH_W1 + mb * 2 * 64 * 8) * 2 + 1024);
+        f32x16 c = lds_bias_init(L, 0, mb);
         if constexpr (NPROD == 3) {
           c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
@@ -840,7 +928,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
       split8<NPROD>(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
     BNV_EPH(2);
-    layer128_h<NPROD>(wh + PH_W2, lb + 128, sh, sl, hb, lane, h);
+    layer128_h<NPROD>(L, PH_W2, 1, sh, sl, hb);
     BNV_EPH(3);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -848,7 +936,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
       split8<NPROD>(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
     }
     BNV_EPH(4);
-    layer128_h<NPROD>(wh + PH_W3, lb + 256, sh, sl, ha, lane, h);
+    layer128_h<NPROD>(L, PH_W3, 2, sh, sl, ha);
     BNV_EPH(5);
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
@@ -860,19 +948,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     {
-      const f32x4 b4 = *(const f32x4*)&lb[384 + 4 * h];
+      const f32x4 b4 = *(lds_f32x4_t*)(L.b + 384 * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = b4[r];
     }
-    // A rows >= 8 only feed output rows >= 8, which nobody reads: every lane loads row (j & 7), no
-    // predication and no zero fill; all 16 fragments are fetched before the accumulate chain starts.
+    // A rows >= 8 only feed output rows >= 8, which nobody reads: lanes j < 8 load row j, the others read zeros
+    // (L.w4 points them at the zero block; no predication); the next pair's fragments are fetched under this pair.
     half8 w4h[2][2], w4l[2][2];
 #define BNV_LOAD_W4(gp)                                                                             \
   {                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
-      const _Float16* w = wh + PH_W4 + (((((gp) * 2 + u) * 2) * 2 + h) * 8 + (j & 7)) * 8;          \
-      w4h[(gp) & 1][u] = *(const half8*)w;                                                          \
-      w4l[(gp) & 1][u] = *(const half8*)(w + 2 * 8 * 8);                                            \
+      const uint32_t a4 = L.w4 + (uint32_t)(((gp) * 2 + u) * 4 * 8 * 16);                           \
+      w4h[(gp) & 1][u] = *(lds_half8_t*)a4;                                                         \
+      w4l[(gp) & 1][u] = *(lds_half8_t*)(a4 + 2 * 8 * 16);                                          \
     }                                                                                               \
   }
     __builtin_amdgcn_sched_barrier(0);  // keep these loads below layer 3 (register peak)

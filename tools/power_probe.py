@@ -1,0 +1,42 @@
+"""Is the point encoder bound by cycles or by power?  Same kernel, same instruction stream, same launch sequence:
+once with the real weights, once with the packed weights zeroed (every MFMA operand, activation and feature is then
+zero; the instruction stream is identical).  A large difference in kernel time = the kernel runs at the power limit."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bnv_fusion_amd as bnv
+from bnv_fusion_amd import synthetic, _lib
+dims, voxel = synthetic.GRID_DIMS[256]
+model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
+vol = bnv.SparseVolume(8, voxel, np.array([dims] * 3), 8, device="cuda:0")
+lib = _lib.load()
+frames = [torch.from_numpy(synthetic.frame(t)).cuda() for t in range(4)]
+real = model.pointnet_pack.clone()
+
+
+def timeit(tag, reps=25):
+    for rep in range(5):
+        for p in frames:
+            model.encode_pointcloud_async(p, vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
+    torch.cuda.synchronize()
+    lib.bnv_profile_enable(1)
+    for rep in range(reps):
+        for p in frames:
+            model.encode_pointcloud_async(p, vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
+    torch.cuda.synchronize()
+    ms, n = (C.c_double * 4)(), (C.c_int64 * 4)()
+    lib.bnv_profile_read(ms, n)
+    lib.bnv_profile_enable(0)
+    print(f"{tag}: pointnet+scatter kernel {ms[0] / max(n[0], 1):.4f} ms over {n[0]} launches")
+
+
+for mode in (1, 3):
+    bnv.set_mlp_mode(mode)
+    for rnd in range(2):
+        model.pointnet_pack.copy_(real)
+        timeit(f"mode {mode} real weights")
+        z = torch.zeros_like(real)
+        z[-4:] = real[-4:]          # keep the range-certificate trailer
+        model.pointnet_pack.copy_(z)
+        timeit(f"mode {mode} zero weights")
+model.pointnet_pack.copy_(real)
