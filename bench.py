@@ -501,6 +501,32 @@ def main():
     main_run, kern_run, kern_note = measure(args.mlp_mode)
     elapsed = main_run["elapsed"]
 
+    def sustainable_mfma():
+        """What the f16 MFMA pipe of THIS box sustains when nothing else is issued (bnv_probe_mfma_rate: every CU, two
+        waves per SIMD, ~8 ms): the MLP kernels run at the package power limit, where the clock settles below the
+        2.4 GHz the 2.5 PFLOP/s peak is quoted at -- by how much depends on the operand data (zeros toggle nothing).
+        Measured right behind the timed frames, GPU warm."""
+        out = {}
+        for name, operands, iters in (("random_f16_operands", 1, 16000), ("zero_operands", 0, 8000)):
+            ms, flop = C.c_double(), C.c_double()
+            _lib.check(lib.bnv_probe_mfma_rate(operands, iters, C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                               C.byref(ms), C.byref(flop)), "bnv_probe_mfma_rate")
+            out[name] = {"tflops": flop.value / (ms.value * 1e-3) / 1e12, "ms": ms.value}
+        return out
+
+    power_ceiling = None
+    if world == 1 and not tcnn and args.mlp_mode in (1, 3):
+        pc = sustainable_mfma()
+        issued = kern_run["dec_tflops"] * MFMA_PER_PRODUCT[args.mlp_mode]
+        power_ceiling = {
+            "what": "rate of an MFMA-ONLY stream of v_mfma_f32_32x32x16_f16 on this GPU (every CU, two waves per SIMD, "
+                    "~8 ms, right behind the timed frames): the package power limit, not the 2.4 GHz clock ceiling "
+                    "behind roofline.peak",
+            "tflops_random_f16_operands": pc["random_f16_operands"]["tflops"],
+            "tflops_zero_operands": pc["zero_operands"]["tflops"],
+            "dominant_kernel_issued_tflops": issued,
+            "dominant_kernel_frac_of_it": issued / pc["random_f16_operands"]["tflops"]}
+
     extras = {}
     alts = []
     if not args.no_alt_mode and world == 1 and not tcnn:
@@ -615,7 +641,8 @@ def main():
                                        "replicated volume, one RCCL all-gather of encoded voxels per batch"
                                        if frame_parallel else
                                        f"spatial-hash voxel sharding x{world} + one RCCL all-gather of boundary records per frame")},
-            "roofline": roofline_of(m, kern_run, kern_note),
+            "roofline": dict(roofline_of(m, kern_run, kern_note),
+                             **({"power_limited_mfma_ceiling": power_ceiling} if power_ceiling else {})),
             "kernels": {"pointnet_scatter": {"avg_ms": kern_run["enc_ms"], "tflops": kern_run["enc_tflops"],
                                              "frac_of_peak": kern_run["enc_tflops"] / peak}},
             "parity": main_run["parity"],

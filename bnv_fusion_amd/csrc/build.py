@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["encode.hip", "volume.hip", "decode.hip", "frontend.hip", "tsdf.hip", "mesh.hip", "rays.hip", "io.hip", "shard.hip"]
+SOURCES = ["encode.hip", "volume.hip", "decode.hip", "frontend.hip", "tsdf.hip", "mesh.hip", "rays.hip", "io.hip", "shard.hip", "probe.hip"]
 HEADERS = ["bnv_common.hpp", "frontend.hpp", os.path.join("..", "..", "include", "bnv_fusion.h")]
 OUT = os.path.join(HERE, "..", "libbnv_fusion_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

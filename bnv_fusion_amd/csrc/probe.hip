@@ -1,0 +1,85 @@
+// Diagnostic, not on the product path: what rate of v_mfma_f32_32x32x16_f16 does THIS GPU sustain right now?
+// The two MLP kernels of the frame run at the package power limit: the clock, and with it
+// the dense MFMA rate, settles well below the 2.4 GHz the 2.5 PFLOP/s peak is quoted at, and by how much depends
+// on the operand data (zeros toggle nothing).  bench.py runs this beside the timed frames and reports the
+// dominant kernel against both numbers: the guide's peak (roofline.peak) and this measured ceiling.
+#include <hip/hip_runtime.h>
+
+#include "../../include/bnv_fusion.h"
+#include "bnv_common.hpp"
+
+namespace bnv {
+
+typedef _Float16 pr_half8 __attribute__((ext_vector_type(8)));
+typedef float pr_f32x16 __attribute__((ext_vector_type(16)));
+
+// 8 waves per workgroup (two per SIMD), one workgroup per CU-slot; every wave issues iters x 12 MFMAs on four
+// accumulators, operands from four register sets: zeros (operands = 0) or uniform random f16 in [-2, 2) (1)
+__global__ __launch_bounds__(512) void k_probe_mfma(float* __restrict__ sink, int iters, int operands) {
+  pr_f32x16 acc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+  pr_half8 A[4], B[4];
+  unsigned s = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      s = s * 1664525u + 1013904223u;
+      const float ra = ((s >> 8) & 0xffff) * (4.0f / 65536.0f) - 2.0f;
+      s = s * 1664525u + 1013904223u;
+      const float rb = ((s >> 8) & 0xffff) * (4.0f / 65536.0f) - 2.0f;
+      A[q][e] = operands ? (_Float16)ra : (_Float16)0.f;
+      B[q][e] = operands ? (_Float16)rb : (_Float16)0.f;
+    }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 12; ++u)
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+                   : "+v"(acc[u & 3])
+                   : "v"(A[(u + (u >> 2)) & 3]), "v"(B[(u >> 1) & 3]));
+    if ((it & 63) == 63) {   // keep the sums finite (rare: 1 pass in 64)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] *= 0.001f;
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += acc[a][r];
+  if (sum == 123.456f) sink[0] = sum;   // never true: keeps the accumulators alive without a store per thread
+}
+
+}  // namespace bnv
+
+extern "C" int bnv_probe_mfma_rate(int operands, int iters, void* stream_, double* ms_host, double* flop_host) {
+  using namespace bnv;
+  if (!ms_host || !flop_host || iters <= 0 || (operands != 0 && operands != 1)) return BNV_ERR_INVALID_ARGUMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  int dev = 0, cus = 0;
+  BNV_HIP_CHECK(hipGetDevice(&dev));
+  BNV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  float* sink = nullptr;
+  BNV_HIP_CHECK(hipMalloc(&sink, 16));
+  hipEvent_t e0, e1;
+  BNV_HIP_CHECK(hipEventCreate(&e0));
+  BNV_HIP_CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_probe_mfma, dim3(cus), dim3(512), 0, stream, sink, iters / 8 + 1, operands);   // warm
+  BNV_HIP_CHECK(hipEventRecord(e0, stream));
+  hipLaunchKernelGGL(k_probe_mfma, dim3(cus), dim3(512), 0, stream, sink, iters, operands);
+  BNV_HIP_CHECK(hipEventRecord(e1, stream));
+  BNV_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  BNV_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  BNV_HIP_CHECK(hipEventDestroy(e0));
+  BNV_HIP_CHECK(hipEventDestroy(e1));
+  BNV_HIP_CHECK(hipFree(sink));
+  *ms_host = ms;
+  *flop_host = (double)cus * 8.0 * (double)iters * 12.0 * (2.0 * 32 * 32 * 16);
+  return BNV_OK;
+}
