@@ -1635,6 +1635,326 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_lattice_table_x: the same tables on v_mfma_f32_16x16x32_f16.
+// Both MLP kernels run at the package power limit (tools/power_probe.py), and under that limit the 16x16x32 form
+// delivers ~14 % more FLOP/s than the 32x32x16 form (tools/probe_shapes.hip: 1.88 against 1.65 PFLOP/s with random
+// f16 operands, MFMA-only streams): half the accumulator traffic per FLOP.  Same tile (128 evaluations), same
+// split arithmetic (three products, fp32 accumulation), same bytes from L2 and LDS; what changes is the shape of
+// a wave's work and therefore every layout:
+//  * wave w still owns output features [32 w, 32 w + 32) of every layer for all 128 evaluations: 2 row blocks
+//    (rb) of 16 features x 8 column blocks (cb) of 16 evaluations = 16 accumulators of 4 registers.  Lane
+//    (n = l & 15, g = l >> 4), register i of acc[rb][cb] is feature 32 w + 16 rb + 4 g + i of evaluation 16 cb + n;
+//  * a K-step is 32 deep: operand slot jj of a lane of K-group g is K index 8 g + jj.  The activations live in LDS
+//    as OCTETS [32 octets][128 evaluations][8 halves] (hi plane, lo plane 64 KB behind): octet 4 s + g of K-step
+//    s.  A lane's 8 registers {acc[0][cb][0..3], acc[1][cb][0..3]} are exactly one octet (4 w + g) of the next
+//    layer's input, so the epilogue is again one ds_write_b128 per plane and column block, and K-step s of the
+//    next layer consumes what wave s produced: slot jj <-> feature 32 s + 16 (jj >> 2) + 4 g + (jj & 3).  The weight
+//    fragments are packed to that order on the host (weights.py: _pack_split16; SX_* below);
+//  * one UNIT = (K-step, row block) = 24 MFMAs of 16 cycles = the 384 cycles of a 32x32x16 K-step: the weight
+//    ring (5 units, 3 ahead, 50 units per tile) carries over unchanged.  A K-step's 16 activation fragments stay
+//    in registers for both of its units; the second unit reloads them for the next K-step as it frees them.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SX_W0 = 0;                              // [8 w][2 units][2 hi/lo][64 lane][8]
+constexpr int SX_W1 = SX_W0 + 8 * 2 * 2 * 64 * 8;     // [8 w][16 units][2 hi/lo][64 lane][8]
+constexpr int SX_W2 = SX_W1 + 8 * 16 * 2 * 64 * 8;
+constexpr int SX_W3 = SX_W2 + 8 * 16 * 2 * 64 * 8;
+constexpr int SX_TOTAL = SX_W3 + 8 * 16 * 2 * 64 * 8;  // 409,600 halves, behind the SH_* pack
+static_assert(SX_TOTAL == SH_TOTAL, "16x16x32 pack size");
+constexpr int SD_PACK_FLOATS_X = SD_PACK_FLOATS + SX_TOTAL / 2;
+
+typedef __attribute__((address_space(3))) const half8 lds_half8_t;
+typedef __attribute__((address_space(3))) half8 lds_half8_w_t;
+
+// One layer.  NU = units of this layer (2 for layer 0, 16 for the others), BASE = units before it within the tile
+// (ring phase); the ring holds units 0 .. kTAhead-1 on entry; the last kTAhead units request the NEXT layer's
+// first fragments.  b_hi / b_lo: this lane's LDS byte address of octet g, evaluation n in the source planes.
+template <int NU, int BASE, int NEXT_NU, int NPROD>
+__device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
+                                              const float* __restrict__ bias, uint32_t b_hi, uint32_t b_lo,
+                                              ARing& ring, f32x4 (&acc)[2][8], int w, int g) {
+  const f32x4 bias0 = *(const f32x4*)&bias[32 * w + 4 * g];
+  const f32x4 bias1 = *(const f32x4*)&bias[32 * w + 16 + 4 * g];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    acc[0][cb] = bias0;
+    acc[1][cb] = bias1;
+  }
+  const int sl = off + w * NU * 2048;
+  const int sn = off_next + w * NEXT_NU * 2048;
+  half8 bh[8], bl[8];
+#define BNV_LOAD_BH(s, cb) bh[cb] = *(lds_half8_t*)(b_hi + (uint32_t)((s) * 8192 + (cb) * 256))
+#define BNV_LOAD_BL(s, cb) bl[cb] = *(lds_half8_t*)(b_lo + (uint32_t)((s) * 8192 + (cb) * 256))
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    BNV_LOAD_BH(0, cb);
+    if (NPROD == 3) BNV_LOAD_BL(0, cb);
+  }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int s = u >> 1, rb = u & 1;
+    const int nx = u + kTAhead;   // the unit requested during this one
+    bool loads_a = false;
+    if (nx < NU) {
+      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + nx * 2048);
+      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + nx * 2048 + 1024);
+      loads_a = true;
+    } else if (nx - NU < NEXT_NU && nx - NU < kTAhead) {
+      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + (nx - NU) * 2048);
+      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + (nx - NU) * 2048 + 1024);
+      loads_a = true;
+    }
+    const half8 a_hi = ring.hi[(BASE + u) % kTRing];
+    const bool reload = rb == 1 && 2 * (s + 1) < NU;   // this K-step's fragments are free behind their last use
+    if constexpr (NPROD == 3) {
+      const half8 a_lo = ring.lo[(BASE + u) % kTRing];
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl[cb], acc[rb][cb], 0, 0, 0);
+      if (reload) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) BNV_LOAD_BL(s + 1, cb);
+      }
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh[cb], acc[rb][cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh[cb], acc[rb][cb], 0, 0, 0);
+      if (reload) BNV_LOAD_BH(s + 1, cb);
+    }
+    // issue order: every prefetch in the shadow of an MFMA
+    if constexpr (NPROD == 3) {
+      if (loads_a) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        }
+      }
+      if (reload) {
+        if (loads_a) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // rest of product 1
+        else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // product 2 beside the lo reloads, product 3 each
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // followed by its hi reload
+        }
+      }
+    } else if (reload) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_BH
+#undef BNV_LOAD_BL
+}
+
+// ReLU + hi/lo split of a wave's 32 features x 128 evaluations into octet 4 w + g of the activation planes
+template <int NPROD>
+__device__ __forceinline__ void store_relu_x(uint32_t st_hi, uint32_t st_lo, const f32x4 (&acc)[2][8]) {
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb) {
+    half8 hi, lo;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = relu1(acc[e >> 2][cb][e & 3]);
+    if (NPROD == 3) {
+      split8_f16(x, hi, lo);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hi[e] = (_Float16)x[e];
+    }
+    *(lds_half8_w_t*)(st_hi + (uint32_t)(cb * 256)) = hi;
+    if (NPROD == 3) *(lds_half8_w_t*)(st_lo + (uint32_t)(cb * 256)) = lo;
+  }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
+  const int64_t n_tiles = (n_evals + DM - 1) / DM;
+  const float* pack = A.pack;
+  const _Float16* px = (const _Float16*)(pack + SD_PACK_FLOATS);
+  const float s5 = sinf(0.5f), c5 = cosf(0.5f);
+  const bool gatherer = threadIdx.x < DM;
+
+  // the 32 network inputs (17 used) of (entry ent, features f0 f1) into PARK at evaluation e: octet o holds
+  // inputs 8 o .. 8 o + 7
+  auto stage_park = [&](int e, int ent, const f32x4& f0, const f32x4& f1) {
+    float in[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) in[f] = 0.f;
+    if (ent >= 0) {
+      {
+        const float fe[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        check_feature_range(fe, pack[SD_BA + 1], A.vol.n_rows);
+      }
+      const int l = ent & 31;
+      const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
+      const int li[3] = {lx, ly, lz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        in[a] = (float)li[a] * 0.5f;
+        in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
+        in[6 + a] = li[a] == 0 ? 1.f : c5;
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        in[9 + f] = f0[f];
+        in[13 + f] = f1[f];
+      }
+    } else {
+      in[6] = in[7] = in[8] = 1.f;  // what k_decode stages for an empty column: cos(0)
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      half8 hi, lo;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float x = in[8 * o + jj];
+        const _Float16 t = (_Float16)x;
+        hi[jj] = t;
+        if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
+      }
+      *(half8*)&lds[T_PARK_HI + (o * DM + e) * 4] = hi;
+      if (NPROD == 3) *(half8*)&lds[T_PARK_LO + (o * DM + e) * 4] = lo;
+    }
+  };
+  auto load_feats = [&](int ent, f32x4& f0, f32x4& f1) {
+    if (ent >= 0) {
+      const size_t row = (size_t)(ent >> 5);
+      f0 = *(const f32x4*)&A.features[row * 8];
+      f1 = *(const f32x4*)&A.features[row * 8 + 4];
+    }
+  };
+
+  // tiles are handed out dynamically, one tile ahead (see k_lattice_table_h)
+  __shared__ int s_tile[3];
+  int* tile_ctr = (int*)A.n_list + 2;
+  if (threadIdx.x == 0) {
+    s_tile[0] = atomicAdd(tile_ctr, 1);
+    s_tile[1] = atomicAdd(tile_ctr, 1);
+  }
+  __syncthreads();
+  int64_t tile = s_tile[0], tile_nx = s_tile[1];
+  int ent_cur = -1, ent_nx = -1;
+  f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
+  if (gatherer) {
+    if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
+    if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + threadIdx.x, n_evals);
+    load_feats(ent_cur, f0, f1);
+    stage_park(threadIdx.x, ent_cur, f0, f1);
+  }
+  ARing ring;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)px, 0, SX_TOTAL * 2, 0x00020000);
+  const int voff = lane * 16;
+  constexpr int O0 = SX_W0 * 2, O1 = SX_W1 * 2, O2 = SX_W2 * 2, O3 = SX_W3 * 2;  // byte offsets of the layers
+  {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {  // layer 0 has 2 units; its third request slot belongs to layer 1
+      ring.hi[p] = load_frag(rs, voff, O0 + (w * 2 + p) * 2048);
+      if (NPROD == 3) ring.lo[p] = load_frag(rs, voff, O0 + (w * 2 + p) * 2048 + 1024);
+    }
+    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16) * 2048);
+    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16) * 2048 + 1024);
+  }
+  // LDS byte addresses of this lane (opaque to the optimiser: base + 16-bit immediates, encode.hip: EncLds)
+  uint32_t act_hi, act_lo, park_hi, park_lo, st_hi, st_lo;
+  {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    const uint32_t lane_off = (uint32_t)(g * DM + n) * 16u;
+    act_hi = lds0 + L_HL * 4 + lane_off;
+    act_lo = lds0 + L_HLO * 4 + lane_off;
+    park_hi = lds0 + T_PARK_HI * 4 + lane_off;
+    park_lo = lds0 + T_PARK_LO * 4 + lane_off;
+    st_hi = act_hi + (uint32_t)w * 8192u;     // octet 4 w + g
+    st_lo = act_lo + (uint32_t)w * 8192u;
+    asm volatile("" : "+v"(act_hi), "+v"(act_lo), "+v"(park_hi), "+v"(park_lo), "+v"(st_hi), "+v"(st_lo));
+  }
+  // fc_alpha weights of this lane's eight features
+  f32x4 wa0, wa1;
+  wa0 = *(const f32x4*)&pack[SD_WA + 32 * w + 4 * g];
+  wa1 = *(const f32x4*)&pack[SD_WA + 32 * w + 16 + 4 * g];
+  __syncthreads();
+
+  while (tile < n_tiles) {
+    if (threadIdx.x == 0) s_tile[2] = atomicAdd(tile_ctr, 1);
+    int ent_nx2 = -1;
+    if (gatherer) {
+      f0 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      load_feats(ent_nx, f0, f1);
+    }
+    f32x4 acc[2][8];
+    chain_layer_x<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hi, park_lo, ring, acc, w, g);
+    __syncthreads();
+    const int64_t tile_nx2 = s_tile[2];
+    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    if (gatherer) {
+      stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
+      if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + threadIdx.x, n_evals);
+    }
+    __syncthreads();
+    chain_layer_x<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, act_hi, act_lo, ring, acc, w, g);
+    __syncthreads();
+    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    __syncthreads();
+    chain_layer_x<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, act_hi, act_lo, ring, acc, w, g);
+    __syncthreads();
+    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    __syncthreads();
+    chain_layer_x<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, act_hi, act_lo, ring, acc, w, g);
+    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16) * 2048);  // (50 + 2) % 5: layer 1's unit 0, next tile
+    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16) * 2048 + 1024);
+    // fc_alpha: 256 -> 1.  Partial over this lane's 8 features, K-groups g and g + 2 combined across the lane
+    // halves, 16 partials per evaluation through LDS
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum = fmaf(wa0[i], relu_bits(acc[0][cb][i]), sum);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sum = fmaf(wa1[i], relu_bits(acc[1][cb][i]), sum);
+      sum += __shfl_xor(sum, 32, 64);
+      if (g < 2) lds[L_PART + (w * 2 + g) * DM + cb * 16 + n] = sum;
+    }
+    __syncthreads();
+    if (gatherer) {
+      if (ent_cur >= 0) {
+        float sum = pack[SD_BA];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + threadIdx.x];
+        const int row = ent_cur >> 5;
+        A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
+        if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
+      }
+      ent_cur = ent_nx;
+      ent_nx = ent_nx2;
+    }
+    tile = tile_nx;
+    tile_nx = tile_nx2;
+  }
+  if (threadIdx.x == 0) {
+    int* done = (int*)A.n_list + 3;
+    __threadfence();
+    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+      *tile_ctr = 0;
+      *done = 0;
+    }
+  }
+}
+
 // ---- lattice decode: neighbour lookup + blend ------------------------------------------------
 struct LatticeWs {
   int32_t* nbr_rows;  // [n][27]
@@ -2009,7 +2329,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   out[t] = o;
 }
 
-int g_lattice_pipe = 1; // 1: k_lattice_table_h (cross-tile / cross-layer pipelined); 0: k_decode<LATTICE, 1>
+int g_lattice_pipe = 2; // 2: k_lattice_table_x (16x16x32 MFMA); 1: k_lattice_table_h (32x32x16); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
 constexpr int kProfLds = 2048;
@@ -2023,7 +2343,12 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   if (grid < 1) grid = 1;
   if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
-    if (g_mlp_mode == 1)
+    if (g_lattice_pipe == 2) {
+      if (g_mlp_mode == 1)
+        hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+      else
+        hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+    } else if (g_mlp_mode == 1)
       hipLaunchKernelGGL(k_lattice_table_h<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
     else
       hipLaunchKernelGGL(k_lattice_table_h<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
@@ -2099,6 +2424,10 @@ int bnv_decode_init() {
   BNV_OPT_IN(MODE_DENSE, 3);
   BNV_OPT_IN(MODE_DENSE1, 3);
 #undef BNV_OPT_IN
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_x<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T_TOTAL * 4 + kProfLds));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_x<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    T_TOTAL * 4 + kProfLds));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2114,7 +2443,7 @@ int bnv_decode_init() {
   return BNV_OK;
 }
 
-size_t bnv_sdfmlp_pack_floats(void) { return SD_PACK_FLOATS; }
+size_t bnv_sdfmlp_pack_floats(void) { return SD_PACK_FLOATS_X; }
 
 #ifdef BNV_PHASE_PROF
 // development builds only (not in include/bnv_fusion.h): read and reset the phase cycle counters

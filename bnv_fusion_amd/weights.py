@@ -186,6 +186,29 @@ def _pack_split(W, nks, n_blocks=8):
     return o.ravel()
 
 
+def _pack_split16(W, n_steps, first_layer=False):
+    """Split pack for v_mfma_f32_16x16x32_f16 (SX_* of csrc/decode.hip, k_lattice_table_x):
+    [8 w][2 n_steps units][hi/lo][64 lane][8] halves, unit u = 2 s + rb.  Slot jj of lane (m = l & 15, g = l >> 4) =
+    W[32 w + 16 rb + m][k] with k = 32 s + 16 (jj >> 2) + 4 g + (jj & 3) -- the order in which a wave's accumulator
+    registers leave the previous layer -- or, for the first layer, k = 8 g + jj (inputs beyond W's columns are 0)."""
+    lane = np.arange(64)
+    m, g = lane & 15, lane >> 4
+    jj = np.arange(8)
+    Wp = np.zeros((256, 32 * n_steps), np.float32)
+    Wp[:W.shape[0], :W.shape[1]] = W
+    o = np.zeros((8, 2 * n_steps, 2, 64, 8), np.float16)
+    for w in range(8):
+        for s in range(n_steps):
+            for rb in range(2):
+                if first_layer:
+                    k = 8 * g[:, None] + jj[None, :]
+                else:
+                    k = 32 * s + 16 * (jj[None, :] >> 2) + 4 * g[:, None] + (jj[None, :] & 3)
+                v = Wp[(32 * w + 16 * rb + m)[:, None], k]
+                o[w, 2 * s + rb, 0], o[w, 2 * s + rb, 1] = split_f16(v)
+    return o.ravel()
+
+
 def pack_sdf_mlp_bwd(sd):
     """Transposed layers for bnv_decode_pts_backward -> float32 [204800] (SB_* layout of csrc/decode.hip):
     W3^T, W2^T, W1^T as 256x256 split packs, then W0^T (17 x 256, rows padded to 32)."""
@@ -226,7 +249,11 @@ def pack_sdf_mlp(sd):
     halves = np.concatenate([_pack_split(Ws[0], 2), _pack_split(Ws[1], 16), _pack_split(Ws[2], 16),
                              _pack_split(Ws[3], 16)])
     assert halves.size == 409600
-    return np.concatenate([fp32_part, halves.view(np.float32)])
+    # the same four layers in the operand order of the 16x16x32 MFMA (k_lattice_table_x), behind the 32x32x16 pack
+    halves_x = np.concatenate([_pack_split16(Ws[0], 1, first_layer=True), _pack_split16(Ws[1], 8),
+                               _pack_split16(Ws[2], 8), _pack_split16(Ws[3], 8)])
+    assert halves_x.size == 409600
+    return np.concatenate([fp32_part, halves.view(np.float32), halves_x.view(np.float32)])
 
 
 # --------------------------------------------------------------------------------------------------

@@ -90,7 +90,7 @@ def test_sdf_mlp_pack_matches_direct_mlp():
     SD_W2, SD_W3 = SD_W1 + 65536, SD_W1 + 2 * 65536
     SD_B0 = SD_W3 + 65536
     SD_WA, SD_BA = SD_B0 + 1024, SD_B0 + 1024 + 256
-    assert pack.size == SD_BA + 4 + 409600 // 2
+    assert pack.size == SD_BA + 4 + 2 * (409600 // 2)      # 32x32x16 split pack + 16x16x32 split pack
     DM = 128
     rng = np.random.default_rng(1)
     x = rng.uniform(-1, 1, size=(DM, 17))
@@ -309,6 +309,96 @@ def test_sdf_mlp_split_pack_matches_direct_mlp():
             s = (wa * np.maximum(accs[w][pt], 0)).sum(1)
             for l in range(64):
                 alpha[pt * 32 + N_[l]] += s[l]
+    tsd = orc.load_weights(WEIGHTS_FP32)
+    ref = orc.geo_forward(tsd, torch.from_numpy(x).float())[:, 0].numpy()
+    assert np.abs(alpha - ref).max() < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# v_mfma_f32_16x16x32_f16 (k_lattice_table_x): A lane l holds A[m = l & 15][k = 8 (l >> 4) + jj], B lane l holds
+# B[k = 8 (l >> 4) + jj][n = l & 15], D lane l register i holds D[m = 4 (l >> 4) + i][n = l & 15]
+# (cdna_hip_programming.md section 3).
+# ---------------------------------------------------------------------------------------------
+M16, G16 = LANE & 15, LANE >> 4
+
+
+def mfma16x16x32(a, b, c):
+    """a, b: [64, 8] per-lane operand slots; c: [64, 4]."""
+    A = np.zeros((16, 32))
+    B = np.zeros((32, 16))
+    for jj in range(8):
+        A[M16, 8 * G16 + jj] = a[:, jj]
+        B[8 * G16 + jj, M16] = b[:, jj]
+    D = A @ B
+    return c + np.stack([D[4 * G16 + i, M16] for i in range(4)], 1)
+
+
+def test_sdf_mlp_x_pack_matches_direct_mlp():
+    """The 16x16x32 pack (weights._pack_split16) against the index arithmetic of k_lattice_table_x: octet layout of
+    the activation planes, unit order of the weight fragments, bias / fc_alpha fragments, the 16 partials."""
+    sd = W.load_npz(WEIGHTS_FP32)
+    pack = W.pack_sdf_mlp(sd)
+    SD_TOTAL = 6144 + 3 * 65536 + 1024 + 256 + 4
+    assert pack.size == SD_TOTAL + 2 * 409600 // 2
+    fp = pack[:SD_TOTAL].astype(np.float64)
+    hx = pack[SD_TOTAL + 409600 // 2:].view(np.float16).astype(np.float64)
+    SD_B0 = 6144 + 3 * 65536
+    SD_WA, SD_BA = SD_B0 + 1024, SD_B0 + 1280
+    SX = [0, 16384, 16384 + 131072, 16384 + 2 * 131072]
+    DM = 128
+    J8 = np.arange(8)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(DM, 17)).astype(np.float32)
+    xin = np.zeros((DM, 32), np.float32)
+    xin[:, :17] = x
+    # PARK: octet o of evaluation e = inputs 8 o .. 8 o + 7
+    hi = np.zeros((4, DM, 8))
+    lo = np.zeros((4, DM, 8))
+    for o in range(4):
+        hi[o], lo[o] = _split(xin[:, 8 * o: 8 * o + 8])
+
+    def layer(woff, boff, n_units, hi, lo):
+        accs = []
+        for w in range(8):
+            acc = [[np.stack([fp[boff + 32 * w + 16 * rb + 4 * G16 + i] for i in range(4)], 1) for _ in range(8)]
+                   for rb in range(2)]
+            for u in range(n_units):
+                s, rb = u >> 1, u & 1
+                wi = woff + (w * n_units + u) * 1024 + LANE[:, None] * 8 + J8[None, :]
+                ah, al = hx[wi], hx[wi + 512]
+                for cb in range(8):
+                    bh, bl = hi[4 * s + G16, 16 * cb + M16], lo[4 * s + G16, 16 * cb + M16]
+                    c = acc[rb][cb]
+                    c = mfma16x16x32(ah, bl, c)
+                    c = mfma16x16x32(al, bh, c)
+                    acc[rb][cb] = mfma16x16x32(ah, bh, c)
+            accs.append(acc)
+        return accs
+
+    def store(accs):
+        hi = np.zeros((32, DM, 8))
+        lo = np.zeros((32, DM, 8))
+        for w in range(8):
+            for cb in range(8):
+                v = np.concatenate([accs[w][0][cb], accs[w][1][cb]], 1)      # [64 lanes][8]: one octet per lane
+                a, b = _split(np.maximum(v, 0).astype(np.float32))
+                hi[4 * w + G16, 16 * cb + M16] = a
+                lo[4 * w + G16, 16 * cb + M16] = b
+        return hi, lo
+
+    hi, lo = store(layer(SX[0], SD_B0, 2, hi, lo))
+    hi, lo = store(layer(SX[1], SD_B0 + 256, 16, hi, lo))
+    hi, lo = store(layer(SX[2], SD_B0 + 512, 16, hi, lo))
+    accs = layer(SX[3], SD_B0 + 768, 16, hi, lo)
+    part = np.zeros((16, DM))
+    for w in range(8):
+        wa = [np.stack([fp[SD_WA + 32 * w + 16 * rb + 4 * G16 + i] for i in range(4)], 1) for rb in range(2)]
+        for cb in range(8):
+            s = sum((wa[rb] * np.maximum(accs[w][rb][cb], 0)).sum(1) for rb in range(2))     # [64]
+            s = s + s[LANE ^ 32]
+            for l in range(32):                                                           # lanes with g < 2
+                part[w * 2 + G16[l], cb * 16 + M16[l]] = s[l]
+    alpha = fp[SD_BA] + part.sum(0)
     tsd = orc.load_weights(WEIGHTS_FP32)
     ref = orc.geo_forward(tsd, torch.from_numpy(x).float())[:, 0].numpy()
     assert np.abs(alpha - ref).max() < 2e-5

@@ -1,5 +1,6 @@
-"""A/B of the lattice-table kernels: k_decode<LATTICE,1> (lattice_pipe=0) vs k_lattice_table_h (=1):
-bitwise equality of the decoded SDF and interleaved kernel timings."""
+"""A/B of the lattice-table kernels: k_decode<LATTICE,1> (lattice_pipe=0), k_lattice_table_h (=1: 32x32x16 MFMA,
+bit-identical to 0) and k_lattice_table_x (=2: 16x16x32 MFMA, same arithmetic in another summation grouping):
+differences of the decoded SDF and interleaved kernel timings.  Usage: ab_pipe.py [mlp_mode]"""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
@@ -10,23 +11,27 @@ nm = bnv.NeuralMap(np.array([dims]*3), voxel, model, capacity=1<<20, device="cud
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)} for t in range(60)]
 for t in range(30): nm.integrate(frames[t])
 lib = _lib.load()
+if len(sys.argv) > 1:
+    bnv.set_mlp_mode(int(sys.argv[1]))
 coords = nm.integrate(frames[30])
 outs = {}
-for opt in (0, 1):
+for opt in (0, 1, 2):
     lib.bnv_set_option(b"lattice_pipe", opt)
     outs[opt] = nm.volume.decode_lattice(coords, model.nerf, None, query_tensor=False).clone()
-print("bitwise equal:", torch.equal(outs[0], outs[1]), "max diff", float((outs[0]-outs[1]).abs().max()),
+print("pipe 1 vs 0: bitwise equal:", torch.equal(outs[0], outs[1]), "max diff", float((outs[0]-outs[1]).abs().max()),
       "live", float((outs[1] != voxel).float().mean()))
+print("pipe 2 vs 0: bitwise equal:", torch.equal(outs[0], outs[2]), "max diff", float((outs[0]-outs[2]).abs().max()),
+      "mask decisions equal:", bool(((outs[0] == voxel) == (outs[2] == voxel)).all()))
 # small / ragged sizes
 for n in (1, 5, 129, 1000):
     a = {}
-    for opt in (0, 1):
+    for opt in (0, 1, 2):
         lib.bnv_set_option(b"lattice_pipe", opt)
         a[opt] = nm.volume.decode_lattice(coords[:n], model.nerf, None, query_tensor=False).clone()
-    print(n, torch.equal(a[0], a[1]))
-res = {0: [], 1: []}
+    print(n, torch.equal(a[0], a[1]), float((a[0] - a[2]).abs().max()))
+res = {0: [], 1: [], 2: []}
 for rnd in range(4):
-    for opt in (0, 1):
+    for opt in (0, 1, 2):
         lib.bnv_set_option(b"lattice_pipe", opt)
         nm.fuse_and_decode(frames[30]); torch.cuda.synchronize()
         lib.bnv_profile_enable(1)
@@ -34,4 +39,6 @@ for rnd in range(4):
         torch.cuda.synchronize()
         ms=(C.c_double*4)(); n=(C.c_int64*4)(); lib.bnv_profile_read(ms,n); lib.bnv_profile_enable(0)
         res[opt].append(ms[1]/n[1])
-print("lattice MLP kernel ms  pipe=0:", ["%.3f"%x for x in res[0]], " pipe=1:", ["%.3f"%x for x in res[1]])
+print("lattice MLP kernel ms  pipe=0:", ["%.3f"%x for x in res[0]], " pipe=1:", ["%.3f"%x for x in res[1]],
+      " pipe=2:", ["%.3f"%x for x in res[2]])
+lib.bnv_set_option(b"lattice_pipe", 2)
