@@ -57,8 +57,8 @@ DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
          2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
          3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_32x32x16_f16, f32 accumulate"}
-DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_h<3>", 2: "k_decode<LATTICE, tcnn>",
-                 3: "k_lattice_table_h<1>"}
+DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_x<3>", 2: "k_decode<LATTICE, tcnn>",
+                 3: "k_lattice_table_x<1>"}
 PARITY_VOXELS = 2048
 
 # Row capacity of the volume in the timed runs.  The tables grow on demand like the reference's Open3D map, but a
@@ -487,7 +487,7 @@ def main():
         peak = PEAK_TFLOPS[mode]
         traffic, src = (None, None)
         if mode == 1 and world == 1 and not tcnn:
-            traffic, src = pmc_traffic("k_lattice_table_h<3>", kern["rows"])
+            traffic, src = pmc_traffic("k_lattice_table_x<3>", kern["rows"])
         # achieved = algorithmic FLOPs (402,432 per MLP evaluation x evaluations per launch; the split mode issues 3
         # MFMA products per algorithmic product, which are NOT counted) / mean kernel time from HIP events recorded
         # on the launch stream
@@ -503,15 +503,19 @@ def main():
 
     def sustainable_mfma():
         """What the f16 MFMA pipe of THIS box sustains when nothing else is issued (bnv_probe_mfma_rate: every CU, two
-        waves per SIMD, ~8 ms): the MLP kernels run at the package power limit, where the clock settles below the
-        2.4 GHz the 2.5 PFLOP/s peak is quoted at -- by how much depends on the operand data (zeros toggle nothing).
+        waves per SIMD, ~8 ms per case): the MLP kernels run at the package power limit, where the clock settles below
+        the 2.4 GHz the 2.5 PFLOP/s peak is quoted at -- by how much depends on the MFMA shape (the 16x16x32 form the
+        dominant kernel uses moves half the accumulator data per FLOP) and on the operand data (zeros toggle nothing).
         Measured right behind the timed frames, GPU warm."""
         out = {}
-        for name, operands, iters in (("random_f16_operands", 1, 16000), ("zero_operands", 0, 8000)):
+        for name, shape, operands, iters in (("16x16x32_random_f16_operands", 1, 1, 16000),
+                                             ("32x32x16_random_f16_operands", 0, 1, 16000),
+                                             ("16x16x32_zero_operands", 1, 0, 8000)):
             ms, flop = C.c_double(), C.c_double()
-            _lib.check(lib.bnv_probe_mfma_rate(operands, iters, C.c_void_p(torch.cuda.current_stream().cuda_stream),
+            _lib.check(lib.bnv_probe_mfma_rate(shape, operands, iters,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream),
                                                C.byref(ms), C.byref(flop)), "bnv_probe_mfma_rate")
-            out[name] = {"tflops": flop.value / (ms.value * 1e-3) / 1e12, "ms": ms.value}
+            out[name] = flop.value / (ms.value * 1e-3) / 1e12
         return out
 
     power_ceiling = None
@@ -519,13 +523,14 @@ def main():
         pc = sustainable_mfma()
         issued = kern_run["dec_tflops"] * MFMA_PER_PRODUCT[args.mlp_mode]
         power_ceiling = {
-            "what": "rate of an MFMA-ONLY stream of v_mfma_f32_32x32x16_f16 on this GPU (every CU, two waves per SIMD, "
-                    "~8 ms, right behind the timed frames): the package power limit, not the 2.4 GHz clock ceiling "
-                    "behind roofline.peak",
-            "tflops_random_f16_operands": pc["random_f16_operands"]["tflops"],
-            "tflops_zero_operands": pc["zero_operands"]["tflops"],
+            "what": "rate of an MFMA-ONLY stream on this GPU (every CU, two waves per SIMD, ~8 ms per case, right "
+                    "behind the timed frames): the package power limit, not the 2.4 GHz clock ceiling behind "
+                    "roofline.peak; the dominant kernel issues v_mfma_f32_16x16x32_f16",
+            "tflops_16x16x32_random_f16_operands": pc["16x16x32_random_f16_operands"],
+            "tflops_32x32x16_random_f16_operands": pc["32x32x16_random_f16_operands"],
+            "tflops_16x16x32_zero_operands": pc["16x16x32_zero_operands"],
             "dominant_kernel_issued_tflops": issued,
-            "dominant_kernel_frac_of_it": issued / pc["random_f16_operands"]["tflops"]}
+            "dominant_kernel_frac_of_it": issued / pc["16x16x32_random_f16_operands"]}
 
     extras = {}
     alts = []

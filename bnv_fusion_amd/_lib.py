@@ -142,7 +142,7 @@ def load():
         "bnv_set_option": (C.c_int, [C.c_char_p, C.c_int]),
         "bnv_profile_enable": (C.c_int, [C.c_int]),
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
-        "bnv_probe_mfma_rate": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "bnv_probe_mfma_rate": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),

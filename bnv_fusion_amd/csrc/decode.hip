@@ -1651,9 +1651,9 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
 //    layer's input, so the epilogue is again one ds_write_b128 per plane and column block, and K-step s of the
 //    next layer consumes what wave s produced: slot jj <-> feature 32 s + 16 (jj >> 2) + 4 g + (jj & 3).  The weight
 //    fragments are packed to that order on the host (weights.py: _pack_split16; SX_* below);
-//  * one UNIT = (K-step, row block) = 24 MFMAs of 16 cycles = the 384 cycles of a 32x32x16 K-step: the weight
-//    ring (5 units, 3 ahead, 50 units per tile) carries over unchanged.  A K-step's 16 activation fragments stay
-//    in registers for both of its units; the second unit reloads them for the next K-step as it frees them.
+//  * one UNIT = half a K-step = 24 MFMAs of 16 cycles = the 384 cycles of a 32x32x16 K-step, so the weight ring
+//    (5 units of one hi + one lo fragment, 3 ahead, 50 units per tile) and the activation double buffer carry
+//    over unchanged (chain_layer_x).
 // ---------------------------------------------------------------------------------------------------
 constexpr int SX_W0 = 0;                              // [8 w][2 units][2 hi/lo][64 lane][8]
 constexpr int SX_W1 = SX_W0 + 8 * 2 * 2 * 64 * 8;     // [8 w][16 units][2 hi/lo][64 lane][8]
@@ -1667,8 +1667,12 @@ typedef __attribute__((address_space(3))) const half8 lds_half8_t;
 typedef __attribute__((address_space(3))) half8 lds_half8_w_t;
 
 // One layer.  NU = units of this layer (2 for layer 0, 16 for the others), BASE = units before it within the tile
-// (ring phase); the ring holds units 0 .. kTAhead-1 on entry; the last kTAhead units request the NEXT layer's
-// first fragments.  b_hi / b_lo: this lane's LDS byte address of octet g, evaluation n in the source planes.
+// (ring phase).  A WEIGHT unit is (K-step s, row block rb), index 2 s + rb: one hi + one lo fragment; a COMPUTE unit
+// is (K-step s, column half ch), index 2 s + ch: both row blocks x 4 column blocks x 3 products = 24 MFMAs, reading
+// both weight units of its K-step and 4 + 4 activation fragments.  The ring holds weight units 0 .. kTAhead-1 on
+// entry; compute unit u requests weight unit u + kTAhead (the last ones those of the NEXT layer) and the activation
+// fragments of compute unit u + 1 (double buffer) -- per unit 24 MFMAs, 8 LDS reads, 2 L2 reads, like a K-step of
+// the 32x32x16 kernel.  b_hi / b_lo: this lane's LDS byte address of octet g, evaluation n in the source planes.
 template <int NU, int BASE, int NEXT_NU, int NPROD>
 __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
                                               const float* __restrict__ bias, uint32_t b_hi, uint32_t b_lo,
@@ -1682,18 +1686,20 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
   }
   const int sl = off + w * NU * 2048;
   const int sn = off_next + w * NEXT_NU * 2048;
-  half8 bh[8], bl[8];
-#define BNV_LOAD_BH(s, cb) bh[cb] = *(lds_half8_t*)(b_hi + (uint32_t)((s) * 8192 + (cb) * 256))
-#define BNV_LOAD_BL(s, cb) bl[cb] = *(lds_half8_t*)(b_lo + (uint32_t)((s) * 8192 + (cb) * 256))
-#pragma unroll
-  for (int cb = 0; cb < 8; ++cb) {
-    BNV_LOAD_BH(0, cb);
-    if (NPROD == 3) BNV_LOAD_BL(0, cb);
+  half8 bh[2][4], bl[2][4];
+#define BNV_LOAD_B(u)                                                                                         \
+  {                                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                           \
+      const uint32_t o = (uint32_t)(((u) >> 1) * 8192 + (((u) & 1) * 4 + c) * 256);                           \
+      bh[(u) & 1][c] = *(lds_half8_t*)(b_hi + o);                                                             \
+      if (NPROD == 3) bl[(u) & 1][c] = *(lds_half8_t*)(b_lo + o);                                             \
+    }                                                                                                         \
   }
+  BNV_LOAD_B(0);
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int s = u >> 1, rb = u & 1;
-    const int nx = u + kTAhead;   // the unit requested during this one
+    const int s = u >> 1, ch = u & 1;
+    const int nx = u + kTAhead;   // the weight unit requested during this compute unit
     bool loads_a = false;
     if (nx < NU) {
       ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + nx * 2048);
@@ -1704,55 +1710,45 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
       if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + (nx - NU) * 2048 + 1024);
       loads_a = true;
     }
-    const half8 a_hi = ring.hi[(BASE + u) % kTRing];
-    const bool reload = rb == 1 && 2 * (s + 1) < NU;   // this K-step's fragments are free behind their last use
+    if (u + 1 < NU) BNV_LOAD_B(u + 1);
     if constexpr (NPROD == 3) {
-      const half8 a_lo = ring.lo[(BASE + u) % kTRing];
 #pragma unroll
-      for (int cb = 0; cb < 8; ++cb)
-        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bl[cb], acc[rb][cb], 0, 0, 0);
-      if (reload) {
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) BNV_LOAD_BL(s + 1, cb);
-      }
+        for (int c = 0; c < 4; ++c)
+          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bl[u & 1][c],
+                                                                       acc[rb][4 * ch + c], 0, 0, 0);
 #pragma unroll
-      for (int cb = 0; cb < 8; ++cb)
-        acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bh[cb], acc[rb][cb], 0, 0, 0);
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.lo[(BASE + 2 * s + rb) % kTRing], bh[u & 1][c],
+                                                                       acc[rb][4 * ch + c], 0, 0, 0);
     }
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bh[cb], acc[rb][cb], 0, 0, 0);
-      if (reload) BNV_LOAD_BH(s + 1, cb);
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bh[u & 1][c],
+                                                                     acc[rb][4 * ch + c], 0, 0, 0);
+    // issue order: every prefetch in the shadow of an MFMA (one memory instruction behind each)
+    if (u + 1 < NU) {
+#pragma unroll
+      for (int q = 0; q < (NPROD == 3 ? 8 : 4); ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+      }
     }
-    // issue order: every prefetch in the shadow of an MFMA
-    if constexpr (NPROD == 3) {
-      if (loads_a) {
+    if (loads_a) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-        }
-      }
-      if (reload) {
-        if (loads_a) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);   // rest of product 1
-        else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // product 2 beside the lo reloads, product 3 each
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // followed by its hi reload
-        }
-      }
-    } else if (reload) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int q = 0; q < (NPROD == 3 ? 2 : 1); ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-#undef BNV_LOAD_BH
-#undef BNV_LOAD_BL
+#undef BNV_LOAD_B
 }
 
 // ReLU + hi/lo split of a wave's 32 features x 128 evaluations into octet 4 w + g of the activation planes

@@ -76,7 +76,8 @@ for rnd in range(2):
     model.nerf.sdf_pack.copy_(z)
     time_decode("decoder zero weights")
 model.nerf.sdf_pack.copy_(real_sdf)
-for operands, name in ((1, "random f16 operands"), (0, "zero operands")):
-    ms, flop = C.c_double(), C.c_double()
-    lib.bnv_probe_mfma_rate(operands, 16000, None, C.byref(ms), C.byref(flop))
-    print(f"MFMA-only stream, {name}: {flop.value / ms.value / 1e9:.0f} TFLOP/s ({ms.value:.2f} ms)")
+for shape, sname in ((1, "16x16x32"), (0, "32x32x16")):
+    for operands, name in ((1, "random f16 operands"), (0, "zero operands")):
+        ms, flop = C.c_double(), C.c_double()
+        lib.bnv_probe_mfma_rate(shape, operands, 16000, None, C.byref(ms), C.byref(flop))
+        print(f"MFMA-only stream, {sname}, {name}: {flop.value / ms.value / 1e9:.0f} TFLOP/s ({ms.value:.2f} ms)")
