@@ -1357,99 +1357,28 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd_t(DecodeBwdArgs B) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// k_lattice_table_h: the hot kernel (lattice table, split-operand mode), software-pipelined ACROSS tiles
-// and layers.  Same arithmetic as k_decode<LATTICE, 1> (bit-identical tables); what changes is when
-// things are fetched (tools/phase_prof.py showed 5 % of a tile in the gather/stage front end, ~600 idle
-// cycles at every layer start waiting for the first weight fragments, 11 barriers per tile):
+// The lattice-table kernel of the split-operand modes (k_lattice_table_x below) is software-pipelined ACROSS
+// tiles and layers.  Same arithmetic as k_decode<LATTICE, 1>, in another summation grouping (tables equal to
+// ~1e-8); what changes is when things are fetched:
 //  * the work-list entry of tile t+2 and the features of tile t+1 are loaded while tile t runs its MLP;
 //    the inputs of tile t+1 are split and staged into a separate LDS buffer (PARK) in the shadow of layer
 //    0's store phase, and layer 0 reads its B operands from PARK -- no gather on the critical path;
-//  * the weight-fragment ring runs continuously through the 50 K-steps of a tile and on into the next
-//    tile: the first fragments of layer L+1 are requested during the last K-steps of layer L, so they
+//  * the weight-fragment ring runs continuously through the 50 units of a tile and on into the next
+//    tile: the first fragments of layer L+1 are requested during the last units of layer L, so they
 //    arrive during the convert/store phase and its barriers;
 //  * sin / cos of the lattice offsets {-.5, 0, .5} are two constants; the final reduction writes the table
 //    directly; 7 barriers per tile.
+// (Round 1's and 2's version of this kernel on v_mfma_f32_32x32x16_f16, k_lattice_table_h, is in the git history
+// up to commit c19da39: bit-identical to k_decode<LATTICE, 1>, 5 % slower than the 16x16x32 form.)
 // ---------------------------------------------------------------------------------------------------
-constexpr int T_PARK_HI = L_PART + 16 * DM;            // [2 ks][2 h][128 j][8 halves] = 8 KB
+constexpr int T_PARK_HI = L_PART + 16 * DM;            // [4 octets][128 evaluations][8 halves] = 8 KB
 constexpr int T_PARK_LO = T_PARK_HI + 2 * 2 * DM * 4;  // lo plane
 constexpr int T_TOTAL = T_PARK_LO + 2 * 2 * DM * 4;    // 38,912 floats = 155,648 B
-constexpr int kTRing = 5, kTAhead = 3;                 // 50 K-steps per tile: 50 % 5 == 0 keeps the ring phase
+constexpr int kTRing = 5, kTAhead = 3;                 // 50 units per tile: 50 % 5 == 0 keeps the ring phase
 
 struct ARing {
   half8 hi[kTRing], lo[kTRing];
 };
-
-// One layer of the chain.  BASE = K-steps before this layer within the tile (ring phase); the ring holds
-// this layer's fragments 0 .. kTAhead-1 on entry; the last kTAhead steps request the NEXT layer's first
-// fragments from wp_next (its per-wave stride NEXT_NKS).
-template <int NKS, int BASE, int NEXT_NKS, int NPROD>
-__device__ __forceinline__ void chain_layer(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
-                                            const float* __restrict__ bias, const float* __restrict__ hh,
-                                            const float* __restrict__ hl, ARing& ring, f32x16 (&acc)[4], int w,
-                                            int h) {
-  // weight fragments through the buffer descriptor of the whole split pack: `off` / `off_next` are the byte
-  // offsets of this / the next layer, the per-wave and per-fragment parts are scalar too -- no 64-bit address
-  // VGPRs for the 100 loads of a tile (flat loads get their addresses hoisted out of the tile loop and spill)
-  const f32x16 b0 = frag256(bias, w, h);
-#pragma unroll
-  for (int pt = 0; pt < 4; ++pt) acc[pt] = b0;
-  const int sl = off + w * NKS * 2 * 1024;
-  const int sn = off_next + w * NEXT_NKS * 2 * 1024;
-  half8 bh[2][4], bl[2][4];
-#define BNV_LOAD_B(ks)                                                                    \
-  {                                                                                       \
-    _Pragma("unroll") for (int pt = 0; pt < 4; ++pt) {                                    \
-      bh[(ks) & 1][pt] = *(const half8*)(hh + ((ks) * 2 * DM + pt * 32) * 4);             \
-      if (NPROD == 3) bl[(ks) & 1][pt] = *(const half8*)(hl + ((ks) * 2 * DM + pt * 32) * 4); \
-    }                                                                                     \
-  }
-  BNV_LOAD_B(0);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int nx = ks + kTAhead;  // the fragment requested during this step
-    bool loads_a = false;
-    if (nx < NKS) {
-      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2) * 1024);
-      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sl + (nx * 2 + 1) * 1024);
-      loads_a = true;
-    } else if (nx - NKS < NEXT_NKS && nx - NKS < kTAhead) {
-      ring.hi[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2) * 1024);
-      if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + ((nx - NKS) * 2 + 1) * 1024);
-      loads_a = true;
-    }
-    if (ks + 1 < NKS) BNV_LOAD_B(ks + 1);
-    const half8 a_hi = ring.hi[(BASE + ks) % kTRing];
-    if constexpr (NPROD == 3) {
-      const half8 a_lo = ring.lo[(BASE + ks) % kTRing];
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt)
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh[ks & 1][pt], acc[pt], 0, 0, 0);
-#pragma unroll
-      for (int pt = 0; pt < 4; ++pt)
-        acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl[ks & 1][pt], acc[pt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt)
-      acc[pt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh[ks & 1][pt], acc[pt], 0, 0, 0);
-    if (ks + 1 < NKS) {
-#pragma unroll
-      for (int g = 0; g < (NPROD == 3 ? 8 : 3); ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
-      }
-      if (NPROD == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    if (loads_a) {
-#pragma unroll
-      for (int g = 0; g < (NPROD == 3 ? 2 : 1); ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef BNV_LOAD_B
-}
 
 // (row, l) of evaluation e of the work list, or row = -1 beyond its end
 __device__ __forceinline__ int lattice_entry(const DecodeArgs& A, int64_t e, int64_t n_evals) {
@@ -1457,182 +1386,6 @@ __device__ __forceinline__ int lattice_entry(const DecodeArgs& A, int64_t e, int
   if (A.entries) return A.entries[e];
   const int64_t ci = e / 27;
   return (A.list[ci] << 5) | (int)(e - ci * 27);
-}
-
-template <int NPROD>
-__global__ __launch_bounds__(512, 2) void k_lattice_table_h(DecodeArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const float voxel = A.grid.voxel_size;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
-  const int64_t n_tiles = (n_evals + DM - 1) / DM;
-  const float* pack = A.pack;
-  const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
-  const float s5 = sinf(0.5f), c5 = cosf(0.5f);
-  const bool gatherer = threadIdx.x < DM;
-
-  // stage the 17 network inputs of (entry ent, features f0 f1) into PARK at column e
-  auto stage_park = [&](int e, int ent, const f32x4& f0, const f32x4& f1) {
-    float in[32];
-#pragma unroll
-    for (int f = 0; f < 32; ++f) in[f] = 0.f;
-    if (ent >= 0) {
-      {
-        const float fe[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-        check_feature_range(fe, pack[SD_BA + 1], A.vol.n_rows);
-      }
-      const int l = ent & 31;
-      const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
-      const int li[3] = {lx, ly, lz};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        in[a] = (float)li[a] * 0.5f;
-        in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
-        in[6 + a] = li[a] == 0 ? 1.f : c5;
-      }
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        in[9 + f] = f0[f];
-        in[13 + f] = f1[f];
-      }
-    } else {
-      in[6] = in[7] = in[8] = 1.f;  // what k_decode stages for an empty column: cos(0)
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        half8 hi, lo;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const float x = in[16 * ks + 8 * (jj >> 2) + 4 * hh + (jj & 3)];
-          const _Float16 t = (_Float16)x;
-          hi[jj] = t;
-          if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
-        }
-        const int o = ((ks * 2 + hh) * DM + e) * 4;
-        *(half8*)&lds[T_PARK_HI + o] = hi;
-        if (NPROD == 3) *(half8*)&lds[T_PARK_LO + o] = lo;
-      }
-    }
-  };
-  auto load_feats = [&](int ent, f32x4& f0, f32x4& f1) {
-    if (ent >= 0) {
-      const size_t row = (size_t)(ent >> 5);
-      f0 = *(const f32x4*)&A.features[row * 8];
-      f1 = *(const f32x4*)&A.features[row * 8 + 4];
-    }
-  };
-
-  // ---- tiles are handed out DYNAMICALLY (one atomic per tile on a counter in the workspace, fetched one tile
-  // ahead): when another stream's kernel still holds some CUs at launch (the next frame's encoder, an RCCL
-  // collective), the workgroups that start late simply take fewer tiles instead of stretching the kernel's tail
-  __shared__ int s_tile[3];
-  int* tile_ctr = (int*)A.n_list + 2;
-  if (threadIdx.x == 0) {
-    s_tile[0] = atomicAdd(tile_ctr, 1);
-    s_tile[1] = atomicAdd(tile_ctr, 1);
-  }
-  __syncthreads();
-  // ---- prologue: inputs of the first tile into PARK, entry of the second tile, first weight fragments
-  int64_t tile = s_tile[0], tile_nx = s_tile[1];
-  int ent_cur = -1, ent_nx = -1;
-  f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
-  if (gatherer) {
-    if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
-    if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + threadIdx.x, n_evals);
-    load_feats(ent_cur, f0, f1);
-    stage_park(threadIdx.x, ent_cur, f0, f1);
-  }
-  ARing ring;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ph, 0, SH_TOTAL * 2, 0x00020000);
-  const int voff = lane * 16;
-  constexpr int O0 = SH_W0 * 2, O1 = SH_W1 * 2, O2 = SH_W2 * 2, O3 = SH_W3 * 2;  // byte offsets of the layers
-  {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {  // layer 0 has 2 K-steps; its third request slot belongs to layer 1
-      ring.hi[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2) * 1024);
-      if (NPROD == 3) ring.lo[p] = load_frag(rs, voff, O0 + (w * 2 * 2 + p * 2 + 1) * 1024);
-    }
-    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);
-    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
-  }
-  __syncthreads();
-
-  const float* park_hh = lds + T_PARK_HI + (h * DM + j) * 4;
-  const float* park_hl = lds + T_PARK_LO + (h * DM + j) * 4;
-  const float* hl_hh = lds + L_HL + (h * DM + j) * 4;
-  const float* hl_hl = lds + L_HLO + (h * DM + j) * 4;
-  while (tile < n_tiles) {
-    // ---- requests for the following tiles: the id of the tile after next (thread 0; everybody reads it behind
-    // the next barrier), features of the next tile (gather lanes) --------------------------------------------
-    if (threadIdx.x == 0) s_tile[2] = atomicAdd(tile_ctr, 1);
-    int ent_nx2 = -1;
-    if (gatherer) {
-      f0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_feats(ent_nx, f0, f1);
-    }
-    f32x16 acc[4];
-    // layer 0 (B from PARK); K-steps 0, 1 of the tile; requests fragments 1, 2 of layer 1 (0 is in the ring)
-    chain_layer<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hh, park_hl, ring, acc, w, h);
-    __syncthreads();
-    const int64_t tile_nx2 = s_tile[2];
-    store_relu_h<NPROD>(lds, acc, w, j, h);
-    if (gatherer) {
-      stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
-      if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + threadIdx.x, n_evals);
-    }
-    __syncthreads();
-    chain_layer<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, hl_hh, hl_hl, ring, acc, w, h);
-    __syncthreads();
-    store_relu_h<NPROD>(lds, acc, w, j, h);
-    __syncthreads();
-    chain_layer<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, hl_hh, hl_hl, ring, acc, w, h);
-    __syncthreads();
-    store_relu_h<NPROD>(lds, acc, w, j, h);
-    __syncthreads();
-    // layer 3; its last steps request layer 0's two fragments and layer 1's first for the NEXT tile
-    chain_layer<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, hl_hh, hl_hl, ring, acc, w, h);
-    ring.hi[2] = load_frag(rs, voff, O1 + (w * 16 * 2) * 1024);  // (50 + 2) % 5: layer 1's fragment 0, next tile
-    if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16 * 2 + 1) * 1024);
-    // fc_alpha: 256 -> 1
-    const f32x16 wa = frag256(pack + SD_WA, w, h);
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      float sum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum = fmaf(wa[r], relu_bits(acc[pt][r]), sum);
-      lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = sum;
-    }
-    __syncthreads();
-    if (gatherer) {
-      if (ent_cur >= 0) {
-        float sum = pack[SD_BA];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + threadIdx.x];
-        const int row = ent_cur >> 5;
-        A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
-        if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
-      }
-      ent_cur = ent_nx;
-      ent_nx = ent_nx2;
-    }
-    tile = tile_nx;
-    tile_nx = tile_nx2;
-  }
-  // the last workgroup to leave resets the hand-out counter (word 2) and the exit count (word 3), so the kernel
-  // can be launched again without any host-side reset
-  if (threadIdx.x == 0) {
-    int* done = (int*)A.n_list + 3;
-    __threadfence();
-    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
-      *tile_ctr = 0;
-      *done = 0;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1751,7 +1504,11 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
 #undef BNV_LOAD_B
 }
 
-// ReLU + hi/lo split of a wave's 32 features x 128 evaluations into octet 4 w + g of the activation planes
+// ReLU + hi/lo split of a wave's 32 features x 128 evaluations into octet 4 w + g of the activation planes, one
+// column block at a time (conversion and ds_write_b128 interleaved), BEHIND the barrier that frees the planes.
+// (Converting before that barrier -- the older wave of a SIMD wins MFMA arbitration and leaves the K-loop ~6,000
+// cycles early, tools/phase_prof.py -- was measured: its VALU stream then takes issue slots from the younger
+// wave's MFMAs and the tile gets 2.6 % longer; converting all blocks before the first store: +1.7 %.)
 template <int NPROD>
 __device__ __forceinline__ void store_relu_x(uint32_t st_hi, uint32_t st_lo, const f32x4 (&acc)[2][8]) {
 #pragma unroll
@@ -1771,6 +1528,20 @@ __device__ __forceinline__ void store_relu_x(uint32_t st_hi, uint32_t st_lo, con
   }
 }
 
+#ifdef BNV_PHASE_PROF
+#define BNV_PHX(i)                                                                 \
+  do {                                                                             \
+    if ((threadIdx.x & 63) == 0) {                                                 \
+      unsigned long long* _p = (unsigned long long*)(lds + T_TOTAL) + (threadIdx.x >> 6) * 32; \
+      const unsigned long long _t = clock64();                                     \
+      _p[i] += _t - _p[31];                                                        \
+      _p[31] = _t;                                                                 \
+    }                                                                              \
+  } while (0)
+#else
+#define BNV_PHX(i)
+#endif
+
 template <int NPROD>
 __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1783,75 +1554,89 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   const float* pack = A.pack;
   const _Float16* px = (const _Float16*)(pack + SD_PACK_FLOATS);
   const float s5 = sinf(0.5f), c5 = cosf(0.5f);
-  const bool gatherer = threadIdx.x < DM;
+  // Division of the per-tile side work (tools/phase_prof.py: with everything on threads 0..127 waves 0 and 1 were
+  // ~1,400 cycles behind the others at two barriers of every tile):
+  //  * staging of the next tile's network inputs: thread t stages octet so = t >> 7 (inputs 8 so .. 8 so + 7) of
+  //    evaluation se = t & 127; octet 3 (inputs 24..31) is zero for good and written once;
+  //  * the final 16-partial reduction and the table write: threads 128..255 (waves 2 and 3).
+  const int se = threadIdx.x & (DM - 1);
+  const int so = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const bool writer = so == 1;
 
-  // the 32 network inputs (17 used) of (entry ent, features f0 f1) into PARK at evaluation e: octet o holds
-  // inputs 8 o .. 8 o + 7
-  auto stage_park = [&](int e, int ent, const f32x4& f0, const f32x4& f1) {
-    float in[32];
+  // inputs 8 so .. 8 so + 7 of (entry ent, features f0 f1) into PARK at evaluation se
+  auto stage_park = [&](int ent, const f32x4& f0, const f32x4& f1) {
+    if (so == 3) return;
+    float in[8];
 #pragma unroll
-    for (int f = 0; f < 32; ++f) in[f] = 0.f;
+    for (int f = 0; f < 8; ++f) in[f] = 0.f;
     if (ent >= 0) {
-      {
-        const float fe[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-        check_feature_range(fe, pack[SD_BA + 1], A.vol.n_rows);
-      }
       const int l = ent & 31;
       const int lx = l / 9 - 1, ly = (l / 3) % 3 - 1, lz = l % 3 - 1;
-      const int li[3] = {lx, ly, lz};
+      if (so == 0) {
+        const int li[3] = {lx, ly, lz};
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        in[a] = (float)li[a] * 0.5f;
-        in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
-        in[6 + a] = li[a] == 0 ? 1.f : c5;
-      }
+        for (int a = 0; a < 3; ++a) {
+          in[a] = (float)li[a] * 0.5f;
+          in[3 + a] = li[a] == 0 ? 0.f : (li[a] > 0 ? s5 : -s5);
+        }
+        in[6] = lx == 0 ? 1.f : c5;
+        in[7] = ly == 0 ? 1.f : c5;
+      } else if (so == 1) {
+        const float fe[8] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
+        check_feature_range(fe, pack[SD_BA + 1], A.vol.n_rows);
+        in[0] = lz == 0 ? 1.f : c5;
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        in[9 + f] = f0[f];
-        in[13 + f] = f1[f];
+        for (int f = 0; f < 4; ++f) in[1 + f] = f0[f];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) in[5 + f] = f1[f];
+      } else {
+        in[0] = f1[3];
       }
-    } else {
-      in[6] = in[7] = in[8] = 1.f;  // what k_decode stages for an empty column: cos(0)
+    } else if (so == 0) {
+      in[6] = in[7] = 1.f;   // what k_decode stages for an empty column: cos(0)
+    } else if (so == 1) {
+      in[0] = 1.f;
     }
+    half8 hi, lo;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-      half8 hi, lo;
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const float x = in[8 * o + jj];
-        const _Float16 t = (_Float16)x;
-        hi[jj] = t;
-        if (NPROD == 3) lo[jj] = (_Float16)(x - (float)t);
-      }
-      *(half8*)&lds[T_PARK_HI + (o * DM + e) * 4] = hi;
-      if (NPROD == 3) *(half8*)&lds[T_PARK_LO + (o * DM + e) * 4] = lo;
+    for (int jj = 0; jj < 8; ++jj) {
+      const _Float16 t = (_Float16)in[jj];
+      hi[jj] = t;
+      if (NPROD == 3) lo[jj] = (_Float16)(in[jj] - (float)t);
     }
+    *(half8*)&lds[T_PARK_HI + (so * DM + se) * 4] = hi;
+    if (NPROD == 3) *(half8*)&lds[T_PARK_LO + (so * DM + se) * 4] = lo;
   };
   auto load_feats = [&](int ent, f32x4& f0, f32x4& f1) {
-    if (ent >= 0) {
+    if (ent >= 0 && (so == 1 || so == 2)) {
       const size_t row = (size_t)(ent >> 5);
-      f0 = *(const f32x4*)&A.features[row * 8];
+      if (so == 1) f0 = *(const f32x4*)&A.features[row * 8];
       f1 = *(const f32x4*)&A.features[row * 8 + 4];
     }
   };
 
-  // tiles are handed out dynamically, one tile ahead (see k_lattice_table_h)
+  // ---- tiles are handed out DYNAMICALLY (one atomic per tile on a counter in the workspace, fetched one tile
+  // ahead): when another stream's kernel still holds some CUs at launch (the next frame's encoder, an RCCL
+  // collective), the workgroups that start late simply take fewer tiles instead of stretching the kernel's tail
   __shared__ int s_tile[3];
   int* tile_ctr = (int*)A.n_list + 2;
   if (threadIdx.x == 0) {
     s_tile[0] = atomicAdd(tile_ctr, 1);
     s_tile[1] = atomicAdd(tile_ctr, 1);
   }
+  if (so == 3) {   // octet 3 of PARK: inputs 24..31, always zero
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    *(half8*)&lds[T_PARK_HI + (3 * DM + se) * 4] = z;
+    *(half8*)&lds[T_PARK_LO + (3 * DM + se) * 4] = z;
+  }
   __syncthreads();
   int64_t tile = s_tile[0], tile_nx = s_tile[1];
   int ent_cur = -1, ent_nx = -1;
   f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
-  if (gatherer) {
-    if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + threadIdx.x, n_evals);
-    if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + threadIdx.x, n_evals);
-    load_feats(ent_cur, f0, f1);
-    stage_park(threadIdx.x, ent_cur, f0, f1);
-  }
+  if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + se, n_evals);
+  if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + se, n_evals);
+  load_feats(ent_cur, f0, f1);
+  stage_park(ent_cur, f0, f1);
   ARing ring;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)px, 0, SX_TOTAL * 2, 0x00020000);
   const int voff = lane * 16;
@@ -1883,36 +1668,55 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   wa0 = *(const f32x4*)&pack[SD_WA + 32 * w + 4 * g];
   wa1 = *(const f32x4*)&pack[SD_WA + 32 * w + 16 + 4 * g];
   __syncthreads();
+#ifdef BNV_PHASE_PROF
+  if (threadIdx.x < 256) ((unsigned long long*)(lds + T_TOTAL))[threadIdx.x] = 0;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) ((unsigned long long*)(lds + T_TOTAL))[(threadIdx.x >> 6) * 32 + 31] = clock64();
+#endif
 
   while (tile < n_tiles) {
-    if (threadIdx.x == 0) s_tile[2] = atomicAdd(tile_ctr, 1);
+    // requests for the following tiles: the id of the tile after next (thread 0 asks now and publishes it behind
+    // layer 0, so that the round trip of the atomic is off its wave's critical path), features of the next tile
+    int next_id = 0;
+    if (threadIdx.x == 0) next_id = atomicAdd(tile_ctr, 1);
     int ent_nx2 = -1;
-    if (gatherer) {
-      f0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      f1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_feats(ent_nx, f0, f1);
-    }
+    f0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_feats(ent_nx, f0, f1);
     f32x4 acc[2][8];
+    BNV_PHX(0);
     chain_layer_x<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hi, park_lo, ring, acc, w, g);
+    if (threadIdx.x == 0) s_tile[2] = next_id;
+    BNV_PHX(1);
     __syncthreads();
+    BNV_PHX(2);
     const int64_t tile_nx2 = s_tile[2];
     store_relu_x<NPROD>(st_hi, st_lo, acc);
-    if (gatherer) {
-      stage_park(threadIdx.x, ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
-      if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + threadIdx.x, n_evals);
-    }
+    stage_park(ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
+    if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + se, n_evals);
+    BNV_PHX(3);
     __syncthreads();
+    BNV_PHX(4);
     chain_layer_x<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, act_hi, act_lo, ring, acc, w, g);
+    BNV_PHX(5);
     __syncthreads();
+    BNV_PHX(6);
     store_relu_x<NPROD>(st_hi, st_lo, acc);
+    BNV_PHX(7);
     __syncthreads();
+    BNV_PHX(8);
     chain_layer_x<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, act_hi, act_lo, ring, acc, w, g);
+    BNV_PHX(9);
     __syncthreads();
+    BNV_PHX(10);
     store_relu_x<NPROD>(st_hi, st_lo, acc);
+    BNV_PHX(11);
     __syncthreads();
+    BNV_PHX(12);
     chain_layer_x<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, act_hi, act_lo, ring, acc, w, g);
     ring.hi[2] = load_frag(rs, voff, O1 + (w * 16) * 2048);  // (50 + 2) % 5: layer 1's unit 0, next tile
     if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16) * 2048 + 1024);
+    BNV_PHX(13);
     // fc_alpha: 256 -> 1.  Partial over this lane's 8 features, K-groups g and g + 2 combined across the lane
     // halves, 16 partials per evaluation through LDS
 #pragma unroll
@@ -1925,22 +1729,31 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
       sum += __shfl_xor(sum, 32, 64);
       if (g < 2) lds[L_PART + (w * 2 + g) * DM + cb * 16 + n] = sum;
     }
+    BNV_PHX(14);
     __syncthreads();
-    if (gatherer) {
-      if (ent_cur >= 0) {
-        float sum = pack[SD_BA];
+    BNV_PHX(15);
+    if (writer && ent_cur >= 0) {
+      float sum = pack[SD_BA];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + threadIdx.x];
-        const int row = ent_cur >> 5;
-        A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
-        if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
-      }
-      ent_cur = ent_nx;
-      ent_nx = ent_nx2;
+      for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + se];
+      const int row = ent_cur >> 5;
+      A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
+      if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
     }
+    ent_cur = ent_nx;
+    ent_nx = ent_nx2;
     tile = tile_nx;
     tile_nx = tile_nx2;
+    BNV_PHX(17);
   }
+#ifdef BNV_PHASE_PROF
+  __syncthreads();
+  if (threadIdx.x < 256 && (threadIdx.x & 31) != 31)
+    atomicAdd(&g_phase_cycles[threadIdx.x], ((unsigned long long*)(lds + T_TOTAL))[threadIdx.x]);
+  if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[31], 1ull);
+#endif
+  // the last workgroup to leave resets the hand-out counter (word 2) and the exit count (word 3), so the kernel
+  // can be launched again without any host-side reset
   if (threadIdx.x == 0) {
     int* done = (int*)A.n_list + 3;
     __threadfence();
@@ -2325,7 +2138,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   out[t] = o;
 }
 
-int g_lattice_pipe = 2; // 2: k_lattice_table_x (16x16x32 MFMA); 1: k_lattice_table_h (32x32x16); 0: k_decode<LATTICE, 1>
+int g_lattice_pipe = 1; // 1: k_lattice_table_x (cross-tile / cross-layer pipelined, 16x16x32 MFMA); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
 constexpr int kProfLds = 2048;
@@ -2339,15 +2152,10 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
   if (grid < 1) grid = 1;
   if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
-    if (g_lattice_pipe == 2) {
-      if (g_mlp_mode == 1)
-        hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
-      else
-        hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
-    } else if (g_mlp_mode == 1)
-      hipLaunchKernelGGL(k_lattice_table_h<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+    if (g_mlp_mode == 1)
+      hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
     else
-      hipLaunchKernelGGL(k_lattice_table_h<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4, stream, args);
+      hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
@@ -2424,10 +2232,6 @@ int bnv_decode_init() {
                                     T_TOTAL * 4 + kProfLds));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_x<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     T_TOTAL * 4 + kProfLds));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_lattice_table_h<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    T_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd_t, hipFuncAttributeMaxDynamicSharedMemorySize,

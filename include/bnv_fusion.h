@@ -110,9 +110,10 @@ int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 
 /* Tuning switches (A/B experiments; defaults are the measured-best):
- *   "lattice_pipe"  1 (default): lattice-table MLP of modes 1 and 3 runs k_lattice_table_h (operands prefetched
- *                  across tiles and layers, dynamic tile hand-out); 0: the generic k_decode<LATTICE> (bit-identical
- *                  tables, 3-5 % slower);
+ *   "lattice_pipe"  1 (default): lattice-table MLP of modes 1 and 3 runs k_lattice_table_x (v_mfma_f32_16x16x32_f16,
+ *                  operands prefetched across tiles and layers, dynamic tile hand-out); 0: the generic
+ *                  k_decode<LATTICE> (32x32x16 MFMA; the same arithmetic in another summation grouping: tables equal
+ *                  to ~1e-8, 8-10 % slower);
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside

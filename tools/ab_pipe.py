@@ -1,6 +1,6 @@
-"""A/B of the lattice-table kernels: k_decode<LATTICE,1> (lattice_pipe=0), k_lattice_table_h (=1: 32x32x16 MFMA,
-bit-identical to 0) and k_lattice_table_x (=2: 16x16x32 MFMA, same arithmetic in another summation grouping):
-differences of the decoded SDF and interleaved kernel timings.  Usage: ab_pipe.py [mlp_mode]"""
+"""A/B of the lattice-table kernels: k_decode<LATTICE,1> (lattice_pipe=0: 32x32x16 MFMA) and k_lattice_table_x (=1:
+16x16x32 MFMA, same arithmetic in another summation grouping): differences of the decoded SDF and interleaved
+kernel timings.  Usage: ab_pipe.py [mlp_mode]"""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
@@ -15,23 +15,22 @@ if len(sys.argv) > 1:
     bnv.set_mlp_mode(int(sys.argv[1]))
 coords = nm.integrate(frames[30])
 outs = {}
-for opt in (0, 1, 2):
+for opt in (0, 1):
     lib.bnv_set_option(b"lattice_pipe", opt)
     outs[opt] = nm.volume.decode_lattice(coords, model.nerf, None, query_tensor=False).clone()
 print("pipe 1 vs 0: bitwise equal:", torch.equal(outs[0], outs[1]), "max diff", float((outs[0]-outs[1]).abs().max()),
+      "mask decisions equal:", bool(((outs[0] == voxel) == (outs[1] == voxel)).all()),
       "live", float((outs[1] != voxel).float().mean()))
-print("pipe 2 vs 0: bitwise equal:", torch.equal(outs[0], outs[2]), "max diff", float((outs[0]-outs[2]).abs().max()),
-      "mask decisions equal:", bool(((outs[0] == voxel) == (outs[2] == voxel)).all()))
 # small / ragged sizes
 for n in (1, 5, 129, 1000):
     a = {}
-    for opt in (0, 1, 2):
+    for opt in (0, 1):
         lib.bnv_set_option(b"lattice_pipe", opt)
         a[opt] = nm.volume.decode_lattice(coords[:n], model.nerf, None, query_tensor=False).clone()
-    print(n, torch.equal(a[0], a[1]), float((a[0] - a[2]).abs().max()))
-res = {0: [], 1: [], 2: []}
+    print(n, float((a[0] - a[1]).abs().max()))
+res = {0: [], 1: []}
 for rnd in range(4):
-    for opt in (0, 1, 2):
+    for opt in (0, 1):
         lib.bnv_set_option(b"lattice_pipe", opt)
         nm.fuse_and_decode(frames[30]); torch.cuda.synchronize()
         lib.bnv_profile_enable(1)
@@ -39,6 +38,5 @@ for rnd in range(4):
         torch.cuda.synchronize()
         ms=(C.c_double*4)(); n=(C.c_int64*4)(); lib.bnv_profile_read(ms,n); lib.bnv_profile_enable(0)
         res[opt].append(ms[1]/n[1])
-print("lattice MLP kernel ms  pipe=0:", ["%.3f"%x for x in res[0]], " pipe=1:", ["%.3f"%x for x in res[1]],
-      " pipe=2:", ["%.3f"%x for x in res[2]])
-lib.bnv_set_option(b"lattice_pipe", 2)
+print("lattice MLP kernel ms  pipe=0:", ["%.3f"%x for x in res[0]], " pipe=1:", ["%.3f"%x for x in res[1]])
+lib.bnv_set_option(b"lattice_pipe", 1)

@@ -16,10 +16,10 @@ os.environ.setdefault("BNV_FUSION_LIB", os.path.abspath("tools/libbnv_phase_prof
 import bnv_fusion_amd as bnv  # noqa: E402
 from bnv_fusion_amd import synthetic, _lib  # noqa: E402
 
-NAMES = {0: "front end (gather, stage)", 18: "barrier after front end", 1: "L0 mfma", 2: "barrier", 3: "L0 relu+split+store",
+NAMES = {0: "tile top (requests)", 18: "-", 1: "L0 mfma", 2: "barrier", 3: "L0 store + stage next inputs",
          4: "barrier", 5: "L1 mfma", 6: "barrier", 7: "L1 store", 8: "barrier", 9: "L2 mfma", 10: "barrier",
          11: "L2 store", 12: "barrier", 13: "L3 mfma", 14: "fc_alpha partials", 15: "barrier",
-         16: "alpha reduce + barrier", 17: "table write", 19: "end barrier"}
+         16: "-", 17: "reduce + table write", 19: "-"}
 ORDER = [0, 18, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19]
 
 dev = "cuda:0"
@@ -52,7 +52,7 @@ for i in ORDER:
     print(f"  {NAMES[i]:28s}" + "".join(f"{v[w, i] / tiles:8.0f}" for w in range(8)) + f"   {100 * v[0, i] / tot:5.1f} % (w0)")
 mf = v[:, [1, 5, 9, 13]].sum(1)
 print("  MFMA phases total %          " + "".join(f"{100 * mf[w] / tot:8.1f}" for w in range(8)))
-print("  MFMA-bound tile = 600 MFMA x 2 waves/SIMD x 24.5 cyc (two waves of a SIMD issue one MFMA per ~24.5 cycles, probe_lds_mfma.hip) = 29400 cyc")
+print("  MFMA pipe time of a tile = 1200 v_mfma_f32_16x16x32_f16 x 2 waves/SIMD x 16 cyc = 38400 cyc")
 
 # ---- point encoder (k_pointnet_scatter_h): per-wave phase cycles per 32-pair tile ----
 lib.bnv_dev_enc_phase_read.argtypes = [C.POINTER(C.c_ulonglong)]
