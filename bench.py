@@ -222,6 +222,8 @@ def main():
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true",
                     help="skip the fp32_exact run, the f16-operand run, the sustained pass and the growth run")
+    ap.add_argument("--no-power-probe", action="store_true",
+                    help="skip the MFMA-only rate probe (roofline.power_limited_mfma_ceiling)")
     ap.add_argument("--sustained-frames", type=int, default=1000,
                     help="frames of the sustained pass (1 GPU; 0 = skip)")
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"],
@@ -519,7 +521,7 @@ def main():
         return out
 
     power_ceiling = None
-    if world == 1 and not tcnn and args.mlp_mode in (1, 3):
+    if world == 1 and not tcnn and args.mlp_mode in (1, 3) and not args.no_power_probe:
         pc = sustainable_mfma()
         issued = kern_run["dec_tflops"] * MFMA_PER_PRODUCT[args.mlp_mode]
         power_ceiling = {

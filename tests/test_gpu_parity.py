@@ -106,6 +106,46 @@ def test_encode_empty_and_ragged(bnv, model):
         assert out[0] is None or out[2].shape[0] == out[0].shape[0]
 
 
+@pytest.mark.parametrize("pattern", ["one_voxel", "alternating", "runs_with_gaps", "run_across_tiles"])
+def test_encode_scatter_run_patterns_vs_oracle(bnv, model, orc, sd, pattern):
+    """The tile scatter sums RUNS of equal voxels inside 32-pair tiles (a prefix sum over the lanes and differences at
+    the run ends, csrc/encode.hip: scatter_tile): run shapes the golden frames do not pin -- one run filling every
+    tile, runs of length 1, invalid rows (NaN / out of bounds) cutting runs, runs crossing tile and half-tile
+    boundaries -- against the oracle's scatter_mean: counts bit-exact, features to the encoder tolerance."""
+    z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
+    vol = _vol(bnv, z)
+    rng = np.random.default_rng(7)
+    n = 4096 + 19                                               # ragged last tile
+    a = np.array([0.113, -0.207, 0.051], np.float32)            # two points well inside different voxels
+    b = np.array([-0.331, 0.149, 0.263], np.float32)
+    xyz = np.empty((n, 3), np.float32)
+    if pattern == "one_voxel":
+        xyz[:] = a + rng.uniform(-1e-3, 1e-3, (n, 3)).astype(np.float32)
+    elif pattern == "alternating":
+        xyz[0::2] = a
+        xyz[1::2] = b
+        xyz += rng.uniform(-1e-3, 1e-3, (n, 3)).astype(np.float32)
+    elif pattern == "runs_with_gaps":
+        seg = rng.integers(1, 9, n).cumsum() // 8               # runs of random length 1..8+
+        xyz[:] = np.where((seg % 2 == 0)[:, None], a, b) + rng.uniform(-1e-3, 1e-3, (n, 3)).astype(np.float32)
+        bad = rng.random(n) < 0.15
+        xyz[bad & (rng.random(n) < 0.5)] = np.nan               # invalid rows inside the runs
+        xyz[bad & np.isfinite(xyz[:, 0])] += 50.0               # ... and out-of-bounds ones
+    else:                                                       # runs of 24: cross the 16- and 32-pair boundaries
+        seg = np.arange(n) // 24
+        xyz[:] = np.where((seg % 2 == 0)[:, None], a, b) + rng.uniform(-1e-3, 1e-3, (n, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = torch.from_numpy(np.concatenate([xyz, nrm], 1)[None])
+    f, c, ids, g, navg = _encode(model, vol, pts)
+    fo, co, io, go, no = orc.encode_pointcloud(sd, pts, vol.n_xyz.cpu(), vol.min_coords.cpu(), vol.max_coords.cpu(),
+                                               vol.voxel_size)
+    assert torch.equal(ids.cpu(), io) and torch.equal(c.cpu(), co) and torch.equal(g.cpu(), go)
+    assert float(navg) == float(no)
+    err = float((f.cpu() - fo).abs().max())
+    assert err <= FEAT_TOL, err
+
+
 def test_voxelize_pairs_bit_exact_vs_oracle(bnv, model, orc):
     z = np.load(os.path.join(GOLDEN, "encode_64.npz"))
     vol = _vol(bnv, z)
@@ -1134,6 +1174,51 @@ def test_lattice_table_stage_can_be_relaunched(bnv, model, golden_volume):
         _lib.check(lib.bnv_lattice_blend(*args, _lib.ptr(coords.contiguous()), n, None, C.byref(d), _lib.ptr(ws),
                                          ws.numel(), _lib.ptr(out), _lib.stream_ptr()), "blend")
         assert torch.equal(out, ref), rep
+
+
+@pytest.mark.parametrize("n", [1, 5, 129, 1000, 4000])
+def test_lattice_table_kernel_vs_generic_kernel(bnv, model, golden_volume, n):
+    """k_lattice_table_x (v_mfma_f32_16x16x32_f16, operands staged by octets, cross-tile pipeline; lattice_pipe 1, the
+    default) against the generic k_decode<LATTICE> (32x32x16; lattice_pipe 0) on ragged work lists: the same
+    arithmetic in another summation grouping -- equal to 2e-6 (measured ~1e-8) with identical mask decisions.  Only
+    the split / f16-operand modes have the dedicated kernel; in exact fp32 both settings run the generic one."""
+    from bnv_fusion_amd import _lib
+    lib = _lib.load()
+    vol = golden_volume
+    coords = vol.active_coordinates
+    coords = coords[torch.arange(n, device=coords.device) % coords.shape[0]][:n].contiguous() if n > coords.shape[0] \
+        else coords[:n].contiguous()
+    out = {}
+    mode0 = bnv.get_mlp_mode()
+    try:
+        for mode in (mode0, 3):
+            bnv.set_mlp_mode(mode)
+            for pipe in (0, 1):
+                assert lib.bnv_set_option(b"lattice_pipe", pipe) == 0
+                out[(mode, pipe)] = vol.decode_lattice(coords, model.nerf, None, query_tensor=False).clone()
+            a, b = out[(mode, 0)], out[(mode, 1)]
+            masked = float(vol.voxel_size)
+            assert torch.equal(a == masked, b == masked)
+            assert float((a - b).abs().max()) <= (2e-6 if mode != 3 else 2e-5)
+    finally:
+        lib.bnv_set_option(b"lattice_pipe", 1)
+        bnv.set_mlp_mode(mode0)
+
+
+def test_mfma_rate_probe(bnv):
+    """bnv_probe_mfma_rate (the power-limited MFMA ceiling bench.py reports next to the dominant kernel) returns a
+    plausible rate for both MFMA shapes and rejects bad arguments."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib
+    lib = _lib.load()
+    for shape in (0, 1):
+        ms, flop = C.c_double(), C.c_double()
+        assert lib.bnv_probe_mfma_rate(shape, 1, 500, None, C.byref(ms), C.byref(flop)) == 0
+        tflops = flop.value / (ms.value * 1e-3) / 1e12
+        assert 200.0 < tflops < 2600.0, tflops        # the dense f16 peak is 2,500 TFLOP/s
+    ms, flop = C.c_double(), C.c_double()
+    assert lib.bnv_probe_mfma_rate(2, 1, 500, None, C.byref(ms), C.byref(flop)) != 0
+    assert lib.bnv_probe_mfma_rate(0, 1, 0, None, C.byref(ms), C.byref(flop)) != 0
 
 
 def test_tsdf_kernel_vs_reference_cpu_path_golden(bnv, orc):
