@@ -65,15 +65,17 @@ constexpr int PN_B3 = PN_B2 + 128;
 constexpr int PN_B4 = PN_B3 + 128;              // [8]
 constexpr int PN_TOTAL = PN_B4 + 8;             // 34,952 floats = 139,808 B of LDS
 
-// split-operand variant (appended to the same pack, units: 16-bit halves from float offset PN_TOTAL)
-constexpr int PH_W1 = 0;                        // [4 mb][2 hi/lo][64 lane][8]
-constexpr int PH_W2 = PH_W1 + 4 * 2 * 64 * 8;   // [4 mb][4 nb][2 ksl][2 hi/lo][64 lane][8]
-constexpr int PH_W3 = PH_W2 + 4 * 4 * 2 * 2 * 64 * 8;
-constexpr int PH_W4 = PH_W3 + 4 * 4 * 2 * 2 * 64 * 8;   // [4 nb][2 ksl][2 hi/lo][2 h][8 n][8]
-constexpr int PH_TOTAL = PH_W4 + 4 * 2 * 2 * 2 * 8 * 8; // 71,680 halves = 143,360 B
-constexpr int PN_CERT = PN_TOTAL + PH_TOTAL / 2;   // [4]: certified bound on |normal component| of the split modes
+// split-operand pack of the f16 modes (appended to the same pack, units: 16-bit halves from float offset PN_TOTAL),
+// operand order of v_mfma_f32_16x16x32_f16 (k_pointnet_scatter_x)
+constexpr int PX_W1 = 0;                          // [8 rb][hi/lo][64 lane][8]
+constexpr int PX_W2 = PX_W1 + 8 * 2 * 64 * 8;     // [4 s][8 rb][hi/lo][64 lane][8]
+constexpr int PX_W3 = PX_W2 + 4 * 8 * 2 * 64 * 8;
+constexpr int PX_W4 = PX_W3 + 4 * 8 * 2 * 64 * 8; // [4 s][hi/lo][64 lane][8], rows >= 8 zero
+constexpr int PX_TOTAL = PX_W4 + 4 * 2 * 64 * 8;  // 77,824 halves = 155,648 B
+constexpr int PX_OFF = PN_TOTAL;                  // float offset of the PX pack in the packed weights
+constexpr int PN_CERT = PN_TOTAL + PX_TOTAL / 2;  // [4]: certified bound on |normal component| of the split modes
 constexpr int PN_PACK_FLOATS = PN_CERT + 4;
-constexpr int PH_LDS_BYTES = PH_TOTAL * 2 + (128 * 3 + 8) * 4 + 16;  // halves + fp32 biases + tile counter = 144,944 B
+constexpr int PX_LDS_BYTES = PX_TOTAL * 2 + (128 * 3 + 8) * 4 + 32;  // halves + fp32 biases + tile counter (+ pad: lanes g = 3 read 16 B past b4) = 157,248 B
 
 constexpr float kFixedScale = 4294967296.0f;    // 2^32: per-voxel sums are exact integers
 
@@ -655,160 +657,226 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
 
 
 // ------------------------------------------------------------------------------------------
-// k_pointnet_scatter_h: the same network with every fp32 operand split into f16 hi + lo
-// (x = hi + lo to ~22 bits; f16 subnormals are kept by the MFMA) and a.b ~ ah.bh + ah.bl + al.bh
-// on v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-class results at 16/3 x the fp32 MFMA rate.
-// K-step (nb, ksl) consumes D registers 8*ksl .. 8*ksl+7 of input block nb: operand slot jj of lane
-// half h is feature nb*32 + 16*ksl + 8*(jj>>2) + 4*h + (jj&3).
+// Split-operand encoder (MLP modes 1 and 3): every fp32 operand is split into f16 hi + lo (x = hi + lo to ~22 bits;
+// f16 subnormals are kept by the MFMA) and a.b ~ ah.bh + ah.bl + al.bh on the f16 MFMA with fp32 accumulation:
+// fp32-class results at 16/3 x the fp32 MFMA rate (mode 3: ah.bh only).
 // ------------------------------------------------------------------------------------------
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-template <int NPROD = 3>
-__device__ __forceinline__ void split8(const f32x16& v, int base, bool relu, half8* hi, half8* lo) {
-  float x[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = relu ? relu_bits(v[base + e]) : v[base + e];
-  if (NPROD == 3) {
-    split8_f16(x, *hi, *lo);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) (*hi)[e] = (_Float16)x[e];
-  }
-}
-
 // LDS reads of the split-operand encoder go through a handful of OPAQUE 32-bit base addresses plus compile-time
-// byte offsets that fit the 16-bit immediate of ds_read_b128.  Written as plain pointer arithmetic on the 143 KB
+// byte offsets that fit the 16-bit immediate of ds_read_b128.  Written as plain pointer arithmetic on the 150 KB
 // weight image the compiler kept ~40 VGPRs of pre-added addresses alive across the tile loop (and spilled the
-// staged point of the next tile for them); with three weight bases (lane * 16 + 0 / 60 KB / 120 KB), one for the
-// last layer's rows and one for the biases it keeps five.
-#ifndef BNV_ENC_AHEAD
-#define BNV_ENC_AHEAD 1
-#endif
+// staged point of the next tile for them); with three weight bases (lane * 16 + 0 / 60 KB / 120 KB) and one for
+// the biases it keeps four.
 typedef __attribute__((address_space(3))) const half8 lds_half8_t;
 typedef __attribute__((address_space(3))) const f32x4 lds_f32x4_t;
 constexpr int kLdsWin = 61440;   // span of one weight base (< 64 KB immediate range, multiple of 1024)
-struct EncLds {
-  uint32_t w[3];   // lane * 16 + kLdsWin * {0, 1, 2}
-  uint32_t w4;     // layer 4: row (j & 7) of lane half h
-  uint32_t b;      // biases: 4 * h floats into the bias block
-};
-__device__ __forceinline__ half8 lds_wfrag(const EncLds& L, int byte_off) {
-  const int b = byte_off / kLdsWin;
-  return *(lds_half8_t*)((b == 0 ? L.w[0] : (b == 1 ? L.w[1] : L.w[2])) + (uint32_t)(byte_off - b * kLdsWin));
-}
-__device__ __forceinline__ f32x16 lds_bias_init(const EncLds& L, int layer, int mb) {
-  f32x16 v;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 t = *(lds_f32x4_t*)(L.b + (uint32_t)((layer * 128 + mb * 32 + 8 * q) * 4));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[4 * q + i] = t[i];
-  }
-  return v;
-}
 
-// W_OFF: half offset of the layer's weights in the LDS image (PH_W2 / PH_W3); layer = index of its bias block
-template <int NPROD = 3>
-__device__ __forceinline__ void layer128_h(const EncLds& L, int w_off, int layer, const half8 (&inh)[8],
-                                           const half8 (&inl)[8], f32x16 (&out)[4]) {
-#pragma unroll
-  for (int mb = 0; mb < 4; ++mb) out[mb] = lds_bias_init(L, layer, mb);
-  // 32 steps q = (K-step g = (nb, ksl), output block mb): three accumulate-chained products per step
-  // (chained MFMAs on one accumulator issue back to back); the weight fragments of step q+1 are
-  // fetched from LDS before the MFMAs of step q.
-  // BNV_ENC_AHEAD steps of look-ahead on the weight fragments (register ring of BNV_ENC_AHEAD + 1)
-  constexpr int kAhead = BNV_ENC_AHEAD, kRing = kAhead + 1;
-  half8 ah[kRing], al[kRing];
-#define BNV_LOAD_W(q)                                                                          \
-  {                                                                                            \
-    const int wb = (w_off + ((((q) & 3) * 8 + ((q) >> 2)) * 2) * 64 * 8) * 2;                   \
-    ah[(q) % kRing] = lds_wfrag(L, wb);                                                        \
-    if (NPROD == 3) al[(q) % kRing] = lds_wfrag(L, wb + 1024);                                 \
-  }
-#pragma unroll
-  for (int p = 0; p < kAhead; ++p) BNV_LOAD_W(p);
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    if (q + kAhead < 32) BNV_LOAD_W(q + kAhead);
-    __builtin_amdgcn_sched_barrier(0);
-    const int g = q >> 2, mb = q & 3;
-    if constexpr (NPROD == 3) {
-      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q % kRing], inh[g], out[mb], 0, 0, 0);
-      out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q % kRing], inl[g], out[mb], 0, 0, 0);
-    }
-    out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q % kRing], inh[g], out[mb], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#undef BNV_LOAD_W
-}
-
-// Rows 8..31 of the last layer's A operand feed output rows nobody reads.  They used to be replicas of rows 0..7
-// (every lane loads row j & 7: no predication); lanes j >= 8 now read a 4 KB block of zeros instead: the kernel runs
-// at the package power limit (tools/power_probe.py: 0.447 ms with the real weights, 0.363 ms with zeroed ones, same
-// instruction stream) and zero operands are what an MFMA spends least energy on: -1.6 % kernel time.
-constexpr int kEncZeroLds = 4096;
 #ifdef BNV_PHASE_PROF
 __device__ unsigned long long g_enc_phase[8 * 16];
 #define BNV_EPH(i)                                                                          \
   do {                                                                                      \
     if ((threadIdx.x & 63) == 0) {                                                          \
-      unsigned long long* _p = (unsigned long long*)((char*)lds + PH_LDS_BYTES) + (threadIdx.x >> 6) * 16; \
+      unsigned long long* _p = (unsigned long long*)((char*)lds + PX_LDS_BYTES) + (threadIdx.x >> 6) * 16; \
       const unsigned long long _t = clock64();                                              \
       _p[i] += _t - _p[15];                                                                 \
       _p[15] = _t;                                                                          \
     }                                                                                       \
   } while (0)
-constexpr int kEncProfLds = 8 * 16 * 8 + kEncZeroLds;
+constexpr int kEncProfLds = 8 * 16 * 8;
 #else
 #define BNV_EPH(i)
-constexpr int kEncProfLds = kEncZeroLds;
+constexpr int kEncProfLds = 0;
 #endif
 
-// amdgpu_num_vgpr(120) = 240 of the unified register file (the attribute counts half of it on this target): at 241
-// the two waves of a SIMD leave 16 VGPRs per lane to kernels of other streams, at 240 they leave 32 -- enough for the
-// frame's small kernels (upsert, TSDF, neighbour rows, blend) to run BESIDE this kernel instead of behind it
-// (tools/probe_coresidency.py).  No spills.
+// ------------------------------------------------------------------------------------------
+// k_pointnet_scatter_x: the split-operand encoder on v_mfma_f32_16x16x32_f16.
+// The kernel runs at the package power limit (tools/power_probe.py) and under that limit the 16x16x32 form
+// delivers ~14 % more FLOP/s than the 32x32x16 form (tools/probe_shapes.hip).  Same
+// arithmetic (three products, fp32 accumulation), same bytes from LDS, another shape of a wave's tile:
+//  * lane (n = l & 15, g = l >> 4); a tile is still 32 pairs = 2 COLUMN blocks of 16 (pair p = 16 cb + n) and a
+//    128-wide layer is 8 ROW blocks of 16 features: 16 accumulators of 4 registers, register i of acc[rb][cb] =
+//    feature 16 rb + 4 g + i of pair 16 cb + n;
+//  * chaining: a K-step is 32 deep, operand slot jj of K-group g is K index 8 g + jj.  The eight registers
+//    {acc[2 s][cb][0..3], acc[2 s + 1][cb][0..3]} of a lane are exactly its operand of K-step s of the next layer
+//    for column block cb (slot jj <-> feature 32 s + 16 (jj >> 2) + 4 g + (jj & 3)): no cross-lane traffic
+//    between the layers, as before.  The weights are packed to that order on the host (weights.py:
+//    _pack_pointnet_split16, PX_* below);
+//  * a pair is STAGED by the two lanes (n, 2 c) and (n, 2 c + 1) of its column block c (both need its slot for the
+//    scatter: they scatter output features 0..3 and 4..7); the first layer's inputs live in K-group 0, so lanes
+//    g = 0 take the six inputs of pair 16 + n from lane l + 32;
+//  * the last layer is ONE row block (8 of 16 rows used) instead of one 32-row tile (8 of 32): half the MFMA work
+//    of that layer; its outputs for column block 1 go back to the lanes that staged those pairs (lane l + 32);
+//  * the scatter's prefix sums are row-local (a DPP row = a column block of a feature half: 4 steps) and joined
+//    across the two column blocks through lane 15.
+// ------------------------------------------------------------------------------------------
+struct EncLdsX {
+  uint32_t w[3];   // lane * 16 + kLdsWin * {0, 1, 2}
+  uint32_t b;      // biases: 4 * g floats into the bias block
+};
+__device__ __forceinline__ half8 ldsx_wfrag(const EncLdsX& L, int byte_off) {
+  const int b = byte_off / kLdsWin;
+  return *(lds_half8_t*)((b == 0 ? L.w[0] : (b == 1 ? L.w[1] : L.w[2])) + (uint32_t)(byte_off - b * kLdsWin));
+}
+__device__ __forceinline__ f32x4 ldsx_bias(const EncLdsX& L, int layer, int rb) {
+  return *(lds_f32x4_t*)(L.b + (uint32_t)((layer * 128 + rb * 16) * 4));
+}
+
+// 128 -> 128 layer: 32 steps q = (K-step s = q >> 3, row block rb = q & 7), six MFMAs per step (two column blocks
+// x three products; the two chains of a step alternate), the weight fragments of step q + 1 fetched before them
 template <int NPROD>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_h(
+__device__ __forceinline__ void layer128_x(const EncLdsX& L, int w_off, int layer, const half8 (&inh)[4][2],
+                                           const half8 (&inl)[4][2], f32x4 (&out)[8][2]) {
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) out[rb][0] = out[rb][1] = ldsx_bias(L, layer, rb);
+  half8 ah[2], al[2];
+#define BNV_LOAD_WX(q)                                                        \
+  {                                                                           \
+    const int wb = (w_off + (q) * 2 * 64 * 8) * 2;                            \
+    ah[(q) & 1] = ldsx_wfrag(L, wb);                                          \
+    if (NPROD == 3) al[(q) & 1] = ldsx_wfrag(L, wb + 1024);                   \
+  }
+  BNV_LOAD_WX(0);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    if (q + 1 < 32) BNV_LOAD_WX(q + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int s = q >> 3, rb = q & 7;
+    if constexpr (NPROD == 3) {
+      out[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q & 1], inh[s][0], out[rb][0], 0, 0, 0);
+      out[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q & 1], inh[s][1], out[rb][1], 0, 0, 0);
+      out[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], inl[s][0], out[rb][0], 0, 0, 0);
+      out[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], inl[s][1], out[rb][1], 0, 0, 0);
+    }
+    out[rb][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], inh[s][0], out[rb][0], 0, 0, 0);
+    out[rb][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], inh[s][1], out[rb][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef BNV_LOAD_WX
+}
+
+// ReLU + hi/lo split of a layer's accumulators into the next layer's operands
+template <int NPROD>
+__device__ __forceinline__ void split_x(const f32x4 (&acc)[8][2], half8 (&oh)[4][2], half8 (&ol)[4][2]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = relu_bits(acc[2 * s + (e >> 2)][cb][e & 3]);
+      if (NPROD == 3) {
+        split8_f16(x, oh[s][cb], ol[s][cb]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[s][cb][e] = (_Float16)x[e];
+      }
+    }
+}
+
+// Scatter of one tile: this lane holds output features 4 fh .. 4 fh + 3 (fh = g & 1) of pair p = 16 (g >> 1) + n: the
+// 32 pairs of a feature half are DPP rows fh and fh + 2.  Same scheme as scatter_tile (run sums = differences of ONE
+// inclusive prefix sum over the 32 pairs, exact in modular arithmetic; the run's pair count is its length): row-local
+// prefix sums (4 DPP steps), then rows 2 and 3 add the totals of rows 0 and 1 (lane 15 of those rows).
+__device__ __forceinline__ void scatter_tile_x(const f32x4& o, int slot, int n, int g, int32_t* __restrict__ counts,
+                                               long long* __restrict__ acc) {
+  uint32_t lo[4], hi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float r = __builtin_rintf(o[q] * kFixedScale);
+    const float hf = __builtin_floorf(r * (1.0f / kFixedScale));
+    hi[q] = (uint32_t)(int)hf;
+    lo[q] = (uint32_t)__builtin_fmaf(hf, -kFixedScale, r);
+  }
+#define BNV_SCAN_STEP(ctrl)                                                      \
+  "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %4, vcc, %4, %4 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %5, vcc, %5, %5, vcc " ctrl "\n"                            \
+  "v_add_co_u32_dpp %6, vcc, %6, %6 " ctrl "\n"                                  \
+  "v_addc_co_u32_dpp %7, vcc, %7, %7, vcc " ctrl "\n"
+  asm volatile("s_nop 1\n"
+               BNV_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               BNV_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])
+               :
+               : "vcc");
+#undef BNV_SCAN_STEP
+  {   // rows 2, 3 (pairs 16..31): + the total of pairs 0..15 of the same feature half (lane 15 of row g - 2)
+    const int tsrc = ((g & 1) * 16 + 15) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t tl = (uint32_t)__builtin_amdgcn_ds_bpermute(tsrc, (int)lo[q]);
+      const uint32_t th = (uint32_t)__builtin_amdgcn_ds_bpermute(tsrc, (int)hi[q]);
+      if (g >= 2) {
+        const unsigned long long v = (((unsigned long long)hi[q] << 32) | lo[q]) + (((unsigned long long)th << 32) | tl);
+        lo[q] = (uint32_t)v;
+        hi[q] = (uint32_t)(v >> 32);
+      }
+    }
+  }
+  const int p = (g >> 1) * 16 + n;
+  const int slot15 = __builtin_amdgcn_readlane(slot, 15);                     // pair 15 (lanes 15 and 31 stage it)
+  const int prev_row = __builtin_amdgcn_update_dpp(0, slot, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+  const int prev = n == 0 ? slot15 : prev_row;
+  const unsigned long long heads64 = __ballot(p == 0 || prev != slot);
+  const uint32_t heads = ((uint32_t)heads64 & 0xffffu) | (((uint32_t)(heads64 >> 32) & 0xffffu) << 16);   // rows 0 and 2
+  const int s = 31 - __clz((int)(heads & (0xffffffffu >> (31 - p))));         // head of this lane's run (bit 0 is set)
+  const bool is_end = p == 31 || ((heads >> (p + 1)) & 1u);
+  const int sp = s > 0 ? s - 1 : 0;                                            // pair holding P[s - 1]
+  const int src = (((sp >> 4) * 2 + (g & 1)) * 16 + (sp & 15)) * 4;
+  uint32_t plo[4], phi[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    plo[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[q]);
+    phi[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[q]);
+  }
+  if (slot >= 0 && is_end) {
+    unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)(g & 1));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned long long v = ((unsigned long long)hi[q] << 32) | lo[q];
+      if (s > 0) v -= ((unsigned long long)phi[q] << 32) | plo[q];
+      atomicAdd(dst + q, v);
+    }
+    if ((g & 1) == 0) atomicAdd(&counts[slot], p - s + 1);
+  }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void k_pointnet_scatter_x(
     const float* __restrict__ pts, int n_points, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix,
     int32_t* __restrict__ counts, long long* __restrict__ acc, int32_t* __restrict__ error,
     const int32_t* __restrict__ pair_list, const int32_t* __restrict__ n_pairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // Range certificate of the f16-split arithmetic (weights.py: certified_input_bound): with the relative
-  // coordinates in [-1, 1] and |normal components| <= n_cert no value of any layer can reach the f16 overflow
-  // threshold.  A normal beyond that bound (or NaN) raises the frame's error word instead of silently becoming inf.
   const float n_cert = wpack[PN_CERT];
-  _Float16* wh = (_Float16*)lds;                       // PH_TOTAL halves
-  float* lb = lds + PH_TOTAL / 2;                      // b1 b2 b3 b4
-  for (int i = threadIdx.x * 4; i < PH_TOTAL / 2; i += 512 * 4)
-    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[PN_TOTAL + i];
+  float* lb = lds + PX_TOTAL / 2;                      // b1 b2 b3 b4
+  for (int i = threadIdx.x * 4; i < PX_TOTAL / 2; i += 512 * 4)
+    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[PX_OFF + i];
   for (int i = threadIdx.x; i < 128 * 3 + 8; i += 512) lb[i] = wpack[PN_B1 + i];
-  int* tile_ctr = (int*)((char*)lds + PH_TOTAL * 2 + (128 * 3 + 8) * 4);
+  int* tile_ctr = (int*)((char*)lds + PX_TOTAL * 2 + (128 * 3 + 8) * 4);
   if (threadIdx.x == 0) *tile_ctr = 0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int j = lane & 31, h = lane >> 5;
+  const int n = lane & 15, gk = lane >> 4;          // K-group / accumulator row group
+  const int pair = (gk >> 1) * 16 + n;              // the pair this lane stages and scatters
   const PairTiles T = pair_tiles(n_points, pair_list, n_pairs);
   const int n_tiles = T.n_tiles;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
-  EncLds L;
+  EncLdsX L;
   {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
     L.w[0] = lds0 + lane * 16;
     L.w[1] = L.w[0] + kLdsWin;
     L.w[2] = L.w[0] + 2 * kLdsWin;
-    L.w4 = lds0 + PH_W4 * 2 + (h * 8 + (j & 7)) * 16;
-    {
-      const uint32_t zero0 = lds0 + PH_LDS_BYTES + (kEncProfLds - kEncZeroLds);
-      for (int i = threadIdx.x; i < kEncZeroLds / 4; i += 512) lds[(PH_LDS_BYTES + (kEncProfLds - kEncZeroLds)) / 4 + i] = 0.f;
-      if (j >= 8) L.w4 = zero0;
-      __syncthreads();
-    }
-    L.b = lds0 + PH_TOTAL * 2 + h * 16;
-    asm volatile("" : "+v"(L.w[0]), "+v"(L.w[1]), "+v"(L.w[2]), "+v"(L.w4), "+v"(L.b));
+    L.b = lds0 + PX_TOTAL * 2 + gk * 16;
+    asm volatile("" : "+v"(L.w[0]), "+v"(L.w[1]), "+v"(L.w[2]), "+v"(L.b));
   }
 
   // Software pipeline over this wave's tiles: while tile t runs its MLP, the point of tile t+2 and the
@@ -818,7 +886,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   // static split the younger waves were still working when the older ones had finished
   // (tools/phase_prof.py).  The scatter is order-independent, so results do not depend on who takes what.
   const int tstep = gridDim.x * 8;
-  (void)wave;
   auto grab = [&]() -> int {
     int c = 0;
     if (lane == 0) c = atomicAdd(tile_ctr, 1);
@@ -828,14 +895,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   float raw[6];                 // stage 1 (tile t+2): the raw point and its corner
   int raw_k = 0;
   bool raw_ok = false;
-  float nin[4];                 // stage 2 (tile t+1): network inputs, voxel id, its bitmap/prefix words
+  float nin[6];                 // stage 2 (tile t+1): network inputs (lanes of even g), voxel id, bitmap / prefix words
   uint32_t n_id = 0, n_word = 0, n_pref = 0;
   bool n_own = false;
   auto stage1 = [&](int t) {
     raw_ok = false;
     if (t < n_tiles) {
       int i = 0;
-      if (tile_pair(T, t, j, &i, &raw_k)) {
+      if (tile_pair(T, t, pair, &i, &raw_k)) {
         const float* p = pts + (size_t)i * 6;
 #pragma unroll
         for (int c = 0; c < 6; ++c) raw[c] = p[c];
@@ -846,7 +913,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   auto stage2 = [&](int t) {
     n_own = false;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) nin[c] = 0.f;
+    for (int c = 0; c < 6; ++c) nin[c] = 0.f;
     if (raw_ok && in_bounds(raw[0], raw[1], raw[2], g)) {
       const int k = raw_k;
       const float xn = voxel_coord(raw[0], g.bound_min[0], g.voxel_size);
@@ -861,14 +928,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
         n_word = bitmap[n_id >> 5];
         n_pref = word_prefix[n_id >> 5];
       }
-      if (h == 0) {
+      if ((gk & 1) == 0) {
         nin[0] = relative_coord(xn, gx, g.voxel_size);
         nin[1] = relative_coord(yn, gy, g.voxel_size);
         nin[2] = relative_coord(zn, gz, g.voxel_size);
         nin[3] = raw[3];
-      } else {
-        nin[0] = raw[4];
-        nin[1] = raw[5];
+        nin[4] = raw[4];
+        nin[5] = raw[5];
       }
       if (!(fmaxf(fmaxf(fabsf(raw[3]), fabsf(raw[4])), fabsf(raw[5])) <= n_cert)) *error = 3;
     }
@@ -880,113 +946,109 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   stage1(t_next);
 #ifdef BNV_PHASE_PROF
   if ((threadIdx.x & 63) < 16)
-    ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)] = 0;
-  if ((threadIdx.x & 63) == 0) ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + 15] = clock64();
+    ((unsigned long long*)((char*)lds + PX_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)] = 0;
+  if ((threadIdx.x & 63) == 0) ((unsigned long long*)((char*)lds + PX_LDS_BYTES))[(threadIdx.x >> 6) * 16 + 15] = clock64();
 #endif
 
   for (; t < n_tiles; t = t_next, t_next = t_next2) {
-    // stage 3 (tile t): slot from the words fetched one MLP ago
-    float in[4];  // slots 0..3 of this lane half: features 4h .. 4h+3 of [rel(3), normal(3)]
+    float in[6];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) in[c] = nin[c];
+    for (int c = 0; c < 6; ++c) in[c] = nin[c];
     const int slot = n_own ? (int)(n_pref + __popc(n_word & ((1u << (n_id & 31)) - 1u))) : -1;
-    stage2(t_next);         // consumes the point fetched one MLP ago, issues its bitmap / prefix loads
+    stage2(t_next);
     t_next2 = grab();
-    stage1(t_next2);        // issues the next point load
+    stage1(t_next2);
     __builtin_amdgcn_sched_barrier(0);
     BNV_EPH(0);
     if (__ballot(slot >= 0) == 0ULL) continue;
 
-    f32x16 o;
-    // ---- layer 1: 6 -> 128, one K-step of 16 (10 zero slots) -----------------------------
-    f32x16 ha[4], hb[4];
+    // ---- layer 1: 6 -> 128, one K-step of 32 (inputs in K-group 0: slots 0..5 of lanes g = 0) --------------
+    f32x4 ha[8][2], hb[8][2];
     {
-      half8 bh, bl;
+      half8 bh[2], bl[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = e < 4 ? in[e] : 0.f;
-        const _Float16 hh = (_Float16)x;
-        bh[e] = hh;
-        if (NPROD == 3) bl[e] = (_Float16)(x - (float)hh);
+      for (int cb = 0; cb < 2; ++cb) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const float other = __shfl(in[e], (lane + 32) & 63, 64);   // pair 16 + n is staged by lane l + 32
+          x[e] = gk == 0 ? (cb == 0 ? in[e] : other) : 0.f;
+        }
+        if (NPROD == 3) {
+          split8_f16(x, bh[cb], bl[cb]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bh[cb][e] = (_Float16)x[e];
+        }
       }
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb) {
-        const half8 ahi = lds_wfrag(L, (PH_W1 + mb * 2 * 64 * 8) * 2), alo = lds_wfrag(L, (PH_W1 + mb * 2 * 64 * 8) * 2 + 1024);
-        f32x16 c = lds_bias_init(L, 0, mb);
-        if constexpr (NPROD == 3) {
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bl, c, 0, 0, 0);
+      for (int rb = 0; rb < 8; ++rb) {
+        const half8 ahi = ldsx_wfrag(L, (PX_W1 + rb * 2 * 64 * 8) * 2), alo = ldsx_wfrag(L, (PX_W1 + rb * 2 * 64 * 8) * 2 + 1024);
+        const f32x4 b = ldsx_bias(L, 0, rb);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x4 c = b;
+          if constexpr (NPROD == 3) {
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bh[cb], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bl[cb], c, 0, 0, 0);
+          }
+          ha[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bh[cb], c, 0, 0, 0);
         }
-        ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bh, c, 0, 0, 0);
       }
     }
     BNV_EPH(1);
-    half8 sh[8], sl[8];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      split8<NPROD>(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8<NPROD>(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
-    }
+    half8 sh[4][2], sl[4][2];
+    split_x<NPROD>(ha, sh, sl);
     BNV_EPH(2);
-    layer128_h<NPROD>(L, PH_W2, 1, sh, sl, hb);
+    layer128_x<NPROD>(L, PX_W2, 1, sh, sl, hb);
     BNV_EPH(3);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      split8<NPROD>(hb[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8<NPROD>(hb[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
-    }
+    split_x<NPROD>(hb, sh, sl);
     BNV_EPH(4);
-    layer128_h<NPROD>(L, PH_W3, 2, sh, sl, ha);
+    layer128_x<NPROD>(L, PX_W3, 2, sh, sl, ha);
     BNV_EPH(5);
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-      split8<NPROD>(ha[nb], 0, true, &sh[nb * 2], &sl[nb * 2]);
-      split8<NPROD>(ha[nb], 8, true, &sh[nb * 2 + 1], &sl[nb * 2 + 1]);
-    }
+    split_x<NPROD>(ha, sh, sl);
     BNV_EPH(6);
-    // ---- layer 4: 128 -> 8 ------------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    // ---- layer 4: 128 -> 8, one row block (rows >= 8 are zero weights); rows 4 g + i of lanes g >= 2 are unused
+    f32x4 o[2];
+    o[0] = o[1] = *(lds_f32x4_t*)(L.b + 384 * 4);
     {
-      const f32x4 b4 = *(lds_f32x4_t*)(L.b + 384 * 4);
+      half8 w4h[4], w4l[4];
+      __builtin_amdgcn_sched_barrier(0);  // keep these loads below layer 3 (register peak)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = b4[r];
-    }
-    // A rows >= 8 only feed output rows >= 8, which nobody reads: lanes j < 8 load row j, the others read zeros
-    // (L.w4 points them at the zero block; no predication); the next pair's fragments are fetched under this pair.
-    half8 w4h[2][2], w4l[2][2];
-#define BNV_LOAD_W4(gp)                                                                             \
-  {                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
-      const uint32_t a4 = L.w4 + (uint32_t)(((gp) * 2 + u) * 4 * 8 * 16);                           \
-      w4h[(gp) & 1][u] = *(lds_half8_t*)a4;                                                         \
-      w4l[(gp) & 1][u] = *(lds_half8_t*)(a4 + 2 * 8 * 16);                                          \
-    }                                                                                               \
-  }
-    __builtin_amdgcn_sched_barrier(0);  // keep these loads below layer 3 (register peak)
-    BNV_LOAD_W4(0);
+      for (int s = 0; s < 4; ++s) {
+        w4h[s] = ldsx_wfrag(L, (PX_W4 + s * 2 * 64 * 8) * 2);
+        if (NPROD == 3) w4l[s] = ldsx_wfrag(L, (PX_W4 + s * 2 * 64 * 8) * 2 + 1024);
+      }
 #pragma unroll
-    for (int gp = 0; gp < 4; ++gp) {       // pairs of K-steps; the next pair's fragments load under this pair's MFMAs
-      if (gp + 1 < 4) BNV_LOAD_W4(gp + 1);
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int gq = gp * 2 + u;
-        if constexpr (NPROD == 3) {
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4l[gp & 1][u], sh[gq], o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sl[gq], o, 0, 0, 0);
+        for (int cb = 0; cb < 2; ++cb) {
+          if constexpr (NPROD == 3) {
+            o[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w4l[s], sh[s][cb], o[cb], 0, 0, 0);
+            o[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w4h[s], sl[s][cb], o[cb], 0, 0, 0);
+          }
+          o[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w4h[s], sh[s][cb], o[cb], 0, 0, 0);
         }
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(w4h[gp & 1][u], sh[gq], o, 0, 0, 0);
       }
     }
-#undef BNV_LOAD_W4
+    // outputs of column block 1 back to the lanes that staged those pairs: lane (n, g) with g >= 2 takes features
+    // 4 (g & 1) .. + 3 of pair 16 + n from lane l - 32
+    f32x4 mine;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float other = __shfl(o[1][i], (lane + 32) & 63, 64);
+      mine[i] = gk < 2 ? o[0][i] : other;
+    }
     BNV_EPH(7);
-    scatter_tile(o, slot, j, h, counts, acc);
+    scatter_tile_x(mine, slot, n, gk, counts, acc);
     BNV_EPH(8);
   }
 #ifdef BNV_PHASE_PROF
   if ((threadIdx.x & 63) < 15)
     atomicAdd(&g_enc_phase[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)],
-              ((unsigned long long*)((char*)lds + PH_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)]);
+              ((unsigned long long*)((char*)lds + PX_LDS_BYTES))[(threadIdx.x >> 6) * 16 + (threadIdx.x & 63)]);
 #endif
 }
 
@@ -1290,10 +1352,10 @@ int bnv_init(int device) {
   g_num_cus = cus;
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, PN_TOTAL * 4));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<3>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
-  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_h<1>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, PH_LDS_BYTES + kEncProfLds));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_x<3>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS_BYTES + kEncProfLds));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_pointnet_scatter_x<1>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PX_LDS_BYTES + kEncProfLds));
   extern int bnv_decode_init();
   return bnv_decode_init();
 }
@@ -1445,11 +1507,11 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
                          ws.acc, plist, &ws.ctl->n_pairs);
     else if (g_mlp_mode == 1) {
-      hipLaunchKernelGGL((k_pointnet_scatter_h<3>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+      hipLaunchKernelGGL((k_pointnet_scatter_x<3>), dim3(grid_pn), dim3(512), PX_LDS_BYTES + kEncProfLds, stream,
                          input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
                          plist, &ws.ctl->n_pairs);
     } else if (g_mlp_mode == 3) {
-      hipLaunchKernelGGL((k_pointnet_scatter_h<1>), dim3(grid_pn), dim3(512), PH_LDS_BYTES + kEncProfLds, stream,
+      hipLaunchKernelGGL((k_pointnet_scatter_x<1>), dim3(grid_pn), dim3(512), PX_LDS_BYTES + kEncProfLds, stream,
                          input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
                          plist, &ws.ctl->n_pairs);
     } else

@@ -87,7 +87,7 @@ def sdf_feature_bound(sd):
 
 
 def pack_pointnet(sd):
-    """-> float32 [34952 + split pack + 4] in the PN_* layout of csrc/encode.hip; the trailing 4 floats hold the
+    """-> float32 [34952 + split pack + 4] in the PN_* / PX_* layouts of csrc/encode.hip; the trailing 4 floats hold the
     certified bound on |normal| of the split modes (pointnet_normal_bound) and padding.
 
     MFMA tile: lane l = (n = l & 31, h = l >> 5).  A K-step that consumes D register r of input
@@ -121,7 +121,7 @@ def pack_pointnet(sd):
                                 b1, b2, b3, b4]).astype(np.float32)
     trailer = np.zeros(4, np.float32)
     trailer[0] = min(pointnet_normal_bound(sd), 3.0e38)
-    return np.concatenate([fp32_part, _pack_pointnet_split(W1, W2, W3, W4), trailer])
+    return np.concatenate([fp32_part, _pack_pointnet_split16(W1, W2, W3, W4), trailer])
 
 
 def split_f16(x):
@@ -137,36 +137,38 @@ def _slot_feature(jj, h):
     return 8 * (jj >> 2) + 4 * h + (jj & 3)
 
 
-def _pack_pointnet_split(W1, W2, W3, W4):
-    """Split-operand layout PH_* of csrc/encode.hip, returned as float32 words (2 halves each)."""
+def _pack_pointnet_split16(W1, W2, W3, W4):
+    """Split-operand layout PX_* of csrc/encode.hip (k_pointnet_scatter_x, v_mfma_f32_16x16x32_f16), as float32 words.
+    A fragments: lane (m = l & 15, g = l >> 4), slot jj.  Layer 1: [8 rb][hi/lo][64][8] = W1[16 rb + m][8 g + jj]
+    (6 inputs, the other 26 K slots zero).  Layers 2, 3: [4 s][8 rb][hi/lo][64][8] = W[16 rb + m][32 s + 16 (jj >> 2) +
+    4 g + (jj & 3)] -- K-step s consumes what accumulator row blocks 2 s and 2 s + 1 of the previous layer hold.
+    Layer 4: [4 s][hi/lo][64][8], rows m >= 8 zero."""
     lane = np.arange(64)
-    n, h = lane & 31, lane >> 5
+    m, g = lane & 15, lane >> 4
     jj = np.arange(8)
-    # W1: one K-step over the 6 inputs (padded to 16): [4 mb][hi/lo][64][8]
-    w1 = np.zeros((4, 2, 64, 8), np.float16)
-    W1p = np.zeros((128, 16), np.float32)
+    W1p = np.zeros((128, 32), np.float32)
     W1p[:, :6] = W1
-    for mb in range(4):
-        v = W1p[(mb * 32 + n)[:, None], _slot_feature(jj[None, :], h[:, None])]
-        w1[mb, 0], w1[mb, 1] = split_f16(v)
+    w1 = np.zeros((8, 2, 64, 8), np.float16)
+    for rb in range(8):
+        w1[rb, 0], w1[rb, 1] = split_f16(W1p[(16 * rb + m)[:, None], 8 * g[:, None] + jj[None, :]])
+
+    def kidx(s):
+        return 32 * s + 16 * (jj[None, :] >> 2) + 4 * g[:, None] + (jj[None, :] & 3)
 
     def pack128(W):
-        o = np.zeros((4, 4, 2, 2, 64, 8), np.float16)
-        for mb in range(4):
-            for nb in range(4):
-                for ksl in range(2):
-                    v = W[(mb * 32 + n)[:, None], nb * 32 + 16 * ksl + _slot_feature(jj[None, :], h[:, None])]
-                    o[mb, nb, ksl, 0], o[mb, nb, ksl, 1] = split_f16(v)
+        o = np.zeros((4, 8, 2, 64, 8), np.float16)
+        for s in range(4):
+            for rb in range(8):
+                o[s, rb, 0], o[s, rb, 1] = split_f16(W[(16 * rb + m)[:, None], kidx(s)])
         return o
 
-    w4 = np.zeros((4, 2, 2, 2, 8, 8), np.float16)      # [nb][ksl][hi/lo][h][n][8]
-    for nb in range(4):
-        for ksl in range(2):
-            for hh in range(2):
-                v = W4[np.arange(8)[:, None], nb * 32 + 16 * ksl + _slot_feature(jj[None, :], hh)]
-                w4[nb, ksl, 0, hh], w4[nb, ksl, 1, hh] = split_f16(v)
+    W4p = np.zeros((16, 128), np.float32)
+    W4p[:8] = W4
+    w4 = np.zeros((4, 2, 64, 8), np.float16)
+    for s in range(4):
+        w4[s, 0], w4[s, 1] = split_f16(W4p[m[:, None], kidx(s)])
     halves = np.concatenate([w1.ravel(), pack128(W2).ravel(), pack128(W3).ravel(), w4.ravel()])
-    assert halves.size == 71680
+    assert halves.size == 77824
     return halves.view(np.float32)
 
 

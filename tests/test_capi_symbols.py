@@ -27,7 +27,7 @@ def test_library_exports_every_symbol():
     lib = _lib.load()
     for name in _declared():
         assert hasattr(lib, name), name
-    assert int(lib.bnv_pointnet_pack_floats()) == 34952 + 71680 // 2 + 4      # + certified-range trailer
+    assert int(lib.bnv_pointnet_pack_floats()) == 34952 + 77824 // 2 + 4      # + split pack + certified-range trailer
     assert int(lib.bnv_sdfmlp_pack_floats()) == 6144 + 3 * 65536 + 1024 + 256 + 4 + 2 * (409600 // 2)
     assert lib.bnv_status_string(0) == b"ok"
     # without bnv_init every compute entry refuses to run instead of silently doing nothing

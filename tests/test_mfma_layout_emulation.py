@@ -35,7 +35,7 @@ def test_pointnet_pack_matches_direct_mlp():
     PN_W4 = PN_W3 + 16384
     PN_B1 = PN_W4 + 1024
     PN_B2, PN_B3, PN_B4 = PN_B1 + 128, PN_B1 + 256, PN_B1 + 384
-    assert PN_B4 + 8 == 34952 and pack.size == 34952 + 71680 // 2 + 4      # + certified-range trailer
+    assert PN_B4 + 8 == 34952 and pack.size == 34952 + 77824 // 2 + 4      # + 16x16x32 split pack + certified-range trailer
     rng = np.random.default_rng(0)
     x = rng.uniform(-1, 1, size=(32, 6))  # 32 pairs
 
@@ -165,78 +165,6 @@ def _split(x):
 
 def _mfma3(ah, al, bh, bl, c):
     return mfma16(ah, bh, mfma16(ah, bl, mfma16(al, bh, c)))
-
-
-def test_pointnet_split_pack_matches_direct_mlp():
-    sd = W.load_npz(WEIGHTS_FP32)
-    pack = W.pack_pointnet(sd)
-    halves = pack[34952: 34952 + 71680 // 2].view(np.float16).astype(np.float64)
-    fp = pack[:34952].astype(np.float64)
-    PH_W1, PH_W2 = 0, 4096
-    PH_W3, PH_W4 = PH_W2 + 32768, PH_W2 + 65536
-    PN_B1 = 33536 + 1024
-    rng = np.random.default_rng(2)
-    x = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)
-    J8 = np.arange(8)
-
-    def bias_init(off, mb):
-        v = np.zeros((64, 16))
-        for q in range(4):
-            for i in range(4):
-                v[:, 4 * q + i] = fp[off + mb * 32 + 8 * q + 4 * H_ + i]
-        return v
-
-    xin = np.zeros((64, 8), np.float32)
-    for l in range(64):
-        if H_[l] == 0:
-            xin[l, :4] = x[N_[l], :4]
-        else:
-            xin[l, :2] = x[N_[l], 4:6]
-    bh, bl = _split(xin)
-    ha = []
-    for mb in range(4):
-        w = PH_W1 + ((mb * 2) * 64 + LANE[:, None]) * 8 + J8[None, :]
-        ha.append(_mfma3(halves[w], halves[w + 512], bh, bl, bias_init(PN_B1, mb)))
-
-    def to_ops(hs):
-        oh, ol = [], []
-        for nb in range(4):
-            for ksl in range(2):
-                a, b = _split(np.maximum(hs[nb][:, 8 * ksl: 8 * ksl + 8], 0).astype(np.float32))
-                oh.append(a)
-                ol.append(b)
-        return oh, ol
-
-    def layer(woff, boff, oh, ol):
-        out = [bias_init(boff, mb) for mb in range(4)]
-        for nb in range(4):
-            for ksl in range(2):
-                for mb in range(4):
-                    w = woff + ((((mb * 4 + nb) * 2 + ksl) * 2) * 64 + LANE[:, None]) * 8 + J8[None, :]
-                    out[mb] = _mfma3(halves[w], halves[w + 512], oh[nb * 2 + ksl], ol[nb * 2 + ksl], out[mb])
-        return out
-
-    oh, ol = to_ops(ha)
-    hb = layer(PH_W2, PN_B1 + 128, oh, ol)
-    oh, ol = to_ops(hb)
-    ha = layer(PH_W3, PN_B1 + 256, oh, ol)
-    oh, ol = to_ops(ha)
-    o = np.zeros((64, 16))
-    for r in range(4):
-        o[:, r] = fp[PN_B1 + 384 + 4 * H_ + r]
-    for nb in range(4):
-        for ksl in range(2):
-            w = PH_W4 + (((((nb * 2 + ksl) * 2) * 2 + H_[:, None]) * 8) + np.minimum(N_, 7)[:, None]) * 8 + J8[None, :]
-            ahi = np.where((N_ < 8)[:, None], halves[w], 0.0)
-            alo = np.where((N_ < 8)[:, None], halves[w + 128], 0.0)
-            o = _mfma3(ahi, alo, oh[nb * 2 + ksl], ol[nb * 2 + ksl], o)
-    got = np.zeros((32, 8))
-    for l in range(64):
-        for q in range(4):
-            got[N_[l], 4 * H_[l] + q] = o[l, q]
-    tsd = orc.load_weights(WEIGHTS_FP32)
-    ref = orc.pointnet_encoder(tsd, torch.from_numpy(x.T[None]).float())[0].T.numpy()
-    assert np.abs(got - ref).max() < 2e-5
 
 
 def test_sdf_mlp_split_pack_matches_direct_mlp():
@@ -402,6 +330,79 @@ def test_sdf_mlp_x_pack_matches_direct_mlp():
     tsd = orc.load_weights(WEIGHTS_FP32)
     ref = orc.geo_forward(tsd, torch.from_numpy(x).float())[:, 0].numpy()
     assert np.abs(alpha - ref).max() < 2e-5
+
+
+def test_pointnet_x_pack_matches_direct_mlp():
+    """The 16x16x32 point-encoder pack (weights._pack_pointnet_split16) against the index arithmetic of
+    k_pointnet_scatter_x: inputs in K-group 0 of layer 1, register-to-operand chaining between the layers (row blocks
+    2 s, 2 s + 1 -> K-step s), 8 output rows of the last layer."""
+    sd = W.load_npz(WEIGHTS_FP32)
+    pack = W.pack_pointnet(sd)
+    PX_OFF = 34952
+    assert pack.size == PX_OFF + 77824 // 2 + 4            # + certified-range trailer
+    hx = pack[PX_OFF: PX_OFF + 77824 // 2].view(np.float16).astype(np.float64)
+    fp = pack[:34952].astype(np.float64)
+    PX_W1, PX_W2 = 0, 8192
+    PX_W3, PX_W4 = PX_W2 + 32768, PX_W2 + 65536
+    PN_B1 = 33536 + 1024
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, size=(32, 6)).astype(np.float32)      # 32 pairs: pair p = 16 cb + n
+    J8 = np.arange(8)
+
+    def bias4(layer, rb):
+        return np.stack([fp[PN_B1 + layer * 128 + 16 * rb + 4 * G16 + i] for i in range(4)], 1)
+
+    def frag(off):
+        w = off + LANE[:, None] * 8 + J8[None, :]
+        return hx[w], hx[w + 512]
+
+    # layer 1: B fragments live in K-group 0 (lanes g = 0): slots 0..5 = the pair's six inputs
+    bfr = []
+    for cb in range(2):
+        xin = np.zeros((64, 8), np.float32)
+        xin[G16 == 0, :6] = x[16 * cb + M16[G16 == 0]]
+        bfr.append(_split(xin))
+    acc = [[None, None] for _ in range(8)]
+    for rb in range(8):
+        ah, al = frag(PX_W1 + rb * 1024)
+        for cb in range(2):
+            c = bias4(0, rb)
+            c = mfma16x16x32(al, bfr[cb][0], c)
+            c = mfma16x16x32(ah, bfr[cb][1], c)
+            acc[rb][cb] = mfma16x16x32(ah, bfr[cb][0], c)
+
+    def to_ops(acc):
+        return [[_split(np.maximum(np.concatenate([acc[2 * s][cb], acc[2 * s + 1][cb]], 1), 0).astype(np.float32))
+                 for cb in range(2)] for s in range(4)]
+
+    def layer(woff, layer_idx, ops):
+        out = [[bias4(layer_idx, rb) for _ in range(2)] for rb in range(8)]
+        for s in range(4):
+            for rb in range(8):
+                ah, al = frag(woff + (s * 8 + rb) * 1024)
+                for cb in range(2):
+                    c = out[rb][cb]
+                    c = mfma16x16x32(al, ops[s][cb][0], c)
+                    c = mfma16x16x32(ah, ops[s][cb][1], c)
+                    out[rb][cb] = mfma16x16x32(ah, ops[s][cb][0], c)
+        return out
+
+    acc = layer(PX_W2, 1, to_ops(acc))
+    acc = layer(PX_W3, 2, to_ops(acc))
+    ops = to_ops(acc)
+    got = np.zeros((32, 8))
+    for cb in range(2):
+        o = np.stack([np.where(G16 < 2, fp[PN_B1 + 384 + np.minimum(4 * G16 + i, 7)], 0.0) for i in range(4)], 1)
+        for s in range(4):
+            ah, al = frag(PX_W4 + s * 1024)
+            o = mfma16x16x32(al, ops[s][cb][0], o)
+            o = mfma16x16x32(ah, ops[s][cb][1], o)
+            o = mfma16x16x32(ah, ops[s][cb][0], o)
+        for l in range(32):                                  # lanes g = 0, 1 hold output features 4 g .. 4 g + 3
+            got[16 * cb + M16[l], 4 * G16[l]: 4 * G16[l] + 4] = o[l]
+    tsd = orc.load_weights(WEIGHTS_FP32)
+    ref = orc.pointnet_encoder(tsd, torch.from_numpy(x.T[None]).float())[0].T.numpy()
+    assert np.abs(got - ref).max() < 2e-5
 
 
 # ---------------------------------------------------------------------------------------------

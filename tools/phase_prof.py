@@ -54,7 +54,7 @@ mf = v[:, [1, 5, 9, 13]].sum(1)
 print("  MFMA phases total %          " + "".join(f"{100 * mf[w] / tot:8.1f}" for w in range(8)))
 print("  MFMA pipe time of a tile = 1200 v_mfma_f32_16x16x32_f16 x 2 waves/SIMD x 16 cyc = 38400 cyc")
 
-# ---- point encoder (k_pointnet_scatter_h): per-wave phase cycles per 32-pair tile ----
+# ---- point encoder (k_pointnet_scatter_x): per-wave phase cycles per 32-pair tile ----
 lib.bnv_dev_enc_phase_read.argtypes = [C.POINTER(C.c_ulonglong)]
 eb = (C.c_ulonglong * 128)()
 lib.bnv_dev_enc_phase_read(eb)
@@ -65,6 +65,6 @@ e = np.array(list(eb), dtype=np.float64).reshape(8, 16)
 n_tiles = n * (307200 // 32) * 8 / 8.0          # tiles per wave index (8 waves share them evenly)
 EN = ["voxelise/stage", "L1 6->128", "split 1", "L2 128->128", "split 2", "L3 128->128", "split 3", "L4 128->8", "scatter"]
 etot = e[:, :9].sum(1)
-print(f"encoder: {etot.mean() / n_tiles:.0f} cycles per tile per wave; MFMA-bound = 228 MFMA x 2 waves/SIMD x 24.5 cyc = 11200")
+print(f"encoder: {etot.mean() / n_tiles:.0f} cycles per tile per wave; MFMA pipe time = 456 v_mfma_f32_16x16x32_f16 x 16 cyc = 7300 per wave, two waves per SIMD")
 for i, name in enumerate(EN):
     print(f"  {name:16s}" + "".join(f"{e[w, i] / n_tiles:8.0f}" for w in range(8)) + f"   {100 * e[:, i].sum() / etot.sum():5.1f} %")
