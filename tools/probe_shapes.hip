@@ -7,7 +7,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int SHAPE, int NSETS>
+template <int SHAPE, int NSETS, int NA = NSETS, int NB = NSETS>
 __global__ __launch_bounds__(512) void k(float* out, int iters) {
   half8 A[4], B[4];
   unsigned s = (blockIdx.x * 512 + threadIdx.x) * 2654435761u + 12345u;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int u = 0; u < 24; ++u)
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[u & 7]) : "v"(A[NSETS == 1 ? 0 : ((u + (u >> 2)) & (NSETS - 1))]), "v"(B[NSETS == 1 ? 0 : ((u >> 1) & (NSETS - 1))]));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[u & 7]) : "v"(A[NA == 1 ? 0 : ((u + (u >> 2)) & (NA - 1))]), "v"(B[NB == 1 ? 0 : ((u >> 1) & (NB - 1))]));
       if ((it & 63) == 63) for (int a = 0; a < 8; ++a) for (int r = 0; r < 4; ++r) acc[a][r] *= 0.001f;
     }
     for (int a = 0; a < 8; ++a) for (int r = 0; r < 4; ++r) sum += acc[a][r];
@@ -63,5 +63,7 @@ int main() {
     run("32x32x16 f16, 2 operand sets", k<32, 2>, 16000);
     run("16x16x32 f16, 4 operand sets", k<16, 4>, 16000);
     run("16x16x32 f16, 1 operand set", k<16, 1>, 16000);
+    run("16x16x32 f16, A fixed, B 4 sets", k<16, 4, 1, 4>, 16000);
+    run("16x16x32 f16, A 4 sets, B fixed", k<16, 4, 4, 1>, 16000);
   }
 }

@@ -7,7 +7,7 @@ O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # the default workload (50 steps, 5 warm-up), single stream, so that per-launch PMC figures match the default bench line
-BENCH="python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap"
+BENCH="python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe"
 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 python3 bench.py --checkpoint tcnn --no-cpu-baseline > $O/bench_line_tcnn.json 2> $O/bench_line_tcnn.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $BENCH > $O/trace_stdout.log 2>&1
