@@ -343,20 +343,25 @@ def main():
         elif not args.sync_frames:
             # (1 GPU, and the spatially sharded mode: the same handle interface)  software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU
             # never waits for the host (each result() waits on that frame's own event only)
-            pending = None
+            from collections import deque
+            pending = deque()
+            # frames enqueued ahead of the oldest uncollected one.  2: the encode of frame t + 2 (second stream; it
+            # depends on the frame only) is always queued before frame t + 1's upsert / neighbour / mark chain starts,
+            # so the MFMA pipes are never idle behind a host round trip: +5 % against 1 (3: no further gain)
+            depth = int(os.environ.get("BNV_BENCH_DEPTH", "2"))
             _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
             for t in idx:
                 _a = time.perf_counter()
                 h = m.fuse_and_decode_async(frames[t], decode=decode)
                 if _dbg is not None:
                     _dbg.append(time.perf_counter() - _a)
-                if pending is not None:
-                    r = pending.result()
+                pending.append(h)
+                if len(pending) > depth:
+                    r = pending.popleft().result()
                     if collect is not None:
                         collect(r)
-                pending = h
-            if pending is not None:
-                last = pending.result()
+            while pending:
+                last = pending.popleft().result()
                 if collect is not None:
                     collect(last)
             if _dbg:

@@ -164,8 +164,10 @@ class NeuralMap:
     def fuse_and_decode_async(self, frame, decode=True):
         """The same work as fuse_and_decode, enqueued without any host synchronisation: integrate and the
         lattice decode read the frame's voxel count from device memory.  Returns a FrameHandle; call
-        ``.result()`` after enqueuing the NEXT frame to keep the GPU busy (``result()`` also settles the frame's
-        row reservation and raises on a device-side upsert error)."""
+        ``.result()`` after enqueuing the NEXT frame -- or the next TWO: then the encode of frame t + 2 is always
+        queued before frame t + 1's upsert / decode front end runs (+5 % frames/s, bench.py) -- to keep the GPU busy
+        (``result()`` also settles the frame's row reservation and raises on a device-side upsert error).  Any number
+        of uncollected frames gives the synchronous results bit for bit."""
         with torch.no_grad():
             v = self.volume
             main = torch.cuda.current_stream()

@@ -736,6 +736,35 @@ def test_async_frames_equal_sync_frames(bnv, resident):
     assert b.volume.num_rows() == a.volume.num_rows()
 
 
+@pytest.mark.parametrize("depth", [2, 4])
+def test_async_frames_several_in_flight_equal_sync_frames(bnv, depth):
+    """bench.py keeps TWO frames in flight (the encode of frame t + 2 is enqueued while frame t is still being decoded:
+    +5 % frames/s): any number of uncollected frames gives exactly the synchronous results -- every frame owns its
+    output tensors and its pinned counters, the shared workspaces are used in stream order, the volume's row bound
+    accounts for the reservations in flight (starting from the reference's small capacity, so it grows under way)."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    a = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True, capacity=20000)
+    b = bnv.NeuralMap(np.array([dims] * 3), voxel, model, device=DEV, tsdf=True, capacity=20000)
+    b.inputs_resident = True
+    frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t, 240, 320)).to(DEV),
+               "intr_mat": synthetic.intrinsics(240, 320), "T_wc": synthetic.pose(t)} for t in range(14)]
+    sync_out = [a.fuse_and_decode(f) for f in frames]
+    pending, async_out = [], []
+    for f in frames:
+        pending.append(b.fuse_and_decode_async(f))
+        if len(pending) > depth:
+            async_out.append(pending.pop(0).result())
+    async_out += [h.result() for h in pending]
+    for (c0, s0), (c1, s1) in zip(sync_out, async_out):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    assert a.volume.num_rows() == b.volume.num_rows() and b.volume._rows_upper == b.volume.num_rows()
+    assert torch.equal(a.tsdf_vol.tsdf, b.tsdf_vol.tsdf)
+    fa, fb = a.volume.to_tensor(), b.volume.to_tensor()
+    assert torch.equal(a.volume.features, b.volume.features) and torch.equal(a.volume.weights, b.volume.weights)
+
+
 def test_fused_depth_encode_equals_points_encode(bnv):
     """encode_depth_async (front end fused into the voxelisation: rows in pixel order, NaN rows for invalid pixels)
     gives exactly the outputs of the front end followed by encode_pointcloud; invalid pixels, pixels beyond
