@@ -54,9 +54,9 @@ PEAK_TFLOPS = {0: 157.3, 1: 2500.0, 2: 2500.0, 3: 2500.0}   # dense MFMA peaks, 
 MODE_NAME = {0: "fp32_exact", 1: "split_f16", 2: "tcnn_f16", 3: "f16_operands"}
 MFMA_PER_PRODUCT = {0: 1, 1: 3, 2: 1, 3: 1}
 DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
-         1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16, f32 accumulate",
+         1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_16x16x32_f16, f32 accumulate",
          2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
-         3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_32x32x16_f16, f32 accumulate"}
+         3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_16x16x32_f16, f32 accumulate"}
 DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_x<3>", 2: "k_decode<LATTICE, tcnn>",
                  3: "k_lattice_table_x<1>"}
 PARITY_VOXELS = 2048
