@@ -97,8 +97,9 @@ int bnv_last_hip_error(void);
  * accumulate in fp32:
  *   0  exact fp32: v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain), 157 TFLOP/s peak;
  *   1  (default) split operands: every fp32 operand x = hi + lo with hi, lo in f16 (about 22 significant
- *      bits; f16 subnormals are kept), a.b ~ ah.bh + ah.bl + al.bh on v_mfma_f32_32x32x16_f16:
- *      fp32-class accuracy (differences at the level of fp32 summation order) at 16/3 the MFMA rate;
+ *      bits; f16 subnormals are kept), a.b ~ ah.bh + ah.bl + al.bh on the f16 MFMA (v_mfma_f32_16x16x32_f16 in
+ *      the per-frame kernels, 32x32x16 in the generic decode and backward kernels): fp32-class accuracy
+ *      (differences at the level of fp32 summation order) at 16/3 the MFMA rate;
  *   2  the tiny-cuda-nn networks of the reference's default checkpoint (pointnet_tcnn.ckpt): inputs
  *      padded with 1.0, 64-wide, no bias, fp16 weights and activations, f16 MFMA with fp32
  *      accumulation.  The pack buffers then hold the tcnn layouts (weights.py: pack_*_tcnn);
