@@ -10,6 +10,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 BENCH="python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe"
 python3 bench.py > $O/bench_line.json 2> $O/bench_line.err
 python3 bench.py --checkpoint tcnn --no-cpu-baseline > $O/bench_line_tcnn.json 2> $O/bench_line_tcnn.err
+# the other BASELINE grids on one GPU (config 1: 128^3 / voxel 0.02; the 512^3 grid of config 3)
+for G in 128 512; do python3 bench.py --grid $G --no-cpu-baseline --no-alt-mode > $O/bench_line_grid$G.json 2> $O/bench_line_grid$G.err; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $BENCH > $O/trace_stdout.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc1 -o p -- $BENCH > $O/pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc2 -o p -- $BENCH > $O/pmc2.log 2>&1
