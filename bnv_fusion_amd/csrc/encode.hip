@@ -835,6 +835,9 @@ __device__ __forceinline__ void scatter_tile_x(const f32x4& o, int slot, int n, 
     plo[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[q]);
     phi[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[q]);
   }
+#ifdef BNV_PROBE_NO_SCATTER   // development probe (tools/enc_time.py): keeps 1 of 64 workgroups' atomics
+  if ((blockIdx.x & 63) != 0) return;
+#endif
   if (slot >= 0 && is_end) {
     unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)(g & 1));
 #pragma unroll
