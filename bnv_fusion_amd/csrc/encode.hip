@@ -6,18 +6,19 @@
 //   k_rank            one pass over the flagged chunks (decoupled look-back): bitmap words + popcount prefix --
 //                     the rank of a voxel's bit IS its position in torch.unique's ascending output
 //                     (replaces sort+unique)                                                   (HBM/L2)
-//   k_pointnet_scatter[_h|_t]  per (point, corner) pair: 6->128->128->128->8 MLP on MFMA
+//   k_pointnet_scatter[_x|_t]  per (point, corner) pair: 6->128->128->128->8 MLP on MFMA
 //                     (transposed chaining: layer L's D registers are layer L+1's B operands, no
 //                     cross-lane traffic), then order-independent 64-bit fixed-point atomics into
 //                     per-voxel accumulators                                                   (MFMA)
 //   k_finalize        mean, min-points filter, ordered compaction in one pass (look-back), unflatten,
 //                     scratch cleanup, the frame's counters                                    (HBM)
 //
-// Layout of one MFMA tile: 32 pairs = 32 consecutive points x one corner; lane l = (j = l & 31:
-// pair, h = l >> 5).  D register r of a 32-feature block holds feature (r&3) + 8*(r>>2) + 4*h of
-// pair j, so the K-step that consumes D[r] as its B operand contracts features
-// {f0(r), f0(r)+4}; the packed A operands (weights) are pre-permuted on the host to match
-// (bnv_fusion_amd/weights.py: pack_pointnet).
+// Layout of one MFMA tile: 32 pairs = 32 consecutive points x one corner.  Exact fp32 (k_pointnet_scatter,
+// 32x32x2 MFMA): lane l = (j = l & 31: pair, h = l >> 5); D register r of a 32-feature block holds feature
+// (r&3) + 8*(r>>2) + 4*h of pair j, so the K-step that consumes D[r] as its B operand contracts features
+// {f0(r), f0(r)+4}.  Split modes (k_pointnet_scatter_x, 16x16x32 MFMA): lane l = (n = l & 15, g = l >> 4), two
+// column blocks of 16 pairs, eight row blocks of 16 features (layout at the kernel).  The packed A operands
+// (weights) are pre-permuted on the host to match (bnv_fusion_amd/weights.py: pack_pointnet).
 #include <stddef.h>
 
 #include <utility>
@@ -497,6 +498,7 @@ __device__ __forceinline__ void layer128(const float* __restrict__ wp, const flo
 //    they hold -- cancel exactly, so nothing is masked; one ds_bpermute per register fetches P[s - 1];
 //  * the run's pair count is its length.
 // (Round 1's segmented Hillis-Steele scan over ds_bpermute took ~300 instructions per tile; this takes ~110.)
+// Used by the exact-fp32 encoder (lane = (pair j, feature half h)); the split modes use scatter_tile_x.
 __device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, int h, int32_t* __restrict__ counts,
                                              long long* __restrict__ acc) {
   uint32_t lo[4], hi[4];
