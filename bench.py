@@ -111,12 +111,20 @@ class SmiSampler:
 
     def __init__(self, period=0.25):
         self.period, self.samples, self._stop, self._th = period, [], False, None
+        # Under a profiler (rocprofv3 preloads a tool library that initialises the GPU before main) a child that
+        # re-execs -- rocm-smi is a `#!/usr/bin/env python3` script -- is the exec-after-GPU-init this pool forbids:
+        # no sampling then; otherwise the child gets an environment without any preload / profiler variables.
+        env = os.environ
+        self.disabled = ("rocprof" in env.get("LD_PRELOAD", "").lower()
+                         or any(k.startswith(("ROCPROFILER_", "ROCP_TOOL", "ROCPROF_")) for k in env))
+        self._env = {k: v for k, v in env.items()
+                     if k != "LD_PRELOAD" and not k.startswith(("ROCPROFILER_", "ROCP_", "ROCPROF_", "HSA_TOOLS_"))}
 
     def _loop(self):
-        while not self._stop:
+        while not self._stop and not self.disabled:
             try:
                 o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True,
-                                   text=True, timeout=5).stdout
+                                   text=True, timeout=5, env=self._env).stdout
                 card = next(iter(json.loads(o).values()))
                 sclk = pwr = None
                 for k, v in card.items():

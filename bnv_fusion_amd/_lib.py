@@ -23,6 +23,9 @@ SYMBOLS = [
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
     "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
+    "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped",
+    "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
+    "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
 
 
@@ -46,6 +49,30 @@ class Volume(C.Structure):
 
 class SdfDelta(C.Structure):
     _fields_ = [("data", C.c_void_p), ("dims", C.c_int32 * 3)]
+
+
+class IntegrateExtras(C.Structure):
+    _fields_ = [("shard_block", C.c_void_p), ("shard_block_capacity", C.c_int64), ("grid_host", C.POINTER(Grid)),
+                ("lattice_ws", C.c_void_p), ("stamp_epoch", C.c_int32)]
+
+
+class FrameSlot(C.Structure):
+    _fields_ = [("input_pts", C.c_void_p), ("feats", C.c_void_p), ("pcounts", C.c_void_p), ("flat_ids", C.c_void_p),
+                ("grid_ids", C.c_void_p), ("counters", C.c_void_p), ("sdf", C.c_void_p), ("send_block", C.c_void_p),
+                ("host_words", C.c_void_p)]
+
+
+class TsdfDesc(C.Structure):
+    _fields_ = [("tsdf", C.c_void_p), ("weight", C.c_void_p), ("color", C.c_void_p), ("dim", C.c_int32 * 3),
+                ("origin", C.c_float * 3), ("voxel_size", C.c_float), ("trunc_margin", C.c_float)]
+
+
+class FramePipeConfig(C.Structure):
+    _fields_ = [("grid", Grid), ("max_points", C.c_int64), ("out_capacity", C.c_int64), ("send_capacity", C.c_int64),
+                ("pointnet_pack", C.c_void_p), ("enc_ws", C.c_void_p), ("enc_ws_bytes", C.c_size_t),
+                ("enc_ws_max_points", C.c_int64), ("max_depth", C.c_double), ("tsdf", TsdfDesc),
+                ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
+                ("main_stream", C.c_void_p)]
 
 
 class BnvError(RuntimeError):
@@ -146,6 +173,21 @@ def load():
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),
+        "bnv_shard_install_reset": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp, vp]),
+        "bnv_volume_integrate_frame": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, vp, sz,
+                                                 C.POINTER(IntegrateExtras), vp]),
+        "bnv_decode_lattice_stamped": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
+                                                 C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
+        "bnv_frame_pipe_create": (C.c_int, [C.POINTER(FramePipeConfig), C.POINTER(vp)]),
+        "bnv_frame_pipe_destroy": (C.c_int, [vp]),
+        "bnv_frame_begin_depth": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), vp]),
+        "bnv_frame_begin_points": (C.c_int, [vp, C.c_int, vp, i64]),
+        "bnv_frame_upsert": (C.c_int, [vp, C.c_int, C.POINTER(Volume), vp, sz, vp, i32]),
+        "bnv_frame_bound": (C.c_int, [vp, C.c_int, C.POINTER(i32)]),
+        "bnv_frame_finish": (C.c_int, [vp, C.c_int, C.POINTER(Volume), vp, i64, vp, C.POINTER(SdfDelta), vp, sz, i32]),
+        "bnv_frame_result": (C.c_int, [vp, C.c_int, C.POINTER(i32)]),
+        "bnv_frame_ready": (C.c_int, [vp, C.c_int]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -141,6 +141,18 @@ __device__ __forceinline__ bool shard_adjacent_to(int x, int y, int z, const bnv
   return false;
 }
 
+// ---- boundary records of the sharded exchange (shard.hip; appended by the frame upsert in volume.hip) ----------------
+struct ShardRec {   // 48 bytes, 16-byte aligned: three dwordx4
+  int32_t x, y, z;
+  float w;
+  float f[8];
+};
+static_assert(sizeof(ShardRec) == BNV_SHARD_RECORD_BYTES, "record size");
+// header record of a block: x = number of records, y = sender rank, z = 1 if the block overflowed its capacity
+
+// workspace words of the lattice decode that kernels of other files touch (decode.hip: lattice_ws_layout)
+void lattice_ws_frame_words(void* ws, int64_t row_capacity, int32_t** origin_stamp, int32_t** ctl);
+
 // ---- packed volume keys -------------------------------------------------------------------
 constexpr uint64_t kEmptyKey = ~0ULL;
 constexpr int64_t kKeyOffset = 1 << 20;

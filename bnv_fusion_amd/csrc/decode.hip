@@ -1814,6 +1814,13 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   return off;
 }
 
+void lattice_ws_frame_words(void* ws_ptr, int64_t row_capacity, int32_t** origin_stamp, int32_t** ctl) {
+  LatticeWs ws;
+  lattice_ws_layout(1, row_capacity, (char*)ws_ptr, &ws);   // both sit in the part that depends on row_capacity only
+  *origin_stamp = ws.origin_stamp;
+  *ctl = ws.n_list;
+}
+
 constexpr int kOriginBit = 1 << 30;   // flag in nbr_rows entries (rows are < 2^30)
 
 // origin_stamp[row of origin b] = epoch: which rows are decoded origins of this call
@@ -1839,9 +1846,13 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            int32_t* __restrict__ list, int32_t* __restrict__ n_list,
                                                            const uint8_t* __restrict__ row_skip,
                                                            int32_t* __restrict__ origin_stamp,
-                                                           const int32_t* __restrict__ n_dev) {
+                                                           const int32_t* __restrict__ n_dev,
+                                                           int32_t* __restrict__ ctl_clear) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;  // count from device memory; n = grid capacity
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // origins stamped by the frame's upsert (bnv_volume_integrate_frame): no k_lattice_stamp launch in front of this
+  // one, so the control words of the stages behind are cleared here
+  if (ctl_clear && t == 0) ctl_clear[1] = ctl_clear[2] = ctl_clear[3] = 0;
   if (t >= n * 27) return;
   const int64_t b = t / 27;
   const int nb = (int)(t - b * 27);
@@ -2380,9 +2391,10 @@ size_t bnv_decode_lattice_list_offset(int64_t n_voxels, int64_t row_capacity) {
   return (size_t)((char*)ws.list - (char*)256);
 }
 
-int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights, int64_t row_limit,
-                          const int64_t* origins, int64_t n, const int32_t* n_dev, const uint8_t* row_skip,
-                          int build_list, void* ws_ptr, size_t ws_bytes, int32_t epoch, bnv_stream_t stream_) {
+static int lattice_neighbors_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights,
+                                  int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
+                                  const uint8_t* row_skip, int build_list, void* ws_ptr, size_t ws_bytes, int32_t epoch,
+                                  bool prestamped, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   if (!ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
@@ -2391,14 +2403,24 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
   if (build_list) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list, 0, 16, stream));  // rows listed, (entries), tile counter, spare
   if (n == 0) return BNV_OK;
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
-  hipLaunchKernelGGL(k_lattice_stamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, origins, n,
-                     row_limit, ws.origin_stamp, epoch, n_dev, build_list ? (int32_t*)nullptr : ws.n_list);
-  BNV_LAUNCH_CHECK();
+  if (!prestamped) {
+    hipLaunchKernelGGL(k_lattice_stamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, origins, n,
+                       row_limit, ws.origin_stamp, epoch, n_dev, build_list ? (int32_t*)nullptr : ws.n_list);
+    BNV_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
                      n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
-                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp, n_dev);
+                     build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp, n_dev,
+                     (prestamped && !build_list) ? ws.n_list : (int32_t*)nullptr);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights, int64_t row_limit,
+                          const int64_t* origins, int64_t n, const int32_t* n_dev, const uint8_t* row_skip,
+                          int build_list, void* ws_ptr, size_t ws_bytes, int32_t epoch, bnv_stream_t stream) {
+  return lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, row_skip, build_list, ws_ptr,
+                                ws_bytes, epoch, false, stream);
 }
 
 static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
@@ -2464,22 +2486,39 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
   return BNV_OK;
 }
 
-int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                       const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
-                       int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes,
-                       int32_t epoch, float* out_sdf, bnv_stream_t stream) {
+static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                               const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                               const int64_t* origins, int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta,
+                               void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bool prestamped,
+                               bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend
-  int rc = bnv_lattice_neighbors(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
-                                 epoch, stream);
+  int rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
+                                  epoch, prestamped, stream);
   if (rc != BNV_OK) return rc;
   rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
   if (rc != BNV_OK) return rc;
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;
   return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
+}
+
+int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                       const float* weights, int64_t row_limit, const float* sdfmlp_pack, const int64_t* origins,
+                       int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta, void* ws_ptr, size_t ws_bytes,
+                       int32_t epoch, float* out_sdf, bnv_stream_t stream) {
+  return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, delta, ws_ptr,
+                             ws_bytes, epoch, out_sdf, false, stream);
+}
+
+int bnv_decode_lattice_stamped(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                               const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                               const int64_t* origins, int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta,
+                               void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bnv_stream_t stream) {
+  return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, delta, ws_ptr,
+                             ws_bytes, epoch, out_sdf, true, stream);
 }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 // (weights) are pre-permuted on the host to match (bnv_fusion_amd/weights.py: pack_pointnet).
 #include <stddef.h>
 
+#include <atomic>
 #include <utility>
 #include <vector>
 
@@ -171,8 +172,15 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
 }
 
 // every launch of a look-back kernel takes a fresh epoch (bnv_common.hpp: lookback_exclusive)
-static uint32_t g_epoch = 0;
-uint32_t next_epoch() { return ++g_epoch; }
+// (atomic: host threads driving different streams / volumes each get their own; the 30-bit tag never takes the value
+// 0, which is what a zero-initialised workspace word carries)
+static std::atomic<uint32_t> g_epoch{0};
+uint32_t next_epoch() {
+  uint32_t e;
+  do e = g_epoch.fetch_add(1, std::memory_order_relaxed) + 1;
+  while ((e & 0x3fffffffu) == 0);
+  return e;
+}
 
 // ------------------------------------------------------------------------------------------
 // mark: one thread per point; flags its 8 corner voxels in the grid byte map

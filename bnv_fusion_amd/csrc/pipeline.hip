@@ -1,0 +1,243 @@
+// pipeline.hip -- one frame of the hot path behind a handful of C calls (host-side orchestration only; the kernels
+// live in encode.hip / volume.hip / shard.hip / decode.hip / tsdf.hip).
+//
+// What NeuralMap.integrate (run_e2e.py:78-109) + the per-frame lattice decode (sparse_volume.py:697-738) cost the
+// host when every stage is a Python call of its own: ~15 kernel launches through ~8 ctypes calls, a dozen tensor
+// allocations, event objects, a pinned allocation -- and, in the sharded mode, one host wait in the MIDDLE of the
+// frame (the exchange bound) behind which the GPU ran dry (profiles/r02_spatial_world8.txt: 0.47 ms per frame of
+// which ~0.17 ms were launch gaps).  Here a frame in flight lives in a SLOT of caller-owned, persistent buffers and
+// moves through two HIP streams:
+//
+//   E (encode stream)  begin:   front end + voxel marking, rank  ->  exchange bound to pinned memory (event)  ->
+//                               point-encoder MLP + scatter, finalize  ->  TSDF side fusion
+//   M (main stream)    upsert:  waits for the slot's encode; ONE launch = upsert + running average + decode-origin
+//                               stamps + (sharded) boundary records appended to the slot's send block
+//                      [the caller runs the frame's ONE all-gather on M: RCCL through torch.distributed]
+//                      finish:  install ghost rows (resets the send block), neighbours, mark, table MLP, blend,
+//                               counters / row count / evaluation count to pinned memory, done event
+//
+// E of frame t+1 depends on the frame only, so it runs beside M of frame t; the host wait for the bound of frame
+// t+1 (bnv_frame_bound) therefore returns while M still holds most of frame t, and the GPU never waits for the host.
+// Nothing here allocates device memory; the object owns HIP events only.
+#include <new>
+
+#include "bnv_common.hpp"
+
+using namespace bnv;
+
+struct bnv_frame_pipe {
+  bnv_frame_pipe_config_t cfg;
+  hipStream_t E, M;
+  hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
+      ev_done[BNV_PIPE_MAX_SLOTS];
+  int state[BNV_PIPE_MAX_SLOTS];        // 0 free, 1 begun, 2 upserted, 3 finished (result pending)
+  bool used[BNV_PIPE_MAX_SLOTS];        // ev_done has been recorded at least once
+  int64_t n_points[BNV_PIPE_MAX_SLOTS];
+  size_t bound_off;
+};
+
+static bool slot_ok(const bnv_frame_pipe* p, int slot) { return p && slot >= 0 && slot < p->cfg.n_slots; }
+
+extern "C" {
+
+int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t** out) {
+  if (!cfg || !out || cfg->n_slots < 1 || cfg->n_slots > BNV_PIPE_MAX_SLOTS || !cfg->pointnet_pack || !cfg->enc_ws ||
+      cfg->max_points < 1 || cfg->enc_ws_max_points < cfg->max_points || cfg->out_capacity < 1)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (cfg->grid.shard_world < 1 || cfg->grid.shard_world > 64) return BNV_ERR_INVALID_ARGUMENT;
+  for (int s = 0; s < cfg->n_slots; ++s) {
+    const bnv_frame_slot_t& b = cfg->slots[s];
+    if (!b.feats || !b.pcounts || !b.flat_ids || !b.grid_ids || !b.counters || !b.host_words)
+      return BNV_ERR_INVALID_ARGUMENT;
+    if (cfg->grid.shard_world > 1 && (!b.send_block || cfg->send_capacity < 1)) return BNV_ERR_INVALID_ARGUMENT;
+  }
+  bnv_frame_pipe* p = new (std::nothrow) bnv_frame_pipe();
+  if (!p) return BNV_ERR_CAPACITY;
+  p->cfg = *cfg;
+  p->E = (hipStream_t)cfg->encode_stream;
+  p->M = (hipStream_t)cfg->main_stream;
+  p->bound_off = bnv_encode_shard_counts_offset();
+  for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
+    p->state[s] = 0;
+    p->used[s] = false;
+    p->n_points[s] = 0;
+    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_done[s] = nullptr;
+  }
+  for (int s = 0; s < cfg->n_slots; ++s) {
+    hipEvent_t* evs[4] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_done[s]};
+    for (hipEvent_t* e : evs)
+      if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
+        bnv_frame_pipe_destroy(p);
+        return BNV_ERR_HIP;
+      }
+  }
+  *out = p;
+  return BNV_OK;
+}
+
+int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
+  if (!p) return BNV_OK;
+  for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
+    hipEvent_t evs[4] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_done[s]};
+    for (hipEvent_t e : evs)
+      if (e) (void)hipEventDestroy(e);
+  }
+  delete p;
+  return BNV_OK;
+}
+
+// the part of `begin` behind the voxelisation, common to depth and point frames
+static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n) {
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  if (c.grid.shard_world > 1) {
+    // the exchange bound: touched boundary voxels per rank, identical on every rank, known before the encoder MLP
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_BOUNDS, (const char*)c.enc_ws + p->bound_off,
+                                 4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->E));
+  }
+  BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->E));
+  const int rc = bnv_encode_finish(pts, n, &c.grid, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points,
+                                   b.feats, b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters, p->E);
+  if (rc != BNV_OK) return rc;
+  BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
+  p->n_points[slot] = n;
+  p->state[slot] = 1;
+  return BNV_OK;
+}
+
+static int begin_head(bnv_frame_pipe* p, int slot) {
+  if (!slot_ok(p, slot) || p->state[slot] != 0) return BNV_ERR_INVALID_ARGUMENT;
+  // the slot's buffers are still read by the main-stream work of the frame that used it last
+  if (p->used[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_done[slot], 0));
+  return BNV_OK;
+}
+
+int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int depth_dtype, int H, int W,
+                          const double* intr_host, const double* T_wc_host, const float* color_im) {
+  if (!slot_ok(p, slot)) return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  if (!b.input_pts || (int64_t)H * W > c.max_points || !intr_host || !T_wc_host) return BNV_ERR_INVALID_ARGUMENT;
+  if (c.tsdf.tsdf && depth_dtype == 2) return BNV_ERR_INVALID_ARGUMENT;   // the TSDF kernel reads f32 / u16 images
+  int rc = begin_head(p, slot);
+  if (rc != BNV_OK) return rc;
+  rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &c.grid, c.enc_ws,
+                              c.enc_ws_bytes, c.enc_ws_max_points, b.input_pts, p->E);
+  if (rc != BNV_OK) return rc;
+  rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W);
+  if (rc != BNV_OK) return rc;
+  if (c.tsdf.tsdf) {   // run_e2e.py:99-109, gated on the device by the frame's in-bounds point count
+    float K[9], T[16];
+    for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
+    for (int i = 0; i < 16; ++i) T[i] = (float)T_wc_host[i];
+    const int32_t* gate = &b.counters->n_valid_points;
+    if (depth_dtype == 0)
+      rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim,
+                                  c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)depth,
+                                  color_im, H, W, K, T, 1.0f, (float)c.max_depth, gate, p->E);
+    else
+      rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim, c.tsdf.origin,
+                              c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)depth, color_im, H, W, K, T, 1.0f,
+                              (float)c.max_depth, gate, p->E);
+    if (rc != BNV_OK) return rc;
+  }
+  BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
+  return BNV_OK;
+}
+
+int bnv_frame_begin_points(bnv_frame_pipe_t* p, int slot, const float* input_pts, int64_t n_points) {
+  int rc = begin_head(p, slot);
+  if (rc != BNV_OK) return rc;
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  if (!input_pts || n_points < 0 || n_points > c.max_points) return BNV_ERR_INVALID_ARGUMENT;
+  rc = bnv_encode_begin(input_pts, n_points, &c.grid, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points, p->E);
+  if (rc != BNV_OK) return rc;
+  rc = begin_tail(p, slot, input_pts, n_points);
+  if (rc != BNV_OK) return rc;
+  BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
+  return BNV_OK;
+}
+
+int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, void* vol_ws, size_t vol_ws_bytes,
+                     void* lattice_ws, int32_t lattice_epoch) {
+  if (!slot_ok(p, slot) || p->state[slot] != 1 || !vol) return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
+  bnv_integrate_extras_t x = {};
+  if (c.grid.shard_world > 1) {
+    x.shard_block = b.send_block;
+    x.shard_block_capacity = c.send_capacity;
+    x.grid_host = &c.grid;
+  }
+  x.lattice_ws = lattice_ws;
+  x.stamp_epoch = lattice_epoch;
+  const int rc = bnv_volume_integrate_frame(vol, b.grid_ids, b.feats, b.pcounts, c.out_capacity, &b.counters->n_out,
+                                            vol_ws, vol_ws_bytes, &x, p->M);
+  if (rc != BNV_OK) return rc;
+  p->state[slot] = 2;
+  return BNV_OK;
+}
+
+int bnv_frame_bound(bnv_frame_pipe_t* p, int slot, int32_t* max_bound_host) {
+  if (!slot_ok(p, slot) || p->state[slot] < 1 || !max_bound_host) return BNV_ERR_INVALID_ARGUMENT;
+  *max_bound_host = 0;
+  if (p->cfg.grid.shard_world <= 1) return BNV_OK;
+  BNV_HIP_CHECK(hipEventSynchronize(p->ev_bound[slot]));
+  const int32_t* w = p->cfg.slots[slot].host_words + BNV_PIPE_WORD_BOUNDS;
+  int32_t m = 0;
+  for (int r = 0; r < p->cfg.grid.shard_world; ++r) m = w[r] > m ? w[r] : m;
+  *max_bound_host = m;
+  return BNV_OK;
+}
+
+int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, const void* blocks, int64_t block_capacity,
+                     const float* sdfmlp_pack, const bnv_sdf_delta_t* delta, void* lattice_ws, size_t lattice_ws_bytes,
+                     int32_t lattice_epoch) {
+  if (!slot_ok(p, slot) || p->state[slot] != 2 || !vol) return BNV_ERR_INVALID_ARGUMENT;
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  int rc;
+  if (c.grid.shard_world > 1 && blocks && block_capacity > 0) {
+    rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
+    if (rc != BNV_OK) return rc;
+  }
+  if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
+    if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
+    rc = bnv_decode_lattice_stamped(vol, &c.grid, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+                                    b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws,
+                                    lattice_ws_bytes, lattice_epoch, b.sdf, p->M);
+    if (rc != BNV_OK) return rc;
+    int32_t *stamp = nullptr, *ctl = nullptr;
+    lattice_ws_frame_words(lattice_ws, vol->row_capacity, &stamp, &ctl);
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_EVALS, ctl + 1, 4, hipMemcpyDeviceToHost, p->M));
+  }
+  BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_COUNTERS, b.counters, sizeof(bnv_encode_counters_t),
+                               hipMemcpyDeviceToHost, p->M));
+  BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->M));
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
+  BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->M));
+  p->used[slot] = true;
+  p->state[slot] = 3;
+  return BNV_OK;
+}
+
+int bnv_frame_result(bnv_frame_pipe_t* p, int slot, int32_t* words_host) {
+  if (!slot_ok(p, slot) || p->state[slot] != 3) return BNV_ERR_INVALID_ARGUMENT;
+  BNV_HIP_CHECK(hipEventSynchronize(p->ev_done[slot]));
+  if (words_host)
+    for (int i = 0; i < BNV_PIPE_HOST_WORDS; ++i) words_host[i] = p->cfg.slots[slot].host_words[i];
+  p->state[slot] = 0;
+  return BNV_OK;
+}
+
+int bnv_frame_ready(bnv_frame_pipe_t* p, int slot) {
+  if (!slot_ok(p, slot) || p->state[slot] != 3) return BNV_ERR_INVALID_ARGUMENT;
+  const hipError_t e = hipEventQuery(p->ev_done[slot]);
+  if (e == hipSuccess) return 1;
+  if (e == hipErrorNotReady) return 0;
+  g_last_hip_error = (int)e;
+  return BNV_ERR_HIP;
+}
+
+}  // extern "C"

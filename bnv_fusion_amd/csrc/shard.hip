@@ -20,14 +20,6 @@
 
 namespace bnv {
 
-struct ShardRec {   // 48 bytes, 16-byte aligned: three dwordx4
-  int32_t x, y, z;
-  float w;
-  float f[8];
-};
-static_assert(sizeof(ShardRec) == BNV_SHARD_RECORD_BYTES, "record size");
-// header record of a block: x = number of records, y = sender rank, z = 1 if the block overflowed its capacity
-
 __global__ __launch_bounds__(256) void k_shard_pack(bnv_volume_t v, bnv_grid_t g, const int64_t* __restrict__ coords,
                                                     int64_t n, const int32_t* __restrict__ n_dev,
                                                     ShardRec* __restrict__ block, int64_t capacity) {
@@ -77,8 +69,12 @@ __global__ void k_shard_pack_header(ShardRec* __restrict__ block, int rank) {
 // one thread per (sender, record slot)
 __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_t g,
                                                        const ShardRec* __restrict__ blocks, int world,
-                                                       int64_t capacity, int32_t* __restrict__ error) {
+                                                       int64_t capacity, int32_t* __restrict__ error,
+                                                       ShardRec* __restrict__ own_block) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the frame pipeline (pipeline.hip) appends a frame's records from inside the upsert kernel; the block that was
+  // just exchanged starts its next frame empty (the collective that read it is complete: this kernel is behind it)
+  if (t == 0 && own_block) own_block[0].x = 0;
   const int sender = (int)(t / capacity);
   const int64_t i = t - (int64_t)sender * capacity;
   bool want = false;
@@ -179,16 +175,21 @@ int bnv_shard_pack(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_
   return BNV_OK;
 }
 
-int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
-                      int64_t capacity, bnv_stream_t stream_) {
+int bnv_shard_install_reset(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
+                            int64_t capacity, void* own_send_block, bnv_stream_t stream_) {
   if (!shard_vol_ok(vol) || !grid || !blocks || world < 1 || world != grid->shard_world || capacity < 0)
     return BNV_ERR_INVALID_ARGUMENT;
   if (capacity == 0 || world == 1) return BNV_OK;
   const int64_t total = (int64_t)world * capacity;
   hipLaunchKernelGGL(k_shard_install, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, *vol,
-                     *grid, (const ShardRec*)blocks, world, capacity, vol->n_rows + 1);
+                     *grid, (const ShardRec*)blocks, world, capacity, vol->n_rows + 1, (ShardRec*)own_send_block);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
+}
+
+int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
+                      int64_t capacity, bnv_stream_t stream) {
+  return bnv_shard_install_reset(vol, grid, blocks, world, capacity, nullptr, stream);
 }
 
 }  // extern "C"

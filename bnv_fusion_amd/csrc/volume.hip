@@ -19,12 +19,19 @@ struct VolWs {
   int32_t* is_new;         // [n] 1 if this thread's CAS created the slot
   uint32_t* block_sums;    // [n_blocks + 1]
   uint32_t* block_new;     // [ceil(n / 256) + 1] created keys per 256-key block (integrate)
-  uint64_t* tile_state;    // [ceil(n / 256) + 1] look-back state of k_vol_integrate (epoch-tagged, never cleared)
+  uint64_t* tile_state;    // [ws_bytes / 2048 + 2] look-back state of k_vol_integrate (epoch-tagged, never cleared; fixed place)
   int32_t* total_new;      // [1] workspace word 0: created keys (insert) / first new row (integrate)
   int32_t* error;          // [1] = vol.n_rows + 1: sticky error code (1 table full, 2 key range, 3 row capacity)
 };
 
-static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
+// The look-back words sit at a FIXED place -- right behind the control block, sized from the workspace's own byte
+// count, never from a call's n -- so that no per-call array (slot_of / is_new of a larger call) can ever alias them:
+// the words are epoch-tagged and never cleared, and a stale slot index in their place could pass for a published
+// prefix of the current epoch (the workspace is shared by insert / integrate / integrate_batch calls of any size).
+// n keys take >= 8 bytes of workspace, i.e. ws_bytes / 2048 + 2 words cover every tile count a call can have.
+static size_t vol_tile_bytes(size_t ws_bytes) { return ((ws_bytes / 2048 + 2) * 8 + 255) / 256 * 256; }
+
+static size_t vol_ws_layout(int64_t n, char* base, size_t ws_bytes, VolWs* ws) {
   if (n < 1) n = 1;
   const int64_t nb = (n + kVolTile - 1) / kVolTile;
   size_t off = 0;
@@ -34,11 +41,11 @@ static size_t vol_ws_layout(int64_t n, char* base, VolWs* ws) {
     return p;
   };
   char* d = take(256);   // control words first: their offsets do not depend on n
+  char* t = take(vol_tile_bytes(ws_bytes));
   char* a = take(n * 4);
   char* b = take(n * 4);
   char* c = take((nb + 1) * 4);
   char* e = take(((n + 255) / 256 + 1) * 4);
-  char* t = take(((n + 255) / 256 + 1) * 8);
   if (ws) {
     ws->tile_state = (uint64_t*)t;
     ws->slot_of = (int32_t*)a;
@@ -205,12 +212,27 @@ __global__ void k_vol_commit(int32_t* __restrict__ n_rows, const int32_t* __rest
 // batch order: the reference's insertion order; tile 0 seeds the chain with the volume's row count, the last tile
 // commits the new count), creates the rows and applies the running average.  Keys are unique within a batch, so a
 // slot / row is touched by exactly one thread; the look-back state is epoch-tagged and needs no clearing.
+//
+// FRAME (bnv_volume_integrate_frame, the per-frame pipeline): the same launch also does what used to be two more --
+//  * the rows it touches are the ORIGINS of the frame's lattice decode: origin_stamp[row] = stamp_epoch
+//    (k_lattice_stamp's job; the decode then starts at k_lattice_neighbors);
+//  * sharded volume: the boundary voxels among them leave as 48-byte records {x, y, z, weight, features} with the
+//    values just written, appended behind the block's header (k_shard_pack's job, without re-finding the rows).
+struct IntegrateExtras {
+  ShardRec* block;          // null: no records
+  int64_t block_capacity;
+  bnv_grid_t grid;          // ownership / boundary predicates (with block)
+  int32_t* origin_stamp;    // null: no stamps
+  int32_t stamp_epoch;
+};
+
+template <bool FRAME>
 __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
                                                        const float* __restrict__ feats,
                                                        const int64_t* __restrict__ pcounts, int64_t n,
                                                        const int32_t* __restrict__ n_dev,
                                                        uint64_t* __restrict__ tile_state, uint32_t epoch,
-                                                       int32_t* __restrict__ error) {
+                                                       int32_t* __restrict__ error, IntegrateExtras X) {
   n = dev_count(n, n_dev);
   if ((int64_t)blockIdx.x * 256 >= n) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -306,6 +328,32 @@ __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int
   *(f32x4*)&v.features[row * 8] = o[0];
   *(f32x4*)&v.features[row * 8 + 4] = o[1];
   v.weights[row] = w_new;
+  if constexpr (FRAME) {
+    if (X.origin_stamp) X.origin_stamp[row] = X.stamp_epoch;
+    if (!X.block) return;
+    const int x = (int)coords[i * 3 + 0], y = (int)coords[i * 3 + 1], z = (int)coords[i * 3 + 2];
+    const bool send = shard_is_boundary(x, y, z, X.grid);
+    // append, wave-aggregated: one atomic per wave on the block's counter (record order is free)
+    const unsigned long long m = __ballot(send);
+    if (!send) return;
+    const int leader = (int)__ffsll((long long)m) - 1;
+    int base = 0;
+    if (ln == leader) base = atomicAdd(&X.block[0].x, (int)__popcll(m));
+    base = __shfl(base, leader, 64);
+    const int64_t at = (int64_t)base + (int64_t)__popcll(m & ((1ull << ln) - 1ull));
+    if (at >= X.block_capacity) {
+      X.block[0].z = 1;   // cannot happen when the capacity covers the frame's emitted voxels; checked by the receiver
+      return;
+    }
+    ShardRec r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    r.w = w_new;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) r.f[f] = o[f >> 2][f & 3];
+    X.block[1 + at] = r;
+  }
 }
 
 // ---- batched _integrate: up to kVolBatchMax consecutive frames in 2 launches, results identical to integrating
@@ -559,7 +607,13 @@ using namespace bnv;
 
 extern "C" {
 
-size_t bnv_volume_workspace_bytes(int64_t max_keys) { return vol_ws_layout(max_keys, nullptr, nullptr); }
+size_t bnv_volume_workspace_bytes(int64_t max_keys) {
+  // fixed point of size = arrays(max_keys) + look-back words(size); + 512: the words' share grows by one 256-byte
+  // step per 64 KB of workspace, so a caller that rounds the size up still passes the layout check
+  size_t s = vol_ws_layout(max_keys, nullptr, 0, nullptr);
+  for (int it = 0; it < 8; ++it) s = vol_ws_layout(max_keys, nullptr, s, nullptr);
+  return s + 512;
+}
 
 int bnv_volume_clear(const bnv_volume_t* vol, bnv_stream_t stream) {
   if (!vol_ok(vol)) return BNV_ERR_INVALID_ARGUMENT;
@@ -591,12 +645,42 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   if (n == 0) return BNV_OK;
   if (!coords || !feats || !pcounts || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
-  if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (vol_ws_layout(n, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   const unsigned nb256 = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_vol_integrate, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
-                     ws.tile_state, next_epoch(), ws.error);
+  hipLaunchKernelGGL(k_vol_integrate<false>, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+                     ws.tile_state, next_epoch(), ws.error, IntegrateExtras{});
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_integrate_frame(const bnv_volume_t* vol, const int64_t* coords, const float* feats,
+                               const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
+                               const bnv_integrate_extras_t* extras, bnv_stream_t stream_) {
+  if (!vol_ok(vol) || n < 0 || !extras) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!coords || !feats || !pcounts || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  IntegrateExtras X = {};
+  if (extras->shard_block) {
+    if (!extras->grid_host || extras->shard_block_capacity < 0) return BNV_ERR_INVALID_ARGUMENT;
+    X.block = (ShardRec*)extras->shard_block;
+    X.block_capacity = extras->shard_block_capacity;
+    X.grid = *extras->grid_host;
+  }
+  if (extras->lattice_ws) {
+    if (extras->stamp_epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
+    int32_t* ctl = nullptr;
+    lattice_ws_frame_words(extras->lattice_ws, vol->row_capacity, &X.origin_stamp, &ctl);
+    X.stamp_epoch = extras->stamp_epoch;
+  }
+  VolWs ws;
+  if (vol_ws_layout(n, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  ws.error = vol->n_rows + 1;
+  hipStream_t stream = (hipStream_t)stream_;
+  const unsigned nb256 = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_vol_integrate<true>, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+                     ws.tile_state, next_epoch(), ws.error, X);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -625,7 +709,7 @@ int bnv_volume_integrate_batch(const bnv_volume_t* vol, int n_frames, const int6
   if (blocks == 0) return BNV_OK;
   if (blocks > 0x7fffffff / 256) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
-  if (vol_ws_layout(blocks * 256, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (vol_ws_layout(blocks * 256, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(k_vol_batch_probe, dim3((unsigned)blocks), dim3(256), 0, stream, *vol, b, ws.slot_of, slot_mask,
@@ -644,7 +728,7 @@ int bnv_volume_insert(const bnv_volume_t* vol, const int64_t* coords, const floa
   if (n == 0) return BNV_OK;
   if (!coords || !feats || !weights || !num_hits || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   VolWs ws;
-  if (vol_ws_layout(n, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (vol_ws_layout(n, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
   const int rc = vol_upsert_rows(*vol, coords, n, nullptr, ws, stream);

@@ -106,11 +106,13 @@ class ShardFrame:
 
 
 class HipShardBackend:
-    """One shard of the volume on one GPU, HIP kernels.  Nothing here waits for the GPU except ``bound`` (the
-    frame's one host wait) and ``result``."""
+    """One shard of the volume on one GPU: the frame chain of csrc/pipeline.hip (FramePipe) with persistent per-slot
+    buffers -- the phases below enqueue launches and nothing else; no tensor, event or pinned buffer is made per
+    frame.  Host waits: ``bound`` (the frame's ONE wait on the data path; it returns while the main stream still
+    holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4):
         from .sparse_volume import SparseVolume, make_grid
         self.pointnet = pointnet
         self.rank, self.world = rank, world
@@ -129,88 +131,69 @@ class HipShardBackend:
             mn, mx, _ = get_world_range(dimensions, 0.025)
             self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
         self._lib = v._lib
+        self.n_slots = n_slots
+        self.inputs_resident = False      # True: frames are complete in device memory when they are passed in
+        self.copy_results = True          # False: result() returns views into the slot buffers (valid for n_slots - 1 more frames)
+        self.pipe = None
+        self._recv = None
+        self._last_evals = 0
+
+    def _pipe_for(self, frame):
+        n = int(frame["input_pts"].shape[1]) if "input_pts" in frame else int(frame["depth"].shape[-2] * frame["depth"].shape[-1])
+        if self.pipe is None or self.pipe.max_points < n:
+            from .pipeline import FramePipe
+            assert self.pipe is None or not any(self.pipe._busy), "a larger frame arrived while frames are in flight"
+            self.pipe = FramePipe(self.volume, self.pointnet, n, n_slots=self.n_slots, tsdf_vol=self.tsdf_vol,
+                                  max_depth=self.max_depth)
+        self.pipe.inputs_resident = self.inputs_resident
+        self.pipe.sdf_delta = self.sdf_delta
+        return self.pipe
 
     # ---- phases ---------------------------------------------------------------------------------
     def encode(self, frame):
-        """Voxelise the whole frame, encode + upsert the voxels this rank owns; the per-rank bounds of the
-        exchange are copied to pinned memory between the two halves of the encode (before the encoder MLP)."""
-        v = self.volume
+        """Encode stream: voxelise the whole frame (replicated), the exchange bounds to pinned memory, the point
+        encoder on the pairs this rank owns, TSDF side fusion."""
         self.pointnet.shard = (self.rank, self.world, BLOCK_LOG2)
-        bound_host = torch.empty(self.world, dtype=torch.int32, pin_memory=True)
-        ev = torch.cuda.Event()
-
-        def between():
-            bound_host.copy_(self.pointnet.shard_boundary_counts(), non_blocking=True)
-            ev.record()
-
-        if "input_pts" in frame:
-            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_pointcloud_async(
-                frame["input_pts"], v.n_xyz, v.min_coords, v.max_coords, v.voxel_size, between=between)
-        else:
-            feats, pcounts, flat_ids, grid_ids, counters, cap = self.pointnet.encode_depth_async(
-                frame["depth"], frame["intr_mat"], frame["T_wc"], self.max_depth, v.n_xyz, v.min_coords,
-                v.max_coords, v.voxel_size, between=between)[:6]
-        n_dev = counters[2:3]
-        v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
-        if self.tsdf_vol is not None and "depth" in frame:
-            self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.,
-                                    max_depth=self.max_depth, gate=counters[0:1])
-        return ShardFrame(grid_ids=grid_ids, counters=counters, n_dev=n_dev, cap=cap, bound_host=bound_host,
-                          bound_event=ev)
+        pipe = self._pipe_for(frame)
+        return ShardFrame(slot=pipe.begin(frame), capacity=0, blocks=None, decode=False)
 
     def bound(self, fr):
         """Largest number of boundary records any rank can send for this frame (the same number on every rank)."""
-        fr.bound_event.synchronize()
-        return int(fr.bound_host.max()) if self.world > 1 else 0
+        return self.pipe.bound(fr.slot) if self.world > 1 else 0
 
-    def pack(self, fr, capacity):
-        """This rank's block: header + ``capacity`` records, int32 words."""
-        v = self.volume
-        block = torch.empty((capacity + 1) * REC_WORDS, dtype=torch.int32, device=self.dev)
-        _lib.check(self._lib.bnv_shard_pack(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(fr.grid_ids), fr.cap,
-                                            _lib.ptr(fr.n_dev), _lib.ptr(block), capacity, _lib.stream_ptr()),
-                   "bnv_shard_pack")
-        return block
+    def upsert(self, fr, capacity, decode=True):
+        """Main stream: upsert of the owned voxels in ONE launch that also appends their boundary records to the slot's
+        send block and stamps them as the frame's decode origins.  -> this rank's block (header + ``capacity``
+        records, int32 words) or None when nothing is exchanged."""
+        fr.decode = decode
+        send = self.pipe.upsert(fr.slot, decode=decode, ghost_rows=(self.world - 1) * capacity)
+        return None if capacity == 0 else send[: (capacity + 1) * REC_WORDS]
 
-    def install(self, blocks, capacity):
-        """blocks: [world, (capacity + 1) * REC_WORDS] int32 -- the all-gather's output."""
-        v = self.volume
-        bound = (self.world - 1) * capacity          # ghost rows this call can create at most
-        v._reserve(bound)
-        _lib.check(self._lib.bnv_shard_install(C.byref(v._struct()), C.byref(v._grid), _lib.ptr(blocks), self.world,
-                                               capacity, _lib.stream_ptr()), "bnv_shard_install")
-        v._rows_upper += bound
-        v._inflight += bound
-        return bound
+    def recv_buffer(self, words):
+        if self._recv is None or self._recv.numel() < words:
+            self._recv = torch.empty(int(words * 1.5), dtype=torch.int32, device=self.dev)
+        return self._recv[:words]
+
+    def install(self, fr, blocks, capacity):
+        """blocks: [world * (capacity + 1) * REC_WORDS] int32 -- the all-gather's output; installed (and the send block
+        reset) by the frame's finish call."""
+        fr.blocks, fr.capacity = blocks, capacity
+        return (self.world - 1) * capacity
 
     def decode(self, fr):
-        v = self.volume
-        return v.decode_lattice(fr.grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False, n_dev=fr.n_dev)
+        return self.pipe.sdf[fr.slot]
 
     def finish(self, fr, sdf, reserved):
-        """Read-backs of the frame (async) -> what ``result`` needs."""
-        host = torch.empty(8, dtype=torch.int32, pin_memory=True)
-        host.copy_(fr.counters, non_blocking=True)
-        fr.host, fr.host_rows, fr.sdf, fr.reserved = host, self.volume.status_readback(), sdf, reserved + fr.cap
-        fr.event = torch.cuda.Event()
-        fr.event.record()
+        self.pipe.finish(fr.slot, fr.blocks, fr.capacity)
+        fr.blocks = None
         return fr
 
     def result(self, fr):
         """-> (coords [U'_r, 3] of the voxels this rank owns among the frame's, sdf [U'_r, 27]) or (None, None)."""
-        fr.event.synchronize()
-        v = self.volume
-        v.settle(fr.reserved, int(fr.host_rows[0]))
-        v.check_status(fr.host_rows[1])
-        h = fr.host
-        if int(h[4]):
-            from .fusion import encode_error_message
-            raise _lib.BnvError(encode_error_message(int(h[4])))
-        if int(h[0]) == 0:
-            return None, None
-        v.track_n_pts(float(h[3:4].view(torch.float32)[0]))
-        n_out = int(h[2])
-        return fr.grid_ids[:n_out], None if fr.sdf is None else fr.sdf[:n_out]
+        w = self.pipe.result(fr.slot)
+        from .pipeline import W_EVALS
+        self._last_evals = int(w[W_EVALS])
+        return self.pipe.outputs(fr.slot, w, copy=self.copy_results)
 
     def owned_rows_mask(self):
         """bool [rows]: rows this rank owns (the others are ghost rows)."""
@@ -236,9 +219,11 @@ class ShardHandle:
 class ShardedNeuralMap:
     """Per-frame driver over one shard; every rank calls the same methods with the same frame.
 
-    fuse_and_decode_async enqueues: encode (whole frame voxelised, owned voxels encoded) -> upsert -> pack boundary
-    records -> ONE all-gather -> install ghost rows -> lattice decode of the owned voxels.  One host wait (the
-    exchange bound, read while the encoder runs); the outputs are collected through the returned handle."""
+    fuse_and_decode_async enqueues: encode (whole frame voxelised, owned voxels encoded; its own stream) -> upsert
+    (+ boundary records) -> ONE all-gather -> install ghost rows -> lattice decode of the owned voxels.  One host
+    wait (the exchange bound -- read from pinned memory; the encode stream reaches it while the main stream still
+    works on the previous frame); the outputs are collected through the returned handle.  At most ``n_slots - 1``
+    handles may stay uncollected (HIP backend; the oldest is collected on demand)."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
                  group=None, capacity=1 << 20, tsdf=False):
@@ -252,24 +237,35 @@ class ShardedNeuralMap:
         self.voxel_size = voxel_size
         self.exchanged_bytes = 0          # bytes this rank has received in all-gathers (statistics)
         self.host_waits = 0
+        self._open = []                   # handles not collected yet, oldest first (HIP backend: they hold slots)
 
     def fuse_and_decode_async(self, frame, decode=True):
         import torch.distributed as dist
         be = self.backend
+        ring = getattr(be, "n_slots", None)
+        if ring is not None:
+            self._open = [h for h in self._open if h._done is None]
+            while len(self._open) >= ring:            # the slot ring is full: collect the oldest frame
+                self._open.pop(0).result()
         with torch.no_grad():
             fr = be.encode(frame)
-            bound = be.bound(fr)                       # the frame's one host wait (the encoder is running)
+            bound = be.bound(fr)                       # the frame's one host wait
             self.host_waits += 1
+            capacity = -(-bound // REC_QUANTUM) * REC_QUANTUM
+            send = be.upsert(fr, capacity, decode)
             reserved = 0
-            if bound > 0:
-                capacity = -(-bound // REC_QUANTUM) * REC_QUANTUM
-                send = be.pack(fr, capacity)
-                recv = torch.empty((self.world, send.numel()), dtype=send.dtype, device=send.device)
-                dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)      # THE collective of the frame
-                self.exchanged_bytes += recv.numel() * 4
-                reserved = be.install(recv, capacity)
+            if capacity > 0:
+                words = self.world * send.numel()
+                recv = be.recv_buffer(words) if hasattr(be, "recv_buffer") else torch.empty(
+                    words, dtype=send.dtype, device=send.device)
+                dist.all_gather_into_tensor(recv, send, group=self.group)      # THE collective of the frame
+                self.exchanged_bytes += words * 4
+                reserved = be.install(fr, recv, capacity)
             sdf = be.decode(fr) if decode else None
-            return ShardHandle(self, be.finish(fr, sdf, reserved))
+            h = ShardHandle(self, be.finish(fr, sdf, reserved))
+        if ring is not None:
+            self._open.append(h)
+        return h
 
     def fuse_and_decode(self, frame):
         return self.fuse_and_decode_async(frame).result()

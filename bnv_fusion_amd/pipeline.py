@@ -1,0 +1,216 @@
+"""FramePipe -- the per-frame chain (NeuralMap.integrate, run_e2e.py:78-109, + the lattice decode of the frame's voxels,
+sparse_volume.py:697-738) behind the C object of csrc/pipeline.hip: persistent per-slot buffers, two HIP streams, no
+per-frame allocation, event object or size read on the host.  Used by the spatially sharded map
+(distributed.HipShardBackend) and usable on one GPU (world 1).
+
+A frame occupies a slot from ``begin`` to ``result``:
+
+    slot = pipe.begin(frame)              # encode stream: front end, voxelise, rank, [bound -> pinned], PointNet, TSDF
+    bound = pipe.bound(slot)              # host wait (0 when unsharded)
+    send = pipe.upsert(slot, decode, ghost_rows)   # main stream: upsert (+ boundary records, + origin stamps)
+    ... all-gather of send[: (capacity + 1) * REC_WORDS] on the main stream ...
+    pipe.finish(slot, blocks, capacity)   # main stream: install, lattice decode, read-backs
+    words = pipe.result(slot)             # host wait; then pipe.outputs(slot, words)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+REC_WORDS = 12          # BNV_SHARD_RECORD_BYTES / 4
+HOST_WORDS = 96         # BNV_PIPE_HOST_WORDS
+W_COUNTERS, W_STATUS, W_EVALS, W_BOUNDS = 0, 8, 10, 16
+
+
+class FramePipe:
+    def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None):
+        from .frontend import DEPTH_DTYPES
+        self._dtypes = DEPTH_DTYPES
+        self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
+        self.max_depth = float(max_depth)
+        self.sdf_delta = sdf_delta
+        v = volume
+        dev = v._dev
+        self.dev = dev
+        self._lib = v._lib
+        lib = self._lib
+        self.n_slots = int(n_slots)
+        assert 1 <= self.n_slots <= 8
+        self.max_points = int(max_points)
+        self.world = int(v.shard[1])
+        self.main = torch.cuda.current_stream(dev)
+        self.enc = torch.cuda.Stream(device=dev)
+        res = v._n_xyz_host
+        nvox = res[0] * res[1] * res[2]
+        self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)
+        self.send_cap = self.cap if self.world > 1 else 0
+        n_arr = (C.c_int32 * 3)(*res)
+        need = int(lib.bnv_encode_workspace_bytes(self.max_points, n_arr))
+        self._enc_ws = torch.zeros(need, dtype=torch.uint8, device=dev)          # zero-filled = clean
+        cap, S = self.cap, self.n_slots
+        self.input_pts = torch.empty((S, self.max_points, 6), dtype=torch.float32, device=dev)
+        self.feats = torch.empty((S, cap, 8), dtype=torch.float32, device=dev)
+        self.pcounts = torch.empty((S, cap), dtype=torch.int64, device=dev)
+        self.flat_ids = torch.empty((S, cap), dtype=torch.int64, device=dev)
+        self.grid_ids = torch.empty((S, cap, 3), dtype=torch.int64, device=dev)
+        self.counters = torch.zeros((S, 8), dtype=torch.int32, device=dev)
+        self.sdf = torch.empty((S, cap, 27), dtype=torch.float32, device=dev)
+        self.send = None
+        if self.world > 1:
+            self.send = torch.zeros((S, (self.send_cap + 1) * REC_WORDS), dtype=torch.int32, device=dev)
+            self.send[:, 1] = int(v.shard[0])                                     # header {count 0, sender rank, 0}
+        self.host = torch.zeros((S, HOST_WORDS), dtype=torch.int32).pin_memory()
+        self._host_np = self.host.numpy()
+        cfg = _lib.FramePipeConfig()
+        self._grid = v._grid
+        cfg.grid = v._grid
+        cfg.max_points, cfg.out_capacity, cfg.send_capacity = self.max_points, cap, self.send_cap
+        cfg.pointnet_pack = pointnet.pointnet_pack.data_ptr()
+        cfg.enc_ws, cfg.enc_ws_bytes, cfg.enc_ws_max_points = self._enc_ws.data_ptr(), need, self.max_points
+        cfg.max_depth = self.max_depth
+        if tsdf_vol is not None:
+            t = tsdf_vol
+            cfg.tsdf.tsdf, cfg.tsdf.weight, cfg.tsdf.color = t.tsdf.data_ptr(), t.weight.data_ptr(), t.color.data_ptr()
+            for a in range(3):
+                cfg.tsdf.dim[a] = int(t._vol_dim[a])
+                cfg.tsdf.origin[a] = float(t._vol_origin[a])
+            cfg.tsdf.voxel_size = float(np.float32(t._voxel_size))
+            cfg.tsdf.trunc_margin = float(np.float32(t._trunc_margin))
+        cfg.n_slots = S
+        for s in range(S):
+            b = cfg.slots[s]
+            b.input_pts, b.feats, b.pcounts = self.input_pts[s].data_ptr(), self.feats[s].data_ptr(), self.pcounts[s].data_ptr()
+            b.flat_ids, b.grid_ids, b.counters = self.flat_ids[s].data_ptr(), self.grid_ids[s].data_ptr(), self.counters[s].data_ptr()
+            b.sdf = self.sdf[s].data_ptr()
+            b.send_block = self.send[s].data_ptr() if self.send is not None else None
+            b.host_words = self.host[s].data_ptr()
+        cfg.encode_stream, cfg.main_stream = self.enc.cuda_stream, self.main.cuda_stream
+        self._cfg = cfg
+        h = C.c_void_p()
+        _lib.check(lib.bnv_frame_pipe_create(C.byref(cfg), C.byref(h)), "bnv_frame_pipe_create")
+        self._h = h
+        self._next = 0
+        self._busy = [False] * S
+        self._reserved = [0] * S
+        self._decode = [False] * S
+        self._epoch = [0] * S
+        self._lws = [None] * S
+        self._words = (C.c_int32 * HOST_WORDS)()
+        self._keep = [None] * S
+        self.inputs_resident = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.bnv_frame_pipe_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- phases -----------------------------------------------------------------------------------
+    def free_slot(self):
+        """The next slot of the ring, or None while the frame that holds it has not been collected."""
+        s = self._next
+        return None if self._busy[s] else s
+
+    def begin(self, frame, slot=None):
+        s = self._next if slot is None else slot
+        assert not self._busy[s], "slot still holds an uncollected frame"
+        lib = self._lib
+        col = None
+        if "input_pts" not in frame and self.tsdf_vol is not None and frame.get("rgb") is not None:
+            col = self.tsdf_vol._fold_color(frame["rgb"])                 # (caller's stream)
+        if not self.inputs_resident or col is not None:
+            # the frame's tensors may still be in production on the caller's stream (callers whose frames are complete
+            # in device memory set inputs_resident: the encode then overlaps the previous frame's decode)
+            self.enc.wait_stream(self.main)
+        self.pointnet._select_mode(lib)
+        if "input_pts" in frame:
+            pts = frame["input_pts"][0].detach().float().contiguous()
+            self._keep[s] = pts                                           # alive until the slot is begun again
+            _lib.check(lib.bnv_frame_begin_points(self._h, s, _lib.ptr(pts), int(pts.shape[0])), "bnv_frame_begin_points")
+        else:
+            d = frame["depth"].contiguous()
+            if d.dtype == torch.float64 and self.tsdf_vol is not None:
+                raise _lib.BnvError("FramePipe with a TSDF side volume takes uint16 (mm) or float32 (m) depth images")
+            H, W = int(d.shape[-2]), int(d.shape[-1])
+            K = (C.c_double * 9)(*np.asarray(frame["intr_mat"], dtype=np.float64)[:3, :3].reshape(-1))
+            T = (C.c_double * 16)(*np.asarray(frame["T_wc"], dtype=np.float64).reshape(-1))
+            self._keep[s] = (d, col)
+            _lib.check(lib.bnv_frame_begin_depth(self._h, s, _lib.ptr(d), self._dtypes[d.dtype], H, W, K, T,
+                                                 _lib.ptr(col)), "bnv_frame_begin_depth")
+        self._busy[s] = True
+        self._next = (s + 1) % self.n_slots
+        return s
+
+    def bound(self, slot):
+        m = C.c_int32(0)
+        _lib.check(self._lib.bnv_frame_bound(self._h, slot, C.byref(m)), "bnv_frame_bound")
+        return int(m.value)
+
+    def upsert(self, slot, decode=True, ghost_rows=0):
+        """Upsert of the slot's encoded voxels; ``ghost_rows``: rows the frame's install may create on top (the
+        volume is grown for both BEFORE the upsert: the decode-origin stamps live in a workspace that growth
+        re-makes).  Returns the slot's send block (int32 words) or None."""
+        v = self.volume
+        need = self.cap + int(ghost_rows)
+        v._reserve(need)
+        v._rows_upper += need
+        v._inflight += need
+        self._reserved[slot] = need
+        self._decode[slot] = bool(decode)
+        lws = None
+        if decode:
+            lws, self._epoch[slot] = v._lattice_workspace(self.cap)
+        self._lws[slot] = lws
+        ws = v._workspace(self.cap)
+        _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),
+                                              _lib.ptr(lws), self._epoch[slot]), "bnv_frame_upsert")
+        return None if self.send is None else self.send[slot]
+
+    def finish(self, slot, blocks=None, capacity=0):
+        v = self.volume
+        nerf = self.pointnet.nerf
+        v._select_mode(nerf)
+        lws = self._lws[slot]
+        d, keep = v._delta(self.sdf_delta)
+        _lib.check(self._lib.bnv_frame_finish(self._h, slot, C.byref(v._struct()), _lib.ptr(blocks), int(capacity),
+                                              _lib.ptr(nerf.sdf_pack), C.byref(d), _lib.ptr(lws),
+                                              lws.numel() if lws is not None else 0, self._epoch[slot]),
+                   "bnv_frame_finish")
+
+    def ready(self, slot):
+        r = self._lib.bnv_frame_ready(self._h, slot)
+        if r < 0:
+            _lib.check(r, "bnv_frame_ready")
+        return bool(r)
+
+    def result(self, slot):
+        """Host wait for the slot's frame -> its pinned words as a numpy int32 array (a copy); settles the frame's row
+        reservation and raises on device-side errors.  The slot is free again afterwards."""
+        _lib.check(self._lib.bnv_frame_result(self._h, slot, self._words), "bnv_frame_result")
+        w = np.frombuffer(self._words, dtype=np.int32).copy()
+        self._busy[slot] = False
+        v = self.volume
+        v.settle(self._reserved[slot], int(w[W_STATUS]))
+        v.check_status(int(w[W_STATUS + 1]))
+        if int(w[W_COUNTERS + 4]):
+            from .fusion import encode_error_message
+            raise _lib.BnvError(encode_error_message(int(w[W_COUNTERS + 4])))
+        return w
+
+    def outputs(self, slot, words, copy=True):
+        """(coords [U', 3] i64, sdf [U', 27] or None) of a collected frame, or (None, None) for a frame without a point
+        inside the volume.  ``copy=False``: views into the slot's buffers, valid until the slot is begun again."""
+        if int(words[W_COUNTERS]) == 0:
+            return None, None
+        self.volume.track_n_pts(float(words[W_COUNTERS + 3: W_COUNTERS + 4].view(np.float32)[0]))
+        n_out = int(words[W_COUNTERS + 2])
+        c = self.grid_ids[slot, :n_out]
+        s = self.sdf[slot, :n_out] if self._decode[slot] else None
+        if copy:
+            c = c.clone()
+            s = None if s is None else s.clone()
+        return c, s

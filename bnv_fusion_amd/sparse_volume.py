@@ -49,7 +49,13 @@ def _pow2_at_least(x):
 
 
 class SparseVolume:
-    def __init__(self, n_feats, voxel_size, dimensions, min_pts_in_grid, capacity=100000, device="cuda:0"):
+    # Dense row index of the grid ("brick", include/bnv_fusion.h): kept automatically for grids up to this many
+    # voxels (4 B each: 64 MB at 256^3, 512 MB at 512^3); ``brick=True / False`` in the constructor overrides.  The
+    # hash is always complete, so a volume without the index only decodes a little slower.
+    BRICK_MAX_VOXELS = 1 << 27
+
+    def __init__(self, n_feats, voxel_size, dimensions, min_pts_in_grid, capacity=100000, device="cuda:0",
+                 brick=None):
         min_coords, max_coords, n_xyz = get_world_range(dimensions, voxel_size)
         self.device = device
         self._dev = torch.device(device)
@@ -66,6 +72,8 @@ class SparseVolume:
         self.min_pts_in_grid = min_pts_in_grid
         self.shard = (0, 1, 3)
         self._grid = make_grid(n_xyz, min_coords, max_coords, voxel_size, min_pts_in_grid, self.shard)
+        self._want_brick = brick
+        self._brick = None
         self._ws = None
         self._slot_mask = None        # side tables of integrate_batch (per slot; re-made with the slot table)
         self._slot_items = None
@@ -109,10 +117,17 @@ class SparseVolume:
         self._features = torch.zeros((cap, 8), dtype=torch.float32, device=d)
         self._weights = torch.zeros(cap, dtype=torch.float32, device=d)
         self._num_hits = torch.zeros(cap, dtype=torch.float32, device=d)
-        # dense row index of the grid (include/bnv_fusion.h: bnv_volume_t.brick): 4 B per voxel of the grid -- 64 MB
-        # at 256^3, 512 MB at 512^3 -- filled with -1 by bnv_volume_clear below; kept for grids up to 2^30 voxels
+        # dense row index of the grid (include/bnv_fusion.h: bnv_volume_t.brick): 4 B per voxel of the grid, filled
+        # with -1 by bnv_volume_clear below; the allocation survives reset(); no memory for it -> go without
         nvox = self._n_xyz_host[0] * self._n_xyz_host[1] * self._n_xyz_host[2]
-        self._brick = torch.empty(nvox, dtype=torch.int32, device=d) if nvox <= (1 << 30) else None
+        want = (nvox <= self.BRICK_MAX_VOXELS) if self._want_brick is None else bool(self._want_brick)
+        if not want or nvox >= (1 << 31):
+            self._brick = None
+        elif self._brick is None or self._brick.numel() != nvox:
+            try:
+                self._brick = torch.empty(nvox, dtype=torch.int32, device=d)
+            except torch.OutOfMemoryError:
+                self._brick = None
         self._status = torch.zeros(2, dtype=torch.int32, device=d)   # {rows in use, sticky upsert error}
         self._n_rows = self._status[:1]
         self._rows_upper = 0          # host-side upper bound of *n_rows (avoids a sync per insert)
@@ -434,12 +449,7 @@ class SparseVolume:
             return out
         f, w, lim = self._values(query_tensor)
         d, keep = self._delta(sdf_delta)
-        need = int(self._lib.bnv_decode_lattice_workspace_bytes(n, self._row_capacity))
-        if self._lattice_ws is None or self._lattice_ws.numel() < need:
-            # zero-filled: the per-row stamps at the front of the workspace must start at 0
-            self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
-            self._lattice_epoch = 0
-        self._lattice_epoch += 1
+        self._lattice_workspace(n)
         _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
                                                 _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
@@ -447,6 +457,17 @@ class SparseVolume:
                                                 self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_decode_lattice")
         return out
+
+    def _lattice_workspace(self, n):
+        """(workspace of the lattice decode for up to n voxels, a fresh epoch).  Re-made (zero-filled) when the volume
+        grows: its front part is indexed by row."""
+        need = int(self._lib.bnv_decode_lattice_workspace_bytes(int(n), self._row_capacity))
+        if self._lattice_ws is None or self._lattice_ws.numel() < need:
+            # zero-filled: the per-row stamps at the front of the workspace must start at 0
+            self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            self._lattice_epoch = 0
+        self._lattice_epoch += 1
+        return self._lattice_ws, self._lattice_epoch
 
     def last_lattice_table_rows(self):
         """Device int32 tensor [1]: rows listed by the last bnv_lattice_neighbors(build_list) (sharded

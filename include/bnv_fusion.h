@@ -201,6 +201,10 @@ int bnv_shard_pack(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_
                    const int32_t* n_dev, void* block, int64_t capacity, bnv_stream_t stream);
 int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
                       int64_t capacity, bnv_stream_t stream);
+/* The same, and the header count of own_send_block (the block this rank contributed to `blocks`; may be NULL) is set
+ * back to 0: the block is then ready for the records bnv_volume_integrate_frame appends for the next frame. */
+int bnv_shard_install_reset(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
+                            int64_t capacity, void* own_send_block, bnv_stream_t stream);
 
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
@@ -277,6 +281,23 @@ size_t bnv_volume_workspace_bytes(int64_t max_keys);
 int bnv_volume_integrate(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
                          const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws,
                          size_t ws_bytes, bnv_stream_t stream);
+
+/* bnv_volume_integrate for the per-frame pipeline: the same single launch also (a) marks the rows it touches as the
+ * ORIGINS of the frame's lattice decode in `lattice_ws` (the workspace bnv_decode_lattice_stamped is then called with,
+ * same stamp_epoch != 0; NULL: no stamps) and (b) with a sharded volume appends the boundary voxels among the
+ * upserted keys -- with the values just written -- to shard_block as bnv_shard_pack would (header count must be 0 or
+ * hold the records of this frame so far: bnv_shard_install_reset leaves it so; NULL: no records).  Replaces the launches
+ * of k_lattice_stamp and bnv_shard_pack (local_point_fusion.py:647-673 has no counterpart of either: new design). */
+typedef struct bnv_integrate_extras {
+  void* shard_block;             /* (1 + shard_block_capacity) records of BNV_SHARD_RECORD_BYTES, or NULL */
+  int64_t shard_block_capacity;
+  const bnv_grid_t* grid_host;   /* ownership predicates; needed with shard_block */
+  void* lattice_ws;              /* lattice-decode workspace sized for vol->row_capacity, or NULL */
+  int32_t stamp_epoch;
+} bnv_integrate_extras_t;
+int bnv_volume_integrate_frame(const bnv_volume_t* vol_host, const int64_t* coords, const float* feats,
+                               const int64_t* pcounts, int64_t n, const int32_t* n_dev, void* ws, size_t ws_bytes,
+                               const bnv_integrate_extras_t* extras_host, bnv_stream_t stream);
 
 /* The same for up to BNV_VOLUME_BATCH_MAX consecutive frames in ONE call (4 launches): the result -- row order, row
  * count, features, weights -- is identical to calling bnv_volume_integrate once per frame in order (the replay loop of
@@ -410,6 +431,14 @@ int bnv_decode_lattice(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host
                        const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
                        float* out_sdf, bnv_stream_t stream);
 
+/* bnv_decode_lattice for origins that bnv_volume_integrate_frame has already stamped in `ws` with this `epoch` (the
+ * origins are exactly the keys of that upsert): one launch less. */
+int bnv_decode_lattice_stamped(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
+                               const float* features, const float* weights, int64_t row_limit,
+                               const float* sdfmlp_pack, const int64_t* origins, int64_t n, const int32_t* n_dev,
+                               const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
+                               float* out_sdf, bnv_stream_t stream);
+
 /* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
  * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
@@ -455,6 +484,86 @@ int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int3
                      float voxel_size, int32_t min_pts_in_grid, const float* sdfmlp_pack,
                      const float* voxel_coords, int64_t n, int32_t variant, float* out_sdf, float* out_feats,
                      int32_t* status, bnv_stream_t stream);
+
+/* ---- the per-frame chain as one object: NeuralMap.integrate (run_e2e.py:78-109: encode_pointcloud -> track_n_pts ->
+ * _integrate -> TSDF side fusion) followed by the lattice decode of the frame's voxels (sparse_volume.py:697-738),
+ * for one GPU or for one shard of a spatially sharded volume.  Replaces the per-stage calls
+ * above on the per-frame path: a frame in flight occupies a SLOT of caller-owned persistent buffers and runs on two
+ * streams -- the encode (a function of the frame only) on encode_stream, the volume-dependent part on main_stream --
+ * so frame t+1's encode overlaps frame t's exchange + decode, and no stage needs a host-side allocation, event object
+ * or size read.  Per frame and slot, in this order:
+ *   bnv_frame_begin_depth | _points   encode_stream: front end + voxelise + rank; exchange bound -> pinned memory;
+ *                                     point encoder + reduction + filter; TSDF side fusion (depth frames, if configured)
+ *   bnv_frame_upsert                  main_stream: upsert + running average (+ boundary records into the slot's send
+ *                                     block, + decode-origin stamps when lattice_ws is given)
+ *   bnv_frame_bound                   HOST wait for the frame's exchange bound (max over ranks; 0 unsharded)
+ *   [sharded: the caller all-gathers the first (1 + capacity) records of every rank's send block on main_stream]
+ *   bnv_frame_finish                  main_stream: install ghost rows from `blocks`, lattice decode into the slot's sdf
+ *                                     (when lattice_ws is given), read-backs into the slot's pinned words
+ *   bnv_frame_result                  HOST wait for the frame; copies the slot's pinned words out; frees the slot
+ * The volume and its workspaces are passed per call (they are re-made when the volume grows).  The object owns HIP
+ * events only; every buffer is the caller's and must outlive it. */
+#define BNV_PIPE_MAX_SLOTS 8
+#define BNV_PIPE_HOST_WORDS 96
+/* int32 words of a slot's pinned area */
+#define BNV_PIPE_WORD_COUNTERS 0  /* [8]  bnv_encode_counters_t of the frame                                     */
+#define BNV_PIPE_WORD_STATUS 8    /* [2]  {volume row count, sticky upsert error} behind the frame               */
+#define BNV_PIPE_WORD_EVALS 10    /* [1]  SDF-MLP evaluations of the frame's decode                              */
+#define BNV_PIPE_WORD_BOUNDS 16   /* [shard_world] touched boundary voxels per rank (the exchange bound)         */
+
+typedef struct bnv_frame_slot {
+  float* input_pts;                 /* [max_points, 6]: written by the depth front end (may be NULL: point frames only) */
+  float* feats;                     /* [out_capacity, 8]  */
+  int64_t* pcounts;                 /* [out_capacity]     */
+  int64_t* flat_ids;                /* [out_capacity]     */
+  int64_t* grid_ids;                /* [out_capacity, 3]  */
+  bnv_encode_counters_t* counters;  /* device             */
+  float* sdf;                       /* [out_capacity, 27] or NULL (never decoding)                               */
+  void* send_block;                 /* sharded: (1 + send_capacity) records, header {0, rank, 0} before first use */
+  int32_t* host_words;              /* PINNED HOST memory, BNV_PIPE_HOST_WORDS int32                             */
+} bnv_frame_slot_t;
+
+typedef struct bnv_tsdf_desc {      /* TSDFVolume (third_parties/fusion.py:19-66); tsdf == NULL: no side fusion   */
+  float* tsdf;
+  float* weight;
+  float* color;
+  int32_t dim[3];
+  float origin[3];
+  float voxel_size, trunc_margin;
+} bnv_tsdf_desc_t;
+
+typedef struct bnv_frame_pipe_config {
+  bnv_grid_t grid;
+  int64_t max_points;               /* largest frame (H * W)                                                      */
+  int64_t out_capacity;             /* rows of the slots' output arrays (>= 8 * max_points / min_pts + 1)         */
+  int64_t send_capacity;            /* records of the slots' send blocks (>= out_capacity is always enough)       */
+  const float* pointnet_pack;
+  void* enc_ws;                     /* bnv_encode_workspace_bytes(enc_ws_max_points, grid.n_xyz), zeroed once     */
+  size_t enc_ws_bytes;
+  int64_t enc_ws_max_points;
+  double max_depth;                 /* depth cut-off of the loader (common.py:110-113)                            */
+  bnv_tsdf_desc_t tsdf;
+  int32_t n_slots;
+  bnv_frame_slot_t slots[BNV_PIPE_MAX_SLOTS];
+  bnv_stream_t encode_stream, main_stream;
+} bnv_frame_pipe_config_t;
+
+typedef struct bnv_frame_pipe bnv_frame_pipe_t;
+int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* config_host, bnv_frame_pipe_t** out);
+int bnv_frame_pipe_destroy(bnv_frame_pipe_t* pipe);
+/* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL */
+int bnv_frame_begin_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
+                          const double* intr_host, const double* T_wc_host, const float* color_im);
+int bnv_frame_begin_points(bnv_frame_pipe_t* pipe, int slot, const float* input_pts, int64_t n_points);
+int bnv_frame_upsert(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, void* vol_ws, size_t vol_ws_bytes,
+                     void* lattice_ws, int32_t lattice_epoch);
+int bnv_frame_bound(bnv_frame_pipe_t* pipe, int slot, int32_t* max_bound_host);
+int bnv_frame_finish(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, const void* blocks,
+                     int64_t block_capacity, const float* sdfmlp_pack, const bnv_sdf_delta_t* delta_host,
+                     void* lattice_ws, size_t lattice_ws_bytes, int32_t lattice_epoch);
+int bnv_frame_result(bnv_frame_pipe_t* pipe, int slot, int32_t* words_host /* [BNV_PIPE_HOST_WORDS] or NULL */);
+/* 1: bnv_frame_result would not block; 0: the frame is still running */
+int bnv_frame_ready(bnv_frame_pipe_t* pipe, int slot);
 
 #ifdef __cplusplus
 }

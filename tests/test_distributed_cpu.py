@@ -49,7 +49,10 @@ class OracleShardBackend:
     def bound(self, fr):
         return int(fr.counts.max()) if self.world > 1 else 0
 
-    def pack(self, fr, capacity):
+    def upsert(self, fr, capacity, decode=True):
+        """(the oracle backend has already upserted in encode: this is the pack half)"""
+        if capacity == 0:
+            return None
         D, v = self.D, self.vol
         g = fr.grid_ids.numpy()
         send = g[D.shard_is_boundary(g, self.world)] if len(g) else g.reshape(0, 3)
@@ -63,7 +66,7 @@ class OracleShardBackend:
             block[1: 1 + len(send), 4:] = f.contiguous().view(torch.int32)
         return block.reshape(-1)
 
-    def install(self, blocks, capacity):
+    def install(self, fr, blocks, capacity):
         D, v = self.D, self.vol
         blocks = blocks.reshape(self.world, capacity + 1, D.REC_WORDS)
         for r in range(self.world):

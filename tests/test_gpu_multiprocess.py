@@ -87,6 +87,30 @@ def test_spatial_sharding_processes_equal_single_gpu(tmp_path, single_512, world
         assert per_frame < 48 * 1.6 * len(ref[-1][0])                               # boundary records only, 48 B each
 
 
+def test_spatial_sharding_eight_processes_512_full_frames(tmp_path, single_512):
+    """BASELINE config 3's shape: 512^3 grid, 640x480 frames, the active-voxel set sharded over EIGHT processes (they
+    share this box's GPU over gloo; the 8-GPU RCCL run is the driver's), one all-gather of boundary records and one
+    host wait per frame -- bit-identical to the single-GPU run."""
+    ref, rows, tsdf, voxel = single_512
+    world = 8
+    ranks = _launch(world, "spatial", 512, len(ref), tmp_path, (480, 640))
+    for t, (rc, rs) in enumerate(ref):
+        parts = [r["out"][t] for r in ranks]
+        assert all(p[0] is not None and len(p[0]) > 0 for p in parts)
+        coords = torch.cat([p[0] for p in parts])
+        sdf = torch.cat([p[1] for p in parts])
+        order = torch.argsort((coords[:, 0] * 512 + coords[:, 1]) * 512 + coords[:, 2])
+        assert torch.equal(coords[order], rc), t
+        assert torch.equal(sdf[order], rs), t
+    sizes = [len(r["out"][len(ref) - 1][0]) for r in ranks]
+    assert max(sizes) < 1.35 * (sum(sizes) / world)
+    for r in ranks:
+        m = r["meta"]
+        assert m["host_waits"] == len(ref) and torch.equal(m["tsdf"], tsdf)
+        assert rows / world < m["rows"] < rows
+        assert m["exchanged_bytes"] / len(ref) < 48 * 1.6 * len(ref[-1][0])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_frame_parallel_processes_equal_single_gpu(tmp_path, single_256, world):
     """Frame-parallel mode: ranks encode / decode different frames of a batch, replicated volume."""

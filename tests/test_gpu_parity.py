@@ -479,7 +479,8 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
     far = {"input_pts": torch.from_numpy(z["frames"][0]).to(DEV) + 50.0}
     for b in shards:
         f = b.encode(far)
-        assert b.bound(f) == 0 and b.result(b.finish(f, b.decode(f), 0)) == (None, None)
+        assert b.bound(f) == 0 and b.upsert(f, 0) is None
+        assert b.result(b.finish(f, b.decode(f), 0)) == (None, None)
         assert b.volume.num_rows() == 0
     for fr in z["frames"]:
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
@@ -488,17 +489,21 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
         frs = [b.encode(frame) for b in shards]
         bounds = [b.bound(f) for b, f in zip(shards, frs)]
         assert len(set(bounds)) == 1 and bounds[0] > 0                   # every rank computes the same bound
-        counts = [f.bound_host.clone() for f in frs]
+        from bnv_fusion_amd.pipeline import W_BOUNDS
+        counts = [b.pipe.host[f.slot, W_BOUNDS: W_BOUNDS + world].clone() for b, f in zip(shards, frs)]
         assert all(torch.equal(c, counts[0]) for c in counts)
         cap = -(-bounds[0] // D.REC_QUANTUM) * D.REC_QUANTUM
-        blocks = torch.stack([b.pack(f, cap) for b, f in zip(shards, frs)])
+        # the upsert launch appends the boundary records of the voxels it has just updated to the slot's send block
+        blocks = torch.stack([b.upsert(f, cap) for b, f in zip(shards, frs)])
         hdr = blocks.view(world, cap + 1, D.REC_WORDS)[:, 0, :3].cpu()
         for r in range(world):
             assert int(hdr[r, 1]) == r and int(hdr[r, 2]) == 0 and int(hdr[r, 0]) <= int(counts[0][r])
         outs = []
         for b, f in zip(shards, frs):
-            res = b.install(blocks, cap)
+            res = b.install(f, blocks.view(-1), cap)
             outs.append(b.result(b.finish(f, b.decode(f), res)))
+        for b, f in zip(shards, frs):      # the install has reset the send block for the slot's next frame
+            assert int(b.pipe.send[f.slot, 0]) == 0 and int(b.pipe.send[f.slot, 1]) == b.rank
     model.shard = (0, 1, 3)
     owned = [o[0] for o in outs]
     for r in range(world):

@@ -1,0 +1,262 @@
+"""The per-frame chain behind the C object of csrc/pipeline.hip (FramePipe) and the kernels folded for it
+(bnv_volume_integrate_frame, bnv_decode_lattice_stamped, bnv_shard_install_reset); the volume workspace's look-back
+words; the volume without its dense row index.  Everything is compared bit for bit (torch.equal) with the per-stage
+path the other GPU tests pin against the reference's goldens.  Needs a real MI355X: run with  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", params=["split_f16", "fp32_exact"])
+def bnv(request):
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU (no CPU fallback exists)")
+    import bnv_fusion_amd
+    bnv_fusion_amd.set_mlp_mode(1 if request.param == "split_f16" else 0)
+    yield bnv_fusion_amd
+    bnv_fusion_amd.set_mlp_mode(1)
+
+
+def _frames(n, hw=(240, 320), start=0):
+    from bnv_fusion_amd import synthetic
+    return [{"depth": torch.from_numpy(synthetic.depth_u16(t, *hw)).to(DEV), "intr_mat": synthetic.intrinsics(*hw),
+             "T_wc": synthetic.pose(t)} for t in range(start, start + n)]
+
+
+def _run_pipe(pipe, frames, depth_in_flight, decode=True):
+    """Drives a FramePipe (world 1) with ``depth_in_flight`` frames enqueued ahead of the oldest uncollected one."""
+    outs, pend = [], []
+
+    def collect():
+        s = pend.pop(0)
+        outs.append(pipe.outputs(s, pipe.result(s), copy=True))
+
+    for fr in frames:
+        while len(pend) >= min(depth_in_flight, pipe.n_slots):
+            collect()
+        s = pipe.begin(fr)
+        assert pipe.bound(s) == 0
+        assert pipe.upsert(s, decode=decode) is None
+        pipe.finish(s)
+        pend.append(s)
+    while pend:
+        collect()
+    return outs
+
+
+@pytest.mark.parametrize("in_flight", [1, 3])
+@pytest.mark.parametrize("kind", ["depth", "points"])
+def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind):
+    """One GPU: the pipe's outputs, volume and TSDF volume equal NeuralMap.fuse_and_decode's, frame by frame, with
+    one or several frames in flight (slots reused: 14 frames through 4 slots), from depth images (front end fused,
+    TSDF side fusion) and from input_pts; an empty frame in the middle."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.frontend import depth_to_input_pts
+    from bnv_fusion_amd.pipeline import FramePipe
+    from bnv_fusion_amd.sparse_volume import get_world_range
+    from bnv_fusion_amd.tsdf import TSDFVolume
+    dims, voxel = synthetic.GRID_DIMS[256]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(14)
+    far = dict(frames[5])
+    T = np.array(far["T_wc"], dtype=np.float64)
+    T[:3, 3] += 50.0                                   # no point inside the volume
+    far["T_wc"] = T
+    frames[5] = far
+    if kind == "points":
+        frames = [{"input_pts": depth_to_input_pts(f["depth"], f["intr_mat"], f["T_wc"], max_depth=3.0,
+                                                   compact=False)[0]} for f in frames]
+    tsdf = kind == "depth"
+    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV, tsdf=tsdf)
+    ref = [ref_nm.fuse_and_decode(f) for f in frames]
+    vol = bnv.SparseVolume(8, voxel, dims3, 8, device=DEV)
+    tv = None
+    if tsdf:
+        mn, mx, _ = get_world_range(dims3, 0.025)
+        tv = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=DEV)
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv)
+    got = _run_pipe(pipe, frames, in_flight)
+    for t, ((rc, rs), (gc, gs)) in enumerate(zip(ref, got)):
+        if rc is None:
+            assert gc is None and gs is None and t == 5
+            continue
+        assert torch.equal(rc, gc), t
+        assert torch.equal(rs, gs), t
+    assert float((ref[-1][1] != voxel).float().mean()) > 0.05           # the decode mask is live
+    a, b = ref_nm.volume, vol
+    n = a.num_rows()
+    assert b.num_rows() == n
+    assert torch.equal(a._row_coords[:n], b._row_coords[:n]) and torch.equal(a._features[:n], b._features[:n])
+    assert torch.equal(a._weights[:n], b._weights[:n])
+    assert vol.n_frames == ref_nm.volume.n_frames and vol.n_pts_list == ref_nm.volume.n_pts_list
+    if tsdf:
+        assert torch.equal(tv.tsdf, ref_nm.tsdf_vol.tsdf) and torch.equal(tv.weight, ref_nm.tsdf_vol.weight)
+
+
+def test_frame_pipe_grows_the_volume_mid_stream(bnv):
+    """A volume of the reference's initial capacity grows (re-allocation + re-hash, new lattice workspace) while
+    frames are in flight: same outputs as the per-stage path."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    dims, voxel = synthetic.GRID_DIMS[256]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(12, hw=(480, 640))
+    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV, capacity=1 << 20)
+    ref = [ref_nm.fuse_and_decode(f) for f in frames]
+    vol = bnv.SparseVolume(8, voxel, dims3, 8, capacity=2000, device=DEV)
+    cap0 = vol._row_capacity
+    got = _run_pipe(FramePipe(vol, model, 480 * 640, n_slots=3), frames, 2)
+    assert vol._row_capacity > cap0
+    for (rc, rs), (gc, gs) in zip(ref, got):
+        assert torch.equal(rc, gc) and torch.equal(rs, gs)
+
+
+def test_integrate_frame_packs_the_records_bnv_shard_pack_does(bnv):
+    """bnv_volume_integrate_frame on a sharded grid: the records it appends are the ones bnv_shard_pack lists for the
+    same keys after a plain upsert (as sets; record order is free), rows / values equal the plain upsert's."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib, distributed as D
+    from bnv_fusion_amd.sparse_volume import make_grid
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    dims, voxel = z["dims"], float(z["voxel_size"])
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    lib = _lib.load()
+    world, rank = 3, 1
+    vols = [bnv.SparseVolume(8, voxel, dims, 8, device=DEV) for _ in range(2)]
+    for v in vols:
+        v.shard = (rank, world, D.BLOCK_LOG2)
+        v._grid = make_grid(v._n_xyz_host, v.min_coords, v.max_coords, voxel, 8, v.shard)
+    for k, fr in enumerate(z["frames"][:6]):
+        f, c, ids, g, n = model.encode_pointcloud(torch.from_numpy(fr).to(DEV), vols[0].n_xyz, vols[0].min_coords,
+                                                  vols[0].max_coords, voxel, return_dense=False)
+        own = torch.from_numpy(D.voxel_owner(g.cpu().numpy(), world) == rank).to(DEV)
+        g, f, c = g[own].contiguous(), f[own].contiguous(), c[own, 0].contiguous()
+        m = int(g.shape[0])
+        a, b = vols
+        a.integrate(g, f, c)
+        blk_a = torch.zeros((m + 1) * D.REC_WORDS, dtype=torch.int32, device=DEV)
+        _lib.check(lib.bnv_shard_pack(C.byref(a._struct()), C.byref(a._grid), _lib.ptr(g), m, None, _lib.ptr(blk_a), m,
+                                      _lib.stream_ptr()), "bnv_shard_pack")
+        b._reserve(m)
+        ws = b._workspace(m)
+        lws, ep = b._lattice_workspace(m)
+        blk_b = torch.zeros((m + 1) * D.REC_WORDS, dtype=torch.int32, device=DEV)
+        blk_b[1] = rank
+        x = _lib.IntegrateExtras()
+        x.shard_block, x.shard_block_capacity, x.grid_host = blk_b.data_ptr(), m, C.pointer(b._grid)
+        x.lattice_ws, x.stamp_epoch = lws.data_ptr(), ep
+        _lib.check(lib.bnv_volume_integrate_frame(C.byref(b._struct()), _lib.ptr(g), _lib.ptr(f), _lib.ptr(c), m, None,
+                                                  _lib.ptr(ws), ws.numel(), C.byref(x), _lib.stream_ptr()),
+                   "bnv_volume_integrate_frame")
+        b._rows_upper += m
+        ra = blk_a.view(m + 1, D.REC_WORDS).cpu().numpy()
+        rb = blk_b.view(m + 1, D.REC_WORDS).cpu().numpy()
+        na, nb = int(ra[0, 0]), int(rb[0, 0])
+        assert na == nb > 0 and list(rb[0, :3]) == [nb, rank, 0]
+        ka, kb = ra[1: 1 + na], rb[1: 1 + nb]
+        assert np.array_equal(ka[np.lexsort(ka[:, :3].T[::-1])], kb[np.lexsort(kb[:, :3].T[::-1])]), k
+        n_rows = a.num_rows()
+        assert b.num_rows() == n_rows and torch.equal(a._row_coords[:n_rows], b._row_coords[:n_rows])
+        assert torch.equal(a._features[:n_rows], b._features[:n_rows]) and torch.equal(a._weights[:n_rows], b._weights[:n_rows])
+        # the stamped decode equals the plain one
+        sa = a.decode_lattice(g, model.nerf, query_tensor=False)
+        sb = torch.empty((m, 27), dtype=torch.float32, device=DEV)
+        d, _ = b._delta(None)
+        _lib.check(lib.bnv_decode_lattice_stamped(C.byref(b._struct()), C.byref(b._grid), _lib.ptr(b._features),
+                                                  _lib.ptr(b._weights), b._row_capacity, _lib.ptr(model.nerf.sdf_pack),
+                                                  _lib.ptr(g), m, None, C.byref(d), _lib.ptr(lws), lws.numel(), ep,
+                                                  _lib.ptr(sb), _lib.stream_ptr()), "bnv_decode_lattice_stamped")
+        assert torch.equal(sa, sb), k
+
+
+def test_volume_workspace_lookback_words_never_alias(bnv):
+    """the look-back words of the volume workspace used to sit behind arrays sized by the call's n, so a
+    small call's words landed in the slot indices a larger call had left there.  Large and small insert / integrate /
+    integrate_batch calls alternate on ONE volume (one workspace, stale words and all); its rows must equal those of
+    a volume that runs the same calls with a zero-filled workspace each, and be the keys in first-occurrence order."""
+    rng = np.random.default_rng(3)
+    dims = np.array([2.54] * 3)
+
+    def calls():
+        # (kind, keys): sizes chosen so that small calls' tile words would fall inside large calls' slot_of arrays
+        out = []
+        nxt = 0
+        for rep in range(40):
+            for kind, n in (("batch", 70000), ("integrate", 300), ("insert", 50000), ("batch", 900), ("integrate", 5000)):
+                fresh = np.arange(nxt, nxt + n // 2)
+                nxt += n // 2
+                old = rng.integers(0, max(nxt - n // 2, 1), n - n // 2)
+                ids = np.unique(np.concatenate([fresh, old]))
+                rng.shuffle(ids)
+                out.append((kind, ids))
+        return out
+
+    def keys_of(ids):
+        return torch.from_numpy(np.stack([ids // 65536, (ids // 256) % 256, ids % 256], 1)).to(DEV)
+
+    def apply(vol, kind, ids, fresh_ws):
+        k = keys_of(ids)
+        n = len(ids)
+        f = torch.full((n, 8), 0.5, device=DEV)
+        c = torch.full((n,), 16, dtype=torch.int64, device=DEV)
+        if fresh_ws:
+            vol._ws = None
+        if kind == "integrate":
+            vol.integrate(k, f, c)
+        elif kind == "insert":
+            vol.insert(k, f, torch.ones(n, device=DEV), torch.zeros(n, device=DEV))
+        else:
+            h = n // 3
+            vol.integrate_batch([(k[:h], f[:h], c[:h], None), (k[h:], f[h:], c[h:], None)])
+
+    seq = calls()
+    a = bnv.SparseVolume(8, 0.01, dims, 8, capacity=1 << 22, device=DEV)
+    b = bnv.SparseVolume(8, 0.01, dims, 8, capacity=1 << 22, device=DEV)
+    for kind, ids in seq:
+        apply(a, kind, ids, fresh_ws=False)      # one shared workspace, stale words and all
+        apply(b, kind, ids, fresh_ws=True)       # a zero-filled workspace per call
+    n = a.num_rows()
+    assert n == b.num_rows() and n > 1_000_000
+    assert torch.equal(a._row_coords[:n], b._row_coords[:n])
+    assert torch.equal(a._weights[:n], b._weights[:n])
+    # and the rows are the keys in first-occurrence order (a batch numbers its frames in order: the same order)
+    seen = np.zeros(max(int(ids.max()) for _, ids in seq) + 1, dtype=bool)
+    order = []
+    for _, ids in seq:
+        new = ids[~seen[ids]]
+        seen[new] = True
+        order.append(new)
+    rc = a._row_coords[:n].cpu().numpy()
+    assert np.array_equal(rc[:, 0] * 65536 + rc[:, 1] * 256 + rc[:, 2], np.concatenate(order))
+
+
+def test_volume_without_dense_row_index(bnv):
+    """``brick=False``: the hash alone serves every look-up; decode and upserts equal the indexed volume's."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(10)
+    vols = [bnv.SparseVolume(8, voxel, dims3, 8, device=DEV, brick=flag) for flag in (None, False)]
+    assert vols[0]._brick is not None and vols[1]._brick is None
+    for fr in frames:
+        outs = []
+        for v in vols:
+            f, c, fl, g, cnt, cap = model.encode_depth_async(fr["depth"], fr["intr_mat"], fr["T_wc"], 3.0, v.n_xyz,
+                                                             v.min_coords, v.max_coords, voxel)[:6]
+            n = int(cnt[2])
+            v.integrate(g[:n], f[:n], c[:n])
+            outs.append(v.decode_lattice(g[:n], model.nerf, query_tensor=False))
+        assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] != voxel).float().mean()) > 0.05
+    n = vols[0].num_rows()
+    assert vols[1].num_rows() == n and torch.equal(vols[0]._features[:n], vols[1]._features[:n])

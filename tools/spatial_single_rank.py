@@ -29,7 +29,7 @@ model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
           for t in range(30 + args.frames)]
 be = D.HipShardBackend(np.array([dims] * 3), voxel, model, 0, W, capacity=1 << 21, device="cuda:0", tsdf=True)
-PH = ("encode+upsert", "pack", "all_gather", "install", "decode")
+PH = ("encode", "upsert+pack", "all_gather", "(install: in finish)", "install+decode")
 acc = {k: 0.0 for k in PH}
 waits = recv_bytes = own = evals = 0
 
@@ -42,14 +42,14 @@ def frame(fr, decode=True, timed=False):
     ev[1].record()
     bound = be.bound(f); waits += 1                      # the frame's one host wait
     cap = -(-bound // D.REC_QUANTUM) * D.REC_QUANTUM
-    send = be.pack(f, cap)
+    send = be.upsert(f, cap, decode)
     ev[2].record()
     one = torch.empty((1, send.numel()), dtype=send.dtype, device=send.device)
     dist.all_gather_into_tensor(one.view(-1), send)      # the collective call itself (1-rank group)
     recv = one.repeat(W, 1)                              # the other ranks' blocks: copies, sender ids patched
     recv.view(W, cap + 1, D.REC_WORDS)[:, 0, 1] = torch.arange(W, dtype=torch.int32, device=recv.device)
     ev[3].record()
-    res = be.install(recv, cap)
+    res = be.install(f, recv.view(-1), cap)
     ev[4].record()
     sdf = be.decode(f) if decode else None
     ev[5].record()
