@@ -62,7 +62,7 @@ def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind):
     from bnv_fusion_amd.pipeline import FramePipe
     from bnv_fusion_amd.sparse_volume import get_world_range
     from bnv_fusion_amd.tsdf import TSDFVolume
-    dims, voxel = synthetic.GRID_DIMS[256]
+    dims, voxel = synthetic.GRID_DIMS[128]             # 0.02 m voxels: weights reach min_pts within 8 frames
     dims3 = np.array([dims] * 3)
     model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     frames = _frames(14)
@@ -106,7 +106,7 @@ def test_frame_pipe_grows_the_volume_mid_stream(bnv):
     frames are in flight: same outputs as the per-stage path."""
     from bnv_fusion_amd import synthetic
     from bnv_fusion_amd.pipeline import FramePipe
-    dims, voxel = synthetic.GRID_DIMS[256]
+    dims, voxel = synthetic.GRID_DIMS[128]
     dims3 = np.array([dims] * 3)
     model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     frames = _frames(12, hw=(480, 640))
@@ -118,6 +118,7 @@ def test_frame_pipe_grows_the_volume_mid_stream(bnv):
     assert vol._row_capacity > cap0
     for (rc, rs), (gc, gs) in zip(ref, got):
         assert torch.equal(rc, gc) and torch.equal(rs, gs)
+    assert float((ref[-1][1] != voxel).float().mean()) > 0.05
 
 
 def test_integrate_frame_packs_the_records_bnv_shard_pack_does(bnv):
