@@ -1,6 +1,13 @@
 """bnv_fusion_amd -- MI355X (gfx950) implementation of BNV-Fusion's per-frame local-geometry fusion
 and SDF decode hot path, behind the reference's LitFusionPointNet / SparseVolume call surface.
 See DESIGN.md (layout, kernels, rooflines) and INTEGRATION.md (how run_e2e.py picks it up)."""
+import os as _os
+
+# The HIP runtime serves a process's streams from GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
+# queue run strictly in submission order.  More queues make it likelier that the pipelines' side streams get one of
+# their own (streams.py still verifies it); only effective when set before the runtime initialises.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .fusion import LitFusionPointNet, LocalNeRFModel, get_neighbors, load_pretrained  # noqa: F401
 from .sparse_volume import SparseVolume, VolumeList, get_world_range  # noqa: F401
 from .neural_map import NeuralMap  # noqa: F401

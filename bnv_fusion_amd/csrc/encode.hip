@@ -388,13 +388,19 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
       if (run < max_unique) ids[run] = id;
       else ctl->error = 1;
       ++run;
-      if (g.shard_world > 1) {
-        const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
-        if (shard_is_boundary(x, y, z, g)) atomicAdd(&s_hist[voxel_owner(x, y, z, g) & 63], 1);
-      }
     }
   }
   if (g.shard_world > 1) {
+    // the exchange bound: touched BOUNDARY voxels per owner.  The set bits sit in a few threads (a thread holds 256
+    // consecutive voxels), so the ~30 ownership hashes of a boundary test are spread over the workgroup: it walks
+    // the ids it has just written (its own stretch of the sorted list), one voxel per thread and step
+    __syncthreads();
+    const int64_t lo = s_excl, hi = (int64_t)s_excl + total < max_unique ? (int64_t)s_excl + total : max_unique;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += kScanThreads) {
+      const int id = __hip_atomic_load(&ids[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by other lanes of this workgroup)
+      const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+      if (shard_is_boundary(x, y, z, g)) atomicAdd(&s_hist[voxel_owner(x, y, z, g) & 63], 1);
+    }
     __syncthreads();
     if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
       atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);

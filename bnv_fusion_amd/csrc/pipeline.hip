@@ -25,8 +25,20 @@
 
 using namespace bnv;
 
+// the frame's read-backs in ONE small launch that writes the slot's pinned words directly (three hipMemcpyAsync of
+// 4-32 bytes were three blit kernels of ~4.3 us each on the main stream)
+__global__ void k_frame_readback(const int32_t* __restrict__ counters, const int32_t* __restrict__ status,
+                                 const int32_t* __restrict__ evals, int32_t* __restrict__ host_words) {
+  const int t = threadIdx.x;
+  if (t < 8) host_words[BNV_PIPE_WORD_COUNTERS + t] = counters[t];
+  else if (t < 10) host_words[BNV_PIPE_WORD_STATUS + t - 8] = status[t - 8];
+  else if (t == 10) host_words[BNV_PIPE_WORD_EVALS] = evals ? *evals : 0;
+  __threadfence_system();
+}
+
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
+  int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
   hipStream_t E, M;
   hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
       ev_done[BNV_PIPE_MAX_SLOTS];
@@ -62,6 +74,12 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->used[s] = false;
     p->n_points[s] = 0;
     p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_done[s] = nullptr;
+    p->host_dev[s] = nullptr;
+  }
+  for (int s = 0; s < cfg->n_slots; ++s) {
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, cfg->slots[s].host_words, 0) == hipSuccess) p->host_dev[s] = (int32_t*)d;
+    else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
     hipEvent_t* evs[4] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_done[s]};
@@ -208,13 +226,20 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
                                     b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws,
                                     lattice_ws_bytes, lattice_epoch, b.sdf, p->M);
     if (rc != BNV_OK) return rc;
-    int32_t *stamp = nullptr, *ctl = nullptr;
-    lattice_ws_frame_words(lattice_ws, vol->row_capacity, &stamp, &ctl);
-    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_EVALS, ctl + 1, 4, hipMemcpyDeviceToHost, p->M));
   }
-  BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_COUNTERS, b.counters, sizeof(bnv_encode_counters_t),
-                               hipMemcpyDeviceToHost, p->M));
-  BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->M));
+  int32_t *stamp = nullptr, *ctl = nullptr;
+  if (lattice_ws) lattice_ws_frame_words(lattice_ws, vol->row_capacity, &stamp, &ctl);
+  if (p->host_dev[slot]) {
+    hipLaunchKernelGGL(k_frame_readback, dim3(1), dim3(64), 0, p->M, (const int32_t*)b.counters,
+                       (const int32_t*)vol->n_rows, ctl ? (const int32_t*)(ctl + 1) : (const int32_t*)nullptr,
+                       p->host_dev[slot]);
+    BNV_LAUNCH_CHECK();
+  } else {
+    if (ctl) BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_EVALS, ctl + 1, 4, hipMemcpyDeviceToHost, p->M));
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_COUNTERS, b.counters, sizeof(bnv_encode_counters_t),
+                                 hipMemcpyDeviceToHost, p->M));
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->M));
+  }
   BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
   BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->M));
   p->used[slot] = true;

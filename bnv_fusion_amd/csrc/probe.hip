@@ -104,3 +104,22 @@ extern "C" int bnv_probe_mfma_rate(int shape, int operands, int iters, void* str
   *flop_host = (double)cus * 8.0 * (double)iters * 12.0 * (2.0 * 32 * 32 * 16);
   return BNV_OK;
 }
+
+// ---- do two HIP streams of this process really run side by side?  A single-workgroup kernel that spins for a number
+// of shader cycles: one on each of two streams takes as long as one alone if the streams are served by different
+// hardware queues (bnv_fusion_amd/streams.py picks the frame pipeline's encode stream with it; tools/stream_probe.py).
+namespace bnv {
+__global__ void k_probe_spin(long long cycles, int* sink) {
+  const long long t0 = clock64();
+  while (clock64() - t0 < cycles) {
+  }
+  if (sink && cycles < 0) *sink = 1;
+}
+}  // namespace bnv
+
+extern "C" int bnv_probe_spin(int n_blocks, int64_t cycles, void* stream) {
+  if (n_blocks < 1 || cycles < 0) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(bnv::k_probe_spin, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, (long long)cycles, (int*)nullptr);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}

@@ -338,12 +338,14 @@ class HipFrameBackend:
             self.tsdf_vol = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=device)
         self._scratch_ids = None
         # high priority: its few small launches are on the path of the next batch (measured: -35 us per batch)
-        self._side = torch.cuda.Stream(device=self.dev, priority=-1)       # header / payload exchange: never behind the decode
+        from .streams import concurrent_stream
+        main = torch.cuda.current_stream(self.dev)
+        self._side = concurrent_stream(self.dev, main, priority=-1)        # header / payload exchange: never behind the decode
         # the encode of batch k+1 depends on its frame only: on its own stream it runs beside batch k's upserts and
         # decode (its latency-bound kernels fill the decode's tail), as in NeuralMap.fuse_and_decode_async
         import os
         self.overlap_encode = os.environ.get("BNV_FP_ENCODE_STREAM", "1") != "0"
-        self._enc = torch.cuda.Stream(device=self.dev)
+        self._enc = concurrent_stream(self.dev, main, exclude=(self._side,))
         self._enc_src = None
 
     def record_rows(self, frame):

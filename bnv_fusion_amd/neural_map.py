@@ -173,7 +173,8 @@ class NeuralMap:
             main = torch.cuda.current_stream()
             if self.overlap_encode:
                 if self._enc_stream is None:
-                    self._enc_stream = torch.cuda.Stream(device=v._dev)
+                    from .streams import concurrent_stream
+                    self._enc_stream = concurrent_stream(v._dev, main)     # one that really runs beside `main`
                 enc = self._enc_stream
                 if self.inputs_resident:
                     # only a synchronous integrate() on the caller's stream can still hold the TSDF volume

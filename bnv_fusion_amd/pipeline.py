@@ -40,8 +40,9 @@ class FramePipe:
         assert 1 <= self.n_slots <= 8
         self.max_points = int(max_points)
         self.world = int(v.shard[1])
+        from .streams import concurrent_stream
         self.main = torch.cuda.current_stream(dev)
-        self.enc = torch.cuda.Stream(device=dev)
+        self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
         res = v._n_xyz_host
         nvox = res[0] * res[1] * res[2]
         self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)

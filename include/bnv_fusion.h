@@ -137,6 +137,11 @@ int bnv_profile_read(double* total_ms_host /*[4]*/, int64_t* launches_host /*[4]
  * reports the dominant kernel.  Synchronises on `stream`; writes the
  * elapsed milliseconds and the FLOPs issued (2 x 32 x 32 x 16 per MFMA) to host memory. */
 int bnv_probe_mfma_rate(int shape, int operands, int iters, void* stream, double* ms_host, double* flop_host);
+/* Diagnostic: n_blocks single-wave workgroups that spin for `cycles` shader cycles on `stream`.  The runtime maps HIP
+ * streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two streams that share one are served
+ * strictly in submission order; one spin on each of two streams, timed with events, tells whether they overlap.  The
+ * frame pipeline picks its encode stream that way (bnv_fusion_amd/streams.py). */
+int bnv_probe_spin(int n_blocks, int64_t cycles, void* stream);
 
 /* ---- front end: depth image -> input_pts (FusionInferenceAbstractDataset.__getitem__,
  * src/datasets/fusion_inference_dataset.py:40-90; geometry.py:150-171; kornia depth_to_normals) --------
