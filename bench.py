@@ -12,19 +12,26 @@ region.
 N > 1: one rank per GPU over RCCL.  Started either by `python -m torch.distributed.run --nproc-per-node N bench.py
 --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or as plain `python bench.py --gpus N`, which
 starts the N ranks itself as a child `torch.distributed.run` BEFORE this process makes any GPU call and exits with
-the child's code.  Default decomposition: frame-parallel (ranks encode / decode different frames of a batch,
-replicated volume, one all-gather of encoded voxels per batch; one step = one batch of N consecutive frames of
-the same stream, weak scaling, `value` counts all of them); --parallelism spatial shards the active-voxel set by
-spatial hash and exchanges boundary records per frame (bnv_fusion_amd/distributed.py).
+the child's code.  Both decompositions are measured in the same run; `value` is the one --parallelism names.
+Default: 'spatial', the decomposition BASELINE.json names -- the active-voxel set sharded by spatial hash, every rank
+works on every frame, one all-gather of boundary-voxel records per frame (strong scaling of one stream; a step = one
+frame).  'frame': ranks encode / decode different frames of a batch, replicated volume, one all-gather of encoded
+voxels per batch (weak scaling; a step = one batch of N consecutive frames, `value` counts all of them)
+(bnv_fusion_amd/distributed.py).  Collectives time out (--dist-timeout) and any rank's failure
+ends the job with a non-zero exit code.
 
 The timed region runs with the cyclic garbage collector disabled and a volume that does not grow inside it
 (timing hygiene); BNV_BENCH_DEBUG=1 prints per-frame enqueue times to stderr.
-Rank 0 prints ONE JSON line: metric / value plus
+Rank 0 prints ONE JSON line: metric / value -- a SUSTAINED rate: the timed steps run right behind --preheat untimed
+frames, so the clock has settled under the package power limit -- plus
+  burst            the same steps from an idle GPU (what earlier rounds reported as `value`);
   roofline         dominant kernel of the headline arithmetic mode, timed alone (HIP events on its stream);
   fp32_exact       the same --steps in IEEE-fp32 MFMA arithmetic (the reference's precision to the letter), with its
                    own kernel-alone roofline and parity check;
   sustained        >= 1,000 frames back to back (frames/s, shader clock and package power while it ran);
   growth           frames/s from an empty volume of the reference's initial capacity (100,000 rows), growing on demand;
+  sequence         a long moving-camera sweep of a room-sized 512^3 volume (bnv_fusion_amd/sequence.py): frames/s over
+                   the whole sequence incl. table growth, rows reached, periodic oracle checks;
   parity           GPU outputs of the last timed frame against the oracle (>= 2,000 voxels);
   other_mlp_modes  the f16-operand mode (lower precision, never the headline);
   cpu_baseline     the oracle on the host cores.
@@ -39,6 +46,10 @@ import subprocess
 import sys
 import threading
 import time
+
+# streams that share a hardware queue run in submission order (bnv_fusion_amd/streams.py): more queues, set before the
+# HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -199,8 +210,9 @@ def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
         vol.decode_pts(orc.lattice_coords(sel.numpy()), sd, None, is_coords=True, query_tensor=False)
         t_dec = (time.perf_counter() - t0) * len(g) / len(sel)
     total = t_front + t_enc + t_int + t_dec
-    return {"value": 1.0 / total, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": (f"oracle (PyTorch-CPU fp32 restatement, {threads} threads; numpy float64 front end): 1 full "
+    return {"value": 1.0 / total, "unit": "frames/s", "cores": os.cpu_count(), "threads_used": threads, "kind": "port",
+            "sample": (f"oracle (PyTorch-CPU fp32 restatement, {threads} threads -- the fastest of a probe -- on a host "
+                       f"with {os.cpu_count()} cores; numpy float64 front end): 1 full "
                        f"640x480 frame depth->points {t_front:.2f}s + encode {t_enc:.2f}s + integrate {t_int:.2f}s + "
                        f"lattice decode of {len(sel)} of {len(g)} voxels scaled to the frame = {t_dec:.2f}s"),
             "front_end_s": t_front, "encode_s": t_enc, "integrate_s": t_int, "decode_s_scaled": t_dec}
@@ -221,7 +233,7 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -230,15 +242,24 @@ def main():
     ap.add_argument("--preroll", type=int, default=30,
                     help="frames fused (untimed setup) before warm-up so that voxel weights reach "
                          "min_pts_in_grid and the decode mask is live (SURVEY.md section 8d)")
+    ap.add_argument("--preheat", type=int, default=320,
+                    help="untimed frames run back to back immediately before the warm-up + timed steps, so that the "
+                         "clock has settled under the package power limit when the timed region starts (`value` is a "
+                         "sustained rate; the rate from an idle GPU is reported as `burst`); 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1, 3],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true",
-                    help="skip the fp32_exact run, the f16-operand run, the sustained pass and the growth run")
+                    help="skip the fp32_exact run, the f16-operand run, the sustained pass, the growth run, the long "
+                         "sequence and (N > 1) the second decomposition")
     ap.add_argument("--no-power-probe", action="store_true",
                     help="skip the MFMA-only rate probe (roofline.power_limited_mfma_ceiling)")
     ap.add_argument("--sustained-frames", type=int, default=1000,
                     help="frames of the sustained pass (1 GPU; 0 = skip)")
+    ap.add_argument("--sequence-frames", type=int, default=600,
+                    help="frames of the moving-camera sequence pass (1 GPU; 0 = skip): the room-sweep trajectory of "
+                         "bnv_fusion_amd.synthetic.sweep_pose over a 512^3 volume that grows from the reference's "
+                         "initial capacity while two frames are in flight")
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"],
                     help="fp32: pointnet.ckpt networks (oracle-pinned; the headline); tcnn: the reference's default "
                          "tiny-cuda-nn fp16 networks (pointnet_tcnn.ckpt)")
@@ -250,15 +271,23 @@ def main():
                          "pipelined fuse_and_decode_async")
     ap.add_argument("--no-stream-overlap", action="store_true",
                     help="1 GPU: enqueue a frame's encode on the main stream instead of a second HIP stream")
-    ap.add_argument("--parallelism", default="frame", choices=["frame", "spatial"],
-                    help="N > 1: 'frame' = ranks encode/decode different frames of a batch, replicated volume, one "
-                         "all-gather per batch (throughput scaling); 'spatial' = voxels sharded by spatial hash, "
-                         "boundary exchange per frame")
+    ap.add_argument("--parallelism", default="spatial", choices=["frame", "spatial"],
+                    help="N > 1: which decomposition `value` reports (the other one is measured in the same run and "
+                         "reported beside it).  'spatial' (default; the decomposition BASELINE.json names): the "
+                         "active-voxel set sharded by spatial hash, one RCCL all-gather of boundary-voxel records per "
+                         "frame, every frame worked on by all ranks (strong scaling of one stream); 'frame': ranks "
+                         "encode/decode different frames of a batch, replicated volume, one all-gather per batch "
+                         "(weak scaling)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="N > 1: seconds after which a collective (or the rendezvous) gives up instead of hanging")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="launcher test (no GPU needed): every rank checks RANK / WORLD_SIZE against --gpus, rank 0 "
                          "prints them, all exit before any GPU call")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def main():
+    args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -284,64 +313,45 @@ def main():
     dev = f"cuda:{local_dev}"
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # a wedged rank must fail the run, not hang it: every collective (and the rendezvous) times out
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if backend == "nccl":
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
             # RCCL's stream at high priority: the exchange kernels are short and on the path of the next batch;
             # they should take a CU as soon as one of the (CU-filling) compute kernels releases it
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group("nccl", device_id=torch.device(dev), pg_options=opts)
+            dist.init_process_group("nccl", device_id=torch.device(dev), pg_options=opts, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+    try:
+        out = run_bench(args, rank, world, dev, dist, backend)
+    except BaseException:
+        # any rank's failure ends the job with a non-zero code (torch.distributed.run then stops the other ranks,
+        # and the self-launching parent leaves with the child's code)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
-    import bnv_fusion_amd as bnv
-    from bnv_fusion_amd import synthetic, _lib
 
-    dims, voxel = synthetic.GRID_DIMS[args.grid]
-    dims3 = np.array([dims] * 3)
-    tcnn = args.checkpoint == "tcnn"
-    model = bnv.load_pretrained(device=dev, voxel_size=voxel, tiny_cuda=tcnn)
-    if tcnn:
-        args.no_alt_mode = True
-        args.mlp_mode = 2
-    frame_parallel = world > 1 and args.parallelism == "frame"
-    with_tsdf = args.input == "depth"
-    if frame_parallel:
-        from bnv_fusion_amd.distributed import FrameParallelNeuralMap
-        nm = FrameParallelNeuralMap(dims3, voxel, model, device=dev, tsdf=with_tsdf, capacity=CAPACITY)
-        nm.backend.inputs_resident = True
-    elif world > 1:
-        from bnv_fusion_amd.distributed import ShardedNeuralMap
-        nm = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY, tsdf=with_tsdf)
-    else:
-        nm = bnv.NeuralMap(dims3, voxel, model, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
-        nm.overlap_encode = not args.no_stream_overlap
-        nm.inputs_resident = True      # every frame is uploaded (and synchronised) before anything is timed
+class Driver:
+    """Runs frames through a map of one of three kinds: 'single' (NeuralMap) and 'spatial' (ShardedNeuralMap) hand
+    out one handle per frame; 'frame' (FrameParallelNeuralMap) works on batches of `world` frames."""
 
-    # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
-    # frames per step: one frame on one GPU; in frame-parallel mode a step is one batch = one frame PER RANK
-    # (weak scaling: per-GPU work per step is fixed, `value` counts the frames of all ranks)
-    fpu = world if frame_parallel else 1
-    n_frames = args.preroll + (args.warmup + args.steps) * fpu
-    POOL = 64                      # two pan periods (synthetic.yaw_deg): the sustained pass cycles over them
-    if world == 1 and not args.no_alt_mode and args.sustained_frames:
-        n_frames = max(n_frames, args.preroll + POOL)
-    depth_host = [synthetic.depth_u16(t) for t in range(n_frames)]
-    intr = synthetic.intrinsics()
-    if args.input == "depth":
-        frames = [{"depth": torch.from_numpy(d).to(dev), "intr_mat": intr, "T_wc": synthetic.pose(t)}
-                  for t, d in enumerate(depth_host)]
-    else:
-        frames = [{"input_pts": torch.from_numpy(synthetic.depth_to_input_pts(
-            d.astype(np.float64) / 1000.0, intr, synthetic.pose(t)).astype(np.float32)[None]).to(dev)}
-            for t, d in enumerate(depth_host)]
-    n_points = int((depth_host[0] > 0).sum())
-    torch.cuda.synchronize()
+    def __init__(self, args, frames, world):
+        self.args, self.frames, self.world = args, frames, world
 
-    def run_frames(idx, decode=True, collect=None, m=None):
+    def run(self, m, kind, idx, decode=True, collect=None):
         """Processes the frames with indices ``idx`` in order on map ``m``; returns this rank's last (coords, sdf)."""
-        m = m or nm
+        frames, world = self.frames, self.world
         last = (None, None)
-        if frame_parallel:
+        if kind == "frame":
             # batches of `world` consecutive frames, software-pipelined (batch k+1's encode + all-gather are
             # enqueued before batch k's integrate + decode); only the last handle is read back on the host
             batches = [[frames[t] for t in idx[b0: b0 + world]] for b0 in range(0, len(idx), world)]
@@ -353,15 +363,16 @@ def main():
                 out = handle.result()
                 if out[0] is not None:
                     last = out
-        elif not args.sync_frames:
-            # (1 GPU, and the spatially sharded mode: the same handle interface)  software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU
-            # never waits for the host (each result() waits on that frame's own event only)
+        elif not self.args.sync_frames:
+            # software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU never waits
+            # for the host (each result() waits on that frame's own event only).  Frames enqueued ahead of the oldest
+            # uncollected one -- 1 GPU: 2 (the encode of frame t + 2, second stream, is always queued before frame
+            # t + 1's upsert / neighbour / mark chain starts: +5 % against 1, 3 brings no more); sharded: 3 (the
+            # encode stream then runs a whole frame ahead of the main stream: 0.279 against 0.315 ms per frame at a
+            # simulated world of 8)
             from collections import deque
             pending = deque()
-            # frames enqueued ahead of the oldest uncollected one.  2: the encode of frame t + 2 (second stream; it
-            # depends on the frame only) is always queued before frame t + 1's upsert / neighbour / mark chain starts,
-            # so the MFMA pipes are never idle behind a host round trip: +5 % against 1 (3: no further gain)
-            depth = int(os.environ.get("BNV_BENCH_DEPTH", "2"))
+            depth = int(os.environ.get("BNV_BENCH_DEPTH", "3" if kind == "spatial" else "2"))
             _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
             for t in idx:
                 _a = time.perf_counter()
@@ -386,45 +397,96 @@ def main():
                     collect(last)
         return last
 
-    run_frames(list(range(args.preroll)), decode=False)           # setup: make the decode mask live
 
+def run_bench(args, rank, world, dev, dist, backend):
+    import bnv_fusion_amd as bnv
+    from bnv_fusion_amd import synthetic, _lib
+
+    dims, voxel = synthetic.GRID_DIMS[args.grid]
+    dims3 = np.array([dims] * 3)
+    tcnn = args.checkpoint == "tcnn"
+    model = bnv.load_pretrained(device=dev, voxel_size=voxel, tiny_cuda=tcnn)
+    if tcnn:
+        args.mlp_mode = 2
+    with_tsdf = args.input == "depth"
     lib = _lib.load()
 
-    def timed(mode, idx, warm_idx):
-        """Untimed warm-up over ``warm_idx``, then times exactly the steps ``idx`` (a multiple of `fpu` frame
-        indices), in MLP mode ``mode``."""
+    def make_map(kind):
+        if kind == "frame":
+            from bnv_fusion_amd.distributed import FrameParallelNeuralMap
+            m = FrameParallelNeuralMap(dims3, voxel, model, device=dev, tsdf=with_tsdf, capacity=CAPACITY)
+            m.backend.inputs_resident = True
+        elif kind == "spatial":
+            from bnv_fusion_amd.distributed import ShardedNeuralMap
+            m = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY, tsdf=with_tsdf)
+            m.backend.inputs_resident = True      # every frame is uploaded (and synchronised) before anything is timed
+            m.backend.copy_results = False        # results are views into the slot ring (collected before reuse)
+            m.backend.n_slots = 5
+        else:
+            m = bnv.NeuralMap(dims3, voxel, model, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
+            m.overlap_encode = not args.no_stream_overlap
+            m.inputs_resident = True
+        return m
+
+    kinds = ["single"] if world == 1 else ([args.parallelism] + ([] if args.no_alt_mode else
+                                           [k for k in ("spatial", "frame") if k != args.parallelism]))
+
+    # ---- synthetic inputs, resident in HBM before anything is timed -----------------------------
+    # frames per step: one frame on one GPU and in the sharded mode (every rank works on every frame); in
+    # frame-parallel mode a step is one batch = one frame PER RANK (weak scaling, `value` counts all of them)
+    POOL = 64                      # two pan periods (synthetic.yaw_deg): long passes cycle over them
+    fpu_max = world if "frame" in kinds else 1
+    n_frames = args.preroll + max((args.warmup + args.steps) * fpu_max, POOL)
+    depth_host = [synthetic.depth_u16(t) for t in range(n_frames)]
+    intr = synthetic.intrinsics()
+    if args.input == "depth":
+        frames = [{"depth": torch.from_numpy(d).to(dev), "intr_mat": intr, "T_wc": synthetic.pose(t)}
+                  for t, d in enumerate(depth_host)]
+    else:
+        frames = [{"input_pts": torch.from_numpy(synthetic.depth_to_input_pts(
+            d.astype(np.float64) / 1000.0, intr, synthetic.pose(t)).astype(np.float32)[None]).to(dev)}
+            for t, d in enumerate(depth_host)]
+    n_points = int((depth_host[0] > 0).sum())
+    torch.cuda.synchronize()
+    drv = Driver(args, frames, world)
+    pool = list(range(args.preroll, args.preroll + POOL))      # 2 pan periods: cycling continues the pan
+
+    def timed(m, kind, mode, idx, warm_idx, preheat=0):
+        """[`preheat` untimed frames of the pool, back to back,] untimed warm-up over ``warm_idx``, then times exactly
+        the steps ``idx`` (a multiple of the frames per step), in MLP mode ``mode``.  Nothing happens on the host
+        between the pre-heat and the timed steps but a stream synchronisation."""
+        fpu = world if kind == "frame" else 1
         if mode != 2:
             bnv.set_mlp_mode(mode)
-        run_frames(warm_idx)
-        lib.bnv_profile_enable(1)
-        table_rows, n_vox = [], []
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
         # the cyclic garbage collector stays out of the timed region (as timeit does): with torch imported a full
         # collection takes ~40 ms, and one landed on the third timed frame of every process but the first on a box
         # (350 instead of 540 frames/s over 40 frames; found with per-frame enqueue times, BNV_BENCH_DEBUG=1)
         gc.collect()
         gc.disable()
+        if preheat:
+            pre = [pool[i % POOL] for i in range(-(-preheat // fpu) * fpu)]
+            drv.run(m, kind, pre)
+        drv.run(m, kind, warm_idx)
+        lib.bnv_profile_enable(1)
+        n_vox = []
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
 
         def collect(res):
             c, _ = res
             n_vox.append(0 if c is None else int(c.shape[0]))
 
-        if frame_parallel:
-            coords, sdf = run_frames(idx)
-            table_rows.append(nm.volume.last_lattice_evals().clone() if coords is not None
-                              else torch.zeros(1, dtype=torch.int32, device=dev))
-            n_vox.append(0 if coords is None else int(coords.shape[0]))
-        else:
-            coords, sdf = run_frames(idx, collect=collect)
-            table_rows.append(nm.volume.last_lattice_evals().clone())
+        coords, sdf = drv.run(m, kind, idx, collect=None if kind == "frame" else collect)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         gc.enable()
+        if kind == "frame":
+            n_vox.append(0 if coords is None else int(coords.shape[0]))
+        evals = float(m.volume.last_lattice_evals().item()) if coords is not None else 0.0
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -433,28 +495,25 @@ def main():
         prof_n = (C.c_int64 * 4)()
         lib.bnv_profile_read(prof_ms, prof_n)
         lib.bnv_profile_enable(0)
-        rows = torch.stack(table_rows).cpu().numpy().reshape(-1)
         live = float((sdf != voxel).float().mean()) if sdf is not None and sdf.numel() else 0.0
         dec_ms = prof_ms[1] / max(prof_n[1], 1)
         enc_ms = prof_ms[0] / max(prof_n[0], 1)
-        dec_flop = float(rows.mean()) * (FLOP_PER_EVAL_TCNN if mode == 2 else FLOP_PER_EVAL)
-        enc_flop = 8.0 * n_points * (FLOP_PER_PAIR_TCNN if mode == 2 else FLOP_PER_PAIR)
+        dec_flop = evals * (FLOP_PER_EVAL_TCNN if mode == 2 else FLOP_PER_EVAL)
+        share = world if kind == "spatial" else 1          # a rank encodes 1 / world of the pairs when sharded
+        enc_flop = 8.0 * n_points * (FLOP_PER_PAIR_TCNN if mode == 2 else FLOP_PER_PAIR) / share
         steps = len(idx) // fpu
-        return {"elapsed": elapsed, "steps": steps, "fps": len(idx) / elapsed, "rows": float(rows.mean()),
-                "n_vox": float(np.mean(n_vox)), "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
+        return {"elapsed": elapsed, "steps": steps, "fps": len(idx) / elapsed, "rows": evals,
+                "n_vox": float(np.mean(n_vox)) if n_vox else 0.0, "live": live, "dec_ms": dec_ms, "enc_ms": enc_ms,
                 "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
                 "enc_tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0, "dec_flop": dec_flop,
-                "coords": coords, "sdf": sdf,
-                "frames_this_rank": len(idx) // world if frame_parallel else len(idx)}
-
-    first = args.preroll + args.warmup * fpu
-    warm_idx = list(range(args.preroll, first))
-    step_idx = list(range(first, first + args.steps * fpu))
+                "coords": coords, "sdf": sdf, "kind": kind, "fpu": fpu,
+                "frames_this_rank": len(idx) // world if kind == "frame" else len(idx)}
 
     # parity check of a configuration against the oracle (PARITY_VOXELS voxels of its last frame): the SDF lattice
-    # decoded by the GPU from the GPU's own volume vs the oracle's decode of the same volume values
-    def parity_check(run):
-        if not ((world == 1 or frame_parallel) and rank == 0 and run["coords"] is not None):
+    # decoded by the GPU from the GPU's own volume vs the oracle's decode of the same volume values.  Sharded: rank 0
+    # checks voxels IT owns -- their neighbourhoods are its own rows + the ghost rows the exchange installed
+    def parity_check(m, run):
+        if not (rank == 0 and run["coords"] is not None):
             return None
         from oracle import bnv_oracle as orc           # checker only
         sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
@@ -467,7 +526,7 @@ def main():
         pick = g[sel].cpu()
         off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
         nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
-        fo, wo, _ = nm.volume.query(nbr.to(dev))
+        fo, wo, _ = m.volume.query(nbr.to(dev))
         ovol = orc.OracleSparseVolume(8, voxel, dims3, 8)
         present = wo[:, 0].cpu() > 0
         ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
@@ -475,33 +534,19 @@ def main():
         with torch.no_grad():
             ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
                                   geo=geo)[0, :, :, 0]
-        if world == 1:
+        if run["kind"] != "frame":
             got = run["sdf"][sel].cpu()     # the very output of the last timed frame (no extra launch)
         else:                               # replicated volume has moved on: decode again from the current state
-            got = nm.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
+            got = m.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
         return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
                 "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
                 "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)),
                 "live_fraction_checked": float((ref != voxel).float().mean()),
                 "voxels_checked": int(len(pick)), "sdf_values_checked": int(ref.numel())}
 
-    def measure(mode):
-        """Timed region + parity + kernel-alone pass in MLP mode ``mode`` -> (timed run, kernel-alone run, note)."""
-        run = timed(mode, step_idx, warm_idx)
-        run["parity"] = parity_check(run)  # right after the timed region: the volume is in that run's final state
-        # Kernel-alone pass for the roofline: with the encode on a second stream the two MLP kernels of consecutive
-        # frames share the GPU, so their event-to-event durations overlap.  A roofline needs the kernel's own
-        # duration: the same frames are run again with everything on one stream (and that is how the committed
-        # rocprofv3 summaries are taken: --no-stream-overlap).
-        kern, note = run, "timed region"
-        if world == 1 and getattr(nm, "overlap_encode", False):
-            nm.overlap_encode = False
-            kern = timed(mode, step_idx, warm_idx)
-            nm.overlap_encode = True
-            note = (f"the same {kern['steps']} frames (+{args.warmup} warm-up) re-run from an idle GPU with the encode "
-                    "on the main stream, so that each kernel has the GPU to itself (in the timed region the two MLP "
-                    f"kernels of consecutive frames overlap); that pass ran at {kern['fps']:.1f} frames/s")
-        return run, kern, note
+    def idx_of(fpu):
+        first = args.preroll + args.warmup * fpu
+        return list(range(args.preroll, first)), list(range(first, first + args.steps * fpu))
 
     def roofline_of(mode, kern, note):
         peak = PEAK_TFLOPS[mode]
@@ -511,15 +556,129 @@ def main():
         # achieved = algorithmic FLOPs (402,432 per MLP evaluation x evaluations per launch; the split mode issues 3
         # MFMA products per algorithmic product, which are NOT counted) / mean kernel time from HIP events recorded
         # on the launch stream
-        return {"bound": "mfma", "kernel": DECODE_KERNEL[mode] + " (SDF MLP 17-256x4-1)",
+        return {"bound": "mfma", "kernel": DECODE_KERNEL[mode] + (" (SDF MLP 32-64x3-16, tiny-cuda-nn layout)" if mode == 2
+                                                                  else " (SDF MLP 17-256x4-1)"),
                 "achieved": kern["dec_tflops"], "peak": peak, "unit": "TFLOP/s", "frac": kern["dec_tflops"] / peak,
                 "traffic": traffic, "traffic_source": src,
                 "avg_kernel_ms": kern["dec_ms"], "flop_per_launch": kern["dec_flop"],
                 "mlp_evals_per_launch": kern["rows"],
                 "mfma_issue_frac": kern["dec_tflops"] * MFMA_PER_PRODUCT[mode] / peak, "timing": note}
 
-    main_run, kern_run, kern_note = measure(args.mlp_mode)
-    elapsed = main_run["elapsed"]
+    def entry(run, parity=None):
+        return {"value": run["fps"], "unit": "frames/s", "steps": run["steps"],
+                "ms_per_step": 1e3 * run["elapsed"] / run["steps"], **({"parity": parity} if parity else {})}
+
+    out_common = {"metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid", "unit": "frames/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                  "vs_baseline": None, "dtype": DTYPE[args.mlp_mode], "data": "synthetic"}
+    workload = (f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, voxel {voxel}, "
+                f"{'pointnet_tcnn.ckpt (fp16 tcnn)' if tcnn else 'fp32 pointnet.ckpt'} weights; step = "
+                + ("uint16 depth image -> points + normals (GPU front end) + " if args.input == "depth" else "")
+                + "encode_pointcloud + _integrate + "
+                + ("TSDF side fusion at 0.025 m + " if args.input == "depth" else "")
+                + "decode of the 3x3x3 lattice of every touched voxel")
+
+    # =========================================================================================================
+    # N > 1: both decompositions, the one --parallelism names in `value`
+    # =========================================================================================================
+    if world > 1:
+        results = {}
+        for kind in kinds:
+            m = make_map(kind)
+            fpu = world if kind == "frame" else 1
+            drv.run(m, kind, list(range(-(-args.preroll // fpu) * fpu)), decode=False)     # setup: live decode mask
+            warm_idx, step_idx = idx_of(fpu)
+            run = timed(m, kind, args.mlp_mode, step_idx, warm_idx, preheat=min(args.preheat, 4 * POOL))
+            run["parity"] = parity_check(m, run)
+            extra = {}
+            if kind == "spatial":
+                extra = {"received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
+                         "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
+                             bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}
+            results[kind] = (run, extra)
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, {"frames": int(run["frames_this_rank"]), "voxels_per_frame": run["n_vox"],
+                                              "mlp_evals_last_frame": run["rows"]})
+            results[kind][1]["per_rank"] = per_rank
+            del m
+            model.shard = (0, 1, 3)
+            torch.cuda.empty_cache()
+        names = [None] * world
+        dist.all_gather_object(names, {"rank": rank, "device": torch.cuda.get_device_name(dev), "local_device": dev,
+                                       "host": socket.gethostname()})
+        if rank != 0:
+            return None
+        DESCR = {"spatial": (f"active-voxel set sharded by spatial hash (8^3-voxel blocks) over {world} ranks; every "
+                             "rank voxelises the whole frame, encodes / upserts / decodes the voxels it owns; per frame "
+                             "ONE RCCL all-gather of boundary-voxel records (48 B: key, weight, 8 features) and one host "
+                             "wait (the exchange bound, read while the previous frame decodes); a step = one frame "
+                             "worked on by all ranks", "strong"),
+                 "frame": (f"frame-parallel x{world}: a step = one batch of {world} consecutive frames; ranks encode / "
+                           "decode different frames of the batch, replicated volume, one RCCL all-gather of encoded "
+                           "voxels per batch", "weak")}
+
+        def dist_entry(kind):
+            run, extra = results[kind]
+            return {**entry(run, run["parity"]), "scaling": DESCR[kind][1], "decomposition": DESCR[kind][0],
+                    "frames_per_step": run["fpu"], "voxels_per_frame_rank0": run["n_vox"],
+                    "decode_live_fraction_rank0": run["live"], "decode_kernel_ms_rank0": run["dec_ms"],
+                    "pointnet_kernel_ms_rank0": run["enc_ms"], **extra}
+
+        prim, _ = results[kinds[0]]
+        m_ = args.mlp_mode
+        out = dict(out_common)
+        out.update({
+            "value": prim["fps"], "ms_per_step": 1e3 * prim["elapsed"] / prim["steps"], "scaling": DESCR[kinds[0]][1],
+            "config": {"workload": workload, "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
+                       "preheat_frames": min(args.preheat, 4 * POOL), "frames_per_step": prim["fpu"],
+                       "mlp_mode": MODE_NAME[m_], "parallelism": DESCR[kinds[0]][0]},
+            "roofline": roofline_of(m_, prim, "rank 0's launches inside the timed region (the two streams of the frame "
+                                              "pipeline overlap: durations include time shared with the other "
+                                              "stream's kernels)"),
+            "kernels": {"pointnet_scatter": {"avg_ms": prim["enc_ms"], "tflops": prim["enc_tflops"],
+                                             "frac_of_peak": prim["enc_tflops"] / PEAK_TFLOPS[m_]}},
+            "parity": prim["parity"],
+            "distributed": {"backend": "rccl" if backend == "nccl" else backend,
+                            "world_size_seen_by_backend": dist.get_world_size(), "ranks": names,
+                            "collective_timeout_s": args.dist_timeout,
+                            "launcher": ("bench.py started torch.distributed.run itself"
+                                         if os.environ.get("BNV_BENCH_SELF_LAUNCHED") == "1"
+                                         else "external torch.distributed.run")},
+            "spatial_sharding" if kinds[0] == "spatial" else "frame_parallel": dist_entry(kinds[0]),
+        })
+        for kind in kinds[1:]:
+            out["spatial_sharding" if kind == "spatial" else "frame_parallel"] = dist_entry(kind)
+        return out
+
+    # =========================================================================================================
+    # one GPU
+    # =========================================================================================================
+    nm = make_map("single")
+    drv.run(nm, "single", list(range(args.preroll)), decode=False)           # setup: make the decode mask live
+    warm_idx, step_idx = idx_of(1)
+
+    def measure(mode):
+        """-> (sustained run: pre-heated timed region [+ parity], burst run: the same steps from an idle GPU,
+        kernel-alone run, note)."""
+        burst = timed(nm, "single", mode, step_idx, warm_idx)
+        run = timed(nm, "single", mode, step_idx, warm_idx, preheat=args.preheat)
+        run["parity"] = parity_check(nm, run)  # right after the timed region: the volume is in that run's final state
+        # Kernel-alone pass for the roofline: with the encode on a second stream the two MLP kernels of consecutive
+        # frames share the GPU, so their event-to-event durations overlap.  A roofline needs the kernel's own
+        # duration: the same frames are run again with everything on one stream (and that is how the committed
+        # rocprofv3 summaries are taken: --no-stream-overlap), pre-heated like the timed region.
+        kern, note = run, "timed region"
+        if getattr(nm, "overlap_encode", False):
+            nm.overlap_encode = False
+            kern = timed(nm, "single", mode, step_idx, warm_idx, preheat=args.preheat)
+            nm.overlap_encode = True
+            note = (f"the same {kern['steps']} frames (+{args.warmup} warm-up, behind {args.preheat} pre-heat frames) "
+                    "re-run with the encode on the main stream, so that each kernel has the GPU to itself (in the timed "
+                    f"region the two MLP kernels of consecutive frames overlap); that pass ran at {kern['fps']:.1f} "
+                    "frames/s")
+        return run, burst, kern, note
+
+    main_run, burst_run, kern_run, kern_note = measure(args.mlp_mode)
 
     def sustainable_mfma():
         """What the f16 MFMA pipe of THIS box sustains when nothing else is issued (bnv_probe_mfma_rate: every CU, two
@@ -527,7 +686,7 @@ def main():
         the 2.4 GHz the 2.5 PFLOP/s peak is quoted at -- by how much depends on the MFMA shape (the 16x16x32 form the
         dominant kernel uses moves half the accumulator data per FLOP) and on the operand data (zeros toggle nothing).
         Measured right behind the timed frames, GPU warm."""
-        out = {}
+        res = {}
         for name, shape, operands, iters in (("16x16x32_random_f16_operands", 1, 1, 16000),
                                              ("32x32x16_random_f16_operands", 0, 1, 16000),
                                              ("16x16x32_zero_operands", 1, 0, 8000)):
@@ -535,11 +694,11 @@ def main():
             _lib.check(lib.bnv_probe_mfma_rate(shape, operands, iters,
                                                C.c_void_p(torch.cuda.current_stream().cuda_stream),
                                                C.byref(ms), C.byref(flop)), "bnv_probe_mfma_rate")
-            out[name] = flop.value / (ms.value * 1e-3) / 1e12
-        return out
+            res[name] = flop.value / (ms.value * 1e-3) / 1e12
+        return res
 
     power_ceiling = None
-    if world == 1 and not tcnn and args.mlp_mode in (1, 3) and not args.no_power_probe:
+    if not tcnn and args.mlp_mode in (1, 3) and not args.no_power_probe:
         pc = sustainable_mfma()
         issued = kern_run["dec_tflops"] * MFMA_PER_PRODUCT[args.mlp_mode]
         power_ceiling = {
@@ -554,44 +713,45 @@ def main():
 
     extras = {}
     alts = []
-    if not args.no_alt_mode and world == 1 and not tcnn:
+    if not args.no_alt_mode and not tcnn:
         # ---- the reference's precision to the letter: IEEE fp32 MFMA, the full --steps, its own roofline -------
         if args.mlp_mode != 0:
-            r0, k0, n0 = measure(0)
+            r0, b0, k0, n0 = measure(0)
             extras["fp32_exact"] = {
-                "dtype": DTYPE[0], "value": r0["fps"], "unit": "frames/s", "steps": r0["steps"],
-                "ms_per_step": 1e3 * r0["elapsed"] / r0["steps"], "roofline": roofline_of(0, k0, n0),
+                "dtype": DTYPE[0], **entry(r0, r0["parity"]), "burst": entry(b0), "roofline": roofline_of(0, k0, n0),
                 "kernels": {"pointnet_scatter": {"avg_ms": k0["enc_ms"], "tflops": k0["enc_tflops"],
-                                                 "frac_of_peak": k0["enc_tflops"] / PEAK_TFLOPS[0]}},
-                "parity": r0["parity"]}
+                                                 "frac_of_peak": k0["enc_tflops"] / PEAK_TFLOPS[0]}}}
         # ---- lower precision, reported for completeness (never the headline) ------------------------------------
         for am in (1, 3):
             if am == args.mlp_mode:
                 continue
-            r = timed(am, step_idx[: 8], warm_idx[-3:])
-            r["mode"], r["parity"] = am, parity_check(r)
+            r = timed(nm, "single", am, step_idx[: 8], warm_idx[-3:])
+            r["mode"], r["parity"] = am, parity_check(nm, r)
             alts.append(r)
         bnv.set_mlp_mode(args.mlp_mode)
 
-        # ---- sustained pass: >= 1,000 frames back to back in the headline mode -----------------------------------
+    if not args.no_alt_mode:
+        # ---- sustained pass: >= 1,000 frames back to back in the headline mode, clock + power sampled ------------
         if args.sustained_frames:
-            pool = list(range(args.preroll, args.preroll + POOL))      # 2 pan periods: cycling continues the pan
             idx = [pool[i % POOL] for i in range(args.sustained_frames)]
-            run_frames(pool[:8])
+            drv.run(nm, "single", pool[:8])
             torch.cuda.synchronize()
             gc.collect()
             gc.disable()
             with SmiSampler() as smi:
                 t0 = time.perf_counter()
-                run_frames(idx)
+                drv.run(nm, "single", idx)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
             gc.enable()
+            summ = smi.summary(t0, t1)
             extras["sustained"] = {"frames": len(idx), "value": len(idx) / (t1 - t0), "unit": "frames/s",
                                    "ms_per_frame": 1e3 * (t1 - t0) / len(idx), "mlp_mode": MODE_NAME[args.mlp_mode],
                                    "frames_note": f"the {POOL} frames after the pre-roll (two periods of the +-4 degree "
                                                   "pan), cycled; the volume keeps accumulating",
-                                   **smi.summary(t0, t1)}
+                                   **summ,
+                                   "joules_per_frame": (summ["mean_package_power_w"] * (t1 - t0) / len(idx)
+                                                        if summ.get("mean_package_power_w") else None)}
 
         # ---- growth: from an EMPTY volume of the reference's initial capacity (sparse_volume.py:486: 100,000) ---
         nm2 = bnv.NeuralMap(dims3, voxel, model, capacity=100000, device=dev, tsdf=with_tsdf)
@@ -600,7 +760,7 @@ def main():
         n_g = min(60, n_frames)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_frames(list(range(n_g)), m=nm2)
+        drv.run(nm2, "single", list(range(n_g)))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         extras["growth"] = {"frames": n_g, "value": n_g / (t1 - t0), "unit": "frames/s",
@@ -611,86 +771,42 @@ def main():
                                     "min_pts), so this prices the growth steps, not the steady state"}
         del nm2
 
-    if world > 1 and frame_parallel and not args.no_alt_mode:
-        # ---- the north-star decomposition next to the throughput mode: the active-voxel set sharded by spatial hash,
-        # one all-gather of boundary-voxel records per frame (every frame is worked on by ALL ranks: strong scaling of
-        # one frame; `value` above stays the frame-parallel figure) --------------------------------------------------
-        from bnv_fusion_amd.distributed import ShardedNeuralMap
-        nm_fp = nm
-        nm = ShardedNeuralMap(dims3, voxel, model, device=dev, capacity=CAPACITY, tsdf=with_tsdf)
-        frame_parallel = False
-        run_frames(list(range(args.preroll)), decode=False)
-        sp_idx = list(range(args.preroll + args.warmup, args.preroll + args.warmup + args.steps))
-        sp = timed(args.mlp_mode, sp_idx, list(range(args.preroll, args.preroll + args.warmup)))
-        extras["spatial_sharding"] = {
-            "value": len(sp_idx) / sp["elapsed"], "unit": "frames/s", "steps": len(sp_idx),
-            "ms_per_frame": 1e3 * sp["elapsed"] / len(sp_idx), "scaling": "strong",
-            "decomposition": f"active-voxel set sharded by spatial hash (8^3-voxel blocks) over {world} ranks; per frame "
-                             "ONE RCCL all-gather of boundary-voxel records (48 B: key, weight, 8 features), one host "
-                             "wait (the exchange bound, read while the encoder runs)",
-            "received_bytes_per_frame_and_rank": nm.exchanged_bytes / max(nm.host_waits, 1),
-            "host_waits_per_frame": 1, "voxels_per_frame_rank0": sp["n_vox"],
-            "mlp_evals_per_frame_rank0": sp["rows"], "decode_kernel_ms_rank0": sp["dec_ms"],
-            "pointnet_kernel_ms_rank0": sp["enc_ms"]}
-        nm, frame_parallel = nm_fp, True
-        model.shard = (0, 1, 3)
-    if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, int(main_run["frames_this_rank"]))
-    if rank == 0:
-        fps = args.steps * fpu / elapsed
-        m = args.mlp_mode
-        peak = PEAK_TFLOPS[m]
-        out = {
-            "metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid",
-            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak" if (frame_parallel or world == 1) else "strong",
-            "vs_baseline": None, "dtype": DTYPE[m], "data": "synthetic",
-            "config": {"workload": f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, "
-                                   f"voxel {voxel}, {'pointnet_tcnn.ckpt (fp16 tcnn)' if tcnn else 'fp32 pointnet.ckpt'} weights; step = "
-                                   + ("uint16 depth image -> points + normals (GPU front end) + "
-                                      if args.input == "depth" else "")
-                                   + "encode_pointcloud + _integrate + "
-                                   + ("TSDF side fusion at 0.025 m + " if args.input == "depth" else "")
-                                   + "decode of the 3x3x3 lattice of every "
-                                     "touched voxel",
-                       "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
-                       "frames_per_step": fpu,
-                       "mlp_mode": MODE_NAME[m],
-                       "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
-                       "decode_live_fraction": main_run["live"],
-                       "parallelism": ("1 GPU" if world == 1 else
-                                       f"frame-parallel x{world}: one step = one batch of {world} consecutive frames, ranks encode/decode "
-                                       "different frames of the batch, "
-                                       "replicated volume, one RCCL all-gather of encoded voxels per batch"
-                                       if frame_parallel else
-                                       f"spatial-hash voxel sharding x{world} + one RCCL all-gather of boundary records per frame")},
-            "roofline": dict(roofline_of(m, kern_run, kern_note),
-                             **({"power_limited_mfma_ceiling": power_ceiling} if power_ceiling else {})),
-            "kernels": {"pointnet_scatter": {"avg_ms": kern_run["enc_ms"], "tflops": kern_run["enc_tflops"],
-                                             "frac_of_peak": kern_run["enc_tflops"] / peak}},
-            "parity": main_run["parity"],
-        }
-        if world > 1:
-            out["distributed"] = {"backend": "rccl" if backend == "nccl" else backend, "world_size": world,
-                                  "frames_per_rank": per_rank,
-                                  "launcher": ("bench.py started torch.distributed.run itself"
-                                               if os.environ.get("BNV_BENCH_SELF_LAUNCHED") == "1"
-                                               else "external torch.distributed.run")}
-        out.update(extras)
-        out["other_mlp_modes"] = [
-            {"mlp_mode": MODE_NAME[a["mode"]], "dtype": DTYPE[a["mode"]], "value": a["fps"], "unit": "frames/s",
-             "steps": a["steps"], "ms_per_step": 1e3 * a["elapsed"] / a["steps"], "decode_kernel_ms": a["dec_ms"],
-             "decode_tflops": a["dec_tflops"], "decode_frac_of_peak": a["dec_tflops"] / PEAK_TFLOPS[a["mode"]],
-             "pointnet_kernel_ms": a["enc_ms"], "pointnet_tflops": a["enc_tflops"], "parity": a["parity"]}
-            for a in alts]
-        if not args.no_cpu_baseline and world == 1 and not tcnn:
-            out["cpu_baseline"] = cpu_baseline(depth_host[0], intr, synthetic.pose(0), args.grid)
-            out["speedup_vs_cpu_baseline"] = fps / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        # ---- a long moving-camera sequence: the surrogate of BASELINE configs 0 / 2 / 4 (datasets absent) ----------
+        if args.sequence_frames and args.input == "depth":
+            from bnv_fusion_amd import sequence
+            extras["sequence"] = sequence.bench_pass(model, dev, args.sequence_frames, tcnn=tcnn)
+
+    m = args.mlp_mode
+    peak = PEAK_TFLOPS[m]
+    roof = dict(roofline_of(m, kern_run, kern_note), **({"power_limited_mfma_ceiling": power_ceiling} if power_ceiling else {}))
+    out = dict(out_common)
+    out.update({
+        "value": main_run["fps"], "ms_per_step": 1e3 * main_run["elapsed"] / args.steps, "scaling": "weak",
+        "value_note": f"the {args.steps} timed steps run right behind {args.preheat} untimed pre-heat frames + "
+                      f"{args.warmup} warm-up steps (clock settled under the package power limit); `burst` is the same "
+                      "steps from an idle GPU",
+        "burst": entry(burst_run),
+        "config": {"workload": workload, "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
+                   "preheat_frames": args.preheat, "frames_per_step": 1, "mlp_mode": MODE_NAME[m],
+                   "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
+                   "decode_live_fraction": main_run["live"], "parallelism": "1 GPU"},
+        "roofline": roof,
+        "traffic_source": (roof["traffic_source"] or {}).get("file") if roof.get("traffic") else None,
+        "kernels": {"pointnet_scatter": {"avg_ms": kern_run["enc_ms"], "tflops": kern_run["enc_tflops"],
+                                         "frac_of_peak": kern_run["enc_tflops"] / peak}},
+        "parity": main_run["parity"],
+    })
+    out.update(extras)
+    out["other_mlp_modes"] = [
+        {"mlp_mode": MODE_NAME[a["mode"]], "dtype": DTYPE[a["mode"]], "value": a["fps"], "unit": "frames/s",
+         "steps": a["steps"], "ms_per_step": 1e3 * a["elapsed"] / a["steps"], "decode_kernel_ms": a["dec_ms"],
+         "decode_tflops": a["dec_tflops"], "decode_frac_of_peak": a["dec_tflops"] / PEAK_TFLOPS[a["mode"]],
+         "pointnet_kernel_ms": a["enc_ms"], "pointnet_tflops": a["enc_tflops"], "parity": a["parity"]}
+        for a in alts]
+    if not args.no_cpu_baseline and not tcnn:
+        out["cpu_baseline"] = cpu_baseline(depth_host[0], intr, synthetic.pose(0), args.grid)
+        out["speedup_vs_cpu_baseline"] = main_run["fps"] / out["cpu_baseline"]["value"]
+    return out
 
 
 if __name__ == "__main__":

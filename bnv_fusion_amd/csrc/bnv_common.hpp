@@ -55,6 +55,27 @@ __device__ __forceinline__ void split8_f16(const float (&x)[8], bnv_half8& hi, b
   lo = __builtin_bit_cast(bnv_half8, l);
 }
 
+// Cooperative global -> LDS copy of `bytes` (a multiple of 16; src and dst 16-byte aligned) by the NT threads of a
+// workgroup through the LDS-DMA path (global_load_lds_dwordx4: no VGPR round trip, every piece in flight at once).
+// The persistent MLP kernels stage 20-150 KB of weights per workgroup before their first tile; written as a
+// load / ds_write loop the compiler kept ONE 16-byte load in flight per thread (load, s_waitcnt vmcnt(0), ds_write,
+// branch): 19 dependent memory round trips = ~15 us of every launch of the point encoder.  A wave's piece is 1 KB:
+// wave-uniform LDS base + lane * 16.  Ends with vmcnt(0); the caller's __syncthreads() publishes the data.
+template <int NT>
+__device__ __forceinline__ void stage_to_lds(const void* __restrict__ src, void* __restrict__ lds_dst, int bytes) {
+  typedef __attribute__((address_space(1))) const void gptr_t;
+  typedef __attribute__((address_space(3))) void lptr_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const char* s = (const char*)src;
+  char* d = (char*)lds_dst;
+  for (int base = wave * 1024; base < bytes; base += NT * 16) {   // (wave-uniform loop)
+    if (base + lane * 16 < bytes)
+      __builtin_amdgcn_global_load_lds((gptr_t*)(s + base + lane * 16), (lptr_t*)(d + base), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 struct ProfScope {
   int kind;
   hipStream_t stream;

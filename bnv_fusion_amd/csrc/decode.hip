@@ -1617,12 +1617,18 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
 
   // ---- tiles are handed out DYNAMICALLY (one atomic per tile on a counter in the workspace, fetched one tile
   // ahead): when another stream's kernel still holds some CUs at launch (the next frame's encoder, an RCCL
-  // collective), the workgroups that start late simply take fewer tiles instead of stretching the kernel's tail
+  // collective), the workgroups that start late simply take fewer tiles instead of stretching the kernel's tail.
+  // The first two tiles of a workgroup are static (b, b + grid): 2 x 256 atomics on ONE address at the start of every
+  // launch serialised in the memory-side atomic unit for ~6 us before the first MFMA; dynamic ids start at 2 x grid.
+  // Every loop iteration takes exactly one id and every tile is one iteration, so the counter ends at n_tiles: the
+  // thread that draws n_tiles - 1 has drawn the launch's last id and puts the counter back to 0 for the next launch
+  // (no exit count, no fence).
   __shared__ int s_tile[3];
   int* tile_ctr = (int*)A.n_list + 2;
+  const int64_t dyn0 = 2 * (int64_t)gridDim.x;
   if (threadIdx.x == 0) {
-    s_tile[0] = atomicAdd(tile_ctr, 1);
-    s_tile[1] = atomicAdd(tile_ctr, 1);
+    s_tile[0] = (int)blockIdx.x;
+    s_tile[1] = (int)(blockIdx.x + gridDim.x);
   }
   if (so == 3) {   // octet 3 of PARK: inputs 24..31, always zero
     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1678,7 +1684,11 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
     // requests for the following tiles: the id of the tile after next (thread 0 asks now and publishes it behind
     // layer 0, so that the round trip of the atomic is off its wave's critical path), features of the next tile
     int next_id = 0;
-    if (threadIdx.x == 0) next_id = atomicAdd(tile_ctr, 1);
+    if (threadIdx.x == 0) {
+      const int drawn = atomicAdd(tile_ctr, 1);
+      if ((int64_t)drawn == n_tiles - 1) *tile_ctr = 0;   // the last draw of this launch
+      next_id = (int)(dyn0 + drawn);
+    }
     int ent_nx2 = -1;
     f0 = f32x4{0.f, 0.f, 0.f, 0.f};
     f1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1752,16 +1762,6 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
     atomicAdd(&g_phase_cycles[threadIdx.x], ((unsigned long long*)(lds + T_TOTAL))[threadIdx.x]);
   if (threadIdx.x == 0) atomicAdd(&g_phase_cycles[31], 1ull);
 #endif
-  // the last workgroup to leave resets the hand-out counter (word 2) and the exit count (word 3), so the kernel
-  // can be launched again without any host-side reset
-  if (threadIdx.x == 0) {
-    int* done = (int*)A.n_list + 3;
-    __threadfence();
-    if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
-      *tile_ctr = 0;
-      *done = 0;
-    }
-  }
 }
 
 // ---- lattice decode: neighbour lookup + blend ------------------------------------------------

@@ -579,8 +579,7 @@ __global__ __launch_bounds__(512, 2) void k_pointnet_scatter(
     const int32_t* __restrict__ n_pairs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // stage all packed weights into LDS once per workgroup (persistent grid)
-  for (int i = threadIdx.x * 4; i < PN_TOTAL; i += 512 * 4)
-    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[i];
+  stage_to_lds<512>(wpack, lds, PN_TOTAL * 4);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -875,9 +874,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(120))) void 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const float n_cert = wpack[PN_CERT];
   float* lb = lds + PX_TOTAL / 2;                      // b1 b2 b3 b4
-  for (int i = threadIdx.x * 4; i < PX_TOTAL / 2; i += 512 * 4)
-    *(f32x4*)&lds[i] = *(const f32x4*)&wpack[PX_OFF + i];
   for (int i = threadIdx.x; i < 128 * 3 + 8; i += 512) lb[i] = wpack[PN_B1 + i];
+  stage_to_lds<512>(wpack + PX_OFF, lds, PX_TOTAL * 2);
   int* tile_ctr = (int*)((char*)lds + PX_TOTAL * 2 + (128 * 3 + 8) * 4);
   if (threadIdx.x == 0) *tile_ctr = 0;
   __syncthreads();
@@ -1107,8 +1105,7 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
     int32_t* __restrict__ counts, long long* __restrict__ acc, const int32_t* __restrict__ pair_list,
     const int32_t* __restrict__ n_pairs) {
   __shared__ __attribute__((aligned(16))) _Float16 wh[PT_TOTAL];
-  for (int i = threadIdx.x * 4; i < PT_TOTAL / 2; i += 256 * 4)
-    *(f32x4*)&((float*)wh)[i] = *(const f32x4*)&wpack[i];
+  stage_to_lds<256>(wpack, wh, PT_TOTAL * 2);
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
