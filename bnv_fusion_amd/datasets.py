@@ -63,11 +63,15 @@ def read_png16(path):
     return out.reshape(h, w).astype(np.uint16)
 
 
-def write_png16(path, image, filter_type=0):
+def write_png16(path, image, filter_type=0, level=6):
     """numpy [H, W] uint16 -> 16-bit greyscale PNG.  ``filter_type`` 0..4 selects the scanline filter of every
-    row (the tests write all five)."""
+    row (the tests write all five); ``level``: zlib compression level."""
     img = np.ascontiguousarray(np.asarray(image, dtype=np.uint16))
     h, w = img.shape
+    if filter_type == 0:      # (fast path: no predictor arithmetic)
+        raw = np.concatenate([np.zeros((h, 1), np.uint8), img.astype(">u2").view(np.uint8).reshape(h, 2 * w)],
+                             axis=1).tobytes()
+        return _write_png(path, w, h, raw, level)
     rows = img.astype(">u2").view(np.uint8).reshape(h, 2 * w).astype(np.int32)
     bpp = 2
     left = np.zeros_like(rows)
@@ -92,13 +96,16 @@ def write_png16(path, image, filter_type=0):
         raise ValueError("filter_type must be 0..4")
     filt = ((rows - pred) & 0xFF).astype(np.uint8)
     raw = np.concatenate([np.full((h, 1), filter_type, np.uint8), filt], axis=1).tobytes()
+    return _write_png(path, w, h, raw, level)
 
+
+def _write_png(path, w, h, raw, level):
     def chunk(kind, body):
         return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xFFFFFFFF)
 
     with open(path, "wb") as fh:
         fh.write(_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0))
-                 + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+                 + chunk(b"IDAT", zlib.compress(raw, level)) + chunk(b"IEND", b""))
     return path
 
 
@@ -158,16 +165,17 @@ class FusionInferenceDataset:
             yield self[k]
 
 
-def write_sequence(data_dir, scan_id, depths_u16, intrinsics, poses, dimensions, filter_type=4):
+def write_sequence(data_dir, scan_id, depths_u16, intrinsics, poses, dimensions, filter_type=4, level=6):
     """Writes a sequence in the reference's layout (depth PNGs, pose / intrinsics / dimensions text files; one empty
-    placeholder per colour image so that the reference's frame count -- len(os.listdir("image")) -- agrees)."""
+    placeholder per colour image so that the reference's frame count -- len(os.listdir("image")) -- agrees).
+    ``depths_u16`` / ``poses`` may be generators (a 2,000-frame sequence is never held in memory)."""
     root = os.path.join(data_dir, scan_id)
     for sub in ("depth", "pose", "image"):
         os.makedirs(os.path.join(root, sub), exist_ok=True)
     with open(os.path.join(root, "pose", "dimensions.txt"), "w") as fh:
         fh.write(" ".join(repr(float(v)) for v in dimensions) + "\n")
     for i, (d, T) in enumerate(zip(depths_u16, poses)):
-        write_png16(os.path.join(root, "depth", f"{i}.png"), d, filter_type)
+        write_png16(os.path.join(root, "depth", f"{i}.png"), d, filter_type, level)
         K = np.asarray(intrinsics[i] if np.ndim(intrinsics) == 3 else intrinsics, dtype=np.float64)
         with open(os.path.join(root, "pose", f"intr_mat_{i}.txt"), "w") as fh:
             fh.write(" ".join(repr(float(v)) for v in K.reshape(-1)) + "\n")

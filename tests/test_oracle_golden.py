@@ -283,3 +283,51 @@ def test_headline_config_oracle_vs_reference_golden():
     assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
     assert np.abs(got.numpy() - ref).max() <= 2e-6
     assert (ref != np.float32(voxel)).mean() > 0.3
+
+
+def test_sweep_window_oracle_vs_reference_golden():
+    """The oracle on the moving-camera window the reference itself ran (tests/golden/sweep_256.npz,
+    make_golden_sequence.py): the frames in which the camera walks out of the volume -- fewer and fewer points inside,
+    points inside but no voxel reaching min_pts, not a single point inside (the reference's `None`) -- ids / counts
+    through SHA-256, n_avg_pts; then the lattice decode of 1,024 voxels from the reference's own fused values."""
+    from bnv_fusion_amd import sequence, synthetic
+    z = np.load(os.path.join(GOLDEN, "sweep_256.npz"))
+    voxel, dims = float(z["voxel_size"]), z["dims"]
+    H, W = [int(v) for v in z["hw"]]
+    scale = sequence.DIMS["golden"][2]
+    sd = orc.load_weights(WEIGHTS_FP32)
+    torch.set_num_threads(8)
+    vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+    assert vol.n_xyz.tolist() == [256, 256, 256]
+    K = sequence.intrinsics(H, W)
+    seen = set()
+    for k in range(3, 13):          # t = 445 .. 490: 738 emitted voxels down to none, then no point inside
+        t = int(z["frames"][k])
+        d16 = sequence.depth_u16(t, H, W, scale, device="cpu").numpy()
+        assert _sha(d16) == str(z["depth_sha256"][k])             # the very frames the reference saw
+        pts = synthetic.depth_to_input_pts(d16.astype(np.float64) / 1000.0, K, sequence.sweep_pose(t, scale),
+                                           max_depth=3.0).astype(np.float32)[None]
+        assert _sha(pts) == str(z["input_pts_sha256"][k])
+        with torch.no_grad():
+            f, c, ids, g, n = orc.encode_pointcloud(sd, torch.from_numpy(pts), vol.n_xyz, vol.min_coords,
+                                                    vol.max_coords, voxel)
+        if int(z["n_out"][k]) == 0 and float(z["n_avg_pts"][k]) < 0:
+            assert f is None                                      # local_point_fusion.py:101-102
+            seen.add("none")
+            continue
+        ids_h, c_h = ids.numpy().astype(np.int64), c.numpy().reshape(-1).astype(np.int64)
+        assert len(ids_h) == int(z["n_out"][k])
+        assert _sha(ids_h) + _sha(c_h) == str(z["ids_counts_sha256"][k]), k
+        assert float(n) == float(z["n_avg_pts"][k])
+        seen.add("empty_output" if len(ids_h) == 0 else "voxels")
+    assert seen == {"none", "empty_output", "voxels"}
+    keys = torch.from_numpy(z["nbr_keys"].astype(np.int64))
+    vol.insert(keys, torch.from_numpy(z["nbr_feats"]), torch.from_numpy(z["nbr_weights"])[:, None],
+               torch.zeros(len(keys), 1))
+    origins = z["decode_origins"].astype(np.int64)
+    with torch.no_grad():
+        got = vol.decode_pts(orc.lattice_coords(origins), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+    ref = z["decode_sdf"]
+    assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
+    assert np.abs(got.numpy() - ref).max() <= 2e-6
+    assert (ref != np.float32(voxel)).mean() > 0.2
