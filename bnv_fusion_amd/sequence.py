@@ -8,7 +8,7 @@ host, which the reference goldens of tests/golden/make_golden_sequence.py rely o
 x walls lie OUTSIDE the volume.  Camera: a full turn every 720 frames (0.5 degrees per frame, like the bench's pan)
 with a +-12 degree nod, while it walks back and forth along the room -- about a fifth of the time it is outside the
 volume, looking back into it (frames that are partly inside) or out of it (16 % of the frames have not a single point
-inside: the reference's `None` path, run_e2e.py:91-92).  Over 2,000 frames the map grows to > 1 M rows through five doublings of the reference's initial 100,000-row table.
+inside: the reference's `None` path, run_e2e.py:91-92).  Over 2,000 frames the map grows to > 1 M rows from the reference's initial 100,000-row tables.
 
 ``sweep_frames`` yields the frame dicts NeuralMap takes; ``run`` drives a map over a frame source synchronously or
 pipelined and returns per-frame checksums + statistics; ``bench_pass`` is bench.py's `sequence` entry.
@@ -121,10 +121,11 @@ def run(nm, frames, pipelined=True, in_flight=2, on_frame=None, checksums=True, 
     """``NeuralMap`` over a frame source: per-frame fuse + decode (run_e2e.py:243-252's loop with the per-frame
     decode of the metric), synchronously or with ``in_flight`` frames enqueued ahead of the oldest uncollected one.
     -> dict(frames, empty_frames, rows [per frame: the row count read back behind it; exact in the pipelined
-    form], capacity [per frame], sums [per frame: (coords, sdf) checksums], seconds).  ``on_frame(k, frame, coords,
+    form], capacity [initial, then after every enqueue], sums [per frame: (coords, sdf) checksums], seconds).  ``on_frame(k, frame, coords,
     sdf)`` is called for every collected frame; every ``check_every`` frames the pipeline is drained and
     ``on_check(k, frame, coords, sdf)`` sees that frame with the volume in exactly the state it was decoded from."""
-    rows, caps, sums = [], [], []
+    rows, sums = [], []
+    caps = [nm.volume._row_capacity]           # after every enqueue (growth happens in the enqueue)
     empty = 0
     pend = []
     k_done = 0
@@ -137,7 +138,6 @@ def run(nm, frames, pipelined=True, in_flight=2, on_frame=None, checksums=True, 
             empty += 1
         sums.append((checksum(c), checksum(s)) if checksums else None)
         rows.append(nm.volume._rows_known)
-        caps.append(nm.volume._row_capacity)
         if on_frame is not None:
             on_frame(k_done, fr, c, s)
         k_done += 1
@@ -153,6 +153,7 @@ def run(nm, frames, pipelined=True, in_flight=2, on_frame=None, checksums=True, 
             last = None
         else:
             last = collect((fr, nm.fuse_and_decode(fr)))
+        caps.append(nm.volume._row_capacity)
         if check_every and k % check_every == check_every - 1:
             while pend:
                 last = collect(pend.pop(0))
