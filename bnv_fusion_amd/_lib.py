@@ -13,7 +13,7 @@ SYMBOLS = [
     "bnv_init", "bnv_num_compute_units", "bnv_status_string", "bnv_last_hip_error",
     "bnv_encode_workspace_bytes", "bnv_encode_workspace_reset", "bnv_pointnet_pack_floats",
     "bnv_sdfmlp_pack_floats", "bnv_encode_pointcloud", "bnv_encode_begin", "bnv_encode_begin_depth",
-    "bnv_encode_finish", "bnv_encode_shard_counts_offset", "bnv_shard_pack", "bnv_shard_install", "bnv_voxelize_pairs",
+    "bnv_encode_finish", "bnv_encode_finish_image", "bnv_encode_shard_counts_offset", "bnv_shard_pack", "bnv_shard_install", "bnv_voxelize_pairs",
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_integrate_batch",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
@@ -111,6 +111,8 @@ def load():
                                              C.POINTER(C.c_double), C.c_double, C.POINTER(Grid), vp, sz, i64, vp, vp]),
         "bnv_encode_finish": (C.c_int, [vp, i64, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64, C.c_int,
                                         vp, vp]),
+        "bnv_encode_finish_image": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
+                                              C.c_int, vp, vp]),
         "bnv_encode_shard_counts_offset": (sz, []),
         "bnv_shard_pack": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, vp, i64, vp]),
         "bnv_shard_install": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp]),

@@ -1838,6 +1838,22 @@ __global__ __launch_bounds__(256) void k_lattice_stamp(bnv_volume_t v, const int
   if (row >= 0 && row < row_limit) origin_stamp[row] = epoch;
 }
 
+// row (| kOriginBit) of neighbour nb (0..26) of origin b, or -1: absent, below min_pts (such rows can only ever appear
+// under a false mask) or beyond row_limit
+__device__ __forceinline__ int lattice_neighbor_row(const bnv_volume_t& v, const int64_t* __restrict__ origins, int64_t b,
+                                                    int nb, const float* __restrict__ weights, int64_t row_limit,
+                                                    float min_pts, const int32_t* __restrict__ origin_stamp,
+                                                    int32_t epoch) {
+  const int64_t x = origins[b * 3 + 0] + (nb / 9 - 1);
+  const int64_t y = origins[b * 3 + 1] + ((nb / 3) % 3 - 1);
+  const int64_t z = origins[b * 3 + 2] + (nb % 3 - 1);
+  int row = volume_row(v, x, y, z);
+  if (row >= row_limit) row = -1;
+  if (row < 0 || !(weights[row] >= min_pts)) return -1;
+  const bool is_origin = origin_stamp && origin_stamp[row] == epoch;
+  return row | (is_origin ? (1 << 30) : 0);
+}
+
 __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const int64_t* __restrict__ origins,
                                                            int64_t n, const float* __restrict__ weights,
                                                            int64_t row_limit, float min_pts,
@@ -1897,13 +1913,26 @@ constexpr int kMarkThreads = BNV_MARK_THREADS;
 constexpr int kMarkChunks = BNV_MARK_CHUNKS;
 constexpr int kMarkOrigins = kMarkThreads / 27 + 2;   // origins a chunk's lattice points can belong to
 constexpr int kMarkBuf = kMarkChunks > 1 ? 16 * kMarkThreads : 8 * kMarkThreads;   // LDS entry buffer; a chunk appends at most 8 per thread
+// FUSED: the neighbour rows are looked up HERE (and written to nbr_rows for the blend) instead of by a
+// k_lattice_neighbors launch in front: one launch and one 10 MB round trip less per frame.  Needs the origin stamps
+// of the call to be complete (k_lattice_stamp or the frame's upsert) and the control words cleared.
+struct MarkFused {
+  bnv_volume_t v;
+  const int64_t* origins;
+  const float* weights;
+  int64_t row_limit;
+  float min_pts;
+  int32_t* nbr_rows_out;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
                                                                int32_t* __restrict__ entries,
                                                                int32_t* __restrict__ n_entries,
                                                                int64_t entry_capacity,
-                                                               const int32_t* __restrict__ n_dev) {
+                                                               const int32_t* __restrict__ n_dev, MarkFused F) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
   if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
   __shared__ int s_buf[kMarkBuf];
@@ -1951,7 +1980,18 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     const int64_t b0 = t0 / 27;
     for (int i = threadIdx.x; i < kMarkOrigins * 27; i += kMarkThreads) {
       const int64_t g = b0 * 27 + i;
-      s_nbr[i] = g < n * 27 ? nbr_rows[g] : -1;
+      int r = -1;
+      if (g < n * 27) {
+        if constexpr (FUSED) {
+          const int ob = i / 27;
+          r = lattice_neighbor_row(F.v, F.origins, b0 + ob, i - ob * 27, F.weights, F.row_limit, F.min_pts, origin_stamp,
+                                   epoch);
+          F.nbr_rows_out[g] = r;   // (a chunk boundary inside an origin: both chunks write the same values)
+        } else {
+          r = nbr_rows[g];
+        }
+      }
+      s_nbr[i] = r;
     }
     __syncthreads();
     const int64_t t = t0 + threadIdx.x;
@@ -2273,6 +2313,10 @@ int bnv_set_option(const char* name, int value) {
     g_lattice_pipe = value;
     return BNV_OK;
   }
+  if (!strcmp(name, "tcnn_block_encoder")) {
+    g_tcnn_block_encoder = value != 0;
+    return BNV_OK;
+  }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value >= g_num_cus) return BNV_ERR_INVALID_ARGUMENT;
     g_reserve_cus = value;
@@ -2432,9 +2476,39 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
+  hipLaunchKernelGGL(k_lattice_mark<false>, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev);
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, MarkFused{});
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+// stamp (unless the frame's upsert did it) -> neighbours + mark in ONE launch
+static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights,
+                                        int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
+                                        void* ws_ptr, size_t ws_bytes, int32_t epoch, bool prestamped,
+                                        bnv_stream_t stream_) {
+  if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  LatticeWs ws;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0) return BNV_OK;
+  if (!origins) return BNV_ERR_INVALID_ARGUMENT;
+  if (!prestamped) {   // (also clears the control words of the stages behind)
+    hipLaunchKernelGGL(k_lattice_stamp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *vol, origins, n,
+                       row_limit, ws.origin_stamp, epoch, n_dev, ws.n_list);
+    BNV_LAUNCH_CHECK();
+  }   // (prestamped: the frame's upsert has cleared the control words too)
+  MarkFused F;
+  F.v = *vol;
+  F.origins = origins;
+  F.weights = weights;
+  F.row_limit = row_limit;
+  F.min_pts = (float)grid->min_pts_in_grid;
+  F.nbr_rows_out = ws.nbr_rows;
+  hipLaunchKernelGGL(k_lattice_mark<true>, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
+                     dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n, ws.origin_stamp, epoch, ws.need_mask,
+                     ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -2494,11 +2568,9 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
-  // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend
-  int rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes,
-                                  epoch, prestamped, stream);
-  if (rc != BNV_OK) return rc;
-  rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
+  // neighbour rows + entries read by live lattice points (one launch) -> MLP on those entries only -> blend
+  int rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
+                                        prestamped, stream);
   if (rc != BNV_OK) return rc;
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
   if (rc != BNV_OK) return rc;

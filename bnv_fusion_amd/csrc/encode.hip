@@ -32,6 +32,7 @@ namespace bnv {
 int g_num_cus = 0;
 int g_last_hip_error = 0;
 int g_reserve_cus = 0;  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
+int g_tcnn_block_encoder = 1;  // bnv_set_option("tcnn_block_encoder"): 1 = k_pointnet_scatter_tb for whole frames
 int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
@@ -513,8 +514,10 @@ __device__ __forceinline__ void layer128(const float* __restrict__ wp, const flo
 //  * the run's pair count is its length.
 // (Round 1's segmented Hillis-Steele scan over ds_bpermute took ~300 instructions per tile; this takes ~110.)
 // Used by the exact-fp32 encoder (lane = (pair j, feature half h)); the split modes use scatter_tile_x.
-__device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, int h, int32_t* __restrict__ counts,
-                                             long long* __restrict__ acc) {
+// -> for the LAST lane of every run of equal slots: v[q] = the run's sum of output 4 h + q (2^32 fixed point), len = its
+// pair count; is_end tells whether this lane is such a lane (lanes with slot < 0 form runs too: the caller skips them)
+__device__ __forceinline__ void tile_run_sums(const f32x16& o, int slot, int j, int h, unsigned long long (&v)[4],
+                                              bool& is_end, int& len) {
   uint32_t lo[4], hi[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -549,26 +552,32 @@ __device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, i
   const unsigned long long heads64 = __ballot(j == 0 || prev != slot);
   const uint32_t heads = h ? (uint32_t)(heads64 >> 32) : (uint32_t)heads64;
   const int s = 31 - __clz((int)(heads & (0xffffffffu >> (31 - j))));   // head of this lane's run (bit 0 is set)
-  const bool is_end = j == 31 || ((heads >> (j + 1)) & 1u);
+  is_end = j == 31 || ((heads >> (j + 1)) & 1u);
+  len = j - s + 1;
   const int src = (h * 32 + (s > 0 ? s - 1 : 0)) * 4;                      // lane holding P[s - 1]
-  uint32_t plo[4], phi[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    plo[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[q]);
-    phi[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[q]);
+    const uint32_t plo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lo[q]);
+    const uint32_t phi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)hi[q]);
+    v[q] = ((unsigned long long)hi[q] << 32) | lo[q];
+    if (s > 0) v[q] -= ((unsigned long long)phi << 32) | plo;
   }
+}
+
+__device__ __forceinline__ void scatter_tile(const f32x16& o, int slot, int j, int h, int32_t* __restrict__ counts,
+                                             long long* __restrict__ acc) {
+  unsigned long long v[4];
+  bool is_end;
+  int len;
+  tile_run_sums(o, slot, j, h, v, is_end, len);
 #ifdef BNV_PROBE_NO_SCATTER   // development probe (tools/): what do the scatter atomics cost?  keeps 1 of 64 tiles' atomics
   if ((blockIdx.x & 63) != 0) return;
 #endif
   if (slot >= 0 && is_end) {
     unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)h);   // 32-bit index: no loop-invariant 64-bit VGPR pair
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      unsigned long long v = ((unsigned long long)hi[q] << 32) | lo[q];
-      if (s > 0) v -= ((unsigned long long)phi[q] << 32) | plo[q];
-      atomicAdd(dst + q, v);
-    }
-    if (h == 0) atomicAdd(&counts[slot], j - s + 1);
+    for (int q = 0; q < 4; ++q) atomicAdd(dst + q, v[q]);
+    if (h == 0) atomicAdd(&counts[slot], len);
   }
 }
 
@@ -1191,6 +1200,195 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pointnet_scatter_tb: the tiny-cuda-nn encoder for WHOLE frames (unsharded encode), built around the scatter.
+// With this small network the kernel's floor was its global atomics: 5.7 M device-scope 64-bit atomics per frame
+// (366 MB of write traffic tallied at 64 B each) = 0.31 ms whatever the weights, against 0.22 ms without them
+// (profiles/r02_power_probe.txt, r02_bench_line_tcnn.json).  Here a wave's unit of work is a BLOCK of 32 points --
+// 8 x 4 pixels of the depth image when the frame's width is known, else 32 consecutive points -- with all EIGHT
+// corner tiles of those points, and the per-voxel sums of a block are formed in a wave-private LDS table:
+//  * a 2.3 x 1.2 cm pixel patch with its 8 corners touches ~20 voxels, each ~13 times: the table (64 entries:
+//    slot, count, 8 x i64; open addressing on slot & 63, LDS compare-and-swap) takes the run sums of the eight tiles
+//    with LDS atomics and is flushed once per block -- ~4x fewer global atomics than the per-tile run sums, ~13x fewer
+//    than one per pair; sums are integers, so the result is bit-identical to any other order.  A table that is full
+//    (cannot happen on surfaces; 64 distinct voxels in one block) falls back to global atomics for that run;
+//  * the point is loaded and voxelised ONCE for its eight corners (3 + 6 IEEE divisions per point instead of 48:
+//    the relative coordinate of an axis has two values, floor and ceil) and the 16 bitmap / prefix words of the
+//    eight corners are requested together;
+//  * no barrier: tables are per wave.  512 threads share one copy of the weights (22.5 KB) + 8 tables (36.9 KB):
+//    two workgroups per CU, four waves per SIMD as before.
+// Sharded encodes (owned-pair list) keep k_pointnet_scatter_t.
+// ------------------------------------------------------------------------------------------
+constexpr int kAccCap = 64;
+struct WaveAcc {
+  int key[kAccCap];
+  int cnt[kAccCap];
+  unsigned long long sum[kAccCap][8];
+};
+
+__global__ __launch_bounds__(512) void k_pointnet_scatter_tb(
+    const float* __restrict__ pts, int n_points, int frame_w, bnv_grid_t g, const float* __restrict__ wpack,
+    const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix, int32_t* __restrict__ counts,
+    long long* __restrict__ acc) {
+  __shared__ __attribute__((aligned(16))) _Float16 wh[PT_TOTAL];
+  __shared__ WaveAcc tabs[8];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  WaveAcc& T = tabs[wave];
+  T.key[lane] = -1;
+  T.cnt[lane] = 0;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) T.sum[lane][f] = 0ull;
+  stage_to_lds<512>(wpack, wh, PT_TOTAL * 2);
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  // blocks: 8 x 4 pixel patches of a frame_w-wide image, or runs of 32 points
+  const bool image = frame_w > 0 && n_points % frame_w == 0;
+  const int frame_h = image ? n_points / frame_w : 1;
+  const int bw = image ? (frame_w + 7) >> 3 : 0;
+  const int n_blocks = image ? bw * ((frame_h + 3) >> 2) : (n_points + 31) >> 5;
+  for (int b = blockIdx.x * 8 + wave; b < n_blocks; b += gridDim.x * 8) {
+    int i = -1;
+    if (image) {
+      const int by = b / bw, bx = b - by * bw;
+      const int x = bx * 8 + (j & 7), y = by * 4 + (j >> 3);
+      if (x < frame_w && y < frame_h) i = y * frame_w + x;
+    } else if (b * 32 + j < n_points) {
+      i = b * 32 + j;
+    }
+    bool valid = false;
+    float px = 0.f, py = 0.f, pz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    if (i >= 0) {
+      const float* p = pts + (size_t)i * 6;
+      px = p[0], py = p[1], pz = p[2], n0 = p[3], n1 = p[4], n2 = p[5];
+      valid = in_bounds(px, py, pz, g);
+    }
+    if (__ballot(valid) == 0ULL) continue;
+    // voxelisation of the point, once for its eight corners
+    int lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
+    _Float16 rl[3], rh[3];     // relative coordinate of an axis towards its floor / ceil voxel, as the network takes it
+    {
+      const float c3[3] = {px, py, pz};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float xn = valid ? voxel_coord(c3[a], g.bound_min[a], g.voxel_size) : 0.f;
+        lo3[a] = (int)floorf(xn);
+        hi3[a] = (int)ceilf(xn);
+        rl[a] = (_Float16)relative_coord(xn, lo3[a], g.voxel_size);
+        rh[a] = (_Float16)relative_coord(xn, hi3[a], g.voxel_size);
+      }
+    }
+    // bitmap word + prefix of the eight corner voxels, all requested before the first is used
+    uint32_t bw8[8], pf8[8], id8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int gx = (k & 1) ? hi3[0] : lo3[0], gy = (k & 2) ? hi3[1] : lo3[1], gz = (k & 4) ? hi3[2] : lo3[2];
+      id8[k] = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
+      bw8[k] = 0u;
+      pf8[k] = 0u;
+      if (valid) {
+        bw8[k] = bitmap[id8[k] >> 5];
+        pf8[k] = word_prefix[id8[k] >> 5];
+      }
+    }
+    const _Float16 hn0 = (_Float16)n0, hn1 = (_Float16)n1, hn2 = (_Float16)n2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int slot = valid ? (int)(pf8[k] + __popc(bw8[k] & ((1u << (id8[k] & 31)) - 1u))) : -1;
+      // operand slots of this lane half: features 8 (jj >> 2) + 4 h + (jj & 3); inputs 0..5, the rest 1.0
+      half8 bop;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bop[e] = (_Float16)1.0f;
+      if (valid) {
+        if (h == 0) {
+          bop[0] = (k & 1) ? rh[0] : rl[0];
+          bop[1] = (k & 2) ? rh[1] : rl[1];
+          bop[2] = (k & 4) ? rh[2] : rl[2];
+          bop[3] = hn0;
+        } else {
+          bop[0] = hn1;
+          bop[1] = hn2;
+        }
+      }
+      f32x16 ha[2], hb[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+        ha[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[PT_W1 + (mb * 64 + lane) * 8], bop, zero16(),
+                                                        0, 0, 0);
+      half8 s4[4];
+      auto layer64 = [&](int woff, const f32x16 (&in)[2], f32x16 (&out)[2]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          s4[nb * 2] = to_half8_relu(in[nb], 0);
+          s4[nb * 2 + 1] = to_half8_relu(in[nb], 8);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          out[mb] = zero16();
+#pragma unroll
+          for (int gk = 0; gk < 4; ++gk)
+            out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[woff + ((mb * 4 + gk) * 64 + lane) * 8],
+                                                            s4[gk], out[mb], 0, 0, 0);
+        }
+      };
+      layer64(PT_W2, ha, hb);
+      layer64(PT_W3, hb, ha);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        s4[nb * 2] = to_half8_relu(ha[nb], 0);
+        s4[nb * 2 + 1] = to_half8_relu(ha[nb], 8);
+      }
+      f32x16 o = zero16();
+#pragma unroll
+      for (int gk = 0; gk < 4; ++gk)
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[PT_W4 + (gk * 64 + lane) * 8], s4[gk], o, 0, 0, 0);
+      // the network returns fp16; lane (j, h) holds outputs 4h .. 4h+3 of pair j
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (float)(_Float16)o[q];
+      unsigned long long v[4];
+      bool is_end;
+      int len;
+      tile_run_sums(o, slot, j, h, v, is_end, len);
+      if (slot >= 0 && is_end) {
+        // the run's sums into the wave's table (both halves of a pair probe the same way and meet in the same entry)
+        int p = slot & (kAccCap - 1), found = -1;
+        for (int probe = 0; probe < kAccCap; ++probe) {
+          const int old = atomicCAS(&T.key[p], -1, slot);
+          if (old == -1 || old == slot) {
+            found = p;
+            break;
+          }
+          p = (p + 1) & (kAccCap - 1);
+        }
+        if (found >= 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) atomicAdd(&T.sum[found][4 * h + q], v[q]);
+          if (h == 0) atomicAdd(&T.cnt[found], len);
+        } else {   // table full: straight to the global accumulators
+          unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) atomicAdd(dst + q, v[q]);
+          if (h == 0) atomicAdd(&counts[slot], len);
+        }
+      }
+    }
+    // flush: one entry per lane; the table is empty again for the next block
+    const int key = T.key[lane];
+    if (key >= 0) {
+      unsigned long long* dst = (unsigned long long*)acc + (uint32_t)key * 8u;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        atomicAdd(dst + f, T.sum[lane][f]);
+        T.sum[lane][f] = 0ull;
+      }
+      atomicAdd(&counts[key], T.cnt[lane]);
+      T.key[lane] = -1;
+      T.cnt[lane] = 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // finalize: mean, min-points filter, ORDERED compaction of the emitted voxels (one pass: decoupled look-back over the
 // workgroups), unflatten, cleanup of the per-frame scratch; the workgroup of the last tile completes the frame's
 // counters and clears the control block.
@@ -1496,8 +1694,18 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
 int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,
                       const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
                       float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
-                      int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream_) {
+                      int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream) {
+  return bnv_encode_finish_image(input_pts, n_points, 0, grid_host, pointnet_pack, ws_ptr, ws_bytes, ws_max_points,
+                                 out_feats, out_pcounts, out_flat_ids, out_grid_ids, out_capacity, emit_all, counters,
+                                 stream);
+}
+
+int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_width, const bnv_grid_t* grid_host,
+                            const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
+                            float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                            int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (image_width < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
       n_points > (1 << 27) || ws_max_points < n_points)
     return BNV_ERR_INVALID_ARGUMENT;
@@ -1518,7 +1726,12 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
   const int32_t* plist = g.shard_world > 1 ? ws.pair_list : (const int32_t*)nullptr;   // sharded: owned pairs only
   {
     ProfScope prof(PROF_POINTNET, stream);
-    if (g_mlp_mode == 2)
+    if (g_mlp_mode == 2 && !plist && g_tcnn_block_encoder) {
+      const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
+      const int grid_tb = g_num_cus * 2 < (n_blocks + 7) / 8 ? g_num_cus * 2 : (n_blocks + 7) / 8;
+      hipLaunchKernelGGL(k_pointnet_scatter_tb, dim3(grid_tb), dim3(512), 0, stream, input_pts, n, image_width, g,
+                         pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
+    } else if (g_mlp_mode == 2)
       hipLaunchKernelGGL(k_pointnet_scatter_t, dim3(g_num_cus * 4 < (n_tiles + 3) / 4 ? g_num_cus * 4 : (n_tiles + 3) / 4),
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
                          ws.acc, plist, &ws.ctl->n_pairs);

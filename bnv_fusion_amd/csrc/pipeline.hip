@@ -105,7 +105,7 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
 }
 
 // the part of `begin` behind the voxelisation, common to depth and point frames
-static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n) {
+static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, int image_width) {
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
   if (c.grid.shard_world > 1) {
@@ -114,8 +114,9 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n) 
                                  4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->E));
   }
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->E));
-  const int rc = bnv_encode_finish(pts, n, &c.grid, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points,
-                                   b.feats, b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters, p->E);
+  const int rc = bnv_encode_finish_image(pts, n, image_width, &c.grid, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes,
+                                         c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
+                                         c.out_capacity, 0, b.counters, p->E);
   if (rc != BNV_OK) return rc;
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
   p->n_points[slot] = n;
@@ -142,7 +143,7 @@ int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int 
   rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &c.grid, c.enc_ws,
                               c.enc_ws_bytes, c.enc_ws_max_points, b.input_pts, p->E);
   if (rc != BNV_OK) return rc;
-  rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W);
+  rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W, W);
   if (rc != BNV_OK) return rc;
   if (c.tsdf.tsdf) {   // run_e2e.py:99-109, gated on the device by the frame's in-bounds point count
     float K[9], T[16];
@@ -170,7 +171,7 @@ int bnv_frame_begin_points(bnv_frame_pipe_t* p, int slot, const float* input_pts
   if (!input_pts || n_points < 0 || n_points > c.max_points) return BNV_ERR_INVALID_ARGUMENT;
   rc = bnv_encode_begin(input_pts, n_points, &c.grid, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points, p->E);
   if (rc != BNV_OK) return rc;
-  rc = begin_tail(p, slot, input_pts, n_points);
+  rc = begin_tail(p, slot, input_pts, n_points, 0);
   if (rc != BNV_OK) return rc;
   BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
   return BNV_OK;

@@ -224,6 +224,7 @@ struct IntegrateExtras {
   bnv_grid_t grid;          // ownership / boundary predicates (with block)
   int32_t* origin_stamp;    // null: no stamps
   int32_t stamp_epoch;
+  int32_t* lattice_ctl;     // with origin_stamp: control words of the decode's later stages, cleared here
 };
 
 template <bool FRAME>
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int
                                                        uint64_t* __restrict__ tile_state, uint32_t epoch,
                                                        int32_t* __restrict__ error, IntegrateExtras X) {
   n = dev_count(n, n_dev);
+  if constexpr (FRAME) {
+    // entries listed / tile counter / spare of the lattice decode that follows (k_lattice_stamp's other job)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && X.lattice_ctl) X.lattice_ctl[1] = X.lattice_ctl[2] = X.lattice_ctl[3] = 0;
+  }
   if ((int64_t)blockIdx.x * 256 >= n) return;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   uint64_t key;
@@ -670,8 +675,7 @@ int bnv_volume_integrate_frame(const bnv_volume_t* vol, const int64_t* coords, c
   }
   if (extras->lattice_ws) {
     if (extras->stamp_epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
-    int32_t* ctl = nullptr;
-    lattice_ws_frame_words(extras->lattice_ws, vol->row_capacity, &X.origin_stamp, &ctl);
+    lattice_ws_frame_words(extras->lattice_ws, vol->row_capacity, &X.origin_stamp, &X.lattice_ctl);
     X.stamp_epoch = extras->stamp_epoch;
   }
   VolWs ws;

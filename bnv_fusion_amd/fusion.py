@@ -309,9 +309,10 @@ class LitFusionPointNet(nn.Module):
                    "bnv_encode_begin_depth")
         if between is not None:
             between()
-        _lib.check(lib.bnv_encode_finish(_lib.ptr(pts), n, C.byref(grid), _lib.ptr(self.pointnet_pack), *ws,
-                                         _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids), _lib.ptr(grid_ids),
-                                         cap, 0, _lib.ptr(counters), _lib.stream_ptr()), "bnv_encode_finish")
+        _lib.check(lib.bnv_encode_finish_image(_lib.ptr(pts), n, W, C.byref(grid), _lib.ptr(self.pointnet_pack), *ws,
+                                               _lib.ptr(feats), _lib.ptr(pcounts), _lib.ptr(flat_ids),
+                                               _lib.ptr(grid_ids), cap, 0, _lib.ptr(counters), _lib.stream_ptr()),
+                   "bnv_encode_finish_image")
         return feats, pcounts, flat_ids, grid_ids, counters, cap, pts.unsqueeze(0)
 
     def encode_pointcloud(self, input_pts, n_xyz, bound_min, bound_max, voxel_size, return_dense=True):

@@ -115,6 +115,8 @@ int bnv_get_mlp_mode(void);
  *                  operands prefetched across tiles and layers, dynamic tile hand-out); 0: the generic
  *                  k_decode<LATTICE> (32x32x16 MFMA; the same arithmetic in another summation grouping: tables equal
  *                  to ~1e-8, 8-10 % slower);
+ *   "tcnn_block_encoder"  1 (default): whole-frame encodes with the tiny-cuda-nn networks run k_pointnet_scatter_tb
+ *                  (32-point blocks x 8 corners, per-wave LDS accumulation of the voxel sums); 0: the per-tile kernel.
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside
@@ -246,6 +248,15 @@ int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t
                       const float* pointnet_pack, void* ws, size_t ws_bytes, int64_t ws_max_points,
                       float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                       int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream);
+/* bnv_encode_finish for a frame whose points are the pixels of an image in row-major order (the out_pts of
+ * bnv_encode_begin_depth): image_width > 0 with n_points a multiple of it lets the encoder work on 2-D pixel patches
+ * (the tiny-cuda-nn encoder accumulates a patch's per-voxel sums on chip before touching the global accumulators:
+ * neighbouring pixels in BOTH directions share voxels); 0 = no such structure (bnv_encode_finish).  Results are
+ * identical either way (integer sums). */
+int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_width, const bnv_grid_t* grid_host,
+                            const float* pointnet_pack, void* ws, size_t ws_bytes, int64_t ws_max_points,
+                            float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                            int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream);
 size_t bnv_encode_shard_counts_offset(void);
 
 /* input_pts [n_points, 6] f32 (world xyz, world normal).
