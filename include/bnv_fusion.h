@@ -115,6 +115,8 @@ int bnv_get_mlp_mode(void);
  *                  operands prefetched across tiles and layers, dynamic tile hand-out); 0: the generic
  *                  k_decode<LATTICE> (32x32x16 MFMA; the same arithmetic in another summation grouping: tables equal
  *                  to ~1e-8, 8-10 % slower);
+ *   "fused_mark"   -1 (default): bnv_decode_lattice looks the 27 neighbour rows up inside the live-entry marking kernel
+ *                  for calls of up to 49,152 voxels and in a launch of its own above; 1 / 0 force either.
  *   "tcnn_block_encoder"  1 (default): whole-frame encodes with the tiny-cuda-nn networks run k_pointnet_scatter_tb
  *                  (32-point blocks x 8 corners, per-wave LDS accumulation of the voxel sums); 0: the per-tile kernel.
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
