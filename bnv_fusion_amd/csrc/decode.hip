@@ -1764,6 +1764,114 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_lattice_table_t: the lattice tables with the tiny-cuda-nn decoder (MLP mode 2), one WAVE per 32 entries.
+// The generic k_decode<LATTICE, 2> is built around the fp32 decoder's tile: 512 threads, 141 KB of LDS (one workgroup
+// per CU), the 128 staged inputs of a tile pass through LDS behind a barrier and only four of the eight waves run
+// the (tiny) network: 0.162 ms per frame, 40 % of the tcnn frame's MLP time for 6 % of its FLOPs.  Here a wave
+// loads its 32 entries, gathers their feature rows, builds the network's B operands in registers (positional
+// encoding of a lattice offset: three values of {0, +-0.5} and their sin / cos), runs all four layers in registers
+// with the weights in LDS (24.5 KB, staged once per workgroup) and writes its 32 table entries: no barrier, no LDS
+// traffic for activations, 256-thread workgroups, four to five waves per SIMD.  Same operand values in the same MFMA
+// order as the generic kernel: bit-identical tables (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lattice_table_t(DecodeArgs A) {
+  __shared__ __attribute__((aligned(16))) _Float16 wh[ST_TOTAL];
+  stage_to_lds<256>(A.pack, wh, ST_TOTAL * 2);
+  __syncthreads();
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
+  const int64_t n_tiles = (n_evals + 31) / 32;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < n_tiles; t += (int64_t)gridDim.x * 4) {
+    const int ent = lattice_entry(A, t * 32 + j, n_evals);
+    float in[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) in[f] = 1.0f;       // inputs 17..31: the padding of the tcnn encoding
+    int row = 0, l = 0;
+    if (ent >= 0) {
+      row = ent >> 5;
+      l = ent & 31;
+      const float loc[3] = {(float)(l / 9 - 1) * 0.5f, (float)((l / 3) % 3 - 1) * 0.5f, (float)(l % 3 - 1) * 0.5f};
+      const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
+      const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        in[a] = loc[a];
+        in[3 + a] = sinf(loc[a]);
+        in[6 + a] = cosf(loc[a]);
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        in[9 + f] = f0[f];
+        in[13 + f] = f1[f];
+      }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 17; ++f) in[f] = 0.f;      // (an empty column; its output is not written)
+    }
+    // operand slot jj of K-step ks of this lane half: input 16 ks + 8 (jj >> 2) + 4 h + (jj & 3)  (stage_input_t)
+    half8 b[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const float lo = in[16 * ks + 8 * (jj >> 2) + (jj & 3)], hi = in[16 * ks + 8 * (jj >> 2) + 4 + (jj & 3)];
+        b[ks][jj] = (_Float16)(h ? hi : lo);
+      }
+    f32x16 a0[2], a1[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a0[mb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        a0[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[ST_W0 + ((mb * 2 + ks) * 64 + lane) * 8], b[ks],
+                                                        a0[mb], 0, 0, 0);
+    }
+    half8 s4[4];
+    auto layer64 = [&](int woff, const f32x16 (&inp)[2], f32x16 (&out)[2]) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        s4[nb * 2] = relu_half8(inp[nb], 0);
+        s4[nb * 2 + 1] = relu_half8(inp[nb], 8);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[mb][r] = 0.f;
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk)
+          out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[woff + ((mb * 4 + gk) * 64 + lane) * 8],
+                                                          s4[gk], out[mb], 0, 0, 0);
+      }
+    };
+    layer64(ST_W1, a0, a1);
+    layer64(ST_W2, a1, a0);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      s4[nb * 2] = relu_half8(a0[nb], 0);
+      s4[nb * 2 + 1] = relu_half8(a0[nb], 8);
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk)
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const half8*)&wh[ST_W3 + (gk * 64 + lane) * 8], s4[gk], o, 0, 0, 0);
+    // output 0 = row 0 of the tile = register 0 of the lanes with h == 0; the network returns fp16, and
+    // half tensor * python float stays half (sparse_volume.py:813)
+    if (h == 0 && ent >= 0) {
+      float av = __fmul_rn((float)(_Float16)o[0], voxel);
+      av = (float)(_Float16)av;
+      A.table[(size_t)row * 27 + l] = av;
+      if (A.entries) A.need_mask[row] = 0u;   // leave the per-row masks clean for the next call
+    }
+  }
+}
+
 // ---- lattice decode: neighbour lookup + blend ------------------------------------------------
 struct LatticeWs {
   int32_t* nbr_rows;  // [n][27]
@@ -2208,6 +2316,16 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
       hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
     else
       hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
+    BNV_LAUNCH_CHECK();
+    return BNV_OK;
+  }
+  if (mode == MODE_LATTICE && g_mlp_mode == 2 && g_lattice_pipe) {
+    ProfScope prof(PROF_DECODE_LATTICE, stream);
+    int64_t gt = (int64_t)g_num_cus * 4;                    // four 4-wave workgroups per CU, grid-stride over the tiles
+    const int64_t wgs = (n_tiles_hint * (DM / 32) + 3) / 4;   // (the hint counts 128-evaluation tiles)
+    if (wgs < gt) gt = wgs;
+    if (gt < 1) gt = 1;
+    hipLaunchKernelGGL(k_lattice_table_t, dim3((unsigned)gt), dim3(256), 0, stream, args);
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }

@@ -681,6 +681,30 @@ def test_tcnn_checkpoint_encode_decode_vs_oracle(bnv, orc):
     assert float((ref != voxel).float().mean()) > 0.05
     assert (lat - gen).abs().max() <= 2e-6
     assert (lat - ref).abs().max() <= 1e-4, float((lat - ref).abs().max())     # SDF = fp16 net output x 0.02
+    # the wave-per-32-entries table kernel (k_lattice_table_t, the default) against the generic tile kernel
+    # (lattice_pipe 0): same operands in the same MFMA order -> the same bits, on whole and ragged work lists
+    from bnv_fusion_amd import _lib
+    lib = _lib.load()
+    allv = nm.volume.active_coordinates
+    try:
+        for n in (1, 31, 33, 120, int(allv.shape[0])):
+            outs = []
+            for pipe in (1, 0):
+                assert lib.bnv_set_option(b"lattice_pipe", pipe) == 0
+                outs.append(nm.volume.decode_lattice(allv[:n].contiguous(), model.nerf, query_tensor=False).clone())
+            assert torch.equal(outs[0], outs[1]), n
+        # and the 32-point-block encoder against the per-tile one
+        pts = torch.from_numpy(z["frames"][3]).to(DEV)
+        enc_out = []
+        for opt in (1, 0):
+            assert lib.bnv_set_option(b"tcnn_block_encoder", opt) == 0
+            enc_out.append(model.encode_pointcloud(pts, nm.volume.n_xyz, nm.volume.min_coords, nm.volume.max_coords,
+                                                   voxel, return_dense=False))
+        for a, b in zip(enc_out[0][:4], enc_out[1][:4]):
+            assert torch.equal(a, b)
+    finally:
+        lib.bnv_set_option(b"lattice_pipe", 1)
+        lib.bnv_set_option(b"tcnn_block_encoder", 1)
     # a tcnn model and an fp32 model can alternate in one process (the MLP mode follows the model)
     m32 = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     a = m32.encode_pointcloud(torch.from_numpy(z["frames"][0]).to(DEV), nm.volume.n_xyz, nm.volume.min_coords,
