@@ -2,7 +2,7 @@
 # Collects everything profiles/<round>_* is built from (run on the GPU box through gpurun; tools/make_profiles.py then
 # builds the committed summaries from gpurun_out/).  Kernel trace and PMC passes are separate runs, as the pool requires.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -16,7 +16,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- $BE
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace --output-format csv -d $O/pmc1 -o p -- $BENCH > $O/pmc1.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc2 -o p -- $BENCH > $O/pmc2.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc3 -o p -- $BENCH > $O/pmc3.log 2>&1
-python3 tools/spatial_single_rank.py --world 8 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids" > $O/spatial_world8.txt
-python3 tools/spatial_single_rank.py --world 2 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids" > $O/spatial_world2.txt
+# the tiny-cuda-nn (reference default) networks: kernel table + the scatter's write traffic
+BENCHT="python3 bench.py --checkpoint tcnn --no-cpu-baseline --no-alt-mode --no-stream-overlap --preheat 100"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tcnn -o bench -- $BENCHT > $O/trace_tcnn_stdout.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_tcnn_w -o p -- $BENCHT > $O/pmc_tcnn_w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_tcnn_f -o p -- $BENCHT > $O/pmc_tcnn_f.log 2>&1
+F="RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids"
+python3 tools/spatial_single_rank.py --world 8 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world8.txt
+python3 tools/spatial_single_rank.py --world 8 --in-flight 2 2>&1 | grep -v "$F" > $O/spatial_world8_2inflight.txt
+python3 tools/spatial_single_rank.py --world 2 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world2.txt
+python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --checkpoint tcnn 2>&1 | grep -v "$F" > $O/spatial_world8_tcnn.txt
+GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/queue_probe.txt
+python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_sp8 -o sp8 -- python3 tools/spatial_single_rank.py --world 8 --frames 300 > $O/trace_sp8_stdout.log 2>&1
 python3 tools/fp_single_rank.py --replay 8 > $O/fp_replay8.txt 2>&1
 ls -la $O
