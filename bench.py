@@ -564,11 +564,14 @@ def run_bench(args, rank, world, dev, dist, backend):
                 "traffic": traffic, "traffic_source": src,
                 "avg_kernel_ms": kern["dec_ms"], "flop_per_launch": kern["dec_flop"],
                 "mlp_evals_per_launch": kern["rows"],
-                "mfma_issue_frac": kern["dec_tflops"] * MFMA_PER_PRODUCT[mode] / peak, "timing": note}
+                "mfma_issue_frac": kern["dec_tflops"] * MFMA_PER_PRODUCT[mode] / peak, "timing": note,
+                "state": "sustained: measured behind the pre-heat frames like `value` (the same kernel runs ~20 % "
+                         "faster on a GPU that has been idle: burst.kernel_alone)" if world == 1 else "timed region"}
 
     def entry(run, parity=None):
         return {"value": run["fps"], "unit": "frames/s", "steps": run["steps"],
-                "ms_per_step": 1e3 * run["elapsed"] / run["steps"], **({"parity": parity} if parity else {})}
+                "ms_per_step": 1e3 * run["elapsed"] / run["steps"], **({"parity": parity} if parity else {}),
+                **({"kernel_alone": run["kernel_alone"]} if "kernel_alone" in run else {})}
 
     out_common = {"metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid", "unit": "frames/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
@@ -664,6 +667,13 @@ def run_bench(args, rank, world, dev, dist, backend):
         kernel-alone run, note)."""
         ph = args.preheat if mode != 0 else min(args.preheat, 300)     # (exact fp32 draws less: burst == sustained)
         burst = timed(nm, "single", mode, step_idx, warm_idx)
+        if getattr(nm, "overlap_encode", False):      # the dominant kernel alone at the burst clock, as rounds 1-2 quoted it
+            nm.overlap_encode = False
+            kb = timed(nm, "single", mode, step_idx, warm_idx)
+            nm.overlap_encode = True
+            burst["kernel_alone"] = {"decode_kernel_ms": kb["dec_ms"], "decode_tflops": kb["dec_tflops"],
+                                     "decode_frac_of_peak": kb["dec_tflops"] / PEAK_TFLOPS[mode],
+                                     "pointnet_kernel_ms": kb["enc_ms"], "pointnet_tflops": kb["enc_tflops"]}
         run = timed(nm, "single", mode, step_idx, warm_idx, preheat=ph)
         run["parity"] = parity_check(nm, run)  # right after the timed region: the volume is in that run's final state
         # Kernel-alone pass for the roofline: with the encode on a second stream the two MLP kernels of consecutive

@@ -1973,31 +1973,23 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
                                                            const int32_t* __restrict__ n_dev,
                                                            int32_t* __restrict__ ctl_clear) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;  // count from device memory; n = grid capacity
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   // origins stamped by the frame's upsert (bnv_volume_integrate_frame): no k_lattice_stamp launch in front of this
   // one, so the control words of the stages behind are cleared here
-  if (ctl_clear && t == 0) ctl_clear[1] = ctl_clear[2] = ctl_clear[3] = 0;
-  if (t >= n * 27) return;
-  const int64_t b = t / 27;
-  const int nb = (int)(t - b * 27);
-  const int64_t x = origins[b * 3 + 0] + (nb / 9 - 1);
-  const int64_t y = origins[b * 3 + 1] + ((nb / 3) % 3 - 1);
-  const int64_t z = origins[b * 3 + 2] + (nb % 3 - 1);
-  // (from the dense row index when the volume keeps one: the 27 look-ups of a voxel are 9 runs of 3 neighbouring
-  // words, and neighbouring voxels share them -- against 27 hash probes that each pull a line of their own)
-  int row = volume_row(v, x, y, z);
-  if (row >= row_limit) row = -1;
-  bool usable = false;
-  if (row >= 0) usable = weights[row] >= min_pts;
-  // rows below min_pts can only ever appear under a false mask: mark them as unusable corners.  Bit 30 of a usable
-  // row: its voxel is itself a decoded origin of this call (k_lattice_stamp ran first), which the live-entry marking
-  // needs for the owner test -- read here next to the row's weight instead of a dependent gather per lattice point
-  // there (~1 M scattered loads per frame).
-  const bool is_origin = usable && origin_stamp && origin_stamp[row] == epoch;
-  nbr_rows[t] = usable ? (row | (is_origin ? kOriginBit : 0)) : -1;
-  // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
-  if (usable && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
-    list[atomicAdd(n_list, 1)] = row;
+  if (ctl_clear && blockIdx.x == 0 && threadIdx.x == 0) ctl_clear[1] = ctl_clear[2] = ctl_clear[3] = 0;
+  // grid-stride: the launch is sized for the CAPACITY (the count is on the device) but capped, so a frame that holds
+  // a fraction of it (a shard's 1 / world) does not pay for ten thousand workgroups that only exit
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n * 27; t += (int64_t)gridDim.x * 256) {
+    const int64_t b = t / 27;
+    const int nb = (int)(t - b * 27);
+    // (from the dense row index when the volume keeps one: the 27 look-ups of a voxel are 9 runs of 3 neighbouring
+    // words, and neighbouring voxels share them -- against 27 hash probes that each pull a line of their own)
+    const int r = lattice_neighbor_row(v, origins, b, nb, weights, row_limit, min_pts, origin_stamp, epoch);
+    nbr_rows[t] = r;
+    // list = rows whose table must be (re)computed here; halo rows (row_skip) get theirs by exchange
+    const int row = r & ~(1 << 30);
+    if (r >= 0 && list && !(row_skip && row_skip[row]) && atomicExch(&stamp[row], epoch) != epoch)
+      list[atomicAdd(n_list, 1)] = row;
+  }
 }
 
 // One thread per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is
@@ -2043,6 +2035,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
                                                                const int32_t* __restrict__ n_dev, MarkFused F) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
   if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
+  // (grid-stride over virtual workgroups vb: the launch is sized for the capacity, capped at two workgroups per CU)
   __shared__ int s_buf[kMarkBuf];
   __shared__ int s_nbr[kMarkOrigins * 27];
   __shared__ int s_corner[216 + 27];
@@ -2050,7 +2043,6 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   __shared__ uint32_t s_wave[kMarkThreads / 64];
 #endif
   __shared__ int s_count, s_base;
-  if (threadIdx.x == 0) s_count = 0;
   if (threadIdx.x < 216 + 27) {
     if (threadIdx.x < 216) {
       const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
@@ -2081,8 +2073,11 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
                                   : -1;
     }
   }
+  for (int64_t vb = blockIdx.x; vb * kMarkThreads * kMarkChunks < n * 27; vb += gridDim.x) {
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
   for (int ch = 0; ch < kMarkChunks; ++ch) {
-    const int64_t t0 = ((int64_t)blockIdx.x * kMarkChunks + ch) * kMarkThreads;
+    const int64_t t0 = (vb * kMarkChunks + ch) * kMarkThreads;
     const bool last = ch == kMarkChunks - 1 || t0 + kMarkThreads >= n * 27;
     // the neighbour rows of the chunk's origins: one coalesced read, then 8 LDS reads per lattice point
     const int64_t b0 = t0 / 27;
@@ -2183,6 +2178,8 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     }
     if (last) break;
   }
+  __syncthreads();
+  }
 }
 
 // DELTA = false: the streaming case (no TSDF prior): 8 table reads and a weighted sum, few registers -- it runs
@@ -2193,16 +2190,20 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
                                                        float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
-  if ((int64_t)blockIdx.x * 256 >= n * 27) return;
   // the neighbour rows of the block's origins: one coalesced read, then 8 LDS reads per lattice point
   __shared__ int s_nbr[(256 / 27 + 2) * 27];
-  const int64_t b0 = ((int64_t)blockIdx.x * 256) / 27;
+  // grid-stride over virtual workgroups vb (the launch is sized for the capacity, capped at 8 workgroups per CU: a
+  // frame that holds a fraction of it does not pay for tens of thousands of workgroups that only exit)
+  for (int64_t vb = blockIdx.x; vb * 256 < n * 27; vb += gridDim.x) {
+  if (vb != (int64_t)blockIdx.x) __syncthreads();   // s_nbr of the previous round is no longer read
+  const int64_t b0 = (vb * 256) / 27;
   for (int i = threadIdx.x; i < (256 / 27 + 2) * 27; i += 256) {
     const int64_t gidx = b0 * 27 + i;
     s_nbr[i] = gidx < n * 27 ? nbr_rows[gidx] : -1;
   }
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t = vb * 256 + threadIdx.x;
+  [&]() {
   if (t >= n * 27) return;
   const int64_t b = t / 27;
   const int p = (int)(t - b * 27);
@@ -2295,6 +2296,14 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   float o = ok ? acc : g.voxel_size;
   if (DELTA) o = __fadd_rn(o, dacc);
   out[t] = o;
+  }();
+  }
+}
+
+// grid of a grid-stride kernel: the blocks the work needs, at most `per_cu` per CU
+static unsigned capped_grid(int64_t blocks, int per_cu) {
+  const int64_t cap = (int64_t)(g_num_cus > 0 ? g_num_cus : 256) * per_cu;
+  return (unsigned)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
 }
 
 int g_fused_mark = -1;  // bnv_set_option("fused_mark"): 1 / 0 force, -1 (default): by the call's size
@@ -2575,7 +2584,7 @@ static int lattice_neighbors_impl(const bnv_volume_t* vol, const bnv_grid_t* gri
                        row_limit, ws.origin_stamp, epoch, n_dev, build_list ? (int32_t*)nullptr : ws.n_list);
     BNV_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_lattice_neighbors, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, stream, *vol, origins,
+  hipLaunchKernelGGL(k_lattice_neighbors, dim3(capped_grid((n * 27 + 255) / 256, 16)), dim3(256), 0, stream, *vol, origins,
                      n, weights, row_limit, (float)grid->min_pts_in_grid, ws.nbr_rows, ws.stamp, epoch,
                      build_list ? ws.list : (int32_t*)nullptr, ws.n_list, row_skip, ws.origin_stamp, n_dev,
                      (prestamped && !build_list) ? ws.n_list : (int32_t*)nullptr);
@@ -2599,7 +2608,7 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark<false>, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
+  hipLaunchKernelGGL(k_lattice_mark<false>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
                      ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, MarkFused{});
   BNV_LAUNCH_CHECK();
@@ -2629,7 +2638,7 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
   F.row_limit = row_limit;
   F.min_pts = (float)grid->min_pts_in_grid;
   F.nbr_rows_out = ws.nbr_rows;
-  hipLaunchKernelGGL(k_lattice_mark<true>, dim3((unsigned)((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks))),
+  hipLaunchKernelGGL(k_lattice_mark<true>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
                      dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n, ws.origin_stamp, epoch, ws.need_mask,
                      ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
@@ -2674,10 +2683,10 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
   bnv_sdf_delta_t d = {};
   if (delta) d = *delta;
   if (d.data)
-    hipLaunchKernelGGL(k_lattice_blend<true>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(k_lattice_blend<true>, dim3(capped_grid((n * 27 + 255) / 256, 8)), dim3(256), 0,
                        (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   else
-    hipLaunchKernelGGL(k_lattice_blend<false>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(k_lattice_blend<false>, dim3(capped_grid((n * 27 + 255) / 256, 8)), dim3(256), 0,
                        (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;

@@ -3,6 +3,9 @@ sequence directory, periodic global optimisation, mesh extraction, final artefac
 
     python examples/run_e2e.py --data-dir DATA --scan-id scene3d/lounge --out OUT          # the reference's layout
     python examples/run_e2e.py --synthetic 24 --out /tmp/bnv_demo                          # writes a synthetic scene first
+    python examples/run_e2e.py --sweep 600 --grid 512 --decode-frames --pipelined --no-optimize --out /tmp/sweep
+                                                    # a moving-camera room sweep (bnv_fusion_amd/sequence.py), per-frame
+                                                    # SDF decode of the touched voxels, two frames in flight
 
 Frames are read from ``<data-dir>/<scan-id>/{depth/<i>.png, pose/T_wc_<i>.txt, pose/intr_mat_<i>.txt,
 pose/dimensions.txt}`` (bnv_fusion_amd/datasets.py), the volume extent comes from ``dimensions.txt`` exactly as in
@@ -35,6 +38,14 @@ def main():
     ap.add_argument("--no-optimize", action="store_true")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--sweep", type=int, default=0, help="write this many frames of the moving-camera room sweep "
+                                                          "(bnv_fusion_amd/sequence.py) and use them")
+    ap.add_argument("--grid", type=int, default=512, choices=[256, 512], help="--sweep: volume of the sweep")
+    ap.add_argument("--decode-frames", action="store_true",
+                    help="decode the SDF lattice of every frame's touched voxels (the unit of the benchmark metric)")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="with --decode-frames: two frames in flight (fuse_and_decode_async) instead of one "
+                         "synchronous call per frame")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = "cuda:0"
@@ -47,11 +58,30 @@ def main():
                                 [synthetic.depth_u16(t, H, W) for t in range(args.synthetic)],
                                 synthetic.intrinsics(H, W), [synthetic.pose(t) for t in range(args.synthetic)],
                                 [dims] * 3)
+    if args.sweep:
+        from bnv_fusion_amd import sequence
+        args.data_dir = args.data_dir or os.path.join(args.out, "data")
+        args.scan_id = "sweep/room"
+        dims_m, args.voxel_size, scale = sequence.DIMS[args.grid]
+        datasets.write_sequence(args.data_dir, args.scan_id,
+                                (sequence.depth_u16(t, scale=scale, device=dev).cpu().numpy() for t in range(args.sweep)),
+                                sequence.intrinsics(), (sequence.sweep_pose(t, scale) for t in range(args.sweep)),
+                                [dims_m] * 3, filter_type=0, level=1)
     data = datasets.FusionInferenceDataset(args.data_dir, args.scan_id, skip_images=args.skip_images, device=dev)
     model = bnv.load_pretrained(device=dev, voxel_size=args.voxel_size, tiny_cuda=args.tiny_cuda)
     nm = bnv.NeuralMap(data.dimensions, args.voxel_size, model, capacity=1 << 20, device=dev, tsdf=True,
                        max_depth=data.max_depth)
     t_local = t_global = 0.0
+    if args.decode_frames:
+        # the per-frame loop of the benchmark metric: fuse + decode of the touched voxels, synchronous or pipelined
+        from bnv_fusion_amd import sequence
+        nm.volume.reset(100000)                  # the reference's initial capacity: the tables grow on demand
+        st = sequence.run(nm, data, pipelined=args.pipelined, in_flight=2, checksums=False,
+                          on_frame=lambda k, fr, c, s: nm.frames.append(fr))
+        print(f"fused + decoded {st['frames']} frames ({st['empty_frames']} without a point inside the volume) at "
+              f"{st['frames'] / st['seconds']:.1f} frames/s incl. file reading; {nm.volume.num_rows()} voxels")
+        data = []
+        t_local = st["seconds"]
     for idx, frame in enumerate(data):                                   # run_e2e.py:243-279
         t0 = time.perf_counter()
         nm.integrate(frame)

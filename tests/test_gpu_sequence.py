@@ -182,3 +182,26 @@ def test_two_thousand_frame_sweep_sync_equals_pipelined(tmp_path):
         assert err <= SDF_TOL and mask_equal, (k, err)
     assert max(l for _, _, _, l in checks) > 0.2                           # the decode is live
     assert torch.cuda.max_memory_allocated(DEV) < 24e9                     # two 512^3 maps + their workspaces
+
+
+def test_run_e2e_example_sweep_pipelined(tmp_path, monkeypatch, capsys):
+    """examples/run_e2e.py --sweep: the room sweep written in the reference's on-disk layout, read back, fused and
+    decoded per frame with two frames in flight, meshed and saved (in-process: no exec from a GPU-initialised process)."""
+    import importlib.util
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("run_e2e_example", os.path.join(root, "examples", "run_e2e.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    monkeypatch.setattr(sys, "argv", ["run_e2e.py", "--sweep", "60", "--grid", "256", "--decode-frames", "--pipelined",
+                                      "--no-optimize", "--out", str(out)])
+    try:
+        mod.main()
+    finally:
+        import bnv_fusion_amd
+        bnv_fusion_amd.set_mlp_mode(1)
+    printed = capsys.readouterr().out
+    assert "fused + decoded 60 frames" in printed and "speed on local fusion" in printed
+    for f in ("before_optim.ply", "final.ply", "final_sparse_volume.pth", "room.npy"):
+        assert (out / f).exists(), f
