@@ -218,6 +218,38 @@ def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
             "front_end_s": t_front, "encode_s": t_enc, "integrate_s": t_int, "decode_s_scaled": t_dec}
 
 
+def oracle_lattice_check(volume, coords, sdf, tcnn=False, n_voxels=PARITY_VOXELS, seed=0, decode_again=None):
+    """SDF lattices the GPU decoded for ``n_voxels`` of ``coords`` against the CPU oracle's decode of the SAME volume
+    values (the voxels' 3x3x3 neighbourhoods are read back from the GPU volume -- for a shard: own + ghost rows).
+    Checker only.  -> dict like the line's `parity`."""
+    from oracle import bnv_oracle as orc           # checker only
+    sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+    geo = None
+    if tcnn:
+        geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
+            ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
+    dev = coords.device
+    voxel = volume.voxel_size
+    sel = torch.randperm(len(coords), generator=torch.Generator().manual_seed(seed))[:n_voxels].to(dev)
+    pick = coords[sel].cpu()
+    off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
+    nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
+    fo, wo, _ = volume.query(nbr.to(dev))
+    ovol = orc.OracleSparseVolume(8, voxel, np.asarray(volume.dimensions), 8)
+    present = wo[:, 0].cpu() > 0
+    ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
+                              geo=geo)[0, :, :, 0]
+    got = sdf[sel].cpu() if decode_again is None else decode_again(pick.to(dev)).cpu()
+    return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
+            "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
+            "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)),
+            "live_fraction_checked": float((ref != voxel).float().mean()),
+            "voxels_checked": int(len(pick)), "sdf_values_checked": int(ref.numel())}
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (a fresh
     process tree; this process has not touched the GPU and never will) and leave with the child's exit code."""
@@ -517,34 +549,10 @@ def run_bench(args, rank, world, dev, dist, backend):
     def parity_check(m, run):
         if not (rank == 0 and run["coords"] is not None):
             return None
-        from oracle import bnv_oracle as orc           # checker only
-        sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
-        geo = None
-        if tcnn:
-            geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(
-                ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.npz"))["nerf.model.params"])
-        g = run["coords"]
-        sel = torch.randperm(len(g), generator=torch.Generator().manual_seed(0))[:PARITY_VOXELS].to(g.device)
-        pick = g[sel].cpu()
-        off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
-        nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
-        fo, wo, _ = m.volume.query(nbr.to(dev))
-        ovol = orc.OracleSparseVolume(8, voxel, dims3, 8)
-        present = wo[:, 0].cpu() > 0
-        ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
-        torch.set_num_threads(min(32, os.cpu_count() or 1))
-        with torch.no_grad():
-            ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
-                                  geo=geo)[0, :, :, 0]
-        if run["kind"] != "frame":
-            got = run["sdf"][sel].cpu()     # the very output of the last timed frame (no extra launch)
-        else:                               # replicated volume has moved on: decode again from the current state
-            got = m.volume.decode_lattice(pick.to(dev), model.nerf, query_tensor=False).cpu()
-        return {"sdf_max_abs_err_vs_oracle": float((got - ref).abs().max()), "tolerance": 1e-4,
-                "oracle": "fp16 restatement of the tcnn layout (parity unpinned)" if tcnn else "pinned fp32 oracle",
-                "mask_decisions_equal": bool(torch.equal(got == voxel, ref == voxel)),
-                "live_fraction_checked": float((ref != voxel).float().mean()),
-                "voxels_checked": int(len(pick)), "sdf_values_checked": int(ref.numel())}
+        # frame-parallel: the replicated volume has moved on behind this rank's frame: decode again from its current state
+        again = (lambda pick: m.volume.decode_lattice(pick, model.nerf, query_tensor=False)) if run["kind"] == "frame" \
+            else None
+        return oracle_lattice_check(m.volume, run["coords"], run["sdf"], tcnn=tcnn, decode_again=again)
 
     def idx_of(fpu):
         first = args.preroll + args.warmup * fpu
@@ -787,7 +795,11 @@ def run_bench(args, rank, world, dev, dist, backend):
         # ---- a long moving-camera sequence: the surrogate of BASELINE configs 0 / 2 / 4 (datasets absent) ----------
         if args.sequence_frames and args.input == "depth":
             from bnv_fusion_amd import sequence
-            extras["sequence"] = sequence.bench_pass(model, dev, args.sequence_frames, tcnn=tcnn)
+            def seq_check(nm_s, c, sdf_s):
+                r = oracle_lattice_check(nm_s.volume, c, sdf_s, tcnn=tcnn, n_voxels=256)
+                return r["sdf_max_abs_err_vs_oracle"], r["mask_decisions_equal"], r["live_fraction_checked"]
+
+            extras["sequence"] = sequence.bench_pass(model, dev, args.sequence_frames, check=seq_check)
 
     m = args.mlp_mode
     peak = PEAK_TFLOPS[m]

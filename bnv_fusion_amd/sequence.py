@@ -11,7 +11,8 @@ volume, looking back into it (frames that are partly inside) or out of it (16 % 
 inside: the reference's `None` path, run_e2e.py:91-92).  Over 2,000 frames the map grows to > 1 M rows from the reference's initial 100,000-row tables.
 
 ``sweep_frames`` yields the frame dicts NeuralMap takes; ``run`` drives a map over a frame source synchronously or
-pipelined and returns per-frame checksums + statistics; ``bench_pass`` is bench.py's `sequence` entry.
+pipelined and returns per-frame checksums + statistics; ``bench_pass`` is bench.py's `sequence` entry (its periodic
+checks against the CPU checker are the caller's: nothing here knows about it).
 """
 import math
 import time
@@ -166,39 +167,12 @@ def run(nm, frames, pipelined=True, in_flight=2, on_frame=None, checksums=True, 
     return {"frames": k_done, "empty_frames": empty, "rows": rows, "capacity": caps, "sums": sums, "seconds": dt}
 
 
-def oracle_check(nm, coords, sdf, model_is_tcnn=False, n_voxels=512, seed=0):
-    """SDF lattices of ``n_voxels`` of a frame's voxels against the CPU oracle's decode of the same volume values
-    (checker only: imports oracle/).  -> (max abs err, mask decisions equal, live fraction)."""
-    import os
-    from oracle import bnv_oracle as orc
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sd = orc.load_weights(os.path.join(root, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
-    geo = None
-    if model_is_tcnn:
-        geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(root, "bnv_fusion_amd", "weights",
-                                                                 "pointnet_tcnn.npz"))["nerf.model.params"])
-    v = nm.volume
-    sel = torch.randperm(len(coords), generator=torch.Generator().manual_seed(seed))[:n_voxels].to(coords.device)
-    pick = coords[sel].cpu()
-    off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
-    nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
-    fo, wo, _ = v.query(nbr.to(coords.device))
-    ovol = orc.OracleSparseVolume(8, v.voxel_size, np.asarray(v.dimensions), 8)
-    present = wo[:, 0].cpu() > 0
-    ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
-    with torch.no_grad():
-        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
-                              geo=geo)[0, :, :, 0]
-    got = sdf[sel].cpu()
-    voxel = np.float32(v.voxel_size)
-    return (float((got - ref).abs().max()), bool(torch.equal(got == voxel, ref == voxel)),
-            float((ref != voxel).float().mean()))
-
-
-def bench_pass(model, dev, n_frames, tcnn=False, grid=512, check_every=200):
+def bench_pass(model, dev, n_frames, check=None, grid=512, check_every=200):
     """bench.py's `sequence` entry: ``n_frames`` of the sweep through a NeuralMap that starts at the reference's
     initial capacity (sparse_volume.py:486: 100,000 rows) and grows on demand, two frames in flight, TSDF side fusion
-    on; frames are rendered on the GPU ahead of the timed loop (resident inputs, like the headline)."""
+    on; frames are rendered on the GPU ahead of the timed loop (resident inputs, like the headline).
+    ``check(nm, coords, sdf) -> (max abs err, mask decisions equal, live fraction)``: the caller's checker (bench.py:
+    its CPU checker), run every ``check_every`` frames with the pipeline drained."""
     import bnv_fusion_amd as bnv
     dims, voxel, scale = DIMS[grid]
     frames = list(sweep_frames(range(n_frames), scale=scale, device=dev))
@@ -207,11 +181,12 @@ def bench_pass(model, dev, n_frames, tcnn=False, grid=512, check_every=200):
     checks = []
 
     def on_check(k, fr, c, s):
-        checks.append((k,) + oracle_check(nm, c, s, tcnn, n_voxels=256))
+        if check is not None:
+            checks.append((k,) + tuple(check(nm, c, s)))
 
     torch.cuda.reset_peak_memory_stats(dev)
     run(nm, frames, pipelined=True, in_flight=2, checksums=False, check_every=check_every, on_check=on_check)
-    # (the oracle checks run on the host inside the loop: time the loop again without them for the rate)
+    # (the periodic checks run on the host inside the loop: time the loop again without them for the rate)
     nm2 = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=100000, device=dev, tsdf=True)
     nm2.inputs_resident = True
     st2 = run(nm2, frames, pipelined=True, in_flight=2, checksums=False)
@@ -225,5 +200,5 @@ def bench_pass(model, dev, n_frames, tcnn=False, grid=512, check_every=200):
             "empty_frames": st2["empty_frames"], "rows_end": rows_end, "row_capacity_end": caps[-1] if caps else None,
             "growth_steps": int(sum(1 for a, b in zip(caps, caps[1:]) if b > a)),
             "peak_device_memory_mb": torch.cuda.max_memory_allocated(dev) / 1e6,
-            "oracle_checks": [{"frame": k, "sdf_max_abs_err": e, "mask_decisions_equal": m, "live_fraction": l}
+            "parity_checks": [{"frame": k, "sdf_max_abs_err": e, "mask_decisions_equal": m, "live_fraction": l}
                               for k, e, m, l in checks]}

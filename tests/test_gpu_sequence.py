@@ -22,6 +22,35 @@ SDF_TOL = 1e-4
 FEAT_TOL = 1e-4
 
 
+def _oracle_check(nm, coords, sdf, model_is_tcnn=False, n_voxels=512, seed=0):
+    """SDF lattices of ``n_voxels`` of a frame's voxels against the CPU oracle's decode of the same volume values
+    (checker only: imports oracle/).  -> (max abs err, mask decisions equal, live fraction)."""
+    from oracle import bnv_oracle as orc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sd = orc.load_weights(os.path.join(root, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+    geo = None
+    if model_is_tcnn:
+        geo = orc.tcnn_geo_forward(orc.load_weights(os.path.join(root, "bnv_fusion_amd", "weights",
+                                                                 "pointnet_tcnn.npz"))["nerf.model.params"])
+    v = nm.volume
+    sel = torch.randperm(len(coords), generator=torch.Generator().manual_seed(seed))[:n_voxels].to(coords.device)
+    pick = coords[sel].cpu()
+    off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)])
+    nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
+    fo, wo, _ = v.query(nbr.to(coords.device))
+    ovol = orc.OracleSparseVolume(8, v.voxel_size, np.asarray(v.dimensions), 8)
+    present = wo[:, 0].cpu() > 0
+    ovol.insert(nbr[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
+    with torch.no_grad():
+        ref = ovol.decode_pts(orc.lattice_coords(pick.numpy()), sd, None, is_coords=True, query_tensor=False,
+                              geo=geo)[0, :, :, 0]
+    got = sdf[sel].cpu()
+    voxel = np.float32(v.voxel_size)
+    return (float((got - ref).abs().max()), bool(torch.equal(got == voxel, ref == voxel)),
+            float((ref != voxel).float().mean()))
+
+
+
 def _sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -161,7 +190,7 @@ def test_two_thousand_frame_sweep_sync_equals_pipelined(tmp_path):
             while pend:
                 c, s = collect(*pend.pop(0))
             if c is not None:
-                checks.append((k,) + sequence.oracle_check(pipe, c, s, n_voxels=512))
+                checks.append((k,) + _oracle_check(pipe, c, s, n_voxels=512))
     while pend:
         collect(*pend.pop(0))
     assert sums_sync == sums_pipe                            # every frame, coords and SDF lattices, bit for bit
