@@ -1426,15 +1426,21 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
   const uint32_t fl = sl < n ? flags(sl) : 0u;
   int id = 0, c = 0;
   long long a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // sharded encode: 1 / world of the touched voxels are this rank's; the accumulators of the others were never
+  // written (count 0), so their 64-byte rows are neither read nor cleaned
+  bool dirty = false;
   if (sl < n) {
     id = ids[sl];
     c = counts[sl];
-    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    dirty = g.shard_world <= 1 || c != 0;
+    if (dirty) {
+      typedef long long i64x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const i64x2 v = *(const i64x2*)&acc[sl * 8 + 2 * q];
-      a8[2 * q] = v[0];
-      a8[2 * q + 1] = v[1];
+      for (int q = 0; q < 4; ++q) {
+        const i64x2 v = *(const i64x2*)&acc[sl * 8 + 2 * q];
+        a8[2 * q] = v[0];
+        a8[2 * q + 1] = v[1];
+      }
     }
   }
   uint32_t total;
@@ -1491,8 +1497,8 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     out_grid[(size_t)run * 3 + 2] = z;
   }
   // leave the scratch clean for the next frame
-  counts[sl] = 0;
-  {
+  if (dirty) {
+    counts[sl] = 0;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const i64x2 z2 = {0, 0};
 #pragma unroll

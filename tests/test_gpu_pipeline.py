@@ -261,3 +261,21 @@ def test_volume_without_dense_row_index(bnv):
     assert float((outs[0] != voxel).float().mean()) > 0.05
     n = vols[0].num_rows()
     assert vols[1].num_rows() == n and torch.equal(vols[0]._features[:n], vols[1]._features[:n])
+
+
+def test_side_streams_are_verified_to_overlap():
+    """streams.concurrent_stream hands out a stream that a spin-kernel test has shown to run beside the caller's; two
+    streams forced onto one hardware queue are told apart by the same test."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib, streams
+    lib = _lib.require_device(0)
+    main = torch.cuda.current_stream()
+    s = streams.concurrent_stream(DEV, main)
+    assert s.cuda_stream != main.cuda_stream and s.bnv_concurrent
+    ok, one, two = streams._overlaps(lib, main, s)
+    assert ok and two < 1.6 * one
+    same, one2, two2 = streams._overlaps(lib, main, main)          # the same stream: strictly one after the other
+    assert not same and two2 > 1.8 * one2
+    assert lib.bnv_probe_spin(0, 10, None) != 0 and lib.bnv_probe_spin(1, -1, None) != 0      # bad arguments are refused
+    t = streams.concurrent_stream(DEV, main, exclude=(s,))
+    assert t.cuda_stream not in (main.cuda_stream, s.cuda_stream)
