@@ -279,3 +279,40 @@ def test_side_streams_are_verified_to_overlap():
     assert lib.bnv_probe_spin(0, 10, None) != 0 and lib.bnv_probe_spin(1, -1, None) != 0      # bad arguments are refused
     t = streams.concurrent_stream(DEV, main, exclude=(s,))
     assert t.cuda_stream not in (main.cuda_stream, s.cuda_stream)
+
+
+def test_frame_pipe_integrate_only_frames_and_tsdf_prior(bnv):
+    """FramePipe with frames that are only fused (decode=False: run_e2e.py's integrate) followed by frames decoded WITH
+    the TSDF prior (sdf_delta, sparse_volume.py:819-832) and a smaller frame in between: equal to NeuralMap."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(12, hw=(240, 320))
+    small = _frames(1, hw=(120, 160), start=5)[0]
+    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV, tsdf=True)
+    vol = bnv.SparseVolume(8, voxel, dims3, 8, device=DEV)
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=3, tsdf_vol=None)
+    for fr in frames[:8]:                                  # fuse only
+        ref_c = ref_nm.integrate(fr)
+        s = pipe.begin(fr)
+        pipe.bound(s)
+        pipe.upsert(s, decode=False)
+        pipe.finish(s)
+        c, sdf = pipe.outputs(s, pipe.result(s))
+        assert sdf is None and torch.equal(c, ref_c)
+    delta = ref_nm.prepare_tsdf_volume()                   # [1, 1, X, Y, Z] prior from the 8 fused frames
+    ref_nm.sdf_delta = delta
+    pipe.sdf_delta = delta
+    for fr in frames[8:10] + [small] + frames[10:]:
+        rc, rs = ref_nm.fuse_and_decode(fr)
+        s = pipe.begin(fr)
+        pipe.bound(s)
+        pipe.upsert(s, decode=True)
+        pipe.finish(s)
+        c, sdf = pipe.outputs(s, pipe.result(s))
+        assert torch.equal(c, rc) and torch.equal(sdf, rs)
+    assert float((rs != voxel).float().mean()) > 0.05
+    plain = ref_nm.volume.decode_lattice(rc, model.nerf, None, query_tensor=False)
+    assert not torch.equal(plain, rs)                      # the prior does change the decode
