@@ -2166,11 +2166,11 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
 #endif
     const int cnt = s_count;
     if (cnt > 0 && (last || cnt > kMarkBuf - 8 * kMarkThreads)) {   // flush (block-uniform)
-      if (threadIdx.x == 0) {
-        s_base = atomicAdd(n_entries, cnt);
-        s_count = 0;
-      }
+      if (threadIdx.x == 0) s_base = atomicAdd(n_entries, cnt);
       __syncthreads();
+      // (only now has every wave read s_count above: resetting it next to the atomicAdd let a late wave see 0, skip
+      // the flush and fall out of step with the workgroup's barriers)
+      if (threadIdx.x == 0) s_count = 0;
       const int base = s_base;
       for (int i = threadIdx.x; i < cnt; i += kMarkThreads)
         if (base + i < entry_capacity) entries[base + i] = s_buf[i];
