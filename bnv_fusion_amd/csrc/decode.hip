@@ -2449,6 +2449,10 @@ int bnv_set_option(const char* name, int value) {
     g_tcnn_block_encoder = value != 0;
     return BNV_OK;
   }
+  if (!strcmp(name, "tcnn_shared_table")) {
+    g_tcnn_shared_table = value != 0;
+    return BNV_OK;
+  }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value >= g_num_cus) return BNV_ERR_INVALID_ARGUMENT;
     g_reserve_cus = value;

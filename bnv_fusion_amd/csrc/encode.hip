@@ -32,6 +32,7 @@ namespace bnv {
 int g_num_cus = 0;
 int g_last_hip_error = 0;
 int g_reserve_cus = 0;  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
+int g_tcnn_shared_table = 1;    // bnv_set_option("tcnn_shared_table"): 1 = one LDS table per workgroup and 16 x 16 patch, 0 = per wave and block
 int g_tcnn_block_encoder = 1;  // bnv_set_option("tcnn_block_encoder"): 1 = k_pointnet_scatter_tb for whole frames
 int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
 
@@ -1205,56 +1206,90 @@ __global__ __launch_bounds__(256) void k_pointnet_scatter_t(
 // (366 MB of write traffic tallied at 64 B each) = 0.31 ms whatever the weights, against 0.22 ms without them
 // (profiles/r02_power_probe.txt, r02_bench_line_tcnn.json).  Here a wave's unit of work is a BLOCK of 32 points --
 // 8 x 4 pixels of the depth image when the frame's width is known, else 32 consecutive points -- with all EIGHT
-// corner tiles of those points, and the per-voxel sums of a block are formed in a wave-private LDS table:
-//  * a 2.3 x 1.2 cm pixel patch with its 8 corners touches ~20 voxels, each ~13 times: the table (64 entries:
-//    slot, count, 8 x i64; open addressing on slot & 63, LDS compare-and-swap) takes the run sums of the eight tiles
-//    with LDS atomics and is flushed once per block -- ~4x fewer global atomics than the per-tile run sums, ~13x fewer
-//    than one per pair; sums are integers, so the result is bit-identical to any other order.  A table that is full
-//    (cannot happen on surfaces; 64 distinct voxels in one block) falls back to global atomics for that run;
+// corner tiles of those points, and the per-voxel sums are formed in an LDS table before they go to the global
+// accumulators (sums are integers: bit-identical in any order):
 //  * the point is loaded and voxelised ONCE for its eight corners (3 + 6 IEEE divisions per point instead of 48:
 //    the relative coordinate of an axis has two values, floor and ceil) and the 16 bitmap / prefix words of the
 //    eight corners are requested together;
-//  * no barrier: tables are per wave.  512 threads share one copy of the weights (22.5 KB) + 8 tables (36.9 KB):
-//    two workgroups per CU, four waves per SIMD as before.
+//  * the table (slot, count, 8 x i64; open addressing on a multiplicative hash of the slot, LDS compare-and-swap,
+//    kAccProbes probes, then the run goes to the global accumulators itself) takes the run sums of the eight tiles
+//    with LDS atomics.  How much that saves depends on the patch it covers -- measured on the bench frame (134 k
+//    touched voxels): an 8 x 4 patch with its corners touches 40 voxels (383 k table entries per frame, each
+//    flushed with 9 atomics), 8 x 8: 61 (295 k), 16 x 16: 173 (208 k), 32 x 16: 310 (186 k);
+//  * SHARED = false (r03 first version): one 64-entry table per wave, flushed per block, no barrier;
+//    SHARED = true: the workgroup's 8 waves take the 8 blocks of a 16 x 16 patch and share ONE 512-entry table,
+//    flushed by all threads behind a barrier: 46 % fewer flushed entries for two barriers per patch.
+//  512 threads share one copy of the weights (22.5 KB) + 36.9 KB of tables: two workgroups per CU.
 // Sharded encodes (owned-pair list) keep k_pointnet_scatter_t.
 // ------------------------------------------------------------------------------------------
-constexpr int kAccCap = 64;
-struct WaveAcc {
+constexpr int kAccProbes = 6;     // probes before a run goes to the global accumulators instead
+constexpr int kTbWaves = 8;       // waves per workgroup = blocks per 16 x 16 patch
+constexpr int kAccCap = 64 * kTbWaves;
+struct WgAcc {
   int key[kAccCap];
   int cnt[kAccCap];
   unsigned long long sum[kAccCap][8];
 };
 
-__global__ __launch_bounds__(512) void k_pointnet_scatter_tb(
+template <bool SHARED>
+__global__ __launch_bounds__(64 * kTbWaves) void k_pointnet_scatter_tb(
     const float* __restrict__ pts, int n_points, int frame_w, bnv_grid_t g, const float* __restrict__ wpack,
     const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ word_prefix, int32_t* __restrict__ counts,
     long long* __restrict__ acc) {
   __shared__ __attribute__((aligned(16))) _Float16 wh[PT_TOTAL];
-  __shared__ WaveAcc tabs[8];
+  __shared__ WgAcc T;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  WaveAcc& T = tabs[wave];
-  T.key[lane] = -1;
-  T.cnt[lane] = 0;
+  // the table region this wave inserts into: all of it, or its own 64 entries
+  constexpr int kSpan = SHARED ? kAccCap : 64;
+  constexpr int kHashShift = SHARED ? 32 - 9 : 32 - 6;
+  static_assert(kAccCap == 512, "hash width");
+  const int t_base = SHARED ? 0 : wave * 64;
+  T.key[threadIdx.x] = -1;
+  T.cnt[threadIdx.x] = 0;
 #pragma unroll
-  for (int f = 0; f < 8; ++f) T.sum[lane][f] = 0ull;
-  stage_to_lds<512>(wpack, wh, PT_TOTAL * 2);
+  for (int f = 0; f < 8; ++f) T.sum[threadIdx.x][f] = 0ull;
+  stage_to_lds<64 * kTbWaves>(wpack, wh, PT_TOTAL * 2);
   __syncthreads();
   const int j = lane & 31, h = lane >> 5;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
-  // blocks: 8 x 4 pixel patches of a frame_w-wide image, or runs of 32 points
+  // blocks: 8 x 4 pixel patches of a frame_w-wide image, or runs of 32 points; a workgroup's 8 waves take the 2 x 4
+  // blocks of a 16 x 16 patch (SHARED) or 8 consecutive blocks
   const bool image = frame_w > 0 && n_points % frame_w == 0;
   const int frame_h = image ? n_points / frame_w : 1;
-  const int bw = image ? (frame_w + 7) >> 3 : 0;
-  const int n_blocks = image ? bw * ((frame_h + 3) >> 2) : (n_points + 31) >> 5;
-  for (int b = blockIdx.x * 8 + wave; b < n_blocks; b += gridDim.x * 8) {
+  const int bw = image ? (frame_w + 7) >> 3 : 0, bh = image ? (frame_h + 3) >> 2 : 0;
+  const int n_blocks = image ? bw * bh : (n_points + 31) >> 5;
+  const int uw = (bw + 1) >> 1;
+  const int n_units = (SHARED && image) ? uw * ((bh + 3) >> 2) : (n_blocks + kTbWaves - 1) / kTbWaves;
+  // entry e of the table goes to the global accumulators and is empty again
+  auto flush_entry = [&](int e) {
+    const int key = T.key[e];
+    if (key >= 0) {
+      unsigned long long* dst = (unsigned long long*)acc + (uint32_t)key * 8u;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        atomicAdd(dst + f, T.sum[e][f]);
+        T.sum[e][f] = 0ull;
+      }
+      atomicAdd(&counts[key], T.cnt[e]);
+      T.key[e] = -1;
+      T.cnt[e] = 0;
+    }
+  };
+  for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
     int i = -1;
-    if (image) {
+    if (SHARED && image) {
+      const int uy = u / uw, ux = u - uy * uw;
+      const int by = uy * 4 + (wave >> 1), bx = ux * 2 + (wave & 1);
+      const int x = bx * 8 + (j & 7), y = by * 4 + (j >> 3);
+      if (bx < bw && x < frame_w && y < frame_h) i = y * frame_w + x;
+    } else if (image) {
+      const int b = u * kTbWaves + wave;
       const int by = b / bw, bx = b - by * bw;
       const int x = bx * 8 + (j & 7), y = by * 4 + (j >> 3);
-      if (x < frame_w && y < frame_h) i = y * frame_w + x;
-    } else if (b * 32 + j < n_points) {
-      i = b * 32 + j;
+      if (b < n_blocks && x < frame_w && y < frame_h) i = y * frame_w + x;
+    } else if ((u * kTbWaves + wave) * 32 + j < n_points) {
+      i = (u * kTbWaves + wave) * 32 + j;
     }
     bool valid = false;
     float px = 0.f, py = 0.f, pz = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
@@ -1263,7 +1298,7 @@ __global__ __launch_bounds__(512) void k_pointnet_scatter_tb(
       px = p[0], py = p[1], pz = p[2], n0 = p[3], n1 = p[4], n2 = p[5];
       valid = in_bounds(px, py, pz, g);
     }
-    if (__ballot(valid) == 0ULL) continue;
+    if (__ballot(valid) != 0ULL) {
     // voxelisation of the point, once for its eight corners
     int lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
     _Float16 rl[3], rh[3];     // relative coordinate of an axis towards its floor / ceil voxel, as the network takes it
@@ -1350,21 +1385,23 @@ __global__ __launch_bounds__(512) void k_pointnet_scatter_tb(
       int len;
       tile_run_sums(o, slot, j, h, v, is_end, len);
       if (slot >= 0 && is_end) {
-        // the run's sums into the wave's table (both halves of a pair probe the same way and meet in the same entry)
-        int p = slot & (kAccCap - 1), found = -1;
-        for (int probe = 0; probe < kAccCap; ++probe) {
-          const int old = atomicCAS(&T.key[p], -1, slot);
+        // the run's sums into the table (both halves of a pair probe the same way and meet in the same entry).
+        // Slots are ranks of ascending voxel ids -- a z-run of voxels is a run of slots: the multiplicative hash
+        // keeps the runs of different rows from piling into one probe chain
+        int p = (int)(((uint32_t)slot * 0x9E3779B1u) >> kHashShift), found = -1;
+        for (int probe = 0; probe < kAccProbes; ++probe) {
+          const int old = atomicCAS(&T.key[t_base + p], -1, slot);
           if (old == -1 || old == slot) {
-            found = p;
+            found = t_base + p;
             break;
           }
-          p = (p + 1) & (kAccCap - 1);
+          p = (p + 1) & (kSpan - 1);
         }
         if (found >= 0) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) atomicAdd(&T.sum[found][4 * h + q], v[q]);
           if (h == 0) atomicAdd(&T.cnt[found], len);
-        } else {   // table full: straight to the global accumulators
+        } else {   // no room within kAccProbes probes: straight to the global accumulators
           unsigned long long* dst = (unsigned long long*)acc + ((uint32_t)slot * 8u + 4u * (uint32_t)h);
 #pragma unroll
           for (int q = 0; q < 4; ++q) atomicAdd(dst + q, v[q]);
@@ -1372,18 +1409,13 @@ __global__ __launch_bounds__(512) void k_pointnet_scatter_tb(
         }
       }
     }
-    // flush: one entry per lane; the table is empty again for the next block
-    const int key = T.key[lane];
-    if (key >= 0) {
-      unsigned long long* dst = (unsigned long long*)acc + (uint32_t)key * 8u;
-#pragma unroll
-      for (int f = 0; f < 8; ++f) {
-        atomicAdd(dst + f, T.sum[lane][f]);
-        T.sum[lane][f] = 0ull;
-      }
-      atomicAdd(&counts[key], T.cnt[lane]);
-      T.key[lane] = -1;
-      T.cnt[lane] = 0;
+    }
+    if constexpr (SHARED) {
+      __syncthreads();            // every wave's runs are in the table
+      flush_entry(threadIdx.x);
+      __syncthreads();            // the table is empty before the next patch inserts
+    } else {
+      flush_entry(t_base + lane);
     }
   }
 }
@@ -1734,8 +1766,10 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
     ProfScope prof(PROF_POINTNET, stream);
     if (g_mlp_mode == 2 && !plist && g_tcnn_block_encoder) {
       const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
-      const int grid_tb = g_num_cus * 2 < (n_blocks + 7) / 8 ? g_num_cus * 2 : (n_blocks + 7) / 8;
-      hipLaunchKernelGGL(k_pointnet_scatter_tb, dim3(grid_tb), dim3(512), 0, stream, input_pts, n, image_width, g,
+      const int n_units = (n_blocks + kTbWaves - 1) / kTbWaves + 64;   // (16 x 16 patches: up to ragged edges)
+      const int grid_tb = g_num_cus * 2 < n_units ? g_num_cus * 2 : n_units;
+      auto kern = g_tcnn_shared_table ? k_pointnet_scatter_tb<true> : k_pointnet_scatter_tb<false>;
+      hipLaunchKernelGGL(kern, dim3(grid_tb), dim3(64 * kTbWaves), 0, stream, input_pts, n, image_width, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
     } else if (g_mlp_mode == 2)
       hipLaunchKernelGGL(k_pointnet_scatter_t, dim3(g_num_cus * 4 < (n_tiles + 3) / 4 ? g_num_cus * 4 : (n_tiles + 3) / 4),

@@ -119,6 +119,8 @@ int bnv_get_mlp_mode(void);
  *                  for calls of up to 49,152 voxels and in a launch of its own above; 1 / 0 force either.
  *   "tcnn_block_encoder"  1 (default): whole-frame encodes with the tiny-cuda-nn networks run k_pointnet_scatter_tb
  *                  (32-point blocks x 8 corners, per-wave LDS accumulation of the voxel sums); 0: the per-tile kernel.
+ *   "tcnn_shared_table"  1 (default): that kernel's 8 waves take the 8 blocks of a 16 x 16-pixel patch and sum them in
+ *                  ONE LDS table per workgroup (flushed behind a barrier); 0: one table per wave, flushed per block.
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside

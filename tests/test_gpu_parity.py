@@ -696,15 +696,36 @@ def test_tcnn_checkpoint_encode_decode_vs_oracle(bnv, orc):
         # and the 32-point-block encoder against the per-tile one
         pts = torch.from_numpy(z["frames"][3]).to(DEV)
         enc_out = []
-        for opt in (1, 0):
+        for opt, shared in ((1, 1), (1, 0), (0, 1)):
             assert lib.bnv_set_option(b"tcnn_block_encoder", opt) == 0
+            assert lib.bnv_set_option(b"tcnn_shared_table", shared) == 0
             enc_out.append(model.encode_pointcloud(pts, nm.volume.n_xyz, nm.volume.min_coords, nm.volume.max_coords,
                                                    voxel, return_dense=False))
-        for a, b in zip(enc_out[0][:4], enc_out[1][:4]):
-            assert torch.equal(a, b)
+        for other in enc_out[1:]:
+            for a, b in zip(enc_out[0][:4], other[:4]):
+                assert torch.equal(a, b)
+        # ... and from depth images (the block encoder's 16 x 16-pixel patches / 8 x 4 blocks), ragged sizes included
+        from bnv_fusion_amd import synthetic
+        v = nm.volume
+        for hw in ((480, 640), (75, 100), (37, 53), (16, 16), (5, 9), (1, 1)):
+            depth = torch.from_numpy(synthetic.depth_u16(7, *hw)).to(DEV)
+            enc_out = []
+            for opt, shared in ((1, 1), (1, 0), (0, 1)):
+                assert lib.bnv_set_option(b"tcnn_block_encoder", opt) == 0
+                assert lib.bnv_set_option(b"tcnn_shared_table", shared) == 0
+                feats, pcounts, _, grid_ids, counters, _, _ = model.encode_depth_async(
+                    depth, synthetic.intrinsics(*hw), synthetic.pose(7), 3.0, v.n_xyz, v.min_coords, v.max_coords,
+                    voxel)
+                n_out = int(counters[2])
+                enc_out.append((feats[:n_out].clone(), pcounts[:n_out].clone(), grid_ids[:n_out].clone(),
+                                counters.clone()))
+            for other in enc_out[1:]:
+                for a, b in zip(enc_out[0], other):
+                    assert torch.equal(a, b), hw
     finally:
         lib.bnv_set_option(b"lattice_pipe", 1)
         lib.bnv_set_option(b"tcnn_block_encoder", 1)
+        lib.bnv_set_option(b"tcnn_shared_table", 1)
     # a tcnn model and an fp32 model can alternate in one process (the MLP mode follows the model)
     m32 = bnv.load_pretrained(device=DEV, voxel_size=voxel)
     a = m32.encode_pointcloud(torch.from_numpy(z["frames"][0]).to(DEV), nm.volume.n_xyz, nm.volume.min_coords,
