@@ -1992,9 +1992,19 @@ __global__ __launch_bounds__(256) void k_lattice_neighbors(bnv_volume_t v, const
   }
 }
 
-// One thread per lattice point (origin b, offset d): if all 8 corner voxels are usable (the point is
-// LIVE), flags the 8 (row, l) table entries it reads; the first thread to flag an entry appends it to
-// the MLP work list.  Entries of masked points are never evaluated.
+// One thread per lattice point P = b + d / 2 (origin b, offset d): if all 8 corner voxels are usable (the point is
+// LIVE), the (row, l) table entries it reads -- one per DISTINCT corner voxel c, l = the offset of P inside c -- go
+// to the MLP work list, each exactly once.  Entries of masked points are never evaluated.
+// An entry (row, l) names one physical point, and whether that point is live depends on the point alone.  So
+//  * the entry of P in the origin's OWN row is appended by this thread, unconditionally: no other thread appends it;
+//  * the entries in other corner rows that are ORIGINS of this call are left to those origins (P is one of their
+//    27 points too, and they see the same live decision);
+//  * entries in corner rows that are not decoded in this call (the fringe of the frame) belong to the origin
+//    floor(P) if that voxel is decoded here; only if it is not are they contended: the first thread to flag
+//    (row, l) in need_mask appends it.
+// Both decisions are bit tests on two 27-bit masks per origin (usable neighbours, neighbours that are origins),
+// cut out of the ballots of the staging loop.  (Until r03 every corner entry of a shared point went through a
+// returning global atomicOr, and an owner rule decided which origin handled a shared point: 35 us.)
 // A workgroup walks kMarkChunks chunks of 1,024 lattice points and collects the new entries in LDS; they go to the
 // global list with ONE atomicAdd on the list counter per flush -- normally one per workgroup.  (Same-address
 // atomics serialise in the memory-side atomic unit at ~11 ns each, tools/probe_mark.hip: one per 1,024 points was
@@ -2039,39 +2049,48 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   __shared__ int s_buf[kMarkBuf];
   __shared__ int s_nbr[kMarkOrigins * 27];
   __shared__ int s_corner[216 + 27];
+  __shared__ uint32_t s_need[27];                              // the neighbours a lattice point's corners are
+  constexpr int kMarkWords = (kMarkOrigins * 27 + 63) / 64 + 1;
+  __shared__ unsigned long long s_ub[kMarkWords], s_ob[kMarkWords];   // bit i: s_nbr[i] usable / an origin of this call
 #if BNV_MARK_SCAN
   __shared__ uint32_t s_wave[kMarkThreads / 64];
 #endif
   __shared__ int s_count, s_base;
-  if (threadIdx.x < 216 + 27) {
-    if (threadIdx.x < 216) {
-      const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
-      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
-      int nbi = 0, li = 0, dup = 0;   // ceil == floor on an axis with d == 0: same entry as the floor corner
-      for (int a = 0; a < 3; ++a) {
-        int nb_a = 0, loc2 = 0;
-        if (d[a] != 0) {
-          if ((k >> a) & 1) {
-            nb_a = (d[a] + 1) / 2;
-            loc2 = -1;
-          } else {
-            nb_a = (d[a] - 1) / 2;
-            loc2 = 1;
-          }
-        } else if ((k >> a) & 1) {
-          dup = 1;
+  if (threadIdx.x < 216) {
+    const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
+    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    int nbi = 0, li = 0, dup = 0;   // ceil == floor on an axis with d == 0: same entry as the floor corner
+    for (int a = 0; a < 3; ++a) {
+      int nb_a = 0, loc2 = 0;
+      if (d[a] != 0) {
+        if ((k >> a) & 1) {
+          nb_a = (d[a] + 1) / 2;
+          loc2 = -1;
+        } else {
+          nb_a = (d[a] - 1) / 2;
+          loc2 = 1;
         }
-        nbi = nbi * 3 + (nb_a + 1);
-        li = li * 3 + (loc2 + 1);
+      } else if ((k >> a) & 1) {
+        dup = 1;
       }
-      s_corner[threadIdx.x] = nbi | (li << 5) | (dup << 10);
-    } else {
-      const int p = threadIdx.x - 216;
-      const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
-      s_corner[threadIdx.x] = (d[0] < 0 || d[1] < 0 || d[2] < 0)
-                                  ? ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)
-                                  : -1;
+      nbi = nbi * 3 + (nb_a + 1);
+      li = li * 3 + (loc2 + 1);
     }
+    s_corner[threadIdx.x] = nbi | (li << 5) | (dup << 10);
+  } else if (threadIdx.x < 216 + 27) {
+    // neighbour index of the voxel floor(P) if some offset of P is negative, else -1 (the origin itself)
+    const int p = threadIdx.x - 216;
+    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    s_corner[threadIdx.x] = (d[0] < 0 || d[1] < 0 || d[2] < 0)
+                                ? ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)
+                                : -1;
+  }
+  if (threadIdx.x < kMarkWords) s_ub[threadIdx.x] = s_ob[threadIdx.x] = 0ull;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    uint32_t m = 0;
+    for (int k = 0; k < 8; ++k) m |= 1u << (s_corner[threadIdx.x * 8 + k] & 31);
+    s_need[threadIdx.x] = m;
   }
   for (int64_t vb = blockIdx.x; vb * kMarkThreads * kMarkChunks < n * 27; vb += gridDim.x) {
   if (threadIdx.x == 0) s_count = 0;
@@ -2079,7 +2098,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   for (int ch = 0; ch < kMarkChunks; ++ch) {
     const int64_t t0 = (vb * kMarkChunks + ch) * kMarkThreads;
     const bool last = ch == kMarkChunks - 1 || t0 + kMarkThreads >= n * 27;
-    // the neighbour rows of the chunk's origins: one coalesced read, then 8 LDS reads per lattice point
+    // the neighbour rows of the chunk's origins: one coalesced read, then LDS
     const int64_t b0 = t0 / 27;
     for (int i = threadIdx.x; i < kMarkOrigins * 27; i += kMarkThreads) {
       const int64_t g = b0 * 27 + i;
@@ -2095,52 +2114,60 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         }
       }
       s_nbr[i] = r;
+      const unsigned long long bu = __ballot(r >= 0), bo = __ballot(r >= 0 && (r & kOriginBit));
+      if ((threadIdx.x & 63) == 0) {
+        s_ub[i >> 6] = bu;
+        s_ob[i >> 6] = bo;
+      }
     }
     __syncthreads();
     const int64_t t = t0 + threadIdx.x;
     int ent[8];
-    uint32_t keep = 0;    // bit k: corner k's entry is appended by this thread
+    uint32_t keep = 0;    // bit k: ent[k] is appended by this thread
     if (t < n * 27) {
       const int64_t b = t / 27;
       const int p = (int)(t - b * 27);
-      const int* nb27 = s_nbr + (int)(b - b0) * 27;
-      // corner k of lattice point p: neighbour index, local-offset index and the duplicate flag from a 216-entry
-      // table (the index arithmetic was most of this kernel's time)
-      int rowk[8], lk[8];
-      bool live = true;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int c = s_corner[p * 8 + k];     // nbi | li << 5 | dup << 10
-        const int row = nb27[c & 31];
-        if (row < 0) live = false;
-        rowk[k] = (c >> 10) ? -1 : (row & ~kOriginBit);
-        lk[k] = (c >> 5) & 31;
+      const int ob = (int)(b - b0);
+      const int* nb27 = s_nbr + ob * 27;
+      const int q = ob * 27, w = q >> 6, sh = q & 63;
+      unsigned long long xu = s_ub[w] >> sh, xo = s_ob[w] >> sh;
+      if (sh > 64 - 27) {
+        xu |= s_ub[w + 1] << (64 - sh);
+        xo |= s_ob[w + 1] << (64 - sh);
       }
-      // A lattice point is shared by up to 8 decoded voxels; if the voxel floor(point) is itself decoded in
-      // this call it flags the point's entries, everybody else skips (floor(point) is corner 0: a usable row).
-      // An entry (corner row, local offset) belongs to exactly ONE lattice point, so a point that is handled once
-      // needs no de-duplication: this voxel is the owner (all offsets >= 0, floor(point) == voxel) -> plain append.
-      // Only a point whose owner voxel is NOT decoded in this call can be reached from several voxels; those few go
-      // through the need_mask atomics.
-      const int dneg = s_corner[216 + p];        // owner's neighbour index if some offset is negative, else -1
-      bool shared = false;
-      if (live && dneg >= 0) {
-        const int owner = nb27[dneg];
-        if (owner >= 0 && (owner & kOriginBit)) live = false;
-        shared = true;
-      }
-      if (live) {
-        // the (few) shared points: all 8 atomics are issued before any result is looked at -- one memory round
-        // trip instead of eight dependent ones (every 1,024-thread workgroup holds some shared point, and a
-        // workgroup is as slow as its slowest thread)
-        uint32_t seen[8];
+      const uint32_t um = (uint32_t)xu & 0x7FFFFFFu, om = (uint32_t)xo & 0x7FFFFFFu, need = s_need[p];
+      if ((um & need) == need) {     // live
+        uint32_t rest = need & ~om;  // corner voxels nobody decodes in this call
+        if (!((rest >> 13) & 1u)) {  // the origin's own row (always, but for a caller's stale stamp array)
+          ent[0] = ((nb27[13] & ~kOriginBit) << 5) | p;     // P inside its origin: l = d
+          keep = 1u;
+        }
+        // Entries in rows that are not decoded here belong to the origin floor(P) when that voxel is decoded in
+        // this call (it is unique: no flag needed); else every origin that holds P asks need_mask
+        const int dneg = s_corner[216 + p];
+        const bool mine = dneg < 0;
+        if (rest && (mine || !((om >> dneg) & 1u))) {
+          // (rare) all atomics are issued before any result is looked at: one memory round trip, not up to eight
+          int rowk[8], lk[8];
+          uint32_t seen[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          seen[k] = (shared && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
+          for (int k = 0; k < 8; ++k) {
+            const int c = s_corner[p * 8 + k];     // nbi | li << 5 | dup << 10
+            rowk[k] = (!(c >> 10) && ((rest >> (c & 31)) & 1u)) ? (nb27[c & 31] & ~kOriginBit) : -1;
+            lk[k] = (c >> 5) & 31;
+          }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          ent[k] = (rowk[k] << 5) | lk[k];
-          if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) keep |= 1u << k;
+          for (int k = 0; k < 8; ++k)
+            seen[k] = (!mine && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
+          int at = (int)keep;
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) {
+              // (at most 8 distinct corners, the own row among them: at < 8)
+              ent[at & 7] = (rowk[k] << 5) | lk[k];
+              keep |= 1u << (at & 7);
+              ++at;
+            }
         }
       }
     }
@@ -2156,11 +2183,20 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     if (threadIdx.x == 0) s_count += (int)tot;
     __syncthreads();
 #else
-    if (keep) {
-      const int at = atomicAdd(&s_count, __popc(keep));
+    {
+      // ent[0] (nearly every live point has exactly this one): one LDS atomic per wave, places by ballot
+      const unsigned long long bal = __ballot(keep & 1u);
+      int base0 = 0;
+      if ((threadIdx.x & 63) == 0 && bal) base0 = atomicAdd(&s_count, __popcll(bal));
+      base0 = __builtin_amdgcn_readfirstlane(base0);
+      if (keep & 1u) s_buf[base0 + __popcll(bal & ((1ull << (threadIdx.x & 63)) - 1ull))] = ent[0];
+      const uint32_t extra = keep >> 1;      // (rare) entries in rows that are not decoded in this call
+      if (extra) {
+        const int at = atomicAdd(&s_count, __popc(extra));
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if ((keep >> k) & 1u) s_buf[at + __popc(keep & ((1u << k) - 1u))] = ent[k];
+        for (int k = 1; k < 8; ++k)
+          if ((extra >> (k - 1)) & 1u) s_buf[at + __popc(extra & ((1u << (k - 1)) - 1u))] = ent[k];
+      }
     }
     __syncthreads();
 #endif
