@@ -595,30 +595,49 @@ def run_bench(args, rank, world, dev, dist, backend):
     # N > 1: both decompositions, the one --parallelism names in `value`
     # =========================================================================================================
     if world > 1:
-        results = {}
-        for kind in kinds:
-            m = make_map(kind)
-            fpu = world if kind == "frame" else 1
-            drv.run(m, kind, list(range(-(-args.preroll // fpu) * fpu)), decode=False)     # setup: live decode mask
-            warm_idx, step_idx = idx_of(fpu)
-            run = timed(m, kind, args.mlp_mode, step_idx, warm_idx, preheat=min(args.preheat, 4 * POOL))
-            run["parity"] = parity_check(m, run)
-            extra = {}
-            if kind == "spatial":
-                extra = {"received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
-                         "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
-                             bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}
-            results[kind] = (run, extra)
-            per_rank = [None] * world
-            dist.all_gather_object(per_rank, {"frames": int(run["frames_this_rank"]), "voxels_per_frame": run["n_vox"],
-                                              "mlp_evals_last_frame": run["rows"]})
-            results[kind][1]["per_rank"] = per_rank
-            del m
-            model.shard = (0, 1, 3)
-            torch.cuda.empty_cache()
         names = [None] * world
         dist.all_gather_object(names, {"rank": rank, "device": torch.cuda.get_device_name(dev), "local_device": dev,
                                        "host": socket.gethostname()})
+        results, errors = {}, {}
+        for kind in kinds:
+            # A decomposition that raises on this rank (an argument the backend rejects, a capacity, ...) is reported
+            # and the other one still measured -- every rank votes, so that all of them skip it together.  A rank that
+            # hangs or dies is not survivable: the collective times out and the job ends non-zero (main()).
+            m, run, extra, err = None, None, {}, None
+            try:
+                if os.environ.get("BNV_BENCH_FAIL_KIND") == kind:        # (fault injection for the tests)
+                    raise RuntimeError("injected failure")
+                m = make_map(kind)
+                fpu = world if kind == "frame" else 1
+                drv.run(m, kind, list(range(-(-args.preroll // fpu) * fpu)), decode=False)     # setup: live decode mask
+                warm_idx, step_idx = idx_of(fpu)
+                run = timed(m, kind, args.mlp_mode, step_idx, warm_idx, preheat=min(args.preheat, 4 * POOL))
+                run["parity"] = parity_check(m, run)
+                if kind == "spatial":
+                    extra = {"received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
+                             "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
+                                 bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}
+            except Exception as e:       # noqa: BLE001 -- reported in the output line
+                import traceback
+                traceback.print_exc()
+                err = f"rank {rank}: {type(e).__name__}: {e}"
+            votes = [None] * world
+            dist.all_gather_object(votes, {"error": err, "frames": int(run["frames_this_rank"]) if run else 0,
+                                           "voxels_per_frame": run["n_vox"] if run else 0,
+                                           "mlp_evals_last_frame": run["rows"] if run else 0})
+            failed = [v["error"] for v in votes if v["error"]]
+            if failed:
+                errors[kind] = failed
+            else:
+                extra["per_rank"] = [{k: v[k] for k in ("frames", "voxels_per_frame", "mlp_evals_last_frame")}
+                                     for v in votes]
+                results[kind] = (run, extra)
+            del m
+            model.shard = (0, 1, 3)
+            torch.cuda.empty_cache()
+        if not results:
+            raise RuntimeError(f"every decomposition failed: {errors}")
+        kinds = [k for k in kinds if k in results]       # (the first one that ran is `value`)
         if rank != 0:
             return None
         DESCR = {"spatial": (f"active-voxel set sharded by spatial hash (8^3-voxel blocks) over {world} ranks; every "
@@ -661,6 +680,8 @@ def run_bench(args, rank, world, dev, dist, backend):
         })
         for kind in kinds[1:]:
             out["spatial_sharding" if kind == "spatial" else "frame_parallel"] = dist_entry(kind)
+        for kind, errs in errors.items():
+            out["spatial_sharding" if kind == "spatial" else "frame_parallel"] = {"error": errs}
         return out
 
     # =========================================================================================================
