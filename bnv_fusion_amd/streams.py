@@ -14,7 +14,6 @@ import torch
 from . import _lib
 
 _SPIN_CYCLES = 240_000         # ~115 us: long against the ~15 us a cross-stream event wait costs
-_picked = {}
 
 
 def _overlaps(lib, main, cand):

@@ -1449,3 +1449,87 @@ def test_encode_capacity_overflow_is_reported(bnv, model):
     assert int(counters[4]) != 0                                  # flagged
     if guard is not None:
         assert bool((guard[cap:] == -7.0).all())                  # nothing written past the capacity
+
+
+def test_noncubic_min_pts5_vs_reference_golden(bnv):
+    """A configuration no other fixture has, against what the REFERENCE ITSELF produced (tests/golden/noncubic.npz,
+    make_golden_noncubic.py): a NON-CUBIC volume (n_xyz 105 x 67 x 129 -- three different strides in every flatten /
+    unflatten / brick index), voxel 0.02, ``min_pts_in_grid`` 5, a scene the bounds cut on two axes.  12 frames
+    through encode_pointcloud + _integrate from the reference's float32 input_pts, through the pipelined NeuralMap
+    from the uint16 depth images (GPU front end), and through the FramePipe C object; with and without the dense row
+    index.  Voxel ids / counts bit-exact per frame, volume keys in the reference's insertion order, weights
+    bit-exact, features and SDF within 1e-4, mask decisions identical (a fifth of the rows have a weight in [5, 8):
+    usable with this threshold, masked with the default)."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    z = np.load(os.path.join(GOLDEN, "noncubic.npz"))
+    voxel, dims, min_pts = float(z["voxel_size"]), z["dims"], int(z["min_pts"])
+    H, W = [int(v) for v in z["hw"]]
+    K = synthetic.intrinsics(H, W)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel, min_pts_in_grid=min_pts)
+    vols = [bnv.SparseVolume(8, voxel, dims, min_pts, device=DEV, brick=b) for b in (True, False)]
+    assert vols[0].n_xyz.tolist() == z["n_xyz"].tolist() and len(set(vols[0].n_xyz.tolist())) == 3
+    # (models of their own: a model's encode workspace serves one stream at a time)
+    nm = bnv.NeuralMap(dims, voxel, bnv.load_pretrained(device=DEV, voxel_size=voxel, min_pts_in_grid=min_pts),
+                       min_pts_in_grid=min_pts, device=DEV)
+    pv = bnv.SparseVolume(8, voxel, dims, min_pts, device=DEV)
+    pipe = FramePipe(pv, bnv.load_pretrained(device=DEV, voxel_size=voxel, min_pts_in_grid=min_pts), H * W, n_slots=3)
+    handles, slots = [], []
+    for k, t in enumerate(int(t) for t in z["frames"]):
+        d16 = synthetic.depth_u16(t, H, W)
+        pts = synthetic.depth_to_input_pts(d16.astype(np.float64) / 1000.0, K, synthetic.pose(t),
+                                           max_depth=3.0).astype(np.float32)[None]
+        assert _sha(pts) == str(z["input_pts_sha256"][k])         # the very points the reference saw
+        fr = {"depth": torch.from_numpy(d16).to(DEV), "intr_mat": K, "T_wc": synthetic.pose(t)}
+        handles.append(nm.fuse_and_decode_async(fr))
+        if len(slots) == pipe.n_slots:
+            pipe.result(slots.pop(0))
+        s = pipe.begin(fr)
+        assert pipe.bound(s) == 0 and pipe.upsert(s, decode=True) is None
+        pipe.finish(s)
+        slots.append(s)
+        for vol in vols:
+            f, c, ids, g, n = _encode(model, vol, torch.from_numpy(pts))
+            ids_h, c_h = ids.cpu().numpy().astype(np.int64), c.cpu().numpy().reshape(-1).astype(np.int64)
+            assert np.array_equal(ids_h, np.cumsum(z[f"flat_ids_delta_{k}"].astype(np.int64))), k
+            assert np.array_equal(c_h, z[f"pcounts_{k}"].astype(np.int64)) and int(c_h.min()) == min_pts
+            assert _sha(ids_h) + _sha(c_h) == str(z["ids_counts_sha256"][k]), k
+            assert float(n) == float(z["n_avg_pts"][k])
+            if f"feats8_{k}" in z.files:
+                assert np.abs(f.cpu().numpy()[::8] - z[f"feats8_{k}"]).max() <= FEAT_TOL, k
+            vol.track_n_pts(n)
+            model._integrate(vol, g, f, c)
+    outs = [h.result() for h in handles]
+    last = None
+    while slots:
+        s = slots.pop(0)
+        last = pipe.outputs(s, pipe.result(s), copy=True)
+    for k, (c, s) in enumerate(outs):
+        assert len(c) == int(z["n_out"][k]), k
+    for v in vols + [nm.volume, pv]:
+        v.to_tensor()
+        assert np.array_equal(v.active_coordinates.cpu().numpy(), z["volume_keys"].astype(np.int64))   # insertion order
+        assert np.array_equal(v.weights.cpu().numpy().reshape(-1), z["volume_weights"])                # bit-exact
+        assert np.abs(v.features.cpu().numpy()[::8] - z["volume_feats8"]).max() <= FEAT_TOL
+    assert torch.equal(vols[0].features, vols[1].features) and torch.equal(vols[0].features, nm.volume.features)
+    assert torch.equal(nm.volume.features, pv.features)
+    origins = torch.from_numpy(z["decode_origins"].astype(np.int64)).to(DEV)
+    ref = z["decode_sdf"]
+    lat = torch.tensor(_LATTICE, device=DEV)
+    for v in vols + [nm.volume, pv]:
+        got = v.decode_lattice(origins, model.nerf, None, query_tensor=False).cpu().numpy()
+        assert np.array_equal(got == np.float32(voxel), ref == np.float32(voxel))       # mask decisions
+        assert np.abs(got - ref).max() <= SDF_TOL
+        gen = v.decode_pts((origins[:, None, :].float() + lat[None])[None], model.nerf, None, is_coords=True,
+                           query_tensor=False)[0, :, :, 0].cpu().numpy()
+        assert np.array_equal(gen == np.float32(voxel), ref == np.float32(voxel))
+        assert np.abs(gen - ref).max() <= SDF_TOL
+    assert (ref != np.float32(voxel)).mean() > 0.3
+    # the last frame's own decodes (pipelined NeuralMap, FramePipe) hold the same lattices for these voxels
+    n = vols[0].n_xyz.tolist()
+    key = lambda a: (a[:, 0] * n[1] + a[:, 1]) * n[2] + a[:, 2]
+    want = key(z["decode_origins"].astype(np.int64))
+    for c_last, s_last in (outs[-1], (last[0], last[1])):
+        pos = {int(v): i for i, v in enumerate(key(c_last.cpu().numpy()))}
+        rows = [pos[int(v)] for v in want]
+        assert np.abs(s_last.cpu().numpy()[rows] - ref).max() <= SDF_TOL

@@ -331,3 +331,48 @@ def test_sweep_window_oracle_vs_reference_golden():
     assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
     assert np.abs(got.numpy() - ref).max() <= 2e-6
     assert (ref != np.float32(voxel)).mean() > 0.2
+
+
+def test_noncubic_min_pts5_oracle_vs_reference_golden():
+    """The oracle on the reference's own run of a NON-CUBIC volume (n_xyz 105 x 67 x 129: three different strides in
+    every flatten / unflatten), voxel 0.02, ``min_pts_in_grid`` 5, a scene cut by the bounds on two axes
+    (tests/golden/noncubic.npz, make_golden_noncubic.py): 12 frames of encode -> _integrate (ids / counts through
+    SHA-256 and in clear, n_avg_pts, features), the fused volume (keys in insertion order, weights bit-exact), the
+    lattice decode of 384 voxels -- a fifth of the rows have a weight in [5, 8): usable here, masked at the default."""
+    from bnv_fusion_amd import synthetic
+    z = np.load(os.path.join(GOLDEN, "noncubic.npz"))
+    voxel, dims, min_pts = float(z["voxel_size"]), z["dims"], int(z["min_pts"])
+    H, W = [int(v) for v in z["hw"]]
+    sd = orc.load_weights(WEIGHTS_FP32)
+    torch.set_num_threads(8)
+    vol = orc.OracleSparseVolume(8, voxel, dims, min_pts)
+    assert vol.n_xyz.tolist() == z["n_xyz"].tolist() and len(set(vol.n_xyz.tolist())) == 3
+    K = synthetic.intrinsics(H, W)
+    for k, t in enumerate(int(t) for t in z["frames"]):
+        pts = synthetic.depth_to_input_pts(synthetic.depth_u16(t, H, W).astype(np.float64) / 1000.0, K,
+                                           synthetic.pose(t), max_depth=3.0).astype(np.float32)[None]
+        assert _sha(pts) == str(z["input_pts_sha256"][k])         # the very points the reference saw
+        with torch.no_grad():
+            f, c, ids, g, n = orc.encode_pointcloud(sd, torch.from_numpy(pts), vol.n_xyz, vol.min_coords,
+                                                    vol.max_coords, voxel, min_pts_in_grid=min_pts)
+            orc.integrate(vol, g, f, c)
+        ids_h, c_h = ids.numpy().astype(np.int64), c.numpy().reshape(-1).astype(np.int64)
+        assert np.array_equal(ids_h, np.cumsum(z[f"flat_ids_delta_{k}"].astype(np.int64))), k
+        assert np.array_equal(c_h, z[f"pcounts_{k}"].astype(np.int64)) and int(c_h.min()) == min_pts
+        assert _sha(ids_h) + _sha(c_h) == str(z["ids_counts_sha256"][k]), k
+        assert float(n) == float(z["n_avg_pts"][k])
+        if f"feats8_{k}" in z.files:
+            assert np.abs(f.numpy()[::8] - z[f"feats8_{k}"]).max() <= 2e-6, k
+    vol.to_tensor()
+    assert np.array_equal(vol.active_coordinates.numpy(), z["volume_keys"].astype(np.int64))       # insertion order
+    assert np.array_equal(vol.weights.numpy().reshape(-1), z["volume_weights"])                    # bit-exact
+    assert np.abs(vol.features.numpy()[::8] - z["volume_feats8"]).max() <= 2e-6
+    w = z["volume_weights"]
+    assert ((w >= 5) & (w < 8)).mean() > 0.1
+    origins = z["decode_origins"].astype(np.int64)
+    with torch.no_grad():
+        got = vol.decode_pts(orc.lattice_coords(origins), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
+    ref = z["decode_sdf"]
+    assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
+    assert np.abs(got.numpy() - ref).max() <= 2e-6
+    assert (ref != np.float32(voxel)).mean() > 0.3
