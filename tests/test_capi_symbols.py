@@ -97,3 +97,42 @@ def test_missing_library_fails_loudly(tmp_path):
     env = dict(os.environ, BNV_FUSION_LIB=str(tmp_path / "absent.so"), PYTHONPATH=ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "LOUD" in out.stdout, out.stdout + out.stderr
+
+
+def test_header_is_plain_c_and_cxx():
+    """include/bnv_fusion.h is what a cgo / JNI / N-API / C host includes: it must compile as C99 and as C++11 on its
+    own (no HIP, no torch types in any signature)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "bnv_fusion.h")
+    for cc, args in (("gcc", ["-x", "c", "-std=c99"]), ("g++", ["-x", "c++", "-std=c++11"])):
+        if not shutil.which(cc):
+            pytest.skip(f"{cc} not found")
+        r = subprocess.run([cc, "-fsyntax-only", "-Wall", "-Wextra", "-Werror"] + args + [hdr],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    txt = open(hdr).read()
+    assert "#include <hip" not in txt and "at::" not in txt and "c10::" not in txt
+
+
+def test_cpp_host_example_builds_against_the_library(tmp_path):
+    """examples/capi_host.cpp (the hot path from a host without Python or torch) compiles and links against the
+    in-tree library; the GPU test runs it (tests/test_gpu_capi_host.py)."""
+    import shutil
+    import subprocess
+    from bnv_fusion_amd import _lib
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "capi_host")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "capi_host.cpp"), "-o", exe, "-L" + lib_dir,
+                        "-l:" + os.path.basename(_lib.LIB_PATH), "-Wl,-rpath," + lib_dir],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libbnv_fusion_hip" in ldd and "torch" not in ldd and "python" not in ldd
