@@ -1253,6 +1253,7 @@ __global__ __launch_bounds__(64 * kTbWaves) void k_pointnet_scatter_tb(
   __syncthreads();
   const int j = lane & 31, h = lane >> 5;
   const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  const bool sharded = g.shard_world > 1;
   // blocks: 8 x 4 pixel patches of a frame_w-wide image, or runs of 32 points; a workgroup's 8 waves take the 2 x 4
   // blocks of a 16 x 16 patch (SHARED) or 8 consecutive blocks
   const bool image = frame_w > 0 && n_points % frame_w == 0;
@@ -1315,13 +1316,17 @@ __global__ __launch_bounds__(64 * kTbWaves) void k_pointnet_scatter_tb(
     }
     // bitmap word + prefix of the eight corner voxels, all requested before the first is used
     uint32_t bw8[8], pf8[8], id8[8];
+    bool own8[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int gx = (k & 1) ? hi3[0] : lo3[0], gy = (k & 2) ? hi3[1] : lo3[1], gz = (k & 4) ? hi3[2] : lo3[2];
       id8[k] = (uint32_t)(gx * nyz + gy * g.n_xyz[2] + gz);
       bw8[k] = 0u;
       pf8[k] = 0u;
-      if (valid) {
+      // sharded volume: only the pairs whose voxel this rank owns (ownership goes by 8^3-voxel blocks, a patch of
+      // the image lies in one or two of them: most corner tiles are all or nothing and the others are skipped)
+      own8[k] = valid && (!sharded || voxel_owner(gx, gy, gz, g) == g.shard_rank);
+      if (own8[k]) {
         bw8[k] = bitmap[id8[k] >> 5];
         pf8[k] = word_prefix[id8[k] >> 5];
       }
@@ -1329,7 +1334,8 @@ __global__ __launch_bounds__(64 * kTbWaves) void k_pointnet_scatter_tb(
     const _Float16 hn0 = (_Float16)n0, hn1 = (_Float16)n1, hn2 = (_Float16)n2;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int slot = valid ? (int)(pf8[k] + __popc(bw8[k] & ((1u << (id8[k] & 31)) - 1u))) : -1;
+      const int slot = own8[k] ? (int)(pf8[k] + __popc(bw8[k] & ((1u << (id8[k] & 31)) - 1u))) : -1;
+      if (sharded && __ballot(slot >= 0) == 0ULL) continue;     // nothing of this corner tile is ours
       // operand slots of this lane half: features 8 (jj >> 2) + 4 h + (jj & 3); inputs 0..5, the rest 1.0
       half8 bop;
 #pragma unroll
@@ -1679,6 +1685,10 @@ static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, hipStream_t stre
   return BNV_OK;
 }
 
+// The tiny-cuda-nn block encoder finds a shard's pairs itself: `begin` then makes no pair list.  (begin and finish of
+// one frame run under one MLP mode: the mode follows the weight pack.)
+static bool tcnn_blocks() { return g_mlp_mode == 2 && g_tcnn_block_encoder; }
+
 static bool grid_ok(const bnv_grid_t& g) {
   return (int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] < (1LL << 31) && g.n_xyz[0] > 0 && g.n_xyz[1] > 0 &&
          g.n_xyz[2] > 0 && g.shard_world >= 1 && g.shard_world <= 64 && g.shard_rank >= 0 &&
@@ -1703,7 +1713,7 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   const int n = (int)n_points;
   hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bytemap, ws.chunk_flag,
                      ws.valid_blocks,
-                     g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1724,7 +1734,7 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bytemap,
-                     ws.chunk_flag, ws.valid_blocks, g.shard_world > 1 ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     ws.chunk_flag, ws.valid_blocks, (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1761,10 +1771,11 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
   const int n_tiles = ((n + 31) / 32) * 8;
   int grid_pn = g_num_cus - g_reserve_cus > 0 ? g_num_cus - g_reserve_cus : 1;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
-  const int32_t* plist = g.shard_world > 1 ? ws.pair_list : (const int32_t*)nullptr;   // sharded: owned pairs only
+  // sharded: owned pairs only -- from the list `begin` made, or (block encoder) by an ownership test in the kernel
+  const int32_t* plist = (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (const int32_t*)nullptr;
   {
     ProfScope prof(PROF_POINTNET, stream);
-    if (g_mlp_mode == 2 && !plist && g_tcnn_block_encoder) {
+    if (tcnn_blocks()) {
       const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
       const int n_units = (n_blocks + kTbWaves - 1) / kTbWaves + 64;   // (16 x 16 patches: up to ragged edges)
       const int grid_tb = g_num_cus * 2 < n_units ? g_num_cus * 2 : n_units;
