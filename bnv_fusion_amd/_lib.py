@@ -23,7 +23,7 @@ SYMBOLS = [
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
     "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
-    "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped",
+    "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
@@ -179,6 +179,7 @@ def load():
         "bnv_shard_install_reset": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp, vp]),
         "bnv_volume_integrate_frame": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, vp, sz,
                                                  C.POINTER(IntegrateExtras), vp]),
+        "bnv_readback_words": (C.c_int, [vp, vp, vp, vp]),
         "bnv_decode_lattice_stamped": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                                  C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_frame_pipe_create": (C.c_int, [C.POINTER(FramePipeConfig), C.POINTER(vp)]),

@@ -36,6 +36,15 @@ __global__ void k_frame_readback(const int32_t* __restrict__ counters, const int
   __threadfence_system();
 }
 
+// the same for callers that drive the stages themselves (NeuralMap): counters[8] | status[2] -> host_words[0..9]
+__global__ void k_readback_words(const int32_t* __restrict__ counters, const int32_t* __restrict__ status,
+                                 int32_t* __restrict__ host_words) {
+  const int t = threadIdx.x;
+  if (t < 8) host_words[t] = counters[t];
+  else if (t < 10) host_words[t] = status[t - 8];
+  __threadfence_system();
+}
+
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
   int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
@@ -51,6 +60,20 @@ struct bnv_frame_pipe {
 static bool slot_ok(const bnv_frame_pipe* p, int slot) { return p && slot >= 0 && slot < p->cfg.n_slots; }
 
 extern "C" {
+
+int bnv_readback_words(const int32_t* counters, const int32_t* status, int32_t* host_words, bnv_stream_t stream) {
+  if (!counters || !status || !host_words) return BNV_ERR_INVALID_ARGUMENT;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host_words, 0) == hipSuccess && d) {
+    hipLaunchKernelGGL(k_readback_words, dim3(1), dim3(64), 0, (hipStream_t)stream, counters, status, (int32_t*)d);
+    BNV_LAUNCH_CHECK();
+    return BNV_OK;
+  }
+  (void)hipGetLastError();   // not mapped into the device's address space: two copies instead
+  BNV_HIP_CHECK(hipMemcpyAsync(host_words, counters, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  BNV_HIP_CHECK(hipMemcpyAsync(host_words + 8, status, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return BNV_OK;
+}
 
 int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t** out) {
   if (!cfg || !out || cfg->n_slots < 1 || cfg->n_slots > BNV_PIPE_MAX_SLOTS || !cfg->pointnet_pack || !cfg->enc_ws ||

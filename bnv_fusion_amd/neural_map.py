@@ -7,8 +7,11 @@
 * ``optimize``                    run_e2e.py:111-162: the global optimiser over ``self.frames``;
 * ``extract_mesh`` / ``save``     run_e2e.py:164-194.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib
 from ._lib import BnvError as _lib_error
 from .sparse_volume import SparseVolume
 
@@ -204,12 +207,15 @@ class NeuralMap:
                 feats, pcounts, flat_ids, grid_ids, counters, cap = self._encode_frame_async(frame)
                 self._integrate_tsdf(frame, gate=counters[0:1])
             n_dev = counters[2:3]
-            host = torch.empty(8, dtype=torch.int32, pin_memory=True)
-            v.integrate(grid_ids, feats, pcounts, n_dev=n_dev)
+            host = torch.empty(16, dtype=torch.int32, pin_memory=True)
+            # (the upsert also stamps the decode's origins: k_lattice_stamp's launch goes)
+            v.integrate(grid_ids, feats, pcounts, n_dev=n_dev, stamp_origins=decode)
             sdf = v.decode_lattice(grid_ids, self.pointnet.nerf, self.sdf_delta, query_tensor=False,
-                                   n_dev=n_dev) if decode else None
-            host.copy_(counters, non_blocking=True)
-            host_rows = v.status_readback()
+                                   n_dev=n_dev, prestamped=True) if decode else None
+            # counters + {row count, sticky error} in one small launch that writes the pinned words directly
+            _lib.check(v._lib.bnv_readback_words(_lib.ptr(counters), _lib.ptr(v._status), C.c_void_p(host.data_ptr()),
+                                                 _lib.stream_ptr()), "bnv_readback_words")
+            host_rows = host[8:10]
             if self.overlap_encode:
                 main.wait_event(tsdf_ev)      # long finished by now: the frame's event covers its TSDF update too
             ev = torch.cuda.Event()

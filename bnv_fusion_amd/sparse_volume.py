@@ -79,6 +79,7 @@ class SparseVolume:
         self._slot_items = None
         self._lattice_ws = None
         self._stamp = None
+        self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         self._epoch = 0
         self.reset(capacity)
         self.avg_n_pts = 0
@@ -135,6 +136,7 @@ class SparseVolume:
         self._rows_known = 0          # largest row count read back so far
         self._lattice_ws = None
         self._stamp = None
+        self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
         self.tensor_indexer = None
         self.features = None
@@ -229,6 +231,7 @@ class SparseVolume:
         self._slot_rows = torch.empty(self._n_slots, dtype=torch.int32, device=d)
         self._lattice_ws = None
         self._stamp = None
+        self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         _lib.check(self._lib.bnv_volume_rehash(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_rehash")
 
     def _workspace(self, n):
@@ -238,11 +241,14 @@ class SparseVolume:
         return self._ws
 
     # ---- reference API ---------------------------------------------------------------------------
-    def integrate(self, coords, feats, pcounts, n_dev=None):
+    def integrate(self, coords, feats, pcounts, n_dev=None, stamp_origins=False):
         """Fused LitFusionPointNet._integrate (local_point_fusion.py:647-673): query + running
         average + upsert for UNIQUE keys in one pass.  ``n_dev`` (device int32 [1]): take the element
-        count from the device; the tensors are then capacity-sized buffers (no host sync needed)."""
+        count from the device; the tensors are then capacity-sized buffers (no host sync needed).
+        ``stamp_origins``: the same launch marks the rows it touches as the origins of the NEXT lattice decode, which
+        must be ``decode_lattice(coords, ..., prestamped=True)`` on the same stream (one launch less per frame)."""
         n = int(coords.shape[0])
+        self._stamped = None
         if n == 0:
             return
         coords = coords.reshape(-1, 3).long().contiguous()
@@ -250,9 +256,20 @@ class SparseVolume:
         pcounts = pcounts.reshape(-1).long().contiguous()
         self._reserve(n)
         ws = self._workspace(n)
-        _lib.check(self._lib.bnv_volume_integrate(C.byref(self._struct()), _lib.ptr(coords), _lib.ptr(feats),
-                                                  _lib.ptr(pcounts), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
-                                                  _lib.stream_ptr()), "bnv_volume_integrate")
+        if stamp_origins:
+            lws, epoch = self._lattice_workspace(n)          # (behind _reserve: growth re-makes this workspace)
+            ex = _lib.IntegrateExtras()
+            ex.lattice_ws = lws.data_ptr()
+            ex.stamp_epoch = epoch
+            _lib.check(self._lib.bnv_volume_integrate_frame(C.byref(self._struct()), _lib.ptr(coords), _lib.ptr(feats),
+                                                            _lib.ptr(pcounts), n, _lib.ptr(n_dev), _lib.ptr(ws),
+                                                            ws.numel(), C.byref(ex), _lib.stream_ptr()),
+                       "bnv_volume_integrate_frame")
+            self._stamped = (epoch, coords.data_ptr(), n)
+        else:
+            _lib.check(self._lib.bnv_volume_integrate(C.byref(self._struct()), _lib.ptr(coords), _lib.ptr(feats),
+                                                      _lib.ptr(pcounts), n, _lib.ptr(n_dev), _lib.ptr(ws), ws.numel(),
+                                                      _lib.stream_ptr()), "bnv_volume_integrate")
         self._rows_upper += n
         if n_dev is not None:
             self._inflight += n
@@ -438,9 +455,10 @@ class SparseVolume:
                    "bnv_decode_pts")
         return out.reshape(shape[:-1] + [1])
 
-    def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True, n_dev=None):
+    def decode_lattice(self, origins, nerf, sdf_delta=None, query_tensor=True, n_dev=None, prestamped=False):
         """decode_pts on the 3x3x3 lattice {-0.5, 0, 0.5}^3 around integer voxel ``origins`` [B, 3]
-        (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27]."""
+        (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27].
+        ``prestamped``: ``origins`` is the very tensor the last ``integrate(..., stamp_origins=True)`` upserted."""
         self._select_mode(nerf)
         o = origins.detach().reshape(-1, 3).long().contiguous()
         n = int(o.shape[0])
@@ -449,6 +467,18 @@ class SparseVolume:
             return out
         f, w, lim = self._values(query_tensor)
         d, keep = self._delta(sdf_delta)
+        stamped = getattr(self, "_stamped", None)
+        self._stamped = None
+        if prestamped:
+            if stamped != (self._lattice_epoch, o.data_ptr(), n) or self._lattice_ws is None:
+                raise _lib.BnvError("decode_lattice(prestamped=True) needs the origins of the integrate(..., "
+                                    "stamp_origins=True) right before it")
+            _lib.check(self._lib.bnv_decode_lattice_stamped(
+                C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+                _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n, _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
+                self._lattice_ws.numel(), self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
+                "bnv_decode_lattice_stamped")
+            return out
         self._lattice_workspace(n)
         _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,

@@ -569,6 +569,11 @@ typedef struct bnv_frame_pipe_config {
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;
+/* A frame's read-backs in one launch for callers that drive the stages themselves: the encode's counters (8 int32)
+ * and the volume's {row count, sticky error} (bnv_volume_t.n_rows) -> host_words[0..9], PINNED host memory (written
+ * through its device mapping; two small copies if it has none).  Valid once `stream` has passed this point. */
+int bnv_readback_words(const int32_t* counters, const int32_t* status, int32_t* host_words, bnv_stream_t stream);
+
 int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* config_host, bnv_frame_pipe_t** out);
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* pipe);
 /* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL */
