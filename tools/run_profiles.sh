@@ -30,4 +30,6 @@ GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/qu
 python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_sp8 -o sp8 -- python3 tools/spatial_single_rank.py --world 8 --frames 300 > $O/trace_sp8_stdout.log 2>&1
 python3 tools/fp_single_rank.py --replay 8 > $O/fp_replay8.txt 2>&1
+# functional only: both multi-GPU decompositions as two gloo ranks sharing this GPU (no RCCL: it refuses two ranks per GPU)
+BNV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --no-cpu-baseline 2> $O/bench_line_2rank_gloo.err | tail -1 > $O/bench_line_2rank_gloo.json
 ls -la $O
