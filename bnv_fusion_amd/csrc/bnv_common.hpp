@@ -18,6 +18,7 @@ extern int g_mlp_mode;
 extern int g_reserve_cus;
 extern int g_tcnn_block_encoder;
 extern int g_tcnn_shared_table;
+extern int g_finalize_blocks;
 
 // optional HIP-event timing of the dominant kernels (bnv_profile_enable / bnv_profile_read)
 enum ProfKind { PROF_POINTNET = 0, PROF_DECODE_LATTICE = 1, PROF_DECODE_PTS = 2, PROF_DECODE_DENSE = 3, PROF_KINDS = 4 };

@@ -2485,6 +2485,11 @@ int bnv_set_option(const char* name, int value) {
     g_tcnn_block_encoder = value != 0;
     return BNV_OK;
   }
+  if (!strcmp(name, "finalize_blocks")) {
+    if (value < 0) return BNV_ERR_INVALID_ARGUMENT;
+    g_finalize_blocks = value;
+    return BNV_OK;
+  }
   if (!strcmp(name, "tcnn_shared_table")) {
     g_tcnn_shared_table = value != 0;
     return BNV_OK;

@@ -32,6 +32,7 @@ namespace bnv {
 int g_num_cus = 0;
 int g_last_hip_error = 0;
 int g_reserve_cus = 0;  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
+int g_finalize_blocks = 0;      // bnv_set_option("finalize_blocks"): workgroups of k_finalize (0: 8 per CU); tests force the striding with a small value
 int g_tcnn_shared_table = 1;    // bnv_set_option("tcnn_shared_table"): 1 = one LDS table per workgroup and 16 x 16 patch, 0 = per wave and block
 int g_tcnn_block_encoder = 1;  // bnv_set_option("tcnn_block_encoder"): 1 = k_pointnet_scatter_tb for whole frames
 int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
@@ -1458,8 +1459,13 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
   }
   // ONE slot per thread: consecutive threads read consecutive 64-byte accumulator rows (with 8 slots per thread
   // every thread walked its own 512-byte stretch and the kernel was latency-bound at 34 us for 25 MB)
-  const int64_t sl = (int64_t)blockIdx.x * kFinTile + threadIdx.x;
-  if ((int64_t)blockIdx.x * kFinTile >= n) return;
+  // The number of slots is only known on the device: the launch is sized for a few thousand tiles at most and the
+  // workgroups stride over the tiles in increasing order (tile t waits for tile t - 1 only: a workgroup that is
+  // behind never waits for one that is ahead).  It used to cover max_unique -- 9,600 workgroups at 640x480, of which
+  // ~500 had a tile and the others read n_unique and left.
+  for (int64_t tile = blockIdx.x; tile * kFinTile < n; tile += gridDim.x) {
+  if (tile != (int64_t)blockIdx.x) __syncthreads();      // wave_tot / s_excl of the previous tile are no longer read
+  const int64_t sl = tile * kFinTile + threadIdx.x;
   ValidFlags flags{counts, ids, g, emit_all};
   const uint32_t fl = sl < n ? flags(sl) : 0u;
   int id = 0, c = 0;
@@ -1483,9 +1489,9 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
   }
   uint32_t total;
   uint32_t run = block_exclusive_scan<kScanThreads>(fl, wave_tot, &total);
-  const bool last_tile = (int64_t)(blockIdx.x + 1) * kFinTile >= n;
+  const bool last_tile = (tile + 1) * kFinTile >= n;
   if (threadIdx.x < 64) {
-    const uint32_t excl = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch);
+    const uint32_t excl = lookback_exclusive(tile_state, (int)tile, total, epoch);
     if (threadIdx.x == 0) s_excl = excl;
     if (last_tile) {
       // every other tile has published (so it has read ctl->n_unique): complete the counters, leave the
@@ -1512,7 +1518,7 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     }
   }
   __syncthreads();
-  if (sl >= n) return;
+  if (sl >= n) continue;
   run += s_excl;
   if (fl && (int64_t)run < out_capacity) {
     const bool keep = c >= g.min_pts_in_grid;  // emit_all: features zeroed below min_pts (:126)
@@ -1543,6 +1549,7 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     for (int q = 0; q < 4; ++q) *(i64x2*)&acc[sl * 8 + 2 * q] = z2;
   }
   bitmap[id >> 5] = 0u;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1799,9 +1806,11 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, plist, &ws.ctl->n_pairs);
   }
   BNV_LAUNCH_CHECK();
-  // ordered compaction of the emitted voxels; the number of slots is only known on the device, so the grid covers
-  // max_unique and workgroups past n_unique exit at once
-  const int nb_u = (int)((ws.max_unique + kFinTile - 1) / kFinTile);
+  // ordered compaction of the emitted voxels; the number of slots is only known on the device: a capped grid strides
+  // over the tiles
+  const int nb_max = (int)((ws.max_unique + kFinTile - 1) / kFinTile);
+  const int nb_cap = g_finalize_blocks > 0 ? g_finalize_blocks : 8 * g_num_cus;
+  const int nb_u = nb_max < nb_cap ? nb_max : nb_cap;
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
                      ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, ws.valid_blocks, (n + 255) / 256, out_feats,
                      out_pcounts, out_flat_ids, out_grid_ids, out_capacity, counters);

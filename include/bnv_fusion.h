@@ -121,6 +121,8 @@ int bnv_get_mlp_mode(void);
  *                  (32-point blocks x 8 corners, per-wave LDS accumulation of the voxel sums); 0: the per-tile kernel.
  *   "tcnn_shared_table"  1 (default): that kernel's 8 waves take the 8 blocks of a 16 x 16-pixel patch and sum them in
  *                  ONE LDS table per workgroup (flushed behind a barrier); 0: one table per wave, flushed per block.
+ *   "finalize_blocks"  0 (default): the encoder's compaction kernel runs on 8 workgroups per CU striding over its
+ *                  tiles; n > 0: on n workgroups (tests force many strides per workgroup with a small n).
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside

@@ -97,3 +97,28 @@ def test_pipelined_frames_repeat_bit_for_bit(setup):
         st = sequence.run(nm, frames[:30], pipelined=True, in_flight=3)
         runs.append(st["sums"])
     assert runs[1] == runs[0] and runs[2] == runs[0]
+
+
+def test_finalize_strides_over_its_tiles(setup):
+    """The encoder's compaction kernel on 5 workgroups (every workgroup strides over ~100 tiles of the look-back
+    chain) and on its default grid: the same voxel order, counts and features."""
+    from bnv_fusion_amd import _lib
+    bnv, model, frames, dims, voxel = setup
+    nm = _map(bnv, model, dims, voxel)
+    v = nm.volume
+    lib = _lib.load()
+    try:
+        for f in frames[20:24]:
+            outs = []
+            for blocks in (0, 5, 1, 0):
+                assert lib.bnv_set_option(b"finalize_blocks", blocks) == 0
+                feats, pcounts, flat_ids, grid_ids, counters, cap, _ = model.encode_depth_async(
+                    f["depth"], f["intr_mat"], f["T_wc"], nm.max_depth, v.n_xyz, v.min_coords, v.max_coords, v.voxel_size)
+                n_out = int(counters[2].item())
+                assert n_out > 50000
+                outs.append([feats[:n_out].clone(), pcounts[:n_out].clone(), grid_ids[:n_out].clone(), counters.clone()])
+            for o in outs[1:]:
+                for a, b in zip(o, outs[0]):
+                    assert torch.equal(a, b), f["frame_id"]
+    finally:
+        lib.bnv_set_option(b"finalize_blocks", 0)
