@@ -121,7 +121,10 @@ struct EncodeWs {
 };
 
 constexpr int kScanThreads = 256;
-constexpr int kFinTile = kScanThreads;                 // 256 slots per workgroup (k_finalize: one per thread)
+#ifndef BNV_FIN_THREADS
+#define BNV_FIN_THREADS 1024
+#endif
+constexpr int kFinTile = BNV_FIN_THREADS;              // slots per workgroup (k_finalize: one per thread)
 constexpr int kRankItems = 4;
 constexpr int kRankTile = kScanThreads * kRankItems;  // 1024 chunks (of 64 voxels = 2 bitmap words) per workgroup (k_rank)
 
@@ -1432,14 +1435,14 @@ __global__ __launch_bounds__(64 * kTbWaves) void k_pointnet_scatter_tb(
 // workgroups), unflatten, cleanup of the per-frame scratch; the workgroup of the last tile completes the frame's
 // counters and clears the control block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kScanThreads) void k_finalize(
+__global__ __launch_bounds__(kFinTile) void k_finalize(
     bnv_grid_t g, int emit_all, uint32_t* __restrict__ bitmap, int32_t* __restrict__ ids,
     int32_t* __restrict__ counts, long long* __restrict__ acc, uint64_t* __restrict__ tile_state, uint32_t epoch,
     EncCtl* __restrict__ ctl, const int32_t* __restrict__ valid_blocks, int n_mark_blocks,
     float* __restrict__ out_feats, int64_t* __restrict__ out_pcounts,
     int64_t* __restrict__ out_flat, int64_t* __restrict__ out_grid, int64_t out_capacity,
     bnv_encode_counters_t* __restrict__ counters) {
-  __shared__ uint32_t wave_tot[kScanThreads / 64];
+  __shared__ uint32_t wave_tot[kFinTile / 64];
   __shared__ uint32_t s_excl;
   const int64_t n = ctl->n_unique;
   if (n == 0) {
@@ -1488,7 +1491,7 @@ __global__ __launch_bounds__(kScanThreads) void k_finalize(
     }
   }
   uint32_t total;
-  uint32_t run = block_exclusive_scan<kScanThreads>(fl, wave_tot, &total);
+  uint32_t run = block_exclusive_scan<kFinTile>(fl, wave_tot, &total);
   const bool last_tile = (tile + 1) * kFinTile >= n;
   if (threadIdx.x < 64) {
     const uint32_t excl = lookback_exclusive(tile_state, (int)tile, total, epoch);
@@ -1809,9 +1812,9 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
   // ordered compaction of the emitted voxels; the number of slots is only known on the device: a capped grid strides
   // over the tiles
   const int nb_max = (int)((ws.max_unique + kFinTile - 1) / kFinTile);
-  const int nb_cap = g_finalize_blocks > 0 ? g_finalize_blocks : 8 * g_num_cus;
+  const int nb_cap = g_finalize_blocks > 0 ? g_finalize_blocks : 2 * g_num_cus;
   const int nb_u = nb_max < nb_cap ? nb_max : nb_cap;
-  hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kScanThreads), 0, stream, g, emit_all, ws.bitmap, ws.ids,
+  hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kFinTile), 0, stream, g, emit_all, ws.bitmap, ws.ids,
                      ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, ws.valid_blocks, (n + 255) / 256, out_feats,
                      out_pcounts, out_flat_ids, out_grid_ids, out_capacity, counters);
   BNV_LAUNCH_CHECK();
