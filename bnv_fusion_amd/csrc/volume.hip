@@ -227,8 +227,12 @@ struct IntegrateExtras {
   int32_t* lattice_ctl;     // with origin_stamp: control words of the decode's later stages, cleared here
 };
 
+#ifndef BNV_INT_THREADS
+#define BNV_INT_THREADS 1024
+#endif
+constexpr int kIntThreads = BNV_INT_THREADS;   // keys per workgroup of the upsert (one per thread): the look-back chain has n / kIntThreads links
 template <bool FRAME>
-__global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
+__global__ __launch_bounds__(kIntThreads) void k_vol_integrate(bnv_volume_t v, const int64_t* __restrict__ coords,
                                                        const float* __restrict__ feats,
                                                        const int64_t* __restrict__ pcounts, int64_t n,
                                                        const int32_t* __restrict__ n_dev,
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int
     // entries listed / tile counter / spare of the lattice decode that follows (k_lattice_stamp's other job)
     if (blockIdx.x == 0 && threadIdx.x == 0 && X.lattice_ctl) X.lattice_ctl[1] = X.lattice_ctl[2] = X.lattice_ctl[3] = 0;
   }
-  if ((int64_t)blockIdx.x * 256 >= n) return;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int64_t)blockIdx.x * kIntThreads >= n) return;
+  const int64_t i = (int64_t)blockIdx.x * kIntThreads + threadIdx.x;
   uint64_t key;
   int32_t slot = -1, created = 0;
   if (i < n) {
@@ -286,19 +290,21 @@ __global__ __launch_bounds__(256) void k_vol_integrate(bnv_volume_t v, const int
       row = -1;
     }
   }
-  __shared__ uint32_t wave_new[4];
+  __shared__ uint32_t wave_new[kIntThreads / 64];
   __shared__ uint32_t s_first;
   const unsigned long long bal = __ballot(created);
   const int ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (ln == 0) wave_new[wv] = (uint32_t)__popcll(bal);
   __syncthreads();
   if (threadIdx.x < 64) {
-    const uint32_t total = wave_new[0] + wave_new[1] + wave_new[2] + wave_new[3];
+    uint32_t total = 0;
+#pragma unroll
+    for (int k = 0; k < kIntThreads / 64; ++k) total += wave_new[k];
     const uint32_t seed = blockIdx.x == 0 ? (uint32_t)v.n_rows[0] : 0u;
     const uint32_t first = lookback_exclusive(tile_state, (int)blockIdx.x, total, epoch, seed);
     if (threadIdx.x == 0) {
       s_first = first;
-      if ((int64_t)(blockIdx.x + 1) * 256 >= n) v.n_rows[0] = (int32_t)(first + total);   // last tile: commit
+      if ((int64_t)(blockIdx.x + 1) * kIntThreads >= n) v.n_rows[0] = (int32_t)(first + total);   // last tile: commit
     }
   }
   __syncthreads();
@@ -588,7 +594,6 @@ static bool vol_ok(const bnv_volume_t* v) {
 
 static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const int32_t* n_dev,
                            const VolWs& ws, hipStream_t stream) {
-  const unsigned nb256 = (unsigned)((n + 255) / 256);
   const int nbt = (int)((n + kVolTile - 1) / kVolTile);
   hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, n_dev, ws.slot_of,
                      ws.is_new, ws.error);
@@ -653,8 +658,7 @@ int bnv_volume_integrate(const bnv_volume_t* vol, const int64_t* coords, const f
   if (vol_ws_layout(n, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
-  const unsigned nb256 = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_vol_integrate<false>, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+  hipLaunchKernelGGL(k_vol_integrate<false>, dim3((unsigned)((n + kIntThreads - 1) / kIntThreads)), dim3(kIntThreads), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
                      ws.tile_state, next_epoch(), ws.error, IntegrateExtras{});
   BNV_LAUNCH_CHECK();
   return BNV_OK;
@@ -682,8 +686,7 @@ int bnv_volume_integrate_frame(const bnv_volume_t* vol, const int64_t* coords, c
   if (vol_ws_layout(n, (char*)ws_ptr, ws_bytes, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   ws.error = vol->n_rows + 1;
   hipStream_t stream = (hipStream_t)stream_;
-  const unsigned nb256 = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_vol_integrate<true>, dim3(nb256), dim3(256), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
+  hipLaunchKernelGGL(k_vol_integrate<true>, dim3((unsigned)((n + kIntThreads - 1) / kIntThreads)), dim3(kIntThreads), 0, stream, *vol, coords, feats, pcounts, n, n_dev,
                      ws.tile_state, next_epoch(), ws.error, X);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
