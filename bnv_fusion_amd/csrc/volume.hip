@@ -595,6 +595,7 @@ static bool vol_ok(const bnv_volume_t* v) {
 static int vol_upsert_rows(const bnv_volume_t& v, const int64_t* coords, int64_t n, const int32_t* n_dev,
                            const VolWs& ws, hipStream_t stream) {
   const int nbt = (int)((n + kVolTile - 1) / kVolTile);
+  const unsigned nb256 = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(k_vol_probe_insert, dim3(nb256), dim3(256), 0, stream, v, coords, n, n_dev, ws.slot_of,
                      ws.is_new, ws.error);
   BNV_LAUNCH_CHECK();
