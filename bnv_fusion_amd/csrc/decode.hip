@@ -1797,11 +1797,15 @@ __global__ __launch_bounds__(256) void k_lattice_table_t(DecodeArgs A) {
       const float loc[3] = {(float)(l / 9 - 1) * 0.5f, (float)((l / 3) % 3 - 1) * 0.5f, (float)(l % 3 - 1) * 0.5f};
       const f32x4 f0 = *(const f32x4*)&A.features[(size_t)row * 8];
       const f32x4 f1 = *(const f32x4*)&A.features[(size_t)row * 8 + 4];
+      // a lattice offset is -0.5, 0 or +0.5: its encoding is one of three constants (sinf / cosf cost more than
+      // the tile's MFMAs; the operands are rounded to f16 below, where sin(0.5) and cos(0.5) sit 0.23 and 0.29 of a
+      // spacing away from the nearest rounding boundary: the last bit of the fp32 value cannot matter)
+      constexpr float kSinHalf = 0.479425538604203f, kCosHalf = 0.8775825618903728f;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         in[a] = loc[a];
-        in[3 + a] = sinf(loc[a]);
-        in[6 + a] = cosf(loc[a]);
+        in[3 + a] = loc[a] == 0.f ? 0.f : (loc[a] > 0.f ? kSinHalf : -kSinHalf);
+        in[6 + a] = loc[a] == 0.f ? 1.f : kCosHalf;
       }
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
