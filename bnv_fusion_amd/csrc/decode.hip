@@ -2224,25 +2224,33 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
 
 // DELTA = false: the streaming case (no TSDF prior): 8 table reads and a weighted sum, few registers -- it runs
 // beside the persistent MLP kernels of the other streams.
+#ifndef BNV_BLEND_PPT
+#define BNV_BLEND_PPT 3
+#endif
+constexpr int kBlendPpt = BNV_BLEND_PPT;     // lattice points per thread of the streaming blend: their gathers are in flight together
 template <bool DELTA>
 __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                        const float* __restrict__ table, bnv_grid_t g,
                                                        const int64_t* __restrict__ origins, bnv_sdf_delta_t delta,
                                                        float* __restrict__ out, const int32_t* __restrict__ n_dev) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
+  constexpr int PPT = DELTA ? 1 : kBlendPpt;
+  constexpr int TILE = 256 * PPT;
   // the neighbour rows of the block's origins: one coalesced read, then 8 LDS reads per lattice point
-  __shared__ int s_nbr[(256 / 27 + 2) * 27];
+  __shared__ int s_nbr[(TILE / 27 + 2) * 27];
   // grid-stride over virtual workgroups vb (the launch is sized for the capacity, capped at 8 workgroups per CU: a
   // frame that holds a fraction of it does not pay for tens of thousands of workgroups that only exit)
-  for (int64_t vb = blockIdx.x; vb * 256 < n * 27; vb += gridDim.x) {
+  for (int64_t vb = blockIdx.x; vb * TILE < n * 27; vb += gridDim.x) {
   if (vb != (int64_t)blockIdx.x) __syncthreads();   // s_nbr of the previous round is no longer read
-  const int64_t b0 = (vb * 256) / 27;
-  for (int i = threadIdx.x; i < (256 / 27 + 2) * 27; i += 256) {
+  const int64_t b0 = (vb * TILE) / 27;
+  for (int i = threadIdx.x; i < (TILE / 27 + 2) * 27; i += 256) {
     const int64_t gidx = b0 * 27 + i;
     s_nbr[i] = gidx < n * 27 ? nbr_rows[gidx] : -1;
   }
   __syncthreads();
-  const int64_t t = vb * 256 + threadIdx.x;
+#pragma unroll
+  for (int rep = 0; rep < PPT; ++rep) {
+  const int64_t t = vb * TILE + rep * 256 + threadIdx.x;
   [&]() {
   if (t >= n * 27) return;
   const int64_t b = t / 27;
@@ -2337,6 +2345,7 @@ __global__ __launch_bounds__(256) void k_lattice_blend(const int32_t* __restrict
   if (DELTA) o = __fadd_rn(o, dacc);
   out[t] = o;
   }();
+  }
   }
 }
 
@@ -2735,7 +2744,7 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
     hipLaunchKernelGGL(k_lattice_blend<true>, dim3(capped_grid((n * 27 + 255) / 256, 8)), dim3(256), 0,
                        (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   else
-    hipLaunchKernelGGL(k_lattice_blend<false>, dim3(capped_grid((n * 27 + 255) / 256, 8)), dim3(256), 0,
+    hipLaunchKernelGGL(k_lattice_blend<false>, dim3(capped_grid((n * 27 + 256 * kBlendPpt - 1) / (256 * kBlendPpt), 8)), dim3(256), 0,
                        (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
