@@ -408,9 +408,13 @@ class Driver:
             pending = deque()
             depth = int(os.environ.get("BNV_BENCH_DEPTH", "3" if kind == "spatial" else "2"))
             _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
-            for t in idx:
+            for j, t in enumerate(idx):
                 _a = time.perf_counter()
-                h = m.fuse_and_decode_async(frames[t], decode=decode)
+                if kind == "spatial":   # the next frame's encode is enqueued before the host waits for this one's bound
+                    nxt = frames[idx[j + 1]] if j + 1 < len(idx) else None
+                    h = m.fuse_and_decode_async(frames[t], decode=decode, next_frame=nxt)
+                else:
+                    h = m.fuse_and_decode_async(frames[t], decode=decode)
                 if _dbg is not None:
                     _dbg.append(time.perf_counter() - _a)
                 pending.append(h)

@@ -22,7 +22,10 @@ MLP_MODE_F16 = 3            # fp32 checkpoint with operands rounded to f16: 1 pr
 
 
 def set_mlp_mode(mode):
-    """Selects the arithmetic of the two MLP kernels (see include/bnv_fusion.h: bnv_set_mlp_mode)."""
+    """The package DEFAULT arithmetic of the MLP kernels for fp32-checkpoint models that do not name one themselves
+    (include/bnv_fusion.h: bnv_set_mlp_mode; ``model.set_mlp_mode(m)`` pins one model).  Every call carries its mode in
+    its bnv_grid_t, so models of different arithmetic -- tiny-cuda-nn ones always run mode 2 -- and host threads do not
+    interfere; only models that follow this default change with it."""
     from . import _lib
     _lib.check(_lib.load().bnv_set_mlp_mode(int(mode)), "bnv_set_mlp_mode")
     if int(mode) in (0, 1, 3):

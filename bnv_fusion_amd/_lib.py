@@ -24,6 +24,7 @@ SYMBOLS = [
     "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
+    "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
@@ -32,7 +33,8 @@ SYMBOLS = [
 class Grid(C.Structure):
     _fields_ = [("bound_min", C.c_float * 3), ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3),
                 ("voxel_size", C.c_float), ("n_xyz", C.c_int32 * 3), ("min_pts_in_grid", C.c_int32),
-                ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_block_log2", C.c_int32)]
+                ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_block_log2", C.c_int32),
+                ("mlp_mode", C.c_int32)]      # 0: process default; 1 + m: arithmetic mode m for calls with this grid
 
 
 class EncodeCounters(C.Structure):
@@ -81,7 +83,32 @@ class BnvError(RuntimeError):
 
 _lib = None
 _initialised_device = None
-fp32_mode = 1   # MLP mode used by fp32-checkpoint models (0 exact fp32, 1 split-f16); see set_mlp_mode
+fp32_mode = 1   # MLP mode of fp32-checkpoint models that do not name one themselves (0 exact fp32, 1 split-f16, 3 f16); see set_mlp_mode
+
+
+def model_mode(m):
+    """Arithmetic mode of a network object (a LitFusionPointNet or its ``nerf``): its own ``mlp_mode`` when it names
+    one (tiny-cuda-nn networks: always 2; ``model.set_mlp_mode``), else the package default for fp32 checkpoints."""
+    mode = getattr(m, "mlp_mode", None)
+    return fp32_mode if mode is None else int(mode)
+
+
+def grid_with_mode(grid, mode, cache=None):
+    """A copy of a bnv_grid_t whose calls run in arithmetic mode ``mode`` (bnv_grid_t.mlp_mode = 1 + mode).  The mode
+    travels with every call instead of living in a process global: two models of different arithmetic, or two host
+    threads, do not interfere.  ``cache``: a dict owned by whoever owns ``grid`` (re-made when ``grid`` is)."""
+    if cache is not None:
+        if cache.get("base") is not grid:
+            cache.clear()
+            cache["base"] = grid
+        g = cache.get(mode)
+        if g is not None:
+            return g
+    g = Grid.from_buffer_copy(grid)
+    g.mlp_mode = int(mode) + 1
+    if cache is not None:
+        cache[mode] = g
+    return g
 
 
 def load():
@@ -176,6 +203,8 @@ def load():
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),
+        "bnv_decode_dense_mode": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]),
+        "bnv_frame_pipe_set_mlp_mode": (C.c_int, [vp, i32]),
         "bnv_shard_install_reset": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp, vp]),
         "bnv_volume_integrate_frame": (C.c_int, [C.POINTER(Volume), vp, vp, vp, i64, vp, vp, sz,
                                                  C.POINTER(IntegrateExtras), vp]),

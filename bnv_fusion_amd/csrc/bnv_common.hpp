@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/bnv_fusion.h"
 
 namespace bnv {
@@ -14,11 +16,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWave = 64;
 extern int g_num_cus;
 extern int g_last_hip_error;
-extern int g_mlp_mode;
-extern int g_reserve_cus;
-extern int g_tcnn_block_encoder;
-extern int g_tcnn_shared_table;
-extern int g_finalize_blocks;
+// process-wide defaults / A-B switches: relaxed atomic words, read once per launch (bnv_set_mlp_mode, bnv_set_option)
+extern std::atomic<int> g_mlp_mode;
+extern std::atomic<int> g_reserve_cus;
+extern std::atomic<int> g_tcnn_block_encoder;
+extern std::atomic<int> g_tcnn_shared_table;
+extern std::atomic<int> g_finalize_blocks;
+// the arithmetic mode of a call: the grid's own (bnv_grid_t.mlp_mode = 1 + m) or the process default
+static inline int mlp_mode_of(int32_t grid_mode) {
+  return grid_mode >= 1 && grid_mode <= 4 ? grid_mode - 1 : g_mlp_mode.load(std::memory_order_relaxed);
+}
+static inline bool mlp_mode_field_ok(int32_t grid_mode) { return grid_mode >= 0 && grid_mode <= 4; }
 
 // optional HIP-event timing of the dominant kernels (bnv_profile_enable / bnv_profile_read)
 enum ProfKind { PROF_POINTNET = 0, PROF_DECODE_LATTICE = 1, PROF_DECODE_PTS = 2, PROF_DECODE_DENSE = 3, PROF_KINDS = 4 };

@@ -2355,8 +2355,8 @@ static unsigned capped_grid(int64_t blocks, int per_cu) {
   return (unsigned)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap));
 }
 
-int g_fused_mark = -1;  // bnv_set_option("fused_mark"): 1 / 0 force, -1 (default): by the call's size
-int g_lattice_pipe = 1; // 1: k_lattice_table_x (cross-tile / cross-layer pipelined, 16x16x32 MFMA); 0: k_decode<LATTICE, 1>
+std::atomic<int> g_fused_mark{-1};  // bnv_set_option("fused_mark"): 1 / 0 force, -1 (default): by the call's size
+std::atomic<int> g_lattice_pipe{1}; // 1: k_lattice_table_x (cross-tile / cross-layer pipelined, 16x16x32 MFMA); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
 constexpr int kProfLds = 2048;
@@ -2364,20 +2364,22 @@ constexpr int kProfLds = 2048;
 constexpr int kProfLds = 0;
 #endif
 
-static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
-  int64_t grid = g_num_cus - g_reserve_cus;
+// `mlp`: the arithmetic mode of the call (mlp_mode_of(grid.mlp_mode))
+static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
+  int64_t grid = g_num_cus - g_reserve_cus.load(std::memory_order_relaxed);
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
-  if (mode == MODE_LATTICE && (g_mlp_mode == 1 || g_mlp_mode == 3) && g_lattice_pipe) {
+  const bool lattice_pipe = g_lattice_pipe.load(std::memory_order_relaxed) != 0;
+  if (mode == MODE_LATTICE && (mlp == 1 || mlp == 3) && lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
-    if (g_mlp_mode == 1)
+    if (mlp == 1)
       hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
     else
       hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
-  if (mode == MODE_LATTICE && g_mlp_mode == 2 && g_lattice_pipe) {
+  if (mode == MODE_LATTICE && mlp == 2 && lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
     int64_t gt = (int64_t)g_num_cus * 4;                    // four 4-wave workgroups per CU, grid-stride over the tiles
     const int64_t wgs = (n_tiles_hint * (DM / 32) + 3) / 4;   // (the hint counts 128-evaluation tiles)
@@ -2395,9 +2397,9 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
     ProfScope prof(PROF_DECODE_PTS, stream);
 #define BNV_LAUNCH_PTS(P) \
   hipLaunchKernelGGL((k_decode_pts<P>), dim3((unsigned)gp), dim3(512), C_TOTAL * 4, stream, args)
-    if (g_mlp_mode == 2) BNV_LAUNCH_PTS(2);
-    else if (g_mlp_mode == 1) BNV_LAUNCH_PTS(1);
-    else if (g_mlp_mode == 3) BNV_LAUNCH_PTS(3);
+    if (mlp == 2) BNV_LAUNCH_PTS(2);
+    else if (mlp == 1) BNV_LAUNCH_PTS(1);
+    else if (mlp == 3) BNV_LAUNCH_PTS(3);
     else BNV_LAUNCH_PTS(0);
 #undef BNV_LAUNCH_PTS
     BNV_LAUNCH_CHECK();
@@ -2407,15 +2409,15 @@ static int launch_decode(int mode, const DecodeArgs& args, int64_t n_tiles_hint,
                  stream);
 #define BNV_LAUNCH_DECODE(M, P) \
   hipLaunchKernelGGL((k_decode<M, P>), dim3((unsigned)grid), dim3(512), L_TOTAL * 4 + kProfLds, stream, args)
-  if (g_mlp_mode == 2) {
+  if (mlp == 2) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 2);
     else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 2);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 2);
-  } else if (g_mlp_mode == 1) {
+  } else if (mlp == 1) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 1);
     else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 1);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 1);
-  } else if (g_mlp_mode == 3) {
+  } else if (mlp == 3) {
     if (mode == MODE_LATTICE) BNV_LAUNCH_DECODE(MODE_LATTICE, 3);
     else if (mode == MODE_DENSE1) BNV_LAUNCH_DECODE(MODE_DENSE1, 3);
     else BNV_LAUNCH_DECODE(MODE_DENSE, 3);
@@ -2487,29 +2489,29 @@ int bnv_dev_phase_read(unsigned long long* out256) {
 int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;
   if (!strcmp(name, "lattice_pipe")) {
-    g_lattice_pipe = value;
+    g_lattice_pipe.store(value, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "fused_mark")) {
-    g_fused_mark = value;
+    g_fused_mark.store(value, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "tcnn_block_encoder")) {
-    g_tcnn_block_encoder = value != 0;
+    g_tcnn_block_encoder.store(value != 0, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "finalize_blocks")) {
     if (value < 0) return BNV_ERR_INVALID_ARGUMENT;
-    g_finalize_blocks = value;
+    g_finalize_blocks.store(value, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "tcnn_shared_table")) {
-    g_tcnn_shared_table = value != 0;
+    g_tcnn_shared_table.store(value != 0, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value >= g_num_cus) return BNV_ERR_INVALID_ARGUMENT;
-    g_reserve_cus = value;
+    g_reserve_cus.store(value, std::memory_order_relaxed);
     return BNV_OK;
   }
   return BNV_ERR_INVALID_ARGUMENT;
@@ -2520,6 +2522,7 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
                    const bnv_sdf_delta_t* delta, float* out_sdf, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (!mlp_mode_field_ok(grid->mlp_mode)) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   if (!coords || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
   DecodeArgs a = {};
@@ -2534,7 +2537,7 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
   a.is_coords = is_coords;
   if (delta) a.delta = *delta;
   a.out = out_sdf;
-  return launch_decode(MODE_PTS, a, (n + 15) / 16, (hipStream_t)stream);
+  return launch_decode(MODE_PTS, mlp_mode_of(grid->mlp_mode), a, (n + 15) / 16, (hipStream_t)stream);
 }
 
 size_t bnv_sdfmlp_bwd_pack_floats(void) { return SB_PACK_FLOATS; }
@@ -2545,7 +2548,8 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
                             const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
                             const float* grad_sdf, float* grad_features, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0)
+  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0 ||
+      !mlp_mode_field_ok(grid->mlp_mode))
     return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   if (!coords || !grad_sdf || !grad_features) return BNV_ERR_INVALID_ARGUMENT;
@@ -2565,7 +2569,7 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
   int64_t nblk = (n + PC_Q - 1) / PC_Q;
   if (nblk > g_num_cus) nblk = g_num_cus;
   ProfScope prof(PROF_DECODE_PTS, (hipStream_t)stream);
-  if (g_mlp_mode == 2)
+  if (mlp_mode_of(grid->mlp_mode) == 2)
     hipLaunchKernelGGL(k_decode_pts_bwd_t, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
   else
     hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
@@ -2576,8 +2580,18 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
 int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int32_t dims[3], float voxel_size,
                      int32_t min_pts_in_grid, const float* sdfmlp_pack, const float* voxel_coords, int64_t n,
                      int32_t variant, float* out_sdf, float* out_feats, int32_t* status, bnv_stream_t stream) {
+  return bnv_decode_dense_mode(feat_grid, pts_weight, dims, voxel_size, min_pts_in_grid, sdfmlp_pack, voxel_coords, n,
+                               variant, 0, out_sdf, out_feats, status, stream);
+}
+
+int bnv_decode_dense_mode(const float* feat_grid, const float* pts_weight, const int32_t dims[3], float voxel_size,
+                          int32_t min_pts_in_grid, const float* sdfmlp_pack, const float* voxel_coords, int64_t n,
+                          int32_t variant, int32_t mlp_mode, float* out_sdf, float* out_feats, int32_t* status,
+                          bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!feat_grid || !pts_weight || !dims || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (!feat_grid || !pts_weight || !dims || !sdfmlp_pack || n < 0 || !mlp_mode_field_ok(mlp_mode))
+    return BNV_ERR_INVALID_ARGUMENT;
+  const int mlp = mlp_mode_of(mlp_mode);
   if (variant < BNV_DENSE_CORNERS || variant > BNV_DENSE_GLOBAL) return BNV_ERR_INVALID_ARGUMENT;
   if (variant == BNV_DENSE_CORNERS && out_feats) return BNV_ERR_INVALID_ARGUMENT;
   if (dims[0] < 2 || dims[1] < 2 || dims[2] < 2) return BNV_ERR_INVALID_ARGUMENT;   // coords / (res - 1)
@@ -2599,8 +2613,8 @@ int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int3
   a.dims[0] = dims[0];
   a.dims[1] = dims[1];
   a.dims[2] = dims[2];
-  if (variant != BNV_DENSE_CORNERS) return launch_decode(MODE_DENSE1, a, (n + DM - 1) / DM, (hipStream_t)stream);
-  return launch_decode(MODE_DENSE, a, (n + 15) / 16, (hipStream_t)stream);
+  if (variant != BNV_DENSE_CORNERS) return launch_decode(MODE_DENSE1, mlp, a, (n + DM - 1) / DM, (hipStream_t)stream);
+  return launch_decode(MODE_DENSE, mlp, a, (n + 15) / 16, (hipStream_t)stream);
 }
 
 size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity) {
@@ -2712,7 +2726,8 @@ int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const flo
                       const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr, size_t ws_bytes,
                       bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
+  if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr || !mlp_mode_field_ok(grid->mlp_mode))
+    return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n_voxels, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes)
     return BNV_ERR_WORKSPACE_TOO_SMALL;
@@ -2727,7 +2742,7 @@ int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const flo
   a.need_mask = ws.need_mask;
   a.entries = use_entries ? ws.entries : nullptr;
   const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
-  return launch_decode(MODE_LATTICE, a, (evals + DM - 1) / DM, (hipStream_t)stream);
+  return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream);
 }
 
 int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
@@ -2756,14 +2771,15 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
                                void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bool prestamped,
                                bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!features || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (!features || !sdfmlp_pack || !grid || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  Small calls (a
   // shard's 1/8 of a frame) look the neighbour rows up inside the marking kernel: one launch less, -9 us of a 0.28 ms
   // frame; on whole frames the 256-thread look-up kernel of its own hides the three dependent loads of a look-up
   // better than the 1,024-thread marking workgroups do (48.7 us for the pair against 62.4 us fused)
   int rc;
-  const bool fuse = g_fused_mark == 1 || (g_fused_mark < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
+  const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
+  const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
   if (fuse) {
     rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
                                       prestamped, stream);

@@ -31,11 +31,13 @@ namespace bnv {
 
 int g_num_cus = 0;
 int g_last_hip_error = 0;
-int g_reserve_cus = 0;  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
-int g_finalize_blocks = 0;      // bnv_set_option("finalize_blocks"): workgroups of k_finalize (0: 8 per CU); tests force the striding with a small value
-int g_tcnn_shared_table = 1;    // bnv_set_option("tcnn_shared_table"): 1 = one LDS table per workgroup and 16 x 16 patch, 0 = per wave and block
-int g_tcnn_block_encoder = 1;  // bnv_set_option("tcnn_block_encoder"): 1 = k_pointnet_scatter_tb for whole frames
-int g_mlp_mode = 1;  // 0: exact fp32 MFMA; 1: fp32 operands split into f16 hi+lo; 2: tcnn fp16 networks; 3: f16 operands
+// Process-wide words, all relaxed atomics read once per launch.  The A/B switches choose between implementations with
+// identical results; the MLP mode here is only the DEFAULT of calls whose grid does not name one (bnv_grid_t.mlp_mode).
+std::atomic<int> g_reserve_cus{0};  // bnv_set_option("reserve_cus"): CUs the persistent MLP kernels leave to other streams
+std::atomic<int> g_finalize_blocks{0};      // bnv_set_option("finalize_blocks"): workgroups of k_finalize (0: 2 per CU, which is also the most it may use); tests force the striding with a small value
+std::atomic<int> g_tcnn_shared_table{1};    // bnv_set_option("tcnn_shared_table"): 1 = one LDS table per workgroup and 16 x 16 patch, 0 = per wave and block
+std::atomic<int> g_tcnn_block_encoder{1};  // bnv_set_option("tcnn_block_encoder"): 1 = k_pointnet_scatter_tb for whole frames
+std::atomic<int> g_mlp_mode{1};  // default arithmetic: 0 exact fp32 MFMA; 1 fp32 operands split into f16 hi+lo; 2 tcnn fp16 networks; 3 f16 operands
 
 // ---- HIP-event timing of the dominant kernels, recorded on the stream they are launched on ----
 bool g_prof_on = false;
@@ -1512,7 +1514,8 @@ __global__ __launch_bounds__(kFinTile) void k_finalize(
         // contributes exactly 8 pairs, so the fp32 sum torch.mean forms is exactly 8 * n_valid
         counters->n_avg_pts = __fdiv_rn((float)(8 * nv), (float)n);
         counters->error = ctl->error ? ctl->error : ((int64_t)n_out > out_capacity ? 2 : 0);
-        counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
+        counters->reserved[0] = ctl->n_pairs;   // sharded encode: the (point, corner) pairs this rank encoded
+        counters->reserved[1] = counters->reserved[2] = 0;
         ctl->n_unique = 0;
         ctl->error = 0;
         ctl->n_pairs = 0;
@@ -1647,10 +1650,10 @@ size_t bnv_pointnet_pack_floats(void) { return PN_PACK_FLOATS; }
 
 int bnv_set_mlp_mode(int mode) {
   if (mode < 0 || mode > 3) return BNV_ERR_INVALID_ARGUMENT;
-  g_mlp_mode = mode;
+  g_mlp_mode.store(mode, std::memory_order_relaxed);
   return BNV_OK;
 }
-int bnv_get_mlp_mode(void) { return g_mlp_mode; }
+int bnv_get_mlp_mode(void) { return g_mlp_mode.load(std::memory_order_relaxed); }
 
 int bnv_profile_enable(int on) {
   for (int k = 0; k < PROF_KINDS; ++k) g_prof_used[k] = 0;
@@ -1696,13 +1699,15 @@ static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, hipStream_t stre
 }
 
 // The tiny-cuda-nn block encoder finds a shard's pairs itself: `begin` then makes no pair list.  (begin and finish of
-// one frame run under one MLP mode: the mode follows the weight pack.)
-static bool tcnn_blocks() { return g_mlp_mode == 2 && g_tcnn_block_encoder; }
+// one frame are called with the same grid, hence the same MLP mode: the mode follows the weight pack.)
+static bool tcnn_blocks(const bnv_grid_t& g) {
+  return mlp_mode_of(g.mlp_mode) == 2 && g_tcnn_block_encoder.load(std::memory_order_relaxed);
+}
 
 static bool grid_ok(const bnv_grid_t& g) {
   return (int64_t)g.n_xyz[0] * g.n_xyz[1] * g.n_xyz[2] < (1LL << 31) && g.n_xyz[0] > 0 && g.n_xyz[1] > 0 &&
          g.n_xyz[2] > 0 && g.shard_world >= 1 && g.shard_world <= 64 && g.shard_rank >= 0 &&
-         g.shard_rank < g.shard_world;
+         g.shard_rank < g.shard_world && mlp_mode_field_ok(g.mlp_mode);
 }
 
 size_t bnv_encode_shard_counts_offset(void) { return offsetof(EncCtl, shard_boundary); }
@@ -1723,7 +1728,7 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   const int n = (int)n_points;
   hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bytemap, ws.chunk_flag,
                      ws.valid_blocks,
-                     (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1744,7 +1749,7 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bytemap,
-                     ws.chunk_flag, ws.valid_blocks, (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     ws.chunk_flag, ws.valid_blocks, (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
   BNV_LAUNCH_CHECK();
   return encode_rank(ws, g, stream);
 }
@@ -1779,28 +1784,30 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
   const int n = (int)n_points;
   // point encoder + scatter
   const int n_tiles = ((n + 31) / 32) * 8;
-  int grid_pn = g_num_cus - g_reserve_cus > 0 ? g_num_cus - g_reserve_cus : 1;
+  const int reserve = g_reserve_cus.load(std::memory_order_relaxed);
+  int grid_pn = g_num_cus - reserve > 0 ? g_num_cus - reserve : 1;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
+  const int mlp = mlp_mode_of(g.mlp_mode);
   // sharded: owned pairs only -- from the list `begin` made, or (block encoder) by an ownership test in the kernel
-  const int32_t* plist = (g.shard_world > 1 && !tcnn_blocks()) ? ws.pair_list : (const int32_t*)nullptr;
+  const int32_t* plist = (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (const int32_t*)nullptr;
   {
     ProfScope prof(PROF_POINTNET, stream);
-    if (tcnn_blocks()) {
+    if (tcnn_blocks(g)) {
       const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
       const int n_units = (n_blocks + kTbWaves - 1) / kTbWaves + 64;   // (16 x 16 patches: up to ragged edges)
       const int grid_tb = g_num_cus * 2 < n_units ? g_num_cus * 2 : n_units;
-      auto kern = g_tcnn_shared_table ? k_pointnet_scatter_tb<true> : k_pointnet_scatter_tb<false>;
+      auto kern = g_tcnn_shared_table.load(std::memory_order_relaxed) ? k_pointnet_scatter_tb<true> : k_pointnet_scatter_tb<false>;
       hipLaunchKernelGGL(kern, dim3(grid_tb), dim3(64 * kTbWaves), 0, stream, input_pts, n, image_width, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);
-    } else if (g_mlp_mode == 2)
+    } else if (mlp == 2)
       hipLaunchKernelGGL(k_pointnet_scatter_t, dim3(g_num_cus * 4 < (n_tiles + 3) / 4 ? g_num_cus * 4 : (n_tiles + 3) / 4),
                          dim3(256), 0, stream, input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts,
                          ws.acc, plist, &ws.ctl->n_pairs);
-    else if (g_mlp_mode == 1) {
+    else if (mlp == 1) {
       hipLaunchKernelGGL((k_pointnet_scatter_x<3>), dim3(grid_pn), dim3(512), PX_LDS_BYTES + kEncProfLds, stream,
                          input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
                          plist, &ws.ctl->n_pairs);
-    } else if (g_mlp_mode == 3) {
+    } else if (mlp == 3) {
       hipLaunchKernelGGL((k_pointnet_scatter_x<1>), dim3(grid_pn), dim3(512), PX_LDS_BYTES + kEncProfLds, stream,
                          input_pts, n, g, pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, &ws.ctl->error,
                          plist, &ws.ctl->n_pairs);
@@ -1812,7 +1819,11 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
   // ordered compaction of the emitted voxels; the number of slots is only known on the device: a capped grid strides
   // over the tiles
   const int nb_max = (int)((ws.max_unique + kFinTile - 1) / kFinTile);
-  const int nb_cap = g_finalize_blocks > 0 ? g_finalize_blocks : 2 * g_num_cus;
+  // forward progress of the look-back needs every launched workgroup resident at once (a tile waits for its
+  // predecessor's word): 1,024-thread workgroups, 2 per CU at most -- the option can lower the count, never raise it
+  const int nb_res = 2 * g_num_cus;
+  const int nb_opt = g_finalize_blocks.load(std::memory_order_relaxed);
+  const int nb_cap = nb_opt > 0 && nb_opt < nb_res ? nb_opt : nb_res;
   const int nb_u = nb_max < nb_cap ? nb_max : nb_cap;
   hipLaunchKernelGGL(k_finalize, dim3(nb_u), dim3(kFinTile), 0, stream, g, emit_all, ws.bitmap, ws.ids,
                      ws.counts, ws.acc, ws.tile_state, next_epoch(), ws.ctl, ws.valid_blocks, (n + 255) / 256, out_feats,

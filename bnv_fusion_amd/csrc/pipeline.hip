@@ -54,8 +54,16 @@ struct bnv_frame_pipe {
   int state[BNV_PIPE_MAX_SLOTS];        // 0 free, 1 begun, 2 upserted, 3 finished (result pending)
   bool used[BNV_PIPE_MAX_SLOTS];        // ev_done has been recorded at least once
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
+  int32_t mlp_mode[BNV_PIPE_MAX_SLOTS];   // bnv_grid_t.mlp_mode a slot's frame was begun with (its decode uses the same)
   size_t bound_off;
 };
+
+// the pipe's grid with the arithmetic mode of the slot's frame
+static bnv_grid_t slot_grid(const bnv_frame_pipe* p, int slot) {
+  bnv_grid_t g = p->cfg.grid;
+  g.mlp_mode = p->mlp_mode[slot];
+  return g;
+}
 
 static bool slot_ok(const bnv_frame_pipe* p, int slot) { return p && slot >= 0 && slot < p->cfg.n_slots; }
 
@@ -79,7 +87,8 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   if (!cfg || !out || cfg->n_slots < 1 || cfg->n_slots > BNV_PIPE_MAX_SLOTS || !cfg->pointnet_pack || !cfg->enc_ws ||
       cfg->max_points < 1 || cfg->enc_ws_max_points < cfg->max_points || cfg->out_capacity < 1)
     return BNV_ERR_INVALID_ARGUMENT;
-  if (cfg->grid.shard_world < 1 || cfg->grid.shard_world > 64) return BNV_ERR_INVALID_ARGUMENT;
+  if (cfg->grid.shard_world < 1 || cfg->grid.shard_world > 64 || !mlp_mode_field_ok(cfg->grid.mlp_mode))
+    return BNV_ERR_INVALID_ARGUMENT;
   for (int s = 0; s < cfg->n_slots; ++s) {
     const bnv_frame_slot_t& b = cfg->slots[s];
     if (!b.feats || !b.pcounts || !b.flat_ids || !b.grid_ids || !b.counters || !b.host_words)
@@ -96,6 +105,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->state[s] = 0;
     p->used[s] = false;
     p->n_points[s] = 0;
+    p->mlp_mode[s] = cfg->grid.mlp_mode;
     p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_done[s] = nullptr;
     p->host_dev[s] = nullptr;
   }
@@ -113,6 +123,12 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
       }
   }
   *out = p;
+  return BNV_OK;
+}
+
+int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* p, int32_t grid_mlp_mode) {
+  if (!p || !mlp_mode_field_ok(grid_mlp_mode)) return BNV_ERR_INVALID_ARGUMENT;
+  p->cfg.grid.mlp_mode = grid_mlp_mode;
   return BNV_OK;
 }
 
@@ -137,7 +153,8 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
                                  4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->E));
   }
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->E));
-  const int rc = bnv_encode_finish_image(pts, n, image_width, &c.grid, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes,
+  const bnv_grid_t g = slot_grid(p, slot);
+  const int rc = bnv_encode_finish_image(pts, n, image_width, &g, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes,
                                          c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
                                          c.out_capacity, 0, b.counters, p->E);
   if (rc != BNV_OK) return rc;
@@ -151,6 +168,7 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
   if (!slot_ok(p, slot) || p->state[slot] != 0) return BNV_ERR_INVALID_ARGUMENT;
   // the slot's buffers are still read by the main-stream work of the frame that used it last
   if (p->used[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_done[slot], 0));
+  p->mlp_mode[slot] = p->cfg.grid.mlp_mode;   // the frame keeps the mode it starts under (bnv_frame_pipe_set_mlp_mode)
   return BNV_OK;
 }
 
@@ -163,7 +181,8 @@ int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int 
   if (c.tsdf.tsdf && depth_dtype == 2) return BNV_ERR_INVALID_ARGUMENT;   // the TSDF kernel reads f32 / u16 images
   int rc = begin_head(p, slot);
   if (rc != BNV_OK) return rc;
-  rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &c.grid, c.enc_ws,
+  const bnv_grid_t g = slot_grid(p, slot);
+  rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &g, c.enc_ws,
                               c.enc_ws_bytes, c.enc_ws_max_points, b.input_pts, p->E);
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W, W);
@@ -192,7 +211,8 @@ int bnv_frame_begin_points(bnv_frame_pipe_t* p, int slot, const float* input_pts
   if (rc != BNV_OK) return rc;
   const bnv_frame_pipe_config_t& c = p->cfg;
   if (!input_pts || n_points < 0 || n_points > c.max_points) return BNV_ERR_INVALID_ARGUMENT;
-  rc = bnv_encode_begin(input_pts, n_points, &c.grid, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points, p->E);
+  const bnv_grid_t g = slot_grid(p, slot);
+  rc = bnv_encode_begin(input_pts, n_points, &g, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points, p->E);
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, input_pts, n_points, 0);
   if (rc != BNV_OK) return rc;
@@ -239,6 +259,8 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   if (!slot_ok(p, slot) || p->state[slot] != 2 || !vol) return BNV_ERR_INVALID_ARGUMENT;
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
+  // the exchanged blocks are prefixes of the slots' send blocks: more records than those hold were never sent
+  if (blocks && block_capacity > c.send_capacity) return BNV_ERR_INVALID_ARGUMENT;
   int rc;
   if (c.grid.shard_world > 1 && blocks && block_capacity > 0) {
     rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
@@ -246,7 +268,8 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   }
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
-    rc = bnv_decode_lattice_stamped(vol, &c.grid, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+    const bnv_grid_t g = slot_grid(p, slot);
+    rc = bnv_decode_lattice_stamped(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
                                     b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws,
                                     lattice_ws_bytes, lattice_epoch, b.sdf, p->M);
     if (rc != BNV_OK) return rc;

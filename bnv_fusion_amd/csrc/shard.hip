@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
   if (sender < world && sender != g.shard_rank) {
     const ShardRec* blk = blocks + (size_t)sender * (size_t)(capacity + 1);
     int cnt = blk[0].x;
-    if (blk[0].z) *error = 4;   // the sender's block overflowed: records are missing
+    // the sender's block overflowed, or it holds more records than were exchanged: records are missing
+    if (blk[0].z || cnt > capacity) *error = 4;
     if (cnt > capacity) cnt = (int)capacity;
     if (i < cnt) {
       r = blk[1 + i];

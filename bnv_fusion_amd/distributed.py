@@ -112,8 +112,11 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership="hash"):
         from .sparse_volume import SparseVolume, make_grid
+        if ownership not in ("hash",):
+            raise ValueError(f"unknown ownership rule {ownership!r}")
+        self.ownership = ownership
         self.pointnet = pointnet
         self.rank, self.world = rank, world
         pointnet.shard = (rank, world, BLOCK_LOG2)
@@ -137,6 +140,7 @@ class HipShardBackend:
         self.pipe = None
         self._recv = None
         self._last_evals = 0
+        self.last_owned_pairs = 0
 
     def _pipe_for(self, frame):
         n = int(frame["input_pts"].shape[1]) if "input_pts" in frame else int(frame["depth"].shape[-2] * frame["depth"].shape[-1])
@@ -161,13 +165,28 @@ class HipShardBackend:
         """Largest number of boundary records any rank can send for this frame (the same number on every rank)."""
         return self.pipe.bound(fr.slot) if self.world > 1 else 0
 
+    def exchange_capacity(self, bound):
+        """Records per rank the frame's all-gather moves: the bound rounded up to REC_QUANTUM, but never more than a
+        slot's send block holds.  The bound counts TOUCHED boundary voxels (before the min-points filter) and the
+        send block is sized for the voxels a frame can EMIT (8 * points / min_pts + 1), which is what a rank really
+        sends: a small or sparse frame can have bound > send_cap, and the exchange must not run past the block.
+        Every rank computes the same number (same bound, same frame sizes)."""
+        if bound <= 0:
+            return 0
+        return min(-(-bound // REC_QUANTUM) * REC_QUANTUM, self.pipe.send_cap)
+
     def upsert(self, fr, capacity, decode=True):
         """Main stream: upsert of the owned voxels in ONE launch that also appends their boundary records to the slot's
         send block and stamps them as the frame's decode origins.  -> this rank's block (header + ``capacity``
         records, int32 words) or None when nothing is exchanged."""
         fr.decode = decode
         send = self.pipe.upsert(fr.slot, decode=decode, ghost_rows=(self.world - 1) * capacity)
-        return None if capacity == 0 else send[: (capacity + 1) * REC_WORDS]
+        if capacity == 0:
+            return None
+        if (capacity + 1) * REC_WORDS > send.numel():
+            raise _lib.BnvError(f"exchange capacity {capacity} exceeds the slot's send block "
+                                f"({send.numel() // REC_WORDS - 1} records)")
+        return send[: (capacity + 1) * REC_WORDS]
 
     def recv_buffer(self, words):
         if self._recv is None or self._recv.numel() < words:
@@ -191,8 +210,9 @@ class HipShardBackend:
     def result(self, fr):
         """-> (coords [U'_r, 3] of the voxels this rank owns among the frame's, sdf [U'_r, 27]) or (None, None)."""
         w = self.pipe.result(fr.slot)
-        from .pipeline import W_EVALS
+        from .pipeline import W_EVALS, W_COUNTERS
         self._last_evals = int(w[W_EVALS])
+        self.last_owned_pairs = int(w[W_COUNTERS + 5])      # bnv_encode_counters_t.reserved[0]
         return self.pipe.outputs(fr.slot, w, copy=self.copy_results)
 
     def owned_rows_mask(self):
@@ -206,13 +226,26 @@ class HipShardBackend:
 
 
 class ShardHandle:
+    """One frame of ShardedNeuralMap.  ``result()`` waits for that frame only; a failure is raised once and again on
+    every later call (the frame's slot is free either way)."""
+
     def __init__(self, nm, fr):
-        self._nm, self._fr, self._done = nm, fr, None
+        self._nm, self._fr, self._done, self._err = nm, fr, None, None
+
+    @property
+    def pending(self):
+        return self._done is None and self._err is None
 
     def result(self):
+        if self._err is not None:
+            raise self._err
         if self._done is None:
-            self._done = self._nm.backend.result(self._fr)
-            self._fr = None
+            fr, self._fr = self._fr, None
+            try:
+                self._done = self._nm.backend.result(fr)
+            except Exception as e:
+                self._err = e
+                raise
         return self._done
 
 
@@ -238,20 +271,34 @@ class ShardedNeuralMap:
         self.exchanged_bytes = 0          # bytes this rank has received in all-gathers (statistics)
         self.host_waits = 0
         self._open = []                   # handles not collected yet, oldest first (HIP backend: they hold slots)
+        self._pre = None                  # (frame, ShardFrame) whose encode was enqueued ahead (next_frame)
 
-    def fuse_and_decode_async(self, frame, decode=True):
+    def fuse_and_decode_async(self, frame, decode=True, next_frame=None):
+        """``next_frame``: the frame the NEXT call will pass (the same object), if the caller knows it: its encode is
+        enqueued now, BEFORE the host waits for this frame's exchange bound, so the encode stream always holds a frame
+        more than the main stream and never idles while the host enqueues this frame's upsert .. decode."""
         import torch.distributed as dist
         be = self.backend
         ring = getattr(be, "n_slots", None)
+        ahead = next_frame is not None and ring is not None
         if ring is not None:
-            self._open = [h for h in self._open if h._done is None]
-            while len(self._open) >= ring:            # the slot ring is full: collect the oldest frame
-                self._open.pop(0).result()
+            self._open = [h for h in self._open if h.pending]
+            need = 1 + (1 if ahead else 0) - (1 if self._pre is not None else 0)
+            while self._open and len(self._open) + (1 if self._pre is not None else 0) + need > ring:
+                self._open.pop(0).result()            # the slot ring is full: collect the oldest frame
         with torch.no_grad():
-            fr = be.encode(frame)
+            if self._pre is not None:
+                if self._pre[0] is not frame:
+                    raise _lib.BnvError("fuse_and_decode_async: the frame announced as next_frame must be the next one passed")
+                fr, self._pre = self._pre[1], None
+            else:
+                fr = be.encode(frame)
+            if ahead:
+                self._pre = (next_frame, be.encode(next_frame))
             bound = be.bound(fr)                       # the frame's one host wait
             self.host_waits += 1
-            capacity = -(-bound // REC_QUANTUM) * REC_QUANTUM
+            capacity = (be.exchange_capacity(bound) if hasattr(be, "exchange_capacity")
+                        else -(-bound // REC_QUANTUM) * REC_QUANTUM)
             send = be.upsert(fr, capacity, decode)
             reserved = 0
             if capacity > 0:

@@ -26,8 +26,8 @@ def export(out_dir, model, volume, depths_u16, K, poses, max_depth=3.0, mlp_mode
     depths = [np.ascontiguousarray(d, dtype="<u2") for d in depths_u16]
     H, W = depths[0].shape
     if mlp_mode is None:
-        mlp_mode = 2 if getattr(model, "tiny_cuda", False) else _lib.fp32_mode
-    gb = bytes(grid)
+        mlp_mode = _lib.model_mode(model)
+    gb = bytes(_lib.grid_with_mode(grid, mlp_mode))
     head = struct.pack("<4i d 9d", H, W, len(depths), int(mlp_mode), float(max_depth),
                        *np.asarray(K, dtype=np.float64)[:3, :3].reshape(-1))
     body = head + gb

@@ -60,6 +60,7 @@ class LocalNeRFModel(nn.Module):
         for i in range(num_layers):
             setattr(self, f"geo_layer{i}", nn.Linear(dims[i], dims[i + 1]))
         self.fc_alpha = nn.Linear(hidden_size, 1)
+        self.mlp_mode = None     # arithmetic of the decode kernels: None = the package default (LitFusionPointNet.set_mlp_mode)
         self.num_layers = num_layers
         self.register_buffer("sdf_pack", torch.zeros(int(_lib.load().bnv_sdfmlp_pack_floats())), persistent=False)
         # transposed layers for the backward of decode_pts w.r.t. the volume features (global optimiser)
@@ -163,6 +164,7 @@ class LitFusionPointNet(nn.Module):
         self._enc_ws_key = None
         self._enc_ws_points = 0
         self._grid_cache = {}
+        self._mlp_mode = None    # fp32 checkpoints: None = the package default (set_mlp_mode pins this model)
 
     # ---- nn.Module plumbing --------------------------------------------------------------------
     @property
@@ -185,12 +187,23 @@ class LitFusionPointNet(nn.Module):
         self.pointnet_pack[: w.numel()].copy_(w)
         self.nerf.repack()
 
-    def _select_mode(self, lib):
-        """MLP arithmetic for this model's kernels: 2 for tcnn checkpoints, else the fp32 mode in force."""
+    @property
+    def mlp_mode(self):
+        """Arithmetic of this model's MLP kernels (include/bnv_fusion.h: bnv_set_mlp_mode): 2 for tiny-cuda-nn
+        checkpoints; else the mode ``set_mlp_mode`` gave this model, else None = the package default
+        (bnv_fusion_amd.set_mlp_mode).  It is passed with every call (bnv_grid_t.mlp_mode), never through a global."""
+        return 2 if self.tiny_cuda else self._mlp_mode
+
+    def set_mlp_mode(self, mode):
+        """Pins THIS model (encoder and decoder) to an fp32-checkpoint arithmetic mode: 0 exact fp32, 1 split f16,
+        3 f16 operands; None: follow the package default again."""
         if self.tiny_cuda:
-            lib.bnv_set_mlp_mode(2)
-        elif lib.bnv_get_mlp_mode() == 2:
-            lib.bnv_set_mlp_mode(_lib.fp32_mode)
+            raise _lib.BnvError("a tiny-cuda-nn checkpoint runs in MLP mode 2 only")
+        if mode is not None and int(mode) not in (0, 1, 3):
+            raise ValueError("mlp mode of an fp32 checkpoint: 0, 1 or 3")
+        self._mlp_mode = None if mode is None else int(mode)
+        self.nerf.mlp_mode = self._mlp_mode
+        return self
 
     def freeze(self):
         for p in self.parameters():
@@ -210,14 +223,15 @@ class LitFusionPointNet(nn.Module):
         device->host reads; anything else is re-read."""
         args = (n_xyz, bound_min, bound_max)
         c = self._grid_cache
-        if c and c["voxel"] == float(voxel_size) and c["extra"] == (self.min_pts_in_grid, self.shard) and all(
+        mode = _lib.model_mode(self)
+        if c and c["voxel"] == float(voxel_size) and c["extra"] == (self.min_pts_in_grid, self.shard, mode) and all(
                 isinstance(a, torch.Tensor) and r() is a and a._version == v
                 for a, r, v in zip(args, c["refs"], c["versions"])):
             return c["grid"], c["res"]
         res = [int(v) for v in n_xyz]
-        grid = make_grid(res, bound_min, bound_max, voxel_size, self.min_pts_in_grid, self.shard)
+        grid = make_grid(res, bound_min, bound_max, voxel_size, self.min_pts_in_grid, self.shard, mlp_mode=mode)
         if all(isinstance(a, torch.Tensor) for a in args):
-            self._grid_cache = {"voxel": float(voxel_size), "extra": (self.min_pts_in_grid, self.shard),
+            self._grid_cache = {"voxel": float(voxel_size), "extra": (self.min_pts_in_grid, self.shard, mode),
                                 "refs": [weakref.ref(a) for a in args], "versions": [a._version for a in args],
                                 "grid": grid, "res": res}
         return grid, res
@@ -266,7 +280,6 @@ class LitFusionPointNet(nn.Module):
         between the two halves of the encode (voxelise + sorted-unique | PointNet + reduction), e.g. to enqueue a
         read-back of shard_boundary_counts()."""
         lib = self._lib_for(self.pointnet_pack)
-        self._select_mode(lib)
         assert input_pts.dim() == 3 and input_pts.shape[0] == 1 and input_pts.shape[2] == 6
         pts = input_pts[0].detach().float().contiguous()
         n = int(pts.shape[0])
@@ -292,7 +305,6 @@ class LitFusionPointNet(nn.Module):
         [1, H*W, 6]."""
         from .frontend import DEPTH_DTYPES
         lib = self._lib_for(self.pointnet_pack)
-        self._select_mode(lib)
         if not depth.is_cuda:
             raise _lib.BnvError("encode_depth_async runs on the GPU only")
         d = depth.contiguous()
@@ -379,7 +391,6 @@ class LitFusionPointNet(nn.Module):
                                       "(local_point_fusion.py:368 uses an undefined name); use SparseVolume.decode_pts "
                                       "for gradients")
         lib = self._lib_for(voxel_coords)
-        self._select_mode(lib)
         q = voxel_coords.detach().reshape(-1, 3).float().contiguous()
         n = int(q.shape[0])
         fg = feat_grid.detach().float().contiguous()
@@ -389,10 +400,11 @@ class LitFusionPointNet(nn.Module):
         variant = 2 if global_coords else (0 if self.interpolate_decode else 1)
         nf1 = torch.empty((n, 8), dtype=torch.float32, device=q.device) if variant else None
         status = torch.zeros(2, dtype=torch.int32, device=q.device)
-        _lib.check(lib.bnv_decode_dense(_lib.ptr(fg), _lib.ptr(pw), dims, float(np.float32(voxel_size)),
-                                        self.min_pts_in_grid, _lib.ptr(self.nerf.sdf_pack), _lib.ptr(q), n, variant,
-                                        _lib.ptr(out), _lib.ptr(nf1) if variant else None, _lib.ptr(status),
-                                        _lib.stream_ptr()), "bnv_decode_dense")
+        _lib.check(lib.bnv_decode_dense_mode(_lib.ptr(fg), _lib.ptr(pw), dims, float(np.float32(voxel_size)),
+                                             self.min_pts_in_grid, _lib.ptr(self.nerf.sdf_pack), _lib.ptr(q), n, variant,
+                                             _lib.model_mode(self) + 1, _lib.ptr(out),
+                                             _lib.ptr(nf1) if variant else None, _lib.ptr(status),
+                                             _lib.stream_ptr()), "bnv_decode_dense_mode")
         if int(status[1]) == 5:
             raise RuntimeError("decode_feature_grid_w_pts: a feature is outside the range the split-f16 MLP arithmetic "
                                "is certified for (or not finite); call bnv_set_mlp_mode(0) (exact fp32) for this grid")

@@ -65,8 +65,9 @@ class FramePipe:
         self.host = torch.zeros((S, HOST_WORDS), dtype=torch.int32).pin_memory()
         self._host_np = self.host.numpy()
         cfg = _lib.FramePipeConfig()
-        self._grid = v._grid
-        cfg.grid = v._grid
+        self._mode = _lib.model_mode(pointnet)
+        self._grid = _lib.grid_with_mode(v._grid, self._mode)
+        cfg.grid = self._grid
         cfg.max_points, cfg.out_capacity, cfg.send_capacity = self.max_points, cap, self.send_cap
         cfg.pointnet_pack = pointnet.pointnet_pack.data_ptr()
         cfg.enc_ws, cfg.enc_ws_bytes, cfg.enc_ws_max_points = self._enc_ws.data_ptr(), need, self.max_points
@@ -110,32 +111,56 @@ class FramePipe:
         except Exception:
             pass
 
+    def _check_device(self, t, name):
+        if not t.is_cuda or (self.dev.index is not None and t.device.index != self.dev.index):
+            raise _lib.BnvError(f"FramePipe: {name} is on {t.device}, the pipe runs on {self.dev} "
+                                "(frames are device tensors; there is no host path)")
+
     # ---- phases -----------------------------------------------------------------------------------
     def free_slot(self):
-        """The next slot of the ring, or None while the frame that holds it has not been collected."""
-        s = self._next
-        return None if self._busy[s] else s
+        """A slot no uncollected frame holds -- the next of the ring if it is free, else the first free one behind it
+        (frames may be collected in any order) -- or None."""
+        for k in range(self.n_slots):
+            s = (self._next + k) % self.n_slots
+            if not self._busy[s]:
+                return s
+        return None
 
     def begin(self, frame, slot=None):
-        s = self._next if slot is None else slot
-        assert not self._busy[s], "slot still holds an uncollected frame"
+        s = self.free_slot() if slot is None else slot
+        if s is None or self._busy[s]:
+            raise _lib.BnvError("FramePipe.begin: every slot holds an uncollected frame (collect one with result())")
         lib = self._lib
+        # conversions first (they run on the CALLER's stream), then the encode stream waits for that stream: whenever a
+        # conversion really ran -- or the caller has not declared its frames complete in device memory
+        # (inputs_resident) -- the encode must not start before the caller's stream has produced the buffer
         col = None
+        converted = False
         if "input_pts" not in frame and self.tsdf_vol is not None and frame.get("rgb") is not None:
             col = self.tsdf_vol._fold_color(frame["rgb"])                 # (caller's stream)
-        if not self.inputs_resident or col is not None:
-            # the frame's tensors may still be in production on the caller's stream (callers whose frames are complete
-            # in device memory set inputs_resident: the encode then overlaps the previous frame's decode)
-            self.enc.wait_stream(self.main)
-        self.pointnet._select_mode(lib)
+            converted = True
         if "input_pts" in frame:
-            pts = frame["input_pts"][0].detach().float().contiguous()
+            src = frame["input_pts"]
+            self._check_device(src, "input_pts")
+            pts = src[0].detach().float().contiguous()
+            converted |= pts.data_ptr() != src.data_ptr() or pts.dtype != src.dtype
+        else:
+            src = frame["depth"]
+            self._check_device(src, "depth")
+            d = src.contiguous()
+            converted |= d.data_ptr() != src.data_ptr()
+            if d.dtype == torch.float64 and self.tsdf_vol is not None:
+                raise _lib.BnvError("FramePipe with a TSDF side volume takes uint16 (mm) or float32 (m) depth images")
+        if not self.inputs_resident or converted:
+            self.enc.wait_stream(self.main)
+        mode = _lib.model_mode(self.pointnet)            # the frame keeps it through its decode (per slot, in C)
+        if mode != self._mode:
+            _lib.check(lib.bnv_frame_pipe_set_mlp_mode(self._h, mode + 1), "bnv_frame_pipe_set_mlp_mode")
+            self._mode = mode
+        if "input_pts" in frame:
             self._keep[s] = pts                                           # alive until the slot is begun again
             _lib.check(lib.bnv_frame_begin_points(self._h, s, _lib.ptr(pts), int(pts.shape[0])), "bnv_frame_begin_points")
         else:
-            d = frame["depth"].contiguous()
-            if d.dtype == torch.float64 and self.tsdf_vol is not None:
-                raise _lib.BnvError("FramePipe with a TSDF side volume takes uint16 (mm) or float32 (m) depth images")
             H, W = int(d.shape[-2]), int(d.shape[-1])
             K = (C.c_double * 9)(*np.asarray(frame["intr_mat"], dtype=np.float64)[:3, :3].reshape(-1))
             T = (C.c_double * 16)(*np.asarray(frame["T_wc"], dtype=np.float64).reshape(-1))
@@ -174,7 +199,6 @@ class FramePipe:
     def finish(self, slot, blocks=None, capacity=0):
         v = self.volume
         nerf = self.pointnet.nerf
-        v._select_mode(nerf)
         lws = self._lws[slot]
         d, keep = v._delta(self.sdf_delta)
         _lib.check(self._lib.bnv_frame_finish(self._h, slot, C.byref(v._struct()), _lib.ptr(blocks), int(capacity),

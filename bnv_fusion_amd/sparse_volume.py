@@ -21,7 +21,7 @@ def get_world_range(dimensions, voxel_size):
     return min_, max_, n_xyz
 
 
-def make_grid(n_xyz, bound_min, bound_max, voxel_size, min_pts_in_grid, shard=(0, 1, 3)):
+def make_grid(n_xyz, bound_min, bound_max, voxel_size, min_pts_in_grid, shard=(0, 1, 3), mlp_mode=None):
     """bnv_grid_t with the float32 values the reference compares against: ``bound_max - voxel_size``
     and ``bound_min + voxel_size`` are float32-tensor (op) python-float results
     (local_point_fusion.py:94-100), evaluated here with the same torch CPU ops."""
@@ -38,6 +38,7 @@ def make_grid(n_xyz, bound_min, bound_max, voxel_size, min_pts_in_grid, shard=(0
     g.voxel_size = float(np.float32(voxel_size))
     g.min_pts_in_grid = int(min_pts_in_grid)
     g.shard_rank, g.shard_world, g.shard_block_log2 = int(shard[0]), int(shard[1]), int(shard[2])
+    g.mlp_mode = 0 if mlp_mode is None else int(mlp_mode) + 1      # 0: the library's process default
     return g
 
 
@@ -72,6 +73,7 @@ class SparseVolume:
         self.min_pts_in_grid = min_pts_in_grid
         self.shard = (0, 1, 3)
         self._grid = make_grid(n_xyz, min_coords, max_coords, voxel_size, min_pts_in_grid, self.shard)
+        self._grid_modes = {}      # copies of _grid per arithmetic mode (_grid_for)
         self._want_brick = brick
         self._brick = None
         self._ws = None
@@ -394,13 +396,13 @@ class SparseVolume:
         to_tensor() snapshot rows).  The autograd edge of decode_pts calls this; the fused optimiser step too."""
         if not hasattr(nerf, "sdf_bwd_pack"):
             raise NotImplementedError("decode_pts backward needs a decoder with sdf_bwd_pack")
-        self._select_mode(nerf)
+        grid = self._grid_for(nerf)
         f, w, _, lim = self._snapshot()
         c = coords.detach().reshape(-1, 3).float().contiguous()
         g = grad_sdf.detach().reshape(-1).float().contiguous()
         assert grad_features.shape == f.shape and grad_features.is_contiguous()
         _lib.check(self._lib.bnv_decode_pts_backward(
-            C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+            C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim),
             _lib.ptr(nerf.sdf_pack), _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]),
             1 if is_coords else 0, _lib.ptr(g), _lib.ptr(grad_features), _lib.stream_ptr()), "bnv_decode_pts_backward")
 
@@ -416,11 +418,9 @@ class SparseVolume:
                 d.dims[a] = int(keep.shape[2 + a])
         return d, keep
 
-    def _select_mode(self, nerf):
-        if getattr(nerf, "mlp_mode", None) == 2:
-            self._lib.bnv_set_mlp_mode(2)
-        elif self._lib.bnv_get_mlp_mode() == 2:
-            self._lib.bnv_set_mlp_mode(_lib.fp32_mode)
+    def _grid_for(self, nerf):
+        """The volume's bnv_grid_t for calls that run ``nerf``'s networks: the arithmetic mode travels in the grid."""
+        return _lib.grid_with_mode(self._grid, _lib.model_mode(nerf), self._grid_modes)
 
     def _values(self, query_tensor):
         if query_tensor:
@@ -442,14 +442,14 @@ class SparseVolume:
         return self._decode_pts_forward(coords, nerf, sdf_delta, is_coords, query_tensor)
 
     def _decode_pts_forward(self, coords, nerf, sdf_delta, is_coords, query_tensor):
-        self._select_mode(nerf)
+        grid = self._grid_for(nerf)
         shape = list(coords.shape)
         c = coords.detach().reshape(-1, 3).float().contiguous()
         n = int(c.shape[0])
         f, w, lim = self._values(query_tensor)
         d, keep = self._delta(sdf_delta)
         out = torch.empty(n, dtype=torch.float32, device=self._dev)
-        _lib.check(self._lib.bnv_decode_pts(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w),
+        _lib.check(self._lib.bnv_decode_pts(C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w),
                                             int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(c), n,
                                             1 if is_coords else 0, C.byref(d), _lib.ptr(out), _lib.stream_ptr()),
                    "bnv_decode_pts")
@@ -459,7 +459,7 @@ class SparseVolume:
         """decode_pts on the 3x3x3 lattice {-0.5, 0, 0.5}^3 around integer voxel ``origins`` [B, 3]
         (the decode SparseVolume.meshlize performs, sparse_volume.py:717-738) -> [B, 27].
         ``prestamped``: ``origins`` is the very tensor the last ``integrate(..., stamp_origins=True)`` upserted."""
-        self._select_mode(nerf)
+        grid = self._grid_for(nerf)
         o = origins.detach().reshape(-1, 3).long().contiguous()
         n = int(o.shape[0])
         out = torch.empty((n, 27), dtype=torch.float32, device=self._dev)
@@ -474,13 +474,13 @@ class SparseVolume:
                 raise _lib.BnvError("decode_lattice(prestamped=True) needs the origins of the integrate(..., "
                                     "stamp_origins=True) right before it")
             _lib.check(self._lib.bnv_decode_lattice_stamped(
-                C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+                C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim),
                 _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n, _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
                 self._lattice_ws.numel(), self._lattice_epoch, _lib.ptr(out), _lib.stream_ptr()),
                 "bnv_decode_lattice_stamped")
             return out
         self._lattice_workspace(n)
-        _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(self._grid), _lib.ptr(f),
+        _lib.check(self._lib.bnv_decode_lattice(C.byref(self._struct()), C.byref(grid), _lib.ptr(f),
                                                 _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack), _lib.ptr(o), n,
                                                 _lib.ptr(n_dev), C.byref(d), _lib.ptr(self._lattice_ws),
                                                 self._lattice_ws.numel(),
@@ -578,13 +578,13 @@ class _DecodePts(torch.autograd.Function):
     def backward(ctx, grad_out):
         features, c, w = ctx.saved_tensors
         volume, nerf = ctx.volume, ctx.nerf
-        volume._select_mode(nerf)
+        grid = volume._grid_for(nerf)
         f = features.detach()
         lim = min(int(f.shape[0]), volume._snapshot_rows)
         g = grad_out.detach().reshape(-1).float().contiguous()
         grad_f = torch.zeros_like(f)
         _lib.check(volume._lib.bnv_decode_pts_backward(
-            C.byref(volume._struct()), C.byref(volume._grid), _lib.ptr(f), _lib.ptr(w), int(lim),
+            C.byref(volume._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim),
             _lib.ptr(nerf.sdf_pack), _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]),
             1 if ctx.is_coords else 0, _lib.ptr(g), _lib.ptr(grad_f), _lib.stream_ptr()), "bnv_decode_pts_backward")
         return grad_f, None, None, None, None, None

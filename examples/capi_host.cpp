@@ -113,7 +113,8 @@ int main(int argc, char** argv) {
   }
   HIP_OK(hipSetDevice(0));
   BNV_OK_OR_DIE(bnv_init(0));
-  BNV_OK_OR_DIE(bnv_set_mlp_mode(m.mlp_mode));
+  // the arithmetic mode travels with every call, in the grid (no process-global switch is touched)
+  m.grid.mlp_mode = BNV_GRID_MLP_MODE(m.mlp_mode);
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
 

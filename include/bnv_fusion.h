@@ -52,7 +52,13 @@ typedef struct bnv_grid {
   int32_t shard_rank;
   int32_t shard_world;
   int32_t shard_block_log2;
+  /* Arithmetic of the MLP kernels for calls made with this grid: 0 = the process default (bnv_set_mlp_mode),
+   * BNV_GRID_MLP_MODE(m) = 1 + m selects mode m for these calls alone.  The mode belongs to the model (its weight
+   * packs are laid out for it), so callers that hold several models -- or drive the library from several host
+   * threads -- state it here instead of flipping the process default around their calls. */
+  int32_t mlp_mode;
 } bnv_grid_t;
+#define BNV_GRID_MLP_MODE(m) ((m) + 1)
 
 /* Device-side result counters of bnv_encode_pointcloud. */
 typedef struct bnv_encode_counters {
@@ -61,7 +67,7 @@ typedef struct bnv_encode_counters {
   int32_t n_out;          /* U': rows written (count >= min_pts_in_grid and owned by this shard) */
   float n_avg_pts;        /* mean pair count over all U voxels (local_point_fusion.py:143)       */
   int32_t error;          /* != 0: an output capacity was exceeded                               */
-  int32_t reserved[3];
+  int32_t reserved[3];    /* [0]: sharded encode: (point, corner) pairs this shard encoded; others 0 */
 } bnv_encode_counters_t;
 
 /* Sparse feature volume = open-addressing hash (packed 3x21-bit key -> row) + dense row arrays
@@ -107,6 +113,9 @@ int bnv_last_hip_error(void);
  *      ONE product per multiply-add on the f16 MFMA, fp32 accumulation: a third of mode 1's MFMAs and no lo
  *      conversions; per-layer relative error ~2^-11, SDF error ~1e-5 against the 1e-4 bar (features ~1e-3).
  *      The backward of decode_pts keeps the split arithmetic. */
+/* The process DEFAULT: used by calls whose grid says mlp_mode = 0 (bnv_decode_dense: whose mlp_mode argument is 0).
+ * A plain atomic word: setting it while another thread launches with mlp_mode = 0 changes that thread's arithmetic --
+ * state the mode in the grid where that matters. */
 int bnv_set_mlp_mode(int mode);
 int bnv_get_mlp_mode(void);
 
@@ -121,13 +130,17 @@ int bnv_get_mlp_mode(void);
  *                  (32-point blocks x 8 corners, per-wave LDS accumulation of the voxel sums); 0: the per-tile kernel.
  *   "tcnn_shared_table"  1 (default): that kernel's 8 waves take the 8 blocks of a 16 x 16-pixel patch and sum them in
  *                  ONE LDS table per workgroup (flushed behind a barrier); 0: one table per wave, flushed per block.
- *   "finalize_blocks"  0 (default): the encoder's compaction kernel runs on 8 workgroups per CU striding over its
- *                  tiles; n > 0: on n workgroups (tests force many strides per workgroup with a small n).
+ *   "finalize_blocks"  0 (default): the encoder's compaction kernel runs on 2 workgroups of 1,024 threads per CU
+ *                  striding over its tiles; n > 0: on n workgroups, clamped to that same 2 per CU (tests force many
+ *                  strides per workgroup with a small n).  The clamp is a forward-progress requirement, not a tuning
+ *                  choice: a tile waits for its predecessor's look-back word, so every launched workgroup must be
+ *                  resident at once.
  *   "reserve_cus"  0 (default); n: the persistent MLP kernels launch on (CUs - n) workgroups, leaving n CUs to
  *                  kernels of other streams (measured on one GPU with the two-stream frame pipeline: no gain for
  *                  n = 4, 8, 16 -- tools/ab_reserve.py; meant for an RCCL collective that must progress beside
  *                  the decode in the multi-GPU mode).
- * Unknown names return BNV_ERR_INVALID_ARGUMENT. */
+ * Unknown names return BNV_ERR_INVALID_ARGUMENT.  The switches are process-wide atomic words read at launch time:
+ * they select between implementations that produce the same results (A/B timing), never the arithmetic. */
 int bnv_set_option(const char* name, int value);
 
 /* Optional timing of the dominant kernels with HIP events recorded on their launch stream.
@@ -506,6 +519,12 @@ int bnv_decode_dense(const float* feat_grid, const float* pts_weight, const int3
                      float voxel_size, int32_t min_pts_in_grid, const float* sdfmlp_pack,
                      const float* voxel_coords, int64_t n, int32_t variant, float* out_sdf, float* out_feats,
                      int32_t* status, bnv_stream_t stream);
+/* The same with the arithmetic mode stated per call (bnv_grid_t.mlp_mode encoding: 0 = process default,
+ * BNV_GRID_MLP_MODE(m) = mode m); bnv_decode_dense = mlp_mode 0. */
+int bnv_decode_dense_mode(const float* feat_grid, const float* pts_weight, const int32_t dims_host[3],
+                          float voxel_size, int32_t min_pts_in_grid, const float* sdfmlp_pack,
+                          const float* voxel_coords, int64_t n, int32_t variant, int32_t mlp_mode, float* out_sdf,
+                          float* out_feats, int32_t* status, bnv_stream_t stream);
 
 /* ---- the per-frame chain as one object: NeuralMap.integrate (run_e2e.py:78-109: encode_pointcloud -> track_n_pts ->
  * _integrate -> TSDF side fusion) followed by the lattice decode of the frame's voxels (sparse_volume.py:697-738),
@@ -558,7 +577,11 @@ typedef struct bnv_frame_pipe_config {
   bnv_grid_t grid;
   int64_t max_points;               /* largest frame (H * W)                                                      */
   int64_t out_capacity;             /* rows of the slots' output arrays (>= 8 * max_points / min_pts + 1)         */
-  int64_t send_capacity;            /* records of the slots' send blocks (>= out_capacity is always enough)       */
+  int64_t send_capacity;            /* records of the slots' send blocks.  out_capacity is enough for what a rank
+                                       SENDS (its emitted boundary voxels); the exchange bound of bnv_frame_bound
+                                       counts TOUCHED boundary voxels and can be larger (small or sparse frames): the
+                                       caller exchanges min(bound rounded up, send_capacity) records per rank, and
+                                       bnv_frame_finish rejects a block_capacity above send_capacity             */
   const float* pointnet_pack;
   void* enc_ws;                     /* bnv_encode_workspace_bytes(enc_ws_max_points, grid.n_xyz), zeroed once     */
   size_t enc_ws_bytes;
@@ -578,6 +601,9 @@ int bnv_readback_words(const int32_t* counters, const int32_t* status, int32_t* 
 
 int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* config_host, bnv_frame_pipe_t** out);
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* pipe);
+/* Arithmetic mode (bnv_grid_t.mlp_mode encoding) of the frames begun from now on; a frame in flight keeps the mode it
+ * was begun with through its decode.  The mode config.grid carried at creation applies until this is called. */
+int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* pipe, int32_t grid_mlp_mode);
 /* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL */
 int bnv_frame_begin_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
                           const double* intr_host, const double* T_wc_host, const float* color_im);

@@ -1,17 +1,19 @@
-"""Spatial-hash sharded mode on ONE GPU, as rank 0 of a simulated world of W ranks: what a frame costs a rank of a
+"""Spatially sharded mode on ONE GPU, as rank r of a simulated world of W ranks: what a frame costs a rank of a
 W-GPU node in that mode, and how many host waits it takes.
 
-    python tools/spatial_single_rank.py [--world 8] [--grid 256] [--frames 200] [--in-flight 2]
+    python tools/spatial_single_rank.py [--world 8] [--rank r | --all-ranks] [--grid 256] [--frames 200] [--in-flight 3]
 
-Rank 0 of W voxelises the whole frame (replicated), encodes + upserts only the 1/W of the voxels it owns (the upsert
-launch appends its boundary records), runs the frame's ONE all-gather (a real RCCL call on a one-rank group; the other
-ranks' blocks are simulated by W - 1 copies of its own block, which the install kernel processes like foreign ones),
-installs and decodes the voxels it owns -- through the product path (HipShardBackend over the C frame pipeline).
-Reported: wall clock per frame with `--in-flight` frames enqueued ahead (the pipelined figure a node would run at if
-every rank keeps this pace), the same with one frame at a time (latency), the host's enqueue time per frame, the
-MLP kernels' own durations (HIP events) and the rank's share of the frame's work.  The volume is pre-rolled like the
-bench (30 frames)."""
-import argparse, ctypes as C, os, socket, sys, time
+Rank r of W (default 0; --all-ranks: every rank in turn, each on a fresh shard of its own, then the MAX over the ranks --
+a rank set runs at the pace of its slowest member) voxelises the whole frame (replicated), encodes + upserts only the
+voxels it owns (the upsert launch appends its boundary records), runs the frame's ONE all-gather (a real RCCL call on
+a one-rank group; the other ranks' blocks are simulated by W - 1 copies of its own block, which the install kernel
+processes like foreign ones), installs and decodes the voxels it owns -- through the product path (HipShardBackend
+over the C frame pipeline).  Reported per rank: wall clock per frame with `--in-flight` frames enqueued ahead (the
+pipelined figure a node would run at if every rank keeps this pace), the host's enqueue time per frame, the MLP
+kernels' own durations (HIP events) and the rank's share of the frame's work (voxels, pairs, MLP evaluations); for
+rank 0 also one frame at a time (latency).  The volume is pre-rolled like the bench (30 frames).  `--frames` >= 2000
+gives the sustained figure (the package heats up over the first ~1000 frames)."""
+import argparse, ctypes as C, gc, os, socket, sys, time
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bnv_fusion_amd as bnv
@@ -20,12 +22,18 @@ from bnv_fusion_amd import distributed as D
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=0, help="the rank of the simulated world this GPU plays")
+ap.add_argument("--all-ranks", action="store_true", help="every rank of the world in turn (fresh shard each), then the max")
 ap.add_argument("--grid", type=int, default=256)
 ap.add_argument("--frames", type=int, default=200)
-ap.add_argument("--in-flight", type=int, default=2)
+ap.add_argument("--in-flight", type=int, default=3)
 ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
 ap.add_argument("--trace", action="store_true", help="HIP-event timeline of the two streams over a few frames")
 ap.add_argument("--reserve", type=int, default=0, help="CUs the persistent MLP kernels leave to other streams")
+ap.add_argument("--ownership", default=None, help="ownership rule of the shards (default: the package's)")
+ap.add_argument("--no-latency", action="store_true")
+ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode is enqueued before the host waits for "
+                "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
 args = ap.parse_args()
 W = args.world
 with socket.socket() as s:
@@ -36,21 +44,10 @@ model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.ch
 POOL = 64
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
           for t in range(30 + POOL)]
-be = D.HipShardBackend(np.array([dims] * 3), voxel, model, 0, W, capacity=1 << 21, device="cuda:0", tsdf=True, n_slots=max(4, args.in_flight + 2))
-be.inputs_resident = True
-be.copy_results = False
-torch.cuda.synchronize()
 lib = _lib.load()
 if args.reserve:
     _lib.check(lib.bnv_set_option(b"reserve_cus", args.reserve), "reserve_cus")
-stats = {"waits": 0, "recv": 0, "own": 0, "evals": 0, "enq": 0.0, "n": 0}
-
-
-HOST = {k: 0.0 for k in ("begin", "bound", "upsert", "all_gather", "simulate", "finish")}
 ranks_i32 = torch.arange(W, dtype=torch.int32, device="cuda:0")
-
-
-TRACE = []
 
 
 def ev(stream):
@@ -59,108 +56,158 @@ def ev(stream):
     return e
 
 
-def enqueue(fr, decode=True):
-    if args.trace and be.pipe is not None:
-        E, M = be.pipe.enc, be.pipe.main
-        e0 = ev(E); f = be.encode(fr); e1 = ev(E)
-        bound = be.bound(f)
-        cap = -(-bound // D.REC_QUANTUM) * D.REC_QUANTUM
-        m0 = ev(M); send = be.upsert(f, cap, decode); m1 = ev(M)
+def price(rank, latency):
+    kw = {} if args.ownership is None else {"ownership": args.ownership}
+    be = D.HipShardBackend(np.array([dims] * 3), voxel, model, rank, W, capacity=1 << 21, device="cuda:0", tsdf=True,
+                           n_slots=max(4, args.in_flight + 2 + args.ahead), **kw)
+    be.inputs_resident = True
+    be.copy_results = False
+    torch.cuda.synchronize()
+    stats = {"waits": 0, "recv": 0, "own": 0, "evals": 0, "pairs": 0, "enq": 0.0, "n": 0}
+    HOST = {k: 0.0 for k in ("begin", "bound", "upsert", "all_gather", "simulate", "finish")}
+    TRACE = []
+
+    def exchange(f, send, cap):
         one = be.recv_buffer(W * send.numel())
-        dist.all_gather_into_tensor(one[: send.numel()], send)
         blocks = one.view(W, cap + 1, D.REC_WORDS)
-        blocks[1:] = blocks[0]
-        blocks[:, 0, 1] = ranks_i32
-        be.install(f, one, cap)
-        m2 = ev(M)
-        h = be.finish(f, be.decode(f) if decode else None, 0)
-        m3 = ev(M)
-        TRACE.append((e0, e1, m0, m1, m2, m3))
-        return h
-    t0 = time.perf_counter()
-    f = be.encode(fr)
-    t1 = time.perf_counter()
-    bound = be.bound(f); stats["waits"] += 1                     # the frame's one host wait
-    t2 = time.perf_counter()
-    cap = -(-bound // D.REC_QUANTUM) * D.REC_QUANTUM
-    send = be.upsert(f, cap, decode)
-    t3 = t4 = t5 = time.perf_counter()
-    if cap:
-        one = be.recv_buffer(W * send.numel())
-        dist.all_gather_into_tensor(one[: send.numel()], send)   # the collective call itself (1-rank group)
+        dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)   # the collective call itself (1-rank group)
         t4 = time.perf_counter()
-        blocks = one.view(W, cap + 1, D.REC_WORDS)
-        blocks[1:] = blocks[0]                                   # the other ranks' blocks: copies, sender ids patched
+        blocks[:] = blocks[rank].clone()                              # the other ranks' blocks: copies, sender ids patched
         blocks[:, 0, 1] = ranks_i32
         be.install(f, one, cap)
         stats["recv"] += one.numel() * 4
-        t5 = time.perf_counter()
-    h = be.finish(f, be.decode(f) if decode else None, 0)
-    t6 = time.perf_counter()
-    for k, d in zip(HOST, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
-        HOST[k] += d
-    stats["enq"] += t6 - t0 - (t5 - t4)                          # (without the simulation of the other ranks)
-    return h
+        return t4
 
+    PRE = [None]      # (frame dict, ShardFrame) whose encode was enqueued ahead
 
-def collect(h):
-    c, s = be.result(h)
-    stats["own"] += 0 if c is None else len(c)
-    stats["evals"] += be._last_evals
-    stats["n"] += 1
+    def begin(fr, nxt):
+        """This frame's ShardFrame (begun now, or ahead by the previous call) and, with --ahead, the next frame's
+        encode enqueued BEFORE the host waits for this frame's bound."""
+        if PRE[0] is not None:
+            assert PRE[0][0] is fr
+            f, PRE[0] = PRE[0][1], None
+        else:
+            f = be.encode(fr)
+        if args.ahead and nxt is not None:
+            PRE[0] = (nxt, be.encode(nxt))
+        return f
 
+    def enqueue(fr, decode=True, nxt=None):
+        if args.trace and be.pipe is not None:
+            E, M = be.pipe.enc, be.pipe.main
+            e0 = ev(E); f = begin(fr, nxt); e1 = ev(E)
+            cap = be.exchange_capacity(be.bound(f))
+            m0 = ev(M); send = be.upsert(f, cap, decode); m1 = ev(M)
+            if cap:
+                exchange(f, send, cap)
+            m2 = ev(M)
+            h = be.finish(f, be.decode(f) if decode else None, 0)
+            m3 = ev(M)
+            TRACE.append((e0, e1, m0, m1, m2, m3))
+            return h
+        t0 = time.perf_counter()
+        f = begin(fr, nxt)
+        t1 = time.perf_counter()
+        bound = be.bound(f); stats["waits"] += 1                     # the frame's one host wait
+        t2 = time.perf_counter()
+        cap = be.exchange_capacity(bound)
+        send = be.upsert(f, cap, decode)
+        t3 = t4 = t5 = time.perf_counter()
+        if cap:
+            t4 = exchange(f, send, cap)
+            t5 = time.perf_counter()
+        h = be.finish(f, be.decode(f) if decode else None, 0)
+        t6 = time.perf_counter()
+        for k, d in zip(HOST, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5)):
+            HOST[k] += d
+        stats["enq"] += t6 - t0 - (t5 - t4)                          # (without the simulation of the other ranks)
+        return h
 
-def run(idx, in_flight, decode=True):
-    pend = []
-    for t in idx:
-        while len(pend) >= in_flight:
+    def collect(h):
+        c, s = be.result(h)
+        stats["own"] += 0 if c is None else len(c)
+        stats["evals"] += be._last_evals
+        stats["pairs"] += be.last_owned_pairs
+        stats["n"] += 1
+
+    def run(idx, in_flight, decode=True):
+        pend = []
+        idx = list(idx)
+        for j, t in enumerate(idx):
+            while len(pend) >= in_flight:
+                collect(pend.pop(0))
+            pend.append(enqueue(frames[t], decode, frames[idx[j + 1]] if j + 1 < len(idx) else None))
+        while pend:
             collect(pend.pop(0))
-        pend.append(enqueue(frames[t], decode))
-    while pend:
-        collect(pend.pop(0))
+
+    out = {}
+    with torch.no_grad():
+        run(range(30), 2, decode=False)
+        run(range(30, 38), 2)
+        idx = [30 + (i % POOL) for i in range(args.frames)]
+        for k in stats:
+            stats[k] = 0
+        for k in HOST:
+            HOST[k] = 0.0
+        lib.bnv_profile_enable(1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(idx, args.in_flight)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        ms, cnt = (C.c_double * 4)(), (C.c_int64 * 4)()
+        lib.bnv_profile_read(ms, cnt)
+        lib.bnv_profile_enable(0)
+        n = stats["n"]
+        out = {"rank": rank, "ms": 1e3 * dt / n, "own": stats["own"] / n, "pairs": stats["pairs"] / n,
+               "evals": stats["evals"] / n, "enc_ms": ms[0] / max(cnt[0], 1), "tab_ms": ms[1] / max(cnt[1], 1),
+               "host_ms": 1e3 * stats["enq"] / n}
+        print(f"rank {rank} of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
+              f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}:")
+        print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
+              f"rank keeps this pace")
+        print(f"  host enqueue time     {1e3 * stats['enq'] / n:.3f} ms per frame (includes the bound wait); host waits per "
+              f"frame: {stats['waits'] / n:.2f}")
+        print("  host time per frame by phase (ms): " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in HOST.items())
+              + "  ('simulate' = this tool's stand-in for the other ranks' blocks, not part of a real rank's frame)")
+        print(f"  MLP kernels (HIP events, overlapping streams): point encoder {out['enc_ms']:.3f} ms, "
+              f"lattice table {out['tab_ms']:.3f} ms")
+        print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
+              f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
+        if args.trace:
+            TRACE.clear()
+            run(idx[:12], args.in_flight)
+            torch.cuda.synchronize()
+            base = TRACE[4][0]
+            print("  stream timeline (us from frame 4's encode start): E = encode stream [begin .. end], M = main stream "
+                  "[upsert start, upsert end, exchange end, finish end]")
+            for k, (e0, e1, m0, m1, m2, m3) in enumerate(TRACE[4:10]):
+                t = [1e3 * base.elapsed_time(x) for x in (e0, e1, m0, m1, m2, m3)]
+                print(f"    frame {k + 4}: E [{t[0]:7.1f} .. {t[1]:7.1f}]   M [{t[2]:7.1f}, {t[3]:7.1f}, {t[4]:7.1f}, {t[5]:7.1f}]")
+            args.trace = False
+        if latency:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            run(idx[:60], 1)
+            torch.cuda.synchronize(); dt1 = time.perf_counter() - t0
+            print(f"  one frame at a time   {1e3 * dt1 / 60:.3f} ms per frame (latency of a frame incl. the host round trips)")
+    del be
+    torch.cuda.synchronize()
+    return out
 
 
-with torch.no_grad():
-    run(range(30), 2, decode=False)
-    run(range(30, 38), 2)
-    idx = [30 + (i % POOL) for i in range(args.frames)]
-    for k in stats:
-        stats[k] = 0
-    for k in HOST:
-        HOST[k] = 0.0
-    lib.bnv_profile_enable(1)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    run(idx, args.in_flight)
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    ms, cnt = (C.c_double * 4)(), (C.c_int64 * 4)()
-    lib.bnv_profile_read(ms, cnt)
-    lib.bnv_profile_enable(0)
-    n = stats["n"]
-    print(f"rank 0 of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
-          f"{args.in_flight} in flight, {args.reserve} CUs reserved:")
-    print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
-          f"rank keeps this pace")
-    print(f"  host enqueue time     {1e3 * stats['enq'] / n:.3f} ms per frame (includes the bound wait); host waits per "
-          f"frame: {stats['waits'] / n:.2f}")
-    print("  host time per frame by phase (ms): " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in HOST.items())
-          + "  ('simulate' = this tool's stand-in for the other ranks' blocks, not part of a real rank's frame)")
-    print(f"  MLP kernels (HIP events, overlapping streams): point encoder {ms[0] / max(cnt[0], 1):.3f} ms, "
-          f"lattice table {ms[1] / max(cnt[1], 1):.3f} ms")
-    print(f"  voxels owned per frame {stats['own'] / n:.0f}; SDF-MLP evaluations {stats['evals'] / n:.0f}; bytes received "
-          f"per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
-    if args.trace:
-        TRACE.clear()
-        run(idx[:12], args.in_flight)
-        torch.cuda.synchronize()
-        base = TRACE[4][0]
-        print("  stream timeline (us from frame 4's encode start): E = encode stream [begin .. end], M = main stream "
-              "[upsert start, upsert end, exchange end, finish end]")
-        for k, (e0, e1, m0, m1, m2, m3) in enumerate(TRACE[4:10]):
-            t = [1e3 * base.elapsed_time(x) for x in (e0, e1, m0, m1, m2, m3)]
-            print(f"    frame {k + 4}: E [{t[0]:7.1f} .. {t[1]:7.1f}]   M [{t[2]:7.1f}, {t[3]:7.1f}, {t[4]:7.1f}, {t[5]:7.1f}]")
-        args.trace = False
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    run(idx[:60], 1)
-    torch.cuda.synchronize(); dt1 = time.perf_counter() - t0
-    print(f"  one frame at a time   {1e3 * dt1 / 60:.3f} ms per frame (latency of a frame incl. the host round trips)")
+gc.collect()
+gc.disable()       # as bench.py: a full collection with torch imported takes ~40 ms
+if args.all_ranks:
+    rows = [price(r, latency=False) for r in range(W)]
+    print(f"\nall {W} ranks ({args.frames} frames each, {args.in_flight} in flight):")
+    print("  rank   ms/frame   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
+    for o in rows:
+        print(f"  {o['rank']:4d}   {o['ms']:8.3f}   {o['own']:12.0f}   {o['pairs']:13.0f}   {o['evals']:15.0f}   "
+              f"{o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
+    for k, name in (("own", "voxels owned"), ("pairs", "pairs encoded"), ("evals", "MLP evaluations")):
+        v = np.array([o[k] for o in rows])
+        print(f"  {name}: max / mean over the ranks {v.max() / max(v.mean(), 1e-9):.3f}")
+    v = np.array([o["ms"] for o in rows])
+    print(f"  ms per frame: mean {v.mean():.3f}, MAX {v.max():.3f} (rank {int(v.argmax())}) -> {1e3 / v.max():.0f} frames/s "
+          f"for the rank set at the pace of its slowest rank")
+else:
+    price(args.rank, latency=not args.no_latency)
 dist.destroy_process_group()
