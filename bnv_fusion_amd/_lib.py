@@ -24,7 +24,8 @@ SYMBOLS = [
     "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
-    "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode",
+    "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
+    "bnv_encode_finish_image_wg",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
@@ -74,7 +75,8 @@ class FramePipeConfig(C.Structure):
                 ("pointnet_pack", C.c_void_p), ("enc_ws", C.c_void_p), ("enc_ws_bytes", C.c_size_t),
                 ("enc_ws_max_points", C.c_int64), ("max_depth", C.c_double), ("tsdf", TsdfDesc),
                 ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
-                ("main_stream", C.c_void_p)]
+                ("main_stream", C.c_void_p), ("enc_ws2", C.c_void_p), ("front_stream", C.c_void_p),
+                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32)]
 
 
 class BnvError(RuntimeError):
@@ -203,6 +205,10 @@ def load():
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),
+        "bnv_decode_lattice_stamped_tables": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
+                                                        vp, sz, i32, vp]),
+        "bnv_encode_finish_image_wg": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
+                                                 C.c_int, vp, C.c_int, vp]),
         "bnv_decode_dense_mode": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]),
         "bnv_frame_pipe_set_mlp_mode": (C.c_int, [vp, i32]),
         "bnv_shard_install_reset": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp, vp]),

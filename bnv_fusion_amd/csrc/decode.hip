@@ -2792,7 +2792,7 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
     if (rc != BNV_OK) return rc;
   }
   rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
-  if (rc != BNV_OK) return rc;
+  if (rc != BNV_OK || !out_sdf) return rc;   // (out_sdf == NULL: the caller blends itself, bnv_decode_lattice_stamped_tables)
   return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
 
@@ -2802,6 +2802,14 @@ int bnv_decode_lattice(const bnv_volume_t* vol, const bnv_grid_t* grid, const fl
                        int32_t epoch, float* out_sdf, bnv_stream_t stream) {
   return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, delta, ws_ptr,
                              ws_bytes, epoch, out_sdf, false, stream);
+}
+
+int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                                      const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                                      const int64_t* origins, int64_t n, const int32_t* n_dev, void* ws_ptr,
+                                      size_t ws_bytes, int32_t epoch, bnv_stream_t stream) {
+  return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, nullptr, ws_ptr,
+                             ws_bytes, epoch, nullptr, true, stream);
 }
 
 int bnv_decode_lattice_stamped(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,

@@ -1767,8 +1767,18 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
                             const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
                             float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                             int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream_) {
+  return bnv_encode_finish_image_wg(input_pts, n_points, image_width, grid_host, pointnet_pack, ws_ptr, ws_bytes,
+                                    ws_max_points, out_feats, out_pcounts, out_flat_ids, out_grid_ids, out_capacity,
+                                    emit_all, counters, 0, stream_);
+}
+
+int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int image_width, const bnv_grid_t* grid_host,
+                               const float* pointnet_pack, void* ws_ptr, size_t ws_bytes, int64_t ws_max_points,
+                               float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                               int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
+                               int max_workgroups, bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (image_width < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (image_width < 0 || max_workgroups < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
       n_points > (1 << 27) || ws_max_points < n_points)
     return BNV_ERR_INVALID_ARGUMENT;
@@ -1786,6 +1796,7 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
   const int n_tiles = ((n + 31) / 32) * 8;
   const int reserve = g_reserve_cus.load(std::memory_order_relaxed);
   int grid_pn = g_num_cus - reserve > 0 ? g_num_cus - reserve : 1;
+  if (max_workgroups > 0 && grid_pn > max_workgroups) grid_pn = max_workgroups;
   if (grid_pn > (n_tiles + 7) / 8) grid_pn = (n_tiles + 7) / 8;
   const int mlp = mlp_mode_of(g.mlp_mode);
   // sharded: owned pairs only -- from the list `begin` made, or (block encoder) by an ownership test in the kernel
@@ -1795,7 +1806,8 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
     if (tcnn_blocks(g)) {
       const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
       const int n_units = (n_blocks + kTbWaves - 1) / kTbWaves + 64;   // (16 x 16 patches: up to ragged edges)
-      const int grid_tb = g_num_cus * 2 < n_units ? g_num_cus * 2 : n_units;
+      const int cus_tb = max_workgroups > 0 && max_workgroups < g_num_cus ? max_workgroups : g_num_cus;
+      const int grid_tb = cus_tb * 2 < n_units ? cus_tb * 2 : n_units;
       auto kern = g_tcnn_shared_table.load(std::memory_order_relaxed) ? k_pointnet_scatter_tb<true> : k_pointnet_scatter_tb<false>;
       hipLaunchKernelGGL(kern, dim3(grid_tb), dim3(64 * kTbWaves), 0, stream, input_pts, n, image_width, g,
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc);

@@ -4,21 +4,30 @@
 // What NeuralMap.integrate (run_e2e.py:78-109) + the per-frame lattice decode (sparse_volume.py:697-738) cost the
 // host when every stage is a Python call of its own: ~15 kernel launches through ~8 ctypes calls, a dozen tensor
 // allocations, event objects, a pinned allocation -- and, in the sharded mode, one host wait in the MIDDLE of the
-// frame (the exchange bound) behind which the GPU ran dry (profiles/r02_spatial_world8.txt: 0.47 ms per frame of
-// which ~0.17 ms were launch gaps).  Here a frame in flight lives in a SLOT of caller-owned, persistent buffers and
-// moves through two HIP streams:
+// frame (the exchange bound) behind which the GPU ran dry.  Here a frame in flight lives in a SLOT of caller-owned,
+// persistent buffers and moves through up to FOUR HIP streams (round 4; two in round 3):
 //
-//   E (encode stream)  begin:   front end + voxel marking, rank  ->  exchange bound to pinned memory (event)  ->
-//                               point-encoder MLP + scatter, finalize  ->  TSDF side fusion
+//   F (front stream)   begin:   front end + voxel marking, rank  ->  exchange bound to pinned memory (event)
+//   E (encode stream)  begin:   point-encoder MLP + scatter, finalize  ->  TSDF side fusion
 //   M (main stream)    upsert:  waits for the slot's encode; ONE launch = upsert + running average + decode-origin
 //                               stamps + (sharded) boundary records appended to the slot's send block
 //                      [the caller runs the frame's ONE all-gather on M: RCCL through torch.distributed]
-//                      finish:  install ghost rows (resets the send block), neighbours, mark, table MLP, blend,
-//                               counters / row count / evaluation count to pinned memory, done event
+//                      finish:  install ghost rows (resets the send block), neighbours + mark, table MLP
+//   B (blend stream)   finish:  blend, counters / row count / evaluation count to pinned memory, done event
 //
-// E of frame t+1 depends on the frame only, so it runs beside M of frame t; the host wait for the bound of frame
-// t+1 (bnv_frame_bound) therefore returns while M still holds most of frame t, and the GPU never waits for the host.
-// Nothing here allocates device memory; the object owns HIP events only.
+// Why four.  The two MLP kernels each fill a CU's LDS, so they can only take turns, and M is one dependent chain:
+// upsert(t) -> all-gather -> install -> mark -> table(t) -> [blend(t)] -> upsert(t+1) ...  With two streams a rank's
+// frame of an 8-GPU run was table 150 us + encoder 60 us + ~90 us in which only small kernels ran: the encoder of
+// frame t+1 became ready exactly when table(t) did (its front end sat behind finalize + TSDF of frame t on the same
+// stream) and the blend sat between table(t) and upsert(t+1).  Now the front end runs on a stream of its own, a
+// frame or two ahead (the encode workspace is double-buffered), so the encoder of frame t+1 is ready as soon as
+// frame t's has finished and runs BESIDE the M chain of frame t; the blend leaves M's chain for B (the decode
+// workspace is double-buffered by the caller); and the encoder is launched on a share of the CUs
+// (encoder_workgroups) so that the chain's small kernels find free CUs while it runs -- they cannot share a CU with
+// it (LDS, registers).  A cycle is then ~ [encoder(t+1) beside chain(t)] + table(t).
+// E of frame t+1 depends on the frame only; the host wait for the bound of frame t+1 (bnv_frame_bound) returns
+// while M still holds most of frame t, and the GPU never waits for the host.  Nothing here allocates device memory;
+// the object owns HIP events only.
 #include <new>
 
 #include "bnv_common.hpp"
@@ -48,9 +57,15 @@ __global__ void k_readback_words(const int32_t* __restrict__ counters, const int
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
   int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
-  hipStream_t E, M;
+  hipStream_t F, E, M, B;                  // F == E and B == M when the config names no stream for them
   hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
-      ev_done[BNV_PIPE_MAX_SLOTS];
+      ev_table[BNV_PIPE_MAX_SLOTS], ev_done[BNV_PIPE_MAX_SLOTS];
+  hipEvent_t ev_encws[2];               // the encode workspace is free again (behind finalize of its last frame)
+  bool encws_used[2];
+  int enc_next;                         // encode workspace of the next frame begun
+  int enc_buf[BNV_PIPE_MAX_SLOTS];
+  void* lws_ptr[4];                     // decode workspaces seen and the slot whose frame used each one last
+  int lws_slot[4];
   int state[BNV_PIPE_MAX_SLOTS];        // 0 free, 1 begun, 2 upserted, 3 finished (result pending)
   bool used[BNV_PIPE_MAX_SLOTS];        // ev_done has been recorded at least once
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
@@ -63,6 +78,10 @@ static bnv_grid_t slot_grid(const bnv_frame_pipe* p, int slot) {
   bnv_grid_t g = p->cfg.grid;
   g.mlp_mode = p->mlp_mode[slot];
   return g;
+}
+
+static void* slot_encws(const bnv_frame_pipe* p, int slot) {
+  return p->enc_buf[slot] ? p->cfg.enc_ws2 : p->cfg.enc_ws;
 }
 
 static bool slot_ok(const bnv_frame_pipe* p, int slot) { return p && slot >= 0 && slot < p->cfg.n_slots; }
@@ -100,22 +119,39 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   p->cfg = *cfg;
   p->E = (hipStream_t)cfg->encode_stream;
   p->M = (hipStream_t)cfg->main_stream;
+  p->F = cfg->front_stream ? (hipStream_t)cfg->front_stream : p->E;
+  p->B = cfg->blend_stream ? (hipStream_t)cfg->blend_stream : p->M;
   p->bound_off = bnv_encode_shard_counts_offset();
+  p->enc_next = 0;
+  for (int k = 0; k < 2; ++k) {
+    p->ev_encws[k] = nullptr;
+    p->encws_used[k] = false;
+  }
+  for (int k = 0; k < 4; ++k) {
+    p->lws_ptr[k] = nullptr;
+    p->lws_slot[k] = -1;
+  }
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
     p->state[s] = 0;
     p->used[s] = false;
     p->n_points[s] = 0;
+    p->enc_buf[s] = 0;
     p->mlp_mode[s] = cfg->grid.mlp_mode;
-    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_done[s] = nullptr;
+    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = nullptr;
     p->host_dev[s] = nullptr;
   }
+  for (int k = 0; k < 2; ++k)
+    if (hipEventCreateWithFlags(&p->ev_encws[k], hipEventDisableTiming) != hipSuccess) {
+      bnv_frame_pipe_destroy(p);
+      return BNV_ERR_HIP;
+    }
   for (int s = 0; s < cfg->n_slots; ++s) {
     void* d = nullptr;
     if (hipHostGetDevicePointer(&d, cfg->slots[s].host_words, 0) == hipSuccess) p->host_dev[s] = (int32_t*)d;
     else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
-    hipEvent_t* evs[4] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_done[s]};
+    hipEvent_t* evs[5] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s]};
     for (hipEvent_t* e : evs)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
         bnv_frame_pipe_destroy(p);
@@ -135,10 +171,12 @@ int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* p, int32_t grid_mlp_mode) {
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
   if (!p) return BNV_OK;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
-    hipEvent_t evs[4] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_done[s]};
+    hipEvent_t evs[5] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s]};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
+  for (int k = 0; k < 2; ++k)
+    if (p->ev_encws[k]) (void)hipEventDestroy(p->ev_encws[k]);
   delete p;
   return BNV_OK;
 }
@@ -147,18 +185,22 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
 static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, int image_width) {
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
+  void* enc_ws = slot_encws(p, slot);
   if (c.grid.shard_world > 1) {
     // the exchange bound: touched boundary voxels per rank, identical on every rank, known before the encoder MLP
-    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_BOUNDS, (const char*)c.enc_ws + p->bound_off,
-                                 4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->E));
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_BOUNDS, (const char*)enc_ws + p->bound_off,
+                                 4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->F));
   }
-  BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->E));
+  BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
+  if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
   const bnv_grid_t g = slot_grid(p, slot);
-  const int rc = bnv_encode_finish_image(pts, n, image_width, &g, c.pointnet_pack, c.enc_ws, c.enc_ws_bytes,
-                                         c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
-                                         c.out_capacity, 0, b.counters, p->E);
+  const int rc = bnv_encode_finish_image_wg(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
+                                            c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
+                                            c.out_capacity, 0, b.counters, c.encoder_workgroups, p->E);
   if (rc != BNV_OK) return rc;
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
+  BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
+  p->encws_used[p->enc_buf[slot]] = true;
   p->n_points[slot] = n;
   p->state[slot] = 1;
   return BNV_OK;
@@ -166,8 +208,14 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
 
 static int begin_head(bnv_frame_pipe* p, int slot) {
   if (!slot_ok(p, slot) || p->state[slot] != 0) return BNV_ERR_INVALID_ARGUMENT;
-  // the slot's buffers are still read by the main-stream work of the frame that used it last
-  if (p->used[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_done[slot], 0));
+  // the slot's buffers are still read by the blend of the frame that used it last
+  if (p->used[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_done[slot], 0));
+  // the encode workspace alternates when there are two: the front end of this frame then only waits for the encoder
+  // of the frame before the last one
+  const int buf = p->cfg.enc_ws2 ? p->enc_next : 0;
+  if (p->cfg.enc_ws2) p->enc_next ^= 1;
+  p->enc_buf[slot] = buf;
+  if (p->encws_used[buf] && p->F != p->E) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_encws[buf], 0));
   p->mlp_mode[slot] = p->cfg.grid.mlp_mode;   // the frame keeps the mode it starts under (bnv_frame_pipe_set_mlp_mode)
   return BNV_OK;
 }
@@ -182,8 +230,8 @@ int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int 
   int rc = begin_head(p, slot);
   if (rc != BNV_OK) return rc;
   const bnv_grid_t g = slot_grid(p, slot);
-  rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &g, c.enc_ws,
-                              c.enc_ws_bytes, c.enc_ws_max_points, b.input_pts, p->E);
+  rc = bnv_encode_begin_depth(depth, depth_dtype, H, W, intr_host, T_wc_host, c.max_depth, &g, slot_encws(p, slot),
+                              c.enc_ws_bytes, c.enc_ws_max_points, b.input_pts, p->F);
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W, W);
   if (rc != BNV_OK) return rc;
@@ -212,7 +260,7 @@ int bnv_frame_begin_points(bnv_frame_pipe_t* p, int slot, const float* input_pts
   const bnv_frame_pipe_config_t& c = p->cfg;
   if (!input_pts || n_points < 0 || n_points > c.max_points) return BNV_ERR_INVALID_ARGUMENT;
   const bnv_grid_t g = slot_grid(p, slot);
-  rc = bnv_encode_begin(input_pts, n_points, &g, c.enc_ws, c.enc_ws_bytes, c.enc_ws_max_points, p->E);
+  rc = bnv_encode_begin(input_pts, n_points, &g, slot_encws(p, slot), c.enc_ws_bytes, c.enc_ws_max_points, p->F);
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, input_pts, n_points, 0);
   if (rc != BNV_OK) return rc;
@@ -226,6 +274,29 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
   BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
+  if (lattice_ws && p->B != p->M) {
+    // the upsert stamps the decode's origins into lattice_ws and clears its control words: the blend (other stream)
+    // of the frame that decoded into this workspace last must be through.  Callers alternate two workspaces, so
+    // this is the blend of the frame before the last one.
+    int k = 0, free_k = -1;
+    for (; k < 4; ++k) {
+      if (p->lws_ptr[k] == lattice_ws) break;
+      if (!p->lws_ptr[k] && free_k < 0) free_k = k;
+    }
+    if (k == 4) {
+      k = free_k >= 0 ? free_k : 0;   // (more than four workspaces: forget the oldest entry, after waiting for it)
+      if (free_k < 0 && p->lws_slot[k] >= 0 && p->used[p->lws_slot[k]])
+        BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[p->lws_slot[k]], 0));
+      p->lws_ptr[k] = lattice_ws;
+      p->lws_slot[k] = -1;
+    }
+    const int prev = p->lws_slot[k];
+    if (prev >= 0 && prev != slot) {
+      if (p->state[prev] == 1 || p->state[prev] == 2) return BNV_ERR_INVALID_ARGUMENT;   // its frame is not finished
+      if (p->used[prev]) BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[prev], 0));
+    }
+    p->lws_slot[k] = slot;
+  }
   bnv_integrate_extras_t x = {};
   if (c.grid.shard_world > 1) {
     x.shard_block = b.send_block;
@@ -269,26 +340,39 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
-    rc = bnv_decode_lattice_stamped(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
-                                    b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws,
-                                    lattice_ws_bytes, lattice_epoch, b.sdf, p->M);
+    rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+                                           b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
+                                           lattice_ws_bytes, lattice_epoch, p->M);
     if (rc != BNV_OK) return rc;
+    if (p->B != p->M) {
+      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
+      BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
+    }
+    // the blend reads the workspace only: on B it leaves M to the next frame's upsert
+    rc = bnv_lattice_blend(vol, &g, b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws, lattice_ws_bytes,
+                           b.sdf, p->B);
+    if (rc != BNV_OK) return rc;
+  } else if (p->B != p->M) {
+    BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
+    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
   }
   int32_t *stamp = nullptr, *ctl = nullptr;
   if (lattice_ws) lattice_ws_frame_words(lattice_ws, vol->row_capacity, &stamp, &ctl);
+  // (on B the row count may already include rows of the NEXT frame's upsert: the host's row bound stays an upper
+  // bound -- it adds that frame's whole reservation on top until its own read-back settles it)
   if (p->host_dev[slot]) {
-    hipLaunchKernelGGL(k_frame_readback, dim3(1), dim3(64), 0, p->M, (const int32_t*)b.counters,
+    hipLaunchKernelGGL(k_frame_readback, dim3(1), dim3(64), 0, p->B, (const int32_t*)b.counters,
                        (const int32_t*)vol->n_rows, ctl ? (const int32_t*)(ctl + 1) : (const int32_t*)nullptr,
                        p->host_dev[slot]);
     BNV_LAUNCH_CHECK();
   } else {
-    if (ctl) BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_EVALS, ctl + 1, 4, hipMemcpyDeviceToHost, p->M));
+    if (ctl) BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_EVALS, ctl + 1, 4, hipMemcpyDeviceToHost, p->B));
     BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_COUNTERS, b.counters, sizeof(bnv_encode_counters_t),
-                                 hipMemcpyDeviceToHost, p->M));
-    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->M));
+                                 hipMemcpyDeviceToHost, p->B));
+    BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->B));
   }
-  BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
-  BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->M));
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
+  BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
   p->used[slot] = true;
   p->state[slot] = 3;
   return BNV_OK;

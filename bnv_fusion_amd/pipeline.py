@@ -25,7 +25,14 @@ W_COUNTERS, W_STATUS, W_EVALS, W_BOUNDS = 0, 8, 10, 16
 
 
 class FramePipe:
-    def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None):
+    # CUs the persistent point encoder leaves to the small kernels of the other streams in the four-stream schedule
+    # (csrc/pipeline.hip): a share of 1 / 4 on a sharded volume, where a rank's encoder launch is small and the main
+    # stream's chain (upsert -> exchange -> install -> mark) runs beside it; all CUs otherwise.  BNV_PIPE_ENCODER_WGS
+    # overrides (0 = all CUs).
+    ENCODER_SHARE_SHARDED = 0.75
+
+    def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None,
+                 streams=4, encoder_workgroups=None):
         from .frontend import DEPTH_DTYPES
         self._dtypes = DEPTH_DTYPES
         self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
@@ -41,8 +48,22 @@ class FramePipe:
         self.max_points = int(max_points)
         self.world = int(v.shard[1])
         from .streams import concurrent_stream
+        import os
         self.main = torch.cuda.current_stream(dev)
         self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
+        # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four)
+        streams = int(os.environ.get("BNV_PIPE_STREAMS", streams))
+        self.front = self.blend = None
+        if streams >= 4:
+            self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
+            self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
+        self.double_buffered = self.front is not None
+        if encoder_workgroups is None:
+            encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
+            if encoder_workgroups is None:
+                cus = int(lib.bnv_num_compute_units())
+                encoder_workgroups = int(cus * self.ENCODER_SHARE_SHARDED) if (self.world > 1 and streams >= 4) else 0
+        self.encoder_workgroups = int(encoder_workgroups)
         res = v._n_xyz_host
         nvox = res[0] * res[1] * res[2]
         self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)
@@ -50,6 +71,7 @@ class FramePipe:
         n_arr = (C.c_int32 * 3)(*res)
         need = int(lib.bnv_encode_workspace_bytes(self.max_points, n_arr))
         self._enc_ws = torch.zeros(need, dtype=torch.uint8, device=dev)          # zero-filled = clean
+        self._enc_ws2 = torch.zeros(need, dtype=torch.uint8, device=dev) if self.double_buffered else None
         cap, S = self.cap, self.n_slots
         self.input_pts = torch.empty((S, self.max_points, 6), dtype=torch.float32, device=dev)
         self.feats = torch.empty((S, cap, 8), dtype=torch.float32, device=dev)
@@ -89,6 +111,10 @@ class FramePipe:
             b.send_block = self.send[s].data_ptr() if self.send is not None else None
             b.host_words = self.host[s].data_ptr()
         cfg.encode_stream, cfg.main_stream = self.enc.cuda_stream, self.main.cuda_stream
+        if self.double_buffered:
+            cfg.enc_ws2 = self._enc_ws2.data_ptr()
+            cfg.front_stream, cfg.blend_stream = self.front.cuda_stream, self.blend.cuda_stream
+        cfg.encoder_workgroups = self.encoder_workgroups
         self._cfg = cfg
         h = C.c_void_p()
         _lib.check(lib.bnv_frame_pipe_create(C.byref(cfg), C.byref(h)), "bnv_frame_pipe_create")
@@ -99,6 +125,7 @@ class FramePipe:
         self._decode = [False] * S
         self._epoch = [0] * S
         self._lws = [None] * S
+        self._lws_next = 0           # decode workspace of the next frame upserted (two alternate with a blend stream)
         self._words = (C.c_int32 * HOST_WORDS)()
         self._keep = [None] * S
         self.inputs_resident = False
@@ -152,7 +179,7 @@ class FramePipe:
             if d.dtype == torch.float64 and self.tsdf_vol is not None:
                 raise _lib.BnvError("FramePipe with a TSDF side volume takes uint16 (mm) or float32 (m) depth images")
         if not self.inputs_resident or converted:
-            self.enc.wait_stream(self.main)
+            (self.front or self.enc).wait_stream(self.main)     # the stream the frame's first kernel runs on
         mode = _lib.model_mode(self.pointnet)            # the frame keeps it through its decode (per slot, in C)
         if mode != self._mode:
             _lib.check(lib.bnv_frame_pipe_set_mlp_mode(self._h, mode + 1), "bnv_frame_pipe_set_mlp_mode")
@@ -189,7 +216,8 @@ class FramePipe:
         self._decode[slot] = bool(decode)
         lws = None
         if decode:
-            lws, self._epoch[slot] = v._lattice_workspace(self.cap)
+            lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0)
+            self._lws_next ^= 1
         self._lws[slot] = lws
         ws = v._workspace(self.cap)
         _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),

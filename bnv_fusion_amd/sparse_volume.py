@@ -80,6 +80,8 @@ class SparseVolume:
         self._slot_mask = None        # side tables of integrate_batch (per slot; re-made with the slot table)
         self._slot_items = None
         self._lattice_ws = None
+        self._lattice_ws2 = None      # second decode workspace (frame pipeline: alternating frames)
+        self._lattice_last = None     # the one handed out last
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         self._epoch = 0
@@ -137,6 +139,8 @@ class SparseVolume:
         self._inflight = 0            # rows reserved by enqueued, not yet settled, device-count integrates
         self._rows_known = 0          # largest row count read back so far
         self._lattice_ws = None
+        self._lattice_ws2 = None
+        self._lattice_last = None
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
@@ -217,6 +221,9 @@ class SparseVolume:
             return
         cap = max(2 * self._row_capacity, need)
         d = self._dev
+        # the arrays and workspaces are re-made: streams other than the current one (the frame pipeline's blend /
+        # encode streams) may still be reading the old ones
+        torch.cuda.synchronize(d)
 
         def grow(t, shape):
             o = torch.zeros(shape, dtype=t.dtype, device=d)
@@ -232,6 +239,8 @@ class SparseVolume:
         self._slot_keys = torch.empty(self._n_slots, dtype=torch.int64, device=d)
         self._slot_rows = torch.empty(self._n_slots, dtype=torch.int32, device=d)
         self._lattice_ws = None
+        self._lattice_ws2 = None
+        self._lattice_last = None
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         _lib.check(self._lib.bnv_volume_rehash(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_rehash")
@@ -488,28 +497,37 @@ class SparseVolume:
                    "bnv_decode_lattice")
         return out
 
-    def _lattice_workspace(self, n):
+    def _lattice_workspace(self, n, which=0):
         """(workspace of the lattice decode for up to n voxels, a fresh epoch).  Re-made (zero-filled) when the volume
-        grows: its front part is indexed by row."""
+        grows: its front part is indexed by row.  ``which`` = 1: a second workspace -- the frame pipeline alternates
+        two, so that a frame's blend (on a stream of its own) and the next frame's marking never share one."""
         need = int(self._lib.bnv_decode_lattice_workspace_bytes(int(n), self._row_capacity))
+        if which:
+            if self._lattice_ws2 is None or self._lattice_ws2.numel() < need:
+                self._lattice_ws2 = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            self._lattice_epoch += 1           # (one counter for both: each workspace sees increasing epochs)
+            self._lattice_last = self._lattice_ws2
+            return self._lattice_ws2, self._lattice_epoch
         if self._lattice_ws is None or self._lattice_ws.numel() < need:
             # zero-filled: the per-row stamps at the front of the workspace must start at 0
             self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
-            self._lattice_epoch = 0
+            if self._lattice_ws2 is None:
+                self._lattice_epoch = 0
         self._lattice_epoch += 1
+        self._lattice_last = self._lattice_ws
         return self._lattice_ws, self._lattice_epoch
 
     def last_lattice_table_rows(self):
         """Device int32 tensor [1]: rows listed by the last bnv_lattice_neighbors(build_list) (sharded
         path: 27 MLP evaluations each)."""
         off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
-        return self._lattice_ws[off: off + 4].view(torch.int32)
+        return self._lattice_last[off: off + 4].view(torch.int32)
 
     def last_lattice_evals(self):
         """Device int32 tensor [1]: SDF-MLP evaluations of the last decode_lattice call (table entries
         read by live lattice points)."""
         off = int(self._lib.bnv_decode_lattice_count_offset(self._row_capacity))
-        return self._lattice_ws[off + 4: off + 8].view(torch.int32)
+        return self._lattice_last[off + 4: off + 8].view(torch.int32)
 
     def meshlize(self, nerf, sdf_delta=None, path=None):
         """sparse_volume.py:697-766: decode the 3x3x3 lattice of every active voxel and run per-voxel

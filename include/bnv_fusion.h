@@ -276,6 +276,14 @@ int bnv_encode_finish_image(const float* input_pts, int64_t n_points, int image_
                             const float* pointnet_pack, void* ws, size_t ws_bytes, int64_t ws_max_points,
                             float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                             int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters, bnv_stream_t stream);
+/* The same with the persistent point-encoder kernel launched on at most max_workgroups workgroups (one per CU;
+ * 0 = every CU).  The encoder and the SDF-decoder kernels each fill a CU's LDS, so nothing else runs on a CU one of
+ * them holds; the frame pipeline leaves a share of the CUs to the small kernels of the other streams this way. */
+int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int image_width, const bnv_grid_t* grid_host,
+                               const float* pointnet_pack, void* ws, size_t ws_bytes, int64_t ws_max_points,
+                               float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
+                               int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
+                               int max_workgroups, bnv_stream_t stream);
 size_t bnv_encode_shard_counts_offset(void);
 
 /* input_pts [n_points, 6] f32 (world xyz, world normal).
@@ -474,6 +482,16 @@ int bnv_decode_lattice_stamped(const bnv_volume_t* vol_host, const bnv_grid_t* g
                                const bnv_sdf_delta_t* delta_host, void* ws, size_t ws_bytes, int32_t epoch,
                                float* out_sdf, bnv_stream_t stream);
 
+/* bnv_decode_lattice_stamped without its last stage: neighbour rows, live entries and the table MLP on `stream`; the
+ * caller finishes with bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws, ws_bytes, out_sdf, other_stream)
+ * behind an event -- the blend reads nothing but `ws`, so on a stream of its own it leaves `stream` free for the next
+ * frame's upsert (the frame pipeline does this; that next frame must then decode into another workspace). */
+int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
+                                      const float* features, const float* weights, int64_t row_limit,
+                                      const float* sdfmlp_pack, const int64_t* origins, int64_t n,
+                                      const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
+                                      bnv_stream_t stream);
+
 /* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
  * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
@@ -532,15 +550,19 @@ int bnv_decode_dense_mode(const float* feat_grid, const float* pts_weight, const
  * above on the per-frame path: a frame in flight occupies a SLOT of caller-owned persistent buffers and runs on two
  * streams -- the encode (a function of the frame only) on encode_stream, the volume-dependent part on main_stream --
  * so frame t+1's encode overlaps frame t's exchange + decode, and no stage needs a host-side allocation, event object
- * or size read.  Per frame and slot, in this order:
- *   bnv_frame_begin_depth | _points   encode_stream: front end + voxelise + rank; exchange bound -> pinned memory;
- *                                     point encoder + reduction + filter; TSDF side fusion (depth frames, if configured)
+ * or size read.  Per frame and slot, in this order (bnv_frame_begin_* of the NEXT frame may come before
+ * bnv_frame_bound of this one: the encode side then runs a frame ahead of the host):
+ *   bnv_frame_begin_depth | _points   front_stream (encode_stream if none): front end + voxelise + rank; exchange bound
+ *                                     -> pinned memory; encode_stream: point encoder + reduction + filter; TSDF side
+ *                                     fusion (depth frames, if configured)
  *   bnv_frame_upsert                  main_stream: upsert + running average (+ boundary records into the slot's send
  *                                     block, + decode-origin stamps when lattice_ws is given)
  *   bnv_frame_bound                   HOST wait for the frame's exchange bound (max over ranks; 0 unsharded)
  *   [sharded: the caller all-gathers the first (1 + capacity) records of every rank's send block on main_stream]
- *   bnv_frame_finish                  main_stream: install ghost rows from `blocks`, lattice decode into the slot's sdf
- *                                     (when lattice_ws is given), read-backs into the slot's pinned words
+ *   bnv_frame_finish                  main_stream: install ghost rows from `blocks`, neighbour rows + live entries +
+ *                                     table MLP of the lattice decode (when lattice_ws is given); blend_stream
+ *                                     (main_stream if none): blend into the slot's sdf, read-backs into the slot's
+ *                                     pinned words
  *   bnv_frame_result                  HOST wait for the frame; copies the slot's pinned words out; frees the slot
  * The volume and its workspaces are passed per call (they are re-made when the volume grows).  The object owns HIP
  * events only; every buffer is the caller's and must outlive it. */
@@ -591,6 +613,19 @@ typedef struct bnv_frame_pipe_config {
   int32_t n_slots;
   bnv_frame_slot_t slots[BNV_PIPE_MAX_SLOTS];
   bnv_stream_t encode_stream, main_stream;
+  /* Round 4 (all optional; zero = the two-stream pipeline of round 3):
+   *   front_stream  the front end (voxelise + rank + exchange bound) runs here instead of on encode_stream, so the
+   *                 encoder of the next frame is ready as soon as this frame's has finished;
+   *   enc_ws2       a second encode workspace (same size as enc_ws, zeroed once): frames alternate, and the front end
+   *                 of a frame only waits for the encoder of the frame before the last one;
+   *   blend_stream  the decode's blend + the frame's read-backs run here instead of on main_stream, which goes
+   *                 straight on to the next frame's upsert; the caller must then pass bnv_frame_upsert /
+   *                 bnv_frame_finish alternating decode workspaces (the pipe orders a workspace's reuse itself);
+   *   encoder_workgroups  the persistent point encoder is launched on this many workgroups (one per CU; 0 = all
+   *                 CUs): the CUs it leaves are where the small kernels of the other streams run meanwhile. */
+  void* enc_ws2;
+  bnv_stream_t front_stream, blend_stream;
+  int32_t encoder_workgroups;
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;

@@ -247,6 +247,20 @@ def install():
          seed_everything=lambda s, **k: torch.manual_seed(s))
 
 
+def install_run_e2e():
+    """Further inert stand-ins that importing the reference's CALLER (src/run_e2e.py and the dataset / helper modules
+    it pulls in) needs on top of install(): names imported at module level from wheels absent here.  None of them is
+    called on the recorded path (tests/golden/make_golden_caller.py)."""
+    def absent(*a, **k):
+        raise RuntimeError("stand-in for a wheel that is absent from this image")
+
+    sys.modules["kornia.geometry.depth"].depth_to_normals = absent
+    sys.modules["kornia.geometry.depth"].depth_to_3d = absent
+    _mod("quaternion")
+    _mod("plyfile", PlyData=object)
+    _mod("numba", njit=lambda *a, **k: (lambda f: f), prange=range)
+
+
 class _StubUnpickler(pickle.Unpickler):
     """Fabricates empty classes for non-torch modules pickled into the Lightning checkpoints."""
 

@@ -1,0 +1,310 @@
+"""Replays the recorded call trace of the reference's own caller -- src/run_e2e.py's ``NeuralMap`` (run_e2e.py:27-194):
+__init__, integrate x 10 (one empty frame), extract_mesh, optimize (2 iterations), extract_mesh, save -- against
+bnv_fusion_amd's classes: every call the reference's caller makes at the boundary is accepted with the recorded
+positional / keyword form and argument types, every attribute it reads exists with the recorded type, dtype and
+shape, every attribute it writes is accepted, and what comes back has the recorded structure and values (integers
+exact, floats <= 1e-4).  The trace (tests/golden/caller_64.npz) was recorded from the reference itself by
+tests/golden/make_golden_caller.py; nothing of the reference is needed here."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden", "caller_64.npz")
+DEV = "cuda:0"
+ATOL = 1e-4
+
+
+def _load():
+    z = np.load(GOLDEN)
+    doc = json.loads(bytes(z["events_json"]).decode())
+    return z, doc["meta"], doc["events"]
+
+
+def test_trace_fixture_is_wellformed_cpu():
+    """CPU check of the fixture: the depth-0 call sequence is the one run_e2e.py:78-194 makes."""
+    z, meta, events = _load()
+    d0 = [e for e in events if e["depth"] == 0]
+    calls = [(e["obj"], e["method"]) for e in d0 if e["op"] == "call"]
+    n_real = meta["n_frames"] - 1
+    assert calls.count(("pointnet", "encode_pointcloud")) == meta["n_frames"]
+    assert calls.count(("pointnet", "_integrate")) == n_real and calls.count(("volume", "track_n_pts")) == n_real
+    assert calls.count(("tsdf_vol", "integrate")) == n_real           # the empty frame returns before both
+    assert calls.count(("volume", "meshlize")) == 2 and calls.count(("volume", "insert")) == 1
+    assert calls.count(("volume", "decode_pts")) == 4 and calls.count(("volume", "count_optim")) == 4
+    assert [e["cls"] for e in d0 if e["op"] == "new"] == ["SparseVolume", "TSDFVolume"]
+    sets = [(e["obj"], e["attr"], e["value"]["param"]) for e in d0 if e["op"] == "set"]
+    assert sets == [("volume", "features", True)]                      # run_e2e.py:114
+    for e in d0:                                                       # every array the events name is in the file
+        for d in _walk(e):
+            for k in ("data", "sample"):
+                if k in d:
+                    assert d[k] in z.files
+
+
+def _walk(node):
+    if isinstance(node, dict):
+        yield node
+        for v in node.values():
+            yield from _walk(v)
+    elif isinstance(node, list):
+        for v in node:
+            yield from _walk(v)
+
+
+class Replay:
+    def __init__(self, z, meta, tmp_path):
+        import bnv_fusion_amd as bnv
+        from bnv_fusion_amd.tsdf import TSDFVolume
+        self.bnv, self.TSDFVolume = bnv, TSDFVolume
+        self.z, self.meta, self.tmp = z, meta, str(tmp_path)
+        bnv.set_mlp_mode(1)
+        model = bnv.load_pretrained(device=DEV, voxel_size=meta["voxel_size"], min_pts_in_grid=meta["min_pts_in_grid"])
+        self.objs = {"pointnet": model, "pointnet.nerf": model.nerf}
+        self.refs = {}                 # recorded tensor ref -> OUR tensor
+        self.pending = None            # (our decode_pts output, the gradient the caller sent back into it)
+        self.n_checked = 0
+
+    # ---- values -----------------------------------------------------------------------------------------------
+    def data(self, d):
+        assert "data" in d, f"the replay needs the full array of {d}"
+        return self.z[d["data"]]
+
+    def build(self, d):
+        """A recorded value as an argument for OUR method."""
+        t = d["t"]
+        if t == "none":
+            return None
+        if t == "py":
+            return d["v"]
+        if t == "obj":
+            return self.objs[d["name"]]
+        if t == "ndarray":
+            return self.data(d).copy()
+        if t in ("tuple", "list"):
+            items = [self.build(x) for x in d["items"]]
+            return tuple(items) if t == "tuple" else items
+        if t == "dict":
+            return {k: self.build(v) for k, v in d["items"].items()}
+        if t == "tensor":
+            ours = self.refs.get(d["ref"])
+            if ours is None and d.get("alias_of") in self.refs:        # a new object over a tensor we hold
+                base = self.refs[d["alias_of"]]
+                ours = torch.nn.Parameter(base.detach()) if d["param"] else base.detach()
+            if ours is None:                                           # produced by the caller's own code: its data
+                ours = torch.from_numpy(self.data(d).copy()).to(DEV)
+                if d["param"]:
+                    ours = torch.nn.Parameter(ours)
+                elif d["requires_grad"]:
+                    ours.requires_grad_(True)
+            elif d.get("changed") and d.get("caller_owned"):           # the caller changed it in place (Adam step)
+                with torch.no_grad():
+                    ours.copy_(torch.from_numpy(self.data(d)).to(DEV))
+            elif "same" not in d:
+                self.compare(ours, d, "argument")
+            self.refs[d["ref"]] = ours
+            return ours
+        raise AssertionError(f"cannot build {d}")
+
+    def compare(self, ours, d, what):
+        """OUR value against the recorded one: structure, then numbers."""
+        t = d["t"]
+        if t == "none":
+            assert ours is None, (what, type(ours))
+        elif t == "py":
+            if d["py"] in ("float", "float32", "float64"):
+                assert abs(float(ours) - d["v"]) <= ATOL * max(1.0, abs(d["v"])), (what, ours, d["v"])
+            elif d["py"] == "str":
+                assert isinstance(ours, str), what
+            else:
+                assert ours == d["v"] and isinstance(ours, (bool, int, np.integer)), (what, ours, d["v"])
+        elif t in ("tuple", "list"):
+            assert isinstance(ours, (tuple, list)) and len(ours) == len(d["items"]), (what, type(ours))
+            for i, (o, x) in enumerate(zip(ours, d["items"])):
+                self.compare(o, x, f"{what}[{i}]")
+        elif t == "dict":
+            assert isinstance(ours, dict) and set(ours) == set(d["items"]), (what, sorted(ours), sorted(d["items"]))
+            for k, x in d["items"].items():
+                self.compare(ours[k], x, f"{what}[{k!r}]")
+        elif t == "ndarray":
+            assert isinstance(ours, np.ndarray), (what, type(ours))
+            self.numbers(ours, d, what)
+        elif t == "tensor":
+            assert isinstance(ours, torch.Tensor), (what, type(ours))
+            assert isinstance(ours, torch.nn.Parameter) == d["param"], (what, "Parameter-ness")
+            assert bool(ours.requires_grad) == d["requires_grad"], (what, "requires_grad")
+            assert ours.is_cuda, (what, "the reference's caller holds this on its device")
+            self.numbers(ours.detach().cpu().numpy(), d, what)
+            if "ref" in d:
+                self.refs.setdefault(d["ref"], ours)
+        elif t == "obj":
+            assert ours is self.objs[d["name"]], what
+        elif t == "opaque":
+            assert ours is not None, what
+        else:
+            raise AssertionError(d)
+
+    def numbers(self, a, d, what):
+        assert str(a.dtype) == d["dtype"], (what, a.dtype, d["dtype"])
+        assert list(a.shape) == d["shape"], (what, a.shape, d["shape"])
+        if "data" in d:
+            ref = self.z[d["data"]]
+        elif "sample" in d:
+            ref, a = self.z[d["sample"]], a.reshape(-1)[::d["stride"]]
+        else:
+            return
+        if a.dtype.kind in "iub":
+            assert np.array_equal(a, ref), what
+        else:
+            err = float(np.abs(a.astype(np.float64) - ref).max()) if a.size else 0.0
+            assert err <= ATOL * max(1.0, float(np.abs(ref).max()) if ref.size else 1.0), (what, err)
+        self.n_checked += 1
+
+    # ---- events -----------------------------------------------------------------------------------------------
+    def new(self, e):
+        args = [self.build(x) for x in e["args"]]
+        kw = {k: self.build(v) for k, v in e["kwargs"].items()}
+        if e["cls"] == "SparseVolume":                       # run_e2e.py:44-48: four positional arguments
+            self.objs["volume"] = self.bnv.SparseVolume(*args, **kw)
+        else:                                                # run_e2e.py:69-71
+            self.objs["tsdf_vol"] = self.TSDFVolume(*args, **kw)
+
+    def get(self, e):
+        obj = self.objs[e["obj"]]
+        assert hasattr(obj, e["attr"]), (e["obj"], e["attr"])
+        ours = getattr(obj, e["attr"])
+        d = e["value"]
+        if d["t"] == "tensor" and d.get("changed") and d.get("caller_owned"):
+            return self.build(d)                             # (the caller's optimiser stepped it)
+        if e["obj"] == "pointnet" and e["attr"] == "device":
+            assert torch.device(ours).type == "cuda"
+            return ours
+        self.compare(ours, d, f"{e['obj']}.{e['attr']}")
+        if d["t"] == "tensor":
+            self.refs[d["ref"]] = ours
+        return ours
+
+    def set(self, e):
+        setattr(self.objs[e["obj"]], e["attr"], self.build(e["value"]))
+        got = getattr(self.objs[e["obj"]], e["attr"])
+        assert got is self.refs[e["value"]["ref"]]           # the caller's object itself is kept (it optimises it)
+
+    def call(self, e):
+        obj, names = self.objs[e["obj"]], list(e["args"])
+        vals = [self.build(e["args"][n]) for n in names]
+        if e["method"] == "save":
+            vals[0] = os.path.join(self.tmp, os.path.basename(vals[0]))
+        npos = e["positional"]
+        fn = getattr(obj, e["method"])
+        ret = fn(*vals[:npos], **dict(zip(names[npos:], vals[npos:])))
+        what = f"{e['obj']}.{e['method']}(...)"
+        if e["method"] == "meshlize":
+            self.check_meshlize(ret, e["ret"], what)
+        else:
+            self.compare(ret, e["ret"], what)
+        if "grad_in" in e:
+            self.pending = (ret, torch.from_numpy(self.z[e["grad_in"]["data"]]).to(DEV))
+        return ret
+
+    def check_meshlize(self, ret, d, what):
+        """(active_pts ndarray, mesh) like the reference's (sparse_volume.py:697-766); the mesh object stands in for
+        trimesh.Trimesh: vertices / faces / export."""
+        assert isinstance(ret, tuple) and len(ret) == 2, what
+        self.compare(ret[0], d["items"][0], what + "[0]")
+        mesh = ret[1]
+        assert hasattr(mesh, "vertices") and hasattr(mesh, "faces") and callable(getattr(mesh, "export", None))
+        assert mesh.vertices.shape[1] == 3 and mesh.faces.shape[1] == 3
+
+    def grad(self, e):
+        """The autograd edge of decode_pts: the gradient the reference's loss sent into the returned SDF values,
+        pushed through OUR graph, must deliver the recorded gradient to the caller's leaf (volume.features)."""
+        out, g_in = self.pending
+        leaf = self.objs["volume"].features
+        assert isinstance(leaf, torch.nn.Parameter) and leaf.requires_grad
+        before = None if leaf.grad is None else leaf.grad.detach().clone()
+        out.backward(g_in)
+        got = leaf.grad.detach() if before is None else leaf.grad.detach() - before
+        ref = self.z[e["value"]["data"]]
+        scale = float(np.abs(ref).max())
+        assert scale > 0
+        err = float(np.abs(got.cpu().numpy() - ref).max())
+        assert err <= 1e-4 * scale, (err, scale)
+        self.pending = None
+        self.n_checked += 1
+
+    def mc(self, e):
+        """The lattices the reference hands to marching cubes (every active voxel whose 27 values straddle 0, in row
+        order): OUR decode of the same lattices, voxels within ATOL of the decision excepted."""
+        vol = self.objs["volume"]
+        delta = self.last_delta
+        sdf = vol.meshlize_sdf(self.objs["pointnet.nerf"], delta)[1].detach().cpu().numpy().reshape(-1, 27)
+        ref = self.z[e["lattices"]["data"]].reshape(-1, 27)
+        hi, lo = sdf.max(1), sdf.min(1)
+        sure, maybe = (hi > ATOL) & (lo < -ATOL), (hi > -ATOL) & (lo < ATOL)
+        j = 0
+        for r in ref:
+            while True:
+                assert j < len(sdf), "the reference meshed a voxel our decode does not straddle"
+                if maybe[j] and np.abs(sdf[j] - r).max() <= ATOL:
+                    j += 1
+                    break
+                assert not sure[j], (j, float(np.abs(sdf[j] - r).max()))
+                j += 1
+        assert not sure[j:].any()
+        assert len(ref) == e["n_calls"] and len(ref) > 50
+        self.n_checked += 1
+
+
+@pytest.mark.gpu
+def test_reference_caller_trace_replays_on_the_hip_classes(tmp_path):
+    z, meta, events = _load()
+    rp = Replay(z, meta, tmp_path)
+    counts = {}
+    for e in events:
+        if e["depth"] != 0:
+            continue                      # what the reference's methods do among themselves
+        op = e["op"]
+        counts[op] = counts.get(op, 0) + 1
+        if op == "new":
+            rp.new(e)
+        elif op == "get":
+            rp.get(e)
+        elif op == "set":
+            rp.set(e)
+        elif op == "call":
+            if e["method"] == "meshlize":
+                rp.last_delta = rp.build(e["args"]["sdf_delta"])
+            rp.call(e)
+        elif op == "grad":
+            rp.grad(e)
+        elif op == "mc":
+            rp.mc(e)
+        elif op == "saved":
+            saved = torch.load(os.path.join(str(tmp_path), "final_sparse_volume.pth"), weights_only=False)
+            ref = e["files"]["final_sparse_volume.pth"]["items"]
+            assert set(saved) == set(ref), (sorted(saved), sorted(ref))
+            order = None
+            for k, d in ref.items():
+                v = saved[k]
+                if d["t"] == "tensor":        # (row order = insertion order on both sides here; Open3D's is its own)
+                    assert isinstance(v, torch.Tensor) and str(v.detach().cpu().numpy().dtype) == d["dtype"], k
+                    assert list(v.shape) == d["shape"], (k, v.shape, d["shape"])
+                    a, r = v.detach().cpu().numpy(), z[d["data"]]
+                    if a.dtype.kind in "iu":
+                        assert np.array_equal(a, r), k
+                    else:
+                        assert np.abs(a - r).max() <= ATOL * max(1.0, float(np.abs(r).max())), k
+                elif d["t"] == "py" and d["py"] != "str":
+                    assert abs(float(v) - float(d["v"])) <= 1e-3 * max(1.0, abs(float(d["v"]))), (k, v, d["v"])
+                elif d["t"] == "ndarray":
+                    assert np.allclose(np.asarray(v), z[d["data"]]), k
+        else:
+            raise AssertionError(op)
+    assert counts["call"] >= 60 and counts["grad"] == 4 and counts["mc"] == 2 and counts["set"] == 1
+    assert rp.n_checked > 100

@@ -150,20 +150,30 @@ def price(rank, latency):
         for k in HOST:
             HOST[k] = 0.0
         lib.bnv_profile_enable(1)
+        # timed in SEGMENTS (each ends with a device synchronisation): the figure of a run is the whole stretch, the
+        # median segment says whether a hiccup of the box (another tenant, a clock dip) sits in it
+        SEG = 10 if args.frames >= 1000 else 1
+        seg_ms = []
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        run(idx, args.in_flight)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        for k in range(SEG):
+            part = idx[k * len(idx) // SEG: (k + 1) * len(idx) // SEG]
+            torch.cuda.synchronize(); s0 = time.perf_counter()
+            run(part, args.in_flight)
+            torch.cuda.synchronize(); seg_ms.append(1e3 * (time.perf_counter() - s0) / max(len(part), 1))
+        dt = time.perf_counter() - t0
         ms, cnt = (C.c_double * 4)(), (C.c_int64 * 4)()
         lib.bnv_profile_read(ms, cnt)
         lib.bnv_profile_enable(0)
         n = stats["n"]
-        out = {"rank": rank, "ms": 1e3 * dt / n, "own": stats["own"] / n, "pairs": stats["pairs"] / n,
+        out = {"rank": rank, "ms": 1e3 * dt / n, "ms_med": float(np.median(seg_ms)), "ms_worst": float(np.max(seg_ms)),
+               "own": stats["own"] / n, "pairs": stats["pairs"] / n,
                "evals": stats["evals"] / n, "enc_ms": ms[0] / max(cnt[0], 1), "tab_ms": ms[1] / max(cnt[1], 1),
                "host_ms": 1e3 * stats["enq"] / n}
         print(f"rank {rank} of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
               f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}:")
         print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
-              f"rank keeps this pace")
+              f"rank keeps this pace" + (f"  ({SEG} segments: median {np.median(seg_ms):.3f}, slowest {np.max(seg_ms):.3f} ms)"
+                                         if SEG > 1 else ""))
         print(f"  host enqueue time     {1e3 * stats['enq'] / n:.3f} ms per frame (includes the bound wait); host waits per "
               f"frame: {stats['waits'] / n:.2f}")
         print("  host time per frame by phase (ms): " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in HOST.items())
@@ -198,16 +208,18 @@ gc.disable()       # as bench.py: a full collection with torch imported takes ~4
 if args.all_ranks:
     rows = [price(r, latency=False) for r in range(W)]
     print(f"\nall {W} ranks ({args.frames} frames each, {args.in_flight} in flight):")
-    print("  rank   ms/frame   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
+    print("  rank   ms/frame   (median, slowest segment)   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
     for o in rows:
-        print(f"  {o['rank']:4d}   {o['ms']:8.3f}   {o['own']:12.0f}   {o['pairs']:13.0f}   {o['evals']:15.0f}   "
-              f"{o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
+        print(f"  {o['rank']:4d}   {o['ms']:8.3f}   ({o['ms_med']:.3f}, {o['ms_worst']:.3f})            {o['own']:12.0f}   "
+              f"{o['pairs']:13.0f}   {o['evals']:15.0f}   {o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
     for k, name in (("own", "voxels owned"), ("pairs", "pairs encoded"), ("evals", "MLP evaluations")):
         v = np.array([o[k] for o in rows])
         print(f"  {name}: max / mean over the ranks {v.max() / max(v.mean(), 1e-9):.3f}")
     v = np.array([o["ms"] for o in rows])
     print(f"  ms per frame: mean {v.mean():.3f}, MAX {v.max():.3f} (rank {int(v.argmax())}) -> {1e3 / v.max():.0f} frames/s "
           f"for the rank set at the pace of its slowest rank")
+    m = np.array([o["ms_med"] for o in rows])
+    print(f"  median segments: mean {m.mean():.3f}, MAX {m.max():.3f} (rank {int(m.argmax())}) -> {1e3 / m.max():.0f} frames/s")
 else:
     price(args.rank, latency=not args.no_latency)
 dist.destroy_process_group()
