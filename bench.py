@@ -56,6 +56,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from bnv_fusion_amd import configure_runtime  # noqa: E402
+
+configure_runtime()      # 8 hardware queues for the frame pipelines' streams; before the first HIP call
 
 FLOP_PER_PAIR = 2 * (6 * 128 + 128 * 128 + 128 * 128 + 128 * 8)          # 69,120  point encoder
 FLOP_PER_EVAL = 2 * (17 * 256 + 3 * 256 * 256 + 256)                      # 402,432 SDF MLP
@@ -68,7 +71,7 @@ DTYPE = {0: "f32 (v_mfma_f32_32x32x2_f32)",
          1: "f32 operands split into f16 hi+lo, 3 products on v_mfma_f32_16x16x32_f16, f32 accumulate",
          2: "f16 weights/activations (tiny-cuda-nn FullyFusedMLP layout), f32 accumulate",
          3: "fp32 checkpoint, operands rounded to f16, 1 product on v_mfma_f32_16x16x32_f16, f32 accumulate"}
-DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_x<3>", 2: "k_decode<LATTICE, tcnn>",
+DECODE_KERNEL = {0: "k_decode<LATTICE, fp32_exact>", 1: "k_lattice_table_x<3>", 2: "k_lattice_table_t",
                  3: "k_lattice_table_x<1>"}
 PARITY_VOXELS = 2048
 
@@ -78,7 +81,7 @@ PARITY_VOXELS = 2048
 # at 640x480 on top of ~350,000 known rows).  What growing from the reference's 100,000 rows costs is reported
 # separately (`growth`).
 CAPACITY = 1 << 22
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def pmc_traffic(kernel_substr, evals_now):
@@ -94,6 +97,15 @@ def pmc_traffic(kernel_substr, evals_now):
     if not (os.path.exists(path) and os.path.exists(meta_path)):
         return None, None
     meta = json.load(open(meta_path))
+    # the profile is only this kernel's while the kernel's source is the one that was profiled (the GPU box has no
+    # git history: the profile's meta file carries the SHA-256 of csrc/decode.hip as it was then)
+    import hashlib
+    with open(os.path.join(ROOT, "bnv_fusion_amd", "csrc", "decode.hip"), "rb") as fh:
+        sha_now = hashlib.sha256(fh.read()).hexdigest()
+    if meta.get("decode_hip_sha256") != sha_now:
+        return None, {"file": f"profiles/{PROFILE_TAG}_pmc_summary.csv", "source_commit": meta.get("commit"),
+                      "dropped": "csrc/decode.hip has changed since the PMC passes were taken (or the profile does "
+                                 "not say which source it saw): re-run tools/run_profiles.sh"}
     fetch = write = None
     for line in open(path):
         if kernel_substr in line:
@@ -464,6 +476,7 @@ def run_bench(args, rank, world, dev, dist, backend):
             m = bnv.NeuralMap(dims3, voxel, model, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
             m.overlap_encode = not args.no_stream_overlap
             m.inputs_resident = True
+            m.copy_results = False            # results are views into the pipeline's slots (collected before reuse)
         return m
 
     kinds = ["single"] if world == 1 else ([args.parallelism] + ([] if args.no_alt_mode else
@@ -512,9 +525,14 @@ def run_bench(args, rank, world, dev, dist, backend):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
 
+        n_pairs, n_evals = [], []
+
         def collect(res):
             c, _ = res
             n_vox.append(0 if c is None else int(c.shape[0]))
+            if kind == "spatial":        # this rank's share of the frame (bnv_encode_counters_t.reserved[0], pinned words)
+                n_pairs.append(int(m.backend.last_owned_pairs))
+                n_evals.append(int(m.backend._last_evals))
 
         coords, sdf = drv.run(m, kind, idx, collect=None if kind == "frame" else collect)
         torch.cuda.synchronize()
@@ -545,6 +563,8 @@ def run_bench(args, rank, world, dev, dist, backend):
                 "dec_tflops": dec_flop / (dec_ms * 1e-3) / 1e12 if dec_ms else 0.0,
                 "enc_tflops": enc_flop / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0, "dec_flop": dec_flop,
                 "coords": coords, "sdf": sdf, "kind": kind, "fpu": fpu,
+                "pairs_per_frame": float(np.mean(n_pairs)) if n_pairs else 0.0,
+                "evals_per_frame": float(np.mean(n_evals)) if n_evals else 0.0,
                 "frames_this_rank": len(idx) // world if kind == "frame" else len(idx)}
 
     # parity check of a configuration against the oracle (PARITY_VOXELS voxels of its last frame): the SDF lattice
@@ -618,7 +638,8 @@ def run_bench(args, rank, world, dev, dist, backend):
                 run = timed(m, kind, args.mlp_mode, step_idx, warm_idx, preheat=min(args.preheat, 4 * POOL))
                 run["parity"] = parity_check(m, run)
                 if kind == "spatial":
-                    extra = {"received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
+                    extra = {"ownership": m.backend.ownership,
+                             "received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
                              "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
                                  bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}
             except Exception as e:       # noqa: BLE001 -- reported in the output line
@@ -628,13 +649,22 @@ def run_bench(args, rank, world, dev, dist, backend):
             votes = [None] * world
             dist.all_gather_object(votes, {"error": err, "frames": int(run["frames_this_rank"]) if run else 0,
                                            "voxels_per_frame": run["n_vox"] if run else 0,
-                                           "mlp_evals_last_frame": run["rows"] if run else 0})
+                                           "pairs_per_frame": run["pairs_per_frame"] if run else 0,
+                                           "mlp_evals_per_frame": run["evals_per_frame"] if run else 0,
+                                           "mlp_evals_last_frame": run["rows"] if run else 0,
+                                           "ms_per_frame": 1e3 * run["elapsed"] / max(run["steps"], 1) if run else 0})
             failed = [v["error"] for v in votes if v["error"]]
             if failed:
                 errors[kind] = failed
             else:
-                extra["per_rank"] = [{k: v[k] for k in ("frames", "voxels_per_frame", "mlp_evals_last_frame")}
-                                     for v in votes]
+                keys = ("frames", "voxels_per_frame", "pairs_per_frame", "mlp_evals_per_frame", "mlp_evals_last_frame")
+                extra["per_rank"] = [{k: v[k] for k in keys} for v in votes]
+                if kind == "spatial":       # what the rank set ran with: the slowest rank sets the pace
+                    def mom(k):
+                        a = np.array([float(v[k]) for v in votes])
+                        return float(a.max() / a.mean()) if a.mean() > 0 else None
+                    extra["load_max_over_mean"] = {k: mom(k) for k in ("voxels_per_frame", "pairs_per_frame",
+                                                                       "mlp_evals_per_frame")}
                 results[kind] = (run, extra)
             del m
             model.shard = (0, 1, 3)

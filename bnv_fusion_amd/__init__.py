@@ -3,10 +3,22 @@ and SDF decode hot path, behind the reference's LitFusionPointNet / SparseVolume
 See DESIGN.md (layout, kernels, rooflines) and INTEGRATION.md (how run_e2e.py picks it up)."""
 import os as _os
 
-# The HIP runtime serves a process's streams from GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a
-# queue run strictly in submission order.  More queues make it likelier that the pipelines' side streams get one of
-# their own (streams.py still verifies it); only effective when set before the runtime initialises.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+def configure_runtime(hw_queues=8):
+    """Optional, and only effective BEFORE the process's first HIP call (e.g. before the first ``torch.cuda`` use): asks
+    the HIP runtime for ``hw_queues`` hardware queues (environment variable GPU_MAX_HW_QUEUES, unless it is set
+    already).  The runtime serves a process's streams from 4 queues by default, and streams that share a queue run
+    strictly in submission order; the frame pipelines here use up to four streams of their own next to the caller's
+    (and RCCL's), so with 4 queues some of them would serialise.  ``streams.concurrent_stream`` verifies every side
+    stream it hands out either way and says so (``.bnv_concurrent``) -- results never depend on this, only the
+    overlap.  Importing the package does NOT touch the environment; bench.py, the tools and the tests call this first.
+    Returns True if the setting will take effect."""
+    import torch
+    if torch.cuda.is_initialized():
+        return _os.environ.get("GPU_MAX_HW_QUEUES") == str(hw_queues)
+    _os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(hw_queues)))
+    return _os.environ["GPU_MAX_HW_QUEUES"] == str(int(hw_queues))
+
 
 from .fusion import LitFusionPointNet, LocalNeRFModel, get_neighbors, load_pretrained  # noqa: F401
 from .sparse_volume import SparseVolume, VolumeList, get_world_range  # noqa: F401

@@ -25,7 +25,7 @@ SYMBOLS = [
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
     "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
-    "bnv_encode_finish_image_wg",
+    "bnv_encode_finish_image_wg", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
@@ -35,7 +35,8 @@ class Grid(C.Structure):
     _fields_ = [("bound_min", C.c_float * 3), ("bound_lo", C.c_float * 3), ("bound_hi", C.c_float * 3),
                 ("voxel_size", C.c_float), ("n_xyz", C.c_int32 * 3), ("min_pts_in_grid", C.c_int32),
                 ("shard_rank", C.c_int32), ("shard_world", C.c_int32), ("shard_block_log2", C.c_int32),
-                ("mlp_mode", C.c_int32)]      # 0: process default; 1 + m: arithmetic mode m for calls with this grid
+                ("mlp_mode", C.c_int32),      # 0: process default; 1 + m: arithmetic mode m for calls with this grid
+                ("shard_state", C.c_void_p)]  # NULL: hash ownership; else the first-touch owner table (device)
 
 
 class EncodeCounters(C.Structure):
@@ -209,6 +210,9 @@ def load():
                                                         vp, sz, i32, vp]),
         "bnv_encode_finish_image_wg": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
                                                  C.c_int, vp, C.c_int, vp]),
+        "bnv_shard_state_bytes": (sz, [C.POINTER(i32), i32]),
+        "bnv_shard_state_loads_offset": (sz, []),
+        "bnv_shard_state_table_offset": (sz, []),
         "bnv_decode_dense_mode": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, i32, vp, vp, vp, vp]),
         "bnv_frame_pipe_set_mlp_mode": (C.c_int, [vp, i32]),
         "bnv_shard_install_reset": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp, vp]),

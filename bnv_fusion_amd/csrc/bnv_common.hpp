@@ -135,13 +135,88 @@ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   return (uint32_t)k;
 }
 
-// Shard owner of a voxel: hash of its block coordinate.
+// ---- first-touch ownership (bnv_grid_t::shard_state; encode.hip: k_shard_assign) ------------------------------------
+// [header 1024 B: uint64 load[64] | int32 any_new | ...][owner table: 1 byte per block][block weights u32][new list u32]
+constexpr size_t kShardHdrBytes = 1024;
+constexpr uint8_t kOwnRank = 0x3f, kOwnAssigned = 0x40, kOwnTouched = 0x80;
+constexpr uint32_t kNewListCap = 4096;   // new blocks of a frame k_rank lists for k_shard_assign (a power of two: sorted in place)
+struct ShardHdr {
+  unsigned long long load[64];   // touched voxels (at first touch) of the blocks each rank owns
+  int32_t any_new;               // k_rank: the blocks this frame touches for the first time (their number)
+};
+static_assert(sizeof(ShardHdr) <= kShardHdrBytes, "shard state header");
+struct ShardState {
+  ShardHdr* hdr;
+  uint8_t* table;
+  uint32_t* blk_w;
+  uint32_t* new_list;
+  int64_t n_blocks;
+};
+__host__ __device__ inline void shard_block_dims(const int32_t n_xyz[3], int s, int nb[3]) {
+  for (int a = 0; a < 3; ++a) nb[a] = (n_xyz[a] + (1 << s) - 1) >> s;
+}
+__host__ __device__ inline size_t shard_state_layout(const int32_t n_xyz[3], int s, char* base, ShardState* S) {
+  int nb[3];
+  shard_block_dims(n_xyz, s, nb);
+  const int64_t n = (int64_t)nb[0] * nb[1] * nb[2];
+  const size_t tab = ((size_t)n + 255) / 256 * 256;
+  if (S) {
+    S->hdr = (ShardHdr*)base;
+    S->table = (uint8_t*)(base + kShardHdrBytes);
+    S->blk_w = (uint32_t*)(base + kShardHdrBytes + tab);
+    S->new_list = (uint32_t*)(base + kShardHdrBytes + tab + (size_t)n * 4);
+    S->n_blocks = n;
+  }
+  return kShardHdrBytes + tab + (size_t)n * 8;
+}
+// the rule that pins blocks nobody has touched yet (neighbours of touched blocks): a lattice rule spreads any
+// axis-aligned stretch of blocks evenly over the ranks
+__host__ __device__ inline int shard_lattice_owner(int bx, int by, int bz, int world) {
+  return (int)(((unsigned)bx + 5u * (unsigned)by + 7u * (unsigned)bz) % (unsigned)world);
+}
+
+// Shard owner of a voxel.  Hash rule: hash of its block coordinate.  First-touch rule: the
+// table's entry, -1 for a voxel outside the grid or in a block without an owner (neither can hold a row that an
+// emitted voxel's decode reads: see bnv_grid_t.shard_state).
 __device__ __forceinline__ int voxel_owner(int x, int y, int z, const bnv_grid_t& g) {
   if (g.shard_world <= 1) return 0;
   const int s = g.shard_block_log2;
+  if (g.shard_state) {
+    if ((unsigned)x >= (unsigned)g.n_xyz[0] || (unsigned)y >= (unsigned)g.n_xyz[1] || (unsigned)z >= (unsigned)g.n_xyz[2])
+      return -1;
+    const int m = (1 << s) - 1;
+    const int nby = (g.n_xyz[1] + m) >> s, nbz = (g.n_xyz[2] + m) >> s;
+    const uint8_t t = ((const uint8_t*)g.shard_state + kShardHdrBytes)[((x >> s) * nby + (y >> s)) * nbz + (z >> s)];
+    return (t & kOwnAssigned) ? (int)(t & kOwnRank) : -1;
+  }
   uint64_t b = ((uint64_t)(uint32_t)(x >> s) << 42) | ((uint64_t)(uint32_t)(y >> s) << 21) |
                (uint64_t)(uint32_t)(z >> s);
   return (int)(mix64(b) % (uint32_t)g.shard_world);
+}
+
+// shard_is_boundary for the moment when some blocks may still be without an owner (first-touch ownership, between
+// the frame's rank kernel and its k_shard_assign): 0 no, 1 yes, 2 cannot say yet -- the voxel's own block or a block
+// of its neighbourhood has no owner.  Neighbours outside the grid hold no voxel and do not count.
+__device__ __forceinline__ int shard_boundary_state(int x, int y, int z, const bnv_grid_t& g) {
+  if (g.shard_world <= 1) return 0;
+  const int m = (1 << g.shard_block_log2) - 1;
+  const int bx = x & m, by = y & m, bz = z & m;
+  const int me = voxel_owner(x, y, z, g);
+  if (me < 0) return 2;
+  if (bx != 0 && bx != m && by != 0 && by != m && bz != 0 && bz != m) return 0;  // interior of its block
+  bool other = false, open = false;
+  for (int dx = (bx == 0 ? -1 : 0); dx <= (bx == m ? 1 : 0); ++dx)
+    for (int dy = (by == 0 ? -1 : 0); dy <= (by == m ? 1 : 0); ++dy)
+      for (int dz = (bz == 0 ? -1 : 0); dz <= (bz == m ? 1 : 0); ++dz) {
+        if ((dx | dy | dz) == 0) continue;
+        const int X = x + dx, Y = y + dy, Z = z + dz;
+        if ((unsigned)X >= (unsigned)g.n_xyz[0] || (unsigned)Y >= (unsigned)g.n_xyz[1] || (unsigned)Z >= (unsigned)g.n_xyz[2])
+          continue;
+        const int o = voxel_owner(X, Y, Z, g);
+        open |= o < 0;
+        other |= o >= 0 && o != me;
+      }
+  return other ? 1 : (open ? 2 : 0);
 }
 
 // Is the voxel a BOUNDARY voxel of the sharding: does any voxel of its 3x3x3 neighbourhood belong to another
@@ -149,6 +224,7 @@ __device__ __forceinline__ int voxel_owner(int x, int y, int z, const bnv_grid_t
 // a voxel reads the rows of that neighbourhood, so boundary voxels are the ones whose rows other ranks need.
 __device__ __forceinline__ bool shard_is_boundary(int x, int y, int z, const bnv_grid_t& g) {
   if (g.shard_world <= 1) return false;
+  if (g.shard_state) return shard_boundary_state(x, y, z, g) != 0;   // (2 cannot occur for an emitted voxel)
   const int m = (1 << g.shard_block_log2) - 1;
   const int bx = x & m, by = y & m, bz = z & m;
   if (bx != 0 && bx != m && by != 0 && by != m && bz != 0 && bz != m) return false;  // interior of its block

@@ -95,7 +95,9 @@ struct EncCtl {
   int32_t n_pairs;             // sharded encode: (point, corner) pairs whose voxel this rank owns (mark kernel)
   int32_t n_unique;            // U: touched voxels (k_rank)
   int32_t error;               // != 0: a capacity was exceeded
-  int32_t pad[13];
+  int32_t n_orphans;           // first-touch ownership: points with a corner voxel in a block that has no owner yet
+  int32_t n_deferred;          // first-touch ownership: touched voxels whose boundary test waits for k_shard_assign
+  int32_t pad[11];
   int32_t shard_boundary[64];  // sharded encode: touched BOUNDARY voxels owned by each rank (k_rank) -- an upper
                                // bound of the boundary records that rank will exchange for this frame, known on
                                // every rank (the voxelisation is replicated) before the encoder MLP starts
@@ -107,6 +109,8 @@ struct EncodeWs {
   uint64_t* tile_state;   // [n_tiles] look-back state of k_rank / k_finalize (epoch-tagged, never cleared)
   int32_t* valid_blocks;  // [ceil(max_points / 256)] points that passed the bounds mask, per workgroup of the mark kernel
   int32_t* pair_list;     // [8 * max_points] sharded encode: (point << 3 | corner) of the pairs this rank owns
+  int32_t* orphan_list;   // [max_points] first-touch ownership: points the mark kernel could not decide (k_shard_own)
+  int32_t* defer_list;    // [max_unique] first-touch ownership: slots whose boundary test k_rank could not decide
   uint8_t* bytemap;       // [n_words * 32] one byte per voxel: set by the mark kernel (plain stores), consumed and
                           // cleared by k_rank
   uint8_t* chunk_flag;    // [n_chunks] one byte per 64 voxels (2 bitmap words): any byte of the chunk set
@@ -152,6 +156,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   char* p_state = take(n_tiles * 8);
   char* p_valid = take(((max_points + 255) / 256 + 1) * 4);
   char* p_pairs = take((size_t)(max_points > 0 ? max_points : 1) * 8 * 4);
+  char* p_orph = take((size_t)(max_points > 0 ? max_points : 1) * 4);
   char* p_bytes = take(n_words * 32);
   char* p_chunks = take(n_chunks);
   char* p_bitmap = take(n_words * 4);
@@ -159,11 +164,13 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
   char* p_ids = take(max_unique * 4);
   char* p_counts = take(max_unique * 4);
   char* p_acc = take(max_unique * 8 * 8);
+  char* p_defer = take(max_unique * 4);
   if (ws) {
     ws->ctl = (EncCtl*)p_ctl;
     ws->tile_state = (uint64_t*)p_state;
     ws->valid_blocks = (int32_t*)p_valid;
     ws->pair_list = (int32_t*)p_pairs;
+    ws->orphan_list = (int32_t*)p_orph;
     ws->bytemap = (uint8_t*)p_bytes;
     ws->chunk_flag = (uint8_t*)p_chunks;
     ws->n_chunks = n_chunks;
@@ -172,6 +179,7 @@ static size_t encode_ws_layout(int64_t max_points, const int32_t n_xyz[3], char*
     ws->ids = (int32_t*)p_ids;
     ws->counts = (int32_t*)p_counts;
     ws->acc = (long long*)p_acc;
+    ws->defer_list = (int32_t*)p_defer;
     ws->n_words = n_words;
     ws->max_unique = max_unique;
     ws->n_tiles = n_tiles;
@@ -207,11 +215,72 @@ uint32_t next_epoch() {
 // pixels stay neighbours and the encoder's wave-level run reduction keeps working -- and the encoder then forms
 // its tiles from the list: 1 / world of the pairs instead of every tile that holds at least one owned pair
 // (with 8^3-voxel blocks that was ~60 % of the tiles at world 8).  One atomicAdd per WORKGROUP on the list counter.
+// The (point, corner) pairs of a 256-thread workgroup's points whose voxel THIS rank owns, appended to pair_list as
+// (point << 3 | corner) in (corner, point) order.  Every thread of the workgroup must call this (two barriers).
+// First-touch ownership, mark kernel (orphan_list set): a point with a corner voxel in a block that has no owner YET
+// (the frame's k_shard_assign has not run) lists nothing here and goes to orphan_list; k_shard_own lists its pairs
+// once the owners are known.  A frame that touches no new block has no orphan.
+__device__ __forceinline__ void list_owned_pairs(bool valid, int fx, int cx, int fy, int cy, int fz, int cz,
+                                                 const bnv_grid_t& g, int point_index,
+                                                 int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs,
+                                                 int32_t* __restrict__ orphan_list = nullptr,
+                                                 int32_t* __restrict__ n_orphans = nullptr) {
+  const int lane = threadIdx.x & 63;
+  __shared__ int s_cnt[32];   // [corner][wave] owned pairs
+  unsigned long long own[8];
+  int owner8[8];
+  bool orphan = false;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
+    owner8[k] = valid ? voxel_owner(gx, gy, gz, g) : -2;
+    orphan |= owner8[k] == -1;
+  }
+  if (orphan_list) {   // (workgroup-uniform)
+    const unsigned long long ob = __ballot(orphan);
+    if (ob) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(n_orphans, (int)__popcll(ob));
+      base = __shfl(base, 0, 64);
+      if (orphan) orphan_list[base + (int)__popcll(ob & ((1ull << lane) - 1ull))] = point_index;
+    }
+    if (orphan) valid = false;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    own[k] = __ballot(valid && owner8[k] == g.shard_rank);
+    if (lane == 0) s_cnt[k * 4 + (threadIdx.x >> 6)] = (int)__popcll(own[k]);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive prefix of the 32 counts (first wave), then the workgroup's place in the list
+    const int c = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0;
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if ((int)threadIdx.x >= d) incl += o;
+    }
+    const int total = __shfl(incl, 31, 64);
+    int base = 0;
+    if (threadIdx.x == 0 && total) base = atomicAdd(n_pairs, total);
+    base = __shfl(base, 0, 64);
+    if (threadIdx.x < 32) s_cnt[threadIdx.x] = base + incl - c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if ((own[k] >> lane) & 1ull)
+      pair_list[s_cnt[k * 4 + (threadIdx.x >> 6)] + (int)__popcll(own[k] & ((1ull << lane) - 1ull))] =
+          (point_index << 3) | k;
+}
+
 __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z, const bnv_grid_t& g,
                                            uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
                                            int32_t* __restrict__ valid_blocks, int point_index = 0,
                                            int32_t* __restrict__ pair_list = nullptr,
-                                           int32_t* __restrict__ n_pairs = nullptr) {
+                                           int32_t* __restrict__ n_pairs = nullptr,
+                                           int32_t* __restrict__ orphan_list = nullptr,
+                                           int32_t* __restrict__ n_orphans = nullptr) {
   int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
   if (valid) {
     const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
@@ -242,35 +311,7 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
   const unsigned long long b = __ballot(valid);
   if (lane == 0) s_valid[threadIdx.x >> 6] = (int)__popcll(b);
   if (pair_list) {   // (workgroup-uniform)
-    __shared__ int s_cnt[32];   // [corner][wave] owned pairs
-    unsigned long long own[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int gx = (k & 1) ? cx : fx, gy = (k & 2) ? cy : fy, gz = (k & 4) ? cz : fz;
-      own[k] = __ballot(valid && voxel_owner(gx, gy, gz, g) == g.shard_rank);
-      if (lane == 0) s_cnt[k * 4 + (threadIdx.x >> 6)] = (int)__popcll(own[k]);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {   // exclusive prefix of the 32 counts (first wave), then the workgroup's place in the list
-      const int c = threadIdx.x < 32 ? s_cnt[threadIdx.x] : 0;
-      int incl = c;
-#pragma unroll
-      for (int d = 1; d < 32; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if ((int)threadIdx.x >= d) incl += o;
-      }
-      const int total = __shfl(incl, 31, 64);
-      int base = 0;
-      if (threadIdx.x == 0 && total) base = atomicAdd(n_pairs, total);
-      base = __shfl(base, 0, 64);
-      if (threadIdx.x < 32) s_cnt[threadIdx.x] = base + incl - c;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if ((own[k] >> lane) & 1ull)
-        pair_list[s_cnt[k * 4 + (threadIdx.x >> 6)] + (int)__popcll(own[k] & ((1ull << lane) - 1ull))] =
-            (point_index << 3) | k;
+    list_owned_pairs(valid, fx, cx, fy, cy, fz, cz, g, point_index, pair_list, n_pairs, orphan_list, n_orphans);
   } else {
     __syncthreads();
   }
@@ -280,7 +321,8 @@ __device__ __forceinline__ void mark_point(bool valid, float x, float y, float z
 __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int n_points, bnv_grid_t g,
                                               uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
                                               int32_t* __restrict__ valid_blocks,
-                                              int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
+                                              int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs,
+                                              int32_t* __restrict__ orphan_list, int32_t* __restrict__ n_orphans) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool valid = false;
   float x = 0.f, y = 0.f, z = 0.f;
@@ -290,7 +332,7 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
     z = pts[(size_t)i * 6 + 2];
     valid = in_bounds(x, y, z, g);
   }
-  mark_point(valid, x, y, z, g, bytemap, chunk_flag, valid_blocks, i, pair_list, n_pairs);
+  mark_point(valid, x, y, z, g, bytemap, chunk_flag, valid_blocks, i, pair_list, n_pairs, orphan_list, n_orphans);
 }
 
 // The same, fused behind the depth front end (frontend.hpp): one thread per PIXEL computes the pixel's world point
@@ -300,7 +342,9 @@ __global__ __launch_bounds__(256) void k_mark(const float* __restrict__ pts, int
 __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restrict__ out_pts, bnv_grid_t g,
                                                     uint8_t* __restrict__ bytemap, uint8_t* __restrict__ chunk_flag,
                                                     int32_t* __restrict__ valid_blocks,
-                                                    int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs) {
+                                                    int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs,
+                                                    int32_t* __restrict__ orphan_list,
+                                                    int32_t* __restrict__ n_orphans) {
   const int64_t n = (int64_t)a.H * a.W;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   float p[6];
@@ -318,7 +362,8 @@ __global__ __launch_bounds__(256) void k_front_mark(FrontArgs a, float* __restri
     }
   }
   const bool valid = have && in_bounds(p[0], p[1], p[2], g);
-  mark_point(valid, p[0], p[1], p[2], g, bytemap, chunk_flag, valid_blocks, (int)i, pair_list, n_pairs);
+  mark_point(valid, p[0], p[1], p[2], g, bytemap, chunk_flag, valid_blocks, (int)i, pair_list, n_pairs, orphan_list,
+             n_orphans);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,7 +385,8 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
                                                        uint32_t epoch, uint32_t* __restrict__ bitmap,
                                                        uint32_t* __restrict__ word_prefix,
                                                        int32_t* __restrict__ ids, int64_t max_unique,
-                                                       EncCtl* __restrict__ ctl, bnv_grid_t g) {
+                                                       EncCtl* __restrict__ ctl, bnv_grid_t g,
+                                                       int32_t* __restrict__ defer_list) {
   __shared__ uint32_t wave_tot[kScanThreads / 64];
   __shared__ uint32_t s_excl;
   __shared__ int s_hist[64];
@@ -398,7 +444,35 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
       ++run;
     }
   }
-  if (g.shard_world > 1) {
+  if (g.shard_world > 1 && g.shard_state) {
+    // first-touch ownership: the touched voxels of every block no frame has touched before are counted -- the
+    // block's weight when k_shard_assign gives it an owner; the exchange bound follows in k_shard_own
+    __syncthreads();
+    ShardState S;
+    shard_state_layout(g.n_xyz, g.shard_block_log2, (char*)g.shard_state, &S);
+    const int sh = g.shard_block_log2, mb = (1 << sh) - 1;
+    const int nby = (g.n_xyz[1] + mb) >> sh, nbz = (g.n_xyz[2] + mb) >> sh;
+    const int64_t lo = s_excl, hi = (int64_t)s_excl + total < max_unique ? (int64_t)s_excl + total : max_unique;
+    for (int64_t j = lo + threadIdx.x; j < hi; j += kScanThreads) {
+      const int id = __hip_atomic_load(&ids[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+      const int b = ((x >> sh) * nby + (y >> sh)) * nbz + (z >> sh);
+      if (!(S.table[b] & kOwnTouched) && atomicAdd(&S.blk_w[b], 1u) == 0u) {
+        // the block's first voxel: list the block (k_shard_assign sorts the list; past its capacity it scans the
+        // weight table instead, so the count alone is what matters then)
+        const uint32_t pos = (uint32_t)atomicAdd(&S.hdr->any_new, 1);
+        if (pos < kNewListCap) S.new_list[pos] = (uint32_t)b;
+      }
+      // the exchange bound with the owners as they stand; a voxel next to a block that has no owner yet is left
+      // to k_shard_own (behind this frame's k_shard_assign).  A frame without a new block defers nothing.
+      const int st = shard_boundary_state(x, y, z, g);
+      if (st == 1) atomicAdd(&s_hist[voxel_owner(x, y, z, g) & 63], 1);
+      else if (st == 2) defer_list[atomicAdd(&ctl->n_deferred, 1)] = (int32_t)j;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
+      atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
+  } else if (g.shard_world > 1) {
     // the exchange bound: touched BOUNDARY voxels per owner.  The set bits sit in a few threads (a thread holds 256
     // consecutive voxels), so the ~30 ownership hashes of a boundary test are spread over the workgroup: it walks
     // the ids it has just written (its own stretch of the sorted list), one voxel per thread and step
@@ -413,6 +487,170 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
     if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
       atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// first-touch ownership (bnv_grid_t.shard_state): owners for the blocks this frame touches for the first time
+// ------------------------------------------------------------------------------------------
+// ONE small workgroup (256 threads, no LDS to speak of: it must find room beside the persistent MLP kernels of the
+// other streams, which leave a CU one wave slot per SIMD and little else -- the first version, 1,024 threads, sat in the
+// front stream for the whole of a table kernel in every frame); nothing to do (one load) in a frame without a new
+// block.  (1) the new blocks in ascending block order: k_rank has listed them (the first voxel that touches a block
+// appends it), a bitonic sort of that list in place -- or, when a frame brings more than the list holds (the first
+// frame of a scene), an ordered compaction of the dense weight table; (2) one wave walks them: a block that has no
+// owner yet goes to the rank with the least load so far (lowest rank on ties), a block that was pinned earlier as
+// somebody's neighbour keeps its owner, and either way its weight joins that rank's load; (3) the neighbour blocks of
+// the new blocks that still have no owner are pinned to the lattice rule; (4) the weights are cleared.  Every rank
+// runs this on the same replicated voxelisation, so every rank's table is the same -- no communication.
+__global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
+  ShardState S;
+  shard_state_layout(g.n_xyz, g.shard_block_log2, (char*)g.shard_state, &S);
+  const uint32_t n_listed = (uint32_t)S.hdr->any_new;     // (k_rank counts the new blocks in it)
+  if (n_listed == 0) return;
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t s_n;
+  const int lane = threadIdx.x & 63;
+  uint32_t n_new;
+  if (n_listed <= kNewListCap) {
+    // bitonic sort of new_list[0, n_listed) padded with ~0 to the next power of two, in global memory (L2)
+    uint32_t np2 = 1;
+    while (np2 < n_listed) np2 <<= 1;
+    for (uint32_t i = n_listed + threadIdx.x; i < np2; i += 256) S.new_list[i] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= np2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+          const uint32_t l = i ^ j;
+          if (l > i) {
+            const uint32_t a = S.new_list[i], b = S.new_list[l];
+            const bool up = (i & k) == 0;
+            if ((a > b) == up) {
+              S.new_list[i] = b;
+              S.new_list[l] = a;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    n_new = n_listed;
+  } else {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < S.n_blocks; b0 += 256) {
+      const int64_t b = b0 + threadIdx.x;
+      const uint32_t f = (b < S.n_blocks && S.blk_w[b] > 0) ? 1u : 0u;
+      uint32_t tot;
+      const uint32_t pos = block_exclusive_scan<256>(f, wave_tot, &tot);
+      const uint32_t base = s_n;
+      if (f) S.new_list[base + pos] = (uint32_t)b;
+      __syncthreads();
+      if (threadIdx.x == 0) s_n = base + tot;
+      __syncthreads();
+    }
+    n_new = s_n;
+  }
+  const int world = g.shard_world;
+  if (threadIdx.x < 64) {
+    unsigned long long load = lane < world ? S.hdr->load[lane] : 0ull;
+    for (uint32_t i0 = 0; i0 < n_new; i0 += 64) {
+      // 64 entries at a time in registers: the walk itself then touches no memory
+      const uint32_t i = i0 + lane;
+      uint32_t mb = 0, mw = 0, mt = 0;
+      if (i < n_new) {
+        mb = S.new_list[i];
+        mw = S.blk_w[mb];
+        mt = S.table[mb];
+      }
+      int mine = -1;
+      const int cnt = (int)(n_new - i0 < 64u ? n_new - i0 : 64u);
+      for (int k = 0; k < cnt; ++k) {
+        const uint32_t w = __shfl(mw, k, 64), t = __shfl(mt, k, 64);
+        int r;
+        if (t & kOwnAssigned) {
+          r = (int)(t & kOwnRank);
+        } else {
+          unsigned long long key = lane < world ? ((load << 6) | (unsigned long long)lane) : ~0ull;
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_xor(key, d, 64);
+            key = o < key ? o : key;
+          }
+          r = (int)(key & 63ull);
+        }
+        if (lane == r) load += w;
+        if (lane == k) mine = r;
+      }
+      if (i < n_new) S.table[mb] = (uint8_t)(mine | kOwnAssigned | kOwnTouched);
+    }
+    if (lane < world) S.hdr->load[lane] = load;
+  }
+  __syncthreads();
+  // every new block has its owner now; blocks around them that nobody has touched yet are pinned to the lattice rule
+  int nb3[3];
+  shard_block_dims(g.n_xyz, g.shard_block_log2, nb3);
+  for (uint64_t q = threadIdx.x; q < (uint64_t)n_new * 27u; q += 256) {
+    const uint32_t b = S.new_list[q / 27u];
+    const int d = (int)(q % 27u);
+    if (d == 13) {
+      S.blk_w[b] = 0u;   // (4)
+      continue;
+    }
+    const int bz = (int)(b % (uint32_t)nb3[2]), by = (int)((b / (uint32_t)nb3[2]) % (uint32_t)nb3[1]),
+              bx = (int)(b / ((uint32_t)nb3[2] * (uint32_t)nb3[1]));
+    const int x = bx + d / 9 - 1, y = by + (d / 3) % 3 - 1, z = bz + d % 3 - 1;
+    if ((unsigned)x >= (unsigned)nb3[0] || (unsigned)y >= (unsigned)nb3[1] || (unsigned)z >= (unsigned)nb3[2]) continue;
+    uint8_t* e = &S.table[((int64_t)x * nb3[1] + y) * nb3[2] + z];
+    if (!(*e & kOwnAssigned)) *e = (uint8_t)(shard_lattice_owner(x, y, z, world) | kOwnAssigned);   // (same value from every writer)
+  }
+  if (threadIdx.x == 0) S.hdr->any_new = 0;
+}
+
+// With the owners of the frame's blocks known: the owned-pair list of the encoder (what the mark kernel does itself
+// under the hash rule) and the exchange bound (what k_rank does itself under the hash rule).
+__global__ __launch_bounds__(256) void k_shard_own(const float* __restrict__ pts, int n_points, bnv_grid_t g,
+                                                   int32_t* __restrict__ pair_list, int32_t* __restrict__ n_pairs,
+                                                   const int32_t* __restrict__ orphan_list,
+                                                   const int32_t* __restrict__ ids,
+                                                   const int32_t* __restrict__ defer_list,
+                                                   EncCtl* __restrict__ ctl) {
+  if (pair_list) {
+    // the points the mark kernel left undecided (a corner voxel in a block without an owner at that time)
+    const int n_orph = ctl->n_orphans;
+    for (int pb = blockIdx.x; pb * 256 < n_orph; pb += gridDim.x) {   // (workgroup-uniform trip count)
+      const int o = pb * 256 + threadIdx.x;
+      const int i = o < n_orph ? orphan_list[o] : n_points;
+      bool valid = false;
+      int fx = 0, cx = 0, fy = 0, cy = 0, fz = 0, cz = 0;
+      if (i < n_points) {
+        const float x = pts[(size_t)i * 6 + 0], y = pts[(size_t)i * 6 + 1], z = pts[(size_t)i * 6 + 2];
+        valid = in_bounds(x, y, z, g);
+        if (valid) {
+          const float xn = voxel_coord(x, g.bound_min[0], g.voxel_size);
+          const float yn = voxel_coord(y, g.bound_min[1], g.voxel_size);
+          const float zn = voxel_coord(z, g.bound_min[2], g.voxel_size);
+          fx = (int)floorf(xn), cx = (int)ceilf(xn);
+          fy = (int)floorf(yn), cy = (int)ceilf(yn);
+          fz = (int)floorf(zn), cz = (int)ceilf(zn);
+        }
+      }
+      list_owned_pairs(valid, fx, cx, fy, cy, fz, cz, g, i, pair_list, n_pairs);
+      __syncthreads();   // s_cnt is reused by the next block of points
+    }
+  }
+  __shared__ int s_hist[64];
+  if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  // the touched voxels whose boundary test k_rank had to leave open
+  const int64_t n = ctl->n_deferred;
+  const int nyz = g.n_xyz[1] * g.n_xyz[2];
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) {
+    const int id = ids[defer_list[q]];
+    const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
+    if (shard_is_boundary(x, y, z, g)) atomicAdd(&s_hist[voxel_owner(x, y, z, g) & 63], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
+    atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
 }
 
 struct ValidFlags {  // 1 where the voxel in slot s is emitted
@@ -1458,6 +1696,8 @@ __global__ __launch_bounds__(kFinTile) void k_finalize(
       counters->reserved[0] = counters->reserved[1] = counters->reserved[2] = 0;
       ctl->error = 0;
       ctl->n_pairs = 0;
+      ctl->n_orphans = 0;
+      ctl->n_deferred = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) ctl->shard_boundary[threadIdx.x] = 0;
     return;
@@ -1519,6 +1759,8 @@ __global__ __launch_bounds__(kFinTile) void k_finalize(
         ctl->n_unique = 0;
         ctl->error = 0;
         ctl->n_pairs = 0;
+        ctl->n_orphans = 0;
+        ctl->n_deferred = 0;
       }
       ctl->shard_boundary[threadIdx.x] = 0;
     }
@@ -1690,11 +1932,27 @@ int bnv_encode_workspace_reset(void* ws, size_t ws_bytes, bnv_stream_t stream) {
 // ---- encode in two halves.  begin = voxelise (bounds mask, 8 corner voxels, bitmap) + sorted-unique (rank);
 // finish = PointNet + scatter-mean + min-points filter + ordered compaction.  Everything between the two lives in
 // the workspace; bnv_encode_pointcloud is begin + finish.
-static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, hipStream_t stream) {
+static bool tcnn_blocks(const bnv_grid_t& g);
+
+// rank (sorted-unique); under first-touch ownership then: owners for the frame's new blocks, the owned-pair list and
+// the exchange bound (`pts`: the frame's input_pts rows)
+static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, const float* pts, int n_points, hipStream_t stream) {
   const int nb_chunks = (int)((ws.n_chunks + kRankTile - 1) / kRankTile);
   hipLaunchKernelGGL(k_rank, dim3(nb_chunks), dim3(kScanThreads), 0, stream, ws.bytemap, ws.chunk_flag, ws.n_chunks,
-                     ws.tile_state, next_epoch(), ws.bitmap, ws.word_prefix, ws.ids, ws.max_unique, ws.ctl, g);
+                     ws.tile_state, next_epoch(), ws.bitmap, ws.word_prefix, ws.ids, ws.max_unique, ws.ctl, g,
+                     ws.defer_list);
   BNV_LAUNCH_CHECK();
+  if (g.shard_world > 1 && g.shard_state) {
+    hipLaunchKernelGGL(k_shard_assign, dim3(1), dim3(256), 0, stream, g);
+    BNV_LAUNCH_CHECK();
+    // (a frame without a new block leaves it nothing to do: a small grid that strides, not a workgroup per 256 points)
+    const int nb = (n_points + 255) / 256;
+    const int cap = 64;
+    hipLaunchKernelGGL(k_shard_own, dim3(nb < cap ? (nb > 0 ? nb : 1) : cap), dim3(256), 0, stream, pts, n_points, g,
+                       tcnn_blocks(g) ? (int32_t*)nullptr : ws.pair_list, &ws.ctl->n_pairs, ws.orphan_list, ws.ids,
+                       ws.defer_list, ws.ctl);
+    BNV_LAUNCH_CHECK();
+  }
   return BNV_OK;
 }
 
@@ -1712,6 +1970,13 @@ static bool grid_ok(const bnv_grid_t& g) {
 
 size_t bnv_encode_shard_counts_offset(void) { return offsetof(EncCtl, shard_boundary); }
 
+size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2) {
+  if (!n_xyz || block_log2 < 0 || block_log2 > 8) return 0;
+  return shard_state_layout(n_xyz, block_log2, nullptr, nullptr);
+}
+size_t bnv_shard_state_loads_offset(void) { return offsetof(ShardHdr, load); }
+size_t bnv_shard_state_table_offset(void) { return kShardHdrBytes; }
+
 int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host, void* ws_ptr,
                      size_t ws_bytes, int64_t ws_max_points, bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
@@ -1728,9 +1993,10 @@ int bnv_encode_begin(const float* input_pts, int64_t n_points, const bnv_grid_t*
   const int n = (int)n_points;
   hipLaunchKernelGGL(k_mark, dim3((n + 255) / 256), dim3(256), 0, stream, input_pts, n, g, ws.bytemap, ws.chunk_flag,
                      ws.valid_blocks,
-                     (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs,
+                     g.shard_state ? ws.orphan_list : (int32_t*)nullptr, &ws.ctl->n_orphans);
   BNV_LAUNCH_CHECK();
-  return encode_rank(ws, g, stream);
+  return encode_rank(ws, g, input_pts, n, stream);
 }
 
 int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, const double* intr_host,
@@ -1749,9 +2015,11 @@ int bnv_encode_begin_depth(const void* depth, int depth_dtype, int H, int W, con
   front_args_fill(a, depth, depth_dtype, H, W, intr_host, T_wc_host, max_depth);
   const int64_t n = (int64_t)H * W;
   hipLaunchKernelGGL(k_front_mark, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, out_pts, g, ws.bytemap,
-                     ws.chunk_flag, ws.valid_blocks, (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs);
+                     ws.chunk_flag, ws.valid_blocks,
+                     (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (int32_t*)nullptr, &ws.ctl->n_pairs,
+                     g.shard_state ? ws.orphan_list : (int32_t*)nullptr, &ws.ctl->n_orphans);
   BNV_LAUNCH_CHECK();
-  return encode_rank(ws, g, stream);
+  return encode_rank(ws, g, out_pts, (int)n, stream);
 }
 
 int bnv_encode_finish(const float* input_pts, int64_t n_points, const bnv_grid_t* grid_host,

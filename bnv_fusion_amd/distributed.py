@@ -33,6 +33,9 @@ import torch
 from . import _lib
 
 BLOCK_LOG2 = 3
+# ownership rule of HipShardBackend when the caller names none: "first_touch" (a per-block owner table kept on the
+# device, new blocks go to the least-loaded rank: max / mean load 1.0x) or "hash" (mix64(block) % world: 1.11-1.16)
+DEFAULT_OWNERSHIP = "first_touch"
 REC_WORDS = 12          # BNV_SHARD_RECORD_BYTES / 4: {x, y, z, weight bits, 8 feature bits}
 REC_QUANTUM = 512       # the per-rank block capacity is rounded up to this many records
 
@@ -48,11 +51,25 @@ def mix64(k):
     return (k & np.uint64(0xFFFFFFFF)).astype(np.uint64)
 
 
-def voxel_owner(coords, world, block_log2=BLOCK_LOG2):
-    """Host restatement of csrc/bnv_common.hpp voxel_owner: coords [n, 3] int -> rank [n]."""
+def lattice_owner(blocks, world):
+    """The rule that pins blocks nobody has touched yet (csrc/bnv_common.hpp: shard_lattice_owner)."""
+    b = np.asarray(blocks, dtype=np.int64)
+    return (b[:, 0] + 5 * b[:, 1] + 7 * b[:, 2]) % world
+
+
+def voxel_owner(coords, world, block_log2=BLOCK_LOG2, table=None, n_xyz=None):
+    """Host restatement of csrc/bnv_common.hpp voxel_owner: coords [n, 3] int -> rank [n].  ``table`` (with ``n_xyz``):
+    the first-touch owner table of a shard (HipShardBackend.owner_table()): -1 outside the grid / without an owner."""
     c = np.asarray(coords, dtype=np.int64)
     if world <= 1:
         return np.zeros(len(c), dtype=np.int64)
+    if table is not None:
+        n = np.asarray(n_xyz, dtype=np.int64)
+        nb = (n + (1 << block_log2) - 1) >> block_log2
+        inside = ((c >= 0) & (c < n)).all(1)
+        b = np.where(inside[:, None], c, 0) >> block_log2
+        t = np.asarray(table).reshape(-1)[(b[:, 0] * nb[1] + b[:, 1]) * nb[2] + b[:, 2]].astype(np.int64)
+        return np.where(inside & ((t & 0x40) != 0), t & 0x3f, -1)
     b = (c >> block_log2).astype(np.uint64) & np.uint64(0xFFFFFFFF)
     key = (b[:, 0] << np.uint64(42)) | (b[:, 1] << np.uint64(21)) | b[:, 2]
     return (mix64(key) % np.uint64(world)).astype(np.int64)
@@ -61,23 +78,28 @@ def voxel_owner(coords, world, block_log2=BLOCK_LOG2):
 _OFF27 = np.array([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)], dtype=np.int64)
 
 
-def shard_is_boundary(coords, world, block_log2=BLOCK_LOG2):
+def shard_is_boundary(coords, world, block_log2=BLOCK_LOG2, table=None, n_xyz=None):
     """Host restatement of csrc/bnv_common.hpp shard_is_boundary: does a voxel of the 3x3x3 neighbourhood belong to
     another rank?  coords [n, 3] -> bool [n]."""
     c = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
-    me = voxel_owner(c, world, block_log2)
+    me = voxel_owner(c, world, block_log2, table, n_xyz)
     out = np.zeros(len(c), dtype=bool)
     for d in _OFF27:
-        out |= voxel_owner(c + d, world, block_log2) != me
+        o = voxel_owner(c + d, world, block_log2, table, n_xyz)
+        if table is None:
+            out |= o != me
+        else:       # first-touch rule: neighbours outside the grid hold no voxel and do not count
+            inside = ((c + d >= 0) & (c + d < np.asarray(n_xyz, dtype=np.int64))).all(1)
+            out |= inside & (o != me)
     return out
 
 
-def shard_adjacent_to(coords, world, rank, block_log2=BLOCK_LOG2):
+def shard_adjacent_to(coords, world, rank, block_log2=BLOCK_LOG2, table=None, n_xyz=None):
     """Host restatement of shard_adjacent_to: does ``rank`` own a voxel of the 3x3x3 neighbourhood (itself included)?"""
     c = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
     out = np.zeros(len(c), dtype=bool)
     for d in _OFF27:
-        out |= voxel_owner(c + d, world, block_log2) == rank
+        out |= voxel_owner(c + d, world, block_log2, table, n_xyz) == rank
     return out
 
 
@@ -112,17 +134,27 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership="hash"):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None):
         from .sparse_volume import SparseVolume, make_grid
-        if ownership not in ("hash",):
+        import os
+        ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
+        if ownership not in ("hash", "first_touch"):
             raise ValueError(f"unknown ownership rule {ownership!r}")
         self.ownership = ownership
         self.pointnet = pointnet
         self.rank, self.world = rank, world
-        pointnet.shard = (rank, world, BLOCK_LOG2)
         self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
         v = self.volume
-        v.shard = (rank, world, BLOCK_LOG2)
+        # first-touch ownership (include/bnv_fusion.h: bnv_grid_t.shard_state): the owner table lives on the device,
+        # is updated by every frame's encode and holds the same content on every rank
+        self._owner_state = None
+        if ownership == "first_touch" and world > 1:
+            n_arr = (C.c_int32 * 3)(*v._n_xyz_host)
+            nbytes = int(v._lib.bnv_shard_state_bytes(n_arr, BLOCK_LOG2))
+            self._owner_state = torch.zeros(nbytes, dtype=torch.uint8, device=v._dev)
+        self.shard = (rank, world, BLOCK_LOG2) + ((self._owner_state.data_ptr(),) if self._owner_state is not None else ())
+        pointnet.shard = self.shard
+        v.shard = self.shard
         v._grid = make_grid(v._n_xyz_host, v.min_coords, v.max_coords, voxel_size, min_pts_in_grid, v.shard)
         self.dev = v._dev
         self.max_depth = max_depth
@@ -157,7 +189,7 @@ class HipShardBackend:
     def encode(self, frame):
         """Encode stream: voxelise the whole frame (replicated), the exchange bounds to pinned memory, the point
         encoder on the pairs this rank owns, TSDF side fusion."""
-        self.pointnet.shard = (self.rank, self.world, BLOCK_LOG2)
+        self.pointnet.shard = self.shard
         pipe = self._pipe_for(frame)
         return ShardFrame(slot=pipe.begin(frame), capacity=0, blocks=None, decode=False)
 
@@ -215,11 +247,28 @@ class HipShardBackend:
         self.last_owned_pairs = int(w[W_COUNTERS + 5])      # bnv_encode_counters_t.reserved[0]
         return self.pipe.outputs(fr.slot, w, copy=self.copy_results)
 
+    def owner_table(self):
+        """The first-touch owner table (numpy uint8, one byte per block: bits 0..5 owner, bit 6 assigned, bit 7 touched)
+        and the per-rank loads (uint64 [world]) as they stand now (host copies; synchronises), or (None, None)."""
+        if self._owner_state is None:
+            return None, None
+        lib = self.volume._lib
+        st = self._owner_state.cpu().numpy()
+        n = np.asarray(self.volume._n_xyz_host, dtype=np.int64)
+        nb = (n + (1 << BLOCK_LOG2) - 1) >> BLOCK_LOG2
+        t0, l0 = int(lib.bnv_shard_state_table_offset()), int(lib.bnv_shard_state_loads_offset())
+        return st[t0: t0 + int(nb.prod())].copy(), st[l0: l0 + 8 * self.world].view(np.uint64).copy()
+
+    def owners(self, coords):
+        """Host restatement of the ownership rule in force: coords [n, 3] -> rank [n]."""
+        table, _ = self.owner_table()
+        return voxel_owner(coords, self.world, BLOCK_LOG2, table, self.volume._n_xyz_host)
+
     def owned_rows_mask(self):
         """bool [rows]: rows this rank owns (the others are ghost rows)."""
         n = self.volume.num_rows()
         c = self.volume._row_coords[:n].cpu().numpy()
-        return torch.from_numpy(voxel_owner(c, self.world) == self.rank).to(self.dev)
+        return torch.from_numpy(self.owners(c) == self.rank).to(self.dev)
 
     def last_mlp_evals(self):
         return self.volume.last_lattice_evals()
@@ -259,13 +308,14 @@ class ShardedNeuralMap:
     handles may stay uncollected (HIP backend; the oldest is collected on demand)."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None, capacity=1 << 20, tsdf=False):
+                 group=None, capacity=1 << 20, tsdf=False, ownership=None):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend or HipShardBackend(dimensions, voxel_size, pointnet, self.rank, self.world,
-                                                  min_pts_in_grid, capacity=capacity, device=device, tsdf=tsdf)
+                                                  min_pts_in_grid, capacity=capacity, device=device, tsdf=tsdf,
+                                                  ownership=ownership)
         self.volume = getattr(self.backend, "volume", None)
         self.voxel_size = voxel_size
         self.exchanged_bytes = 0          # bytes this rank has received in all-gathers (statistics)

@@ -71,6 +71,29 @@ class FrameHandle:
         return self._done
 
 
+class PipeHandle:
+    """A frame enqueued through the C frame pipeline (pipeline.FramePipe).  ``result()`` waits for that frame only."""
+
+    def __init__(self, nm, pipe, slot):
+        self._nm, self._pipe, self._slot, self._done, self._err = nm, pipe, slot, None, None
+
+    @property
+    def pending(self):
+        return self._done is None and self._err is None
+
+    def result(self):
+        if self._err is not None:
+            raise self._err
+        if self._done is None:
+            try:
+                w = self._pipe.result(self._slot)
+                self._done = self._pipe.outputs(self._slot, w, copy=self._nm.copy_results)
+            except Exception as e:
+                self._err = e
+                raise
+        return self._done
+
+
 class NeuralMap:
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, feature_vector_size=8,
                  capacity=100000, device="cuda:0", tsdf=False, truncated_units=10, sdf_delta_weight=0.1,
@@ -94,6 +117,14 @@ class NeuralMap:
         # HIP stream and overlaps the previous frame's integrate / decode kernels on the main stream
         self.overlap_encode = True
         self._enc_stream = None
+        # fuse_and_decode_async through the C frame pipeline (csrc/pipeline.hip: persistent slots, four streams -- front
+        # end / encoder / upsert + decode tables / blend -- no per-frame tensor, event or pinned allocation); False:
+        # the per-stage calls of rounds 1-3 on two streams.  Bit-identical results either way.
+        import os
+        self.frame_pipe = os.environ.get("BNV_NEURAL_MAP_PIPE", "1") != "0"
+        self.copy_results = True      # False: results are views into the pipeline's slots (valid for 2 more frames)
+        self._pipe = None
+        self._pipe_open = []
         # True: the caller guarantees that a frame's tensors are complete in device memory when it is passed in
         # (uploaded / produced and synchronised earlier), so the encode stream need not wait for the caller's stream
         self.inputs_resident = False
@@ -119,10 +150,42 @@ class NeuralMap:
         self.tsdf_vol.integrate(frame.get("rgb"), frame["depth"], frame["intr_mat"], frame["T_wc"], obs_weight=1.,
                                 max_depth=self.max_depth, gate=gate)
 
+    def _drain_pipe(self):
+        """Collects every frame still in the frame pipeline (their side streams also write the TSDF volume)."""
+        while self._pipe_open:
+            h = self._pipe_open.pop(0)
+            if h.pending:
+                h.result()
+
+    def _pipe_frame(self, frame, decode):
+        from .pipeline import FramePipe
+        n = int(frame["input_pts"].shape[1]) if "input_pts" in frame else int(frame["depth"].shape[-2] * frame["depth"].shape[-1])
+        if self._pipe is None or self._pipe.max_points < n or self._pipe.pointnet is not self.pointnet \
+                or self._pipe.tsdf_vol is not self.tsdf_vol:
+            self._drain_pipe()
+            self._pipe = FramePipe(self.volume, self.pointnet, n, n_slots=4, tsdf_vol=self.tsdf_vol,
+                                   max_depth=self.max_depth)
+        pipe = self._pipe
+        pipe.inputs_resident, pipe.sdf_delta = self.inputs_resident, self.sdf_delta
+        self._pipe_open = [h for h in self._pipe_open if h.pending]
+        while pipe.free_slot() is None:                 # every slot holds an uncollected frame: collect the oldest
+            self._pipe_open.pop(0).result()
+        if self._vol_ev is not None:                    # a synchronous integrate()'s TSDF update on the caller's stream
+            pipe.enc.wait_event(self._vol_ev)
+            self._vol_ev = None
+        with torch.no_grad():
+            slot = pipe.begin(frame)
+            pipe.upsert(slot, decode=decode)
+            pipe.finish(slot)
+        h = PipeHandle(self, pipe, slot)
+        self._pipe_open.append(h)
+        return h
+
     def integrate(self, frame):
         """run_e2e.py:78-98.  frame['input_pts'] : [1, N, 6] float32 on the GPU (or a depth frame, see
         frame_input_pts).
         Returns the voxel coordinates the frame touched ([U', 3] int64) or None."""
+        self._drain_pipe()
         input_pts = frame_input_pts(frame, self.max_depth)
         if len(input_pts) == 0:
             return None
@@ -171,6 +234,10 @@ class NeuralMap:
         queued before frame t + 1's upsert / decode front end runs (+5 % frames/s, bench.py) -- to keep the GPU busy
         (``result()`` also settles the frame's row reservation and raises on a device-side upsert error).  Any number
         of uncollected frames gives the synchronous results bit for bit."""
+        if self.frame_pipe and self.overlap_encode and not self.pointnet.dense_volume and not (
+                "input_pts" not in frame and frame["depth"].dtype == torch.float64 and self.tsdf_vol is not None):
+            return self._pipe_frame(frame, decode)
+        self._drain_pipe()
         with torch.no_grad():
             v = self.volume
             main = torch.cuda.current_stream()
@@ -230,6 +297,7 @@ class NeuralMap:
         png in DataLoader workers, fusion_inference_dataset.py:329-420).  Defaults are the values of
         fusion_pointnet_model.yaml / fusion_inference_dataset.yaml."""
         from .optimize import optimize_volume, sample_key_frame
+        self._drain_pipe()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         lo = 0 if last_frame == -1 else last_frame
         cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
@@ -248,12 +316,14 @@ class NeuralMap:
 
     def extract_sdf(self):
         """run_e2e.py:164-167 up to (not including) marching cubes."""
+        self._drain_pipe()
         self.volume.to_tensor()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         return self.volume.meshlize_sdf(self.pointnet.nerf, delta)
 
     def extract_mesh(self, path=None):
         """run_e2e.py:164-167: mesh of the whole volume (TSDF prior included when enabled) -> TriMesh or None."""
+        self._drain_pipe()
         delta = self.prepare_tsdf_volume() if self.tsdf_vol is not None else self.sdf_delta
         self.volume.to_tensor()
         out = self.volume.meshlize(self.pointnet.nerf, delta, path)
@@ -264,6 +334,7 @@ class NeuralMap:
         final_sparse_volume.pth (sparse_volume.py:835-860)."""
         import os
         import numpy as np
+        self._drain_pipe()
         if self.tsdf_vol is not None:
             tsdf, _ = self.tsdf_vol.get_volume()
             np.save(os.path.join(working_dir, scan_id + ".npy"), tsdf * (self.tsdf_voxel_size * 5))

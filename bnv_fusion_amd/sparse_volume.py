@@ -38,6 +38,7 @@ def make_grid(n_xyz, bound_min, bound_max, voxel_size, min_pts_in_grid, shard=(0
     g.voxel_size = float(np.float32(voxel_size))
     g.min_pts_in_grid = int(min_pts_in_grid)
     g.shard_rank, g.shard_world, g.shard_block_log2 = int(shard[0]), int(shard[1]), int(shard[2])
+    g.shard_state = int(shard[3]) if len(shard) > 3 and shard[3] else None     # first-touch owner table (device pointer)
     g.mlp_mode = 0 if mlp_mode is None else int(mlp_mode) + 1      # 0: the library's process default
     return g
 
@@ -558,10 +559,16 @@ class SparseVolume:
     def save(self, path):
         self.print_statistic()
         n = self._snapshot_rows
+
+        def stat(v):
+            # the reference's statistics are 0-d float32 device tensors once a frame has been tracked (track_n_pts
+            # is handed the encode's n_avg_pts tensor, sparse_volume.py:508-513); plain numbers before that
+            return torch.tensor(float(v), dtype=torch.float32, device=self._dev) if self.n_frames else v
+
         out_dict = {
             "25%": getattr(self, "per_25", None), "50%": getattr(self, "per_50", None),
             "75%": getattr(self, "per_75", None), "dimensions": self.dimensions,
-            "voxel_size": self.voxel_size, "mean": self.avg_n_pts, "min": self.min_pts,
+            "voxel_size": self.voxel_size, "mean": stat(self.avg_n_pts), "min": stat(self.min_pts),
             "active_keys": self.active_coordinates, "active_vals": torch.arange(n, device=self._dev)[:, None],
             "features": self.features, "weights": self.weights, "num_hits": self.num_hits,
             "active_coordinates": self.active_coordinates,

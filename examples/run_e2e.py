@@ -21,6 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bnv_fusion_amd as bnv                                   # noqa: E402
+bnv.configure_runtime()                                       # optional: 8 hardware queues for the pipelined streams
 from bnv_fusion_amd import datasets, synthetic                # noqa: E402
 
 

@@ -57,8 +57,24 @@ typedef struct bnv_grid {
    * packs are laid out for it), so callers that hold several models -- or drive the library from several host
    * threads -- state it here instead of flipping the process default around their calls. */
   int32_t mlp_mode;
+  /* Ownership rule of the sharding.  NULL: owner = hash(block coordinate) % shard_world, a pure function.  Else a
+   * device buffer of bnv_shard_state_bytes() (zeroed once, the SAME evolving content on every rank -- the kernels
+   * that update it work on the replicated voxelisation): FIRST-TOUCH ownership.  A block gets its owner in the frame
+   * that first touches it: the new blocks of a frame, in ascending block order, go one by one to the rank that carries
+   * the least load so far (load = touched voxels of a block in that frame); the 26 neighbour blocks of a newly
+   * touched block that have no owner yet are pinned at the same moment to (bx + 5 by + 7 bz) % shard_world, so that
+   * whenever a voxel is emitted every block of its 3x3x3 neighbourhood has an owner that never changes afterwards
+   * (the boundary / ghost-row tests of the exchange rely on that).  Set by bnv_encode_begin* of the frame; every other
+   * call only reads it. */
+  void* shard_state;
 } bnv_grid_t;
 #define BNV_GRID_MLP_MODE(m) ((m) + 1)
+/* Bytes of bnv_grid_t.shard_state for a grid of n_xyz voxels in blocks of (1 << block_log2)^3. */
+size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2);
+/* Byte offsets inside it: the per-rank loads (uint64[64]) and the owner table (one byte per block, index
+ * (bx * nby + by) * nbz + bz; bits 0..5 owner, bit 6 assigned, bit 7 touched), for tools and tests. */
+size_t bnv_shard_state_loads_offset(void);
+size_t bnv_shard_state_table_offset(void);
 
 /* Device-side result counters of bnv_encode_pointcloud. */
 typedef struct bnv_encode_counters {

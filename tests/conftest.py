@@ -14,6 +14,9 @@ WEIGHTS_TCNN = os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_tcnn.np
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # before any test initialises the HIP runtime: 8 hardware queues for the frame pipelines' streams
+    from bnv_fusion_amd import configure_runtime
+    configure_runtime()
 
 
 def pytest_collection_modifyitems(config, items):

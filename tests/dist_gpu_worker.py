@@ -20,9 +20,12 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
+    ap.add_argument("--ownership", default=None, choices=["hash", "first_touch"])
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import bnv_fusion_amd
+    bnv_fusion_amd.configure_runtime()
     torch.cuda.set_device(0)
     dist.init_process_group(os.environ.get("BNV_DIST_BACKEND", "gloo"))
     import bnv_fusion_amd as bnv
@@ -35,7 +38,7 @@ def main():
                "T_wc": synthetic.pose(t)} for t in range(args.frames)]
     out = {}
     if args.mode == "spatial":
-        nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True)
+        nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True, ownership=args.ownership)
         pending = None
         for t, fr in enumerate(frames):                 # pipelined: frame t is enqueued before t-1 is collected
             h = nm.fuse_and_decode_async(fr)
@@ -45,8 +48,10 @@ def main():
             pending = (t, h)
         c, s = pending[1].result()
         out[pending[0]] = (None if c is None else c.cpu(), None if s is None else s.cpu())
+        table, loads = nm.backend.owner_table()
         meta = {"host_waits": nm.host_waits, "exchanged_bytes": nm.exchanged_bytes, "rows": nm.volume.num_rows(),
-                "tsdf": nm.backend.tsdf_vol.tsdf.cpu()}
+                "tsdf": nm.backend.tsdf_vol.tsdf.cpu(), "ownership": nm.backend.ownership, "owner_table": table,
+                "owner_loads": loads}
     else:
         nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True)
         batches = [frames[b0: b0 + world] for b0 in range(0, len(frames), world)]

@@ -66,6 +66,7 @@ class Recorder:
         self.caller_owned = set()
         self.proxies = {}    # id(real object) -> name
         self.by_sha = {}     # (sha, dtype, shape) -> array key
+        self.live = {}       # ref -> the tensor object (caller-owned ones are looked at before every depth-0 call)
         self.sha_ref = {}    # sha of a tensor's data -> the ref that carried it last
 
     def store(self, a):
@@ -80,7 +81,8 @@ class Recorder:
         return out
 
     def _put(self, a):
-        a = np.ascontiguousarray(a).reshape(np.asarray(a).shape)
+        # a COPY: tensor.numpy() shares the tensor's memory, and the caller goes on changing some tensors in place
+        a = np.array(np.ascontiguousarray(a).reshape(np.asarray(a).shape), copy=True)
         h = (sha(a), str(a.dtype), a.shape)
         if h in self.by_sha:                      # the same bytes are stored once
             return self.by_sha[h]
@@ -114,6 +116,7 @@ class Recorder:
                 ref = f"t{len(self.refs)}"
                 self.refs[id(v)] = ref
                 self.keep.append(v)
+                self.live[ref] = v
             d = {"t": "tensor", "ref": ref, "param": isinstance(v, torch.nn.Parameter),
                  "requires_grad": bool(v.requires_grad), "role": "device" if getattr(v, "_was_cuda", True) else "host"}
             h = sha(a)
@@ -185,8 +188,16 @@ class Proxy:
             except (TypeError, ValueError):
                 named = {f"arg{i}": x for i, x in enumerate(a)}
                 named.update(kw)
+            # what the caller's own code did, in place, to tensors it owns since the boundary last saw them (the
+            # optimiser's step on volume.features happens between two calls without touching the boundary)
+            state = {}
+            if rec.depth == 0:
+                for ref in sorted(rec.caller_owned):
+                    d = rec.desc(rec.live[ref])
+                    if "same" not in d:
+                        state[ref] = d
             ev = rec.event(op="call", obj=name, method=k, args={n: rec.desc(x) for n, x in named.items()},
-                           positional=len(a), keywords=sorted(kw))
+                           positional=len(a), keywords=sorted(kw), caller_state=state)
             rec.depth += 1
             try:
                 ret = fn(*a, **kw)

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32"):
+def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -28,7 +28,7 @@ def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32"):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
            "--mode", mode, "--grid", str(grid), "--frames", str(frames), "--height", str(hw[0]), "--width", str(hw[1]),
-           "--checkpoint", checkpoint, "--out", str(out)]
+           "--checkpoint", checkpoint, "--out", str(out)] + (["--ownership", ownership] if ownership else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load(os.path.join(out, f"rank{k}.pt"), weights_only=False) for k in range(world)]
@@ -60,12 +60,18 @@ def single_256():
     return _single(256, 12, (240, 320))
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_spatial_sharding_processes_equal_single_gpu(tmp_path, single_512, world):
-    """BASELINE config 3 in miniature: 512^3 grid, full 640x480 frames, the active-voxel set sharded by spatial hash
-    over ``world`` processes, one all-gather of boundary records per frame."""
+@pytest.mark.parametrize("world,ownership", [(2, "first_touch"), (4, "first_touch"), (4, "hash")])
+def test_spatial_sharding_processes_equal_single_gpu(tmp_path, single_512, world, ownership):
+    """BASELINE config 3 in miniature: 512^3 grid, full 640x480 frames, the active-voxel set sharded by blocks
+    over ``world`` processes (both ownership rules), one all-gather of boundary records per frame."""
     ref, rows, tsdf, voxel = single_512
-    ranks = _launch(world, "spatial", 512, len(ref), tmp_path, (480, 640))
+    ranks = _launch(world, "spatial", 512, len(ref), tmp_path, (480, 640), ownership=ownership)
+    assert all(r["meta"]["ownership"] == ownership for r in ranks)
+    if ownership == "first_touch":      # the same table on every rank, and it levels the load
+        t0, l0 = ranks[0]["meta"]["owner_table"], ranks[0]["meta"]["owner_loads"]
+        assert all(np.array_equal(r["meta"]["owner_table"], t0) and np.array_equal(r["meta"]["owner_loads"], l0)
+                   for r in ranks)
+        assert l0.max() <= 1.05 * l0.mean(), l0
     for t, (rc, rs) in enumerate(ref):
         parts = [r["out"][t] for r in ranks]
         assert all(p[0] is not None and len(p[0]) > 0 for p in parts)              # every rank owns part of every frame
@@ -77,7 +83,7 @@ def test_spatial_sharding_processes_equal_single_gpu(tmp_path, single_512, world
         assert torch.equal(sdf[order], rs), t                                       # bit-identical SDF
     assert float((ref[-1][1] != voxel).float().mean()) > 0.05                       # and the decode is live
     sizes = [len(r["out"][len(ref) - 1][0]) for r in ranks]
-    assert max(sizes) < 1.35 * (sum(sizes) / world)                                 # the block hash balances the load
+    assert max(sizes) < (1.10 if ownership == "first_touch" else 1.35) * (sum(sizes) / world)   # the load is level
     for r in ranks:
         m = r["meta"]
         assert m["host_waits"] == len(ref)                                          # ONE host wait per frame

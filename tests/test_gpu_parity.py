@@ -464,15 +464,22 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
 # ---------------------------------------------------------------------------------------------
 # sharded volume: several shards driven phase by phase on ONE GPU (no process group needed)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("world", [2, 3])
-def test_hip_shards_equal_single_volume(bnv, model, world):
+@pytest.mark.parametrize("world,ownership,growing", [(2, "hash", False), (3, "hash", False), (2, "first_touch", False),
+                                                     (3, "first_touch", False), (3, "first_touch", True),
+                                                     (3, "hash", True)])
+def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     """``world`` shards of the spatially sharded volume driven phase by phase in ONE process (the all-gather is a
     torch.stack): encode with ownership, upsert, pack boundary records, install ghost rows, decode -- the union of
-    the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements."""
+    the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements.
+    Both ownership rules (block hash; first-touch table, include/bnv_fusion.h: bnv_grid_t.shard_state); ``growing``:
+    the surface patch drifts through the volume, so that frames keep touching blocks for the first time -- among
+    them blocks that had been pinned earlier as neighbours of touched ones."""
     from bnv_fusion_amd import distributed as D
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     dims, voxel = z["dims"], float(z["voxel_size"])
-    shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=4096, device=DEV) for r in range(world)]
+    shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=4096, device=DEV, ownership=ownership)
+              for r in range(world)]
+    n_xyz = shards[0].volume._n_xyz_host
     model.shard = (0, 1, 3)
     single = bnv.NeuralMap(dims, voxel, model, device=DEV)
     # an empty frame (no point inside the volume): bound 0 on every shard, nothing to exchange, (None, None) out
@@ -482,7 +489,15 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
         assert b.bound(f) == 0 and b.upsert(f, 0) is None
         assert b.result(b.finish(f, b.decode(f), 0)) == (None, None)
         assert b.volume.num_rows() == 0
-    for fr in z["frames"]:
+    frames_np = list(z["frames"])
+    if growing:       # the same patches, drifting 1.5 voxels per frame along x and y: 9 frames of new territory
+        frames_np = []
+        for t in range(20):
+            f = z["frames"][t % len(z["frames"])].copy()
+            f[..., 0] += 0.03 * t - 0.2
+            f[..., 1] += 0.02 * t - 0.1
+            frames_np.append(f)
+    for fr in frames_np:
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
         model.shard = (0, 1, 3)
         ref_coords, ref_sdf = single.fuse_and_decode(frame)
@@ -506,12 +521,23 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
             assert int(b.pipe.send[f.slot, 0]) == 0 and int(b.pipe.send[f.slot, 1]) == b.rank
     model.shard = (0, 1, 3)
     owned = [o[0] for o in outs]
+    table, loads = shards[0].owner_table()
+    if ownership == "first_touch":
+        # every rank holds the same table and the same loads; a block is only ever touched with an owner in place
+        for b in shards[1:]:
+            t2, l2 = b.owner_table()
+            assert np.array_equal(t2, table) and np.array_equal(l2, loads)
+        assert (table[(table & 0x80) != 0] & 0x40).all() and int(loads.sum()) > 0
+        assert loads.max() <= 1.25 * loads.mean()                      # greedy by weight: the loads stay level
+    else:
+        assert table is None
+    own_of = lambda c: D.voxel_owner(c, world, D.BLOCK_LOG2, table, n_xyz)      # noqa: E731
     for r in range(world):
-        assert np.all(D.voxel_owner(owned[r].cpu().numpy(), world) == r)   # HIP ownership hash == host restatement
+        assert np.all(own_of(owned[r].cpu().numpy()) == r)   # HIP ownership rule == host restatement
         # the records a rank sent are exactly its emitted boundary voxels (device predicate == host restatement)
         n = int(hdr[r, 0])
         sent = blocks.view(world, cap + 1, D.REC_WORDS)[r, 1: 1 + n, :3].cpu().numpy()
-        want = owned[r].cpu().numpy()[D.shard_is_boundary(owned[r].cpu().numpy(), world)]
+        want = owned[r].cpu().numpy()[D.shard_is_boundary(owned[r].cpu().numpy(), world, D.BLOCK_LOG2, table, n_xyz)]
         assert np.array_equal(sent[np.lexsort(sent.T[::-1])], want[np.lexsort(want.T[::-1])])
     coords = torch.cat(owned).cpu().numpy()
     sdf = torch.cat([o[1] for o in outs]).cpu().numpy()
@@ -525,8 +551,9 @@ def test_hip_shards_equal_single_volume(bnv, model, world):
         b.volume.to_tensor()
         own = b.owned_rows_mask().cpu().numpy()
         k = b.volume.active_coordinates.cpu().numpy()
-        assert np.all(D.voxel_owner(k[own], world) == r) and np.all(D.voxel_owner(k[~own], world) != r)
-        assert D.shard_adjacent_to(k[~own], world, r).all() and (~own).sum() > 0
+        assert np.all(own_of(k[own]) == r) and np.all(own_of(k[~own]) != r)
+        assert np.all(own_of(k) >= 0)                                    # every row's block has an owner
+        assert D.shard_adjacent_to(k[~own], world, r, D.BLOCK_LOG2, table, n_xyz).all() and (~own).sum() > 0
         f1, w1, _ = single.volume.query(b.volume.active_coordinates)
         assert torch.equal(f1, b.volume.features) and torch.equal(w1, b.volume.weights)
 

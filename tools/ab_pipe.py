@@ -4,6 +4,7 @@ kernel timings.  Usage: ab_pipe.py [mlp_mode]"""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib
 dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)

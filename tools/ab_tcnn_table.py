@@ -3,6 +3,7 @@ patch -- time of the whole encode (HIP events on one stream) and bit-identity of
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib
 dev = "cuda:0"
 dims, voxel = synthetic.GRID_DIMS[256]

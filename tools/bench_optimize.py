@@ -10,6 +10,7 @@ import torch
 
 sys.path.insert(0, ".")
 import bnv_fusion_amd as bnv  # noqa: E402
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import optimize, synthetic  # noqa: E402
 
 DEV = "cuda:0"

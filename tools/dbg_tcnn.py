@@ -1,6 +1,7 @@
 import sys, os, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from oracle import bnv_oracle as orc
 DEV="cuda:0"
 z = np.load("tests/golden/sequence_64.npz")

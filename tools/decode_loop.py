@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import sequence, synthetic
 
 which = sys.argv[1] if len(sys.argv) > 1 else "sweep"

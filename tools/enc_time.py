@@ -5,6 +5,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib
 dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)

@@ -5,6 +5,7 @@ import argparse, socket, sys, time
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic
 from bnv_fusion_amd.distributed import FrameParallelNeuralMap
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); ap.add_argument("--replay", type=int, default=1); ap.add_argument("--ahead", type=int, default=3); ap.add_argument("--reserve", type=int, default=0); ap.add_argument("--split", action="store_true"); args = ap.parse_args()

@@ -3,6 +3,7 @@ queue (no back-pressure from the GPU), repeated; and the split by call (cProfile
 import sys, time, numpy as np, torch, cProfile, pstats
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic
 dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)

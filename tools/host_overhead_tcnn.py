@@ -4,6 +4,7 @@ import sys, time, numpy as np, torch
 from collections import deque
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic
 dims, voxel = synthetic.GRID_DIMS[256]
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)} for t in range(94)]

@@ -66,7 +66,12 @@ with open(f"{dst}/{R}_pmc_summary.csv", "w") as f:
                 f.write(f"\"{k}\",{c},{sum(x)/len(x):.6e},{len(x)}\n")
                 pm[(k, c)] = sum(x) / len(x)
 commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-json.dump({"commit": commit, "command": "python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe",
+# the source the PMC passes saw (written on the GPU box by run_profiles.sh): bench.py drops the traffic figure when
+# csrc/decode.hip no longer is that file
+sha_path = f"{src}/decode_hip.sha256"
+decode_sha = open(sha_path).read().split()[0] if os.path.exists(sha_path) else None
+json.dump({"commit": commit, "decode_hip_sha256": decode_sha,
+           "command": "python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe",
            "mlp_evals_per_launch": dp["roofline"]["mlp_evals_per_launch"], "dominant_kernel_trace": tail},
           open(f"{dst}/{R}_pmc_meta.json", "w"))
 

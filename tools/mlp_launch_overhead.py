@@ -8,6 +8,7 @@ import argparse, ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib
 
 ap = argparse.ArgumentParser()

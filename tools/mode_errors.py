@@ -1,6 +1,7 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 G = "tests/golden/"
 DEV = "cuda:0"
 for mode in (1, 3):

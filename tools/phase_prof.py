@@ -14,6 +14,7 @@ import torch
 sys.path.insert(0, ".")
 os.environ.setdefault("BNV_FUSION_LIB", os.path.abspath("tools/libbnv_phase_prof.so"))
 import bnv_fusion_amd as bnv  # noqa: E402
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib  # noqa: E402
 
 NAMES = {0: "tile top (requests)", 18: "-", 1: "L0 mfma", 2: "barrier", 3: "L0 store + stage next inputs",

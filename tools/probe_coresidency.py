@@ -3,6 +3,7 @@ decoder T)?  Enqueue the big kernel on stream A, then a 1 MB fill (4 VGPRs) on s
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic
 dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)

@@ -2,6 +2,7 @@ import os, sys, socket
 sys.path.insert(0, os.getcwd())
 import torch, torch.distributed as dist
 import bnv_fusion_amd
+bnv_fusion_amd.configure_runtime()
 from bnv_fusion_amd import _lib, streams
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]

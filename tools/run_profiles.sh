@@ -5,6 +5,7 @@ set -u
 R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
+sha256sum bnv_fusion_amd/csrc/decode.hip > $O/decode_hip.sha256
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # the default workload (50 steps, 5 warm-up), single stream, so that per-launch PMC figures match the default bench line
 BENCH="python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe"

@@ -17,6 +17,7 @@ import argparse, ctypes as C, gc, os, socket, sys, time
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic, _lib
 from bnv_fusion_amd import distributed as D
 

@@ -4,6 +4,7 @@ import sys
 import numpy as np, torch
 sys.path.insert(0, '.')
 import bnv_fusion_amd as bnv
+bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (streams.py)
 from bnv_fusion_amd import synthetic
 dev = "cuda:0"
 dims, voxel = synthetic.GRID_DIMS[256]
