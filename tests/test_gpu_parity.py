@@ -490,13 +490,17 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
         assert b.result(b.finish(f, b.decode(f), 0)) == (None, None)
         assert b.volume.num_rows() == 0
     frames_np = list(z["frames"])
-    if growing:       # the same patches, drifting 1.5 voxels per frame along x and y: 9 frames of new territory
-        frames_np = []
-        for t in range(20):
-            f = z["frames"][t % len(z["frames"])].copy()
-            f[..., 0] += 0.03 * t - 0.2
-            f[..., 1] += 0.02 * t - 0.1
-            frames_np.append(f)
+    if growing:       # a STATIC surface seen through a window that drifts 1.5 / 1 voxels per frame along x / y: every
+        frames_np = []    # frame brings new territory, and a voxel stays in view long enough to go live (weight >= 8)
+        g = torch.Generator().manual_seed(5)
+        for t in range(30):
+            n = 6000
+            xy = (torch.rand(n, 2, generator=g) - 0.5) * 0.4 + torch.tensor([0.03 * t - 0.35, 0.02 * t - 0.25])
+            zz = 0.12 * torch.sin(xy[:, 0] * 6) * torch.cos(xy[:, 1] * 5) + 0.003 * torch.randn(n, generator=g)
+            nrm = torch.stack([-0.72 * torch.cos(xy[:, 0] * 6) * torch.cos(xy[:, 1] * 5),
+                               0.6 * torch.sin(xy[:, 0] * 6) * torch.sin(xy[:, 1] * 5), torch.ones(n)], -1)
+            nrm = torch.nn.functional.normalize(nrm, dim=-1)
+            frames_np.append(torch.cat([xy, zz[:, None], nrm], -1).float()[None].numpy())
     for fr in frames_np:
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
         model.shard = (0, 1, 3)

@@ -462,3 +462,29 @@ def test_tcnn_packs_match_oracle_restatement():
     got = _emulate_tcnn(halves, 2, xp, 1)
     ref = orc.tcnn_mlp(torch.from_numpy(z["nerf.model.params"]), torch.from_numpy(x), 32, 1).numpy()
     assert np.abs(got - ref).max() < 4e-3
+
+
+def test_split_f16_precision_over_a_log_sweep():
+    """The hi / lo split of the split-operand MLP modes (csrc/bnv_common.hpp: split8_f16; hi = rn16(x), lo = rn16(x - hi))
+    against float64 on a log-spaced sweep, restated in numpy (the device form is bit-identical to this C++ form,
+    tools/probe_split_mix.hip).  What the split carries: x - (hi + lo) is bounded by 2^-22 |x| while lo is a NORMAL
+    f16 number, i.e. for |x| >= 2^-3 -- 22 significant bits; below that lo = x - hi falls under 2^-14 and is an
+    f16 SUBNORMAL (kept by gfx950's f16 MFMA), whose spacing is 2^-24 whatever its size: the error is then absolute,
+    <= 2^-25, so a weight of 0.05 is carried to ~20.6 bits and one of 0.001 to ~15.  Values below 2^-25 in magnitude
+    can lose everything but hi.  (DESIGN.md section 3.3 states exactly this.)"""
+    x = np.concatenate([np.logspace(-8, np.log10(6.0e4), 20001), -np.logspace(-8, np.log10(6.0e4), 20001)])
+    x = x.astype(np.float32).astype(np.float64)               # the operands are fp32 values
+    hi = x.astype(np.float32).astype(np.float16)
+    lo = (x.astype(np.float32) - hi.astype(np.float32)).astype(np.float16)        # x - hi is exact in fp32
+    assert np.isfinite(hi).all() and np.isfinite(lo).all()
+    err = np.abs(x - (hi.astype(np.float64) + lo.astype(np.float64)))
+    big = np.abs(x) >= 2.0 ** -3
+    assert (err[big] <= 2.0 ** -22 * np.abs(x[big])).all()                   # lo normal: 11 + 11 significant bits
+    assert (err[~big] <= 2.0 ** -25).all()                                   # lo subnormal: absolute, half its spacing
+    # the bound is attained in order of magnitude on both sides (this is not a loose statement)
+    assert (err[big] / np.abs(x[big])).max() > 2.0 ** -25 and err[~big].max() > 2.0 ** -27
+    # significant bits carried at typical magnitudes
+    bits = lambda v: float(-np.log2(err[np.isclose(np.abs(x), v, rtol=0.02)].max() / v))   # noqa: E731
+    assert bits(1.0) >= 22.0 and 20.0 <= bits(0.05) <= 21.5 and 14.5 <= bits(0.001) <= 16.0
+    # the f16 range guard of the modes is about hi: beyond 65,504 it overflows (tests/test_gpu_range_guard.py)
+    assert np.isinf(np.float32(7.0e4).astype(np.float16))

@@ -181,6 +181,11 @@ def price(rank, latency):
               + "  ('simulate' = this tool's stand-in for the other ranks' blocks, not part of a real rank's frame)")
         print(f"  MLP kernels (HIP events, overlapping streams): point encoder {out['enc_ms']:.3f} ms, "
               f"lattice table {out['tab_ms']:.3f} ms")
+        pp = be.pipe
+        print("  pipeline streams verified concurrent with the main stream and with one another: " + ", ".join(
+            f"{n} {getattr(st, 'bnv_concurrent', None)}" for n, st in (("encode", pp.enc), ("front", pp.front),
+                                                                     ("blend", pp.blend), ("table", pp.table)) if st is not None)
+              + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
         if args.trace:
