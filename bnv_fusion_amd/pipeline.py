@@ -278,6 +278,22 @@ class FramePipe:
         c = self.grid_ids[slot, :n_out]
         s = self.sdf[slot, :n_out] if self._decode[slot] else None
         if copy:
-            c = c.clone()
-            s = None if s is None else s.clone()
+            # The copies run on the stream the frame's last kernels ran on (they are through: result() has waited),
+            # not on the caller's, which may hold several later frames' work; and the slot -- free again for begin() --
+            # is not written before they are done: the stream of a frame's FIRST kernel waits for them.  (Cloning on
+            # the caller's stream let the next frame's encode, a frame or two ahead on its own streams, overwrite the
+            # slot first.)
+            cur = torch.cuda.current_stream(self.dev)
+            side = self.blend or self.main
+            with torch.cuda.stream(side):
+                c = c.clone()
+                s = None if s is None else s.clone()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            (self.front or self.enc).wait_event(ev)
+            if side.cuda_stream != cur.cuda_stream:
+                cur.wait_event(ev)
+                c.record_stream(cur)
+                if s is not None:
+                    s.record_stream(cur)
         return c, s

@@ -11,7 +11,7 @@
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = f"{root}/gpurun_out/{R}"
 dst = f"{root}/profiles"
 
@@ -35,7 +35,8 @@ dt = last_json(f"{src}/bench_line_tcnn.json")
 dp = last_json(f"{src}/trace_stdout.log")
 for name, obj in (("bench_line", d), ("bench_line_tcnn", dt), ("bench_line_profiled_run", dp)):
     open(f"{dst}/{R}_{name}.json", "w").write(json.dumps(obj) + "\n")
-for t in ("spatial_world8", "spatial_world8_2inflight", "spatial_world8_tcnn", "spatial_world2", "fp_replay8", "queue_probe",
+for t in ("spatial_world8", "spatial_world8_all_ranks_256", "spatial_world8_all_ranks_512", "spatial_world8_all_ranks_256_hash",
+          "spatial_world8_r03_schedule", "spatial_world8_tcnn", "spatial_world2", "fp_replay8", "queue_probe",
           "mlp_launch_overhead"):
     if os.path.exists(f"{src}/{t}.txt"):
         import re
@@ -143,7 +144,12 @@ with open(f"{dst}/{R}_README.md", "w") as f:
             W(f"* `{R}_bench_line_grid{G}.json` -- `python bench.py --grid {G}` (voxel {dg['config']['voxel_size']}): {dg['value']:.1f} frames/s, {dg['config']['voxels_per_frame']:.0f} voxels decoded per frame, parity on {dg['parity']['voxels_checked']} voxels {dg['parity']['sdf_max_abs_err_vs_oracle']:.1e}, mask decisions equal: {dg['parity']['mask_decisions_equal']}.\n")
     W(f"* `{R}_bench_kernel_stats.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe` (the default workload: 30 fuse-only pre-roll frames + 55 fuse+decode frames; one stream, so every kernel's duration is its own).  `{R}_bench_line_profiled_run.json` is the line that very run printed: its HIP-event average for the dominant kernel (the last {tail.get('n', 0)} launches: the kernel-alone pass behind its pre-heat frames) is {dp['roofline']['avg_kernel_ms']:.3f} ms; rocprofv3's kernel trace over the same {tail.get('n', 0)} launches: **{tail.get('last_ms', 0):.3f} ms**; the table's {kt[lat]/1e6:.3f} ms averages all {tail.get('launches', 0)} launches of the run, whose first {tail.get('n', 0)} (idle GPU) take {tail.get('first_ms', 0):.3f} ms -- the package heats up and the clock settles ~20 % lower.\n")
     W(f"* `{R}_pmc_summary.csv` (+ `{R}_pmc_meta.json`: commit and MLP evaluations per launch of the profiled run) -- three separate `rocprofv3 --pmc ... --kernel-trace` passes of that command (SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA | FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE), mean per launch.\n")
-    W(f"* `{R}_spatial_world8.txt` (3 frames in flight), `{R}_spatial_world8_2inflight.txt`, `{R}_spatial_world8_tcnn.txt`, `{R}_spatial_world2.txt` -- `tools/spatial_single_rank.py`: the spatially sharded mode through the product path (C frame pipeline) as rank 0 of a simulated world: wall clock per frame, host time by phase, host waits; `{R}_fp_replay8.txt` -- `tools/fp_single_rank.py --replay 8`: the frame-parallel mode's per-batch work of one rank of 8.\n")
+    def tail_of(name, n=3):
+        pth = f"{dst}/{R}_{name}.txt"
+        return " | ".join(l.strip() for l in open(pth).read().splitlines()[-n:]) if os.path.exists(pth) else "(not collected)"
+    W(f"* `{R}_spatial_world8_all_ranks_256.txt`, `{R}_spatial_world8_all_ranks_512.txt` -- `tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000`: the spatially sharded frame through the product path (C frame pipeline, four streams, first-touch ownership) priced on EVERY rank of a simulated world of 8, 2,000 frames per rank (sustained), with each rank's voxels / pairs / MLP evaluations; the rank set runs at the pace of its slowest rank.  256^3: {tail_of('spatial_world8_all_ranks_256')}.  512^3: {tail_of('spatial_world8_all_ranks_512')}.\n")
+    W(f"* `{R}_spatial_world8_all_ranks_256_hash.txt` -- the same with the block-hash ownership of rounds 2-3: {tail_of('spatial_world8_all_ranks_256_hash')}.  `{R}_spatial_world8_r03_schedule.txt` -- rank 0 with round 3's schedule (two streams, the host waits for a frame's bound before it enqueues the next encode, block hash), 2,000 frames: {tail_of('spatial_world8_r03_schedule', 1) if False else ''}see the file.\n")
+    W(f"* `{R}_spatial_world8.txt` (rank 0, 200 frames from an idle GPU + the latency of one frame at a time), `{R}_spatial_world8_tcnn.txt` (tiny-cuda-nn networks, 2,000 frames), `{R}_spatial_world2.txt` (world 2, both ranks); `{R}_fp_replay8.txt` -- `tools/fp_single_rank.py --replay 8`: the frame-parallel mode's per-batch work of one rank of 8.\n")
     if os.path.exists(f"{src}/bench_line_2rank_gloo.json") and os.path.getsize(f"{src}/bench_line_2rank_gloo.json") > 10:
         d2 = last_json(f"{src}/bench_line_2rank_gloo.json")
         open(f"{dst}/{R}_bench_line_2rank_gloo_functional.json", "w").write(json.dumps(d2) + "\n")

@@ -2,7 +2,7 @@
 # Collects everything profiles/<round>_* is built from (run on the GPU box through gpurun; tools/make_profiles.py then
 # builds the committed summaries from gpurun_out/).  Kernel trace and PMC passes are separate runs, as the pool requires.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 sha256sum bnv_fusion_amd/csrc/decode.hip > $O/decode_hip.sha256
@@ -23,10 +23,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tcnn -o bench -
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_tcnn_w -o p -- $BENCHT > $O/pmc_tcnn_w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_tcnn_f -o p -- $BENCHT > $O/pmc_tcnn_f.log 2>&1
 F="RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids"
+# the spatially sharded frame priced on EVERY rank of a simulated world of 8 (sustained: 2,000 frames per rank),
+# at 256^3 and at 512^3, with both ownership rules; then single ranks of other configurations
+python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256.txt
+python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-flight 3 --grid 512 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512.txt
+python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-flight 3 --ownership hash 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_hash.txt
 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world8.txt
-python3 tools/spatial_single_rank.py --world 8 --in-flight 2 2>&1 | grep -v "$F" > $O/spatial_world8_2inflight.txt
-python3 tools/spatial_single_rank.py --world 2 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world2.txt
-python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --checkpoint tcnn 2>&1 | grep -v "$F" > $O/spatial_world8_tcnn.txt
+BNV_PIPE_STREAMS=2 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --ahead 0 --ownership hash --frames 2000 2>&1 | grep -v "$F" > $O/spatial_world8_r03_schedule.txt
+python3 tools/spatial_single_rank.py --world 2 --all-ranks --frames 1000 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world2.txt
+python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --frames 2000 --checkpoint tcnn 2>&1 | grep -v "$F" > $O/spatial_world8_tcnn.txt
 GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/queue_probe.txt
 python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_sp8 -o sp8 -- python3 tools/spatial_single_rank.py --world 8 --frames 300 > $O/trace_sp8_stdout.log 2>&1
