@@ -1886,7 +1886,6 @@ struct LatticeWs {
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
   int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
-  float* snap;        // [row_capacity][8] the feature rows the call's table entries read, as the marking kernel found them
   int64_t list_capacity;
   int64_t entry_capacity;
 };
@@ -1906,7 +1905,6 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   char* tb = take(row_capacity * 27 * 4);
   char* nm = take(row_capacity * 4);
   char* os = take(row_capacity * 4);
-  char* sn = take(row_capacity * 8 * 4);
   char* nl = take(256);
   char* nb = take(n * 27 * 4);
   char* li = take(cap * 4);
@@ -1917,7 +1915,6 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
     ws->need_mask = (uint32_t*)nm;
     ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
-    ws->snap = (float*)sn;
     ws->entry_capacity = ecap;
     ws->stamp = (int32_t*)st;
     ws->table = (float*)tb;
@@ -2040,21 +2037,7 @@ struct MarkFused {
   int64_t row_limit;
   float min_pts;
   int32_t* nbr_rows_out;
-  // Snapshot (both null: none): the feature row of every row that gets a table entry is copied to snap[row] -- the
-  // table MLP then reads the snapshot, and the volume is free for the NEXT frame's upsert while it runs (the frame
-  // pipeline puts the table kernel on a stream of its own).  Every entry of a row that is an origin of the call is
-  // appended by that origin's threads, so its centre point's thread copies the row; entries in other rows (the
-  // fringe) are copied by whoever appends them (the same bytes from every writer).
-  const float* feat_src;
-  float* feat_snap;
 };
-
-__device__ __forceinline__ void snap_row(const MarkFused& F, int row) {
-  const f32x4* s4 = (const f32x4*)(F.feat_src + (size_t)row * 8);
-  f32x4* d4 = (f32x4*)(F.feat_snap + (size_t)row * 8);
-  d4[0] = s4[0];
-  d4[1] = s4[1];
-}
 
 template <bool FUSED>
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
@@ -2157,7 +2140,6 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         xo |= s_ob[w + 1] << (64 - sh);
       }
       const uint32_t um = (uint32_t)xu & 0x7FFFFFFu, om = (uint32_t)xo & 0x7FFFFFFu, need = s_need[p];
-      if (F.feat_snap && p == 13 && nb27[13] >= 0) snap_row(F, nb27[13] & ~kOriginBit);   // the origin's own row
       if ((um & need) == need) {     // live
         uint32_t rest = need & ~om;  // corner voxels nobody decodes in this call
         if (!((rest >> 13) & 1u)) {  // the origin's own row (always, but for a caller's stale stamp array)
@@ -2186,7 +2168,6 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
           for (int k = 0; k < 8; ++k)
             if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) {
               // (at most 8 distinct corners, the own row among them: at < 8)
-              if (F.feat_snap) snap_row(F, rowk[k]);
               ent[at & 7] = (rowk[k] << 5) | lk[k];
               keep |= 1u << (at & 7);
               ++at;
@@ -2384,10 +2365,8 @@ constexpr int kProfLds = 0;
 #endif
 
 // `mlp`: the arithmetic mode of the call (mlp_mode_of(grid.mlp_mode))
-static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream,
-                         int max_workgroups = 0) {
+static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
   int64_t grid = g_num_cus - g_reserve_cus.load(std::memory_order_relaxed);
-  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;   // (persistent kernels, dynamic tile hand-out)
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
   const bool lattice_pipe = g_lattice_pipe.load(std::memory_order_relaxed) != 0;
@@ -2693,7 +2672,7 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
 }
 
 static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
-                             int32_t epoch, bool clear, bnv_stream_t stream_, const float* snap_src = nullptr) {
+                             int32_t epoch, bool clear, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
@@ -2701,12 +2680,9 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  MarkFused F = {};
-  F.feat_src = snap_src;
-  F.feat_snap = snap_src ? ws.snap : nullptr;
   hipLaunchKernelGGL(k_lattice_mark<false>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
                      dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, MarkFused{});
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -2715,7 +2691,7 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
 static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights,
                                         int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
                                         void* ws_ptr, size_t ws_bytes, int32_t epoch, bool prestamped,
-                                        bnv_stream_t stream_, const float* snap_src = nullptr) {
+                                        bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
@@ -2727,15 +2703,13 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
                        row_limit, ws.origin_stamp, epoch, n_dev, ws.n_list);
     BNV_LAUNCH_CHECK();
   }   // (prestamped: the frame's upsert has cleared the control words too)
-  MarkFused F = {};
+  MarkFused F;
   F.v = *vol;
   F.origins = origins;
   F.weights = weights;
   F.row_limit = row_limit;
   F.min_pts = (float)grid->min_pts_in_grid;
   F.nbr_rows_out = ws.nbr_rows;
-  F.feat_src = snap_src;
-  F.feat_snap = snap_src ? ws.snap : nullptr;
   hipLaunchKernelGGL(k_lattice_mark<true>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
                      dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n, ws.origin_stamp, epoch, ws.need_mask,
                      ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
@@ -2748,19 +2722,9 @@ int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, v
   return lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, true, stream);
 }
 
-static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                              const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr,
-                              size_t ws_bytes, int max_workgroups, bnv_stream_t stream);
-
 int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
                       const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr, size_t ws_bytes,
                       bnv_stream_t stream) {
-  return lattice_table_impl(vol, grid, features, sdfmlp_pack, n_voxels, use_entries, ws_ptr, ws_bytes, 0, stream);
-}
-
-static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                              const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr,
-                              size_t ws_bytes, int max_workgroups, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr || !mlp_mode_field_ok(grid->mlp_mode))
     return BNV_ERR_INVALID_ARGUMENT;
@@ -2778,8 +2742,7 @@ static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, c
   a.need_mask = ws.need_mask;
   a.entries = use_entries ? ws.entries : nullptr;
   const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
-  return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream,
-                       max_workgroups);
+  return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream);
 }
 
 int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
@@ -2806,44 +2769,30 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
                                const float* weights, int64_t row_limit, const float* sdfmlp_pack,
                                const int64_t* origins, int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta,
                                void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bool prestamped,
-                               bnv_stream_t stream, int stages = 7, bool snapshot = false, int table_workgroups = 0) {
-  // stages: 1 = neighbour rows + live entries (+ feature snapshot when `snapshot`), 2 = table MLP (from the snapshot
-  // when `snapshot`), 4 = blend
+                               bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!features || !grid || n < 0 || ((stages & 2) && !sdfmlp_pack)) return BNV_ERR_INVALID_ARGUMENT;
+  if (!features || !sdfmlp_pack || !grid || n < 0) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  Small calls (a
   // shard's 1/8 of a frame) look the neighbour rows up inside the marking kernel: one launch less, -9 us of a 0.28 ms
   // frame; on whole frames the 256-thread look-up kernel of its own hides the three dependent loads of a look-up
   // better than the 1,024-thread marking workgroups do (48.7 us for the pair against 62.4 us fused)
   int rc;
-  if (stages & 1) {
-    const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
-    const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
-    const float* snap_src = snapshot ? features : nullptr;
-    if (fuse) {
-      rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
-                                        prestamped, stream, snap_src);
-      if (rc != BNV_OK) return rc;
-    } else {
-      rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes, epoch,
-                                  prestamped, stream);
-      if (rc != BNV_OK) return rc;
-      rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream, snap_src);
-      if (rc != BNV_OK) return rc;
-    }
-  }
-  if (stages & 2) {
-    const float* src = features;
-    if (snapshot) {
-      LatticeWs ws;
-      if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
-      src = ws.snap;
-    }
-    rc = lattice_table_impl(vol, grid, src, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, table_workgroups, stream);
+  const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
+  const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
+  if (fuse) {
+    rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
+                                      prestamped, stream);
+    if (rc != BNV_OK) return rc;
+  } else {
+    rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes, epoch,
+                                prestamped, stream);
+    if (rc != BNV_OK) return rc;
+    rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
     if (rc != BNV_OK) return rc;
   }
-  if (!(stages & 4) || !out_sdf) return BNV_OK;   // (the caller blends itself, bnv_decode_lattice_stamped_tables)
+  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
+  if (rc != BNV_OK || !out_sdf) return rc;   // (out_sdf == NULL: the caller blends itself, bnv_decode_lattice_stamped_tables)
   return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
 
@@ -2860,23 +2809,7 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol, const bnv_grid_t*
                                       const int64_t* origins, int64_t n, const int32_t* n_dev, void* ws_ptr,
                                       size_t ws_bytes, int32_t epoch, bnv_stream_t stream) {
   return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, nullptr, ws_ptr,
-                             ws_bytes, epoch, nullptr, true, stream, 3, false);
-}
-
-int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
-                                    const int32_t* n_dev, void* ws_ptr, size_t ws_bytes, int32_t epoch,
-                                    bnv_stream_t stream) {
-  return decode_lattice_impl(vol, grid, features, weights, row_limit, nullptr, origins, n, n_dev, nullptr, ws_ptr,
-                             ws_bytes, epoch, nullptr, true, stream, 1, true);
-}
-
-int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* sdfmlp_pack,
-                                      int64_t n, void* ws_ptr, size_t ws_bytes, int max_workgroups,
-                                      bnv_stream_t stream) {
-  if (!vol || !vol->features || max_workgroups < 0) return BNV_ERR_INVALID_ARGUMENT;
-  return decode_lattice_impl(vol, grid, vol->features, nullptr, 0, sdfmlp_pack, nullptr, n, nullptr, nullptr, ws_ptr,
-                             ws_bytes, 1, nullptr, true, stream, 2, true, max_workgroups);
+                             ws_bytes, epoch, nullptr, true, stream);
 }
 
 int bnv_decode_lattice_stamped(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,

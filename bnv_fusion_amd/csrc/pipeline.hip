@@ -57,8 +57,7 @@ __global__ void k_readback_words(const int32_t* __restrict__ counters, const int
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
   int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
-  hipStream_t F, E, M, B, T;               // F == E, B == M, T == M when the config names no stream for them
-  hipEvent_t ev_mark[BNV_PIPE_MAX_SLOTS];  // the marking kernel (and its feature snapshot) of the slot's frame is through
+  hipStream_t F, E, M, B;                  // F == E and B == M when the config names no stream for them
   hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
       ev_table[BNV_PIPE_MAX_SLOTS], ev_done[BNV_PIPE_MAX_SLOTS];
   hipEvent_t ev_encws[2];               // the encode workspace is free again (behind finalize of its last frame)
@@ -122,9 +121,6 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   p->M = (hipStream_t)cfg->main_stream;
   p->F = cfg->front_stream ? (hipStream_t)cfg->front_stream : p->E;
   p->B = cfg->blend_stream ? (hipStream_t)cfg->blend_stream : p->M;
-  // the table kernel on a stream of its own needs the blend off the main stream as well (its workspace hazards are
-  // ordered through the blend's done event)
-  p->T = (cfg->table_stream && cfg->blend_stream) ? (hipStream_t)cfg->table_stream : p->M;
   p->bound_off = bnv_encode_shard_counts_offset();
   p->enc_next = 0;
   for (int k = 0; k < 2; ++k) {
@@ -141,7 +137,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->n_points[s] = 0;
     p->enc_buf[s] = 0;
     p->mlp_mode[s] = cfg->grid.mlp_mode;
-    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = p->ev_mark[s] = nullptr;
+    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = nullptr;
     p->host_dev[s] = nullptr;
   }
   for (int k = 0; k < 2; ++k)
@@ -155,8 +151,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
-    hipEvent_t* evs[6] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s],
-                          &p->ev_mark[s]};
+    hipEvent_t* evs[5] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s]};
     for (hipEvent_t* e : evs)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
         bnv_frame_pipe_destroy(p);
@@ -176,7 +171,7 @@ int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* p, int32_t grid_mlp_mode) {
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
   if (!p) return BNV_OK;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
-    hipEvent_t evs[6] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s]};
+    hipEvent_t evs[5] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s]};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -345,29 +340,13 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
-    if (p->T != p->M) {
-      // marking + a snapshot of the feature rows the table entries read, on M; the table MLP on T from the snapshot:
-      // M is free for the next frame's upsert .. marking chain while this frame's table kernel runs
-      rc = bnv_decode_lattice_stamped_mark(vol, &g, vol->features, vol->weights, vol->row_capacity, b.grid_ids,
-                                           c.out_capacity, &b.counters->n_out, lattice_ws, lattice_ws_bytes,
-                                           lattice_epoch, p->M);
-      if (rc != BNV_OK) return rc;
-      BNV_HIP_CHECK(hipEventRecord(p->ev_mark[slot], p->M));
-      BNV_HIP_CHECK(hipStreamWaitEvent(p->T, p->ev_mark[slot], 0));
-      rc = bnv_decode_lattice_snapshot_table(vol, &g, sdfmlp_pack, c.out_capacity, lattice_ws, lattice_ws_bytes,
-                                             c.table_workgroups, p->T);
-      if (rc != BNV_OK) return rc;
-      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->T));
+    rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+                                           b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
+                                           lattice_ws_bytes, lattice_epoch, p->M);
+    if (rc != BNV_OK) return rc;
+    if (p->B != p->M) {
+      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
       BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
-    } else {
-      rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
-                                             b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
-                                             lattice_ws_bytes, lattice_epoch, p->M);
-      if (rc != BNV_OK) return rc;
-      if (p->B != p->M) {
-        BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
-        BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
-      }
     }
     // the blend reads the workspace only: on B it leaves M to the next frame's upsert
     rc = bnv_lattice_blend(vol, &g, b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws, lattice_ws_bytes,

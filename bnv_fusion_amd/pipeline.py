@@ -53,18 +53,10 @@ class FramePipe:
         self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
         # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four)
         streams = int(os.environ.get("BNV_PIPE_STREAMS", streams))
-        self.front = self.blend = self.table = None
+        self.front = self.blend = None
         if streams >= 4:
             self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
             self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
-        # streams = 5 (BNV_PIPE_STREAMS=5): the table MLP on a stream of its own, reading a feature snapshot, so that
-        # the main stream's chain of frame t+1 runs beside table(t).  Correct (the pipeline tests pass with it) but
-        # SLOWER here, and therefore not the default: with both MLP kernels in flight all the time no CU is ever free,
-        # and the chain's small kernels -- which cannot share a CU with either (LDS, registers) -- crawl: upsert 13 ->
-        # 55 us, marking 20 -> 100 us; a rank's frame at world 8 0.266 -> 0.29-0.44 ms whatever the CU split
-        # (encoder_workgroups / BNV_PIPE_TABLE_WGS: 64/176 .. 192/all).
-        if streams >= 5:
-            self.table = concurrent_stream(dev, self.main, exclude=(self.enc, self.front, self.blend))
         self.double_buffered = self.front is not None
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
@@ -72,9 +64,6 @@ class FramePipe:
                 cus = int(lib.bnv_num_compute_units())
                 encoder_workgroups = int(cus * self.ENCODER_SHARE_SHARDED) if (self.world > 1 and streams >= 4) else 0
         self.encoder_workgroups = int(encoder_workgroups)
-        # five streams: both MLP kernels are in flight all the time and their workgroup counts partition the CUs (the
-        # encoder's and the table kernel's share of a frame's MLP work, a few CUs left to the small kernels)
-        self.table_workgroups = int(os.environ.get("BNV_PIPE_TABLE_WGS", 0))
         res = v._n_xyz_host
         nvox = res[0] * res[1] * res[2]
         self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)
@@ -125,9 +114,6 @@ class FramePipe:
         if self.double_buffered:
             cfg.enc_ws2 = self._enc_ws2.data_ptr()
             cfg.front_stream, cfg.blend_stream = self.front.cuda_stream, self.blend.cuda_stream
-            if self.table is not None:
-                cfg.table_stream = self.table.cuda_stream
-                cfg.table_workgroups = self.table_workgroups
         cfg.encoder_workgroups = self.encoder_workgroups
         self._cfg = cfg
         h = C.c_void_p()

@@ -513,20 +513,6 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol_host, const bnv_gr
                                       const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
                                       bnv_stream_t stream);
 
-/* The same in two halves that may run on different streams: `_mark` = neighbour rows + live entries on `stream`, which
- * also copies the feature row of every row that gets a table entry into the workspace; `_snapshot_table` = the table
- * MLP reading that snapshot instead of the volume.  Behind `_mark` the volume's rows are free to change (the next
- * frame's upsert) while the table kernel runs elsewhere -- results are those of the state `_mark` saw.  The caller
- * orders `_snapshot_table` behind `_mark` (an event) and bnv_lattice_blend behind the table. */
-int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
-                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
-                                    const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
-                                    bnv_stream_t stream);
-/* max_workgroups: the persistent table kernel is launched on at most this many workgroups (one per CU; 0 = all) */
-int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
-                                      const float* sdfmlp_pack, int64_t n, void* ws, size_t ws_bytes,
-                                      int max_workgroups, bnv_stream_t stream);
-
 /* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
  * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
@@ -661,15 +647,6 @@ typedef struct bnv_frame_pipe_config {
   void* enc_ws2;
   bnv_stream_t front_stream, blend_stream;
   int32_t encoder_workgroups;
-  /*   table_stream  (with blend_stream) the table MLP of the decode runs here, reading a snapshot of the feature rows
-   *                 the marking kernel took (bnv_decode_lattice_stamped_mark / _snapshot_table): main_stream goes on
-   *                 to the next frame's upsert .. marking chain while the table kernel of this frame runs. */
-  bnv_stream_t table_stream;
-  /*   table_workgroups  with table_stream: workgroups of the persistent table kernel (0 = all CUs).  The two MLP kernels
-   *                 each fill a CU's LDS; with both in flight all the time (table of frame t beside the encoder of
-   *                 frame t+2) their workgroup counts PARTITION the CUs -- encoder_workgroups + table_workgroups should
-   *                 stay below the CU count so that the small kernels of the other streams always find a free CU. */
-  int32_t table_workgroups;
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;

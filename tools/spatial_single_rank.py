@@ -35,8 +35,45 @@ ap.add_argument("--ownership", default=None, help="ownership rule of the shards 
 ap.add_argument("--no-latency", action="store_true")
 ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode is enqueued before the host waits for "
                 "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
+ap.add_argument("--json", action="store_true", help="(internal) print the rank's figures as one JSON line at the end")
 args = ap.parse_args()
 W = args.world
+
+if args.all_ranks:
+    # every rank in a process of its own, one after the other -- as on a node, where a rank IS a process with one frame
+    # pipeline (several pipelines created one after the other in ONE process end up, now and then, with streams that
+    # share a hardware queue: 0.46 instead of 0.27 ms per frame on a random rank; a fresh process never showed it).  The
+    # parent never touches the GPU.
+    import json, subprocess
+    rows = []
+    base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--all-ranks"]
+    # a short throw-away run first: the first process on a fresh box pays for cold file caches and clocks
+    subprocess.run(base + ["--rank", "0", "--frames", "200", "--no-latency"], capture_output=True, text=True, timeout=900)
+    for r in range(W):
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--all-ranks"] + \
+              ["--rank", str(r), "--json", "--no-latency"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+        lines = out.stdout.splitlines()
+        js = [l for l in lines if l.startswith("{\"rank\"")]
+        if out.returncode != 0 or not js:
+            print(out.stdout[-2000:], out.stderr[-2000:])
+            raise SystemExit(f"rank {r} failed")
+        print("\n".join(l for l in lines if not l.startswith("{\"rank\"")))
+        rows.append(json.loads(js[-1]))
+    print(f"\nall {W} ranks ({args.frames} frames each, {args.in_flight} in flight; one process per rank, one after the other):")
+    print("  rank   ms/frame   (median, slowest segment)   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
+    for o in rows:
+        print(f"  {o['rank']:4d}   {o['ms']:8.3f}   ({o['ms_med']:.3f}, {o['ms_worst']:.3f})            {o['own']:12.0f}   "
+              f"{o['pairs']:13.0f}   {o['evals']:15.0f}   {o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
+    for k, name in (("own", "voxels owned"), ("pairs", "pairs encoded"), ("evals", "MLP evaluations")):
+        v = np.array([o[k] for o in rows])
+        print(f"  {name}: max / mean over the ranks {v.max() / max(v.mean(), 1e-9):.3f}")
+    v = np.array([o["ms"] for o in rows])
+    print(f"  ms per frame: mean {v.mean():.3f}, MAX {v.max():.3f} (rank {int(v.argmax())}) -> {1e3 / v.max():.0f} frames/s "
+          f"for the rank set at the pace of its slowest rank")
+    m = np.array([o["ms_med"] for o in rows])
+    print(f"  median segments: mean {m.mean():.3f}, MAX {m.max():.3f} (rank {int(m.argmax())}) -> {1e3 / m.max():.0f} frames/s")
+    raise SystemExit(0)
 with socket.socket() as s:
     s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
@@ -184,8 +221,8 @@ def price(rank, latency):
         pp = be.pipe
         print("  pipeline streams verified concurrent with the main stream and with one another: " + ", ".join(
             f"{n} {getattr(st, 'bnv_concurrent', None)}" for n, st in (("encode", pp.enc), ("front", pp.front),
-                                                                     ("blend", pp.blend), ("table", pp.table)) if st is not None)
-              + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}")
+                                                                     ("blend", pp.blend)) if st is not None)
+              + f"; encoder workgroups {pp.encoder_workgroups}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
         if args.trace:
@@ -211,21 +248,8 @@ def price(rank, latency):
 
 gc.collect()
 gc.disable()       # as bench.py: a full collection with torch imported takes ~40 ms
-if args.all_ranks:
-    rows = [price(r, latency=False) for r in range(W)]
-    print(f"\nall {W} ranks ({args.frames} frames each, {args.in_flight} in flight):")
-    print("  rank   ms/frame   (median, slowest segment)   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
-    for o in rows:
-        print(f"  {o['rank']:4d}   {o['ms']:8.3f}   ({o['ms_med']:.3f}, {o['ms_worst']:.3f})            {o['own']:12.0f}   "
-              f"{o['pairs']:13.0f}   {o['evals']:15.0f}   {o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
-    for k, name in (("own", "voxels owned"), ("pairs", "pairs encoded"), ("evals", "MLP evaluations")):
-        v = np.array([o[k] for o in rows])
-        print(f"  {name}: max / mean over the ranks {v.max() / max(v.mean(), 1e-9):.3f}")
-    v = np.array([o["ms"] for o in rows])
-    print(f"  ms per frame: mean {v.mean():.3f}, MAX {v.max():.3f} (rank {int(v.argmax())}) -> {1e3 / v.max():.0f} frames/s "
-          f"for the rank set at the pace of its slowest rank")
-    m = np.array([o["ms_med"] for o in rows])
-    print(f"  median segments: mean {m.mean():.3f}, MAX {m.max():.3f} (rank {int(m.argmax())}) -> {1e3 / m.max():.0f} frames/s")
-else:
-    price(args.rank, latency=not args.no_latency)
+res = price(args.rank, latency=not args.no_latency)
+if args.json:
+    import json
+    print(json.dumps(res))
 dist.destroy_process_group()
