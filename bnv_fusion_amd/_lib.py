@@ -17,7 +17,7 @@ SYMBOLS = [
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_integrate_batch",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
-    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_depth_to_points_padded", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_tsdf_integrate_batch_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_probe_mfma_rate", "bnv_probe_spin", "bnv_decode_lattice_count_offset",
+    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_depth_to_points_padded", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_tsdf_integrate_batch_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_probe_mfma_rate", "bnv_probe_spin", "bnv_stream_create_cu_mask", "bnv_stream_destroy", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
@@ -203,6 +203,8 @@ def load():
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
         "bnv_probe_mfma_rate": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "bnv_probe_spin": (C.c_int, [C.c_int, i64, vp]),
+        "bnv_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(vp)]),
+        "bnv_stream_destroy": (C.c_int, [vp]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),

@@ -179,6 +179,13 @@ int bnv_probe_mfma_rate(int shape, int operands, int iters, void* stream, double
  * strictly in submission order; one spin on each of two streams, timed with events, tells whether they overlap.  The
  * frame pipeline picks its encode stream that way (bnv_fusion_amd/streams.py). */
 int bnv_probe_spin(int n_blocks, int64_t cycles, void* stream);
+/* A HIP stream whose kernels run only on the compute units named in `cu_mask` (bit i of word i / 32 = CU i of the
+ * device's enumeration, which interleaves the XCDs: a run of low bits takes an equal share of every XCD), and its
+ * release.  `n_words` x 32 must cover the device's CUs and at least one CU must be named.  The sharded frame pipeline
+ * gives each of its two persistent MLP kernels a stream with a disjoint mask, so that neither can take the CUs the other
+ * (or the small kernels between them) needs; the streams are the caller's, like every stream of this interface. */
+int bnv_stream_create_cu_mask(int n_words, const uint32_t* cu_mask, void** stream_out);
+int bnv_stream_destroy(void* stream);
 
 /* ---- front end: depth image -> input_pts (FusionInferenceAbstractDataset.__getitem__,
  * src/datasets/fusion_inference_dataset.py:40-90; geometry.py:150-171; kornia depth_to_normals) --------
