@@ -25,7 +25,7 @@ SYMBOLS = [
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
     "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
-    "bnv_encode_finish_image_wg", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
+    "bnv_encode_finish_image_wg", "bnv_encode_finish_image_parts", "bnv_decode_lattice_snapshot_workspace_bytes", "bnv_decode_lattice_stamped_mark", "bnv_decode_lattice_snapshot_table", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
 ]
@@ -77,7 +77,8 @@ class FramePipeConfig(C.Structure):
                 ("enc_ws_max_points", C.c_int64), ("max_depth", C.c_double), ("tsdf", TsdfDesc),
                 ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
                 ("main_stream", C.c_void_p), ("enc_ws2", C.c_void_p), ("front_stream", C.c_void_p),
-                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32)]
+                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32), ("table_stream", C.c_void_p),
+                ("table_workgroups", C.c_int32)]
 
 
 class BnvError(RuntimeError):
@@ -173,6 +174,9 @@ def load():
         "bnv_mc_emit_indexed": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp, vp, vp, vp, vp,
                                           vp]),
         "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
+        "bnv_decode_lattice_snapshot_workspace_bytes": (sz, [i64, i64]),
+        "bnv_encode_finish_image_parts": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
+                                                    C.c_int, vp, C.c_int, C.c_int, vp]),
         "bnv_decode_lattice_count_offset": (sz, [i64]),
         "bnv_decode_lattice_table_offset": (sz, [i64]),
         "bnv_decode_lattice_list_offset": (sz, [i64, i64]),
@@ -212,6 +216,10 @@ def load():
                                                         vp, sz, i32, vp]),
         "bnv_encode_finish_image_wg": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
                                                  C.c_int, vp, C.c_int, vp]),
+        "bnv_decode_lattice_stamped_mark": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, i64, vp, vp, sz,
+                                                      i32, vp]),
+        "bnv_decode_lattice_snapshot_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, sz, C.c_int,
+                                                        vp]),
         "bnv_shard_state_bytes": (sz, [C.POINTER(i32), i32]),
         "bnv_shard_state_loads_offset": (sz, []),
         "bnv_shard_state_table_offset": (sz, []),

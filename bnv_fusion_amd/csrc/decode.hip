@@ -1886,11 +1886,12 @@ struct LatticeWs {
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
   int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
+  float* snap;        // [row_capacity][8] the feature rows the call's table entries read, as the marking kernel found them (null unless asked for)
   int64_t list_capacity;
   int64_t entry_capacity;
 };
 
-static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws) {
+static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws, bool with_snap = false) {
   if (n < 1) n = 1;
   int64_t cap = 27 * n;
   if (cap > row_capacity) cap = row_capacity;
@@ -1911,10 +1912,13 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   int64_t ecap = 27 * cap;
   if (ecap > 216 * n) ecap = 216 * n;
   char* en = take(ecap * 4);
+  // (last, and only for callers that ask: every other address is the same with and without it)
+  char* sn = with_snap ? take(row_capacity * 8 * 4) : nullptr;
   if (ws) {
     ws->need_mask = (uint32_t*)nm;
     ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
+    ws->snap = (float*)sn;
     ws->entry_capacity = ecap;
     ws->stamp = (int32_t*)st;
     ws->table = (float*)tb;
@@ -2037,9 +2041,23 @@ struct MarkFused {
   int64_t row_limit;
   float min_pts;
   int32_t* nbr_rows_out;
+  // Snapshot (both null: none): the feature row of every row that gets a table entry is copied to snap[row] -- the
+  // table MLP then reads the snapshot, and the volume is free for the NEXT frame's upsert while it runs (the frame
+  // pipeline puts the table kernel on a stream of its own).  Every entry of a row that is an origin of the call is
+  // appended by that origin's threads, so its centre point's thread copies the row; entries in other rows (the
+  // fringe) are copied by whoever appends them (the same bytes from every writer).
+  const float* feat_src;
+  float* feat_snap;
 };
 
-template <bool FUSED>
+__device__ __forceinline__ void snap_row(const MarkFused& F, int row) {
+  const f32x4* s4 = (const f32x4*)(F.feat_src + (size_t)row * 8);
+  f32x4* d4 = (f32x4*)(F.feat_snap + (size_t)row * 8);
+  d4[0] = s4[0];
+  d4[1] = s4[1];
+}
+
+template <bool FUSED, bool SNAP = false>
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
@@ -2140,6 +2158,8 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         xo |= s_ob[w + 1] << (64 - sh);
       }
       const uint32_t um = (uint32_t)xu & 0x7FFFFFFu, om = (uint32_t)xo & 0x7FFFFFFu, need = s_need[p];
+      if constexpr (SNAP)
+        if (p == 13 && nb27[13] >= 0) snap_row(F, nb27[13] & ~kOriginBit);   // the origin's own row
       if ((um & need) == need) {     // live
         uint32_t rest = need & ~om;  // corner voxels nobody decodes in this call
         if (!((rest >> 13) & 1u)) {  // the origin's own row (always, but for a caller's stale stamp array)
@@ -2168,6 +2188,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
           for (int k = 0; k < 8; ++k)
             if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) {
               // (at most 8 distinct corners, the own row among them: at < 8)
+              if constexpr (SNAP) snap_row(F, rowk[k]);
               ent[at & 7] = (rowk[k] << 5) | lk[k];
               keep |= 1u << (at & 7);
               ++at;
@@ -2365,8 +2386,10 @@ constexpr int kProfLds = 0;
 #endif
 
 // `mlp`: the arithmetic mode of the call (mlp_mode_of(grid.mlp_mode))
-static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream) {
+static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_tiles_hint, hipStream_t stream,
+                         int max_workgroups = 0) {
   int64_t grid = g_num_cus - g_reserve_cus.load(std::memory_order_relaxed);
+  if (max_workgroups > 0 && grid > max_workgroups) grid = max_workgroups;   // (persistent kernels, dynamic tile hand-out)
   if (n_tiles_hint < grid) grid = n_tiles_hint;
   if (grid < 1) grid = 1;
   const bool lattice_pipe = g_lattice_pipe.load(std::memory_order_relaxed) != 0;
@@ -2621,6 +2644,10 @@ size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity
   return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr);
 }
 
+size_t bnv_decode_lattice_snapshot_workspace_bytes(int64_t n_voxels, int64_t row_capacity) {
+  return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr, true);
+}
+
 size_t bnv_decode_lattice_count_offset(int64_t row_capacity) {
   LatticeWs ws;
   lattice_ws_layout(1, row_capacity, (char*)256, &ws);
@@ -2672,17 +2699,25 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
 }
 
 static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
-                             int32_t epoch, bool clear, bnv_stream_t stream_) {
+                             int32_t epoch, bool clear, bnv_stream_t stream_, const float* snap_src = nullptr) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
-  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, snap_src != nullptr) > ws_bytes)
+    return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_lattice_mark<false>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
-                     dim3(kMarkThreads), 0, stream, ws.nbr_rows, n, ws.origin_stamp, epoch,
-                     ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, MarkFused{});
+  MarkFused F = {};
+  F.feat_src = snap_src;
+  F.feat_snap = snap_src ? ws.snap : nullptr;
+  const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
+  if (snap_src)
+    hipLaunchKernelGGL((k_lattice_mark<false, true>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else
+    hipLaunchKernelGGL((k_lattice_mark<false, false>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -2691,10 +2726,11 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
 static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights,
                                         int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
                                         void* ws_ptr, size_t ws_bytes, int32_t epoch, bool prestamped,
-                                        bnv_stream_t stream_) {
+                                        bnv_stream_t stream_, const float* snap_src = nullptr) {
   if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
-  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, snap_src != nullptr) > ws_bytes)
+    return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
   if (n == 0) return BNV_OK;
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
@@ -2703,16 +2739,22 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
                        row_limit, ws.origin_stamp, epoch, n_dev, ws.n_list);
     BNV_LAUNCH_CHECK();
   }   // (prestamped: the frame's upsert has cleared the control words too)
-  MarkFused F;
+  MarkFused F = {};
   F.v = *vol;
   F.origins = origins;
   F.weights = weights;
   F.row_limit = row_limit;
   F.min_pts = (float)grid->min_pts_in_grid;
   F.nbr_rows_out = ws.nbr_rows;
-  hipLaunchKernelGGL(k_lattice_mark<true>, dim3(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2)),
-                     dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n, ws.origin_stamp, epoch, ws.need_mask,
-                     ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  F.feat_src = snap_src;
+  F.feat_snap = snap_src ? ws.snap : nullptr;
+  const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
+  if (snap_src)
+    hipLaunchKernelGGL((k_lattice_mark<true, true>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else
+    hipLaunchKernelGGL((k_lattice_mark<true, false>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
@@ -2722,9 +2764,19 @@ int bnv_lattice_mark(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, v
   return lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, true, stream);
 }
 
+static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                              const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr,
+                              size_t ws_bytes, int max_workgroups, bnv_stream_t stream);
+
 int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
                       const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr, size_t ws_bytes,
                       bnv_stream_t stream) {
+  return lattice_table_impl(vol, grid, features, sdfmlp_pack, n_voxels, use_entries, ws_ptr, ws_bytes, 0, stream);
+}
+
+static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                              const float* sdfmlp_pack, int64_t n_voxels, int use_entries, void* ws_ptr,
+                              size_t ws_bytes, int max_workgroups, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !sdfmlp_pack || !ws_ptr || !mlp_mode_field_ok(grid->mlp_mode))
     return BNV_ERR_INVALID_ARGUMENT;
@@ -2742,7 +2794,8 @@ int bnv_lattice_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const flo
   a.need_mask = ws.need_mask;
   a.entries = use_entries ? ws.entries : nullptr;
   const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
-  return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream);
+  return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream,
+                       max_workgroups);
 }
 
 int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int64_t* origins, int64_t n,
@@ -2769,30 +2822,45 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
                                const float* weights, int64_t row_limit, const float* sdfmlp_pack,
                                const int64_t* origins, int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta,
                                void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bool prestamped,
-                               bnv_stream_t stream) {
+                               bnv_stream_t stream, int stages = 7, bool snapshot = false, int table_workgroups = 0) {
+  // stages: 1 = neighbour rows + live entries (+ feature snapshot when `snapshot`), 2 = table MLP (from the snapshot
+  // when `snapshot`), 4 = blend
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (!features || !sdfmlp_pack || !grid || n < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (!features || !grid || n < 0 || ((stages & 2) && !sdfmlp_pack)) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  Small calls (a
   // shard's 1/8 of a frame) look the neighbour rows up inside the marking kernel: one launch less, -9 us of a 0.28 ms
   // frame; on whole frames the 256-thread look-up kernel of its own hides the three dependent loads of a look-up
   // better than the 1,024-thread marking workgroups do (48.7 us for the pair against 62.4 us fused)
   int rc;
-  const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
-  const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
-  if (fuse) {
-    rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
-                                      prestamped, stream);
-    if (rc != BNV_OK) return rc;
-  } else {
-    rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes, epoch,
-                                prestamped, stream);
-    if (rc != BNV_OK) return rc;
-    rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
+  if (stages & 1) {
+    const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
+    const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
+    const float* snap_src = snapshot ? features : nullptr;
+    if (fuse) {
+      rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
+                                        prestamped, stream, snap_src);
+      if (rc != BNV_OK) return rc;
+    } else {
+      rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes, epoch,
+                                  prestamped, stream);
+      if (rc != BNV_OK) return rc;
+      rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream, snap_src);
+      if (rc != BNV_OK) return rc;
+    }
+  }
+  if (stages & 2) {
+    const float* src = features;
+    if (snapshot) {
+      LatticeWs ws;
+      if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, true) > ws_bytes)
+        return BNV_ERR_WORKSPACE_TOO_SMALL;
+      src = ws.snap;
+    }
+    rc = lattice_table_impl(vol, grid, src, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, table_workgroups, stream);
     if (rc != BNV_OK) return rc;
   }
-  rc = bnv_lattice_table(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, stream);
-  if (rc != BNV_OK || !out_sdf) return rc;   // (out_sdf == NULL: the caller blends itself, bnv_decode_lattice_stamped_tables)
+  if (!(stages & 4) || !out_sdf) return BNV_OK;   // (the caller blends itself, bnv_decode_lattice_stamped_tables)
   return bnv_lattice_blend(vol, grid, origins, n, n_dev, delta, ws_ptr, ws_bytes, out_sdf, stream);
 }
 
@@ -2809,7 +2877,23 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol, const bnv_grid_t*
                                       const int64_t* origins, int64_t n, const int32_t* n_dev, void* ws_ptr,
                                       size_t ws_bytes, int32_t epoch, bnv_stream_t stream) {
   return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, nullptr, ws_ptr,
-                             ws_bytes, epoch, nullptr, true, stream);
+                             ws_bytes, epoch, nullptr, true, stream, 3, false);
+}
+
+int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
+                                    const int32_t* n_dev, void* ws_ptr, size_t ws_bytes, int32_t epoch,
+                                    bnv_stream_t stream) {
+  return decode_lattice_impl(vol, grid, features, weights, row_limit, nullptr, origins, n, n_dev, nullptr, ws_ptr,
+                             ws_bytes, epoch, nullptr, true, stream, 1, true);
+}
+
+int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* sdfmlp_pack,
+                                      int64_t n, void* ws_ptr, size_t ws_bytes, int max_workgroups,
+                                      bnv_stream_t stream) {
+  if (!vol || !vol->features || max_workgroups < 0) return BNV_ERR_INVALID_ARGUMENT;
+  return decode_lattice_impl(vol, grid, vol->features, nullptr, 0, sdfmlp_pack, nullptr, n, nullptr, nullptr, ws_ptr,
+                             ws_bytes, 1, nullptr, true, stream, 2, true, max_workgroups);
 }
 
 int bnv_decode_lattice_stamped(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,

@@ -2045,8 +2045,19 @@ int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int ima
                                float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                                int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
                                int max_workgroups, bnv_stream_t stream_) {
+  return bnv_encode_finish_image_parts(input_pts, n_points, image_width, grid_host, pointnet_pack, ws_ptr, ws_bytes,
+                                       ws_max_points, out_feats, out_pcounts, out_flat_ids, out_grid_ids, out_capacity,
+                                       emit_all, counters, max_workgroups, 3, stream_);
+}
+
+int bnv_encode_finish_image_parts(const float* input_pts, int64_t n_points, int image_width,
+                                  const bnv_grid_t* grid_host, const float* pointnet_pack, void* ws_ptr,
+                                  size_t ws_bytes, int64_t ws_max_points, float* out_feats, int64_t* out_pcounts,
+                                  int64_t* out_flat_ids, int64_t* out_grid_ids, int64_t out_capacity, int emit_all,
+                                  bnv_encode_counters_t* counters, int max_workgroups, int parts,
+                                  bnv_stream_t stream_) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
-  if (image_width < 0 || max_workgroups < 0) return BNV_ERR_INVALID_ARGUMENT;
+  if (image_width < 0 || max_workgroups < 0 || parts < 1 || parts > 3) return BNV_ERR_INVALID_ARGUMENT;
   if (!input_pts || !grid_host || !pointnet_pack || !ws_ptr || !counters || n_points < 0 ||
       n_points > (1 << 27) || ws_max_points < n_points)
     return BNV_ERR_INVALID_ARGUMENT;
@@ -2056,7 +2067,7 @@ int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int ima
   EncodeWs ws;
   if (encode_ws_layout(ws_max_points, g.n_xyz, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   if (n_points == 0) {
-    BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
+    if (parts & 2) BNV_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(bnv_encode_counters_t), stream));
     return BNV_OK;
   }
   const int n = (int)n_points;
@@ -2069,7 +2080,7 @@ int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int ima
   const int mlp = mlp_mode_of(g.mlp_mode);
   // sharded: owned pairs only -- from the list `begin` made, or (block encoder) by an ownership test in the kernel
   const int32_t* plist = (g.shard_world > 1 && !tcnn_blocks(g)) ? ws.pair_list : (const int32_t*)nullptr;
-  {
+  if (parts & 1) {
     ProfScope prof(PROF_POINTNET, stream);
     if (tcnn_blocks(g)) {
       const int n_blocks = (n + 31) / 32 + 64;   // (an upper bound of the 8 x 4 patches as well, up to ragged edges)
@@ -2096,6 +2107,7 @@ int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int ima
                          pointnet_pack, ws.bitmap, ws.word_prefix, ws.counts, ws.acc, plist, &ws.ctl->n_pairs);
   }
   BNV_LAUNCH_CHECK();
+  if (!(parts & 2)) return BNV_OK;
   // ordered compaction of the emitted voxels; the number of slots is only known on the device: a capped grid strides
   // over the tiles
   const int nb_max = (int)((ws.max_unique + kFinTile - 1) / kFinTile);

@@ -25,6 +25,18 @@
 // workspace is double-buffered by the caller); and the encoder is launched on a share of the CUs
 // (encoder_workgroups) so that the chain's small kernels find free CUs while it runs -- they cannot share a CU with
 // it (LDS, registers).  A cycle is then ~ [encoder(t+1) beside chain(t)] + table(t).
+//
+// FIVE streams (table_stream; the sharded pipeline's default where CU-masked streams are available).  The cycle above
+// still has the two MLP kernels take turns.  With the table MLP on a stream T of its own -- reading a SNAPSHOT of the
+// feature rows its entries need, taken by the marking kernel, so that the next frame's upsert may change the volume
+// meanwhile -- three things run at once in the steady state: table(t) on T, the chain of frame t+1 on M, the encoder
+// of frame t+2 on E.  Left to the dispatcher that is slower (the two persistent kernels grab every CU and the chain
+// starves: profiles/r04_fifth_stream_experiment.txt); with E and T created as CU-MASKED streams
+// (bnv_stream_create_cu_mask) of disjoint CU sets, sized by the two kernels' share of a frame's MLP work, and a few
+// CUs left to nobody, every stream always has somewhere to run.  E then carries nothing but the encoder kernel:
+// finalize moves to the head of the frame's chain on M, the TSDF side fusion (gated by finalize's point count) to B.
+// A cycle is max(table on its CUs, encoder on its CUs, chain).
+//
 // E of frame t+1 depends on the frame only; the host wait for the bound of frame t+1 (bnv_frame_bound) returns
 // while M still holds most of frame t, and the GPU never waits for the host.  Nothing here allocates device memory;
 // the object owns HIP events only.
@@ -57,7 +69,8 @@ __global__ void k_readback_words(const int32_t* __restrict__ counters, const int
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
   int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
-  hipStream_t F, E, M, B;                  // F == E and B == M when the config names no stream for them
+  hipStream_t F, E, M, B, T;               // F == E, B == M, T == M when the config names no stream for them
+  hipEvent_t ev_mark[BNV_PIPE_MAX_SLOTS];  // the marking kernel (and its feature snapshot) of the slot's frame is through
   hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
       ev_table[BNV_PIPE_MAX_SLOTS], ev_done[BNV_PIPE_MAX_SLOTS];
   hipEvent_t ev_encws[2];               // the encode workspace is free again (behind finalize of its last frame)
@@ -71,6 +84,19 @@ struct bnv_frame_pipe {
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
   int32_t mlp_mode[BNV_PIPE_MAX_SLOTS];   // bnv_grid_t.mlp_mode a slot's frame was begun with (its decode uses the same)
   size_t bound_off;
+  // split mode (T != M): what finalize and the TSDF side fusion of the slot's frame need at upsert time
+  bool split;
+  const float* pts[BNV_PIPE_MAX_SLOTS];
+  int width[BNV_PIPE_MAX_SLOTS];
+  struct SideArgs {
+    bool on;
+    const void* depth;
+    const float* color;
+    int dtype, H, W;
+    float K[9], T[16];
+  } side[BNV_PIPE_MAX_SLOTS];
+  hipEvent_t ev_fin[BNV_PIPE_MAX_SLOTS];   // finalize of the slot's frame is through (split mode)
+  int encws_slot[2];                       // the slot whose frame used the encode workspace last
 };
 
 // the pipe's grid with the arithmetic mode of the slot's frame
@@ -121,11 +147,16 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   p->M = (hipStream_t)cfg->main_stream;
   p->F = cfg->front_stream ? (hipStream_t)cfg->front_stream : p->E;
   p->B = cfg->blend_stream ? (hipStream_t)cfg->blend_stream : p->M;
+  // the table kernel on a stream of its own needs the blend off the main stream as well (its workspace hazards are
+  // ordered through the blend's done event)
+  p->T = (cfg->table_stream && cfg->blend_stream) ? (hipStream_t)cfg->table_stream : p->M;
+  p->split = p->T != p->M;
   p->bound_off = bnv_encode_shard_counts_offset();
   p->enc_next = 0;
   for (int k = 0; k < 2; ++k) {
     p->ev_encws[k] = nullptr;
     p->encws_used[k] = false;
+    p->encws_slot[k] = -1;
   }
   for (int k = 0; k < 4; ++k) {
     p->lws_ptr[k] = nullptr;
@@ -137,7 +168,11 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->n_points[s] = 0;
     p->enc_buf[s] = 0;
     p->mlp_mode[s] = cfg->grid.mlp_mode;
-    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = nullptr;
+    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = p->ev_mark[s] = nullptr;
+    p->ev_fin[s] = nullptr;
+    p->pts[s] = nullptr;
+    p->width[s] = 0;
+    p->side[s].on = false;
     p->host_dev[s] = nullptr;
   }
   for (int k = 0; k < 2; ++k)
@@ -151,7 +186,8 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
-    hipEvent_t* evs[5] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s]};
+    hipEvent_t* evs[7] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s],
+                          &p->ev_mark[s], &p->ev_fin[s]};
     for (hipEvent_t* e : evs)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
         bnv_frame_pipe_destroy(p);
@@ -171,7 +207,8 @@ int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* p, int32_t grid_mlp_mode) {
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
   if (!p) return BNV_OK;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
-    hipEvent_t evs[5] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s]};
+    hipEvent_t evs[7] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s],
+                         p->ev_fin[s]};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -194,13 +231,20 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
   const bnv_grid_t g = slot_grid(p, slot);
-  const int rc = bnv_encode_finish_image_wg(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
-                                            c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
-                                            c.out_capacity, 0, b.counters, c.encoder_workgroups, p->E);
+  // split mode: E carries the persistent MLP kernel only; finalize heads the frame's chain on M (bnv_frame_upsert)
+  const int rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
+                                               c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
+                                               c.out_capacity, 0, b.counters, c.encoder_workgroups, p->split ? 1 : 3,
+                                               p->E);
   if (rc != BNV_OK) return rc;
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
-  BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
+  if (!p->split)
+    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
   p->encws_used[p->enc_buf[slot]] = true;
+  p->encws_slot[p->enc_buf[slot]] = slot;
+  p->pts[slot] = pts;
+  p->width[slot] = image_width;
+  p->side[slot].on = false;
   p->n_points[slot] = n;
   p->state[slot] = 1;
   return BNV_OK;
@@ -213,6 +257,9 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
   // the encode workspace alternates when there are two: the front end of this frame then only waits for the encoder
   // of the frame before the last one
   const int buf = p->cfg.enc_ws2 ? p->enc_next : 0;
+  // split mode: the workspace's event is recorded behind finalize, i.e. when its last frame is UPSERTED
+  if (p->split && p->encws_used[buf] && p->encws_slot[buf] >= 0 && p->state[p->encws_slot[buf]] == 1)
+    return BNV_ERR_INVALID_ARGUMENT;
   if (p->cfg.enc_ws2) p->enc_next ^= 1;
   p->enc_buf[slot] = buf;
   if (p->encws_used[buf] && p->F != p->E) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_encws[buf], 0));
@@ -235,6 +282,18 @@ int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int 
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W, W);
   if (rc != BNV_OK) return rc;
+  if (c.tsdf.tsdf && p->split) {   // behind finalize (its gate), on B: bnv_frame_upsert
+    bnv_frame_pipe::SideArgs& a = p->side[slot];
+    a.on = true;
+    a.depth = depth;
+    a.color = color_im;
+    a.dtype = depth_dtype;
+    a.H = H;
+    a.W = W;
+    for (int i = 0; i < 9; ++i) a.K[i] = (float)intr_host[i];
+    for (int i = 0; i < 16; ++i) a.T[i] = (float)T_wc_host[i];
+    return BNV_OK;
+  }
   if (c.tsdf.tsdf) {   // run_e2e.py:99-109, gated on the device by the frame's in-bounds point count
     float K[9], T[16];
     for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
@@ -274,6 +333,31 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
   BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
+  if (p->split) {
+    const bnv_grid_t g = slot_grid(p, slot);
+    int rc = bnv_encode_finish_image_parts(p->pts[slot], p->n_points[slot], p->width[slot], &g, c.pointnet_pack,
+                                           slot_encws(p, slot), c.enc_ws_bytes, c.enc_ws_max_points, b.feats,
+                                           b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters,
+                                           c.encoder_workgroups, 2, p->M);
+    if (rc != BNV_OK) return rc;
+    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->M));   // finalize has left the workspace clean
+    const bnv_frame_pipe::SideArgs& a = p->side[slot];
+    if (a.on) {   // the TSDF side fusion, gated by the point count finalize wrote
+      BNV_HIP_CHECK(hipEventRecord(p->ev_fin[slot], p->M));
+      BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_fin[slot], 0));
+      const int32_t* gate = &b.counters->n_valid_points;
+      if (a.dtype == 0)
+        rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim,
+                                    c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)a.depth,
+                                    a.color, a.H, a.W, a.K, a.T, 1.0f, (float)c.max_depth, gate, p->B);
+      else
+        rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim,
+                                c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)a.depth, a.color,
+                                a.H, a.W, a.K, a.T, 1.0f, (float)c.max_depth, gate, p->B);
+      if (rc != BNV_OK) return rc;
+      BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->B));
+    }
+  }
   if (lattice_ws && p->B != p->M) {
     // the upsert stamps the decode's origins into lattice_ws and clears its control words: the blend (other stream)
     // of the frame that decoded into this workspace last must be through.  Callers alternate two workspaces, so
@@ -340,13 +424,29 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
-    rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
-                                           b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
-                                           lattice_ws_bytes, lattice_epoch, p->M);
-    if (rc != BNV_OK) return rc;
-    if (p->B != p->M) {
-      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
+    if (p->T != p->M) {
+      // marking + a snapshot of the feature rows the table entries read, on M; the table MLP on T from the snapshot:
+      // M is free for the next frame's upsert .. marking chain while this frame's table kernel runs
+      rc = bnv_decode_lattice_stamped_mark(vol, &g, vol->features, vol->weights, vol->row_capacity, b.grid_ids,
+                                           c.out_capacity, &b.counters->n_out, lattice_ws, lattice_ws_bytes,
+                                           lattice_epoch, p->M);
+      if (rc != BNV_OK) return rc;
+      BNV_HIP_CHECK(hipEventRecord(p->ev_mark[slot], p->M));
+      BNV_HIP_CHECK(hipStreamWaitEvent(p->T, p->ev_mark[slot], 0));
+      rc = bnv_decode_lattice_snapshot_table(vol, &g, sdfmlp_pack, c.out_capacity, lattice_ws, lattice_ws_bytes,
+                                             c.table_workgroups, p->T);
+      if (rc != BNV_OK) return rc;
+      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->T));
       BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
+    } else {
+      rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+                                             b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
+                                             lattice_ws_bytes, lattice_epoch, p->M);
+      if (rc != BNV_OK) return rc;
+      if (p->B != p->M) {
+        BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
+        BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
+      }
     }
     // the blend reads the workspace only: on B it leaves M to the next frame's upsert
     rc = bnv_lattice_blend(vol, &g, b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws, lattice_ws_bytes,

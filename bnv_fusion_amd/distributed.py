@@ -25,6 +25,7 @@ FRAME-PARALLEL (throughput of one frame stream; ``FrameParallelNeuralMap``, belo
 The frame logic talks to a backend; ``HipShardBackend`` / ``HipFrameBackend`` are the product backends (HIP kernels).
 tests/test_distributed_cpu.py drives the same logic over gloo with CPU backends of its own.
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -185,6 +186,16 @@ class HipShardBackend:
         self.pipe.sdf_delta = self.sdf_delta
         return self.pipe
 
+    def stream_context(self, frame):
+        """Context every phase of a frame (and the caller's all-gather between them) runs under.  With CU-masked
+        pipeline streams the pipe runs on a main stream of its own when the caller's is the legacy default stream
+        (FramePipe: masked streams are blocking streams); the caller's stream is ordered before it unless the frames
+        are declared resident."""
+        pipe = self._pipe_for(frame)
+        if pipe.own_main and not self.inputs_resident:
+            pipe.main.wait_stream(torch.cuda.current_stream(self.volume._dev))
+        return pipe.stream_context()
+
     # ---- phases ---------------------------------------------------------------------------------
     def encode(self, frame):
         """Encode stream: voxelise the whole frame (replicated), the exchange bounds to pinned memory, the point
@@ -336,7 +347,8 @@ class ShardedNeuralMap:
             need = 1 + (1 if ahead else 0) - (1 if self._pre is not None else 0)
             while self._open and len(self._open) + (1 if self._pre is not None else 0) + need > ring:
                 self._open.pop(0).result()            # the slot ring is full: collect the oldest frame
-        with torch.no_grad():
+        ctx = be.stream_context(frame) if hasattr(be, "stream_context") else contextlib.nullcontext()
+        with torch.no_grad(), ctx:
             if self._pre is not None:
                 if self._pre[0] is not frame:
                     raise _lib.BnvError("fuse_and_decode_async: the frame announced as next_frame must be the next one passed")

@@ -171,7 +171,7 @@ class NeuralMap:
         while pipe.free_slot() is None:                 # every slot holds an uncollected frame: collect the oldest
             self._pipe_open.pop(0).result()
         if self._vol_ev is not None:                    # a synchronous integrate()'s TSDF update on the caller's stream
-            pipe.enc.wait_event(self._vol_ev)
+            pipe.tsdf_stream.wait_event(self._vol_ev)
             self._vol_ev = None
         with torch.no_grad():
             slot = pipe.begin(frame)

@@ -30,9 +30,17 @@ class FramePipe:
     # stream's chain (upsert -> exchange -> install -> mark) runs beside it; all CUs otherwise.  BNV_PIPE_ENCODER_WGS
     # overrides (0 = all CUs).
     ENCODER_SHARE_SHARDED = 0.75
+    # Five streams with CU-masked encoder and table streams (csrc/pipeline.hip): CUs of the table kernel, CUs of the
+    # encoder; the rest belongs to nobody (the chain's 1,024-thread kernels cannot share a CU with either MLP kernel).
+    # BNV_PIPE_CU_SPLIT="table,encoder" overrides; "0" = the four-stream schedule.
+    # Measured (profiles/r04_cu_mask_experiment.txt): the partition works, but a rank's frame gets SLOWER (0.29-0.33
+    # against 0.263 ms at world 8): with both MLP kernels resident all the time the chain's 1,024-thread kernels find
+    # too few CUs.  Opt-in therefore (cu_split=(160, 64), multiples of 32: an equal number of CUs per shader engine --
+    # other counts leave workgroups of the persistent kernels waiting for a CU and double their time).
+    CU_SPLIT_SHARDED = None
 
     def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None,
-                 streams=4, encoder_workgroups=None):
+                 streams=4, encoder_workgroups=None, cu_split=None):
         from .frontend import DEPTH_DTYPES
         self._dtypes = DEPTH_DTYPES
         self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
@@ -50,13 +58,48 @@ class FramePipe:
         from .streams import concurrent_stream
         import os
         self.main = torch.cuda.current_stream(dev)
-        self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
+        self._masked = []                                     # CU-masked streams this pipe created (destroyed with it)
+        split = os.environ.get("BNV_PIPE_CU_SPLIT")
+        if split is not None:
+            split = tuple(int(x) for x in split.split(",")) if split not in ("", "0") else None
+        elif cu_split is not None:
+            split = tuple(cu_split) if cu_split else None
+        else:
+            split = self.CU_SPLIT_SHARDED if (self.world > 1 and int(os.environ.get("BNV_PIPE_STREAMS", streams)) >= 4
+                                              and _lib.model_mode(pointnet) != 2) else None
+        cus = int(lib.bnv_num_compute_units())
+        if split is not None and (len(split) != 2 or min(split) < 1 or sum(split) > cus):
+            raise ValueError(f"FramePipe: CU split {split} does not fit {cus} CUs")
+        self.cu_split = split
+        # hipExtStreamCreateWithCUMask makes BLOCKING streams: every operation on the legacy default stream (torch's
+        # default "current stream") waits for them and holds them back in turn (measured: 1.2 ms per frame instead of
+        # 0.27).  The pipe then runs on a main stream of its own; callers enter it through stream_context() (the
+        # sharded backend does), and nothing of a frame may touch the default stream.
+        self.own_main = split is not None and self.main.cuda_stream == 0
+        if self.own_main:
+            # (high priority: the chain on it is the frame's critical path; front end and blend run ahead / behind)
+            self.main = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BNV_PIPE_MAIN_PRIORITY", -1)))
+        if split is not None:
+            # table kernel on CUs [0, t), encoder on [t, t + e) of the device's enumeration (which interleaves the
+            # XCDs: each set takes an equal share of every XCD)
+            self.table = self._masked_stream(range(0, split[0]), cus)
+            self.enc = self._masked_stream(range(split[0], split[0] + split[1]), cus)
+            encoder_workgroups = split[1]
+        else:
+            self.enc = concurrent_stream(dev, self.main)      # verified to overlap the main stream
         # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four)
         streams = int(os.environ.get("BNV_PIPE_STREAMS", streams))
         self.front = self.blend = None
-        if streams >= 4:
+        if split is None:
+            self.table = None
+        if streams >= 4 or split is not None:
             self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
             self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
+        # streams = 5 WITHOUT masks (BNV_PIPE_STREAMS=5, BNV_PIPE_CU_SPLIT=0): the table MLP on an ordinary stream of
+        # its own.  Correct but slower than four streams: with both MLP kernels in flight all the time and nothing
+        # reserving CUs, the chain's small kernels crawl (profiles/r04_fifth_stream_experiment.txt).
+        if streams >= 5 and split is None:
+            self.table = concurrent_stream(dev, self.main, exclude=(self.enc, self.front, self.blend))
         self.double_buffered = self.front is not None
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
@@ -64,6 +107,9 @@ class FramePipe:
                 cus = int(lib.bnv_num_compute_units())
                 encoder_workgroups = int(cus * self.ENCODER_SHARE_SHARDED) if (self.world > 1 and streams >= 4) else 0
         self.encoder_workgroups = int(encoder_workgroups)
+        # five streams: both MLP kernels are in flight all the time and their workgroup counts partition the CUs (the
+        # encoder's and the table kernel's share of a frame's MLP work, a few CUs left to the small kernels)
+        self.table_workgroups = split[0] if split is not None else int(os.environ.get("BNV_PIPE_TABLE_WGS", 0))
         res = v._n_xyz_host
         nvox = res[0] * res[1] * res[2]
         self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)
@@ -114,6 +160,9 @@ class FramePipe:
         if self.double_buffered:
             cfg.enc_ws2 = self._enc_ws2.data_ptr()
             cfg.front_stream, cfg.blend_stream = self.front.cuda_stream, self.blend.cuda_stream
+            if self.table is not None:
+                cfg.table_stream = self.table.cuda_stream
+                cfg.table_workgroups = self.table_workgroups
         cfg.encoder_workgroups = self.encoder_workgroups
         self._cfg = cfg
         h = C.c_void_p()
@@ -126,15 +175,53 @@ class FramePipe:
         self._epoch = [0] * S
         self._lws = [None] * S
         self._lws_next = 0           # decode workspace of the next frame upserted (two alternate with a blend stream)
+        # with a table stream, three: a frame's upsert (which stamps into the workspace) then waits for the blend of
+        # the frame THREE back, not two -- with two the chain of frame t+2 could only start behind table(t) + blend(t)
+        # and the table stream idled for the rest of that chain
+        self.n_lattice_ws = int(os.environ.get("BNV_PIPE_LATTICE_WS", 3 if self.table is not None else 2))
         self._words = (C.c_int32 * HOST_WORDS)()
         self._keep = [None] * S
         self.inputs_resident = False
+        torch.cuda.synchronize(dev)      # the zero-filled buffers above are complete before any other stream uses them
+
+    def stream_context(self):
+        """Context in which the caller drives the pipe (and everything between its phases): the pipe's own main stream
+        when it has one (CU-masked streams, see __init__), nothing otherwise."""
+        import contextlib
+        return torch.cuda.stream(self.main) if self.own_main else contextlib.nullcontext()
+
+    @property
+    def tsdf_stream(self):
+        """The stream the TSDF side fusion of a frame runs on (a synchronous TSDF update on another stream must be
+        ordered before it): the blend stream with a table stream, the encode stream otherwise (csrc/pipeline.hip)."""
+        return self.blend if self.table is not None else self.enc
+
+    def _masked_stream(self, cu_ids, cus):
+        words = (cus + 31) // 32
+        mask = (C.c_uint32 * words)()
+        for i in cu_ids:
+            mask[i // 32] |= 1 << (i % 32)
+        out = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(self._lib.bnv_stream_create_cu_mask(words, mask, C.byref(out)), "bnv_stream_create_cu_mask")
+        self._masked.append(out.value)
+        st = torch.cuda.ExternalStream(out.value, device=self.dev)
+        st.bnv_concurrent = True          # a queue of its own
+        return st
+
+    def close(self):
+        """Destroys the C object and the CU-masked streams (every frame must have been collected)."""
+        if getattr(self, "_h", None):
+            self._lib.bnv_frame_pipe_destroy(self._h)
+            self._h = None
+        for h in getattr(self, "_masked", []):
+            torch.cuda.synchronize(self.dev)
+            self._lib.bnv_stream_destroy(C.c_void_p(h))
+        self._masked = []
 
     def __del__(self):
         try:
-            if getattr(self, "_h", None):
-                self._lib.bnv_frame_pipe_destroy(self._h)
-                self._h = None
+            self.close()
         except Exception:
             pass
 
@@ -216,8 +303,9 @@ class FramePipe:
         self._decode[slot] = bool(decode)
         lws = None
         if decode:
-            lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0)
-            self._lws_next ^= 1
+            lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0,
+                                                          snapshot=self.table is not None)
+            self._lws_next = (self._lws_next + 1) % self.n_lattice_ws
         self._lws[slot] = lws
         ws = v._workspace(self.cap)
         _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),

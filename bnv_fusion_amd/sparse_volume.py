@@ -498,17 +498,23 @@ class SparseVolume:
                    "bnv_decode_lattice")
         return out
 
-    def _lattice_workspace(self, n, which=0):
+    def _lattice_workspace(self, n, which=0, snapshot=False):
         """(workspace of the lattice decode for up to n voxels, a fresh epoch).  Re-made (zero-filled) when the volume
         grows: its front part is indexed by row.  ``which`` = 1: a second workspace -- the frame pipeline alternates
-        two, so that a frame's blend (on a stream of its own) and the next frame's marking never share one."""
-        need = int(self._lib.bnv_decode_lattice_workspace_bytes(int(n), self._row_capacity))
+        two, so that a frame's blend (on a stream of its own) and the next frame's marking never share one.
+        ``snapshot``: with room for the feature snapshot of the five-stream pipeline (32 bytes per row at the end)."""
+        size = self._lib.bnv_decode_lattice_snapshot_workspace_bytes if snapshot else self._lib.bnv_decode_lattice_workspace_bytes
+        need = int(size(int(n), self._row_capacity))
         if which:
-            if self._lattice_ws2 is None or self._lattice_ws2.numel() < need:
-                self._lattice_ws2 = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
-            self._lattice_epoch += 1           # (one counter for both: each workspace sees increasing epochs)
-            self._lattice_last = self._lattice_ws2
-            return self._lattice_ws2, self._lattice_epoch
+            # (which = 1, 2, ..: further workspaces; the five-stream pipeline rotates three)
+            if self._lattice_ws2 is None:
+                self._lattice_ws2 = {}
+            ws = self._lattice_ws2.get(which)
+            if ws is None or ws.numel() < need:
+                ws = self._lattice_ws2[which] = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            self._lattice_epoch += 1           # (one counter for all: each workspace sees increasing epochs)
+            self._lattice_last = ws
+            return ws, self._lattice_epoch
         if self._lattice_ws is None or self._lattice_ws.numel() < need:
             # zero-filled: the per-row stamps at the front of the workspace must start at 0
             self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)

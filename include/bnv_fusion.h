@@ -312,6 +312,15 @@ int bnv_encode_finish_image_wg(const float* input_pts, int64_t n_points, int ima
                                float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids, int64_t* out_grid_ids,
                                int64_t out_capacity, int emit_all, bnv_encode_counters_t* counters,
                                int max_workgroups, bnv_stream_t stream);
+/* The same in two parts that may go to different streams (the caller orders them: part 2 behind part 1):
+ * parts & 1 = the point-encoder MLP + scatter, parts & 2 = finalize (mean, filter, ordered compaction, counters, clean
+ * workspace); parts = 3 is bnv_encode_finish_image_wg.  The frame pipeline with CU-masked streams keeps only the
+ * persistent MLP kernel on the encoder's share of the CUs. */
+int bnv_encode_finish_image_parts(const float* input_pts, int64_t n_points, int image_width,
+                                  const bnv_grid_t* grid_host, const float* pointnet_pack, void* ws, size_t ws_bytes,
+                                  int64_t ws_max_points, float* out_feats, int64_t* out_pcounts, int64_t* out_flat_ids,
+                                  int64_t* out_grid_ids, int64_t out_capacity, int emit_all,
+                                  bnv_encode_counters_t* counters, int max_workgroups, int parts, bnv_stream_t stream);
 size_t bnv_encode_shard_counts_offset(void);
 
 /* input_pts [n_points, 6] f32 (world xyz, world normal).
@@ -520,6 +529,22 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol_host, const bnv_gr
                                       const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
                                       bnv_stream_t stream);
 
+/* The same in two halves that may run on different streams: `_mark` = neighbour rows + live entries on `stream`, which
+ * also copies the feature row of every row that gets a table entry into the workspace (`ws` of
+ * bnv_decode_lattice_snapshot_workspace_bytes: the plain workspace + 32 bytes per row at its end); `_snapshot_table` =
+ * the table MLP reading that snapshot instead of the volume.  Behind `_mark` the volume's rows are free to change (the next
+ * frame's upsert) while the table kernel runs elsewhere -- results are those of the state `_mark` saw.  The caller
+ * orders `_snapshot_table` behind `_mark` (an event) and bnv_lattice_blend behind the table. */
+size_t bnv_decode_lattice_snapshot_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
+int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
+                                    const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
+                                    bnv_stream_t stream);
+/* max_workgroups: the persistent table kernel is launched on at most this many workgroups (one per CU; 0 = all) */
+int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
+                                      const float* sdfmlp_pack, int64_t n, void* ws, size_t ws_bytes,
+                                      int max_workgroups, bnv_stream_t stream);
+
 /* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
  * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
@@ -654,6 +679,22 @@ typedef struct bnv_frame_pipe_config {
   void* enc_ws2;
   bnv_stream_t front_stream, blend_stream;
   int32_t encoder_workgroups;
+  /*   table_stream  (with blend_stream) the table MLP of the decode runs here, reading a snapshot of the feature rows
+   *                 the marking kernel took (bnv_decode_lattice_stamped_mark / _snapshot_table; the decode workspaces
+   *                 passed to upsert / finish must then be bnv_decode_lattice_snapshot_workspace_bytes long):
+   *                 main_stream goes on to the next frame's upsert .. marking chain while the table kernel of this
+   *                 frame runs.  In this mode encode_stream carries NOTHING but the persistent point-encoder kernel --
+   *                 finalize runs at the head of the frame's chain on main_stream, the TSDF side fusion on
+   *                 blend_stream -- so that encode_stream and table_stream can be CU-masked streams
+   *                 (bnv_stream_create_cu_mask) with disjoint masks of encoder_workgroups / table_workgroups CUs: each
+   *                 MLP kernel owns its CUs, the rest (and whatever fits beside them) serves the small kernels.  A
+   *                 frame's upsert must be enqueued before the frame after the next one begins. */
+  bnv_stream_t table_stream;
+  /*   table_workgroups  with table_stream: workgroups of the persistent table kernel (0 = all CUs).  The two MLP kernels
+   *                 each fill a CU's LDS; with both in flight all the time (table of frame t beside the encoder of
+   *                 frame t+2) their workgroup counts PARTITION the CUs -- encoder_workgroups + table_workgroups should
+   *                 stay below the CU count so that the small kernels of the other streams always find a free CU. */
+  int32_t table_workgroups;
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;

@@ -51,12 +51,15 @@ def _run_pipe(pipe, frames, depth_in_flight, decode=True):
     return outs
 
 
+@pytest.mark.parametrize("cu_split", [None, (160, 64)])
 @pytest.mark.parametrize("in_flight", [1, 3])
 @pytest.mark.parametrize("kind", ["depth", "points"])
-def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind):
+def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, cu_split):
     """One GPU: the pipe's outputs, volume and TSDF volume equal NeuralMap.fuse_and_decode's, frame by frame, with
     one or several frames in flight (slots reused: 14 frames through 4 slots), from depth images (front end fused,
-    TSDF side fusion) and from input_pts; an empty frame in the middle."""
+    TSDF side fusion) and from input_pts; an empty frame in the middle.  ``cu_split``: the five-stream schedule on
+    CU-masked streams (table MLP from a feature snapshot on 160 CUs, encoder on 64, finalize on the main stream, TSDF
+    on the blend stream, three decode workspaces, the pipe on a main stream of its own)."""
     from bnv_fusion_amd import synthetic
     from bnv_fusion_amd.frontend import depth_to_input_pts
     from bnv_fusion_amd.pipeline import FramePipe
@@ -82,8 +85,12 @@ def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind):
     if tsdf:
         mn, mx, _ = get_world_range(dims3, 0.025)
         tv = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=DEV)
-    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv)
-    got = _run_pipe(pipe, frames, in_flight)
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv, cu_split=cu_split)
+    assert pipe.cu_split == cu_split and (pipe.table is not None) == (cu_split is not None)
+    assert pipe.own_main == (cu_split is not None)      # the tests run on the legacy default stream
+    with pipe.stream_context():
+        got = _run_pipe(pipe, frames, in_flight)
+    torch.cuda.synchronize()
     for t, ((rc, rs), (gc, gs)) in enumerate(zip(ref, got)):
         if rc is None:
             assert gc is None and gs is None and t == 5
@@ -99,6 +106,7 @@ def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind):
     assert vol.n_frames == ref_nm.volume.n_frames and vol.n_pts_list == ref_nm.volume.n_pts_list
     if tsdf:
         assert torch.equal(tv.tsdf, ref_nm.tsdf_vol.tsdf) and torch.equal(tv.weight, ref_nm.tsdf_vol.weight)
+    pipe.close()
 
 
 def test_frame_pipe_grows_the_volume_mid_stream(bnv):

@@ -32,11 +32,15 @@ ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
 ap.add_argument("--trace", action="store_true", help="HIP-event timeline of the two streams over a few frames")
 ap.add_argument("--reserve", type=int, default=0, help="CUs the persistent MLP kernels leave to other streams")
 ap.add_argument("--ownership", default=None, help="ownership rule of the shards (default: the package's)")
+ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-masked five-stream schedule; 0 = four streams "
+                "(default: the package's)")
 ap.add_argument("--no-latency", action="store_true")
 ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode is enqueued before the host waits for "
                 "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
 ap.add_argument("--json", action="store_true", help="(internal) print the rank's figures as one JSON line at the end")
 args = ap.parse_args()
+if args.cu_split is not None:
+    os.environ["BNV_PIPE_CU_SPLIT"] = args.cu_split
 W = args.world
 
 if args.all_ranks:
@@ -179,7 +183,7 @@ def price(rank, latency):
             collect(pend.pop(0))
 
     out = {}
-    with torch.no_grad():
+    with torch.no_grad(), be.stream_context(frames[0]):
         run(range(30), 2, decode=False)
         run(range(30, 38), 2)
         idx = [30 + (i % POOL) for i in range(args.frames)]
@@ -221,8 +225,8 @@ def price(rank, latency):
         pp = be.pipe
         print("  pipeline streams verified concurrent with the main stream and with one another: " + ", ".join(
             f"{n} {getattr(st, 'bnv_concurrent', None)}" for n, st in (("encode", pp.enc), ("front", pp.front),
-                                                                     ("blend", pp.blend)) if st is not None)
-              + f"; encoder workgroups {pp.encoder_workgroups}")
+                                                                     ("blend", pp.blend), ("table", pp.table)) if st is not None)
+              + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}; CU split {pp.cu_split}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
         if args.trace:
