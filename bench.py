@@ -222,7 +222,7 @@ def cpu_baseline(depth_mm, intr, T_wc, grid, n_decode_voxels=1500):
         vol.decode_pts(orc.lattice_coords(sel.numpy()), sd, None, is_coords=True, query_tensor=False)
         t_dec = (time.perf_counter() - t0) * len(g) / len(sel)
     total = t_front + t_enc + t_int + t_dec
-    return {"value": 1.0 / total, "unit": "frames/s", "cores": os.cpu_count(), "threads_used": threads, "kind": "port",
+    return {"value": 1.0 / total, "unit": "frames/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": (f"oracle (PyTorch-CPU fp32 restatement, {threads} threads -- the fastest of a probe -- on a host "
                        f"with {os.cpu_count()} cores; numpy float64 front end): 1 full "
                        f"640x480 frame depth->points {t_front:.2f}s + encode {t_enc:.2f}s + integrate {t_int:.2f}s + "

@@ -289,6 +289,54 @@ def test_side_streams_are_verified_to_overlap():
     assert t.cuda_stream not in (main.cuda_stream, s.cuda_stream)
 
 
+def test_cu_masked_streams_partition_the_gpu():
+    """bnv_stream_create_cu_mask: a stream masked to a quarter of the CUs serves 16 single-wave spin workgroups per CU
+    of the DEVICE in about twice the time the whole device needs (a CU holds 32 waves), two streams with disjoint masks
+    run side by side, bad arguments are refused."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib
+    lib = _lib.require_device(0)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (cus + 31) // 32
+
+    def masked(bits):
+        m = (C.c_uint32 * words)()
+        for b in bits:
+            m[b // 32] |= 1 << (b % 32)
+        out = C.c_void_p()
+        _lib.check(lib.bnv_stream_create_cu_mask(words, m, C.byref(out)), "bnv_stream_create_cu_mask")
+        return out.value, torch.cuda.ExternalStream(out.value, device=torch.device(DEV))
+
+    def timed(streams, blocks):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+        torch.cuda.synchronize()
+        for (a, b), st, n in zip(ev, streams, blocks):
+            a.record(st)
+            _lib.check(lib.bnv_probe_spin(n, 100_000, C.c_void_p(st.cuda_stream)), "bnv_probe_spin")
+            b.record(st)
+        torch.cuda.synchronize()
+        return max(ev[0][0].elapsed_time(b) for _, b in ev)
+
+    plain = torch.cuda.Stream(device=DEV)
+    hq, quarter = masked(range(cus // 4))
+    hr, rest = masked(range(cus // 4, cus))
+    for st in (plain, quarter, rest):
+        timed([st], [16 * cus])
+    whole = min(timed([plain], [16 * cus]) for _ in range(3))
+    part = min(timed([quarter], [16 * cus]) for _ in range(3))
+    assert 1.6 * whole < part < 2.6 * whole, (whole, part)
+    both = min(timed([quarter, rest], [4 * cus, 12 * cus]) for _ in range(3))      # 16 per CU of each mask: one round each
+    assert both < 1.5 * whole, (whole, both)
+    zero = (C.c_uint32 * words)()
+    out = C.c_void_p()
+    assert lib.bnv_stream_create_cu_mask(words, zero, C.byref(out)) != 0               # no CU named
+    assert lib.bnv_stream_create_cu_mask(words - 1, zero, C.byref(out)) != 0           # does not cover the device
+    assert lib.bnv_stream_create_cu_mask(words, None, C.byref(out)) != 0 and lib.bnv_stream_destroy(None) != 0
+    torch.cuda.synchronize()
+    for h in (hq, hr):
+        _lib.check(lib.bnv_stream_destroy(C.c_void_p(h)), "bnv_stream_destroy")
+
+
 def test_frame_pipe_integrate_only_frames_and_tsdf_prior(bnv):
     """FramePipe with frames that are only fused (decode=False: run_e2e.py's integrate) followed by frames decoded WITH
     the TSDF prior (sdf_delta, sparse_volume.py:819-832) and a smaller frame in between: equal to NeuralMap."""

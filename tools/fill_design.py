@@ -54,7 +54,7 @@ tok = {
     "roofline": f"{ro['flop_per_launch'] / 1e12:.3f} TFLOP algorithmic per launch ÷ {ro['avg_kernel_ms']:.3f} ms = {ro['achieved']:.0f} TFLOP/s = **{ro['frac']:.3f}** of the 2.5 PF f16 peak; the box's MFMA-only ceiling (`power_limited_mfma_ceiling`): " + (f"{ro['power_limited_mfma_ceiling']['tflops_16x16x32_random_f16_operands']:.0f} TFLOP/s, the kernel issues {ro['power_limited_mfma_ceiling']['dominant_kernel_frac_of_it']:.2f} of it" if ro.get("power_limited_mfma_ceiling") else "n/a"),
     "traffic": (f"{ro['traffic'] / 1e6:.1f} MB/launch against {40 * ro['mlp_evals_per_launch'] / 1e6:.1f} MB algorithmic (40 B × evaluations)" if ro.get("traffic") else "not in this line (the PMC passes did not exist yet when it ran); `profiles/%s_README.md`: 2 × FETCH + WRITE per launch of the profiled run" % R),
     "parity": f"{d['parity']['sdf_max_abs_err_vs_oracle']:.1e}", "mode3": ", ".join(f"{o['value']:.0f} frames/s, SDF error {o['parity']['sdf_max_abs_err_vs_oracle']:.1e}" for o in d.get("other_mlp_modes", [])),
-    "cpu": f"{d['cpu_baseline']['value']:.4f} frames/s ({d['cpu_baseline']['threads_used']} threads of {d['cpu_baseline']['cores']} cores; ≈ {1 / d['cpu_baseline']['value']:.0f} s per frame, of which the 216-evaluations-per-voxel decode is {d['cpu_baseline']['decode_s_scaled']:.0f} s)",
+    "cpu": f"{d['cpu_baseline']['value']:.4f} frames/s ({d['cpu_baseline']['cores']} threads of the host's {d['cpu_baseline']['host_cores']} cores; ≈ {1 / d['cpu_baseline']['value']:.0f} s per frame, of which the 216-evaluations-per-voxel decode is {d['cpu_baseline']['decode_s_scaled']:.0f} s)",
     "tcnn": f"**{t['value']:.0f}** frames/s sustained ({t['ms_per_step']:.3f} ms/frame), {t['burst']['value']:.0f} burst; encoder {t['kernels']['pointnet_scatter']['avg_ms']:.3f} ms, table kernel {t['roofline']['avg_kernel_ms']:.3f} ms",
     "frame_sum": f"{ro['avg_kernel_ms']:.3f} + {d['kernels']['pointnet_scatter']['avg_ms']:.3f} ms of MLP kernels in a {d['ms_per_step']:.3f} ms frame; the nine other launches take {sum(us(ks, k) for k in ('k_front_mark', 'k_rank', 'k_finalize', 'k_vol_integrate<true>', 'k_tsdf_integrate', 'k_lattice_neighbors', 'k_lattice_mark', 'k_lattice_blend', 'k_readback_words')):.0f} µs alone (`profiles/{R}_bench_kernel_stats.csv`)",
     "balance": f"{ft256['voxels owned']:.3f} / {ft256['pairs encoded']:.3f} / {ft256['MLP evaluations']:.3f} at 256³ and {ft512['voxels owned']:.3f} / {ft512['pairs encoded']:.3f} / {ft512['MLP evaluations']:.3f} at 512³ (block hash: {hs['voxels owned']:.3f} / {hs['pairs encoded']:.3f} / {hs['MLP evaluations']:.3f})",

@@ -30,7 +30,9 @@ def agg(d):
 
 stats = glob.glob(f"{src}/trace/**/*kernel_stats.csv", recursive=True)[0]
 shutil.copy(stats, f"{dst}/{R}_bench_kernel_stats.csv")
-d = last_json(f"{src}/bench_line.json")
+# (bench_line_with_traffic.json: `python bench.py` run again AFTER this script has written the PMC summary, so that its
+# roofline.traffic is filled from it; preferred when present)
+d = last_json(f"{src}/bench_line_with_traffic.json" if os.path.exists(f"{src}/bench_line_with_traffic.json") else f"{src}/bench_line.json")
 dt = last_json(f"{src}/bench_line_tcnn.json")
 dp = last_json(f"{src}/trace_stdout.log")
 for name, obj in (("bench_line", d), ("bench_line_tcnn", dt), ("bench_line_profiled_run", dp)):
@@ -112,7 +114,7 @@ with open(f"{dst}/{R}_README.md", "w") as f:
         fe.get("value", 0), fe.get("roofline", {}).get("frac", 0), gr.get("value", 0), gr.get("frames", 0),
         sq.get("frames", 0), sq.get("value", 0), sq.get("rows_end", 0), ", ".join("%.1e" % c["sdf_max_abs_err"] for c in sq.get("parity_checks", sq.get("oracle_checks", []))),
         d["parity"]["voxels_checked"], d["parity"]["sdf_max_abs_err_vs_oracle"], d["parity"]["mask_decisions_equal"],
-        d.get("cpu_baseline", {}).get("value", 0), d.get("cpu_baseline", {}).get("threads_used", 0), d.get("cpu_baseline", {}).get("cores", 0)))
+        d.get("cpu_baseline", {}).get("value", 0), d.get("cpu_baseline", {}).get("cores", 0), d.get("cpu_baseline", {}).get("host_cores", 0)))
     W(f"* `{R}_bench_line_tcnn.json` -- the same with `--checkpoint tcnn` (the reference's default tiny-cuda-nn networks): {dt['value']:.1f} frames/s sustained ({dt['ms_per_step']:.3f} ms/frame), {dt.get('burst', {}).get('value', 0):.1f} burst; encoder {dt['kernels']['pointnet_scatter']['avg_ms']:.3f} ms, lattice-table kernel {dt['roofline']['avg_kernel_ms']:.3f} ms.\n")
     tst = glob.glob(f"{src}/trace_tcnn/**/*kernel_stats.csv", recursive=True)
     if tst:
