@@ -26,16 +26,16 @@
 // (encoder_workgroups) so that the chain's small kernels find free CUs while it runs -- they cannot share a CU with
 // it (LDS, registers).  A cycle is then ~ [encoder(t+1) beside chain(t)] + table(t).
 //
-// FIVE streams (table_stream; the sharded pipeline's default where CU-masked streams are available).  The cycle above
-// still has the two MLP kernels take turns.  With the table MLP on a stream T of its own -- reading a SNAPSHOT of the
-// feature rows its entries need, taken by the marking kernel, so that the next frame's upsert may change the volume
-// meanwhile -- three things run at once in the steady state: table(t) on T, the chain of frame t+1 on M, the encoder
-// of frame t+2 on E.  Left to the dispatcher that is slower (the two persistent kernels grab every CU and the chain
-// starves: profiles/r04_fifth_stream_experiment.txt); with E and T created as CU-MASKED streams
-// (bnv_stream_create_cu_mask) of disjoint CU sets, sized by the two kernels' share of a frame's MLP work, and a few
-// CUs left to nobody, every stream always has somewhere to run.  E then carries nothing but the encoder kernel:
-// finalize moves to the head of the frame's chain on M, the TSDF side fusion (gated by finalize's point count) to B.
-// A cycle is max(table on its CUs, encoder on its CUs, chain).
+// FIVE streams (table_stream; OPT-IN: measured slower, see below).  The cycle above still has the two MLP kernels take
+// turns.  With the table MLP on a stream T of its own -- reading a SNAPSHOT of the feature rows its entries need, taken
+// by the marking kernel, so that the next frame's upsert may change the volume meanwhile -- three things run at once
+// in the steady state: table(t) on T, the chain of frame t+1 on M, the encoder of frame t+2 on E; E and T are meant to
+// be CU-MASKED streams (bnv_stream_create_cu_mask) of disjoint CU sets.  E then carries nothing but the encoder
+// kernel: finalize moves to the head of the frame's chain on M, the TSDF side fusion (gated by finalize's point
+// count) to B.  Measured (profiles/r04_cu_mask_experiment.txt, r04_fifth_stream_experiment.txt): both MLP kernels run
+// at the pace their CU share predicts, but the chain's small latency-bound kernels, squeezed into the wave slots the
+// persistent kernels leave, run 3-6 x slower (the blend, which fits beside the table kernel, 12 -> 60 us;
+// k_vol_integrate 14 -> 83 us) and bound the frame: 0.29-0.33 ms against 0.263 ms with four streams.
 //
 // E of frame t+1 depends on the frame only; the host wait for the bound of frame t+1 (bnv_frame_bound) returns
 // while M still holds most of frame t, and the GPU never waits for the host.  Nothing here allocates device memory;

@@ -708,7 +708,9 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* pipe);
 /* Arithmetic mode (bnv_grid_t.mlp_mode encoding) of the frames begun from now on; a frame in flight keeps the mode it
  * was begun with through its decode.  The mode config.grid carried at creation applies until this is called. */
 int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* pipe, int32_t grid_mlp_mode);
-/* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL */
+/* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL.  The
+ * device buffers of a frame (depth, color_im, input_pts) are read by kernels enqueued up to the frame's bnv_frame_upsert
+ * (the TSDF side fusion, finalize with a table_stream): they must stay valid until the frame's result is in. */
 int bnv_frame_begin_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
                           const double* intr_host, const double* T_wc_host, const float* color_im);
 int bnv_frame_begin_points(bnv_frame_pipe_t* pipe, int slot, const float* input_pts, int64_t n_points);

@@ -68,7 +68,7 @@ with open(f"{dst}/{R}_pmc_summary.csv", "w") as f:
             for c, x in v.items():
                 f.write(f"\"{k}\",{c},{sum(x)/len(x):.6e},{len(x)}\n")
                 pm[(k, c)] = sum(x) / len(x)
-commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("BNV_COMMIT", "")   # (no .git on the GPU box: tools/run_profiles.sh passes it)
 # the source the PMC passes saw (written on the GPU box by run_profiles.sh): bench.py drops the traffic figure when
 # csrc/decode.hip no longer is that file
 sha_path = f"{src}/decode_hip.sha256"

@@ -38,4 +38,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_sp8 -o sp8 -- p
 python3 tools/fp_single_rank.py --replay 8 > $O/fp_replay8.txt 2>&1
 # functional only: both multi-GPU decompositions as two gloo ranks sharing this GPU (no RCCL: it refuses two ranks per GPU)
 BNV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --no-cpu-baseline 2> $O/bench_line_2rank_gloo.err | tail -1 > $O/bench_line_2rank_gloo.json
+# the PMC summary of THIS run -> profiles/ of this copy, then the default bench line once more: its roofline.traffic comes from
+# that summary (bench.py refuses one taken from another csrc/decode.hip); locally `python tools/make_profiles.py $R` rebuilds
+# the same files from gpurun_out/
+python3 tools/make_profiles.py $R > $O/make_profiles.log 2>&1
+python3 bench.py > $O/bench_line_with_traffic.json 2> $O/bench_line_with_traffic.err
 ls -la $O
