@@ -9,9 +9,15 @@ bnv.configure_runtime()      # 8 hardware queues, before the first HIP call (str
 from bnv_fusion_amd import synthetic
 from bnv_fusion_amd.distributed import FrameParallelNeuralMap
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=60); ap.add_argument("--replay", type=int, default=1); ap.add_argument("--ahead", type=int, default=3); ap.add_argument("--reserve", type=int, default=0); ap.add_argument("--split", action="store_true"); args = ap.parse_args()
-with socket.socket() as s:
-    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+for _try in range(8):     # (a free port can be taken between the probe and the store's listen: try another)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        break
+    except Exception as e:
+        if "EADDRINUSE" not in str(e) or _try == 7:
+            raise
 dims, voxel = synthetic.GRID_DIMS[256]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel)
 frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)} for t in range(30 + args.frames)]

@@ -78,9 +78,15 @@ if args.all_ranks:
     m = np.array([o["ms_med"] for o in rows])
     print(f"  median segments: mean {m.mean():.3f}, MAX {m.max():.3f} (rank {int(m.argmax())}) -> {1e3 / m.max():.0f} frames/s")
     raise SystemExit(0)
-with socket.socket() as s:
-    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+for _try in range(8):     # (a free port can be taken between the probe and the store's listen: try another)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    try:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        break
+    except Exception as e:
+        if "EADDRINUSE" not in str(e) or _try == 7:
+            raise
 dims, voxel = synthetic.GRID_DIMS[args.grid]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.checkpoint == "tcnn")
 POOL = 64
