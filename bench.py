@@ -674,7 +674,11 @@ def run_bench(args, rank, world, dev, dist, backend):
         kinds = [k for k in kinds if k in results]       # (the first one that ran is `value`)
         if rank != 0:
             return None
-        DESCR = {"spatial": (f"active-voxel set sharded by spatial hash (8^3-voxel blocks) over {world} ranks; every "
+        from bnv_fusion_amd.distributed import DEFAULT_OWNERSHIP
+        rule = ("first-touch block ownership (8^3-voxel blocks, a new block goes to the least-loaded rank; every rank "
+                "derives the same table, no communication)" if DEFAULT_OWNERSHIP == "first_touch"
+                else "spatial hash of 8^3-voxel blocks")
+        DESCR = {"spatial": (f"active-voxel set sharded over {world} ranks by {rule}; every "
                              "rank voxelises the whole frame, encodes / upserts / decodes the voxels it owns; per frame "
                              "ONE RCCL all-gather of boundary-voxel records (48 B: key, weight, 8 features) and one host "
                              "wait (the exchange bound, read while the previous frame decodes); a step = one frame "

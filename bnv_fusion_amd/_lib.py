@@ -27,7 +27,7 @@ SYMBOLS = [
     "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
     "bnv_encode_finish_image_wg", "bnv_encode_finish_image_parts", "bnv_decode_lattice_snapshot_workspace_bytes", "bnv_decode_lattice_stamped_mark", "bnv_decode_lattice_snapshot_table", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
-    "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready",
+    "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready", "bnv_frame_pipe_timeline_enable", "bnv_frame_timeline",
 ]
 
 
@@ -241,6 +241,8 @@ def load():
         "bnv_frame_finish": (C.c_int, [vp, C.c_int, C.POINTER(Volume), vp, i64, vp, C.POINTER(SdfDelta), vp, sz, i32]),
         "bnv_frame_result": (C.c_int, [vp, C.c_int, C.POINTER(i32)]),
         "bnv_frame_ready": (C.c_int, [vp, C.c_int]),
+        "bnv_frame_pipe_timeline_enable": (C.c_int, [vp, C.c_int]),
+        "bnv_frame_timeline": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -96,6 +96,11 @@ struct bnv_frame_pipe {
     float K[9], T[16];
   } side[BNV_PIPE_MAX_SLOTS];
   hipEvent_t ev_fin[BNV_PIPE_MAX_SLOTS];   // finalize of the slot's frame is through (split mode)
+  // diagnostic timeline (bnv_frame_pipe_timeline_enable): timing events per slot and point, a base event
+  bool tl_on;
+  hipEvent_t tl_base;
+  hipEvent_t tl[BNV_PIPE_MAX_SLOTS][BNV_PIPE_TIMELINE_POINTS];
+  bool tl_set[BNV_PIPE_MAX_SLOTS][BNV_PIPE_TIMELINE_POINTS];
   int encws_slot[2];                       // the slot whose frame used the encode workspace last
 };
 
@@ -111,6 +116,13 @@ static void* slot_encws(const bnv_frame_pipe* p, int slot) {
 }
 
 static bool slot_ok(const bnv_frame_pipe* p, int slot) { return p && slot >= 0 && slot < p->cfg.n_slots; }
+
+// timeline point k of the slot's frame on `st` (nothing unless the diagnostic is on)
+static void tl_mark(bnv_frame_pipe* p, int slot, int k, hipStream_t st) {
+  if (!p->tl_on) return;
+  if (hipEventRecord(p->tl[slot][k], st) == hipSuccess) p->tl_set[slot][k] = true;
+  else (void)hipGetLastError();
+}
 
 extern "C" {
 
@@ -151,6 +163,13 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   // ordered through the blend's done event)
   p->T = (cfg->table_stream && cfg->blend_stream) ? (hipStream_t)cfg->table_stream : p->M;
   p->split = p->T != p->M;
+  p->tl_on = false;
+  p->tl_base = nullptr;
+  for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s)
+    for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k) {
+      p->tl[s][k] = nullptr;
+      p->tl_set[s][k] = false;
+    }
   p->bound_off = bnv_encode_shard_counts_offset();
   p->enc_next = 0;
   for (int k = 0; k < 2; ++k) {
@@ -206,6 +225,10 @@ int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* p, int32_t grid_mlp_mode) {
 
 int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
   if (!p) return BNV_OK;
+  if (p->tl_base) (void)hipEventDestroy(p->tl_base);
+  for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s)
+    for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k)
+      if (p->tl[s][k]) (void)hipEventDestroy(p->tl[s][k]);
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
     hipEvent_t evs[7] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s],
                          p->ev_fin[s]};
@@ -229,14 +252,25 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
                                  4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->F));
   }
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
+  tl_mark(p, slot, 1, p->F);
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
+  tl_mark(p, slot, 2, p->E);
   const bnv_grid_t g = slot_grid(p, slot);
   // split mode: E carries the persistent MLP kernel only; finalize heads the frame's chain on M (bnv_frame_upsert)
-  const int rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
-                                               c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
-                                               c.out_capacity, 0, b.counters, c.encoder_workgroups, p->split ? 1 : 3,
-                                               p->E);
+  // (with the timeline on, the two parts are enqueued separately so that a mark fits between them: the same launches)
+  const bool two = p->split || p->tl_on;
+  int rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
+                                         c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
+                                         c.out_capacity, 0, b.counters, c.encoder_workgroups, two ? 1 : 3, p->E);
   if (rc != BNV_OK) return rc;
+  tl_mark(p, slot, 3, p->E);
+  if (two && !p->split) {
+    rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
+                                       c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity,
+                                       0, b.counters, c.encoder_workgroups, 2, p->E);
+    if (rc != BNV_OK) return rc;
+  }
+  if (!p->split) tl_mark(p, slot, 4, p->E);
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
   if (!p->split)
     BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
@@ -264,6 +298,8 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
   p->enc_buf[slot] = buf;
   if (p->encws_used[buf] && p->F != p->E) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_encws[buf], 0));
   p->mlp_mode[slot] = p->cfg.grid.mlp_mode;   // the frame keeps the mode it starts under (bnv_frame_pipe_set_mlp_mode)
+  for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k) p->tl_set[slot][k] = false;
+  tl_mark(p, slot, 0, p->F);
   return BNV_OK;
 }
 
@@ -333,6 +369,7 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
   BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
+  tl_mark(p, slot, 5, p->M);
   if (p->split) {
     const bnv_grid_t g = slot_grid(p, slot);
     int rc = bnv_encode_finish_image_parts(p->pts[slot], p->n_points[slot], p->width[slot], &g, c.pointnet_pack,
@@ -341,6 +378,7 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
                                            c.encoder_workgroups, 2, p->M);
     if (rc != BNV_OK) return rc;
     BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->M));   // finalize has left the workspace clean
+    tl_mark(p, slot, 4, p->M);
     const bnv_frame_pipe::SideArgs& a = p->side[slot];
     if (a.on) {   // the TSDF side fusion, gated by the point count finalize wrote
       BNV_HIP_CHECK(hipEventRecord(p->ev_fin[slot], p->M));
@@ -392,6 +430,7 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   const int rc = bnv_volume_integrate_frame(vol, b.grid_ids, b.feats, b.pcounts, c.out_capacity, &b.counters->n_out,
                                             vol_ws, vol_ws_bytes, &x, p->M);
   if (rc != BNV_OK) return rc;
+  tl_mark(p, slot, 6, p->M);
   p->state[slot] = 2;
   return BNV_OK;
 }
@@ -417,10 +456,12 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   // the exchanged blocks are prefixes of the slots' send blocks: more records than those hold were never sent
   if (blocks && block_capacity > c.send_capacity) return BNV_ERR_INVALID_ARGUMENT;
   int rc;
+  tl_mark(p, slot, 7, p->M);
   if (c.grid.shard_world > 1 && blocks && block_capacity > 0) {
     rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
     if (rc != BNV_OK) return rc;
   }
+  tl_mark(p, slot, 8, p->M);
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
@@ -437,12 +478,14 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
                                              c.table_workgroups, p->T);
       if (rc != BNV_OK) return rc;
       BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->T));
+      tl_mark(p, slot, 9, p->T);
       BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
     } else {
       rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
                                              b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
                                              lattice_ws_bytes, lattice_epoch, p->M);
       if (rc != BNV_OK) return rc;
+      tl_mark(p, slot, 9, p->M);
       if (p->B != p->M) {
         BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
         BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
@@ -471,6 +514,7 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
                                  hipMemcpyDeviceToHost, p->B));
     BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->B));
   }
+  tl_mark(p, slot, 10, p->B);
   BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
   BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
   p->used[slot] = true;
@@ -494,6 +538,34 @@ int bnv_frame_ready(bnv_frame_pipe_t* p, int slot) {
   if (e == hipErrorNotReady) return 0;
   g_last_hip_error = (int)e;
   return BNV_ERR_HIP;
+}
+
+int bnv_frame_pipe_timeline_enable(bnv_frame_pipe_t* p, int on) {
+  if (!p) return BNV_ERR_INVALID_ARGUMENT;
+  if (!on) {
+    p->tl_on = false;
+    return BNV_OK;
+  }
+  if (!p->tl_base) {
+    BNV_HIP_CHECK(hipEventCreate(&p->tl_base));
+    for (int s = 0; s < p->cfg.n_slots; ++s)
+      for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k) BNV_HIP_CHECK(hipEventCreate(&p->tl[s][k]));
+  }
+  BNV_HIP_CHECK(hipEventRecord(p->tl_base, p->M));
+  p->tl_on = true;
+  return BNV_OK;
+}
+
+int bnv_frame_timeline(bnv_frame_pipe_t* p, int slot, float* ms_host) {
+  if (!slot_ok(p, slot) || !ms_host || !p->tl_base || p->state[slot] != 0) return BNV_ERR_INVALID_ARGUMENT;
+  for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k) {
+    ms_host[k] = __builtin_nanf("");
+    if (!p->tl_set[slot][k]) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p->tl_base, p->tl[slot][k]) == hipSuccess) ms_host[k] = ms;
+    else (void)hipGetLastError();
+  }
+  return BNV_OK;
 }
 
 }  // extern "C"

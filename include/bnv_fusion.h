@@ -723,6 +723,17 @@ int bnv_frame_finish(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_h
 int bnv_frame_result(bnv_frame_pipe_t* pipe, int slot, int32_t* words_host /* [BNV_PIPE_HOST_WORDS] or NULL */);
 /* 1: bnv_frame_result would not block; 0: the frame is still running */
 int bnv_frame_ready(bnv_frame_pipe_t* pipe, int slot);
+/* Diagnostic: GPU timestamps of a frame's stages (tools/spatial_single_rank.py --timeline).  _enable(1) creates timing
+ * events and records a base event on main_stream; every frame BEGUN afterwards records BNV_PIPE_TIMELINE_POINTS events
+ * on its streams; bnv_frame_timeline, called after bnv_frame_result of that frame and before its slot is begun again,
+ * returns their times in ms since the base (NaN: the frame did not pass that point).  Points: 0 front end starts,
+ * 1 exchange bound copied (front stream), 2 encoder starts, 3 encoder done, 4 finalize done, 5 upsert starts (the
+ * slot's encode has arrived on main_stream), 6 upsert done, 7 finish starts (the caller's all-gather is through),
+ * 8 ghost rows installed, 9 table MLP done (marking + table), 10 blend + read-back done.  The extra marker packets
+ * cost a few us per frame: off by default. */
+#define BNV_PIPE_TIMELINE_POINTS 11
+int bnv_frame_pipe_timeline_enable(bnv_frame_pipe_t* pipe, int on);
+int bnv_frame_timeline(bnv_frame_pipe_t* pipe, int slot, float* ms_host /* [BNV_PIPE_TIMELINE_POINTS] */);
 
 #ifdef __cplusplus
 }

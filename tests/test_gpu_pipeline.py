@@ -289,6 +289,47 @@ def test_side_streams_are_verified_to_overlap():
     assert t.cuda_stream not in (main.cuda_stream, s.cuda_stream)
 
 
+def test_frame_timeline_is_ordered_and_changes_nothing(bnv):
+    """bnv_frame_pipe_timeline_enable / bnv_frame_timeline: with the diagnostic on, every stage of a frame leaves a GPU
+    timestamp, in stage order on each stream; the frames' results are those of a pipe without it."""
+    import ctypes as C
+    from bnv_fusion_amd import _lib, synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(10)
+    outs = []
+    for on in (False, True):
+        vol = bnv.SparseVolume(8, voxel, dims3, 8, device=DEV)
+        pipe = FramePipe(vol, model, 240 * 320, n_slots=4)
+        lib = pipe._lib
+        assert lib.bnv_frame_timeline(pipe._h, 0, (C.c_float * 11)()) != 0          # never enabled
+        if on:
+            _lib.check(lib.bnv_frame_pipe_timeline_enable(pipe._h, 1), "enable")
+        res = []
+        for fr in frames:
+            s = pipe.begin(fr)
+            pipe.upsert(s)
+            pipe.finish(s)
+            if on:
+                assert lib.bnv_frame_timeline(pipe._h, s, (C.c_float * 11)()) != 0  # the frame has not been collected
+            c, sdf = pipe.outputs(s, pipe.result(s), copy=True)
+            res.append((c, sdf))
+            if on:
+                t = (C.c_float * 11)()
+                _lib.check(lib.bnv_frame_timeline(pipe._h, s, t), "bnv_frame_timeline")
+                t = np.array(t[:])
+                assert np.isfinite(t).all(), t
+                for a, b in ((0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10)):
+                    assert t[a] <= t[b], (a, b, t)      # (one frame at a time: the stages do not overlap other frames)
+                assert t[10] - t[0] < 50.0                                           # ms
+        outs.append(res)
+        pipe.close()
+    for (c0, s0), (c1, s1) in zip(*outs):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+
+
 def test_cu_masked_streams_partition_the_gpu():
     """bnv_stream_create_cu_mask: a stream masked to a quarter of the CUs serves 16 single-wave spin workgroups per CU
     of the DEVICE in about twice the time the whole device needs (a CU holds 32 waves), two streams with disjoint masks

@@ -66,6 +66,24 @@ tok = {
     if ratio >= 6.0 else ("NOT met (%.1f×; %.1f× with a 30 µs all-gather on top)" % (ratio, single_ms / (ft256['max'] + 0.03))),
     "fp_replay": (m.group(1) + " ms") if m else "see the file",
 }
+tl = open(P("spatial_world8_timeline.txt")).read()
+N = r"([\d.]+)"
+
+
+def g(pat):
+    return float(re.search(pat.replace("#", N), tl).group(1))
+
+
+v = {"up": g(r"finalize [\d.]+, upsert #,"), "ex": g(r"exchange \(host-enqueued\) #"), "ins": g(r"[\d.]+, install #"), "mt": g(r"marking \+ table #"),
+     "gap": g(r"table\(t\) done -> upsert\(t\+1\) starts #"), "cyc": g(r"cycle \(table done to table done\) #"),
+     "wall": g(r"pipelined wall clock\s+# ms") * 1e3, "enc": g(r"encoder #, finalize"), "slack": g(r"finalize done -> upsert starts #"),
+     "front": g(r"front end #")}
+tok["timeline"] = (
+    "upsert {up:.0f} µs → exchange {ex:.0f} (this tool's stand-in: one RCCL call on a one-rank group + three small launches) → "
+    "install {ins:.0f} → marking + table {mt:.0f} (table kernel ≈ 150: 6 rounds of 24 µs + 16 µs where 5.25 rounds of work exist, "
+    "§3.7) → {gap:.0f} µs until the next frame's upsert starts = the cycle ({cyc:.0f} µs with the timeline's marker events, {wall:.0f} "
+    "without).  The encoder ({enc:.0f} µs on 192 CUs, sharing the GPU with other frames' kernels) runs two frames ahead: finalize "
+    "is done {slack:.0f} µs before its upsert starts, the front end ({front:.0f} µs) before that").format(**v)
 src = open(os.path.join(root, "tools", "design_template.md")).read()
 missing = sorted(set(re.findall(r"@@(\w+)@@", src)) - set(tok))
 assert not missing, missing

@@ -29,6 +29,8 @@ python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-fl
 python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-flight 3 --grid 512 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512.txt
 python3 tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000 --in-flight 3 --ownership hash 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_hash.txt
 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world8.txt
+# GPU timestamps of every stage of 200 pipelined frames (bnv_frame_timeline): what the cycle consists of
+python3 tools/spatial_single_rank.py --world 8 --rank 1 --frames 1000 --in-flight 3 --no-latency --timeline 200 2>&1 | grep -v "$F" > $O/spatial_world8_timeline.txt
 BNV_PIPE_STREAMS=2 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --ahead 0 --ownership hash --frames 2000 2>&1 | grep -v "$F" > $O/spatial_world8_r03_schedule.txt
 python3 tools/spatial_single_rank.py --world 2 --all-ranks --frames 1000 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world2.txt
 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --frames 2000 --checkpoint tcnn 2>&1 | grep -v "$F" > $O/spatial_world8_tcnn.txt

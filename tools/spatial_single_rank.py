@@ -34,6 +34,8 @@ ap.add_argument("--reserve", type=int, default=0, help="CUs the persistent MLP k
 ap.add_argument("--ownership", default=None, help="ownership rule of the shards (default: the package's)")
 ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-masked five-stream schedule; 0 = four streams "
                 "(default: the package's)")
+ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
+                "pipelined frames after the timed run")
 ap.add_argument("--no-latency", action="store_true")
 ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode is enqueued before the host waits for "
                 "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
@@ -127,6 +129,7 @@ def price(rank, latency):
         return t4
 
     PRE = [None]      # (frame dict, ShardFrame) whose encode was enqueued ahead
+    TL_ON = [False]
 
     def begin(fr, nxt):
         """This frame's ShardFrame (begun now, or ahead by the previous call) and, with --ahead, the next frame's
@@ -171,8 +174,14 @@ def price(rank, latency):
         stats["enq"] += t6 - t0 - (t5 - t4)                          # (without the simulation of the other ranks)
         return h
 
+    TL = []
+
     def collect(h):
         c, s = be.result(h)
+        if TL_ON[0]:
+            a = (C.c_float * 11)()
+            _lib.check(lib.bnv_frame_timeline(be.pipe._h, h.slot, a), "bnv_frame_timeline")
+            TL.append(np.array(a[:], dtype=np.float64))
         stats["own"] += 0 if c is None else len(c)
         stats["evals"] += be._last_evals
         stats["pairs"] += be.last_owned_pairs
@@ -235,6 +244,31 @@ def price(rank, latency):
               + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}; CU split {pp.cu_split}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
+        if args.timeline:
+            torch.cuda.synchronize()
+            _lib.check(lib.bnv_frame_pipe_timeline_enable(be.pipe._h, 1), "timeline")
+            run(idx[:8], args.in_flight)                      # (frames begun before the switch carry no marks)
+            TL_ON[0] = True
+            TL.clear()
+            run(idx[8: 8 + args.timeline], args.in_flight)
+            TL_ON[0] = False
+            _lib.check(lib.bnv_frame_pipe_timeline_enable(be.pipe._h, 0), "timeline")
+            T = np.array(TL) * 1e3                            # us
+            names = ["front starts", "bound copied", "encoder starts", "encoder done", "finalize done", "upsert starts",
+                     "upsert done", "finish starts", "installed", "table done", "blend done"]
+            print(f"  stage timeline, GPU timestamps of {len(T)} pipelined frames (us; marker events cost a few us per frame):")
+            k0 = len(T) // 2
+            base = T[k0][0]
+            for k in range(k0, min(k0 + 5, len(T))):
+                print("    frame %d: " % (k - k0) + "  ".join(f"{n.split()[0][:5]}.{n.split()[-1][:5]} {T[k][i] - base:7.1f}" for i, n in enumerate(names)))
+            d = lambda a, b: float(np.nanmean(T[4:, a] - T[4:, b]))       # noqa: E731
+            x = lambda a, b: float(np.nanmean(T[5:, a] - T[4:-1, b]))     # noqa: E731  (frame t+1's point a - frame t's point b)
+            print(f"    durations: front end {d(1, 0):.1f}, encoder {d(3, 2):.1f}, finalize {d(4, 3):.1f}, upsert {d(6, 5):.1f}, "
+                  f"exchange (host-enqueued) {d(7, 6):.1f}, install {d(8, 7):.1f}, marking + table {d(9, 8):.1f}, blend + read-back {d(10, 9):.1f}")
+            print(f"    waits: bound copied -> encoder starts {d(2, 1):.1f}, finalize done -> upsert starts {d(5, 4):.1f}")
+            print(f"    across frames: cycle (table done to table done) {x(9, 9):.1f}; table(t) done -> upsert(t+1) starts {x(5, 9):.1f}; "
+                  f"encoder(t+1) starts - table(t) done {x(2, 9):.1f}; encoder(t+1) done - table(t) done {x(3, 9):.1f}; "
+                  f"front(t+1) starts - table(t) done {x(0, 9):.1f}; upsert(t+1) done -> table(t+1) starts is inside 'marking + table'")
         if args.trace:
             TRACE.clear()
             run(idx[:12], args.in_flight)
