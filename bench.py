@@ -412,13 +412,14 @@ class Driver:
         elif not self.args.sync_frames:
             # software pipeline: frame t is enqueued before frame t-1's result is collected, so the GPU never waits
             # for the host (each result() waits on that frame's own event only).  Frames enqueued ahead of the oldest
-            # uncollected one -- 1 GPU: 2 (the encode of frame t + 2, second stream, is always queued before frame
-            # t + 1's upsert / neighbour / mark chain starts: +5 % against 1, 3 brings no more); sharded: 3 (the
+            # uncollected one -- 1 GPU: 3 (2 is +5 % against 1; on the four-stream pipeline 3 is neutral for the fp32
+            # checkpoint, 546-551 frames/s either way on one box, and +0-2 % / +3-4 % burst with the tiny-cuda-nn
+            # networks, whose frame is short against the host's enqueue time); sharded: 3 (the
             # encode stream then runs a whole frame ahead of the main stream: 0.279 against 0.315 ms per frame at a
             # simulated world of 8)
             from collections import deque
             pending = deque()
-            depth = int(os.environ.get("BNV_BENCH_DEPTH", "3" if kind == "spatial" else "2"))
+            depth = int(os.environ.get("BNV_BENCH_DEPTH", "3"))
             _dbg = [] if os.environ.get("BNV_BENCH_DEBUG") else None
             for j, t in enumerate(idx):
                 _a = time.perf_counter()
