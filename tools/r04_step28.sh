@@ -1,4 +1,5 @@
 #!/bin/bash
+# (BNV_PIPE_CU_SHARED was a one-line experiment in pipeline.py -- both masks starting at CU 0 -- and is NOT in the tree: see profiles/r04_cu_mask_experiment.txt, finding 6)
 mkdir -p gpurun_out/r04/s28
 O=gpurun_out/r04/s28
 F="RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids"
