@@ -365,9 +365,9 @@ def test_cu_masked_streams_partition_the_gpu():
         timed([st], [16 * cus])
     whole = min(timed([plain], [16 * cus]) for _ in range(3))
     part = min(timed([quarter], [16 * cus]) for _ in range(3))
-    assert 1.6 * whole < part < 2.6 * whole, (whole, part)
+    assert 1.5 * whole < part < 3.0 * whole, (whole, part)
     both = min(timed([quarter, rest], [4 * cus, 12 * cus]) for _ in range(3))      # 16 per CU of each mask: one round each
-    assert both < 1.5 * whole, (whole, both)
+    assert both < 1.7 * whole, (whole, both)
     zero = (C.c_uint32 * words)()
     out = C.c_void_p()
     assert lib.bnv_stream_create_cu_mask(words, zero, C.byref(out)) != 0               # no CU named
