@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=None):
+def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=None, _tries=3):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -30,6 +30,9 @@ def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=Non
            "--mode", mode, "--grid", str(grid), "--frames", str(frames), "--height", str(hw[0]), "--width", str(hw[1]),
            "--checkpoint", checkpoint, "--out", str(out)] + (["--ownership", ownership] if ownership else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and _tries > 1 and "EADDRINUSE" in (r.stdout + r.stderr):
+        # the free port found above was taken before the rendezvous store listened on it: once more with another
+        return _launch(world, mode, grid, frames, out, hw, checkpoint, ownership, _tries - 1)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load(os.path.join(out, f"rank{k}.pt"), weights_only=False) for k in range(world)]
 
