@@ -195,4 +195,16 @@ with open(f"{dst}/{R}_README.md", "w") as f:
             extra.append(f"* `{R}_{t}.txt` -- {what}.")
     if extra:
         W("\n" + "\n".join(extra) + "\n")
+    # records written by hand or by their own tools (kept as they are; listed when present)
+    notes = []
+    for t, what in (("spatial_world8_timeline", "`tools/spatial_single_rank.py --timeline 200`: GPU timestamps of every stage of the sharded frame (`bnv_frame_timeline`): what the cycle consists of"),
+                    ("cu_mask_probe", "`tools/cu_mask_probe.py`: CU-masked HIP streams partition the GPU; disjoint masks run side by side"),
+                    ("cu_mask_experiment", "the sharded frame on CU-masked streams (five streams, table MLP from a feature snapshot): every split measured, all slower than four streams; why"),
+                    ("fifth_stream_experiment", "the same without masks (earlier in the round)"),
+                    ("experiments", "the smaller experiments DESIGN.md cites (round 3's tree on every rank, its kernel trace window, the single-GPU frame through the pipeline)"),
+                    ("soak", "`tools/soak_pipeline.py`: 1,500-3,000 frames through the four-stream pipeline with three frames in flight against the same frames one at a time (one GPU fp32 / tcnn; rank 1 of a simulated world of 8): every frame's outputs and the final volume bit-identical")):
+        if os.path.exists(f"{dst}/{R}_{t}.txt"):
+            notes.append(f"* `{R}_{t}.txt` -- {what}.")
+    if notes:
+        W("\n" + "\n".join(notes) + "\n")
 print(open(f"{dst}/{R}_README.md").read()[:3000])
