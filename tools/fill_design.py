@@ -70,6 +70,12 @@ tok["exposed"] = (f"{1e3 * (d['ms_per_step'] - ro['avg_kernel_ms'] - d['kernels'
                   f"({d['ms_per_step']:.3f} ms frame − {ro['avg_kernel_ms']:.3f} − {d['kernels']['pointnet_scatter']['avg_ms']:.3f}), "
                   f"{1e3 * (t['ms_per_step'] - t['roofline']['avg_kernel_ms'] - t['kernels']['pointnet_scatter']['avg_ms']):.0f} µs with the tiny-cuda-nn networks "
                   f"({t['ms_per_step']:.3f} − {t['roofline']['avg_kernel_ms']:.3f} − {t['kernels']['pointnet_scatter']['avg_ms']:.3f})")
+w2, w4 = ranks("spatial_world2.txt"), ranks("spatial_world4.txt")
+tok["curve"] = ("| ranks | slowest rank, ms per frame | frames/s of the rank set | × one GPU | file |\n|---|---|---|---|---|\n"
+                f"| 1 | {single_ms:.3f} | {1e3 / single_ms:,.0f} | 1 | `profiles/{R}_bench_line.json` (`value`) |\n"
+                f"| 2 | {w2['max']:.3f} | {w2['fps']:,.0f} | {single_ms / w2['max']:.2f} | `profiles/{R}_spatial_world2.txt` |\n"
+                f"| 4 | {w4['max']:.3f} | {w4['fps']:,.0f} | {single_ms / w4['max']:.2f} | `profiles/{R}_spatial_world4.txt` |\n"
+                f"| 8 | {ft256['max']:.3f} | {ft256['fps']:,.0f} | {single_ms / ft256['max']:.2f} | `profiles/{R}_spatial_world8_all_ranks_256.txt` |")
 tl = open(P("spatial_world8_timeline.txt")).read()
 N = r"([\d.]+)"
 

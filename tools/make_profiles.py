@@ -38,7 +38,7 @@ dp = last_json(f"{src}/trace_stdout.log")
 for name, obj in (("bench_line", d), ("bench_line_tcnn", dt), ("bench_line_profiled_run", dp)):
     open(f"{dst}/{R}_{name}.json", "w").write(json.dumps(obj) + "\n")
 for t in ("spatial_world8", "spatial_world8_all_ranks_256", "spatial_world8_all_ranks_512", "spatial_world8_all_ranks_256_hash",
-          "spatial_world8_r03_schedule", "spatial_world8_tcnn", "spatial_world8_timeline", "spatial_world2", "fp_replay8", "queue_probe",
+          "spatial_world8_r03_schedule", "spatial_world8_tcnn", "spatial_world8_timeline", "spatial_world2", "spatial_world4", "fp_replay8", "queue_probe",
           "mlp_launch_overhead"):
     if os.path.exists(f"{src}/{t}.txt"):
         import re

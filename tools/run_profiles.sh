@@ -33,6 +33,7 @@ python3 tools/spatial_single_rank.py --world 8 --in-flight 3 2>&1 | grep -v "$F"
 python3 tools/spatial_single_rank.py --world 8 --rank 1 --frames 1000 --in-flight 3 --no-latency --timeline 200 2>&1 | grep -v "$F" > $O/spatial_world8_timeline.txt
 BNV_PIPE_STREAMS=2 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --ahead 0 --ownership hash --frames 2000 2>&1 | grep -v "$F" > $O/spatial_world8_r03_schedule.txt
 python3 tools/spatial_single_rank.py --world 2 --all-ranks --frames 1000 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world2.txt
+python3 tools/spatial_single_rank.py --world 4 --all-ranks --frames 1000 --in-flight 3 2>&1 | grep -v "$F" > $O/spatial_world4.txt
 python3 tools/spatial_single_rank.py --world 8 --in-flight 3 --frames 2000 --checkpoint tcnn 2>&1 | grep -v "$F" > $O/spatial_world8_tcnn.txt
 GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/queue_probe.txt
 python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
