@@ -73,6 +73,7 @@ def main():
     nm = bnv.NeuralMap(data.dimensions, args.voxel_size, model, capacity=1 << 20, device=dev, tsdf=True,
                        max_depth=data.max_depth)
     t_local = t_global = 0.0
+    max_depth = data.max_depth
     if args.decode_frames:
         # the per-frame loop of the benchmark metric: fuse + decode of the touched voxels, synchronous or pipelined
         from bnv_fusion_amd import sequence
@@ -95,7 +96,7 @@ def main():
             last = max(0, len(nm.frames) - args.optim_interval)
             n_iters = min(len(nm.frames), args.optim_interval) * args.skip_images
             t0 = time.perf_counter()
-            nm.optimize(n_iters=n_iters, last_frame=last, ray_max_dist=data.max_depth)
+            nm.optimize(n_iters=n_iters, last_frame=last, ray_max_dist=max_depth)
             torch.cuda.synchronize()
             t_global += time.perf_counter() - t0
             mesh = nm.extract_mesh(os.path.join(args.out, f"{idx}.ply"))
@@ -103,7 +104,7 @@ def main():
     steps = int(len(nm.frames) * args.skip_images) * (1 if args.mode == "demo" else 2)   # :283-284
     if not args.no_optimize:
         t0 = time.perf_counter()
-        nm.optimize(n_iters=steps, last_frame=-1, ray_max_dist=data.max_depth)
+        nm.optimize(n_iters=steps, last_frame=-1, ray_max_dist=max_depth)
         torch.cuda.synchronize()
         t_global += time.perf_counter() - t0
     print(f"speed on local fusion: {len(nm.frames) / max(t_local, 1e-9):.1f} fps"

@@ -234,3 +234,29 @@ def test_run_e2e_example_sweep_pipelined(tmp_path, monkeypatch, capsys):
     assert "fused + decoded 60 frames" in printed and "speed on local fusion" in printed
     for f in ("before_optim.ply", "final.ply", "final_sparse_volume.pth", "room.npy"):
         assert (out / f).exists(), f
+
+
+@pytest.mark.parametrize("argv", [
+    ["--sweep", "24", "--grid", "256", "--decode-frames", "--pipelined"],                 # per-frame decode loop, then optimise
+    ["--synthetic", "12", "--voxel-size", "0.02", "--height", "240", "--width", "320"],   # run_e2e.py's own loop, optimising as it goes
+])
+def test_run_e2e_example_with_the_global_optimiser(tmp_path, monkeypatch, capsys, argv):
+    """examples/run_e2e.py WITH its optimisation steps (the README's command passes --no-optimize): both frame loops reach
+    `NeuralMap.optimize`, the final mesh and `save` (the sweep loop used to lose the dataset's max_depth on the way)."""
+    import importlib.util
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("run_e2e_example", os.path.join(root, "examples", "run_e2e.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    monkeypatch.setattr(sys, "argv", ["run_e2e.py"] + argv + ["--out", str(out)])
+    try:
+        mod.main()
+    finally:
+        import bnv_fusion_amd
+        bnv_fusion_amd.set_mlp_mode(1)
+    printed = capsys.readouterr().out
+    assert "speed on global fusion" in printed
+    for f in ("before_optim.ply", "final.ply", "final_sparse_volume.pth"):
+        assert (out / f).exists(), f
