@@ -466,19 +466,24 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("world,ownership,growing", [(2, "hash", False), (3, "hash", False), (2, "first_touch", False),
                                                      (3, "first_touch", False), (3, "first_touch", True),
-                                                     (3, "hash", True)])
+                                                     (3, "hash", True), (3, "first_touch", "scatter")])
 def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     """``world`` shards of the spatially sharded volume driven phase by phase in ONE process (the all-gather is a
     torch.stack): encode with ownership, upsert, pack boundary records, install ghost rows, decode -- the union of
     the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements.
     Both ownership rules (block hash; first-touch table, include/bnv_fusion.h: bnv_grid_t.shard_state); ``growing``:
     the surface patch drifts through the volume, so that frames keep touching blocks for the first time -- among
-    them blocks that had been pinned earlier as neighbours of touched ones."""
+    them blocks that had been pinned earlier as neighbours of touched ones; ``"scatter"``: a 252^3 grid and thousands of
+    small point clusters all over it, so that the FIRST frame brings more new blocks (> 4,096) than the kernels' short
+    list holds and the owners come from the ordered scan of the dense weight table instead, later frames a few hundred."""
     from bnv_fusion_amd import distributed as D
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     dims, voxel = z["dims"], float(z["voxel_size"])
-    shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=4096, device=DEV, ownership=ownership)
-              for r in range(world)]
+    scatter = growing == "scatter"
+    if scatter:
+        dims = np.array([250 * voxel] * 3)
+    shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=(1 << 17) if scatter else 4096, device=DEV,
+                                ownership=ownership) for r in range(world)]
     n_xyz = shards[0].volume._n_xyz_host
     model.shard = (0, 1, 3)
     single = bnv.NeuralMap(dims, voxel, model, device=DEV)
@@ -490,7 +495,21 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
         assert b.result(b.finish(f, b.decode(f), 0)) == (None, None)
         assert b.volume.num_rows() == 0
     frames_np = list(z["frames"])
-    if growing:       # a STATIC surface seen through a window that drifts 1.5 / 1 voxels per frame along x / y: every
+    if scatter:
+        g = torch.Generator().manual_seed(11)
+        half = 0.5 * float(dims[0]) - 6 * voxel
+
+        def clusters(k):      # k clusters of 40 points inside one voxel cell each: 8 corner voxels with 40 pairs
+            c = ((torch.rand(k, 3, generator=g) * 2 - 1) * half / voxel).floor() * voxel + 0.5 * voxel
+            p = c[:, None, :] + (torch.rand(k, 40, 3, generator=g) - 0.5) * 0.5 * voxel
+            nrm = torch.nn.functional.normalize(torch.randn(k, 40, 3, generator=g), dim=-1)
+            return torch.cat([p, nrm], -1).reshape(-1, 6)
+        pts = clusters(6000)
+        frames_np = []
+        for t in range(9):
+            frames_np.append(pts.float()[None].numpy())
+            pts = torch.cat([pts, clusters(300)])
+    elif growing:     # a STATIC surface seen through a window that drifts 1.5 / 1 voxels per frame along x / y: every
         frames_np = []    # frame brings new territory, and a voxel stays in view long enough to go live (weight >= 8)
         g = torch.Generator().manual_seed(5)
         for t in range(30):
@@ -523,6 +542,9 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
             outs.append(b.result(b.finish(f, b.decode(f), res)))
         for b, f in zip(shards, frs):      # the install has reset the send block for the slot's next frame
             assert int(b.pipe.send[f.slot, 0]) == 0 and int(b.pipe.send[f.slot, 1]) == b.rank
+        if scatter and fr is frames_np[0]:
+            t0_, _ = shards[0].owner_table()
+            assert int(((t0_ & 0x80) != 0).sum()) > 4096        # more new blocks in one frame than the short list holds
     model.shard = (0, 1, 3)
     owned = [o[0] for o in outs]
     table, loads = shards[0].owner_table()
