@@ -262,6 +262,208 @@ def oracle_lattice_check(volume, coords, sdf, tcnn=False, n_voxels=PARITY_VOXELS
             "voxels_checked": int(len(pick)), "sdf_values_checked": int(ref.numel())}
 
 
+def _event_ms(fn, reps, stream=None):
+    """Mean duration (ms) of ``fn()`` over ``reps`` calls between two HIP events on the current stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
+    """SURVEY.md section 8 f-3, the global optimiser at the reference's configuration (run_e2e.py:111-162,
+    fusion_pointnet_model.yaml): Adam steps on the volume features, 5,000 rays of a random key frame per step in splits
+    of 1,000 rays, 20 fine + 15 coarse samples per ray.  -> steps/s ("speed on global fusion", run_e2e.py:289), the two
+    kernels of a split timed alone with their roofline fractions, parity of one split against the oracle's autograd
+    and the oracle's own time for that split on the host cores."""
+    from bnv_fusion_amd import optimize
+    from oracle import bnv_oracle as orc           # checker / baseline only
+    dev = nm.volume._dev
+    voxel = nm.volume.voxel_size
+    nm.frames = list(frames)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    nm.optimize(n_iters=3, last_frame=-1, generator=gen)                     # warm-up (allocations, Adam state)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hist = nm.optimize(n_iters=n_iters, last_frame=-1, generator=gen)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # ---- one split (1,000 rays x 35 samples) through the two kernels alone
+    vol = nm.volume
+    vol.to_tensor()
+    vol.features = torch.nn.Parameter(vol.features)
+    f = frames[3]
+    d = f["depth"]
+    d = d.to(torch.float32) / 1000.0 if d.dtype in (torch.uint16, torch.int16) else d
+    rays = optimize.sample_key_frame(d, f["intr_mat"], f["T_wc"], 1000, 3, generator=gen)
+    with torch.no_grad():
+        out = optimize.render_with_rays(vol, rays, model.nerf, None, nm.truncated_units, nm.truncated_dist, 3, generator=gen)
+    pts = out["pts_on_rays"].detach()
+    n_q = int(pts.numel() // 3)
+    with torch.no_grad():
+        sdf0 = vol.decode_pts(pts, model.nerf, None)
+    live = int((sdf0 != voxel).sum())
+    fwd_ms = _event_ms(lambda: vol.decode_pts(pts, model.nerf, None).detach(), 20)
+    go = torch.ones_like(sdf0)
+
+    def fwd_bwd():
+        vol.features.grad = None
+        vol.decode_pts(pts, model.nerf, None).backward(go)
+
+    both_ms = _event_ms(fwd_bwd, 20)
+    bwd_ms = max(both_ms - fwd_ms, 1e-6)
+    flop_fwd = live * 8.0 * FLOP_PER_EVAL
+    peak = PEAK_TFLOPS[mlp_mode]
+    # ---- parity of a 6,000-query sample against the oracle's forward + autograd (CPU), and the oracle's time
+    sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+    sel = pts.reshape(-1, 3)[torch.randperm(n_q, generator=torch.Generator().manual_seed(1))[:6000].to(dev)]
+    cv = (sel - vol.min_coords) / voxel
+    fl, ce = torch.floor(cv).long(), torch.ceil(cv).long()
+    corners = torch.stack([torch.stack([(ce if b & 1 else fl)[:, 0], (ce if b & 2 else fl)[:, 1],
+                                        (ce if b & 4 else fl)[:, 2]], -1) for b in range(8)], 1).reshape(-1, 3)
+    keys = torch.unique(corners, dim=0)
+    fo, wo, ho = vol.query(keys)
+    present = wo[:, 0] > 0
+    ovol = orc.OracleSparseVolume(8, voxel, np.asarray(vol.dimensions), 8)
+    ovol.insert(keys[present].cpu(), fo[present].detach().cpu(), wo[present].cpu(), ho[present].cpu())
+    ovol.to_tensor()
+    ovol.features.requires_grad_(True)
+    q = sel.cpu().reshape(1, -1, 1, 3)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    t1 = time.perf_counter()
+    ref = ovol.decode_pts(q, sd, None, is_coords=False, query_tensor=True)
+    ref.sum().backward()
+    t_cpu = time.perf_counter() - t1
+    vol.features.grad = None
+    got = vol.decode_pts(sel.reshape(1, -1, 1, 3), model.nerf, None)
+    got.sum().backward()
+    # rows of the sample's corner voxels in the GPU volume's table
+    ac = vol.active_coordinates
+    pack = lambda c: (c[:, 0] * 4096 + c[:, 1]) * 4096 + c[:, 2]      # noqa: E731
+    order = torch.argsort(pack(ac))
+    rows = order[torch.searchsorted(pack(ac)[order], pack(keys[present]))]
+    g_gpu = vol.features.grad[rows].cpu()
+    g_ref = ovol.features.grad
+    err_f = float((got.detach().cpu().reshape(-1) - ref.detach().reshape(-1)).abs().max())
+    err_g = float((g_gpu - g_ref).abs().max() / max(float(g_ref.abs().max()), 1e-30))
+    vol.features = vol.features.detach()
+    live_s = float((ref.detach() != voxel).float().mean())
+    return {"what": "NeuralMap.optimize (run_e2e.py:111-162): Adam steps on the volume features; 5,000 rays of a random "
+                    "key frame per step in 5 splits of 1,000 rays x (20 fine + 15 coarse) samples, decode_pts forward + "
+                    "backward per split",
+            "value": n_iters / dt, "unit": "optimisation steps/s", "ms_per_step": 1e3 * dt / n_iters, "steps": n_iters,
+            "volume_rows": int(vol.num_rows()), "loss_first": float(hist[0]), "loss_last": float(hist[-1]),
+            "split": {"queries": n_q, "live_queries": live,
+                      "k_decode_pts": {"avg_ms": fwd_ms, "tflops": flop_fwd / (fwd_ms * 1e-3) / 1e12,
+                                       "frac_of_peak": flop_fwd / (fwd_ms * 1e-3) / 1e12 / peak,
+                                       "algorithmic_flop": "live queries x 8 corners x 402,432"},
+                      "k_decode_pts_bwd": {"avg_ms": bwd_ms, "tflops": 2 * flop_fwd / (bwd_ms * 1e-3) / 1e12,
+                                           "frac_of_peak": 2 * flop_fwd / (bwd_ms * 1e-3) / 1e12 / peak,
+                                           "algorithmic_flop": "2 x forward (recomputed forward + transposed chain)",
+                                           "timing": "forward + backward minus forward (HIP events, 20 calls each)"},
+                      "peak_tflops": peak},
+            "parity": {"queries_checked": int(q.shape[1]), "live_fraction_checked": live_s,
+                       "sdf_max_abs_err_vs_oracle": err_f, "tolerance": 1e-4,
+                       "grad_max_err_over_max_grad_vs_oracle_autograd": err_g, "grad_tolerance": 1e-4},
+            "cpu_baseline": {"value": 1.0 / (t_cpu * n_q / q.shape[1] * 5), "unit": "optimisation steps/s", "kind": "port",
+                             "cores": min(32, os.cpu_count() or 1),
+                             "sample": f"oracle decode_pts forward + autograd backward of {q.shape[1]} queries: {t_cpu:.2f} s, "
+                                       f"scaled to a step's 5 x {n_q} queries (ray sampling and Adam not counted)"}}
+
+
+def extract_mesh_entry(nm, model, mlp_mode, label):
+    """SURVEY.md section 8 f-4, NeuralMap.extract_mesh (run_e2e.py:164-167 -> SparseVolume.meshlize,
+    sparse_volume.py:697-766) over a WHOLE volume: lattice decode of every active voxel + per-voxel marching cubes."""
+    from bnv_fusion_amd import _lib, mesh as mesh_mod
+    from oracle import bnv_oracle as orc           # checker / baseline only
+    lib = _lib.load()
+    vol = nm.volume
+    dev = vol._dev
+    voxel = vol.voxel_size
+    delta = nm.prepare_tsdf_volume() if nm.tsdf_vol is not None else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = nm.extract_mesh()
+    torch.cuda.synchronize()
+    t_first = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m = nm.extract_mesh()
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    vol.to_tensor()
+    n_vox = int(vol.active_coordinates.shape[0])
+    lib.bnv_profile_enable(1)
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    sdf = vol.decode_lattice(vol.active_coordinates, model.nerf, delta, query_tensor=True)
+    e1.record()
+    verts, faces, _, _ = mesh_mod.marching_cubes_lattice_indexed(sdf, vol.active_coordinates, voxel, vol.min_coords)
+    e2.record()
+    torch.cuda.synchronize()
+    ms, cnt = (C.c_double * 4)(), (C.c_int64 * 4)()
+    lib.bnv_profile_read(ms, cnt)
+    lib.bnv_profile_enable(0)
+    evals = int(vol.last_lattice_evals()[0])
+    tab_ms = ms[1] / max(cnt[1], 1)
+    peak = PEAK_TFLOPS[mlp_mode]
+    # parity + CPU time: the oracle's decode + marching cubes of a sample of voxels (with their neighbourhoods)
+    sel = torch.randperm(n_vox, generator=torch.Generator().manual_seed(2))[:1024].to(dev)
+    pick = vol.active_coordinates[sel]
+    par = oracle_lattice_check(vol, vol.active_coordinates, sdf, n_voxels=1024, seed=2) if delta is None else None
+    sd = orc.load_weights(os.path.join(ROOT, "bnv_fusion_amd", "weights", "pointnet_fp32.npz"))
+    t1 = time.perf_counter()
+    v_ref, f_ref = orc.meshlize_concat(sdf[sel].cpu().numpy().reshape(-1, 3, 3, 3), pick.cpu().numpy(), voxel,
+                                       vol.min_coords.cpu().numpy())
+    t_mc_cpu = time.perf_counter() - t1
+    v_gpu, f_gpu, _, _ = mesh_mod.marching_cubes_lattice_indexed(sdf[sel], pick, voxel, vol.min_coords)
+    same = (tuple(v_ref.shape) == tuple(v_gpu.shape) and tuple(f_ref.shape) == tuple(f_gpu.shape)
+            and bool(np.abs(v_gpu.cpu().numpy() - v_ref).max() <= 1e-6 if len(v_ref) else True)
+            and bool(np.array_equal(f_gpu.cpu().numpy(), f_ref)))
+    cpu = cpu_decode_time(vol, pick[:256], sd) * n_vox / 256 + t_mc_cpu * n_vox / 1024
+    return {"what": f"NeuralMap.extract_mesh over the whole {label} (run_e2e.py:164-167; sparse_volume.py:697-766): "
+                    "to_tensor + lattice decode [M, 27] of every active voxel" + (" with the TSDF prior" if delta is not None else "")
+                    + " + per-voxel marching cubes, vertices / faces to the host",
+            "value": 1e3 * t_all, "unit": "ms per extract_mesh", "higher_is_better": False, "first_call_ms": 1e3 * t_first,
+            "active_voxels": n_vox, "vertices": int(len(m.vertices)) if m is not None else 0,
+            "faces": int(len(m.faces)) if m is not None else 0,
+            "decode_ms": e0.elapsed_time(e1), "marching_cubes_ms": e1.elapsed_time(e2),
+            "table_kernel": {"name": DECODE_KERNEL[mlp_mode], "avg_ms": tab_ms, "mlp_evals": evals,
+                             "tflops": evals * FLOP_PER_EVAL / (tab_ms * 1e-3) / 1e12 if tab_ms else None,
+                             "frac_of_peak": evals * FLOP_PER_EVAL / (tab_ms * 1e-3) / 1e12 / peak if tab_ms else None},
+            "marching_cubes": {"bound": "hbm", "algorithmic_bytes": n_vox * 216 + int(len(verts)) * 12 + int(len(faces)) * 24,
+                               "gb_per_s": (n_vox * 216 + int(len(verts)) * 12 + int(len(faces)) * 24) / (e1.elapsed_time(e2) * 1e-3) / 1e9,
+                               "note": "108 B of lattice per voxel read by the count pass and again by the emit pass, "
+                                       "12 B per vertex + 24 B per triangle (int64 indices) written"},
+            "parity": {"sdf": par, "marching_cubes_equal_oracle_on_1024_voxels": same,
+                       "note": "triangulation of ambiguous cells follows the oracle's restatement; scikit-image's "
+                               "Lewiner tables are absent from this image (parity unpinned, DESIGN.md section 4)"},
+            "cpu_baseline": {"value": 1e3 * cpu, "unit": "ms per extract_mesh", "kind": "port", "cores": min(32, os.cpu_count() or 1),
+                             "sample": "oracle decode of 256 voxels' lattices + oracle marching cubes of 1,024 voxels, "
+                                       "scaled to the volume's active voxels"}}
+
+
+def cpu_decode_time(volume, pick, sd):
+    """Seconds the oracle needs for the lattice decode of ``pick`` (their neighbourhoods read back from the GPU)."""
+    from oracle import bnv_oracle as orc           # baseline only
+    dev = pick.device
+    off = torch.tensor([[x, y, z] for x in (-1, 0, 1) for y in (-1, 0, 1) for z in (-1, 0, 1)], device=dev)
+    nbr = torch.unique((pick[:, None, :] + off[None]).reshape(-1, 3), dim=0)
+    fo, wo, _ = volume.query(nbr)
+    ovol = orc.OracleSparseVolume(8, volume.voxel_size, np.asarray(volume.dimensions), 8)
+    present = wo[:, 0].cpu() > 0
+    ovol.insert(nbr.cpu()[present], fo.cpu()[present], wo.cpu()[present], torch.zeros(int(present.sum()), 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ovol.decode_pts(orc.lattice_coords(pick.cpu().numpy()), sd, None, is_coords=True, query_tensor=False)
+        return time.perf_counter() - t0
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (a fresh
     process tree; this process has not touched the GPU and never will) and leave with the child's exit code."""
@@ -293,6 +495,8 @@ def parse_args():
                          "(~1.8 s): behind 320 the timed steps still ran 3.5 % above the 1,000-frame `sustained` pass, "
                          "behind 1,000 within 1.1 %")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-widened", action="store_true",
+                    help="skip the entries of the widened rows (`optimize`, `extract_mesh`, `extract_mesh_sweep`)")
     ap.add_argument("--mlp-mode", type=int, default=1, choices=[0, 1, 3],
                     help="1 (default): split-f16 operands on the f16 MFMA; 0: exact fp32 MFMA")
     ap.add_argument("--no-alt-mode", action="store_true",
@@ -639,7 +843,7 @@ def run_bench(args, rank, world, dev, dist, backend):
                 run = timed(m, kind, args.mlp_mode, step_idx, warm_idx, preheat=min(args.preheat, 4 * POOL))
                 run["parity"] = parity_check(m, run)
                 if kind == "spatial":
-                    extra = {"ownership": m.backend.ownership,
+                    extra = {"ownership": m.backend.ownership, "block_log2": m.backend.block_log2,
                              "received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
                              "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
                                  bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}
@@ -676,9 +880,13 @@ def run_bench(args, rank, world, dev, dist, backend):
         if rank != 0:
             return None
         from bnv_fusion_amd.distributed import DEFAULT_OWNERSHIP
-        rule = ("first-touch block ownership (8^3-voxel blocks, a new block goes to the least-loaded rank; every rank "
-                "derives the same table, no communication)" if DEFAULT_OWNERSHIP == "first_touch"
-                else "spatial hash of 8^3-voxel blocks")
+        own_rule = results["spatial"][1].get("ownership", DEFAULT_OWNERSHIP) if "spatial" in results else DEFAULT_OWNERSHIP
+        rule = {"region": "first-touch block ownership in contiguous regions (8^3-voxel blocks; the first frame is cut "
+                          "into bands of equal load, later blocks go to the owner of a neighbour block unless it carries "
+                          "more than its share; every rank derives the same table, no communication)",
+                "first_touch": "first-touch block ownership (8^3-voxel blocks, a new block goes to the least-loaded rank; "
+                               "every rank derives the same table, no communication)",
+                "hash": "spatial hash of 8^3-voxel blocks"}[own_rule]
         DESCR = {"spatial": (f"active-voxel set sharded over {world} ranks by {rule}; every "
                              "rank voxelises the whole frame, encodes / upserts / decodes the voxels it owns; per frame "
                              "ONE RCCL all-gather of boundary-voxel records (48 B: key, weight, 8 features) and one host "
@@ -859,7 +1067,23 @@ def run_bench(args, rank, world, dev, dist, backend):
                 r = oracle_lattice_check(nm_s.volume, c, sdf_s, tcnn=tcnn, n_voxels=256)
                 return r["sdf_max_abs_err_vs_oracle"], r["mask_decisions_equal"], r["live_fraction_checked"]
 
-            extras["sequence"] = sequence.bench_pass(model, dev, args.sequence_frames, check=seq_check)
+            kept = []
+            extras["sequence"] = sequence.bench_pass(model, dev, args.sequence_frames, check=seq_check, keep=kept)
+            if not args.no_widened and not tcnn and kept:
+                bnv.set_mlp_mode(args.mlp_mode)
+                extras["extract_mesh_sweep"] = extract_mesh_entry(kept[0], model, args.mlp_mode,
+                                                                  f"sweep volume ({extras['sequence']['rows_end']} rows, 512^3)")
+            del kept
+
+        # ---- the widened rows: the global optimiser and whole-volume mesh extraction
+        # on the bench's own volume.  LAST: the optimiser's Adam steps change the volume's features.
+        if not args.no_widened and not tcnn:
+            bnv.set_mlp_mode(args.mlp_mode)
+            nm._drain_pipe()
+            extras["extract_mesh"] = extract_mesh_entry(nm, model, args.mlp_mode,
+                                                        f"bench volume ({nm.volume.num_rows()} rows, {args.grid}^3)")
+            if args.input == "depth":
+                extras["optimize"] = optimize_entry(nm, model, [frames[i] for i in pool[:32]], args.mlp_mode)
 
     m = args.mlp_mode
     peak = PEAK_TFLOPS[m]

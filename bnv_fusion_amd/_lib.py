@@ -28,6 +28,7 @@ SYMBOLS = [
     "bnv_encode_finish_image_wg", "bnv_encode_finish_image_parts", "bnv_decode_lattice_snapshot_workspace_bytes", "bnv_decode_lattice_stamped_mark", "bnv_decode_lattice_snapshot_table", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready", "bnv_frame_pipe_timeline_enable", "bnv_frame_timeline",
+    "bnv_frame_side_depth", "bnv_frame_cancel", "bnv_frame_pipe_forget_workspaces", "bnv_shard_state_configure",
 ]
 
 
@@ -243,6 +244,11 @@ def load():
         "bnv_frame_ready": (C.c_int, [vp, C.c_int]),
         "bnv_frame_pipe_timeline_enable": (C.c_int, [vp, C.c_int]),
         "bnv_frame_timeline": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
+        "bnv_frame_side_depth": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), vp]),
+        "bnv_frame_cancel": (C.c_int, [vp, C.c_int]),
+        "bnv_frame_pipe_forget_workspaces": (C.c_int, [vp]),
+        "bnv_shard_state_configure": (C.c_int, [vp, i32, i32, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the library does not export it

@@ -143,6 +143,10 @@ constexpr uint32_t kNewListCap = 4096;   // new blocks of a frame k_rank lists f
 struct ShardHdr {
   unsigned long long load[64];   // touched voxels (at first touch) of the blocks each rank owns
   int32_t any_new;               // k_rank: the blocks this frame touches for the first time (their number)
+  int32_t rule;                  // BNV_SHARD_RULE_GREEDY (0) | BNV_SHARD_RULE_REGION (1): bnv_shard_state_configure
+  int32_t axis;                  // region rule: the axis the first frame's bands are stacked along
+  int32_t recv_p1;               // region rule: 1 + the receiver rank (0: none yet)
+  uint32_t cur[64];              // k_rank: the voxels THIS frame touches in blocks each rank owns (cleared by k_shard_assign)
 };
 static_assert(sizeof(ShardHdr) <= kShardHdrBytes, "shard state header");
 struct ShardState {
@@ -167,7 +171,32 @@ __host__ __device__ inline size_t shard_state_layout(const int32_t n_xyz[3], int
     S->new_list = (uint32_t*)(base + kShardHdrBytes + tab + (size_t)n * 4);
     S->n_blocks = n;
   }
-  return kShardHdrBytes + tab + (size_t)n * 8;
+  // the new-block list is sorted in place padded to a power of two (k_shard_assign): room for that
+  size_t list = 1;
+  while (list < (size_t)n && list < kNewListCap) list <<= 1;
+  if (list < (size_t)n) list = (size_t)n;
+  return kShardHdrBytes + tab + (size_t)n * 4 + list * 4;
+}
+// Walk order of a frame's new blocks under the region rule: bands are stacked along `axis` -- that block coordinate is
+// the most significant, the other two follow in x, y, z order.  key <-> block index (x-major) of an nb[3] block grid.
+__host__ __device__ inline uint32_t shard_walk_key(uint32_t b, const int nb[3], int axis) {
+  if (axis == 0) return b;
+  const uint32_t bz = b % (uint32_t)nb[2], by = (b / (uint32_t)nb[2]) % (uint32_t)nb[1], bx = b / ((uint32_t)nb[2] * (uint32_t)nb[1]);
+  return axis == 1 ? (by * (uint32_t)nb[0] + bx) * (uint32_t)nb[2] + bz : (bz * (uint32_t)nb[0] + bx) * (uint32_t)nb[1] + by;
+}
+__host__ __device__ inline uint32_t shard_walk_block(uint32_t key, const int nb[3], int axis) {
+  if (axis == 0) return key;
+  uint32_t bx, by, bz;
+  if (axis == 1) {
+    bz = key % (uint32_t)nb[2];
+    bx = (key / (uint32_t)nb[2]) % (uint32_t)nb[0];
+    by = key / ((uint32_t)nb[2] * (uint32_t)nb[0]);
+  } else {
+    by = key % (uint32_t)nb[1];
+    bx = (key / (uint32_t)nb[1]) % (uint32_t)nb[0];
+    bz = key / ((uint32_t)nb[1] * (uint32_t)nb[0]);
+  }
+  return (bx * (uint32_t)nb[1] + by) * (uint32_t)nb[2] + bz;
 }
 // the rule that pins blocks nobody has touched yet (neighbours of touched blocks): a lattice rule spreads any
 // axis-aligned stretch of blocks evenly over the ranks

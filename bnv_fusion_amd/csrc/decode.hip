@@ -17,6 +17,8 @@
 //   DENSE    decode_feature_grid_w_pts on dense grids.
 #include <string.h>
 
+#include <type_traits>
+
 #include "bnv_common.hpp"
 
 namespace bnv {
@@ -109,6 +111,7 @@ struct DecodeArgs {
   int32_t variant;
   float* nf_out;     // optional [n, 8]: the features the evaluation used
   int32_t* status;   // optional: [1] = 5 when a feature leaves the certified range of the split arithmetic
+  int32_t half_tail; // k_lattice_table_x: hand the last partial round out as 64-evaluation tiles
 };
 
 __device__ __forceinline__ f32x16 frag256(const float* __restrict__ b, int w, int h) {
@@ -1426,7 +1429,10 @@ typedef __attribute__((address_space(3))) half8 lds_half8_w_t;
 // entry; compute unit u requests weight unit u + kTAhead (the last ones those of the NEXT layer) and the activation
 // fragments of compute unit u + 1 (double buffer) -- per unit 24 MFMAs, 8 LDS reads, 2 L2 reads, like a K-step of
 // the 32x32x16 kernel.  b_hi / b_lo: this lane's LDS byte address of octet g, evaluation n in the source planes.
-template <int NU, int BASE, int NEXT_NU, int NPROD>
+// HALF: a 64-evaluation tile (the tail of a launch, k_lattice_table_x): only the compute units of column half 0 run;
+// the weight ring keeps its schedule (every weight unit is still needed), the activation fragments of K-step s + 1
+// are requested during K-step s.
+template <int NU, int BASE, int NEXT_NU, int NPROD, bool HALF = false>
 __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int voff, int off, int off_next,
                                               const float* __restrict__ bias, uint32_t b_hi, uint32_t b_lo,
                                               ARing& ring, f32x4 (&acc)[2][8], int w, int g) {
@@ -1448,7 +1454,19 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
       if (NPROD == 3) bl[(u) & 1][c] = *(lds_half8_t*)(b_lo + o);                                             \
     }                                                                                                         \
   }
-  BNV_LOAD_B(0);
+#define BNV_LOAD_BH(s_)                                                                                       \
+  {                                                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                           \
+      const uint32_t o = (uint32_t)((s_) * 8192 + c * 256);                                                   \
+      bh[(s_) & 1][c] = *(lds_half8_t*)(b_hi + o);                                                            \
+      if (NPROD == 3) bl[(s_) & 1][c] = *(lds_half8_t*)(b_lo + o);                                            \
+    }                                                                                                         \
+  }
+  if constexpr (HALF) {
+    BNV_LOAD_BH(0);
+  } else {
+    BNV_LOAD_B(0);
+  }
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int s = u >> 1, ch = u & 1;
@@ -1463,29 +1481,38 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
       if (NPROD == 3) ring.lo[(BASE + nx) % kTRing] = load_frag(rs, voff, sn + (nx - NU) * 2048 + 1024);
       loads_a = true;
     }
-    if (u + 1 < NU) BNV_LOAD_B(u + 1);
+    if constexpr (HALF) {
+      if (ch == 1) {   // nothing to compute in this unit of a half tile; its weight request stays
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
+      if (2 * (s + 1) < NU) BNV_LOAD_BH(s + 1);
+    } else {
+      if (u + 1 < NU) BNV_LOAD_B(u + 1);
+    }
+    const int bb = HALF ? (s & 1) : (u & 1);
     if constexpr (NPROD == 3) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bl[u & 1][c],
+          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bl[bb][c],
                                                                        acc[rb][4 * ch + c], 0, 0, 0);
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.lo[(BASE + 2 * s + rb) % kTRing], bh[u & 1][c],
+          acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.lo[(BASE + 2 * s + rb) % kTRing], bh[bb][c],
                                                                        acc[rb][4 * ch + c], 0, 0, 0);
     }
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bh[u & 1][c],
+        acc[rb][4 * ch + c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring.hi[(BASE + 2 * s + rb) % kTRing], bh[bb][c],
                                                                      acc[rb][4 * ch + c], 0, 0, 0);
     // issue order: every prefetch in the shadow of an MFMA (one memory instruction behind each)
-    if (u + 1 < NU) {
+    if (HALF ? (2 * (s + 1) < NU) : (u + 1 < NU)) {
 #pragma unroll
       for (int q = 0; q < (NPROD == 3 ? 8 : 4); ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
@@ -1501,6 +1528,7 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+#undef BNV_LOAD_BH
 #undef BNV_LOAD_B
 }
 
@@ -1509,10 +1537,10 @@ __device__ __forceinline__ void chain_layer_x(__amdgpu_buffer_rsrc_t rs, int vof
 // (Converting before that barrier -- the older wave of a SIMD wins MFMA arbitration and leaves the K-loop ~6,000
 // cycles early, tools/phase_prof.py -- was measured: its VALU stream then takes issue slots from the younger
 // wave's MFMAs and the tile gets 2.6 % longer; converting all blocks before the first store: +1.7 %.)
-template <int NPROD>
+template <int NPROD, bool HALF = false>
 __device__ __forceinline__ void store_relu_x(uint32_t st_hi, uint32_t st_lo, const f32x4 (&acc)[2][8]) {
 #pragma unroll
-  for (int cb = 0; cb < 8; ++cb) {
+  for (int cb = 0; cb < (HALF ? 4 : 8); ++cb) {
     half8 hi, lo;
     float x[8];
 #pragma unroll
@@ -1550,7 +1578,20 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int64_t n_evals = A.entries ? (int64_t)A.n_list[1] : (int64_t)(*A.n_list) * 27;
-  const int64_t n_tiles = (n_evals + DM - 1) / DM;
+  // HALF TILES in the tail.  A launch of T tiles on G workgroups takes ceil(T / G) rounds, and a shard of a spatially
+  // sharded volume has only 5-8 tiles per workgroup: 7.2 tiles cost 8 rounds.  When the last round holds R <= G / 2
+  // tiles, they are handed out as 2 R tiles of 64 evaluations (same weights from L2, half the MFMAs: ~0.6 of a round).
+  const int64_t n_full_all = (n_evals + DM - 1) / DM;
+  const int64_t rem = n_full_all % (int64_t)gridDim.x;
+  const int64_t n_full = (A.half_tail && rem > 0 && 2 * rem <= (int64_t)gridDim.x) ? n_full_all - rem : n_full_all;
+  const int64_t half0 = n_full * DM;   // first evaluation of the half tiles
+  const int64_t n_tiles = n_full + (n_evals > half0 ? (n_evals - half0 + 63) / 64 : 0);
+  // entry of evaluation slot se of a tile (-1: none)
+  auto tile_entry = [&](int64_t t, int slot) -> int {
+    if (t >= n_tiles) return -1;
+    if (t < n_full) return lattice_entry(A, t * DM + slot, n_evals);
+    return slot < 64 ? lattice_entry(A, half0 + (t - n_full) * 64 + slot, n_evals) : -1;
+  };
   const float* pack = A.pack;
   const _Float16* px = (const _Float16*)(pack + SD_PACK_FLOATS);
   const float s5 = sinf(0.5f), c5 = cosf(0.5f);
@@ -1639,8 +1680,8 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   int64_t tile = s_tile[0], tile_nx = s_tile[1];
   int ent_cur = -1, ent_nx = -1;
   f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = {0.f, 0.f, 0.f, 0.f};
-  if (tile < n_tiles) ent_cur = lattice_entry(A, tile * DM + se, n_evals);
-  if (tile_nx < n_tiles) ent_nx = lattice_entry(A, tile_nx * DM + se, n_evals);
+  ent_cur = tile_entry(tile, se);
+  ent_nx = tile_entry(tile_nx, se);
   load_feats(ent_cur, f0, f1);
   stage_park(ent_cur, f0, f1);
   ARing ring;
@@ -1680,7 +1721,8 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
   if ((threadIdx.x & 63) == 0) ((unsigned long long*)(lds + T_TOTAL))[(threadIdx.x >> 6) * 32 + 31] = clock64();
 #endif
 
-  while (tile < n_tiles) {
+  auto one_tile = [&](auto half_tag) {
+    constexpr bool HALF = decltype(half_tag)::value;
     // requests for the following tiles: the id of the tile after next (thread 0 asks now and publishes it behind
     // layer 0, so that the round trip of the atomic is off its wave's critical path), features of the next tile
     int next_id = 0;
@@ -1695,42 +1737,42 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
     load_feats(ent_nx, f0, f1);
     f32x4 acc[2][8];
     BNV_PHX(0);
-    chain_layer_x<2, 0, 16, NPROD>(rs, voff, O0, O1, pack + SD_B0, park_hi, park_lo, ring, acc, w, g);
+    chain_layer_x<2, 0, 16, NPROD, HALF>(rs, voff, O0, O1, pack + SD_B0, park_hi, park_lo, ring, acc, w, g);
     if (threadIdx.x == 0) s_tile[2] = next_id;
     BNV_PHX(1);
     __syncthreads();
     BNV_PHX(2);
     const int64_t tile_nx2 = s_tile[2];
-    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    store_relu_x<NPROD, HALF>(st_hi, st_lo, acc);
     stage_park(ent_nx, f0, f1);  // PARK is free: every wave is past layer 0
-    if (tile_nx2 < n_tiles) ent_nx2 = lattice_entry(A, tile_nx2 * DM + se, n_evals);
+    ent_nx2 = tile_entry(tile_nx2, se);
     BNV_PHX(3);
     __syncthreads();
     BNV_PHX(4);
-    chain_layer_x<16, 2, 16, NPROD>(rs, voff, O1, O2, pack + SD_B0 + 256, act_hi, act_lo, ring, acc, w, g);
+    chain_layer_x<16, 2, 16, NPROD, HALF>(rs, voff, O1, O2, pack + SD_B0 + 256, act_hi, act_lo, ring, acc, w, g);
     BNV_PHX(5);
     __syncthreads();
     BNV_PHX(6);
-    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    store_relu_x<NPROD, HALF>(st_hi, st_lo, acc);
     BNV_PHX(7);
     __syncthreads();
     BNV_PHX(8);
-    chain_layer_x<16, 18, 16, NPROD>(rs, voff, O2, O3, pack + SD_B0 + 512, act_hi, act_lo, ring, acc, w, g);
+    chain_layer_x<16, 18, 16, NPROD, HALF>(rs, voff, O2, O3, pack + SD_B0 + 512, act_hi, act_lo, ring, acc, w, g);
     BNV_PHX(9);
     __syncthreads();
     BNV_PHX(10);
-    store_relu_x<NPROD>(st_hi, st_lo, acc);
+    store_relu_x<NPROD, HALF>(st_hi, st_lo, acc);
     BNV_PHX(11);
     __syncthreads();
     BNV_PHX(12);
-    chain_layer_x<16, 34, 2, NPROD>(rs, voff, O3, O0, pack + SD_B0 + 768, act_hi, act_lo, ring, acc, w, g);
+    chain_layer_x<16, 34, 2, NPROD, HALF>(rs, voff, O3, O0, pack + SD_B0 + 768, act_hi, act_lo, ring, acc, w, g);
     ring.hi[2] = load_frag(rs, voff, O1 + (w * 16) * 2048);  // (50 + 2) % 5: layer 1's unit 0, next tile
     if (NPROD == 3) ring.lo[2] = load_frag(rs, voff, O1 + (w * 16) * 2048 + 1024);
     BNV_PHX(13);
     // fc_alpha: 256 -> 1.  Partial over this lane's 8 features, K-groups g and g + 2 combined across the lane
     // halves, 16 partials per evaluation through LDS
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
+    for (int cb = 0; cb < (HALF ? 4 : 8); ++cb) {
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) sum = fmaf(wa0[i], relu_bits(acc[0][cb][i]), sum);
@@ -1755,6 +1797,10 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
     tile = tile_nx;
     tile_nx = tile_nx2;
     BNV_PHX(17);
+  };
+  while (tile < n_tiles) {
+    if (__builtin_amdgcn_readfirstlane((int)(tile >= n_full))) one_tile(std::true_type{});
+    else one_tile(std::false_type{});
   }
 #ifdef BNV_PHASE_PROF
   __syncthreads();
@@ -2377,6 +2423,7 @@ static unsigned capped_grid(int64_t blocks, int per_cu) {
 }
 
 std::atomic<int> g_fused_mark{-1};  // bnv_set_option("fused_mark"): 1 / 0 force, -1 (default): by the call's size
+std::atomic<int> g_half_tail{1};    // bnv_set_option("half_tail"): k_lattice_table_x hands its last partial round out as half tiles
 std::atomic<int> g_lattice_pipe{1}; // 1: k_lattice_table_x (cross-tile / cross-layer pipelined, 16x16x32 MFMA); 0: k_decode<LATTICE, 1>
 
 #ifdef BNV_PHASE_PROF
@@ -2395,10 +2442,12 @@ static int launch_decode(int mode, int mlp, const DecodeArgs& args, int64_t n_ti
   const bool lattice_pipe = g_lattice_pipe.load(std::memory_order_relaxed) != 0;
   if (mode == MODE_LATTICE && (mlp == 1 || mlp == 3) && lattice_pipe) {
     ProfScope prof(PROF_DECODE_LATTICE, stream);
+    DecodeArgs ax = args;
+    ax.half_tail = g_half_tail.load(std::memory_order_relaxed);
     if (mlp == 1)
-      hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
+      hipLaunchKernelGGL(k_lattice_table_x<3>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, ax);
     else
-      hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, args);
+      hipLaunchKernelGGL(k_lattice_table_x<1>, dim3((unsigned)grid), dim3(512), T_TOTAL * 4 + kProfLds, stream, ax);
     BNV_LAUNCH_CHECK();
     return BNV_OK;
   }
@@ -2513,6 +2562,10 @@ int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;
   if (!strcmp(name, "lattice_pipe")) {
     g_lattice_pipe.store(value, std::memory_order_relaxed);
+    return BNV_OK;
+  }
+  if (!strcmp(name, "half_tail")) {
+    g_half_tail.store(value != 0, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "fused_mark")) {

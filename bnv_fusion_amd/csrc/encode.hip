@@ -414,7 +414,11 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
     }
   }
   if (flags) *(uint32_t*)&chunk_flag[base] = 0u;
-  if (g.shard_world > 1 && threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+  __shared__ int s_cur[64];
+  if (g.shard_world > 1 && threadIdx.x < 64) {
+    s_hist[threadIdx.x] = 0;
+    s_cur[threadIdx.x] = 0;
+  }
   uint32_t total;
   uint32_t run = block_exclusive_scan<kScanThreads>(s, wave_tot, &total);
   if (threadIdx.x < 64) {
@@ -457,7 +461,10 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
       const int id = __hip_atomic_load(&ids[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int x = id / nyz, r = id - x * nyz, y = r / g.n_xyz[2], z = r - y * g.n_xyz[2];
       const int b = ((x >> sh) * nby + (y >> sh)) * nbz + (z >> sh);
-      if (!(S.table[b] & kOwnTouched) && atomicAdd(&S.blk_w[b], 1u) == 0u) {
+      const uint8_t tb = S.table[b];
+      // the frame's load per rank with the owners as they stand (region rule: who may take new territory)
+      if (tb & kOwnAssigned) atomicAdd(&s_cur[tb & kOwnRank], 1);
+      if (!(tb & kOwnTouched) && atomicAdd(&S.blk_w[b], 1u) == 0u) {
         // the block's first voxel: list the block (k_shard_assign sorts the list; past its capacity it scans the
         // weight table instead, so the count alone is what matters then)
         const uint32_t pos = (uint32_t)atomicAdd(&S.hdr->any_new, 1);
@@ -470,8 +477,10 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
       else if (st == 2) defer_list[atomicAdd(&ctl->n_deferred, 1)] = (int32_t)j;
     }
     __syncthreads();
-    if (threadIdx.x < 64 && threadIdx.x < g.shard_world && s_hist[threadIdx.x])
-      atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x < 64 && threadIdx.x < g.shard_world) {
+      if (s_hist[threadIdx.x]) atomicAdd(&ctl->shard_boundary[threadIdx.x], s_hist[threadIdx.x]);
+      if (s_cur[threadIdx.x]) atomicAdd(&S.hdr->cur[threadIdx.x], (uint32_t)s_cur[threadIdx.x]);
+    }
   } else if (g.shard_world > 1) {
     // the exchange bound: touched BOUNDARY voxels per owner.  The set bits sit in a few threads (a thread holds 256
     // consecutive voxels), so the ~30 ownership hashes of a boundary test are spread over the workgroup: it walks
@@ -502,11 +511,116 @@ __global__ __launch_bounds__(kScanThreads) void k_rank(uint8_t* __restrict__ byt
 // somebody's neighbour keeps its owner, and either way its weight joins that rank's load; (3) the neighbour blocks of
 // the new blocks that still have no owner are pinned to the lattice rule; (4) the weights are cleared.  Every rank
 // runs this on the same replicated voxelisation, so every rank's table is the same -- no communication.
-__global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
+// ---- region rule (BNV_SHARD_RULE_REGION; include/bnv_fusion.h: bnv_grid_t.shard_state; host restatement:
+// distributed.OwnershipModel) ----------------------------------------------------------------------------------------
+// Table bytes are read and written with relaxed agent-scope atomics and a fence behind every store: the walk reads
+// entries it has written a few iterations earlier.
+__device__ __forceinline__ uint8_t own_load(const uint8_t* t, int64_t i) {
+  return __hip_atomic_load(&t[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void own_store(uint8_t* t, int64_t i, uint8_t v) {
+  __hip_atomic_store(&t[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// least-loaded rank (lowest rank on ties); cur: lane r holds rank r's load
+__device__ __forceinline__ int least_rank(uint32_t cur, int world) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long key = lane < world ? (((unsigned long long)cur << 6) | (unsigned long long)lane) : ~0ull;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned long long o = __shfl_xor(key, d, 64);
+    key = o < key ? o : key;
+  }
+  return (int)(key & 63ull);
+}
+// the first wave of k_shard_assign walks the frame's n_new blocks (new_list holds their WALK KEYS, ascending)
+__device__ void shard_assign_region(const bnv_grid_t& g, const ShardState& S, uint32_t n_new, uint32_t n_touched) {
+  const int lane = threadIdx.x & 63;
+  const int world = g.shard_world, axis = S.hdr->axis;
+  int nb3[3];
+  shard_block_dims(g.n_xyz, g.shard_block_log2, nb3);
+  uint32_t cur = lane < world ? S.hdr->cur[lane] : 0u;
+  unsigned long long load = lane < world ? S.hdr->load[lane] : 0ull;
+  const unsigned long long nt = n_touched;
+  // neighbour this lane looks at (lanes 0..26; 13 = the block itself)
+  const int ddx = lane / 9 - 1, ddy = (lane / 3) % 3 - 1, ddz = lane % 3 - 1;
+  int recv = S.hdr->recv_p1 - 1;
+  {
+    const uint32_t cr = __shfl(cur, recv < 0 ? 0 : recv, 64);
+    if (recv < 0 || (unsigned long long)cr * (unsigned)world >= nt) recv = least_rank(cur, world);
+  }
+  // (1) owners for the new blocks, in walk order
+  for (uint32_t i = 0; i < n_new; ++i) {
+    const uint32_t b = shard_walk_block(S.new_list[i], nb3, axis);
+    const uint32_t w = S.blk_w[b];
+    const uint8_t t = own_load(S.table, b);
+    int r;
+    if (t & kOwnAssigned) {
+      r = (int)(t & kOwnRank);   // pinned earlier: cur counts its voxels already (k_rank)
+    } else {
+      const int bz = (int)(b % (uint32_t)nb3[2]), by = (int)((b / (uint32_t)nb3[2]) % (uint32_t)nb3[1]),
+                bx = (int)(b / ((uint32_t)nb3[2] * (uint32_t)nb3[1]));
+      const int x = bx + ddx, y = by + ddy, z = bz + ddz;
+      uint8_t tv = 0;
+      if (lane < 27 && (unsigned)x < (unsigned)nb3[0] && (unsigned)y < (unsigned)nb3[1] && (unsigned)z < (unsigned)nb3[2])
+        tv = own_load(S.table, ((int64_t)x * nb3[1] + y) * nb3[2] + z);
+      const int c = (int)(tv & kOwnRank);
+      const uint32_t cc = __shfl(cur, c, 64);
+      const bool cand = (tv & kOwnAssigned) && (unsigned long long)cc * (unsigned)world < nt;   // assigned and not full
+      unsigned long long key = cand ? (((unsigned long long)cc << 6) | (unsigned long long)c) : ~0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(key, d, 64);
+        key = o < key ? o : key;
+      }
+      if (key != ~0ull) {
+        r = (int)(key & 63ull);
+      } else {
+        const uint32_t cr = __shfl(cur, recv, 64);
+        if ((unsigned long long)cr * (unsigned)world >= nt) recv = least_rank(cur, world);
+        r = recv;
+      }
+      if (lane == r) cur += w;
+    }
+    if (lane == r) load += w;
+    if (lane == 0) own_store(S.table, b, (uint8_t)(r | kOwnAssigned | kOwnTouched));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
+  // (2) the untouched neighbours of the new blocks are pinned: regions grow outwards
+  {
+    const uint32_t cr = __shfl(cur, recv, 64);
+    if ((unsigned long long)cr * (unsigned)world * 8ull > 9ull * nt) recv = least_rank(cur, world);
+  }
+  for (uint32_t i = 0; i < n_new; ++i) {
+    const uint32_t b = shard_walk_block(S.new_list[i], nb3, axis);
+    int r = (int)(own_load(S.table, b) & kOwnRank);
+    const uint32_t cr = __shfl(cur, r, 64);
+    if ((unsigned long long)cr * (unsigned)world * 8ull > 9ull * nt) r = recv;   // overloaded: no pins for it
+    const int bz = (int)(b % (uint32_t)nb3[2]), by = (int)((b / (uint32_t)nb3[2]) % (uint32_t)nb3[1]),
+              bx = (int)(b / ((uint32_t)nb3[2] * (uint32_t)nb3[1]));
+    const int x = bx + ddx, y = by + ddy, z = bz + ddz;
+    if (lane == 13) S.blk_w[b] = 0u;
+    else if (lane < 27 && (unsigned)x < (unsigned)nb3[0] && (unsigned)y < (unsigned)nb3[1] && (unsigned)z < (unsigned)nb3[2]) {
+      const int64_t e = ((int64_t)x * nb3[1] + y) * nb3[2] + z;
+      if (!(own_load(S.table, e) & kOwnAssigned)) own_store(S.table, e, (uint8_t)(r | kOwnAssigned));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+  }
+  if (lane < world) S.hdr->load[lane] = load;
+  if (lane == 0) S.hdr->recv_p1 = recv + 1;
+}
+
+__global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g, const EncCtl* __restrict__ ctl) {
   ShardState S;
   shard_state_layout(g.n_xyz, g.shard_block_log2, (char*)g.shard_state, &S);
   const uint32_t n_listed = (uint32_t)S.hdr->any_new;     // (k_rank counts the new blocks in it)
-  if (n_listed == 0) return;
+  if (n_listed == 0) {
+    if (threadIdx.x < 64) S.hdr->cur[threadIdx.x] = 0u;   // (k_rank of the NEXT frame adds to it)
+    return;
+  }
+  const bool region = S.hdr->rule == BNV_SHARD_RULE_REGION;
+  int nbw[3];
+  shard_block_dims(g.n_xyz, g.shard_block_log2, nbw);
+  const int axis = region ? S.hdr->axis : 0;
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t s_n;
   const int lane = threadIdx.x & 63;
@@ -515,6 +629,8 @@ __global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
     // bitonic sort of new_list[0, n_listed) padded with ~0 to the next power of two, in global memory (L2)
     uint32_t np2 = 1;
     while (np2 < n_listed) np2 <<= 1;
+    if (axis != 0)   // the region rule walks in key order: sort the keys
+      for (uint32_t i = threadIdx.x; i < n_listed; i += 256) S.new_list[i] = shard_walk_key(S.new_list[i], nbw, axis);
     for (uint32_t i = n_listed + threadIdx.x; i < np2; i += 256) S.new_list[i] = 0xffffffffu;
     __syncthreads();
     for (uint32_t k = 2; k <= np2; k <<= 1)
@@ -537,8 +653,8 @@ __global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     for (int64_t b0 = 0; b0 < S.n_blocks; b0 += 256) {
-      const int64_t b = b0 + threadIdx.x;
-      const uint32_t f = (b < S.n_blocks && S.blk_w[b] > 0) ? 1u : 0u;
+      const int64_t b = b0 + threadIdx.x;   // (a walk key: the list comes out in walk order)
+      const uint32_t f = (b < S.n_blocks && S.blk_w[shard_walk_block((uint32_t)b, nbw, axis)] > 0) ? 1u : 0u;
       uint32_t tot;
       const uint32_t pos = block_exclusive_scan<256>(f, wave_tot, &tot);
       const uint32_t base = s_n;
@@ -550,6 +666,14 @@ __global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
     n_new = s_n;
   }
   const int world = g.shard_world;
+  if (region) {
+    if (threadIdx.x < 64) {
+      shard_assign_region(g, S, n_new, (uint32_t)ctl->n_unique);
+      S.hdr->cur[lane] = 0u;
+      if (lane == 0) S.hdr->any_new = 0;
+    }
+    return;
+  }
   if (threadIdx.x < 64) {
     unsigned long long load = lane < world ? S.hdr->load[lane] : 0ull;
     for (uint32_t i0 = 0; i0 < n_new; i0 += 64) {
@@ -603,6 +727,7 @@ __global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g) {
     if (!(*e & kOwnAssigned)) *e = (uint8_t)(shard_lattice_owner(x, y, z, world) | kOwnAssigned);   // (same value from every writer)
   }
   if (threadIdx.x == 0) S.hdr->any_new = 0;
+  if (threadIdx.x < 64) S.hdr->cur[threadIdx.x] = 0u;
 }
 
 // With the owners of the frame's blocks known: the owned-pair list of the encoder (what the mark kernel does itself
@@ -1943,7 +2068,7 @@ static int encode_rank(const EncodeWs& ws, const bnv_grid_t& g, const float* pts
                      ws.defer_list);
   BNV_LAUNCH_CHECK();
   if (g.shard_world > 1 && g.shard_state) {
-    hipLaunchKernelGGL(k_shard_assign, dim3(1), dim3(256), 0, stream, g);
+    hipLaunchKernelGGL(k_shard_assign, dim3(1), dim3(256), 0, stream, g, (const EncCtl*)ws.ctl);
     BNV_LAUNCH_CHECK();
     // (a frame without a new block leaves it nothing to do: a small grid that strides, not a workgroup per 256 points)
     const int nb = (n_points + 255) / 256;
@@ -1973,6 +2098,14 @@ size_t bnv_encode_shard_counts_offset(void) { return offsetof(EncCtl, shard_boun
 size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2) {
   if (!n_xyz || block_log2 < 0 || block_log2 > 8) return 0;
   return shard_state_layout(n_xyz, block_log2, nullptr, nullptr);
+}
+int bnv_shard_state_configure(void* shard_state, int32_t rule, int32_t axis, bnv_stream_t stream) {
+  if (!shard_state || (rule != BNV_SHARD_RULE_GREEDY && rule != BNV_SHARD_RULE_REGION) || axis < 0 || axis > 2)
+    return BNV_ERR_INVALID_ARGUMENT;
+  const int32_t words[2] = {rule, axis};   // (copied before the call returns: pageable host memory)
+  BNV_HIP_CHECK(hipMemcpyAsync((char*)shard_state + offsetof(ShardHdr, rule), words, sizeof(words), hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+  return BNV_OK;
 }
 size_t bnv_shard_state_loads_offset(void) { return offsetof(ShardHdr, load); }
 size_t bnv_shard_state_table_offset(void) { return kShardHdrBytes; }

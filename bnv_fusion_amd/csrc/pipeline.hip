@@ -79,6 +79,9 @@ struct bnv_frame_pipe {
   int enc_buf[BNV_PIPE_MAX_SLOTS];
   void* lws_ptr[4];                     // decode workspaces seen and the slot whose frame used each one last
   int lws_slot[4];
+  uint64_t lws_serial[4];               // serial of the frame that used the workspace last (0: none)
+  uint64_t serial[BNV_PIPE_MAX_SLOTS];  // serial of the frame the slot holds (or held last)
+  uint64_t next_serial;
   int state[BNV_PIPE_MAX_SLOTS];        // 0 free, 1 begun, 2 upserted, 3 finished (result pending)
   bool used[BNV_PIPE_MAX_SLOTS];        // ev_done has been recorded at least once
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
@@ -180,8 +183,11 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   for (int k = 0; k < 4; ++k) {
     p->lws_ptr[k] = nullptr;
     p->lws_slot[k] = -1;
+    p->lws_serial[k] = 0;
   }
+  p->next_serial = 1;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
+    p->serial[s] = 0;
     p->state[s] = 0;
     p->used[s] = false;
     p->n_points[s] = 0;
@@ -251,8 +257,8 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
     BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_BOUNDS, (const char*)enc_ws + p->bound_off,
                                  4 * (size_t)c.grid.shard_world, hipMemcpyDeviceToHost, p->F));
   }
+  tl_mark(p, slot, 1, p->F);   // (in front of the event E waits for: the timeline's point 2 can then never precede it)
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
-  tl_mark(p, slot, 1, p->F);
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
   tl_mark(p, slot, 2, p->E);
   const bnv_grid_t g = slot_grid(p, slot);
@@ -298,8 +304,48 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
   p->enc_buf[slot] = buf;
   if (p->encws_used[buf] && p->F != p->E) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_encws[buf], 0));
   p->mlp_mode[slot] = p->cfg.grid.mlp_mode;   // the frame keeps the mode it starts under (bnv_frame_pipe_set_mlp_mode)
+  p->serial[slot] = p->next_serial++;
   for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k) p->tl_set[slot][k] = false;
   tl_mark(p, slot, 0, p->F);
+  return BNV_OK;
+}
+
+// The TSDF side fusion of the slot's frame (run_e2e.py:99-109), gated on the device by the frame's in-bounds point
+// count: enqueued on E behind the frame's encode -- or, in split mode, remembered for bnv_frame_upsert (behind finalize,
+// which writes the gate, on B) -- and the slot's side event recorded behind it.
+static int side_depth(bnv_frame_pipe* p, int slot, const void* depth, int depth_dtype, int H, int W,
+                      const double* intr_host, const double* T_wc_host, const float* color_im) {
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  if (c.tsdf.tsdf && p->split) {
+    bnv_frame_pipe::SideArgs& a = p->side[slot];
+    a.on = true;
+    a.depth = depth;
+    a.color = color_im;
+    a.dtype = depth_dtype;
+    a.H = H;
+    a.W = W;
+    for (int i = 0; i < 9; ++i) a.K[i] = (float)intr_host[i];
+    for (int i = 0; i < 16; ++i) a.T[i] = (float)T_wc_host[i];
+    return BNV_OK;
+  }
+  if (c.tsdf.tsdf) {
+    float K[9], T[16];
+    for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
+    for (int i = 0; i < 16; ++i) T[i] = (float)T_wc_host[i];
+    const int32_t* gate = &b.counters->n_valid_points;
+    int rc;
+    if (depth_dtype == 0)
+      rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim,
+                                  c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)depth,
+                                  color_im, H, W, K, T, 1.0f, (float)c.max_depth, gate, p->E);
+    else
+      rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim, c.tsdf.origin,
+                              c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)depth, color_im, H, W, K, T, 1.0f,
+                              (float)c.max_depth, gate, p->E);
+    if (rc != BNV_OK) return rc;
+  }
+  BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
   return BNV_OK;
 }
 
@@ -318,34 +364,8 @@ int bnv_frame_begin_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int 
   if (rc != BNV_OK) return rc;
   rc = begin_tail(p, slot, b.input_pts, (int64_t)H * W, W);
   if (rc != BNV_OK) return rc;
-  if (c.tsdf.tsdf && p->split) {   // behind finalize (its gate), on B: bnv_frame_upsert
-    bnv_frame_pipe::SideArgs& a = p->side[slot];
-    a.on = true;
-    a.depth = depth;
-    a.color = color_im;
-    a.dtype = depth_dtype;
-    a.H = H;
-    a.W = W;
-    for (int i = 0; i < 9; ++i) a.K[i] = (float)intr_host[i];
-    for (int i = 0; i < 16; ++i) a.T[i] = (float)T_wc_host[i];
-    return BNV_OK;
-  }
-  if (c.tsdf.tsdf) {   // run_e2e.py:99-109, gated on the device by the frame's in-bounds point count
-    float K[9], T[16];
-    for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
-    for (int i = 0; i < 16; ++i) T[i] = (float)T_wc_host[i];
-    const int32_t* gate = &b.counters->n_valid_points;
-    if (depth_dtype == 0)
-      rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim,
-                                  c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)depth,
-                                  color_im, H, W, K, T, 1.0f, (float)c.max_depth, gate, p->E);
-    else
-      rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, color_im ? c.tsdf.color : nullptr, c.tsdf.dim, c.tsdf.origin,
-                              c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)depth, color_im, H, W, K, T, 1.0f,
-                              (float)c.max_depth, gate, p->E);
-    if (rc != BNV_OK) return rc;
-  }
-  BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
+  rc = side_depth(p, slot, depth, depth_dtype, H, W, intr_host, T_wc_host, color_im);
+  if (rc != BNV_OK) return rc;
   return BNV_OK;
 }
 
@@ -361,6 +381,15 @@ int bnv_frame_begin_points(bnv_frame_pipe_t* p, int slot, const float* input_pts
   if (rc != BNV_OK) return rc;
   BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->E));
   return BNV_OK;
+}
+
+int bnv_frame_side_depth(bnv_frame_pipe_t* p, int slot, const void* depth, int depth_dtype, int H, int W,
+                         const double* intr_host, const double* T_wc_host, const float* color_im) {
+  if (!slot_ok(p, slot) || p->state[slot] != 1 || !depth || !intr_host || !T_wc_host || H < 1 || W < 1)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (depth_dtype != 0 && depth_dtype != 1) return BNV_ERR_INVALID_ARGUMENT;   // the TSDF kernel reads u16 / f32 images
+  if (!p->cfg.tsdf.tsdf) return BNV_OK;
+  return side_depth(p, slot, depth, depth_dtype, H, W, intr_host, T_wc_host, color_im);
 }
 
 int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, void* vol_ws, size_t vol_ws_bytes,
@@ -400,24 +429,34 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
     // the upsert stamps the decode's origins into lattice_ws and clears its control words: the blend (other stream)
     // of the frame that decoded into this workspace last must be through.  Callers alternate two workspaces, so
     // this is the blend of the frame before the last one.
-    int k = 0, free_k = -1;
+    int k = 0, free_k = -1, lru_k = 0;
     for (; k < 4; ++k) {
       if (p->lws_ptr[k] == lattice_ws) break;
       if (!p->lws_ptr[k] && free_k < 0) free_k = k;
+      if (p->lws_serial[k] < p->lws_serial[lru_k]) lru_k = k;
     }
     if (k == 4) {
-      k = free_k >= 0 ? free_k : 0;   // (more than four workspaces: forget the oldest entry, after waiting for it)
+      // a workspace not seen before; with more than four, the entry used longest ago makes room (after waiting for
+      // the frame that used it)
+      k = free_k >= 0 ? free_k : lru_k;
       if (free_k < 0 && p->lws_slot[k] >= 0 && p->used[p->lws_slot[k]])
         BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[p->lws_slot[k]], 0));
       p->lws_ptr[k] = lattice_ws;
       p->lws_slot[k] = -1;
+      p->lws_serial[k] = 0;
     }
     const int prev = p->lws_slot[k];
     if (prev >= 0 && prev != slot) {
-      if (p->state[prev] == 1 || p->state[prev] == 2) return BNV_ERR_INVALID_ARGUMENT;   // its frame is not finished
+      // The frame that used this workspace last sat in slot `prev`.  If that very frame is still in the slot and its
+      // finish has not been enqueued, its done event does not exist yet: a caller's ordering error.  If the slot has
+      // moved on to a later frame (collected and begun again, in any state), the old frame's finish was enqueued
+      // long ago and ev_done[prev] -- recorded by it, or by a later finish in that slot -- covers its blend.
+      if (p->serial[prev] == p->lws_serial[k] && (p->state[prev] == 1 || p->state[prev] == 2))
+        return BNV_ERR_INVALID_ARGUMENT;
       if (p->used[prev]) BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[prev], 0));
     }
     p->lws_slot[k] = slot;
+    p->lws_serial[k] = p->serial[slot];
   }
   bnv_integrate_extras_t x = {};
   if (c.grid.shard_world > 1) {
@@ -432,6 +471,52 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   if (rc != BNV_OK) return rc;
   tl_mark(p, slot, 6, p->M);
   p->state[slot] = 2;
+  return BNV_OK;
+}
+
+int bnv_frame_pipe_forget_workspaces(bnv_frame_pipe_t* p) {
+  if (!p) return BNV_ERR_INVALID_ARGUMENT;
+  for (int s = 0; s < p->cfg.n_slots; ++s)
+    if (p->state[s] == 2) return BNV_ERR_INVALID_ARGUMENT;   // an upserted frame still needs its workspace
+  for (int k = 0; k < 4; ++k) {
+    if (p->lws_ptr[k] && p->lws_slot[k] >= 0 && p->used[p->lws_slot[k]])
+      BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[p->lws_slot[k]], 0));
+    p->lws_ptr[k] = nullptr;
+    p->lws_slot[k] = -1;
+    p->lws_serial[k] = 0;
+  }
+  return BNV_OK;
+}
+
+int bnv_frame_cancel(bnv_frame_pipe_t* p, int slot) {
+  if (!slot_ok(p, slot) || p->state[slot] != 1) return BNV_ERR_INVALID_ARGUMENT;
+  // the encode side of the frame is enqueued and runs to its end (finalize leaves the encode workspace clean; a
+  // sharded volume's owner table keeps the owners the frame gave to new blocks -- they are the same on every rank);
+  // nothing of it reaches the volume.  The slot's done event covers the encode + side fusion, so the next frame begun
+  // in the slot waits for them before it overwrites the slot's buffers.
+  const bnv_frame_pipe_config_t& c = p->cfg;
+  const bnv_frame_slot_t& b = c.slots[slot];
+  if (p->split) {
+    // finalize belongs to the upsert call in split mode: it still has to run (it cleans the encode workspace); the
+    // TSDF side fusion, which would follow it, is dropped with the frame
+    BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
+    const bnv_grid_t g = slot_grid(p, slot);
+    const int rc = bnv_encode_finish_image_parts(p->pts[slot], p->n_points[slot], p->width[slot], &g, c.pointnet_pack,
+                                                 slot_encws(p, slot), c.enc_ws_bytes, c.enc_ws_max_points, b.feats,
+                                                 b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters,
+                                                 c.encoder_workgroups, 2, p->M);
+    if (rc != BNV_OK) return rc;
+    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->M));
+    BNV_HIP_CHECK(hipEventRecord(p->ev_fin[slot], p->M));
+    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_fin[slot], 0));
+    p->side[slot].on = false;
+  } else {
+    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_enc[slot], 0));
+    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));
+  }
+  BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
+  p->used[slot] = true;
+  p->state[slot] = 0;
   return BNV_OK;
 }
 

@@ -33,10 +33,18 @@ import torch
 
 from . import _lib
 
-BLOCK_LOG2 = 3
-# ownership rule of HipShardBackend when the caller names none: "first_touch" (a per-block owner table kept on the
-# device, new blocks go to the least-loaded rank: max / mean load 1.0x) or "hash" (mix64(block) % world: 1.11-1.16)
-DEFAULT_OWNERSHIP = "first_touch"
+BLOCK_LOG2 = 3          # default block edge (log2 voxels); HipShardBackend(block_log2=) / BNV_SHARD_BLOCK_LOG2 override it
+# ownership rule of HipShardBackend when the caller names none (BNV_SHARD_OWNERSHIP overrides):
+#   "region"       first touch, contiguous regions (include/bnv_fusion.h: BNV_SHARD_RULE_REGION): ~1.03-1.07 x the
+#                  single-GPU decode work in total, max / mean load 1.04 while the view stays put or moves across the
+#                  bands (the benchmark's pan) -- but 1.4-1.5 for a camera that sweeps a room;
+#   "first_touch"  first touch, fine interleave (round 4; BNV_SHARD_RULE_GREEDY): max / mean 1.01-1.06 in ANY view, ~1.2 x
+#                  the work (1.11 with block_log2 = 4): the rule for moving cameras;
+#   "hash"         mix64(block) % world: no table, max / mean 1.11-1.16.
+# tools/shard_model.py prices the three on the CPU (profiles/r05_shard_model.txt).
+DEFAULT_OWNERSHIP = "region"
+DEFAULT_AXIS = 1        # region rule: the first frame's bands are stacked along y (the vertical of the datasets' cameras)
+RULES = {"first_touch": 0, "region": 1}
 REC_WORDS = 12          # BNV_SHARD_RECORD_BYTES / 4: {x, y, z, weight bits, 8 feature bits}
 REC_QUANTUM = 512       # the per-rank block capacity is rounded up to this many records
 
@@ -104,6 +112,196 @@ def shard_adjacent_to(coords, world, rank, block_log2=BLOCK_LOG2, table=None, n_
     return out
 
 
+def touched_voxels(pts, bound_min, bound_max, voxel_size, n_xyz):
+    """Host restatement (numpy, fp32 like csrc/encode.hip: k_mark + k_rank) of a frame's voxelisation: input_pts
+    [N, >= 3] -> (ascending flat ids int64 [U], pair counts [U]) of the voxels its (point, corner) pairs fall into."""
+    n = np.asarray(n_xyz, dtype=np.int64)
+    bmin = np.asarray(bound_min, dtype=np.float32).reshape(3)
+    v = np.float32(voxel_size)
+    lo = (bmin + v).astype(np.float32)
+    hi = (np.asarray(bound_max, dtype=np.float32).reshape(3) - v).astype(np.float32)
+    x = np.asarray(pts)[:, :3].astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        x = x[((x < hi) & (x > lo)).all(1)]                  # strict, one-voxel margin; NaN rows fail
+    xn = (x - bmin) / v                                      # two IEEE fp32 roundings, as voxel_coord()
+    f = np.floor(xn).astype(np.int64)
+    c = np.ceil(xn).astype(np.int64)
+    ids = []
+    for bits in range(8):
+        cx = np.where(bits & 1, c[:, 0], f[:, 0])
+        cy = np.where(bits & 2, c[:, 1], f[:, 1])
+        cz = np.where(bits & 4, c[:, 2], f[:, 2])
+        ids.append((cx * n[1] + cy) * n[2] + cz)
+    if not len(x):
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    return np.unique(np.concatenate(ids), return_counts=True)
+
+
+def unflatten(ids, n_xyz):
+    n = np.asarray(n_xyz, dtype=np.int64)
+    ids = np.asarray(ids, dtype=np.int64)
+    return np.stack([ids // (n[1] * n[2]), (ids // n[2]) % n[1], ids % n[2]], 1)
+
+
+_OFF6 = np.array([[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, -1], [0, 0, 1]], dtype=np.int64)
+OWN_RANK, OWN_ASSIGNED, OWN_TOUCHED = 0x3f, 0x40, 0x80        # bits of an owner-table byte (csrc/bnv_common.hpp)
+
+
+def walk_key(b, nb, axis):
+    """Walk order of a frame's new blocks under the region rule: block coordinates [n, 3] -> sort key.  Bands are
+    stacked along ``axis``: that coordinate is the most significant, the other two follow in x, y, z order
+    (csrc/bnv_common.hpp: shard_walk_key)."""
+    a1, a2 = [a for a in range(3) if a != axis]
+    return (b[:, axis] * nb[a1] + b[:, a1]) * nb[a2] + b[:, a2]
+
+
+class OwnershipModel:
+    """Host restatement of the ownership rules of a spatially sharded volume (csrc/encode.hip: k_rank, k_shard_assign;
+    csrc/bnv_common.hpp: voxel_owner, shard_is_boundary, shard_adjacent_to): fed the touched voxels of every frame in
+    order, it holds the owner table every rank's device table must equal -- the specification the GPU tests compare
+    with, and what tools/shard_model.py prices rules with.
+
+    ``hash``    owner = mix64(block) % world.
+    ``greedy``  round 4's first touch: a frame's new blocks, ascending, each to the rank with the least cumulative load;
+                untouched neighbour blocks pinned to the lattice rule (bx + 5 by + 7 bz) % world.
+    ``region``  round 5's first touch (the default): contiguous regions.  cur[r] = the voxels THIS frame touches in
+                blocks rank r owns.  A new block without an owner, in walk order (bands stacked along ``axis``), goes to
+                the least-loaded owner among its six face neighbours that is not full (cur * world < touched voxels of
+                the frame), else to the least-loaded rank of all; a new block pinned earlier keeps its owner.  Then the
+                untouched neighbour blocks of the new blocks are pinned to the owner of the first new block (walk order)
+                that reaches them -- regions grow outwards -- unless that rank is overloaded
+                (cur * world * 8 > 9 * touched), then to the least-loaded rank: it starts a new region there."""
+
+    def __init__(self, rule, world, n_xyz, block_log2=BLOCK_LOG2, axis=1, pin_num=9, pin_den=8):
+        assert rule in ("hash", "greedy", "region", "first_touch")
+        self.pin_num, self.pin_den = int(pin_num), int(pin_den)
+        self.recv = -1
+        self.rule = "greedy" if rule == "first_touch" else rule
+        self.world, self.s, self.axis = int(world), int(block_log2), int(axis)
+        self.n = np.asarray(n_xyz, dtype=np.int64)
+        self.nb = (self.n + (1 << self.s) - 1) >> self.s
+        self.table = None if self.rule == "hash" else np.zeros(int(self.nb.prod()), dtype=np.uint8)
+        self.load = np.zeros(self.world, dtype=np.uint64)      # cumulative: weights of the blocks at first touch
+        self.cur = np.zeros(self.world, dtype=np.int64)        # region rule: the last frame's load per rank
+
+    # ---- predicates with the table as it stands ---------------------------------------------------
+    def owner(self, coords):
+        return voxel_owner(coords, self.world, self.s, self.table, self.n)
+
+    def is_boundary(self, coords):
+        return shard_is_boundary(coords, self.world, self.s, self.table, self.n)
+
+    def adjacent_to(self, coords, rank):
+        c = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
+        if len(c) == 0:
+            return np.zeros(0, dtype=bool)
+        return shard_adjacent_to(c, self.world, rank, self.s, self.table, self.n)
+
+    def _bidx(self, b):
+        return (b[..., 0] * self.nb[1] + b[..., 1]) * self.nb[2] + b[..., 2]
+
+    def _bcoord(self, i):
+        i = np.asarray(i, dtype=np.int64)
+        return np.stack([i // (self.nb[1] * self.nb[2]), (i // self.nb[2]) % self.nb[1], i % self.nb[2]], -1)
+
+    # ---- one frame --------------------------------------------------------------------------------
+    def frame(self, touched):
+        """``touched``: [U, 3] voxel coordinates this frame touches (every voxel once)."""
+        if self.table is None or self.world <= 1:
+            return
+        t = np.asarray(touched, dtype=np.int64).reshape(-1, 3)
+        if len(t) == 0:
+            return
+        T = self.table
+        bi, w = np.unique(self._bidx(t >> self.s), return_counts=True)
+        new = (T[bi] & OWN_TOUCHED) == 0
+        if self.rule == "greedy":
+            for b, wt in zip(bi[new], w[new]):                       # ascending block index
+                if T[b] & OWN_ASSIGNED:
+                    r = int(T[b] & OWN_RANK)
+                else:
+                    r = int(np.argmin(self.load))                    # (first minimum: lowest rank on ties)
+                self.load[r] += np.uint64(wt)
+                T[b] = r | OWN_ASSIGNED | OWN_TOUCHED
+            for b in bi[new]:
+                for d in _OFF27:
+                    e = self._bcoord(b) + d
+                    if (e < 0).any() or (e >= self.nb).any():
+                        continue
+                    k = int(self._bidx(e))
+                    if not T[k] & OWN_ASSIGNED:
+                        T[k] = int(lattice_owner(e[None], self.world)[0]) | OWN_ASSIGNED
+            return
+        # ---- region rule
+        n_touched = len(t)
+        W = self.world
+        cur = np.zeros(W, dtype=np.int64)
+        asg = (T[bi] & OWN_ASSIGNED) != 0
+        np.add.at(cur, (T[bi[asg]] & OWN_RANK).astype(np.int64), w[asg])
+        nbi, nw = bi[new], w[new]
+        order = np.argsort(walk_key(self._bcoord(nbi), self.nb, self.axis), kind="stable")
+        nbi, nw = nbi[order], nw[order]
+
+        def least(c):
+            return int(np.lexsort((np.arange(W), c))[0])
+
+        # the RECEIVER: the rank new territory goes to when adjacency does not decide.  A rank is FULL -- no more new
+        # blocks for it in this frame -- when it carries its share of the frame's voxels; a rank is OVERLOADED -- no pins
+        # for it -- when it carries more than pin_num / pin_den of its share.
+        def full(c):
+            return cur[c] * W >= n_touched
+
+        def overloaded(c):
+            return cur[c] * W * self.pin_den > self.pin_num * n_touched
+
+        recv = self.recv
+        if recv < 0 or full(recv):
+            recv = least(cur)
+        for b, wt in zip(nbi, nw):
+            if T[b] & OWN_ASSIGNED:
+                r = int(T[b] & OWN_RANK)                             # pinned earlier: cur already counts its voxels
+            else:
+                bc = self._bcoord(b)
+                best = -1
+                for d in _OFF27:
+                    e = bc + d
+                    if (e < 0).any() or (e >= self.nb).any():
+                        continue
+                    v = T[int(self._bidx(e))]
+                    if not v & OWN_ASSIGNED:
+                        continue
+                    c = int(v & OWN_RANK)
+                    if full(c):
+                        continue
+                    if best < 0 or (cur[c], c) < (cur[best], best):
+                        best = c
+                if best >= 0:
+                    r = best
+                else:
+                    if full(recv):
+                        recv = least(cur)
+                    r = recv
+                cur[r] += wt
+            self.load[r] += np.uint64(wt)
+            T[b] = r | OWN_ASSIGNED | OWN_TOUCHED
+        if overloaded(recv):
+            recv = least(cur)
+        for b in nbi:
+            bc = self._bcoord(b)
+            r = int(T[b] & OWN_RANK)
+            if overloaded(r):
+                r = recv
+            for d in _OFF27:
+                e = bc + d
+                if (e < 0).any() or (e >= self.nb).any():
+                    continue
+                k = int(self._bidx(e))
+                if not T[k] & OWN_ASSIGNED:
+                    T[k] = r | OWN_ASSIGNED
+        self.recv = recv
+        self.cur = cur
+
+
 def all_gather_var(t, group=None):
     """All-gather of tensors whose first dimension differs per rank -> concatenation in rank order (host-synchronous;
     used by tests and tools to collect sharded OUTPUTS, not on the per-frame path)."""
@@ -135,13 +333,17 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None):
         from .sparse_volume import SparseVolume, make_grid
         import os
         ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
-        if ownership not in ("hash", "first_touch"):
+        if ownership not in ("hash", "first_touch", "region"):
             raise ValueError(f"unknown ownership rule {ownership!r}")
         self.ownership = ownership
+        self.block_log2 = int(block_log2 if block_log2 is not None else os.environ.get("BNV_SHARD_BLOCK_LOG2", BLOCK_LOG2))
+        if not 1 <= self.block_log2 <= 6:
+            raise ValueError(f"block_log2 {self.block_log2} outside 1..6")
+        self.axis = int(axis if axis is not None else os.environ.get("BNV_SHARD_AXIS", DEFAULT_AXIS))
         self.pointnet = pointnet
         self.rank, self.world = rank, world
         self.volume = SparseVolume(8, voxel_size, dimensions, min_pts_in_grid, capacity=capacity, device=device)
@@ -149,11 +351,13 @@ class HipShardBackend:
         # first-touch ownership (include/bnv_fusion.h: bnv_grid_t.shard_state): the owner table lives on the device,
         # is updated by every frame's encode and holds the same content on every rank
         self._owner_state = None
-        if ownership == "first_touch" and world > 1:
+        if ownership != "hash" and world > 1:
             n_arr = (C.c_int32 * 3)(*v._n_xyz_host)
-            nbytes = int(v._lib.bnv_shard_state_bytes(n_arr, BLOCK_LOG2))
+            nbytes = int(v._lib.bnv_shard_state_bytes(n_arr, self.block_log2))
             self._owner_state = torch.zeros(nbytes, dtype=torch.uint8, device=v._dev)
-        self.shard = (rank, world, BLOCK_LOG2) + ((self._owner_state.data_ptr(),) if self._owner_state is not None else ())
+            _lib.check(v._lib.bnv_shard_state_configure(_lib.ptr(self._owner_state), RULES[ownership], self.axis,
+                                                        _lib.stream_ptr()), "bnv_shard_state_configure")
+        self.shard = (rank, world, self.block_log2) + ((self._owner_state.data_ptr(),) if self._owner_state is not None else ())
         pointnet.shard = self.shard
         v.shard = self.shard
         v._grid = make_grid(v._n_xyz_host, v.min_coords, v.max_coords, voxel_size, min_pts_in_grid, v.shard)
@@ -258,6 +462,10 @@ class HipShardBackend:
         self.last_owned_pairs = int(w[W_COUNTERS + 5])      # bnv_encode_counters_t.reserved[0]
         return self.pipe.outputs(fr.slot, w, copy=self.copy_results)
 
+    def cancel(self, fr):
+        """Abandons a frame whose encode was enqueued and that will not be upserted (bnv_frame_cancel)."""
+        self.pipe.cancel(fr.slot)
+
     def owner_table(self):
         """The first-touch owner table (numpy uint8, one byte per block: bits 0..5 owner, bit 6 assigned, bit 7 touched)
         and the per-rank loads (uint64 [world]) as they stand now (host copies; synchronises), or (None, None)."""
@@ -266,14 +474,14 @@ class HipShardBackend:
         lib = self.volume._lib
         st = self._owner_state.cpu().numpy()
         n = np.asarray(self.volume._n_xyz_host, dtype=np.int64)
-        nb = (n + (1 << BLOCK_LOG2) - 1) >> BLOCK_LOG2
+        nb = (n + (1 << self.block_log2) - 1) >> self.block_log2
         t0, l0 = int(lib.bnv_shard_state_table_offset()), int(lib.bnv_shard_state_loads_offset())
         return st[t0: t0 + int(nb.prod())].copy(), st[l0: l0 + 8 * self.world].view(np.uint64).copy()
 
     def owners(self, coords):
         """Host restatement of the ownership rule in force: coords [n, 3] -> rank [n]."""
         table, _ = self.owner_table()
-        return voxel_owner(coords, self.world, BLOCK_LOG2, table, self.volume._n_xyz_host)
+        return voxel_owner(coords, self.world, self.block_log2, table, self.volume._n_xyz_host)
 
     def owned_rows_mask(self):
         """bool [rows]: rows this rank owns (the others are ghost rows)."""
@@ -319,14 +527,14 @@ class ShardedNeuralMap:
     handles may stay uncollected (HIP backend; the oldest is collected on demand)."""
 
     def __init__(self, dimensions, voxel_size, pointnet, min_pts_in_grid=8, device="cuda:0", backend=None,
-                 group=None, capacity=1 << 20, tsdf=False, ownership=None):
+                 group=None, capacity=1 << 20, tsdf=False, ownership=None, block_log2=None, axis=None):
         import torch.distributed as dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend or HipShardBackend(dimensions, voxel_size, pointnet, self.rank, self.world,
                                                   min_pts_in_grid, capacity=capacity, device=device, tsdf=tsdf,
-                                                  ownership=ownership)
+                                                  ownership=ownership, block_log2=block_log2, axis=axis)
         self.volume = getattr(self.backend, "volume", None)
         self.voxel_size = voxel_size
         self.exchanged_bytes = 0          # bytes this rank has received in all-gathers (statistics)
@@ -348,14 +556,25 @@ class ShardedNeuralMap:
             while self._open and len(self._open) + (1 if self._pre is not None else 0) + need > ring:
                 self._open.pop(0).result()            # the slot ring is full: collect the oldest frame
         ctx = be.stream_context(frame) if hasattr(be, "stream_context") else contextlib.nullcontext()
+        if self._pre is not None and self._pre[0] is not frame:
+            raise _lib.BnvError("fuse_and_decode_async: the frame announced as next_frame must be the next one passed "
+                                "(flush() integrates an announced frame that will not come, abandon() drops it)")
+        try:
+            return self._frame(frame, decode, next_frame if ahead else None, ctx, ring)
+        except Exception:
+            # a frame announced and begun ahead must not keep its slot when this one fails on the way
+            self.abandon()
+            raise
+
+    def _frame(self, frame, decode, next_frame, ctx, ring):
+        import torch.distributed as dist
+        be = self.backend
         with torch.no_grad(), ctx:
             if self._pre is not None:
-                if self._pre[0] is not frame:
-                    raise _lib.BnvError("fuse_and_decode_async: the frame announced as next_frame must be the next one passed")
                 fr, self._pre = self._pre[1], None
             else:
                 fr = be.encode(frame)
-            if ahead:
+            if next_frame is not None:
                 self._pre = (next_frame, be.encode(next_frame))
             bound = be.bound(fr)                       # the frame's one host wait
             self.host_waits += 1
@@ -381,6 +600,33 @@ class ShardedNeuralMap:
 
     def integrate(self, frame):
         return self.fuse_and_decode_async(frame, decode=False).result()[0]
+
+    def abandon(self):
+        """Drops a frame that was announced as ``next_frame`` (its encode is enqueued) and will not be passed: nothing
+        of it reaches the volume, its slot is free again.  Local, no collective -- but every rank must do the same
+        (the ranks' volumes and owner tables stay equal only if all of them drop the frame)."""
+        if self._pre is not None:
+            fr, self._pre = self._pre[1], None
+            if hasattr(self.backend, "cancel"):
+                try:
+                    self.backend.cancel(fr)
+                except Exception:
+                    pass
+
+    def flush(self):
+        """End of a stream: a frame announced as ``next_frame`` that was never passed is integrated now (no decode;
+        COLLECTIVE like every frame), then every open handle is collected.  -> the results of the frames that were
+        still open, oldest first."""
+        if self._pre is not None:
+            self.fuse_and_decode_async(self._pre[0], decode=False)
+        out = []
+        while self._open:
+            h = self._open.pop(0)
+            if h.pending:
+                out.append(h.result())
+        return out
+
+    close = flush
 
     def last_mlp_evals(self):
         """Device int32 [1]: SDF-MLP evaluations this rank ran for the last frame."""

@@ -175,6 +175,7 @@ class FramePipe:
         self._epoch = [0] * S
         self._lws = [None] * S
         self._lws_next = 0           # decode workspace of the next frame upserted (two alternate with a blend stream)
+        self._lws_generation = v._lws_generation
         # with a table stream, three: a frame's upsert (which stamps into the workspace) then waits for the blend of
         # the frame THREE back, not two -- with two the chain of frame t+2 could only start behind table(t) + blend(t)
         # and the table stream idled for the rest of that chain
@@ -250,14 +251,25 @@ class FramePipe:
         # (inputs_resident) -- the encode must not start before the caller's stream has produced the buffer
         col = None
         converted = False
-        if "input_pts" not in frame and self.tsdf_vol is not None and frame.get("rgb") is not None:
+        # the TSDF side fusion reads the frame's depth image whether or not the frame also carries input_pts (the
+        # reference dataset's frames hold both, run_e2e.py:78-109)
+        side = self.tsdf_vol is not None and frame.get("depth") is not None
+        if side and frame.get("rgb") is not None:
             col = self.tsdf_vol._fold_color(frame["rgb"])                 # (caller's stream)
             converted = True
+        side_d = None
         if "input_pts" in frame:
             src = frame["input_pts"]
             self._check_device(src, "input_pts")
             pts = src[0].detach().float().contiguous()
             converted |= pts.data_ptr() != src.data_ptr() or pts.dtype != src.dtype
+            if side:
+                sd = torch.as_tensor(frame["depth"])
+                if sd.dtype in (torch.uint16, torch.int16):
+                    side_d = sd.to(self.dev).contiguous()
+                else:
+                    side_d = sd.to(self.dev, torch.float32).contiguous()
+                converted |= (not sd.is_cuda) or side_d.data_ptr() != sd.data_ptr()
         else:
             src = frame["depth"]
             self._check_device(src, "depth")
@@ -272,8 +284,14 @@ class FramePipe:
             _lib.check(lib.bnv_frame_pipe_set_mlp_mode(self._h, mode + 1), "bnv_frame_pipe_set_mlp_mode")
             self._mode = mode
         if "input_pts" in frame:
-            self._keep[s] = pts                                           # alive until the slot is begun again
+            self._keep[s] = (pts, side_d, col)                            # alive until the slot is begun again
             _lib.check(lib.bnv_frame_begin_points(self._h, s, _lib.ptr(pts), int(pts.shape[0])), "bnv_frame_begin_points")
+            if side_d is not None:
+                H, W = int(side_d.shape[-2]), int(side_d.shape[-1])
+                K = (C.c_double * 9)(*np.asarray(frame["intr_mat"], dtype=np.float64)[:3, :3].reshape(-1))
+                T = (C.c_double * 16)(*np.asarray(frame["T_wc"], dtype=np.float64).reshape(-1))
+                _lib.check(lib.bnv_frame_side_depth(self._h, s, _lib.ptr(side_d), self._dtypes[side_d.dtype], H, W, K, T,
+                                                    _lib.ptr(col)), "bnv_frame_side_depth")
         else:
             H, W = int(d.shape[-2]), int(d.shape[-1])
             K = (C.c_double * 9)(*np.asarray(frame["intr_mat"], dtype=np.float64)[:3, :3].reshape(-1))
@@ -306,6 +324,10 @@ class FramePipe:
             lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0,
                                                           snapshot=self.table is not None)
             self._lws_next = (self._lws_next + 1) % self.n_lattice_ws
+            if self._lws_generation != v._lws_generation:
+                # the volume has re-made its decode workspaces (it grew): the pointers the C object remembers are gone
+                _lib.check(self._lib.bnv_frame_pipe_forget_workspaces(self._h), "bnv_frame_pipe_forget_workspaces")
+                self._lws_generation = v._lws_generation
         self._lws[slot] = lws
         ws = v._workspace(self.cap)
         _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),
@@ -321,6 +343,11 @@ class FramePipe:
                                               _lib.ptr(nerf.sdf_pack), C.byref(d), _lib.ptr(lws),
                                               lws.numel() if lws is not None else 0, self._epoch[slot]),
                    "bnv_frame_finish")
+
+    def cancel(self, slot):
+        """Abandons a frame that was begun and not upserted (include/bnv_fusion.h: bnv_frame_cancel); the slot is free."""
+        _lib.check(self._lib.bnv_frame_cancel(self._h, slot), "bnv_frame_cancel")
+        self._busy[slot] = False
 
     def ready(self, slot):
         r = self._lib.bnv_frame_ready(self._h, slot)

@@ -167,7 +167,7 @@ def run(nm, frames, pipelined=True, in_flight=2, on_frame=None, checksums=True, 
     return {"frames": k_done, "empty_frames": empty, "rows": rows, "capacity": caps, "sums": sums, "seconds": dt}
 
 
-def bench_pass(model, dev, n_frames, check=None, grid=512, check_every=200):
+def bench_pass(model, dev, n_frames, check=None, grid=512, check_every=200, keep=None):
     """bench.py's `sequence` entry: ``n_frames`` of the sweep through a NeuralMap that starts at the reference's
     initial capacity (sparse_volume.py:486: 100,000 rows) and grows on demand, two frames in flight, TSDF side fusion
     on; frames are rendered on the GPU ahead of the timed loop (resident inputs, like the headline).
@@ -192,6 +192,8 @@ def bench_pass(model, dev, n_frames, check=None, grid=512, check_every=200):
     st2 = run(nm2, frames, pipelined=True, in_flight=2, checksums=False)
     rows_end = nm2.volume.num_rows()
     caps = st2["capacity"]
+    if keep is not None:
+        keep.append(nm2)          # (the caller goes on with the map: bench.py meshes the whole sweep volume)
     return {"frames": st2["frames"], "value": st2["frames"] / st2["seconds"], "unit": "frames/s",
             "ms_per_frame": 1e3 * st2["seconds"] / max(st2["frames"], 1),
             "what": f"moving-camera sweep of a room (bnv_fusion_amd/sequence.py), 640x480, {grid}^3 grid / voxel "

@@ -86,6 +86,7 @@ class SparseVolume:
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         self._epoch = 0
+        self._lws_generation = 0      # counts re-makes of the decode workspaces (the frame pipeline forgets old pointers)
         self.reset(capacity)
         self.avg_n_pts = 0
         self.n_pts_list = []
@@ -512,12 +513,14 @@ class SparseVolume:
             ws = self._lattice_ws2.get(which)
             if ws is None or ws.numel() < need:
                 ws = self._lattice_ws2[which] = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+                self._lws_generation += 1
             self._lattice_epoch += 1           # (one counter for all: each workspace sees increasing epochs)
             self._lattice_last = ws
             return ws, self._lattice_epoch
         if self._lattice_ws is None or self._lattice_ws.numel() < need:
             # zero-filled: the per-row stamps at the front of the workspace must start at 0
             self._lattice_ws = torch.zeros(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._dev)
+            self._lws_generation += 1
             if self._lattice_ws2 is None:
                 self._lattice_epoch = 0
         self._lattice_epoch += 1

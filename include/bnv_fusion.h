@@ -65,12 +65,29 @@ typedef struct bnv_grid {
    * touched block that have no owner yet are pinned at the same moment to (bx + 5 by + 7 bz) % shard_world, so that
    * whenever a voxel is emitted every block of its 3x3x3 neighbourhood has an owner that never changes afterwards
    * (the boundary / ghost-row tests of the exchange rely on that).  Set by bnv_encode_begin* of the frame; every other
-   * call only reads it. */
+   * call only reads it.
+   * That is BNV_SHARD_RULE_GREEDY, what a zeroed buffer means: blocks interleave finely, every rank holds an even
+   * sample of ANY view (max / mean load 1.01-1.06) and ~1.2 x the single-GPU decode work is done in total (the halo).
+   * bnv_shard_state_configure selects BNV_SHARD_RULE_REGION instead: contiguous regions.  cur[r] = the voxels THIS
+   * frame touches in blocks rank r owns; a new block without an owner, in walk order (bands stacked along `axis`), goes
+   * to the least-loaded not-full owner among its 26 neighbour blocks, else to the RECEIVER (the least-loaded rank, which
+   * keeps that role until it is full: cur * world >= the frame's touched voxels); then the untouched neighbours of the
+   * new blocks are pinned to the owner of the first new block (walk order) that reaches them -- regions grow outwards
+   * -- or to the receiver when that owner carries more than 9/8 of its share.  Total decode work ~1.03-1.07 x single
+   * GPU, a quarter of the boundary records; balanced while the view stays put or moves ACROSS the bands (1.04 on the
+   * benchmark's pan with bands stacked along the vertical), not for a camera that sweeps a room (1.4-1.5).  Same
+   * invariant, same determinism: every rank computes the same table. */
   void* shard_state;
 } bnv_grid_t;
 #define BNV_GRID_MLP_MODE(m) ((m) + 1)
+#define BNV_SHARD_RULE_GREEDY 0
+#define BNV_SHARD_RULE_REGION 1
 /* Bytes of bnv_grid_t.shard_state for a grid of n_xyz voxels in blocks of (1 << block_log2)^3. */
 size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2);
+/* Selects the first-touch rule of a ZEROED shard_state buffer (before its first frame; the same call on every rank):
+ * rule BNV_SHARD_RULE_*, axis 0 / 1 / 2 = the grid axis the region rule stacks its first bands along (the axis the
+ * camera moves least along: the vertical).  Enqueued on `stream`. */
+int bnv_shard_state_configure(void* shard_state, int32_t rule, int32_t axis, bnv_stream_t stream);
 /* Byte offsets inside it: the per-rank loads (uint64[64]) and the owner table (one byte per block, index
  * (bx * nby + by) * nbz + bz; bits 0..5 owner, bit 6 assigned, bit 7 touched), for tools and tests. */
 size_t bnv_shard_state_loads_offset(void);
@@ -714,6 +731,21 @@ int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* pipe, int32_t grid_mlp_mode);
 int bnv_frame_begin_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
                           const double* intr_host, const double* T_wc_host, const float* color_im);
 int bnv_frame_begin_points(bnv_frame_pipe_t* pipe, int slot, const float* input_pts, int64_t n_points);
+/* The TSDF side fusion (run_e2e.py:99-109) of a frame begun with bnv_frame_begin_points that ALSO carries its depth
+ * image -- the reference dataset's frames hold input_pts, rgbd, intr_mat and T_wc together (run_e2e.py:78-109) -- gated
+ * on the device by the frame's in-bounds point count like the depth path's.  Between the frame's begin and its upsert;
+ * a no-op without a TSDF volume in the config.  depth_dtype 0 = uint16 mm, 1 = float32 m. */
+int bnv_frame_side_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
+                         const double* intr_host, const double* T_wc_host, const float* color_im);
+/* Abandons a frame that was begun but not upserted (an announced frame that never came, an error on the way): its
+ * encode runs to its end and leaves the workspaces clean, nothing of it reaches the feature volume, the slot is free
+ * again (the next frame begun in it waits for the abandoned work).  What the encode side has already done stays done:
+ * a TSDF side fusion enqueued by begin, the owners a sharded volume's first-touch table gave to new blocks (the same
+ * on every rank that began the frame). */
+int bnv_frame_cancel(bnv_frame_pipe_t* pipe, int slot);
+/* The caller has re-made its decode workspaces (the volume grew): the pipe forgets the pointers it has seen, after
+ * ordering main_stream behind the frames that used them.  No frame may sit between its upsert and its finish. */
+int bnv_frame_pipe_forget_workspaces(bnv_frame_pipe_t* pipe);
 int bnv_frame_upsert(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, void* vol_ws, size_t vol_ws_bytes,
                      void* lattice_ws, int32_t lattice_epoch);
 int bnv_frame_bound(bnv_frame_pipe_t* pipe, int slot, int32_t* max_bound_host);

@@ -20,7 +20,9 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
-    ap.add_argument("--ownership", default=None, choices=["hash", "first_touch"])
+    ap.add_argument("--ownership", default=None, choices=["hash", "first_touch", "region"])
+    ap.add_argument("--ahead", action="store_true", help="spatial: announce every next frame (next_frame=), and at the "
+                    "end a frame that never comes: abandon() must free its slot")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -40,18 +42,34 @@ def main():
     if args.mode == "spatial":
         nm = ShardedNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True, ownership=args.ownership)
         pending = None
+        evals = {}
         for t, fr in enumerate(frames):                 # pipelined: frame t is enqueued before t-1 is collected
-            h = nm.fuse_and_decode_async(fr)
+            if args.ahead:
+                # the next frame's encode is enqueued before this frame's bound is waited for; the last frame announces
+                # one that is never passed
+                h = nm.fuse_and_decode_async(fr, next_frame=frames[t + 1] if t + 1 < len(frames) else frames[0])
+                if t + 1 == len(frames):
+                    try:
+                        nm.fuse_and_decode_async(frames[1])        # not the announced frame: refused, nothing changes
+                        raise SystemExit("a frame other than the announced one was accepted")
+                    except bnv.BnvError:
+                        pass
+                    nm.abandon()
+            else:
+                h = nm.fuse_and_decode_async(fr)
             if pending is not None:
                 c, s = pending[1].result()
+                evals[pending[0]] = nm.backend._last_evals
                 out[pending[0]] = (None if c is None else c.cpu(), None if s is None else s.cpu())
             pending = (t, h)
         c, s = pending[1].result()
+        evals[pending[0]] = nm.backend._last_evals
         out[pending[0]] = (None if c is None else c.cpu(), None if s is None else s.cpu())
+        assert nm.flush() == [] and nm._pre is None and not any(nm.backend.pipe._busy)
         table, loads = nm.backend.owner_table()
         meta = {"host_waits": nm.host_waits, "exchanged_bytes": nm.exchanged_bytes, "rows": nm.volume.num_rows(),
                 "tsdf": nm.backend.tsdf_vol.tsdf.cpu(), "ownership": nm.backend.ownership, "owner_table": table,
-                "owner_loads": loads}
+                "owner_loads": loads, "mlp_evals": evals, "block_log2": nm.backend.block_log2, "axis": nm.backend.axis}
     else:
         nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True)
         batches = [frames[b0: b0 + world] for b0 in range(0, len(frames), world)]

@@ -466,12 +466,18 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("world,ownership,growing", [(2, "hash", False), (3, "hash", False), (2, "first_touch", False),
                                                      (3, "first_touch", False), (3, "first_touch", True),
-                                                     (3, "hash", True), (3, "first_touch", "scatter")])
+                                                     (3, "hash", True), (3, "first_touch", "scatter"),
+                                                     (2, "region", False), (3, "region", True), (5, "region", True),
+                                                     (3, "region", "scatter"), (2, "region:x4", False),
+                                                     (4, "region:z", True), (3, "first_touch:4", False),
+                                                     (3, "first_touch", "odd"), (3, "region", "odd")])
 def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     """``world`` shards of the spatially sharded volume driven phase by phase in ONE process (the all-gather is a
     torch.stack): encode with ownership, upsert, pack boundary records, install ghost rows, decode -- the union of
     the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements.
-    Both ownership rules (block hash; first-touch table, include/bnv_fusion.h: bnv_grid_t.shard_state); ``growing``:
+    All ownership rules (block hash; first-touch tables, include/bnv_fusion.h: bnv_grid_t.shard_state -- the fine
+    interleave of round 4 and the contiguous regions of round 5, "rule:x4" = bands stacked along x and 16^3 blocks); the
+    device's owner table equals the host restatement (distributed.OwnershipModel) fed the same frames; ``growing``:
     the surface patch drifts through the volume, so that frames keep touching blocks for the first time -- among
     them blocks that had been pinned earlier as neighbours of touched ones; ``"scatter"``: a 252^3 grid and thousands of
     small point clusters all over it, so that the FIRST frame brings more new blocks (> 4,096) than the kernels' short
@@ -480,11 +486,19 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     dims, voxel = z["dims"], float(z["voxel_size"])
     scatter = growing == "scatter"
+    odd = growing == "odd"        # a block grid whose size is no power of two, most blocks new in ONE frame
     if scatter:
         dims = np.array([250 * voxel] * 3)
+    if odd:
+        dims = np.array([46 * voxel] * 3)          # 48^3 voxels = 6^3 = 216 blocks
+    ownership, _, opt = ownership.partition(":")
+    axis = {"x": 0, "y": 1, "z": 2}.get(opt[:1], None)
+    blog = int(opt.lstrip("xyz")) if opt.lstrip("xyz") else 3
     shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=(1 << 17) if scatter else 4096, device=DEV,
-                                ownership=ownership) for r in range(world)]
+                                ownership=ownership, block_log2=blog, axis=axis) for r in range(world)]
     n_xyz = shards[0].volume._n_xyz_host
+    host_rule = D.OwnershipModel(ownership, world, n_xyz, blog, axis=shards[0].axis)
+    v0 = shards[0].volume
     model.shard = (0, 1, 3)
     single = bnv.NeuralMap(dims, voxel, model, device=DEV)
     # an empty frame (no point inside the volume): bound 0 on every shard, nothing to exchange, (None, None) out
@@ -509,6 +523,17 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
         for t in range(9):
             frames_np.append(pts.float()[None].numpy())
             pts = torch.cat([pts, clusters(300)])
+    elif odd:
+        g = torch.Generator().manual_seed(3)
+        half = 0.5 * float(dims[0]) - 2 * voxel
+        frames_np = []
+        for t in range(9):     # five dense layers of points: 180 of the grid's 216 blocks are new in the first frame --
+            n = 170000         # more than the largest power of two below 216, so the list is sorted padded to 256 entries
+            p = (torch.rand(n, 3, generator=g) * 2 - 1) * half
+            layer = torch.randint(0, 5, (n,), generator=g).float()
+            p[:, 2] = (layer * 8 - 20 + 0.3) * voxel
+            nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+            frames_np.append(torch.cat([p, nrm], -1).float()[None].numpy())
     elif growing:     # a STATIC surface seen through a window that drifts 1.5 / 1 voxels per frame along x / y: every
         frames_np = []    # frame brings new territory, and a voxel stays in view long enough to go live (weight >= 8)
         g = torch.Generator().manual_seed(5)
@@ -524,6 +549,8 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
         frame = {"input_pts": torch.from_numpy(fr).to(DEV)}
         model.shard = (0, 1, 3)
         ref_coords, ref_sdf = single.fuse_and_decode(frame)
+        ids_host, _ = D.touched_voxels(fr[0], v0.min_coords.cpu().numpy(), v0.max_coords.cpu().numpy(), voxel, n_xyz)
+        host_rule.frame(D.unflatten(ids_host, n_xyz))
         frs = [b.encode(frame) for b in shards]
         bounds = [b.bound(f) for b, f in zip(shards, frs)]
         assert len(set(bounds)) == 1 and bounds[0] > 0                   # every rank computes the same bound
@@ -548,22 +575,26 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     model.shard = (0, 1, 3)
     owned = [o[0] for o in outs]
     table, loads = shards[0].owner_table()
-    if ownership == "first_touch":
+    if ownership != "hash":
         # every rank holds the same table and the same loads; a block is only ever touched with an owner in place
         for b in shards[1:]:
             t2, l2 = b.owner_table()
             assert np.array_equal(t2, table) and np.array_equal(l2, loads)
         assert (table[(table & 0x80) != 0] & 0x40).all() and int(loads.sum()) > 0
-        assert loads.max() <= 1.25 * loads.mean()                      # greedy by weight: the loads stay level
+        if ownership == "first_touch":
+            assert loads.max() <= 1.25 * loads.mean()                  # greedy by weight: the loads stay level
+        # the device's table is the host restatement's, byte for byte, and so are the cumulative loads
+        assert np.array_equal(table, host_rule.table), int((table != host_rule.table).sum())
+        assert np.array_equal(loads, host_rule.load)
     else:
         assert table is None
-    own_of = lambda c: D.voxel_owner(c, world, D.BLOCK_LOG2, table, n_xyz)      # noqa: E731
+    own_of = lambda c: D.voxel_owner(c, world, blog, table, n_xyz)      # noqa: E731
     for r in range(world):
         assert np.all(own_of(owned[r].cpu().numpy()) == r)   # HIP ownership rule == host restatement
         # the records a rank sent are exactly its emitted boundary voxels (device predicate == host restatement)
         n = int(hdr[r, 0])
         sent = blocks.view(world, cap + 1, D.REC_WORDS)[r, 1: 1 + n, :3].cpu().numpy()
-        want = owned[r].cpu().numpy()[D.shard_is_boundary(owned[r].cpu().numpy(), world, D.BLOCK_LOG2, table, n_xyz)]
+        want = owned[r].cpu().numpy()[D.shard_is_boundary(owned[r].cpu().numpy(), world, blog, table, n_xyz)]
         assert np.array_equal(sent[np.lexsort(sent.T[::-1])], want[np.lexsort(want.T[::-1])])
     coords = torch.cat(owned).cpu().numpy()
     sdf = torch.cat([o[1] for o in outs]).cpu().numpy()
@@ -579,7 +610,7 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
         k = b.volume.active_coordinates.cpu().numpy()
         assert np.all(own_of(k[own]) == r) and np.all(own_of(k[~own]) != r)
         assert np.all(own_of(k) >= 0)                                    # every row's block has an owner
-        assert D.shard_adjacent_to(k[~own], world, r, D.BLOCK_LOG2, table, n_xyz).all() and (~own).sum() > 0
+        assert D.shard_adjacent_to(k[~own], world, r, blog, table, n_xyz).all() and (~own).sum() > 0
         f1, w1, _ = single.volume.query(b.volume.active_coordinates)
         assert torch.equal(f1, b.volume.features) and torch.equal(w1, b.volume.weights)
 

@@ -413,3 +413,116 @@ def test_frame_pipe_integrate_only_frames_and_tsdf_prior(bnv):
     assert float((rs != voxel).float().mean()) > 0.05
     plain = ref_nm.volume.decode_lattice(rc, model.nerf, None, query_tensor=False)
     assert not torch.equal(plain, rs)                      # the prior does change the decode
+
+
+@pytest.mark.parametrize("with_rgb", [False, True])
+def test_points_frames_with_depth_update_the_tsdf_volume(bnv, with_rgb):
+    """The reference dataset's frames carry input_pts, the depth image and the colour image together
+    (run_e2e.py:78-109): through the frame pipeline the TSDF side volume must receive the depth exactly as through the
+    per-stage path (NeuralMap.frame_pipe = False) -- round 4's pipe dropped it for frames that hold input_pts."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.frontend import depth_to_input_pts
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    g = torch.Generator().manual_seed(2)
+    frames = []
+    for k, f in enumerate(_frames(10)):
+        f = dict(f)
+        f["input_pts"] = depth_to_input_pts(f["depth"], f["intr_mat"], f["T_wc"], max_depth=3.0, compact=False)[0]
+        if k == 4:                                      # metres as float32 instead of uint16 millimetres
+            f["depth"] = f["depth"].to(torch.float32) / 1000.0
+        if with_rgb:
+            f["rgb"] = (torch.rand(240, 320, 3, generator=g) * 255).floor().to(DEV)
+        frames.append(f)
+    far = dict(frames[6])
+    far["input_pts"] = far["input_pts"] + 50.0          # no point inside: the reference returns before the TSDF fusion
+    frames[6] = far
+    maps = []
+    for use_pipe in (False, True):
+        nm = bnv.NeuralMap(dims3, voxel, model, device=DEV, tsdf=True)
+        nm.frame_pipe = use_pipe
+        hs = [nm.fuse_and_decode_async(f) for f in frames[:3]]
+        outs = [h.result() for h in hs]
+        for f in frames[3:]:
+            outs.append(nm.fuse_and_decode_async(f).result())
+        torch.cuda.synchronize()
+        maps.append((nm, outs))
+    (a, oa), (b, ob) = maps
+    assert b._pipe is not None and a._pipe is None
+    for (ca, sa), (cb, sb) in zip(oa, ob):
+        assert (ca is None) == (cb is None)
+        if ca is not None:
+            assert torch.equal(ca, cb) and torch.equal(sa, sb)
+    assert oa[6] == (None, None)
+    assert float((a.tsdf_vol.weight > 0).float().mean()) > 0.01         # the side volume did receive the frames
+    assert torch.equal(a.tsdf_vol.tsdf, b.tsdf_vol.tsdf) and torch.equal(a.tsdf_vol.weight, b.tsdf_vol.weight)
+    if with_rgb:
+        assert torch.equal(a.tsdf_vol.color, b.tsdf_vol.color) and float(a.tsdf_vol.color.abs().sum()) > 0
+    # nine frames fused, not ten: the frame without a point inside the volume left the TSDF volume alone
+    assert float(a.tsdf_vol.weight.max()) == 9.0
+
+
+def test_frame_cancel_frees_the_slot_and_leaves_the_volume_alone(bnv):
+    """bnv_frame_cancel: a frame that was begun (its encode is enqueued) and is never upserted gives its slot back;
+    the frames around it come out as if it had never been begun."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(11)
+    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV)
+    ref = [ref_nm.fuse_and_decode(f) for f in frames[:5] + frames[6:]]
+    vol = bnv.SparseVolume(8, voxel, dims3, 8, device=DEV)
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=2)
+    got = []
+    for t, fr in enumerate(frames):
+        s = pipe.begin(fr)
+        if t == 5:
+            with pytest.raises(Exception):
+                pipe.begin(frames[0], slot=s)          # the slot is busy
+            pipe.cancel(s)
+            with pytest.raises(Exception):
+                pipe.cancel(s)                         # nothing begun in it any more
+            continue
+        pipe.bound(s)
+        pipe.upsert(s)
+        pipe.finish(s)
+        got.append(pipe.outputs(s, pipe.result(s)))
+    for (rc, rs), (gc, gs) in zip(ref, got):
+        assert torch.equal(rc, gc) and torch.equal(rs, gs)
+    assert vol.num_rows() == ref_nm.volume.num_rows()
+
+
+def test_slot_reuse_ahead_of_the_upsert_is_not_an_error(bnv):
+    """Three slots, the NEXT frame begun before this frame's upsert (ShardedNeuralMap(next_frame=...)): slot (t + 1) is
+    the slot frame t - 2 used, and it is begun again (state 1) before upsert(t) looks up the decode workspace that
+    frame t - 2 used last.  Round 4's hazard check took that for an unfinished frame and refused the upsert."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(12)
+    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV)
+    ref = [ref_nm.fuse_and_decode(f) for f in frames]
+    vol = bnv.SparseVolume(8, voxel, dims3, 8, capacity=3000, device=DEV)      # it also grows on the way
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=3)
+    got, pend = [], []
+    pre = pipe.begin(frames[0])
+    for t in range(len(frames)):
+        s = pre
+        while len(pend) >= 1:                          # one finished frame uncollected + this one + the next = 3 slots
+            q = pend.pop(0)
+            got.append(pipe.outputs(q, pipe.result(q)))
+        pre = pipe.begin(frames[t + 1]) if t + 1 < len(frames) else None
+        pipe.bound(s)
+        pipe.upsert(s)
+        pipe.finish(s)
+        pend.append(s)
+    while pend:
+        q = pend.pop(0)
+        got.append(pipe.outputs(q, pipe.result(q)))
+    for (rc, rs), (gc, gs) in zip(ref, got):
+        assert torch.equal(rc, gc) and torch.equal(rs, gs)

@@ -1,17 +1,25 @@
-"""Spatially sharded mode on ONE GPU, as rank r of a simulated world of W ranks: what a frame costs a rank of a
-W-GPU node in that mode, and how many host waits it takes.
+"""Spatially sharded mode on ONE GPU, as rank r of a world of W ranks: what a frame costs a rank of a W-GPU node in that
+mode, with the REAL ghost rows of the other ranks.
 
     python tools/spatial_single_rank.py [--world 8] [--rank r | --all-ranks] [--grid 256] [--frames 200] [--in-flight 3]
+                                        [--ownership region|first_touch|hash] [--block-log2 3] [--scene pan|sweep]
 
-Rank r of W (default 0; --all-ranks: every rank in turn, each on a fresh shard of its own, then the MAX over the ranks --
-a rank set runs at the pace of its slowest member) voxelises the whole frame (replicated), encodes + upserts only the
-voxels it owns (the upsert launch appends its boundary records), runs the frame's ONE all-gather (a real RCCL call on
-a one-rank group; the other ranks' blocks are simulated by W - 1 copies of its own block, which the install kernel
-processes like foreign ones), installs and decodes the voxels it owns -- through the product path (HipShardBackend
-over the C frame pipeline).  Reported per rank: wall clock per frame with `--in-flight` frames enqueued ahead (the
-pipelined figure a node would run at if every rank keeps this pace), the host's enqueue time per frame, the MLP
-kernels' own durations (HIP events) and the rank's share of the frame's work (voxels, pairs, MLP evaluations); for
-rank 0 also one frame at a time (latency).  The volume is pre-rolled like the bench (30 frames).  `--frames` >= 2000
+Two passes.  RECORD (`--record FILE`, a process of its own): all W shards of the volume live in this one process and run
+the frames in lock step through the product path -- encode with ownership, bound, upsert (+ boundary records), the
+exchange as a torch.stack of the W send blocks, install, decode -- exactly what W processes over gloo / RCCL do
+(tests/test_gpu_multiprocess.py checks that equivalence); every frame's W send blocks are kept, and next to them what
+every rank did (voxels, pairs, SDF-MLP evaluations) and what the single volume does for the same frames.  REPLAY
+(`--ghosts FILE`): rank r alone, timed: it voxelises the whole frame (replicated), encodes + upserts the voxels it owns,
+runs the frame's ONE all-gather (a real RCCL call on a one-rank group that lands its own block) into a buffer that
+already holds the OTHER ranks' recorded blocks for that frame (one device copy: the stand-in for the collective's
+payload), installs the adjacent records as ghost rows and decodes the voxels it owns.  Round 4's tool filled the other
+ranks' blocks with copies of the rank's own block: no foreign voxel ever became a ghost row, lattice points with a
+foreign corner stayed dead and a rank of 8 was priced at 171 k evaluations where a real one does ~270 k.
+
+`--all-ranks`: the record pass, then every rank in a process of its own, then the MAX over the ranks (a rank set runs
+at the pace of its slowest member).  Reported per rank: wall clock per frame with `--in-flight` frames enqueued ahead,
+the host's enqueue time, the MLP kernels' own durations (HIP events), the rank's share of the work -- and the
+evaluation count of the record pass beside the replay's (they must agree: same frames, same ghosts).  `--frames` >= 2000
 gives the sustained figure (the package heats up over the first ~1000 frames)."""
 import argparse, ctypes as C, gc, os, socket, sys, time
 import numpy as np, torch, torch.distributed as dist
@@ -32,6 +40,11 @@ ap.add_argument("--checkpoint", default="fp32", choices=["fp32", "tcnn"])
 ap.add_argument("--trace", action="store_true", help="HIP-event timeline of the two streams over a few frames")
 ap.add_argument("--reserve", type=int, default=0, help="CUs the persistent MLP kernels leave to other streams")
 ap.add_argument("--ownership", default=None, help="ownership rule of the shards (default: the package's)")
+ap.add_argument("--block-log2", type=int, default=None, help="block edge of the sharding, log2 voxels (default: the package's)")
+ap.add_argument("--axis", type=int, default=None, help="region rule: axis the first bands are stacked along")
+ap.add_argument("--scene", default="pan", choices=["pan", "sweep"], help="the bench's panning camera or the room sweep (sequence.py)")
+ap.add_argument("--record", default=None, help="(internal) record pass: all W shards in this process, blocks saved to this file")
+ap.add_argument("--ghosts", default=None, help="recorded blocks of the other ranks (from --record); without it --rank records first")
 ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-masked five-stream schedule; 0 = four streams "
                 "(default: the package's)")
 ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
@@ -50,14 +63,22 @@ if args.all_ranks:
     # pipeline (several pipelines created one after the other in ONE process end up, now and then, with streams that
     # share a hardware queue: 0.46 instead of 0.27 ms per frame on a random rank; a fresh process never showed it).  The
     # parent never touches the GPU.
-    import json, subprocess
+    import json, subprocess, tempfile
     rows = []
     base = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--all-ranks"]
+    ghosts = args.ghosts or os.path.join(tempfile.gettempdir(), f"bnv_ghosts_{os.getpid()}.pt")
+    if not args.ghosts:
+        # the record pass: all W shards in one process, real exchange, the blocks of every frame saved
+        out = subprocess.run(base + ["--record", ghosts], capture_output=True, text=True, timeout=1800)
+        print(out.stdout, end="")
+        if out.returncode != 0:
+            print(out.stderr[-3000:])
+            raise SystemExit("record pass failed")
+        base += ["--ghosts", ghosts]
     # a short throw-away run first: the first process on a fresh box pays for cold file caches and clocks
     subprocess.run(base + ["--rank", "0", "--frames", "200", "--no-latency"], capture_output=True, text=True, timeout=900)
     for r in range(W):
-        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--all-ranks"] + \
-              ["--rank", str(r), "--json", "--no-latency"]
+        cmd = base + ["--rank", str(r), "--json", "--no-latency"]
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
         lines = out.stdout.splitlines()
         js = [l for l in lines if l.startswith("{\"rank\"")]
@@ -67,10 +88,14 @@ if args.all_ranks:
         print("\n".join(l for l in lines if not l.startswith("{\"rank\"")))
         rows.append(json.loads(js[-1]))
     print(f"\nall {W} ranks ({args.frames} frames each, {args.in_flight} in flight; one process per rank, one after the other):")
-    print("  rank   ms/frame   (median, slowest segment)   voxels owned   pairs encoded   MLP evaluations   encoder ms   table ms   host ms")
+    print("  rank   ms/frame   (median, slowest segment)   voxels owned   pairs encoded   MLP evaluations (record pass)   encoder ms   table ms   host ms")
     for o in rows:
         print(f"  {o['rank']:4d}   {o['ms']:8.3f}   ({o['ms_med']:.3f}, {o['ms_worst']:.3f})            {o['own']:12.0f}   "
-              f"{o['pairs']:13.0f}   {o['evals']:15.0f}   {o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
+              f"{o['pairs']:13.0f}   {o['evals']:15.0f} ({o.get('evals_rec', 0):9.0f})   {o['enc_ms']:10.3f}   {o['tab_ms']:8.3f}   {o['host_ms']:7.3f}")
+    if rows and rows[0].get("single_evals"):
+        tot = sum(o["evals"] for o in rows)
+        print(f"  sum of the ranks' evaluations / the single volume's ({rows[0]['single_evals']:.0f}, record pass) = "
+              f"{tot / rows[0]['single_evals']:.3f}")
     for k, name in (("own", "voxels owned"), ("pairs", "pairs encoded"), ("evals", "MLP evaluations")):
         v = np.array([o[k] for o in rows])
         print(f"  {name}: max / mean over the ranks {v.max() / max(v.mean(), 1e-9):.3f}")
@@ -79,6 +104,8 @@ if args.all_ranks:
           f"for the rank set at the pace of its slowest rank")
     m = np.array([o["ms_med"] for o in rows])
     print(f"  median segments: mean {m.mean():.3f}, MAX {m.max():.3f} (rank {int(m.argmax())}) -> {1e3 / m.max():.0f} frames/s")
+    if not args.ghosts and os.path.exists(ghosts):
+        os.remove(ghosts)
     raise SystemExit(0)
 for _try in range(8):     # (a free port can be taken between the probe and the store's listen: try another)
     with socket.socket() as s:
@@ -89,14 +116,23 @@ for _try in range(8):     # (a free port can be taken between the probe and the 
     except Exception as e:
         if "EADDRINUSE" not in str(e) or _try == 7:
             raise
-dims, voxel = synthetic.GRID_DIMS[args.grid]
-model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.checkpoint == "tcnn")
 POOL = 64
-frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
-          for t in range(30 + POOL)]
+if args.scene == "sweep":
+    # the room sweep of sequence.py (a camera that turns and walks): frames 0 .. 30 + POOL of it, then the pool cycles
+    from bnv_fusion_amd import sequence
+    dims, voxel, scale = sequence.DIMS[args.grid]
+    frames = list(sequence.sweep_frames(range(30 + POOL), scale=scale, device="cuda:0"))
+else:
+    dims, voxel = synthetic.GRID_DIMS[args.grid]
+    frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
+              for t in range(30 + POOL)]
+model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.checkpoint == "tcnn")
+SHARD_KW = {k: v for k, v in (("ownership", args.ownership), ("block_log2", args.block_log2), ("axis", args.axis)) if v is not None}
 lib = _lib.load()
 if args.reserve:
     _lib.check(lib.bnv_set_option(b"reserve_cus", args.reserve), "reserve_cus")
+if os.environ.get("BNV_HALF_TAIL") is not None:      # A/B: the table kernel's half-tile tail
+    _lib.check(lib.bnv_set_option(b"half_tail", int(os.environ["BNV_HALF_TAIL"])), "half_tail")
 ranks_i32 = torch.arange(W, dtype=torch.int32, device="cuda:0")
 
 
@@ -106,10 +142,84 @@ def ev(stream):
     return e
 
 
+def record(path):
+    """All W shards in this process, lock step, real exchange (the stack of the W send blocks); keeps every frame's
+    blocks and every rank's work, and runs the single volume beside them."""
+    shards = [D.HipShardBackend(np.array([dims] * 3), voxel, model, r, W, capacity=1 << 21, device="cuda:0", tsdf=False,
+                                n_slots=2, **SHARD_KW) for r in range(W)]
+    for b in shards:
+        b.inputs_resident, b.copy_results = True, False
+    model.shard = (0, 1, 3)
+    single = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=1 << 21, device="cuda:0", tsdf=False)
+    single.frame_pipe = False
+    blocks_of, caps, work = [], [], []
+    single_evals, single_vox = [], []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t, fr in enumerate(frames):
+            decode = t >= 30
+            model.shard = (0, 1, 3)
+            if decode:
+                c, _ = single.fuse_and_decode(fr)
+                single_evals.append(int(single.volume.last_lattice_evals()[0]) if c is not None else 0)
+                single_vox.append(0 if c is None else len(c))
+            else:
+                single.integrate(fr)
+                single_evals.append(0)
+                single_vox.append(0)
+            frs = [b.encode(fr) for b in shards]
+            bounds = [b.bound(f) for b, f in zip(shards, frs)]
+            assert len(set(bounds)) == 1, bounds
+            cap = shards[0].exchange_capacity(bounds[0])
+            sends = [b.upsert(f, cap, decode) for b, f in zip(shards, frs)]
+            blk = torch.stack(sends).clone() if cap else None
+            w = []
+            for b, f in zip(shards, frs):
+                if cap:
+                    b.install(f, blk.view(-1), cap)
+                h = b.finish(f, b.decode(f) if decode else None, 0)
+                c, _ = b.result(h)
+                w.append((0 if c is None else len(c), b.last_owned_pairs, b._last_evals))
+            blocks_of.append(None if blk is None else blk.cpu())
+            caps.append(cap)
+            work.append(w)
+    torch.cuda.synchronize()
+    work = np.array(work, dtype=np.float64)              # [frame, rank, (voxels, pairs, evaluations)]
+    tail = slice(30 + 8, None)                           # the frames the replay times
+    ev = work[tail, :, 2]
+    se = np.array(single_evals[30 + 8:], dtype=np.float64)
+    sent = np.array([[int(b.view(W, -1, D.REC_WORDS)[r, 0, 0]) if b is not None else 0 for r in range(W)] for b in blocks_of[30 + 8:]], dtype=np.float64)
+    emitted = work[tail, :, 0].sum(1)
+    print(f"record pass: world {W}, {args.grid}^3, scene {args.scene}, ownership {shards[0].ownership}, blocks "
+          f"{1 << shards[0].block_log2}^3" + (f", bands along axis {shards[0].axis}" if shards[0].ownership == "region" else "")
+          + f": {len(frames)} frames in {time.perf_counter() - t0:.1f} s")
+    print(f"  SDF-MLP evaluations per frame (pool frames): single volume {se.mean():,.0f}; per rank "
+          + " ".join(f"{v:,.0f}" for v in ev.mean(0)))
+    print(f"  sum over ranks / single = {ev.sum(1).mean() / se.mean():.3f}   max / mean per frame = "
+          f"{(ev.max(1) / ev.mean(1)).mean():.3f}   slowest rank / (single / world) = {(ev.max(1) / (se / W)).mean():.3f}")
+    print(f"  pairs max / mean = {(work[tail, :, 1].max(1) / work[tail, :, 1].mean(1)).mean():.3f}   boundary records / emitted "
+          f"voxels = {(sent.sum(1) / np.maximum(emitted, 1)).mean():.3f}   records sent per rank {sent.mean():,.0f}   "
+          f"all-gather {W * (np.mean(caps[30 + 8:]) + 1) * 48 / 1e6:.2f} MB per rank and frame")
+    torch.save({"blocks": blocks_of, "caps": caps, "work": work, "single_evals": single_evals, "world": W,
+                "ownership": shards[0].ownership, "block_log2": shards[0].block_log2, "axis": shards[0].axis,
+                "scene": args.scene, "grid": args.grid}, path)
+
+
+if args.record:
+    record(args.record)
+    dist.destroy_process_group()
+    raise SystemExit(0)
+GH = None
+if args.ghosts:
+    GH = torch.load(args.ghosts, weights_only=False)
+    assert GH["world"] == W and GH["scene"] == args.scene and GH["grid"] == args.grid
+    SHARD_KW.update(ownership=GH["ownership"], block_log2=GH["block_log2"], axis=GH["axis"])
+    GH["dev"] = [None if b is None else b.cuda() for b in GH["blocks"]]
+
+
 def price(rank, latency):
-    kw = {} if args.ownership is None else {"ownership": args.ownership}
     be = D.HipShardBackend(np.array([dims] * 3), voxel, model, rank, W, capacity=1 << 21, device="cuda:0", tsdf=True,
-                           n_slots=max(4, args.in_flight + 2 + args.ahead), **kw)
+                           n_slots=max(4, args.in_flight + 2 + args.ahead), **SHARD_KW)
     be.inputs_resident = True
     be.copy_results = False
     torch.cuda.synchronize()
@@ -117,13 +227,21 @@ def price(rank, latency):
     HOST = {k: 0.0 for k in ("begin", "bound", "upsert", "all_gather", "simulate", "finish")}
     TRACE = []
 
-    def exchange(f, send, cap):
+    def exchange(f, send, cap, t):
         one = be.recv_buffer(W * send.numel())
         blocks = one.view(W, cap + 1, D.REC_WORDS)
-        dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)   # the collective call itself (1-rank group)
-        t4 = time.perf_counter()
-        blocks[:] = blocks[rank].clone()                              # the other ranks' blocks: copies, sender ids patched
-        blocks[:, 0, 1] = ranks_i32
+        if GH is not None:
+            # the other ranks' REAL blocks of this frame (record pass), one device copy = the payload the collective
+            # would land; then the collective call itself (1-rank group) lands this rank's own block over its slot
+            assert GH["caps"][t] == cap, (t, GH["caps"][t], cap)
+            one.copy_(GH["dev"][t].view(-1))
+            dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
+            t4 = time.perf_counter()
+        else:
+            dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
+            t4 = time.perf_counter()
+            blocks[:] = blocks[rank].clone()                          # (round 4's stand-in: copies of the own block)
+            blocks[:, 0, 1] = ranks_i32
         be.install(f, one, cap)
         stats["recv"] += one.numel() * 4
         return t4
@@ -143,14 +261,14 @@ def price(rank, latency):
             PRE[0] = (nxt, be.encode(nxt))
         return f
 
-    def enqueue(fr, decode=True, nxt=None):
+    def enqueue(fr, decode=True, nxt=None, t=-1):
         if args.trace and be.pipe is not None:
             E, M = be.pipe.enc, be.pipe.main
             e0 = ev(E); f = begin(fr, nxt); e1 = ev(E)
             cap = be.exchange_capacity(be.bound(f))
             m0 = ev(M); send = be.upsert(f, cap, decode); m1 = ev(M)
             if cap:
-                exchange(f, send, cap)
+                exchange(f, send, cap, t)
             m2 = ev(M)
             h = be.finish(f, be.decode(f) if decode else None, 0)
             m3 = ev(M)
@@ -165,7 +283,7 @@ def price(rank, latency):
         send = be.upsert(f, cap, decode)
         t3 = t4 = t5 = time.perf_counter()
         if cap:
-            t4 = exchange(f, send, cap)
+            t4 = exchange(f, send, cap, t)
             t5 = time.perf_counter()
         h = be.finish(f, be.decode(f) if decode else None, 0)
         t6 = time.perf_counter()
@@ -193,7 +311,7 @@ def price(rank, latency):
         for j, t in enumerate(idx):
             while len(pend) >= in_flight:
                 collect(pend.pop(0))
-            pend.append(enqueue(frames[t], decode, frames[idx[j + 1]] if j + 1 < len(idx) else None))
+            pend.append(enqueue(frames[t], decode, frames[idx[j + 1]] if j + 1 < len(idx) else None, t))
         while pend:
             collect(pend.pop(0))
 
@@ -226,6 +344,11 @@ def price(rank, latency):
                "own": stats["own"] / n, "pairs": stats["pairs"] / n,
                "evals": stats["evals"] / n, "enc_ms": ms[0] / max(cnt[0], 1), "tab_ms": ms[1] / max(cnt[1], 1),
                "host_ms": 1e3 * stats["enq"] / n}
+        if GH is not None:
+            # what the record pass (all W shards, real exchange) counted for this rank on the same pool frames: the
+            # replay must do the same work (the live set only grows a little while the pool cycles)
+            out["evals_rec"] = float(np.mean(GH["work"][30 + 8:, rank, 2]))
+            out["single_evals"] = float(np.mean(GH["single_evals"][30 + 8:]))
         print(f"rank {rank} of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
               f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}:")
         print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
@@ -243,7 +366,9 @@ def price(rank, latency):
                                                                      ("blend", pp.blend), ("table", pp.table)) if st is not None)
               + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}; CU split {pp.cu_split}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
-              f"evaluations {out['evals']:.0f}; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
+              f"evaluations {out['evals']:.0f}" + (f" (record pass, all {W} shards with the real exchange: {out['evals_rec']:.0f})"
+                                                  if GH is not None else " (NO real ghost rows: --ghosts / --all-ranks)")
+              + f"; bytes received per frame {stats['recv'] / n / 1e6:.2f} MB ({W} blocks)")
         if args.timeline:
             torch.cuda.synchronize()
             _lib.check(lib.bnv_frame_pipe_timeline_enable(be.pipe._h, 1), "timeline")
