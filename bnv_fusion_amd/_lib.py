@@ -49,7 +49,8 @@ class Volume(C.Structure):
     _fields_ = [("slot_keys", C.c_void_p), ("slot_rows", C.c_void_p), ("n_slots", C.c_int64),
                 ("row_coords", C.c_void_p), ("features", C.c_void_p), ("weights", C.c_void_p),
                 ("num_hits", C.c_void_p), ("row_capacity", C.c_int64), ("n_rows", C.c_void_p),
-                ("n_feats", C.c_int32), ("brick", C.c_void_p), ("brick_dims", C.c_int32 * 3)]
+                ("n_feats", C.c_int32), ("brick", C.c_void_p), ("brick_dims", C.c_int32 * 3),
+                ("lattice_table", C.c_void_p), ("lattice_have", C.c_void_p), ("lattice_persist", C.c_int32)]
 
 
 class SdfDelta(C.Structure):

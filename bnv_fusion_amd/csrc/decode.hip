@@ -720,7 +720,7 @@ __global__ __launch_bounds__(512, 2) void k_decode(DecodeArgs A) {
             const int ent = A.entries[e];
             row = ent >> 5;
             l = ent & 31;
-            A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
+            if (A.need_mask) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
           } else {
             const int64_t ci = e / 27;
             l = (int)(e - ci * 27);
@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(512, 2) void k_lattice_table_x(DecodeArgs A) {
       for (int p = 0; p < 16; ++p) sum += lds[L_PART + p * DM + se];
       const int row = ent_cur >> 5;
       A.table[(size_t)row * 27 + (ent_cur & 31)] = __fmul_rn(sum, voxel);
-      if (A.entries) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
+      if (A.entries && A.need_mask) A.need_mask[row] = 0u;  // leave the per-row masks clean for the next call
     }
     ent_cur = ent_nx;
     ent_nx = ent_nx2;
@@ -1917,7 +1917,7 @@ __global__ __launch_bounds__(256) void k_lattice_table_t(DecodeArgs A) {
       float av = __fmul_rn((float)(_Float16)o[0], voxel);
       av = (float)(_Float16)av;
       A.table[(size_t)row * 27 + l] = av;
-      if (A.entries) A.need_mask[row] = 0u;   // leave the per-row masks clean for the next call
+      if (A.entries && A.need_mask) A.need_mask[row] = 0u;   // leave the per-row masks clean for the next call
     }
   }
 }
@@ -2094,6 +2094,11 @@ struct MarkFused {
   // fringe) are copied by whoever appends them (the same bytes from every writer).
   const float* feat_src;
   float* feat_snap;
+  // Persistent tables (bnv_volume_t.lattice_have; null: none): bit l of have[row] = the entry (row, l) is in the
+  // persistent table for the row's current features.  Entries in rows this call does not decode are listed only when
+  // their bit is clear (and the bit is set: the table kernel behind fills them); the entries of the call's own rows
+  // -- always listed, the upsert has just changed the rows -- set their bits for later frames.
+  uint32_t* have;
 };
 
 __device__ __forceinline__ void snap_row(const MarkFused& F, int row) {
@@ -2112,7 +2117,10 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
                                                                int64_t entry_capacity,
                                                                const int32_t* __restrict__ n_dev, MarkFused F) {
   if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
-  if ((int64_t)blockIdx.x * kMarkThreads * kMarkChunks >= n * 27) return;
+  // chunks per (virtual) workgroup: kMarkChunks -- or ONE when the launch's workgroups then still cover the call (a
+  // shard's 1 / world of a frame): twice the workgroups at work, half the dependent chunk passes per workgroup
+  const int CH = (n * 27 <= (int64_t)gridDim.x * kMarkThreads) ? 1 : kMarkChunks;
+  if ((int64_t)blockIdx.x * kMarkThreads * CH >= n * 27) return;
   // (grid-stride over virtual workgroups vb: the launch is sized for the capacity, capped at two workgroups per CU)
   __shared__ int s_buf[kMarkBuf];
   __shared__ int s_nbr[kMarkOrigins * 27];
@@ -2124,6 +2132,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   __shared__ uint32_t s_wave[kMarkThreads / 64];
 #endif
   __shared__ int s_count, s_base;
+  __shared__ uint32_t s_have[kMarkOrigins];   // persistent tables: live-point bits of the chunk's origins
   if (threadIdx.x < 216) {
     const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
     const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
@@ -2160,12 +2169,12 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     for (int k = 0; k < 8; ++k) m |= 1u << (s_corner[threadIdx.x * 8 + k] & 31);
     s_need[threadIdx.x] = m;
   }
-  for (int64_t vb = blockIdx.x; vb * kMarkThreads * kMarkChunks < n * 27; vb += gridDim.x) {
+  for (int64_t vb = blockIdx.x; vb * kMarkThreads * CH < n * 27; vb += gridDim.x) {
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  for (int ch = 0; ch < kMarkChunks; ++ch) {
-    const int64_t t0 = (vb * kMarkChunks + ch) * kMarkThreads;
-    const bool last = ch == kMarkChunks - 1 || t0 + kMarkThreads >= n * 27;
+  for (int ch = 0; ch < CH; ++ch) {
+    const int64_t t0 = (vb * CH + ch) * kMarkThreads;
+    const bool last = ch == CH - 1 || t0 + kMarkThreads >= n * 27;
     // the neighbour rows of the chunk's origins: one coalesced read, then LDS
     const int64_t b0 = t0 / 27;
     for (int i = threadIdx.x; i < kMarkOrigins * 27; i += kMarkThreads) {
@@ -2182,6 +2191,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         }
       }
       s_nbr[i] = r;
+      if (i < kMarkOrigins) s_have[i] = 0u;
       const unsigned long long bu = __ballot(r >= 0), bo = __ballot(r >= 0 && (r & kOriginBit));
       if ((threadIdx.x & 63) == 0) {
         s_ub[i >> 6] = bu;
@@ -2211,6 +2221,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         if (!((rest >> 13) & 1u)) {  // the origin's own row (always, but for a caller's stale stamp array)
           ent[0] = ((nb27[13] & ~kOriginBit) << 5) | p;     // P inside its origin: l = d
           keep = 1u;
+          if (F.have) atomicOr(&s_have[ob], 1u << p);
         }
         // Entries in rows that are not decoded here belong to the origin floor(P) when that voxel is decoded in
         // this call (it is unique: no flag needed); else every origin that holds P asks need_mask
@@ -2226,9 +2237,14 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
             rowk[k] = (!(c >> 10) && ((rest >> (c & 31)) & 1u)) ? (nb27[c & 31] & ~kOriginBit) : -1;
             lk[k] = (c >> 5) & 31;
           }
+          if (F.have) {   // persistent tables: the bit outlives the call (whoever finds it clear lists the entry)
 #pragma unroll
-          for (int k = 0; k < 8; ++k)
-            seen[k] = (!mine && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
+            for (int k = 0; k < 8; ++k) seen[k] = rowk[k] >= 0 ? atomicOr(&F.have[rowk[k]], 1u << lk[k]) : 0u;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              seen[k] = (!mine && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
+          }
           int at = (int)keep;
 #pragma unroll
           for (int k = 0; k < 8; ++k)
@@ -2271,6 +2287,13 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
     }
     __syncthreads();
 #endif
+    if (F.have) {   // (kernel-uniform) the own-row bits of the chunk's origins join the persistent masks
+      if (threadIdx.x < kMarkOrigins && s_have[threadIdx.x]) {
+        const int r13 = s_nbr[threadIdx.x * 27 + 13];
+        if (r13 >= 0) atomicOr(&F.have[r13 & ~kOriginBit], s_have[threadIdx.x]);
+      }
+      __syncthreads();   // s_nbr / s_have are rewritten by the next chunk
+    }
     const int cnt = s_count;
     if (cnt > 0 && (last || cnt > kMarkBuf - 8 * kMarkThreads)) {   // flush (block-uniform)
       if (threadIdx.x == 0) s_base = atomicAdd(n_entries, cnt);
@@ -2751,6 +2774,11 @@ int bnv_lattice_neighbors(const bnv_volume_t* vol, const bnv_grid_t* grid, const
                                 ws_bytes, epoch, false, stream);
 }
 
+// does this call work on the volume's persistent tables (include/bnv_fusion.h: bnv_volume_t.lattice_persist)?
+static bool lattice_persist(const bnv_volume_t* vol) {
+  return vol && vol->lattice_persist && vol->lattice_table && vol->lattice_have;
+}
+
 static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
                              int32_t epoch, bool clear, bnv_stream_t stream_, const float* snap_src = nullptr) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
@@ -2764,6 +2792,7 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   MarkFused F = {};
   F.feat_src = snap_src;
   F.feat_snap = snap_src ? ws.snap : nullptr;
+  F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
   if (snap_src)
     hipLaunchKernelGGL((k_lattice_mark<false, true>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
@@ -2801,6 +2830,7 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
   F.nbr_rows_out = ws.nbr_rows;
   F.feat_src = snap_src;
   F.feat_snap = snap_src ? ws.snap : nullptr;
+  F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
   if (snap_src)
     hipLaunchKernelGGL((k_lattice_mark<true, true>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
@@ -2845,6 +2875,10 @@ static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, c
   a.n_list = ws.n_list;
   a.table = ws.table;
   a.need_mask = ws.need_mask;
+  if (lattice_persist(vol) && use_entries && features == vol->features) {
+    a.table = vol->lattice_table;   // the listed entries are the ones the persistent table lacks
+    a.need_mask = nullptr;          // (the marking kernel kept its books in lattice_have)
+  }
   a.entries = use_entries ? ws.entries : nullptr;
   const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
   return launch_decode(MODE_LATTICE, mlp_mode_of(grid->mlp_mode), a, (evals + DM - 1) / DM, (hipStream_t)stream,
@@ -2861,12 +2895,13 @@ int bnv_lattice_blend(const bnv_volume_t* vol, const bnv_grid_t* grid, const int
   if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   bnv_sdf_delta_t d = {};
   if (delta) d = *delta;
+  const float* table = lattice_persist(vol) ? vol->lattice_table : ws.table;
   if (d.data)
     hipLaunchKernelGGL(k_lattice_blend<true>, dim3(capped_grid((n * 27 + 255) / 256, 8)), dim3(256), 0,
-                       (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
+                       (hipStream_t)stream, ws.nbr_rows, n, table, *grid, origins, d, out_sdf, n_dev);
   else
     hipLaunchKernelGGL(k_lattice_blend<false>, dim3(capped_grid((n * 27 + 256 * kBlendPpt - 1) / (256 * kBlendPpt), 8)), dim3(256), 0,
-                       (hipStream_t)stream, ws.nbr_rows, n, ws.table, *grid, origins, d, out_sdf, n_dev);
+                       (hipStream_t)stream, ws.nbr_rows, n, table, *grid, origins, d, out_sdf, n_dev);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

@@ -82,6 +82,7 @@ struct bnv_frame_pipe {
   uint64_t lws_serial[4];               // serial of the frame that used the workspace last (0: none)
   uint64_t serial[BNV_PIPE_MAX_SLOTS];  // serial of the frame the slot holds (or held last)
   uint64_t next_serial;
+  int last_decoded;                     // slot of the frame whose decode was enqueued last (-1: none)
   int state[BNV_PIPE_MAX_SLOTS];        // 0 free, 1 begun, 2 upserted, 3 finished (result pending)
   bool used[BNV_PIPE_MAX_SLOTS];        // ev_done has been recorded at least once
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
@@ -186,6 +187,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->lws_serial[k] = 0;
   }
   p->next_serial = 1;
+  p->last_decoded = -1;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
     p->serial[s] = 0;
     p->state[s] = 0;
@@ -547,9 +549,20 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
     if (rc != BNV_OK) return rc;
   }
   tl_mark(p, slot, 8, p->M);
+  // persistent lattice tables (bnv_volume_t.lattice_table): not with the snapshot schedule (its table kernel reads a
+  // copy of the rows, on a stream of its own)
+  bnv_volume_t vol_local = *vol;
+  if (p->split) vol_local.lattice_persist = 0;
+  vol = &vol_local;
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
+    if (vol->lattice_persist && vol->lattice_table && p->B != p->M && p->last_decoded >= 0 &&
+        p->last_decoded != slot && p->used[p->last_decoded])
+      // ONE table serves consecutive frames: this frame's table kernel overwrites entries the blend of the frame
+      // decoded before it (blend stream) may still be reading
+      BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[p->last_decoded], 0));
+    p->last_decoded = slot;
     if (p->T != p->M) {
       // marking + a snapshot of the feature rows the table entries read, on M; the table MLP on T from the snapshot:
       // M is free for the next frame's upsert .. marking chain while this frame's table kernel runs

@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
 #pragma unroll
   for (int f = 0; f < 8; ++f) v.features[row * 8 + f] = r.f[f];
   v.weights[row] = r.w;
+  if (v.lattice_have) v.lattice_have[row] = 0u;   // a ghost row with new values: its table entries are stale
 }
 
 }  // namespace bnv

@@ -195,6 +195,7 @@ __global__ __launch_bounds__(kVolThreads) void k_vol_assign_rows(bnv_volume_t v,
         for (int f = 0; f < v.n_feats; ++f) v.features[row * v.n_feats + f] = 0.f;
         v.weights[row] = 0.f;
         v.num_hits[row] = 0.f;
+        if (v.lattice_have) v.lattice_have[row] = 0u;
       } else {
         *error = 3;
       }
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(kIntThreads) void k_vol_integrate(bnv_volume_t v, c
   *(f32x4*)&v.features[row * 8] = o[0];
   *(f32x4*)&v.features[row * 8 + 4] = o[1];
   v.weights[row] = w_new;
+  if (v.lattice_have) v.lattice_have[row] = 0u;   // the row's table entries are those of its former features
   if constexpr (FRAME) {
     if (X.origin_stamp) X.origin_stamp[row] = X.stamp_epoch;
     if (!X.block) return;
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(256) void k_vol_batch_integrate(bnv_volume_t v, Vol
 #pragma unroll
   for (int f = 0; f < 8; ++f) v.features[row * 8 + f] = fo[f];
   v.weights[row] = w_acc;
+  if (v.lattice_have) v.lattice_have[row] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const float* __restrict__ feats,
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(256) void k_vol_insert_apply(bnv_volume_t v, const 
   for (int f = 0; f < v.n_feats; ++f) v.features[row * v.n_feats + f] = feats[i * v.n_feats + f];
   v.weights[row] = weights[i];
   v.num_hits[row] = hits[i];
+  if (v.lattice_have) v.lattice_have[row] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_vol_query(bnv_volume_t v, const int64_t* __restrict__ coords, int64_t n,

@@ -239,6 +239,9 @@ class OwnershipModel:
         asg = (T[bi] & OWN_ASSIGNED) != 0
         np.add.at(cur, (T[bi[asg]] & OWN_RANK).astype(np.int64), w[asg])
         nbi, nw = bi[new], w[new]
+        self.cur = cur
+        if len(nbi) == 0:
+            return                  # (a frame without a new block changes nothing: the receiver keeps its role)
         order = np.argsort(walk_key(self._bcoord(nbi), self.nb, self.axis), kind="stable")
         nbi, nw = nbi[order], nw[order]
 

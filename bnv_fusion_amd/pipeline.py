@@ -176,6 +176,14 @@ class FramePipe:
         self._lws = [None] * S
         self._lws_next = 0           # decode workspace of the next frame upserted (two alternate with a blend stream)
         self._lws_generation = v._lws_generation
+        # persistent lattice tables (include/bnv_fusion.h: bnv_volume_t.lattice_table): SDF table entries of rows a
+        # frame did not update are carried over instead of re-evaluated (~5 % of a frame's entries in a steady scan).
+        # Not with the snapshot schedule (table stream); BNV_PERSISTENT_TABLES=0 switches it off.
+        self.persistent_tables = self.table is None and os.environ.get("BNV_PERSISTENT_TABLES", "1") != "0"
+        if self.persistent_tables:
+            v.enable_persistent_tables()
+        self._tables_mode = None
+        self._slot_mode = [None] * self.n_slots
         # with a table stream, three: a frame's upsert (which stamps into the workspace) then waits for the blend of
         # the frame THREE back, not two -- with two the chain of frame t+2 could only start behind table(t) + blend(t)
         # and the table stream idled for the rest of that chain
@@ -300,6 +308,7 @@ class FramePipe:
             _lib.check(lib.bnv_frame_begin_depth(self._h, s, _lib.ptr(d), self._dtypes[d.dtype], H, W, K, T,
                                                  _lib.ptr(col)), "bnv_frame_begin_depth")
         self._busy[s] = True
+        self._slot_mode[s] = mode
         self._next = (s + 1) % self.n_slots
         return s
 
@@ -334,12 +343,25 @@ class FramePipe:
                                               _lib.ptr(lws), self._epoch[slot]), "bnv_frame_upsert")
         return None if self.send is None else self.send[slot]
 
+    def _vstruct(self):
+        """The volume as the pipe's calls see it: with the persistent lattice tables switched on for them."""
+        s = self.volume._struct()
+        if self.persistent_tables and self.volume._phave is not None:
+            s.lattice_persist = 1
+        return s
+
     def finish(self, slot, blocks=None, capacity=0):
         v = self.volume
         nerf = self.pointnet.nerf
         lws = self._lws[slot]
         d, keep = v._delta(self.sdf_delta)
-        _lib.check(self._lib.bnv_frame_finish(self._h, slot, C.byref(v._struct()), _lib.ptr(blocks), int(capacity),
+        if self.persistent_tables and lws is not None and (self._slot_mode[slot] != self._tables_mode or v._tables_dirty):
+            # table entries are carried across frames: entries computed in another arithmetic mode (or from features
+            # somebody wrote behind the library's back) must not be.  On the main stream, in front of this frame's marking
+            if self._tables_mode is not None or v._tables_dirty:
+                v.invalidate_tables()
+            self._tables_mode = self._slot_mode[slot]
+        _lib.check(self._lib.bnv_frame_finish(self._h, slot, C.byref(self._vstruct()), _lib.ptr(blocks), int(capacity),
                                               _lib.ptr(nerf.sdf_pack), C.byref(d), _lib.ptr(lws),
                                               lws.numel() if lws is not None else 0, self._epoch[slot]),
                    "bnv_frame_finish")

@@ -87,6 +87,12 @@ class SparseVolume:
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
         self._epoch = 0
         self._lws_generation = 0      # counts re-makes of the decode workspaces (the frame pipeline forgets old pointers)
+        # persistent lattice tables of the frame pipeline (include/bnv_fusion.h: bnv_volume_t.lattice_table): made on
+        # demand (enable_persistent_tables), re-made zeroed with the row arrays; _tables_dirty: features may have been
+        # written behind the library's back (through the tensors of to_tensor()), the next pipelined frame starts afresh
+        self._ptable = None
+        self._phave = None
+        self._tables_dirty = False
         self.reset(capacity)
         self.avg_n_pts = 0
         self.n_pts_list = []
@@ -145,6 +151,8 @@ class SparseVolume:
         self._lattice_last = None
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
+        if self._phave is not None:
+            self._make_persistent_tables()
         _lib.check(self._lib.bnv_volume_clear(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_clear")
         self.tensor_indexer = None
         self.features = None
@@ -166,6 +174,9 @@ class SparseVolume:
         v.n_rows = self._n_rows.data_ptr()
         v.n_feats = 8
         v.brick = self._brick.data_ptr() if self._brick is not None else None
+        if self._phave is not None:      # (every kernel that writes features clears the row's word; lattice_persist
+            v.lattice_table = self._ptable.data_ptr()      # stays 0: only the frame pipeline decodes from the tables)
+            v.lattice_have = self._phave.data_ptr()
         for a in range(3):
             v.brick_dims[a] = self._n_xyz_host[a]
         return v
@@ -245,7 +256,27 @@ class SparseVolume:
         self._lattice_last = None
         self._stamp = None
         self._stamped = None          # (epoch, origins pointer, n) of an integrate(..., stamp_origins=True)
+        if self._phave is not None:
+            self._make_persistent_tables()
         _lib.check(self._lib.bnv_volume_rehash(C.byref(self._struct()), _lib.stream_ptr()), "bnv_volume_rehash")
+
+    def _make_persistent_tables(self):
+        self._ptable = torch.empty(self._row_capacity * 27, dtype=torch.float32, device=self._dev)
+        self._phave = torch.zeros(self._row_capacity, dtype=torch.int32, device=self._dev)
+        self._tables_dirty = False
+
+    def enable_persistent_tables(self):
+        """The frame pipeline's persistent lattice tables (112 bytes per row of capacity): SDF table entries of rows a
+        frame did not update are carried over from the frame that computed them."""
+        if self._phave is None:
+            self._make_persistent_tables()
+
+    def invalidate_tables(self):
+        """Call after writing ``features`` by any means other than this class's methods (an optimiser stepping the
+        Parameter made from ``to_tensor()``'s tensor): the persistent table entries are those of the old features."""
+        if self._phave is not None:
+            self._phave.zero_()
+        self._tables_dirty = False
 
     def _workspace(self, n):
         need = int(self._lib.bnv_volume_workspace_bytes(int(n)))

