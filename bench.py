@@ -327,10 +327,17 @@ def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
     corners = torch.stack([torch.stack([(ce if b & 1 else fl)[:, 0], (ce if b & 2 else fl)[:, 1],
                                         (ce if b & 4 else fl)[:, 2]], -1) for b in range(8)], 1).reshape(-1, 3)
     keys = torch.unique(corners, dim=0)
-    fo, wo, ho = vol.query(keys)
-    present = wo[:, 0] > 0
+    # the sample's corner voxels in the snapshot the decode reads (to_tensor(): the optimiser's count_optim has bumped
+    # ITS weights, not the live table's)
+    ac = vol.active_coordinates
+    pack = lambda c: (c[:, 0] * 4096 + c[:, 1]) * 4096 + c[:, 2]      # noqa: E731
+    order = torch.argsort(pack(ac))
+    pos = torch.searchsorted(pack(ac)[order], pack(keys)).clamp(max=len(ac) - 1)
+    rows = order[pos]
+    present = (ac[rows] == keys).all(1)
+    rows = rows[present]
     ovol = orc.OracleSparseVolume(8, voxel, np.asarray(vol.dimensions), 8)
-    ovol.insert(keys[present].cpu(), fo[present].detach().cpu(), wo[present].cpu(), ho[present].cpu())
+    ovol.insert(keys[present].cpu(), vol.features[rows].detach().cpu(), vol.weights[rows].cpu(), vol.num_hits[rows].cpu())
     ovol.to_tensor()
     ovol.features.requires_grad_(True)
     q = sel.cpu().reshape(1, -1, 1, 3)
@@ -342,11 +349,6 @@ def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
     vol.features.grad = None
     got = vol.decode_pts(sel.reshape(1, -1, 1, 3), model.nerf, None)
     got.sum().backward()
-    # rows of the sample's corner voxels in the GPU volume's table
-    ac = vol.active_coordinates
-    pack = lambda c: (c[:, 0] * 4096 + c[:, 1]) * 4096 + c[:, 2]      # noqa: E731
-    order = torch.argsort(pack(ac))
-    rows = order[torch.searchsorted(pack(ac)[order], pack(keys[present]))]
     g_gpu = vol.features.grad[rows].cpu()
     g_ref = ovol.features.grad
     err_f = float((got.detach().cpu().reshape(-1) - ref.detach().reshape(-1)).abs().max())

@@ -420,12 +420,17 @@ def decode_feature_grid_w_pts(sd, voxel_coords, feat_grid, pts_weight, voxel_siz
 # --------------------------------------------------------------------------- #
 
 
-def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True, ste=False):
+def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True, ste=False, acc16=False):
     """tiny-cuda-nn FullyFusedMLP restated: identity encoding pads the input to a multiple of 16
     with 1.0; ``n_hidden`` hidden layers of ``width`` with ReLU, no bias, output padded to 16;
     weights row-major [out, in] in one flat vector (call sites
     pointnet_utils.py:274-279, modules.py:171-176).  ``half`` rounds weights, inputs and every
-    layer output to fp16 as the CUDA kernel stores them (fp32 accumulate)."""
+    layer output to fp16 as the CUDA kernel stores them (fp32 accumulate).
+    ``acc16``: a SENSITIVITY variant, not a parity claim -- the accumulator is rounded to fp16 after every 16-deep
+    step of the contraction, what a kernel that keeps its accumulator fragments in half precision does [from memory of
+    tiny-cuda-nn's fully_fused_mlp.cu: wmma accumulator fragments of __half; the CUDA source is not in the image and
+    cannot be run here].  The HIP kernels accumulate in fp32 like the default; the gap between the two variants bounds
+    what that unverifiable detail could change (tests/test_oracle_golden.py)."""
     q = (lambda t: t.half().float()) if half else (lambda t: t)
     if half and ste:
         # for gradient checks: the fp16 rounding counts as identity in the backward pass (what autograd does
@@ -439,23 +444,29 @@ def tcnn_mlp(params, x, n_in_padded, n_out, width=64, n_hidden=3, half=True, ste
     for i in range(len(dims) - 1):
         w = q(params[off: off + dims[i + 1] * dims[i]].reshape(dims[i + 1], dims[i]))
         off += dims[i + 1] * dims[i]
-        h = h @ w.t()
+        if acc16:
+            acc = torch.zeros((n, dims[i + 1]), dtype=h.dtype)
+            for k0 in range(0, dims[i], 16):
+                acc = (acc + h[:, k0: k0 + 16] @ w[:, k0: k0 + 16].t()).half().float()
+            h = acc
+        else:
+            h = h @ w.t()
         if i < len(dims) - 2:
             h = F.relu(h)
         h = q(h)
     return h[:, :n_out]
 
 
-def tcnn_point_encoder(params):
+def tcnn_point_encoder(params, acc16=False):
     """tcnnPointNetEncoder.forward(x, global_feat=False), pointnet_utils.py:283-294: x [1, 6, P] -> [1, 8, P]."""
-    return lambda x: tcnn_mlp(params, x[0].t(), 16, 8).t()[None]
+    return lambda x: tcnn_mlp(params, x[0].t(), 16, 8, acc16=acc16).t()[None]
 
 
-def tcnn_geo_forward(params, ste=False):
+def tcnn_geo_forward(params, ste=False, acc16=False):
     """tcnnNeRFModel.geo_forward, modules.py:249-253: [..., 17] -> [..., 1]."""
     def f(x):
         shp = list(x.shape)
-        return tcnn_mlp(params, x.reshape(-1, shp[-1]), 32, 1, ste=ste).reshape(shp[:-1] + [1])
+        return tcnn_mlp(params, x.reshape(-1, shp[-1]), 32, 1, ste=ste, acc16=acc16).reshape(shp[:-1] + [1])
     return f
 
 

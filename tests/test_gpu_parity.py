@@ -637,6 +637,27 @@ def test_depth_to_input_pts_vs_oracle(bnv, orc):
         exact = np.mean(got == ref)
         ulp = np.abs(got.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64)).max()
         assert exact > 0.9999 and ulp <= 1, (exact, ulp)   # same float64 op order; float32 rounding once
+    # The normals once more against an INDEPENDENT float64 implementation (not the oracle's code path, which the GPU
+    # kernel was written next to): scipy's correlation with the normalised Sobel kernels of kornia 0.6.2's
+    # spatial_gradient(mode='sobel', order=1, normalized=True) [from memory of that release; the package is absent:
+    # parity with the reference's normals stays unpinned], replicate padding, cross product, unit length, camera
+    # rotation (fusion_inference_dataset.py:52-66).  Bar: 2e-6 absolute per component (float32 rounding of a unit
+    # vector + float64 summation order).
+    from scipy import ndimage
+    d = mm.astype(np.float64) / 1000.0
+    mask = (d > 0) & (d < 10.0)
+    d = d * mask
+    vv, uu = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    xyz = np.stack([(uu - intr[0, 2]) / intr[0, 0] * d, (vv - intr[1, 2]) / intr[1, 1] * d, d])
+    kx = np.array([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+    gu = np.stack([ndimage.correlate(c, kx, mode="nearest") for c in xyz])
+    gv = np.stack([ndimage.correlate(c, kx.T, mode="nearest") for c in xyz])
+    nrm = np.cross(gu, gv, axis=0)
+    nrm = nrm / np.maximum(np.linalg.norm(nrm, axis=0, keepdims=True), 1e-12)
+    nrm_w = np.einsum("ij,jhw->hwi", np.asarray(T, dtype=np.float64)[:3, :3], nrm)[mask]
+    assert nrm_w.shape == got[:, 3:].shape
+    assert np.abs(got[:, 3:].astype(np.float64) - nrm_w).max() <= 2e-6, np.abs(got[:, 3:] - nrm_w).max()
+    assert np.abs(np.linalg.norm(got[:, 3:].astype(np.float64), axis=1) - 1).max() <= 1e-6
     # no-sync variant: NaN padding, dropped by the encoder's bounds mask
     full, n = depth_to_input_pts(torch.from_numpy(mm).to(DEV), intr, T, compact=False)
     assert int(n) == ref.shape[0] and torch.isnan(full[0, int(n):]).all()

@@ -376,3 +376,39 @@ def test_noncubic_min_pts5_oracle_vs_reference_golden():
     assert np.array_equal(got.numpy() == np.float32(voxel), ref == np.float32(voxel))      # mask decisions
     assert np.abs(got.numpy() - ref).max() <= 2e-6
     assert (ref != np.float32(voxel)).mean() > 0.3
+
+
+def test_tcnn_restatement_fp16_accumulate_sensitivity():
+    """The tiny-cuda-nn arithmetic is UNPINNED (CUDA-only fp16 kernels, not in the image).  One detail that cannot be
+    verified here: whether FullyFusedMLP keeps its accumulator fragments in half precision [from memory: it does].  The
+    HIP kernels and the oracle's restatement accumulate in fp32.  This bounds what that detail can change: the same
+    frames through the restatement with the accumulator rounded to fp16 after every 16-deep step of the contraction --
+    encoder features move by <= 3e-3 (the tolerance the tcnn GPU tests use against the restatement; an fp16 ulp of a
+    feature of magnitude 4), the decoded SDF by <= 1e-4 (the north star's bar), with the same mask decisions."""
+    from conftest import WEIGHTS_TCNN
+    tsd = orc.load_weights(WEIGHTS_TCNN)
+    z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
+    dims, voxel = z["dims"], float(z["voxel_size"])
+    res = {}
+    for acc16 in (False, True):
+        enc = orc.tcnn_point_encoder(tsd["pointnet_backbone.model.params"], acc16=acc16)
+        geo = orc.tcnn_geo_forward(tsd["nerf.model.params"], acc16=acc16)
+        vol = orc.OracleSparseVolume(8, voxel, dims, 8)
+        feats = []
+        with torch.no_grad():
+            for fr in z["frames"]:
+                f, c, ids, g, n = orc.encode_pointcloud(None, torch.from_numpy(fr), vol.n_xyz, vol.min_coords,
+                                                        vol.max_coords, voxel, encoder=enc)
+                feats.append(f)
+                orc.integrate(vol, g, f, c)
+            vol.to_tensor()
+            origins = vol.active_coordinates[(vol.weights[:, 0] >= 8).nonzero()[:, 0][:400]]
+            sdf = vol.decode_pts(orc.lattice_coords(origins.numpy()), None, None, is_coords=True, geo=geo)[0, :, :, 0]
+        res[acc16] = (feats, sdf, origins)
+    (fa, sa, oa), (fb, sb, ob) = res[False], res[True]
+    assert torch.equal(oa, ob)
+    d_feat = max(float((a - b).abs().max()) for a, b in zip(fa, fb))
+    assert 0 < d_feat <= 3e-3, d_feat                       # (measured 1.3e-3 on features of magnitude <= 3.6)
+    assert torch.equal(sa == voxel, sb == voxel) and float((sa != voxel).float().mean()) > 0.3
+    d_sdf = float((sa - sb).abs().max())
+    assert 0 < d_sdf <= 1e-4, d_sdf                         # (measured 2.7e-5 at voxel 0.02)
