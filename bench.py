@@ -81,7 +81,7 @@ PARITY_VOXELS = 2048
 # at 640x480 on top of ~350,000 known rows).  What growing from the reference's 100,000 rows costs is reported
 # separately (`growth`).
 CAPACITY = 1 << 22
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def pmc_traffic(kernel_substr, evals_now):

@@ -146,6 +146,8 @@ struct ShardHdr {
   int32_t rule;                  // BNV_SHARD_RULE_GREEDY (0) | BNV_SHARD_RULE_REGION (1): bnv_shard_state_configure
   int32_t axis;                  // region rule: the axis the first frame's bands are stacked along
   int32_t recv_p1;               // region rule: 1 + the receiver rank (0: none yet)
+  int32_t interleave;            // region rule: 1 once a frame's load was out of balance (max > 1.3 x share): new territory
+                                 // is handed out by the greedy rule from then on (a camera that sweeps)
   uint32_t cur[64];              // k_rank: the voxels THIS frame touches in blocks each rank owns (cleared by k_shard_assign)
 };
 static_assert(sizeof(ShardHdr) <= kShardHdrBytes, "shard state header");

@@ -613,11 +613,34 @@ __global__ __launch_bounds__(256) void k_shard_assign(bnv_grid_t g, const EncCtl
   ShardState S;
   shard_state_layout(g.n_xyz, g.shard_block_log2, (char*)g.shard_state, &S);
   const uint32_t n_listed = (uint32_t)S.hdr->any_new;     // (k_rank counts the new blocks in it)
+  // region rule: contiguous regions keep a rank's load level only while the view stays put; a frame whose most loaded
+  // rank carries more than 1.3 x its share of the touched voxels means the camera sweeps -- from then on new territory
+  // is handed out by the greedy rule (fine interleave: every rank holds an even sample of any view).  Sticky.
+  __shared__ int s_inter;
+  if (threadIdx.x < 64) {
+    const int lane_ = threadIdx.x;
+    uint32_t c = lane_ < g.shard_world ? S.hdr->cur[lane_] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(c, d, 64);
+      c = o > c ? o : c;
+    }
+    if (lane_ == 0) {
+      int inter = S.hdr->interleave;
+      if (!inter && S.hdr->rule == BNV_SHARD_RULE_REGION &&
+          (unsigned long long)c * (unsigned)g.shard_world * 10ull > 13ull * (unsigned long long)(uint32_t)ctl->n_unique) {
+        inter = 1;
+        S.hdr->interleave = 1;
+      }
+      s_inter = inter;
+    }
+  }
+  __syncthreads();
   if (n_listed == 0) {
     if (threadIdx.x < 64) S.hdr->cur[threadIdx.x] = 0u;   // (k_rank of the NEXT frame adds to it)
     return;
   }
-  const bool region = S.hdr->rule == BNV_SHARD_RULE_REGION;
+  const bool region = S.hdr->rule == BNV_SHARD_RULE_REGION && !s_inter;
   int nbw[3];
   shard_block_dims(g.n_xyz, g.shard_block_log2, nbw);
   const int axis = region ? S.hdr->axis : 0;

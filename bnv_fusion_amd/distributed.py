@@ -170,12 +170,16 @@ class OwnershipModel:
                 the frame), else to the least-loaded rank of all; a new block pinned earlier keeps its owner.  Then the
                 untouched neighbour blocks of the new blocks are pinned to the owner of the first new block (walk order)
                 that reaches them -- regions grow outwards -- unless that rank is overloaded
-                (cur * world * 8 > 9 * touched), then to the least-loaded rank: it starts a new region there."""
+                (cur * world * 8 > 9 * touched), then to the least-loaded rank: it starts a new region there.
+                Regions balance the load only while the view stays put: the first frame whose most loaded rank carries
+                more than 1.3 x its share switches the table to the greedy rule for all territory to come
+                (``interleave``, sticky): a camera that sweeps a room gets the fine interleave."""
 
     def __init__(self, rule, world, n_xyz, block_log2=BLOCK_LOG2, axis=1, pin_num=9, pin_den=8):
         assert rule in ("hash", "greedy", "region", "first_touch")
         self.pin_num, self.pin_den = int(pin_num), int(pin_den)
         self.recv = -1
+        self.interleave = False      # region rule: True once a frame's load was out of balance (a sweeping camera)
         self.rule = "greedy" if rule == "first_touch" else rule
         self.world, self.s, self.axis = int(world), int(block_log2), int(axis)
         self.n = np.asarray(n_xyz, dtype=np.int64)
@@ -215,7 +219,15 @@ class OwnershipModel:
         T = self.table
         bi, w = np.unique(self._bidx(t >> self.s), return_counts=True)
         new = (T[bi] & OWN_TOUCHED) == 0
-        if self.rule == "greedy":
+        if self.rule == "region":
+            # contiguous regions keep the load level only while the view stays put: once the most loaded rank carries
+            # more than 1.3 x its share of a frame's voxels, new territory goes by the greedy rule for good
+            cur = np.zeros(self.world, dtype=np.int64)
+            asg = (T[bi] & OWN_ASSIGNED) != 0
+            np.add.at(cur, (T[bi[asg]] & OWN_RANK).astype(np.int64), w[asg])
+            if cur.max() * self.world * 10 > 13 * len(t):
+                self.interleave = True
+        if self.rule == "greedy" or self.interleave:
             for b, wt in zip(bi[new], w[new]):                       # ascending block index
                 if T[b] & OWN_ASSIGNED:
                     r = int(T[b] & OWN_RANK)

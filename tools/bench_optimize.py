@@ -50,3 +50,12 @@ for _ in range(3):
     ev[2].record()
 torch.cuda.synchronize()
 print(f"35,000 queries ({live:.2f} live): forward {ev[0].elapsed_time(ev[1]):.3f} ms, backward {ev[1].elapsed_time(ev[2]):.3f} ms")
+
+# whole-volume mesh extraction (run_e2e.py:164-167): lattice decode of every active voxel + per-voxel marching cubes
+vol.features = vol.features.detach()
+for _ in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m = nm.extract_mesh()
+    torch.cuda.synchronize()
+    print(f"extract_mesh: {1e3 * (time.perf_counter() - t0):.2f} ms, {vol.num_rows()} active voxels, {len(m.vertices)} vertices, {len(m.faces)} faces")

@@ -11,7 +11,7 @@
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = f"{root}/gpurun_out/{R}"
 dst = f"{root}/profiles"
 
@@ -37,8 +37,9 @@ dt = last_json(f"{src}/bench_line_tcnn.json")
 dp = last_json(f"{src}/trace_stdout.log")
 for name, obj in (("bench_line", d), ("bench_line_tcnn", dt), ("bench_line_profiled_run", dp)):
     open(f"{dst}/{R}_{name}.json", "w").write(json.dumps(obj) + "\n")
-for t in ("spatial_world8", "spatial_world8_all_ranks_256", "spatial_world8_all_ranks_512", "spatial_world8_all_ranks_256_hash",
-          "spatial_world8_r03_schedule", "spatial_world8_tcnn", "spatial_world8_timeline", "spatial_world2", "spatial_world4", "fp_replay8", "queue_probe",
+for t in ("spatial_world8", "spatial_world8_all_ranks_256", "spatial_world8_all_ranks_256_first_touch", "spatial_world8_all_ranks_512",
+          "spatial_world8_all_ranks_sweep", "spatial_world8_all_ranks_sweep_first_touch", "spatial_world8_all_ranks_sweep_first_touch16",
+          "spatial_world8_tcnn", "spatial_world8_timeline", "spatial_world2", "spatial_world4", "fp_replay8", "queue_probe",
           "mlp_launch_overhead"):
     if os.path.exists(f"{src}/{t}.txt"):
         import re
@@ -148,10 +149,20 @@ with open(f"{dst}/{R}_README.md", "w") as f:
     W(f"* `{R}_pmc_summary.csv` (+ `{R}_pmc_meta.json`: commit and MLP evaluations per launch of the profiled run) -- three separate `rocprofv3 --pmc ... --kernel-trace` passes of that command (SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA | FETCH_SIZE GRBM_GUI_ACTIVE | WRITE_SIZE), mean per launch.\n")
     def tail_of(name, n=3):
         pth = f"{dst}/{R}_{name}.txt"
-        return " | ".join(l.strip() for l in open(pth).read().splitlines()[-n:]) if os.path.exists(pth) else "(not collected)"
-    W(f"* `{R}_spatial_world8_all_ranks_256.txt`, `{R}_spatial_world8_all_ranks_512.txt` -- `tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000`: the spatially sharded frame through the product path (C frame pipeline, four streams, first-touch ownership) priced on EVERY rank of a simulated world of 8, 2,000 frames per rank (sustained), with each rank's voxels / pairs / MLP evaluations; the rank set runs at the pace of its slowest rank.  256^3: {tail_of('spatial_world8_all_ranks_256')}.  512^3: {tail_of('spatial_world8_all_ranks_512')}.\n")
-    W(f"* `{R}_spatial_world8_all_ranks_256_hash.txt` -- the same with the block-hash ownership of rounds 2-3: {tail_of('spatial_world8_all_ranks_256_hash')}.  `{R}_spatial_world8_r03_schedule.txt` -- rank 0 with round 3's schedule (two streams, the host waits for a frame's bound before it enqueues the next encode, block hash), 2,000 frames: {tail_of('spatial_world8_r03_schedule', 1) if False else ''}see the file.\n")
-    W(f"* `{R}_spatial_world8.txt` (rank 0, 200 frames from an idle GPU + the latency of one frame at a time), `{R}_spatial_world8_tcnn.txt` (tiny-cuda-nn networks, 2,000 frames), `{R}_spatial_world2.txt` (world 2, both ranks); `{R}_fp_replay8.txt` -- `tools/fp_single_rank.py --replay 8`: the frame-parallel mode's per-batch work of one rank of 8.\n")
+        return " | ".join(l.strip() for l in open(pth).read().splitlines()[-n:] if l.strip()) if os.path.exists(pth) else "(not collected)"
+    W(f"* `{R}_spatial_world8_all_ranks_256.txt`, `{R}_spatial_world8_all_ranks_512.txt` -- `tools/spatial_single_rank.py --world 8 --all-ranks --frames 2000`: the spatially sharded frame through the product path (C frame pipeline, four streams, region ownership) priced on EVERY rank of a world of 8 WITH THE OTHER RANKS' REAL GHOST ROWS (a record pass runs all 8 shards in one process with the real exchange and keeps every frame's blocks; every rank then runs alone, timed, replaying them), 2,000 frames per rank (sustained), each rank's voxels / pairs / MLP evaluations next to the record pass's; the rank set runs at the pace of its slowest rank.  256^3: {tail_of('spatial_world8_all_ranks_256', 4)}.  512^3: {tail_of('spatial_world8_all_ranks_512', 4)}.\n")
+    W(f"* `{R}_spatial_world8_all_ranks_256_first_touch.txt` -- the same with round 4's fine-interleave first touch: {tail_of('spatial_world8_all_ranks_256_first_touch', 4)}.\n")
+    W(f"* `{R}_spatial_world8_all_ranks_sweep.txt`, `..._sweep_first_touch.txt`, `..._sweep_first_touch16.txt` -- the room sweep (`sequence.py`: a camera that turns and walks), 256^3, 1,000 frames per rank, under the region rule, the fine interleave with 8^3 blocks and with 16^3 blocks.  region: {tail_of('spatial_world8_all_ranks_sweep', 4)}.  first touch 8^3: {tail_of('spatial_world8_all_ranks_sweep_first_touch', 4)}.  first touch 16^3: {tail_of('spatial_world8_all_ranks_sweep_first_touch16', 4)}.\n")
+    W(f"* `{R}_spatial_world2.txt`, `{R}_spatial_world4.txt` (worlds 2 and 4, every rank), `{R}_spatial_world8.txt` (rank 0, 200 frames from an idle GPU + the latency of one frame at a time), `{R}_spatial_world8_tcnn.txt` (tiny-cuda-nn networks); `{R}_fp_replay8.txt` -- `tools/fp_single_rank.py --replay 8`: the frame-parallel mode's per-batch work of one rank of 8.\n")
+    if os.path.exists(f"{src}/bench_line_8rank_gloo.json") and os.path.getsize(f"{src}/bench_line_8rank_gloo.json") > 10:
+        d8 = last_json(f"{src}/bench_line_8rank_gloo.json")
+        open(f"{dst}/{R}_bench_line_8rank_gloo_functional.json", "w").write(json.dumps(d8) + "\n")
+        pr = d8.get("spatial_sharding", {}).get("per_rank", [])
+        W(f"* `{R}_bench_line_8rank_gloo_functional.json` -- `BNV_DIST_BACKEND=gloo python bench.py --gpus 8 --steps 20 --preheat 64`: EIGHT ranks sharing this one GPU over gloo (functional: its rates mean nothing), the real exchange among 8 shards: `spatial_sharding.per_rank[].mlp_evals_per_frame` = {[int(x['mlp_evals_per_frame']) for x in pr]}; parity of rank 0's outputs against the oracle {d8.get('spatial_sharding', {}).get('parity', {}).get('sdf_max_abs_err_vs_oracle')}.\n")
+    wst = glob.glob(f"{src}/trace_widened/**/*kernel_stats.csv", recursive=True)
+    if wst:
+        shutil.copy(wst[0], f"{dst}/{R}_widened_kernel_stats.csv")
+        W(f"* `{R}_widened_kernel_stats.csv` -- rocprofv3 kernel table of `tools/bench_optimize.py`: the global optimiser's kernels (`k_decode_pts`, `k_decode_pts_bwd`, `k_ray_*`, `k_vol_count_optim*`) and whole-volume mesh extraction (`k_mc_count_indexed`, `k_mc_emit_indexed`, the lattice kernels on every active voxel): the rows behind bench.py's `optimize` / `extract_mesh` entries.\n")
     if os.path.exists(f"{src}/bench_line_2rank_gloo.json") and os.path.getsize(f"{src}/bench_line_2rank_gloo.json") > 10:
         d2 = last_json(f"{src}/bench_line_2rank_gloo.json")
         open(f"{dst}/{R}_bench_line_2rank_gloo_functional.json", "w").write(json.dumps(d2) + "\n")

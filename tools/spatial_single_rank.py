@@ -43,6 +43,9 @@ ap.add_argument("--ownership", default=None, help="ownership rule of the shards 
 ap.add_argument("--block-log2", type=int, default=None, help="block edge of the sharding, log2 voxels (default: the package's)")
 ap.add_argument("--axis", type=int, default=None, help="region rule: axis the first bands are stacked along")
 ap.add_argument("--scene", default="pan", choices=["pan", "sweep"], help="the bench's panning camera or the room sweep (sequence.py)")
+ap.add_argument("--preroll", type=int, default=None, help="frames fused (not decoded) before the pool of 64 timed frames "
+                "(default: 30 for the pan, like the bench; 230 for the sweep: the camera has turned a third of the way by then "
+                "and the region rule has met the sweep)")
 ap.add_argument("--record", default=None, help="(internal) record pass: all W shards in this process, blocks saved to this file")
 ap.add_argument("--ghosts", default=None, help="recorded blocks of the other ranks (from --record); without it --rank records first")
 ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-masked five-stream schedule; 0 = four streams "
@@ -117,15 +120,16 @@ for _try in range(8):     # (a free port can be taken between the probe and the 
         if "EADDRINUSE" not in str(e) or _try == 7:
             raise
 POOL = 64
+PRE = args.preroll if args.preroll is not None else (230 if args.scene == "sweep" else 30)
 if args.scene == "sweep":
-    # the room sweep of sequence.py (a camera that turns and walks): frames 0 .. 30 + POOL of it, then the pool cycles
+    # the room sweep of sequence.py (a camera that turns and walks): frames 0 .. PRE + POOL of it, then the pool cycles
     from bnv_fusion_amd import sequence
     dims, voxel, scale = sequence.DIMS[args.grid]
-    frames = list(sequence.sweep_frames(range(30 + POOL), scale=scale, device="cuda:0"))
+    frames = list(sequence.sweep_frames(range(PRE + POOL), scale=scale, device="cuda:0"))
 else:
     dims, voxel = synthetic.GRID_DIMS[args.grid]
     frames = [{"depth": torch.from_numpy(synthetic.depth_u16(t)).cuda(), "intr_mat": synthetic.intrinsics(), "T_wc": synthetic.pose(t)}
-              for t in range(30 + POOL)]
+              for t in range(PRE + POOL)]
 model = bnv.load_pretrained(device="cuda:0", voxel_size=voxel, tiny_cuda=args.checkpoint == "tcnn")
 SHARD_KW = {k: v for k, v in (("ownership", args.ownership), ("block_log2", args.block_log2), ("axis", args.axis)) if v is not None}
 lib = _lib.load()
@@ -157,7 +161,7 @@ def record(path):
     t0 = time.perf_counter()
     with torch.no_grad():
         for t, fr in enumerate(frames):
-            decode = t >= 30
+            decode = t >= PRE
             model.shard = (0, 1, 3)
             if decode:
                 c, _ = single.fuse_and_decode(fr)
@@ -185,10 +189,10 @@ def record(path):
             work.append(w)
     torch.cuda.synchronize()
     work = np.array(work, dtype=np.float64)              # [frame, rank, (voxels, pairs, evaluations)]
-    tail = slice(30 + 8, None)                           # the frames the replay times
+    tail = slice(PRE + 8, None)                           # the frames the replay times
     ev = work[tail, :, 2]
-    se = np.array(single_evals[30 + 8:], dtype=np.float64)
-    sent = np.array([[int(b.view(W, -1, D.REC_WORDS)[r, 0, 0]) if b is not None else 0 for r in range(W)] for b in blocks_of[30 + 8:]], dtype=np.float64)
+    se = np.array(single_evals[PRE + 8:], dtype=np.float64)
+    sent = np.array([[int(b.view(W, -1, D.REC_WORDS)[r, 0, 0]) if b is not None else 0 for r in range(W)] for b in blocks_of[PRE + 8:]], dtype=np.float64)
     emitted = work[tail, :, 0].sum(1)
     print(f"record pass: world {W}, {args.grid}^3, scene {args.scene}, ownership {shards[0].ownership}, blocks "
           f"{1 << shards[0].block_log2}^3" + (f", bands along axis {shards[0].axis}" if shards[0].ownership == "region" else "")
@@ -199,10 +203,10 @@ def record(path):
           f"{(ev.max(1) / ev.mean(1)).mean():.3f}   slowest rank / (single / world) = {(ev.max(1) / (se / W)).mean():.3f}")
     print(f"  pairs max / mean = {(work[tail, :, 1].max(1) / work[tail, :, 1].mean(1)).mean():.3f}   boundary records / emitted "
           f"voxels = {(sent.sum(1) / np.maximum(emitted, 1)).mean():.3f}   records sent per rank {sent.mean():,.0f}   "
-          f"all-gather {W * (np.mean(caps[30 + 8:]) + 1) * 48 / 1e6:.2f} MB per rank and frame")
+          f"all-gather {W * (np.mean(caps[PRE + 8:]) + 1) * 48 / 1e6:.2f} MB per rank and frame")
     torch.save({"blocks": blocks_of, "caps": caps, "work": work, "single_evals": single_evals, "world": W,
                 "ownership": shards[0].ownership, "block_log2": shards[0].block_log2, "axis": shards[0].axis,
-                "scene": args.scene, "grid": args.grid}, path)
+                "scene": args.scene, "grid": args.grid, "preroll": PRE}, path)
 
 
 if args.record:
@@ -212,7 +216,7 @@ if args.record:
 GH = None
 if args.ghosts:
     GH = torch.load(args.ghosts, weights_only=False)
-    assert GH["world"] == W and GH["scene"] == args.scene and GH["grid"] == args.grid
+    assert GH["world"] == W and GH["scene"] == args.scene and GH["grid"] == args.grid and GH["preroll"] == PRE
     SHARD_KW.update(ownership=GH["ownership"], block_log2=GH["block_log2"], axis=GH["axis"])
     GH["dev"] = [None if b is None else b.cuda() for b in GH["blocks"]]
 
@@ -317,9 +321,9 @@ def price(rank, latency):
 
     out = {}
     with torch.no_grad(), be.stream_context(frames[0]):
-        run(range(30), 2, decode=False)
-        run(range(30, 38), 2)
-        idx = [30 + (i % POOL) for i in range(args.frames)]
+        run(range(PRE), 2, decode=False)
+        run(range(PRE, PRE + 8), 2)
+        idx = [PRE + (i % POOL) for i in range(args.frames)]
         for k in stats:
             stats[k] = 0
         for k in HOST:
@@ -347,8 +351,8 @@ def price(rank, latency):
         if GH is not None:
             # what the record pass (all W shards, real exchange) counted for this rank on the same pool frames: the
             # replay must do the same work (the live set only grows a little while the pool cycles)
-            out["evals_rec"] = float(np.mean(GH["work"][30 + 8:, rank, 2]))
-            out["single_evals"] = float(np.mean(GH["single_evals"][30 + 8:]))
+            out["evals_rec"] = float(np.mean(GH["work"][PRE + 8:, rank, 2]))
+            out["single_evals"] = float(np.mean(GH["single_evals"][PRE + 8:]))
         print(f"rank {rank} of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
               f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}:")
         print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
