@@ -117,3 +117,51 @@ def marching_cubes_lattice_indexed(sdf, origins, voxel_size, min_coords, level=0
                                            float(voxel_size), mn, _lib.ptr(table), _lib.ptr(voff), _lib.ptr(toff),
                                            _lib.ptr(verts), _lib.ptr(faces), _lib.stream_ptr()), "bnv_mc_emit_indexed")
     return verts, faces, nv, nt
+
+
+def post_process_mesh(mesh, vertex_threshold=0.005):
+    """``o3d_helper.post_process_mesh`` (src/utils/o3d_helper.py:220-241; called at run_e2e.py:278, 293 with
+    ``vertex_threshold = voxel_size / 4``): merge close vertices, drop degenerate and duplicated triangles and
+    unreferenced / duplicated vertices, one pass of simple Laplacian smoothing.  A one-off at the end of a run, on the
+    host like the reference's (Open3D on the CPU there; numpy + scipy here).
+
+    PARITY UNPINNED: Open3D is not in the image.  Restated from its documented behaviour [from memory of Open3D 0.14]:
+    ``merge_close_vertices(eps)`` replaces every cluster of vertices closer than ``eps`` by its mean -- here a cluster
+    is a connected component of the "closer than eps" graph, Open3D grows clusters greedily in vertex order, which
+    differs where chains of near vertices exist; ``filter_smooth_simple(1)``: v <- (v + sum of its edge neighbours) /
+    (1 + their number).  -> a new TriMesh."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+    v = np.asarray(mesh.vertices, dtype=np.float64).reshape(-1, 3)
+    f = np.asarray(mesh.faces, dtype=np.int64).reshape(-1, 3)
+    if len(v) == 0 or len(f) == 0:
+        return TriMesh(v, f)
+    # exact duplicates first (neighbouring voxels repeat the vertices on their common lattice edges): far fewer points
+    u, inv = np.unique(v.round(9), axis=0, return_inverse=True)
+    pairs = cKDTree(u).query_pairs(float(vertex_threshold), output_type="ndarray")
+    n = len(u)
+    g = coo_matrix((np.ones(len(pairs), dtype=np.int8), (pairs[:, 0], pairs[:, 1])), shape=(n, n))
+    n_c, lab = connected_components(g, directed=False)
+    cnt = np.bincount(lab, minlength=n_c).astype(np.float64)
+    vm = np.stack([np.bincount(lab, weights=u[:, a], minlength=n_c) / cnt for a in range(3)], 1)
+    f = lab[inv.reshape(-1)][f]
+    f = f[(f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])]               # degenerate triangles
+    if len(f):                                                                               # duplicated triangles:
+        lo = np.argmin(f, axis=1)                                                            # the same cyclic order
+        rot = np.take_along_axis(f, (lo[:, None] + np.arange(3)[None]) % 3, axis=1)
+        _, first = np.unique(rot, axis=0, return_index=True)
+        f = f[np.sort(first)]
+    used = np.unique(f)
+    remap = np.full(n_c, -1, dtype=np.int64)
+    remap[used] = np.arange(len(used))
+    vm, f = vm[used], remap[f]
+    # one pass of filter_smooth_simple: neighbours along triangle edges, every neighbour once
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    m = len(vm)
+    adj = coo_matrix((np.ones(2 * len(e)), (np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]]))),
+                     shape=(m, m)).tocsr()
+    deg = np.asarray(adj.sum(1)).reshape(-1)
+    vs = (vm + adj @ vm) / (1.0 + deg)[:, None]
+    return TriMesh(vs.astype(np.float32), f)

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import bnv_fusion_amd as bnv                                   # noqa: E402
 bnv.configure_runtime()                                       # optional: 8 hardware queues for the pipelined streams
 from bnv_fusion_amd import datasets, synthetic                # noqa: E402
+from bnv_fusion_amd.mesh import post_process_mesh             # noqa: E402
 
 
 def main():
@@ -99,7 +100,9 @@ def main():
             nm.optimize(n_iters=n_iters, last_frame=last, ray_max_dist=max_depth)
             torch.cuda.synchronize()
             t_global += time.perf_counter() - t0
-            mesh = nm.extract_mesh(os.path.join(args.out, f"{idx}.ply"))
+            mesh = nm.extract_mesh()
+            if mesh is not None:                                             # :277-280
+                post_process_mesh(mesh).export(os.path.join(args.out, f"{idx}.ply"))
     mesh = nm.extract_mesh(os.path.join(args.out, "before_optim.ply"))   # :280-282
     steps = int(len(nm.frames) * args.skip_images) * (1 if args.mode == "demo" else 2)   # :283-284
     if not args.no_optimize:
@@ -109,7 +112,10 @@ def main():
         t_global += time.perf_counter() - t0
     print(f"speed on local fusion: {len(nm.frames) / max(t_local, 1e-9):.1f} fps"
           + ("" if args.no_optimize else f"; speed on global fusion: {steps / max(t_global, 1e-9):.1f} fps"))
-    mesh = nm.extract_mesh(os.path.join(args.out, "final.ply"))           # :291-294
+    mesh = nm.extract_mesh()                                             # :291-294
+    if mesh is not None:
+        mesh = post_process_mesh(mesh, vertex_threshold=nm.voxel_size / 4)
+        mesh.export(os.path.join(args.out, "final.ply"))
     nm.save(args.out, scan_id=args.scan_id.split("/")[-1])
     print(f"{len(nm.frames)} frames, {nm.volume.num_rows()} voxels, "
           f"{0 if mesh is None else len(mesh.faces)} triangles -> {args.out}")

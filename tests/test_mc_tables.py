@@ -212,3 +212,31 @@ def test_meshlize_concat_follows_the_reference_loop():
         for e in ((a, b), (b, d), (d, a)):
             cnt[e] += 1
     assert all(n == 1 and cnt.get((b, a), 0) == 1 for (a, b), n in cnt.items())
+
+
+def test_post_process_mesh_welds_cleans_and_smooths():
+    """mesh.post_process_mesh (o3d_helper.py:220-241 restated; Open3D absent: unpinned) on the per-voxel mesh of a sphere:
+    the welded mesh is closed and consistently wound (every directed edge once, its reverse once), has neither
+    degenerate nor duplicated triangles nor unreferenced vertices, fewer than half the vertices of the per-voxel
+    concatenation, and one Laplacian pass moves no vertex by more than a lattice cell and keeps the area within 3 %."""
+    from bnv_fusion_amd.mesh import TriMesh, post_process_mesh
+    R, c = 3.3, np.array([6.2, 6.1, 5.9])
+    o = np.stack(np.meshgrid(*[np.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    r = np.arange(3) * 0.5 - 0.5
+    lat = np.stack(np.meshgrid(r, r, r, indexing="ij"), -1)
+    sdf = (np.linalg.norm(o[:, None, None, None, :] + lat[None] - c, axis=-1) - R).astype(np.float32)
+    v, f = orc.meshlize_concat(sdf, o, 1.0, np.zeros(3))
+    out = post_process_mesh(TriMesh(v, f), vertex_threshold=0.02)
+    assert len(out.vertices) < 0.5 * len(v) and len(out.faces) <= len(f) and len(out.faces) > 0.9 * len(f)
+    ff = out.faces
+    assert (ff[:, 0] != ff[:, 1]).all() and (ff[:, 1] != ff[:, 2]).all() and (ff[:, 0] != ff[:, 2]).all()
+    assert np.array_equal(np.unique(ff), np.arange(len(out.vertices)))                  # no unreferenced vertex
+    edges = np.concatenate([ff[:, [0, 1]], ff[:, [1, 2]], ff[:, [2, 0]]])
+    fwd = {tuple(e) for e in edges.tolist()}
+    assert len(fwd) == len(edges) and all((b, a) in fwd for a, b in fwd)               # closed, consistently wound
+    tri = out.vertices[ff].astype(np.float64)
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1).sum()
+    assert abs(area - 4 * np.pi * R * R) < 0.03 * 4 * np.pi * R * R
+    assert np.abs(np.linalg.norm(out.vertices - c, axis=1) - R).max() < 0.25           # smoothing stays near the sphere
+    empty = post_process_mesh(TriMesh(np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64)))
+    assert len(empty.vertices) == 0 and len(empty.faces) == 0
