@@ -815,7 +815,9 @@ def run_bench(args, rank, world, dev, dist, backend):
     out_common = {"metric": "depth frames/sec fused+decoded, 640x480 @ 256^3 grid", "unit": "frames/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
                   "vs_baseline": None, "dtype": DTYPE[args.mlp_mode], "data": "synthetic"}
-    workload = (f"synthetic 640x480 depth ({n_points} valid points/frame), {args.grid}^3 grid, voxel {voxel}, "
+    workload = (f"synthetic 640x480 depth ({n_points} valid points/frame; the analytic surface of BASELINE.md section 3 as a "
+                f"STATIC scene seen by a camera panning +-4 degrees in 0.5-degree steps -- BASELINE.md glues the pattern to "
+                f"the camera, which leaves no voxel with weight >= 8 and a 93 % masked decode), {args.grid}^3 grid, voxel {voxel}, "
                 f"{'pointnet_tcnn.ckpt (fp16 tcnn)' if tcnn else 'fp32 pointnet.ckpt'} weights; step = "
                 + ("uint16 depth image -> points + normals (GPU front end) + " if args.input == "depth" else "")
                 + "encode_pointcloud + _integrate + "

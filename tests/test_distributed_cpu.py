@@ -19,7 +19,7 @@ class OracleShardBackend:
     """The shard protocol of bnv_fusion_amd.distributed.ShardedNeuralMap on the CPU oracle: same phases, same record
     layout (12 int32 words: x, y, z, weight bits, 8 feature bits; block = header record + capacity records)."""
 
-    def __init__(self, dims, voxel, rank, world):
+    def __init__(self, dims, voxel, rank, world, ownership="hash"):
         from oracle import bnv_oracle as orc
         from bnv_fusion_amd import distributed as D
         self.orc, self.D = orc, D
@@ -27,6 +27,9 @@ class OracleShardBackend:
         self.vol = orc.OracleSparseVolume(8, voxel, dims, 8)
         self.rank, self.world, self.voxel = rank, world, voxel
         self.installed = 0
+        # the ownership rule, as the host restatement of the device's owner table (distributed.OwnershipModel): every
+        # rank feeds it the same replicated voxelisation and ends up with the same table -- no communication
+        self.rule = D.OwnershipModel(ownership, world, self.vol.n_xyz.tolist())
 
     def encode(self, frame):
         o, v, D = self.orc, self.vol, self.D
@@ -40,9 +43,10 @@ class OracleShardBackend:
         inb = ((xyz < (v.max_coords - v.voxel_size)) & (xyz > (v.min_coords + v.voxel_size))).all(-1)
         _, gid = o.get_relative_xyz(xyz[inb][None], v.min_coords, v.voxel_size)
         touched = torch.unique(gid.reshape(-1, 3).long(), dim=0).numpy()
-        bnd = D.shard_is_boundary(touched, self.world)
-        counts = np.bincount(D.voxel_owner(touched[bnd], self.world), minlength=self.world)
-        own = torch.from_numpy(D.voxel_owner(g.numpy(), self.world) == self.rank)
+        self.rule.frame(touched)                       # owners for the blocks this frame touches first (+ pins)
+        bnd = self.rule.is_boundary(touched)
+        counts = np.bincount(self.rule.owner(touched[bnd]), minlength=self.world)
+        own = torch.from_numpy(self.rule.owner(g.numpy()) == self.rank)
         o.integrate(v, g[own], f[own], c[own])
         return D.ShardFrame(grid_ids=g[own], counts=counts, n_avg=n)
 
@@ -55,7 +59,7 @@ class OracleShardBackend:
             return None
         D, v = self.D, self.vol
         g = fr.grid_ids.numpy()
-        send = g[D.shard_is_boundary(g, self.world)] if len(g) else g.reshape(0, 3)
+        send = g[self.rule.is_boundary(g)] if len(g) else g.reshape(0, 3)
         assert len(send) <= fr.counts[self.rank] <= capacity       # the bound bounds
         block = torch.zeros((capacity + 1, D.REC_WORDS), dtype=torch.int32)
         block[0, 0], block[0, 1] = len(send), self.rank
@@ -76,7 +80,7 @@ class OracleShardBackend:
             assert int(blocks[r, 0, 1]) == r and int(blocks[r, 0, 2]) == 0 and n <= capacity
             rec = blocks[r, 1: 1 + n]
             keys = rec[:, :3].long()
-            mine = torch.from_numpy(D.shard_adjacent_to(keys.numpy(), self.world, self.rank)) if n else torch.zeros(0, dtype=torch.bool)
+            mine = torch.from_numpy(self.rule.adjacent_to(keys.numpy(), self.rank)) if n else torch.zeros(0, dtype=torch.bool)
             if mine.any():
                 k = keys[mine]
                 v.insert(k, rec[mine, 4:].contiguous().view(torch.float32),
@@ -108,13 +112,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, frames, dims, voxel, ret):
+def _worker(rank, world, port, frames, dims, voxel, ret, ownership="hash"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bnv_fusion_amd.distributed import ShardedNeuralMap, all_gather_var
-    nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world))
+    nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world, ownership))
     # an empty frame first (no point inside the volume): bound 0 on every rank -> no collective, (empty, empty) out
     far = torch.from_numpy(frames[0]).clone()
     far[..., :3] += 50.0
@@ -125,22 +129,25 @@ def _worker(rank, world, port, frames, dims, voxel, ret):
     assert nm.host_waits == len(frames) + 1 and nm.backend.installed > 0  # one host wait per frame; ghosts installed
     allc = all_gather_var(owned)
     alls = all_gather_var(sdf)
+    ret[f"table{rank}"] = None if nm.backend.rule.table is None else nm.backend.rule.table.copy()
     if rank == 0:
         ret["coords"], ret["sdf"], ret["n0"] = allc.numpy(), alls.numpy(), len(owned)
         ret["bytes"] = nm.exchanged_bytes
     dist.destroy_process_group()
 
 
-def test_two_shards_equal_single_process():
+@pytest.mark.parametrize("ownership", ["hash", "region", "first_touch"])
+def test_two_shards_equal_single_process(ownership):
     from oracle import bnv_oracle as orc
-    from bnv_fusion_amd.distributed import voxel_owner
+    from bnv_fusion_amd.distributed import OwnershipModel, touched_voxels, unflatten, voxel_owner
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     frames = list(z["frames"])      # 12 frames x 6000 points: weights reach min_pts
     dims, voxel = z["dims"], float(z["voxel_size"])
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), frames, dims, voxel, ret), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), frames, dims, voxel, ret, ownership), nprocs=2, join=True)
         coords, sdf, n0 = ret["coords"], ret["sdf"], ret["n0"]
+        tables = [ret["table0"], ret["table1"]]
     # single-process reference
     sd = orc.load_weights(WEIGHTS_FP32)
     vol = orc.OracleSparseVolume(8, voxel, dims, 8)
@@ -148,8 +155,18 @@ def test_two_shards_equal_single_process():
         f, c, _, g, _ = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
         orc.integrate(vol, g, f, c)
     ref = vol.decode_pts(orc.lattice_coords(g.numpy()), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
-    # the shards partition the touched set exactly, by the ownership hash
-    own = voxel_owner(coords, 2)
+    # the shards partition the touched set exactly, by the ownership rule -- whose table both ranks derived alone, and
+    # which is what a third party feeding the model the same frames derives too
+    if ownership == "hash":
+        own = voxel_owner(coords, 2)
+    else:
+        assert np.array_equal(tables[0], tables[1])
+        rule = OwnershipModel(ownership, 2, vol.n_xyz.tolist())
+        for fr in frames:
+            ids, _ = touched_voxels(fr[0], vol.min_coords.numpy(), vol.max_coords.numpy(), voxel, vol.n_xyz.tolist())
+            rule.frame(unflatten(ids, vol.n_xyz.tolist()))
+        assert np.array_equal(rule.table, tables[0])
+        own = rule.owner(coords)
     assert np.all(own[:n0] == 0) and np.all(own[n0:] == 1) and 0 < n0 < len(coords)
     order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
     assert np.array_equal(coords[order], g.numpy())
@@ -355,3 +372,46 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-launch"],
                          env=dict(env, WORLD_SIZE="3", RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "does not match" in bad.stderr
+
+
+@pytest.mark.parametrize("rule", ["first_touch", "region"])
+def test_first_touch_tables_keep_the_exchange_invariant(rule):
+    """distributed.OwnershipModel (the host restatement every sharded GPU test compares the device's owner table with):
+    whenever a voxel is touched, every block of its block's 3x3x3 neighbourhood has an owner, and an owner once given
+    never changes -- what the boundary / ghost-row predicates of the exchange rely on; the cumulative loads account for
+    every touched voxel once.  A window drifting over a static surface goes out of balance under the region rule, which
+    then hands new territory out by the greedy rule for good; a static view never trips that."""
+    from bnv_fusion_amd.distributed import OWN_ASSIGNED, OWN_RANK, OWN_TOUCHED, OwnershipModel, _OFF27
+    n = np.array([64, 64, 64])
+    rng = np.random.default_rng(3)
+    for drifting in (True, False):
+        m = OwnershipModel(rule, 4, n)
+        seen = set()
+        weight = 0
+        prev = m.table.copy()
+        for t in range(40):
+            c0 = np.array([10 + (1.1 * t if drifting else 0), 12 + (0.6 * t if drifting else 0)])
+            xy = (rng.random((3000, 2)) * 26 + c0).astype(np.int64)
+            z = (30 + 6 * np.sin(xy[:, 0] / 7.0) * np.cos(xy[:, 1] / 5.0)).astype(np.int64)
+            vox = np.unique(np.stack([xy[:, 0], xy[:, 1], z], 1), axis=0)
+            vox = vox[(vox >= 1).all(1) & (vox < 63).all(1)]
+            m.frame(vox)
+            t_now = m.table
+            was = (prev & OWN_ASSIGNED) != 0
+            assert np.array_equal(t_now[was] & OWN_RANK, prev[was] & OWN_RANK)          # owners never change
+            blocks = np.unique(vox >> 3, axis=0)
+            for d in _OFF27:
+                e = blocks + d
+                ok = ((e >= 0) & (e < m.nb)).all(1)
+                assert (t_now[m._bidx(e[ok])] & OWN_ASSIGNED).all()                      # the neighbourhood has owners
+            assert (t_now[m._bidx(blocks)] & OWN_TOUCHED).all()
+            new = [tuple(b) for b in blocks.tolist() if tuple(b) not in seen]
+            first = np.array([tuple(v >> 3) in set(new) for v in vox]) if new else np.zeros(len(vox), bool)
+            weight += int(first.sum())
+            seen.update(new)
+            assert int(m.load.sum()) == weight                                             # every voxel of a new block once
+            assert (m.owner(vox) >= 0).all()
+            prev = t_now.copy()
+        if rule == "region":
+            assert m.interleave == drifting
+        assert m.load.max() <= (1.6 if rule == "region" else 1.25) * m.load.mean()
