@@ -1102,7 +1102,12 @@ def run_bench(args, rank, world, dev, dist, backend):
         "config": {"workload": workload, "grid": args.grid, "voxel_size": voxel, "preroll_frames": args.preroll,
                    "preheat_frames": args.preheat, "frames_per_step": 1, "mlp_mode": MODE_NAME[m],
                    "voxels_per_frame": main_run["n_vox"], "sdf_values_per_frame": 27.0 * main_run["n_vox"],
-                   "decode_live_fraction": main_run["live"], "parallelism": "1 GPU"},
+                   "decode_live_fraction": main_run["live"], "parallelism": "1 GPU",
+                   "mlp_evals_last_timed_frame": main_run["rows"],
+                   "persistent_lattice_tables": bool(getattr(getattr(nm, "_pipe", None), "persistent_tables", False)),
+                   "mlp_evals_note": "evaluations of the last timed frame: with the persistent tables, entries of rows the "
+                                     "frame did not update are carried over; roofline.mlp_evals_per_launch is a full "
+                                     "recompute of a frame's entries (the kernel timed alone)"},
         "roofline": roof,
         "traffic_source": (roof["traffic_source"] or {}).get("file") if roof.get("traffic") else None,
         "kernels": {"pointnet_scatter": {"avg_ms": kern_run["enc_ms"], "tflops": kern_run["enc_tflops"],
