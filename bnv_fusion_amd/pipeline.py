@@ -75,7 +75,10 @@ class FramePipe:
         # default "current stream") waits for them and holds them back in turn (measured: 1.2 ms per frame instead of
         # 0.27).  The pipe then runs on a main stream of its own; callers enter it through stream_context() (the
         # sharded backend does), and nothing of a frame may touch the default stream.
-        self.own_main = split is not None and self.main.cuda_stream == 0
+        # BNV_PIPE_MAIN_HIGH=1 (experiment): a HIGH-PRIORITY main stream of the pipe's own without CU masks -- the chain on it
+        # (upsert .. table) is a rank's critical path, the front end / encoder of later frames run ahead on the others
+        high = os.environ.get("BNV_PIPE_MAIN_HIGH", "0") == "1"
+        self.own_main = (split is not None or high) and self.main.cuda_stream == 0
         if self.own_main:
             # (high priority: the chain on it is the frame's critical path; front end and blend run ahead / behind)
             self.main = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BNV_PIPE_MAIN_PRIORITY", -1)))
@@ -181,6 +184,8 @@ class FramePipe:
         # Not with the snapshot schedule (table stream); BNV_PERSISTENT_TABLES=0 switches it off.
         self.persistent_tables = self.table is None and os.environ.get("BNV_PERSISTENT_TABLES", "1") != "0"
         if self.persistent_tables:
+            if v._phave is not None:
+                v.invalidate_tables()      # tables another pipe (another model's networks, perhaps) left on this volume
             v.enable_persistent_tables()
         self._tables_mode = None
         self._slot_mode = [None] * self.n_slots

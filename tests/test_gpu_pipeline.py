@@ -586,3 +586,29 @@ def test_persistent_tables_carry_entries_over(bnv, monkeypatch):
     assert sum(ea[late]) < sum(eb[late]), (sum(ea[late]), sum(eb[late]))     # steady state carries ~5 % over, bench.py)
     n = va.num_rows()
     assert n == vb.num_rows() and torch.equal(va._features[:n], vb._features[:n])
+
+
+def test_persistent_tables_do_not_survive_a_change_of_model(bnv):
+    """A NeuralMap whose networks are swapped mid-stream makes a new frame pipeline on the same volume: table entries the
+    old networks computed must not be carried over.  Same outputs as the per-stage path, bit for bit."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    m1 = bnv.load_pretrained(device=DEV, voxel_size=voxel).set_mlp_mode(1)
+    m0 = bnv.load_pretrained(device=DEV, voxel_size=voxel).set_mlp_mode(0)
+    frames = _frames(16)
+    outs = {}
+    for use_pipe in (True, False):
+        nm = bnv.NeuralMap(dims3, voxel, m1, device=DEV)
+        nm.frame_pipe = use_pipe
+        res = []
+        for t, fr in enumerate(frames):
+            if t == 11:
+                nm.pointnet = m0
+            res.append(nm.fuse_and_decode_async(fr).result())
+        outs[use_pipe] = res
+        if use_pipe:
+            assert nm._pipe is not None and nm._pipe.persistent_tables and nm._pipe.pointnet is m0
+    for t, ((ca, sa), (cb, sb)) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(ca, cb) and torch.equal(sa, sb), t
+    assert float((outs[True][-1][1] != voxel).float().mean()) > 0.05
