@@ -2125,9 +2125,10 @@ size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2) {
 int bnv_shard_state_configure(void* shard_state, int32_t rule, int32_t axis, bnv_stream_t stream) {
   if (!shard_state || (rule != BNV_SHARD_RULE_GREEDY && rule != BNV_SHARD_RULE_REGION) || axis < 0 || axis > 2)
     return BNV_ERR_INVALID_ARGUMENT;
-  const int32_t words[2] = {rule, axis};   // (copied before the call returns: pageable host memory)
+  const int32_t words[2] = {rule, axis};
   BNV_HIP_CHECK(hipMemcpyAsync((char*)shard_state + offsetof(ShardHdr, rule), words, sizeof(words), hipMemcpyHostToDevice,
                                (hipStream_t)stream));
+  BNV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));   // (a set-up call: `words` lives on this stack frame)
   return BNV_OK;
 }
 size_t bnv_shard_state_loads_offset(void) { return offsetof(ShardHdr, load); }

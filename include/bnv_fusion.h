@@ -86,7 +86,7 @@ typedef struct bnv_grid {
 size_t bnv_shard_state_bytes(const int32_t n_xyz[3], int32_t block_log2);
 /* Selects the first-touch rule of a ZEROED shard_state buffer (before its first frame; the same call on every rank):
  * rule BNV_SHARD_RULE_*, axis 0 / 1 / 2 = the grid axis the region rule stacks its first bands along (the axis the
- * camera moves least along: the vertical).  Enqueued on `stream`. */
+ * camera moves least along: the vertical).  Ordered on `stream` (and waited for: a set-up call). */
 int bnv_shard_state_configure(void* shard_state, int32_t rule, int32_t axis, bnv_stream_t stream);
 /* Byte offsets inside it: the per-rank loads (uint64[64]) and the owner table (one byte per block, index
  * (bx * nby + by) * nbz + bz; bits 0..5 owner, bit 6 assigned, bit 7 touched), for tools and tests. */
