@@ -255,6 +255,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype, fn.argtypes = sig[name]
     _lib = lib
+    # A/B switches from the environment (tools, experiments): BNV_OPTIONS="name=value,name=value" -> bnv_set_option.
+    # They choose between implementations with identical results.
+    for item in filter(None, os.environ.get("BNV_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        rc = lib.bnv_set_option(name.strip().encode(), int(value))
+        if rc != 0:
+            raise BnvError(f"BNV_OPTIONS: bnv_set_option({name.strip()!r}, {value}) failed ({rc})")
     return lib
 
 

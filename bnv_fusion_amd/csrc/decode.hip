@@ -2312,6 +2312,246 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// k_lattice_mark_o (round 5): the same marking with ONE THREAD PER ORIGIN instead of one per lattice point.
+// What k_lattice_mark spends its time on is not arithmetic (a few bit tests per point) but the per-chunk chain of
+// barriers, LDS appends and flushes over 2.7 M threads, and -- fused with the neighbour look-up, on a shard -- ONE
+// dependent three-load chain per thread.  Here a thread holds its origin's two 27-bit masks (usable neighbours,
+// neighbours that are origins of the call) in registers and derives the live mask of its 27 lattice points with 27 bit
+// tests; the own-row entries of a workgroup's 256 origins are placed by one block scan and leave through LDS as one
+// coalesced copy (<= 27 per origin: the staging area of the neighbour rows is exactly large enough), the fringe
+// entries (rows that are not decoded in this call: a few per cent) through a small LDS buffer; one global atomic per
+// workgroup; fused, every thread has 27 independent look-up chains in flight.  Same entries as k_lattice_mark (in
+// another order, which nothing depends on), same need_mask / lattice_have bookkeeping.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMoThreads = 256;                 // origins per workgroup
+constexpr int kMoExtra = 3072;                  // LDS room for fringe entries of a workgroup (beyond it: direct appends)
+constexpr int kMoWork = 2048;                   // LDS list of a workgroup's lattice points that have fringe corners
+template <bool FUSED, bool SNAP = false>
+__global__ __launch_bounds__(kMoThreads) void k_lattice_mark_o(const int32_t* __restrict__ nbr_rows, int64_t n,
+                                                               const int32_t* __restrict__ origin_stamp, int32_t epoch,
+                                                               uint32_t* __restrict__ need_mask,
+                                                               int32_t* __restrict__ entries,
+                                                               int32_t* __restrict__ n_entries,
+                                                               int64_t entry_capacity,
+                                                               const int32_t* __restrict__ n_dev, MarkFused F) {
+  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
+  if ((int64_t)blockIdx.x * kMoThreads >= n) return;
+  __shared__ int s_nbr[kMoThreads * 27];        // neighbour rows of the workgroup's origins; then its own-row entries
+  __shared__ int s_extra[kMoExtra];
+  __shared__ int s_corner[216 + 27];
+  __shared__ uint32_t s_need[27];
+  __shared__ uint32_t s_wave[kMoThreads / 64];
+  __shared__ uint32_t s_om[kMoThreads];
+  __shared__ int s_work[kMoWork];
+  __shared__ int s_nx, s_nw, s_base;
+  if (threadIdx.x < 216) {
+    const int p = threadIdx.x >> 3, k = threadIdx.x & 7;
+    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    int nbi = 0, li = 0, dup = 0;   // ceil == floor on an axis with d == 0: same entry as the floor corner
+    for (int a = 0; a < 3; ++a) {
+      int nb_a = 0, loc2 = 0;
+      if (d[a] != 0) {
+        if ((k >> a) & 1) {
+          nb_a = (d[a] + 1) / 2;
+          loc2 = -1;
+        } else {
+          nb_a = (d[a] - 1) / 2;
+          loc2 = 1;
+        }
+      } else if ((k >> a) & 1) {
+        dup = 1;
+      }
+      nbi = nbi * 3 + (nb_a + 1);
+      li = li * 3 + (loc2 + 1);
+    }
+    s_corner[threadIdx.x] = nbi | (li << 5) | (dup << 10);
+  } else if (threadIdx.x < 216 + 27) {
+    const int p = threadIdx.x - 216;
+    const int d[3] = {p / 9 - 1, (p / 3) % 3 - 1, p % 3 - 1};
+    s_corner[threadIdx.x] = (d[0] < 0 || d[1] < 0 || d[2] < 0)
+                                ? ((d[0] < 0 ? 0 : 1) * 3 + (d[1] < 0 ? 0 : 1)) * 3 + (d[2] < 0 ? 0 : 1)
+                                : -1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    uint32_t m = 0;
+    for (int k = 0; k < 8; ++k) m |= 1u << (s_corner[threadIdx.x * 8 + k] & 31);
+    s_need[threadIdx.x] = m;
+  }
+  // the fringe entries of ONE live lattice point p of the origin whose neighbour rows are nb27 and origin mask om: the
+  // corner rows that are not decoded in this call, each listed by whoever finds its bit clear.  All atomics of the
+  // point are issued before any result is looked at (one memory round trip)
+  auto fringe_point = [&](const int* nb27, uint32_t om, int p) {
+    const uint32_t rest = s_need[p] & ~om;
+    const bool mine = s_corner[216 + p] < 0;
+    int rowk[8], lk[8];
+    uint32_t seen[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = s_corner[p * 8 + k];     // nbi | li << 5 | dup << 10
+      rowk[k] = (!(c >> 10) && ((rest >> (c & 31)) & 1u)) ? (nb27[c & 31] & ~kOriginBit) : -1;
+      lk[k] = (c >> 5) & 31;
+    }
+    if (F.have) {   // persistent tables: the bit outlives the call
+#pragma unroll
+      for (int k = 0; k < 8; ++k) seen[k] = rowk[k] >= 0 ? atomicOr(&F.have[rowk[k]], 1u << lk[k]) : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        seen[k] = (!mine && rowk[k] >= 0) ? atomicOr(&need_mask[rowk[k]], 1u << lk[k]) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (rowk[k] < 0 || ((seen[k] >> lk[k]) & 1u)) continue;
+      if constexpr (SNAP) snap_row(F, rowk[k]);
+      const int e = (rowk[k] << 5) | lk[k];
+      const int at = atomicAdd(&s_nx, 1);
+      if (at < kMoExtra) {
+        s_extra[at] = e;
+      } else {   // (rare overflow of the LDS buffer: straight to the list)
+        const int g = atomicAdd(n_entries, 1);
+        if (g < entry_capacity) entries[g] = e;
+      }
+    }
+  };
+  for (int64_t vb = blockIdx.x; vb * kMoThreads < n; vb += gridDim.x) {
+    const int64_t b0 = vb * kMoThreads;
+    if (threadIdx.x == 0) s_nx = s_nw = 0;
+    // the neighbour rows of the workgroup's origins
+    bool staged = false;
+    if constexpr (FUSED) {
+      // With the dense row index a thread looks its OWN origin's 27 neighbours up in three rounds of independent loads
+      // (27 index words; then 27 weights + 27 origin stamps) instead of 27 three-load chains one behind the other
+      // (the generic look-up below branches between the loads, which keeps the compiler from overlapping them).
+      if (F.v.brick) {
+        staged = true;
+        const int64_t bb = b0 + threadIdx.x;
+        int rows[27];
+        if (bb < n) {
+          const int64_t ox = F.origins[bb * 3 + 0], oy = F.origins[bb * 3 + 1], oz = F.origins[bb * 3 + 2];
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            const int64_t x = ox + (k / 9 - 1), y = oy + ((k / 3) % 3 - 1), z = oz + (k % 3 - 1);
+            int64_t idx;
+            rows[k] = brick_index(F.v, x, y, z, &idx) ? F.v.brick[idx] : -2;   // -2: outside the index (the hash decides)
+          }
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            if (rows[k] == -2)
+              rows[k] = volume_row(F.v, ox + (k / 9 - 1), oy + ((k / 3) % 3 - 1), oz + (k % 3 - 1));
+            if (rows[k] >= F.row_limit) rows[k] = -1;
+          }
+          float wk[27];
+          int sk[27];
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            const int rr = rows[k] < 0 ? 0 : rows[k];
+            wk[k] = F.weights[rr];
+            sk[k] = origin_stamp ? origin_stamp[rr] : 0;
+          }
+#pragma unroll
+          for (int k = 0; k < 27; ++k) {
+            int r = -1;
+            if (rows[k] >= 0 && wk[k] >= F.min_pts) r = rows[k] | ((origin_stamp && sk[k] == epoch) ? kOriginBit : 0);
+            s_nbr[threadIdx.x * 27 + k] = r;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 27; ++k) s_nbr[threadIdx.x * 27 + k] = -1;
+        }
+      }
+    }
+#pragma unroll 9
+    for (int i = threadIdx.x; i < (staged ? 0 : kMoThreads * 27); i += kMoThreads) {
+      const int64_t g = b0 * 27 + i;
+      int r = -1;
+      if (g < n * 27) {
+        if constexpr (FUSED) {
+          // (no global store in this loop: a store the compiler cannot prove disjoint from the volume's arrays would
+          // order the iterations' look-up chains one behind the other -- 81 dependent loads instead of 3)
+          const int ob = i / 27;
+          r = lattice_neighbor_row(F.v, F.origins, b0 + ob, i - ob * 27, F.weights, F.row_limit, F.min_pts, origin_stamp,
+                                   epoch);
+        } else {
+          r = nbr_rows[g];
+        }
+      }
+      s_nbr[i] = r;
+    }
+    __syncthreads();
+    if constexpr (FUSED) {   // the blend reads the neighbour rows from global memory
+      for (int i = threadIdx.x; i < kMoThreads * 27; i += kMoThreads)
+        if (b0 * 27 + i < n * 27) F.nbr_rows_out[b0 * 27 + i] = s_nbr[i];
+    }
+    const int64_t b = b0 + threadIdx.x;
+    const int* nb27 = s_nbr + threadIdx.x * 27;      // (stride 27 words: conflict-free across the lanes of a wave)
+    uint32_t um = 0, om = 0;
+    if (b < n) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const int r = nb27[k];
+        um |= (r >= 0 ? 1u : 0u) << k;
+        om |= ((r >= 0 && (r & kOriginBit)) ? 1u : 0u) << k;
+      }
+    }
+    const int own_row = (um >> 13) & 1u ? (nb27[13] & ~kOriginBit) : -1;
+    uint32_t live = 0;
+#pragma unroll
+    for (int p = 0; p < 27; ++p) live |= ((um & s_need[p]) == s_need[p] ? 1u : 0u) << p;
+    if (b >= n) live = 0;
+    // the points whose entry in the origin's OWN row this thread lists (always, but for a caller's stale stamp array)
+    const uint32_t own = ((om >> 13) & 1u) ? live : 0u;
+    if constexpr (SNAP)
+      if (own_row >= 0) snap_row(F, own_row);
+    if (own && F.have) atomicOr(&F.have[own_row], own);   // (the upsert cleared the word; nobody else sets bits of an origin's row)
+    // fringe entries: corner rows that are not decoded in this call.  A thread only LISTS its points that have such
+    // corners (origin << 5 | p); the whole workgroup then works the list off, one point per thread and step, the (up
+    // to eight) returning atomics of a point in flight together -- an origin on the fringe has dozens of them, and
+    // one thread taking them one round trip after the other held its workgroup for tens of microseconds
+    s_om[threadIdx.x] = om;
+    if (live) {
+      for (int p = 0; p < 27; ++p) {
+        if (!((live >> p) & 1u) || !(s_need[p] & ~om)) continue;
+        const int dneg = s_corner[216 + p];
+        if (dneg >= 0 && ((om >> dneg) & 1u)) continue;      // the origin floor(P) is decoded here: it lists them
+        const int at = atomicAdd(&s_nw, 1);
+        if (at < kMoWork) s_work[at] = (int)(threadIdx.x << 5) | p;
+        else fringe_point(nb27, om, p);                       // (a call whose fringe dwarfs its origins: inline)
+      }
+    }
+    __syncthreads();
+    {
+      const int nw = s_nw < kMoWork ? s_nw : kMoWork;
+      for (int i = threadIdx.x; i < nw; i += kMoThreads) {
+        const int wi = s_work[i];
+        fringe_point(s_nbr + (wi >> 5) * 27, s_om[wi >> 5], wi & 31);
+      }
+    }
+    uint32_t tot;
+    const uint32_t off = block_exclusive_scan<kMoThreads>((uint32_t)__popc(own), s_wave, &tot);   // (two barriers: s_nbr is read out)
+    {
+      int at = (int)off;
+      uint32_t m = own;
+      while (m) {
+        const int p = __ffs(m) - 1;
+        m &= m - 1;
+        s_nbr[at++] = (own_row << 5) | p;
+      }
+    }
+    __syncthreads();
+    const int nx = s_nx < kMoExtra ? s_nx : kMoExtra;
+    if (threadIdx.x == 0) s_base = (tot + nx) ? atomicAdd(n_entries, (int)tot + nx) : 0;
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < (int)tot; i += kMoThreads)
+      if (base + i < entry_capacity) entries[base + i] = s_nbr[i];
+    for (int i = threadIdx.x; i < nx; i += kMoThreads)
+      if (base + (int)tot + i < entry_capacity) entries[base + (int)tot + i] = s_extra[i];
+    __syncthreads();   // s_nbr / s_extra / s_nx are rewritten by the next round
+  }
+}
+
 // DELTA = false: the streaming case (no TSDF prior): 8 table reads and a weighted sum, few registers -- it runs
 // beside the persistent MLP kernels of the other streams.
 #ifndef BNV_BLEND_PPT
@@ -2446,6 +2686,7 @@ static unsigned capped_grid(int64_t blocks, int per_cu) {
 }
 
 std::atomic<int> g_fused_mark{-1};  // bnv_set_option("fused_mark"): 1 / 0 force, -1 (default): by the call's size
+std::atomic<int> g_mark_per_origin{1};   // bnv_set_option("mark_per_origin"): 1 = k_lattice_mark_o, 0 = k_lattice_mark (one thread per lattice point)
 std::atomic<int> g_half_tail{1};    // bnv_set_option("half_tail"): k_lattice_table_x hands its last partial round out as half tiles
 std::atomic<int> g_lattice_pipe{1}; // 1: k_lattice_table_x (cross-tile / cross-layer pipelined, 16x16x32 MFMA); 0: k_decode<LATTICE, 1>
 
@@ -2585,6 +2826,10 @@ int bnv_set_option(const char* name, int value) {
   if (!name) return BNV_ERR_INVALID_ARGUMENT;
   if (!strcmp(name, "lattice_pipe")) {
     g_lattice_pipe.store(value, std::memory_order_relaxed);
+    return BNV_OK;
+  }
+  if (!strcmp(name, "mark_per_origin")) {
+    g_mark_per_origin.store(value != 0, std::memory_order_relaxed);
     return BNV_OK;
   }
   if (!strcmp(name, "half_tail")) {
@@ -2794,7 +3039,15 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
   F.feat_snap = snap_src ? ws.snap : nullptr;
   F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
-  if (snap_src)
+  const dim3 ogrid(capped_grid((n + kMoThreads - 1) / kMoThreads, 4));
+  const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0;
+  if (per_origin && snap_src)
+    hipLaunchKernelGGL((k_lattice_mark_o<false, true>), ogrid, dim3(kMoThreads), 0, stream, ws.nbr_rows, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else if (per_origin)
+    hipLaunchKernelGGL((k_lattice_mark_o<false, false>), ogrid, dim3(kMoThreads), 0, stream, ws.nbr_rows, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else if (snap_src)
     hipLaunchKernelGGL((k_lattice_mark<false, true>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   else
@@ -2832,7 +3085,16 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
   F.feat_snap = snap_src ? ws.snap : nullptr;
   F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
-  if (snap_src)
+  const dim3 ogrid(capped_grid((n + kMoThreads - 1) / kMoThreads, 4));
+  // (a shard's call keeps the per-point kernel: measured equal to slightly better there, profiles/r05_experiments.txt [e7])
+  const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0 && grid->shard_world <= 1;
+  if (per_origin && snap_src)
+    hipLaunchKernelGGL((k_lattice_mark_o<true, true>), ogrid, dim3(kMoThreads), 0, stream, (const int32_t*)nullptr, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else if (per_origin)
+    hipLaunchKernelGGL((k_lattice_mark_o<true, false>), ogrid, dim3(kMoThreads), 0, stream, (const int32_t*)nullptr, n,
+                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
+  else if (snap_src)
     hipLaunchKernelGGL((k_lattice_mark<true, true>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   else
@@ -2916,14 +3178,17 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !grid || n < 0 || ((stages & 2) && !sdfmlp_pack)) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
-  // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  Small calls (a
-  // shard's 1/8 of a frame) look the neighbour rows up inside the marking kernel: one launch less, -9 us of a 0.28 ms
-  // frame; on whole frames the 256-thread look-up kernel of its own hides the three dependent loads of a look-up
-  // better than the 1,024-thread marking workgroups do (48.7 us for the pair against 62.4 us fused)
+  // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  The marking kernel
+  // looks the neighbour rows up itself (one launch and a 10 MB round trip less): always with the per-origin kernel on
+  // a volume that keeps its dense row index (k_lattice_mark_o: a thread's 27 look-ups are three rounds of independent
+  // loads; tiny-cuda-nn frame 0.254 -> 0.236 ms, fp32 frame unchanged, profiles/r05_experiments.txt [e7]); with the
+  // per-point kernel only on small calls (a shard's 1 / world of a frame), where the 256-thread look-up kernel of its
+  // own would cost more than it hides (48.7 us for the pair against 62.4 us fused on whole frames)
   int rc;
   if (stages & 1) {
     const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
-    const bool fuse = fused_opt == 1 || (fused_opt < 0 && (n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
+    const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0;
+    const bool fuse = fused_opt == 1 || (fused_opt < 0 && ((per_origin && vol->brick) || n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
     const float* snap_src = snapshot ? features : nullptr;
     if (fuse) {
       rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
