@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_tcnn -o bench -
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_tcnn_w -o p -- $BENCHT > $O/pmc_tcnn_w.log 2>&1
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_tcnn_f -o p -- $BENCHT > $O/pmc_tcnn_f.log 2>&1
 # the spatially sharded frame priced with real ghost rows (its own script: it can be re-run alone)
-bash tools/run_profiles_spatial.sh $R
+[ -n "${BNV_PROFILES_SKIP_SPATIAL:-}" ] || bash tools/run_profiles_spatial.sh $R
 F="RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids"
 GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/queue_probe.txt
 python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
