@@ -32,6 +32,11 @@ frames, so the clock has settled under the package power limit -- plus
   growth           frames/s from an empty volume of the reference's initial capacity (100,000 rows), growing on demand;
   sequence         a long moving-camera sweep of a room-sized 512^3 volume (bnv_fusion_amd/sequence.py): frames/s over
                    the whole sequence incl. table growth, rows reached, periodic oracle checks;
+  optimize         the global optimiser at the reference's 5,000-ray configuration (run_e2e.py:111-162): steps/s, the two
+                   decode_pts kernels of a ray split with their roofline fractions, forward + gradient parity against the
+                   oracle's autograd, the oracle's own time (SURVEY.md section 8 f-3);
+  extract_mesh[_sweep]  NeuralMap.extract_mesh over the whole bench volume / the sequence's volume (run_e2e.py:164-167):
+                   ms, table-kernel and marching-cubes figures, marching cubes against the oracle's (section 8 f-4);
   parity           GPU outputs of the last timed frame against the oracle (>= 2,000 voxels);
   other_mlp_modes  the f16-operand mode (lower precision, never the headline);
   cpu_baseline     the oracle on the host cores.
