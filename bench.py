@@ -1011,6 +1011,19 @@ def run_bench(args, rank, world, dev, dist, backend):
 
     extras = {}
     alts = []
+    pipe_ = getattr(nm, "_pipe", None)
+    if pipe_ is not None and getattr(pipe_, "persistent_tables", False) and not args.no_alt_mode:
+        # ---- A/B inside this run: the same timed region with every frame's table entries recomputed (the persistent
+        # lattice tables off), so that what the carried-over entries are worth is a figure of THIS box
+        nm._drain_pipe()
+        pipe_.persistent_tables = False
+        rn = timed(nm, "single", args.mlp_mode, step_idx, warm_idx,
+                   preheat=args.preheat if args.mlp_mode != 0 else min(args.preheat, 300))
+        nm._drain_pipe()
+        pipe_.persistent_tables = True
+        nm.volume.invalidate_tables()
+        extras["without_persistent_tables"] = {**entry(rn), "mlp_evals_last_timed_frame": rn["rows"],
+                                               "note": "every frame re-evaluates all of its table entries"}
     if not args.no_alt_mode and not tcnn:
         # ---- the reference's precision to the letter: IEEE fp32 MFMA, the full --steps, its own roofline -------
         if args.mlp_mode != 0:

@@ -47,6 +47,10 @@ V = {
 ft = jload("bench_line_final_tree.json") if os.path.exists(P("bench_line_final_tree.json")) else d
 V["EVALS_FRAME"] = (f"{ft['config']['mlp_evals_last_timed_frame'] / 1e6:.2f} M" if ft["config"].get("mlp_evals_last_timed_frame")
                     else "≈ 5 % fewer")
+_np = ft.get("without_persistent_tables")
+V["NOPT"] = (f"{_np['value']:.1f} frames/s against {ft['value']:.1f} on that box ({_np['mlp_evals_last_timed_frame'] / 1e6:.2f} M "
+             f"evaluations in the last frame against {ft['config']['mlp_evals_last_timed_frame'] / 1e6:.2f} M)"
+             if _np else "A/B on one box: 558 against 583 frames/s (`profiles/r05_experiments.txt` [e3])")
 V["EVALS_FULL"] = f"{ft['roofline']['mlp_evals_per_launch'] / 1e6:.2f} M"
 if opt:
     sp = opt["split"]

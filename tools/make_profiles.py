@@ -74,6 +74,13 @@ commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], cap
 # csrc/decode.hip no longer is that file
 sha_path = f"{src}/decode_hip.sha256"
 decode_sha = open(sha_path).read().split()[0] if os.path.exists(sha_path) else None
+# (a rebuild of the summaries from the same gpurun_out/ keeps the commit the passes ran at)
+try:
+    old = json.load(open(f"{dst}/{R}_pmc_meta.json"))
+    if old.get("decode_hip_sha256") == decode_sha and old.get("mlp_evals_per_launch") == dp["roofline"]["mlp_evals_per_launch"]:
+        commit = old.get("commit") or commit
+except (OSError, ValueError):
+    pass
 json.dump({"commit": commit, "decode_hip_sha256": decode_sha,
            "command": "python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe",
            "mlp_evals_per_launch": dp["roofline"]["mlp_evals_per_launch"], "dominant_kernel_trace": tail},
@@ -216,6 +223,14 @@ with open(f"{dst}/{R}_README.md", "w") as f:
                     ("soak", "`tools/soak_pipeline.py`: 1,500-3,000 frames through the four-stream pipeline with three frames in flight against the same frames one at a time (one GPU fp32 / tcnn; rank 1 of a simulated world of 8): every frame's outputs and the final volume bit-identical")):
         if os.path.exists(f"{dst}/{R}_{t}.txt"):
             notes.append(f"* `{R}_{t}.txt` -- {what}.")
+    if os.path.exists(f"{dst}/{R}_bench_line_final_tree.json"):
+        ft = last_json(f"{dst}/{R}_bench_line_final_tree.json")
+        npt = ft.get("without_persistent_tables")
+        notes.append(f"* `{R}_bench_line_final_tree.json` -- `python bench.py` of the round's final tree (another box than "
+                     f"`{R}_bench_line.json`; same kernels): {ft['value']:.1f} frames/s"
+                     + (f"; the A/B inside that run with the persistent lattice tables off (`without_persistent_tables`): "
+                        f"{npt['value']:.1f} frames/s, {npt['mlp_evals_last_timed_frame'] / 1e6:.2f} M evaluations per frame "
+                        f"against {ft['config']['mlp_evals_last_timed_frame'] / 1e6:.2f} M" if npt else "") + ".")
     if notes:
         W("\n" + "\n".join(notes) + "\n")
 print(open(f"{dst}/{R}_README.md").read()[:3000])
