@@ -29,6 +29,7 @@ SYMBOLS = [
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready", "bnv_frame_pipe_timeline_enable", "bnv_frame_timeline",
     "bnv_frame_side_depth", "bnv_frame_cancel", "bnv_frame_pipe_forget_workspaces", "bnv_shard_state_configure",
+    "bnv_shard_emit", "bnv_shard_apply", "bnv_frame_exchange_begin", "bnv_frame_exchange_end",
 ]
 
 
@@ -80,7 +81,7 @@ class FramePipeConfig(C.Structure):
                 ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
                 ("main_stream", C.c_void_p), ("enc_ws2", C.c_void_p), ("front_stream", C.c_void_p),
                 ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32), ("table_stream", C.c_void_p),
-                ("table_workgroups", C.c_int32)]
+                ("table_workgroups", C.c_int32), ("early_exchange", C.c_int32), ("encoder_gate", C.c_int32)]
 
 
 class BnvError(RuntimeError):
@@ -248,6 +249,10 @@ def load():
         "bnv_frame_side_depth": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), vp]),
         "bnv_frame_cancel": (C.c_int, [vp, C.c_int]),
+        "bnv_frame_exchange_begin": (C.c_int, [vp, C.c_int, vp]),
+        "bnv_frame_exchange_end": (C.c_int, [vp, C.c_int, vp]),
+        "bnv_shard_emit": (C.c_int, [C.POINTER(Grid), vp, vp, vp, i64, vp, vp, i64, vp]),
+        "bnv_shard_apply": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp]),
         "bnv_frame_pipe_forget_workspaces": (C.c_int, [vp]),
         "bnv_shard_state_configure": (C.c_int, [vp, i32, i32, vp]),
     }

@@ -15,6 +15,11 @@
 //                      finish:  install ghost rows (resets the send block), neighbours + mark, table MLP
 //   B (blend stream)   finish:  blend, counters / row count / evaluation count to pinned memory, done event
 //
+// EARLY EXCHANGE (config.early_exchange; shard.hip): the records carry the frame's contribution to a voxel instead of
+// the row after the upsert, so they leave behind finalize on E, the caller's all-gather runs on a stream of its own
+// between bnv_frame_exchange_begin / _end while M still decodes the frame before, and M's chain is upsert -> apply the
+// received contributions to the ghost rows -> mark -> table: no collective on the critical path.
+//
 // Why four.  The two MLP kernels each fill a CU's LDS, so they can only take turns, and M is one dependent chain:
 // upsert(t) -> all-gather -> install -> mark -> table(t) -> [blend(t)] -> upsert(t+1) ...  With two streams a rank's
 // frame of an 8-GPU run was table 150 us + encoder 60 us + ~90 us in which only small kernels ran: the encoder of
@@ -100,6 +105,12 @@ struct bnv_frame_pipe {
     float K[9], T[16];
   } side[BNV_PIPE_MAX_SLOTS];
   hipEvent_t ev_fin[BNV_PIPE_MAX_SLOTS];   // finalize of the slot's frame is through (split mode)
+  // early exchange (shard.hip): the frame's contribution records leave behind finalize on E; the caller's all-gather
+  // runs on a stream of its choosing between bnv_frame_exchange_begin / _end, off the main stream's chain
+  bool early;
+  hipEvent_t ev_xchg[BNV_PIPE_MAX_SLOTS];
+  bool xchg_set[BNV_PIPE_MAX_SLOTS];
+  uint64_t table_serial[BNV_PIPE_MAX_SLOTS];   // serial of the frame ev_table[slot] was recorded for last (0: never)
   // diagnostic timeline (bnv_frame_pipe_timeline_enable): timing events per slot and point, a base event
   bool tl_on;
   hipEvent_t tl_base;
@@ -167,6 +178,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   // ordered through the blend's done event)
   p->T = (cfg->table_stream && cfg->blend_stream) ? (hipStream_t)cfg->table_stream : p->M;
   p->split = p->T != p->M;
+  p->early = cfg->early_exchange != 0 && !p->split && cfg->grid.shard_world > 1;
   p->tl_on = false;
   p->tl_base = nullptr;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s)
@@ -197,6 +209,9 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->mlp_mode[s] = cfg->grid.mlp_mode;
     p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = p->ev_mark[s] = nullptr;
     p->ev_fin[s] = nullptr;
+    p->ev_xchg[s] = nullptr;
+    p->xchg_set[s] = false;
+    p->table_serial[s] = 0;
     p->pts[s] = nullptr;
     p->width[s] = 0;
     p->side[s].on = false;
@@ -213,8 +228,8 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
-    hipEvent_t* evs[7] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s],
-                          &p->ev_mark[s], &p->ev_fin[s]};
+    hipEvent_t* evs[8] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s],
+                          &p->ev_mark[s], &p->ev_fin[s], &p->ev_xchg[s]};
     for (hipEvent_t* e : evs)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
         bnv_frame_pipe_destroy(p);
@@ -238,8 +253,8 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
     for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k)
       if (p->tl[s][k]) (void)hipEventDestroy(p->tl[s][k]);
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
-    hipEvent_t evs[7] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s],
-                         p->ev_fin[s]};
+    hipEvent_t evs[8] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s],
+                         p->ev_fin[s], p->ev_xchg[s]};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -262,6 +277,18 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
   tl_mark(p, slot, 1, p->F);   // (in front of the event E waits for: the timeline's point 2 can then never precede it)
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
+  if (c.encoder_gate > 0 && p->E != p->M) {
+    // The two MLP kernels exclude each other (each fills a CU's LDS): an encoder that starts while a table kernel runs
+    // only takes CUs from it, and M's small kernels then run with nothing beside them.  Gated, the encoder of frame
+    // t + 1 starts when the table kernel of frame t + 1 - gate is through -- beside M's upsert .. marking of the frame
+    // between them (gate 2 for callers that begin a frame before the previous frame's upsert).
+    const uint64_t want = p->serial[slot] > (uint64_t)c.encoder_gate ? p->serial[slot] - (uint64_t)c.encoder_gate : 0;
+    for (int s2 = 0; want && s2 < c.n_slots; ++s2)
+      if (p->table_serial[s2] == want) {
+        BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_table[s2], 0));
+        break;
+      }
+  }
   tl_mark(p, slot, 2, p->E);
   const bnv_grid_t g = slot_grid(p, slot);
   // split mode: E carries the persistent MLP kernel only; finalize heads the frame's chain on M (bnv_frame_upsert)
@@ -279,6 +306,14 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
     if (rc != BNV_OK) return rc;
   }
   if (!p->split) tl_mark(p, slot, 4, p->E);
+  if (p->early) {
+    // the frame's contribution records (its emitted boundary voxels) into the slot's send block, behind finalize:
+    // ev_enc covers them, and bnv_frame_exchange_begin orders the caller's all-gather behind it
+    rc = bnv_shard_emit(&g, b.grid_ids, b.feats, b.pcounts, c.out_capacity, &b.counters->n_out, b.send_block,
+                        c.send_capacity, p->E);
+    if (rc != BNV_OK) return rc;
+    p->xchg_set[slot] = false;
+  }
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
   if (!p->split)
     BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
@@ -461,7 +496,7 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
     p->lws_serial[k] = p->serial[slot];
   }
   bnv_integrate_extras_t x = {};
-  if (c.grid.shard_world > 1) {
+  if (c.grid.shard_world > 1 && !p->early) {
     x.shard_block = b.send_block;
     x.shard_block_capacity = c.send_capacity;
     x.grid_host = &c.grid;
@@ -522,6 +557,19 @@ int bnv_frame_cancel(bnv_frame_pipe_t* p, int slot) {
   return BNV_OK;
 }
 
+int bnv_frame_exchange_begin(bnv_frame_pipe_t* p, int slot, bnv_stream_t stream) {
+  if (!slot_ok(p, slot) || p->state[slot] != 1 || !p->early) return BNV_ERR_INVALID_ARGUMENT;
+  BNV_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, p->ev_enc[slot], 0));
+  return BNV_OK;
+}
+
+int bnv_frame_exchange_end(bnv_frame_pipe_t* p, int slot, bnv_stream_t stream) {
+  if (!slot_ok(p, slot) || (p->state[slot] != 1 && p->state[slot] != 2) || !p->early) return BNV_ERR_INVALID_ARGUMENT;
+  BNV_HIP_CHECK(hipEventRecord(p->ev_xchg[slot], (hipStream_t)stream));
+  p->xchg_set[slot] = true;
+  return BNV_OK;
+}
+
 int bnv_frame_bound(bnv_frame_pipe_t* p, int slot, int32_t* max_bound_host) {
   if (!slot_ok(p, slot) || p->state[slot] < 1 || !max_bound_host) return BNV_ERR_INVALID_ARGUMENT;
   *max_bound_host = 0;
@@ -545,7 +593,13 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   int rc;
   tl_mark(p, slot, 7, p->M);
   if (c.grid.shard_world > 1 && blocks && block_capacity > 0) {
-    rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
+    if (p->early) {
+      // the exchanged contribution records: the caller's all-gather ran on another stream, long ago as a rule
+      if (p->xchg_set[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_xchg[slot], 0));
+      rc = bnv_shard_apply(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, p->M);
+    } else {
+      rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
+    }
     if (rc != BNV_OK) return rc;
   }
   tl_mark(p, slot, 8, p->M);
@@ -586,6 +640,7 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
       tl_mark(p, slot, 9, p->M);
       if (p->B != p->M) {
         BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
+        p->table_serial[slot] = p->serial[slot];
         BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
       }
     }

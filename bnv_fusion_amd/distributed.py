@@ -348,7 +348,8 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None,
+                 exchange_stream=True):
         from .sparse_volume import SparseVolume, make_grid
         import os
         ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
@@ -390,7 +391,10 @@ class HipShardBackend:
         self.inputs_resident = False      # True: frames are complete in device memory when they are passed in
         self.copy_results = True          # False: result() returns views into the slot buffers (valid for n_slots - 1 more frames)
         self.pipe = None
-        self._recv = None
+        self._recv = {}
+        # False: the early exchange's all-gather runs on the main stream (drivers that run several shards of one process
+        # in lock step on one stream); True: on a stream of its own (FramePipe.xchg)
+        self._exchange_stream = bool(exchange_stream)
         self._last_evals = 0
         self.last_owned_pairs = 0
 
@@ -400,7 +404,7 @@ class HipShardBackend:
             from .pipeline import FramePipe
             assert self.pipe is None or not any(self.pipe._busy), "a larger frame arrived while frames are in flight"
             self.pipe = FramePipe(self.volume, self.pointnet, n, n_slots=self.n_slots, tsdf_vol=self.tsdf_vol,
-                                  max_depth=self.max_depth)
+                                  max_depth=self.max_depth, exchange_stream=self._exchange_stream)
         self.pipe.inputs_resident = self.inputs_resident
         self.pipe.sdf_delta = self.sdf_delta
         return self.pipe
@@ -437,28 +441,55 @@ class HipShardBackend:
             return 0
         return min(-(-bound // REC_QUANTUM) * REC_QUANTUM, self.pipe.send_cap)
 
+    @property
+    def early_exchange(self):
+        """True: the frame's records carry its contributions and are exchanged BEFORE the upsert (emit -> all-gather
+        under exchange_context() -> install -> upsert -> finish); False: round 4's order (upsert -> all-gather on the
+        main stream -> install -> finish).  Known once the pipe exists (after the first encode)."""
+        return bool(self.pipe is not None and self.pipe.early_exchange)
+
+    def emit(self, fr, capacity):
+        """Early exchange: this rank's block for the frame (header + ``capacity`` contribution records, int32 words),
+        complete on the exchange stream -- run the all-gather under ``exchange_context()``.  None when nothing is
+        exchanged."""
+        if capacity == 0:
+            return None
+        return self.pipe.exchange_begin(fr.slot, capacity)
+
+    def exchange_context(self):
+        """Context the early exchange's all-gather runs under: the pipe's exchange stream, if it has one."""
+        if self.pipe is not None and self.pipe.early_exchange and self.pipe.xchg is not None:
+            return torch.cuda.stream(self.pipe.xchg)
+        return contextlib.nullcontext()
+
     def upsert(self, fr, capacity, decode=True):
-        """Main stream: upsert of the owned voxels in ONE launch that also appends their boundary records to the slot's
-        send block and stamps them as the frame's decode origins.  -> this rank's block (header + ``capacity``
-        records, int32 words) or None when nothing is exchanged."""
+        """Main stream: upsert of the owned voxels in ONE launch that also stamps them as the frame's decode origins
+        and -- without the early exchange -- appends their boundary records to the slot's send block.  -> this rank's
+        block (header + ``capacity`` records, int32 words); None when nothing is exchanged or the exchange is early."""
         fr.decode = decode
         send = self.pipe.upsert(fr.slot, decode=decode, ghost_rows=(self.world - 1) * capacity)
-        if capacity == 0:
+        if capacity == 0 or self.pipe.early_exchange:
             return None
         if (capacity + 1) * REC_WORDS > send.numel():
             raise _lib.BnvError(f"exchange capacity {capacity} exceeds the slot's send block "
                                 f"({send.numel() // REC_WORDS - 1} records)")
         return send[: (capacity + 1) * REC_WORDS]
 
-    def recv_buffer(self, words):
-        if self._recv is None or self._recv.numel() < words:
-            self._recv = torch.empty(int(words * 1.5), dtype=torch.int32, device=self.dev)
-        return self._recv[:words]
+    def recv_buffer(self, words, fr=None):
+        """The all-gather's output buffer -- one per slot with the early exchange (a frame's blocks wait for its finish
+        while the next frame's all-gather already runs)."""
+        k = fr.slot if (fr is not None and self.early_exchange) else -1
+        r = self._recv.get(k)
+        if r is None or r.numel() < words:
+            r = self._recv[k] = torch.empty(int(words * 1.5), dtype=torch.int32, device=self.dev)
+        return r[:words]
 
     def install(self, fr, blocks, capacity):
         """blocks: [world * (capacity + 1) * REC_WORDS] int32 -- the all-gather's output; installed (and the send block
-        reset) by the frame's finish call."""
+        reset) / applied to the ghost rows (early exchange) by the frame's finish call."""
         fr.blocks, fr.capacity = blocks, capacity
+        if self.pipe.early_exchange:
+            self.pipe.exchange_end(fr.slot)
         return (self.world - 1) * capacity
 
     def decode(self, fr):
@@ -595,8 +626,21 @@ class ShardedNeuralMap:
             self.host_waits += 1
             capacity = (be.exchange_capacity(bound) if hasattr(be, "exchange_capacity")
                         else -(-bound // REC_QUANTUM) * REC_QUANTUM)
-            send = be.upsert(fr, capacity, decode)
             reserved = 0
+            if getattr(be, "early_exchange", False):
+                # the records are the frame's contributions (complete behind its encode): THE collective of the frame
+                # runs on the exchange stream while the main stream still decodes the frame before; then the upsert
+                if capacity > 0:
+                    send = be.emit(fr, capacity)
+                    words = self.world * send.numel()
+                    recv = be.recv_buffer(words, fr)
+                    with be.exchange_context():
+                        dist.all_gather_into_tensor(recv, send, group=self.group)
+                    self.exchanged_bytes += words * 4
+                    reserved = be.install(fr, recv, capacity)
+                be.upsert(fr, capacity, decode)
+                return self._finish(be, fr, decode, reserved, ring)
+            send = be.upsert(fr, capacity, decode)
             if capacity > 0:
                 words = self.world * send.numel()
                 recv = be.recv_buffer(words) if hasattr(be, "recv_buffer") else torch.empty(
@@ -604,8 +648,11 @@ class ShardedNeuralMap:
                 dist.all_gather_into_tensor(recv, send, group=self.group)      # THE collective of the frame
                 self.exchanged_bytes += words * 4
                 reserved = be.install(fr, recv, capacity)
-            sdf = be.decode(fr) if decode else None
-            h = ShardHandle(self, be.finish(fr, sdf, reserved))
+            return self._finish(be, fr, decode, reserved, ring)
+
+    def _finish(self, be, fr, decode, reserved, ring):
+        sdf = be.decode(fr) if decode else None
+        h = ShardHandle(self, be.finish(fr, sdf, reserved))
         if ring is not None:
             self._open.append(h)
         return h

@@ -11,6 +11,9 @@ A frame occupies a slot from ``begin`` to ``result``:
     ... all-gather of send[: (capacity + 1) * REC_WORDS] on the main stream ...
     pipe.finish(slot, blocks, capacity)   # main stream: install, lattice decode, read-backs
     words = pipe.result(slot)             # host wait; then pipe.outputs(slot, words)
+
+Sharded, early exchange (opt-in, BNV_EARLY_EXCHANGE=1; csrc/shard.hip): begin -> bound -> ``send = pipe.exchange_begin(slot, capacity)``
+-> all-gather on ``pipe.exchange_stream()`` -> ``pipe.exchange_end(slot)`` -> upsert -> finish(slot, blocks, capacity).
 """
 import ctypes as C
 
@@ -40,7 +43,7 @@ class FramePipe:
     CU_SPLIT_SHARDED = None
 
     def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None,
-                 streams=4, encoder_workgroups=None, cu_split=None):
+                 streams=4, encoder_workgroups=None, cu_split=None, exchange_stream=True):
         from .frontend import DEPTH_DTYPES
         self._dtypes = DEPTH_DTYPES
         self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
@@ -104,6 +107,26 @@ class FramePipe:
         if streams >= 5 and split is None:
             self.table = concurrent_stream(dev, self.main, exclude=(self.enc, self.front, self.blend))
         self.double_buffered = self.front is not None
+        # early exchange (csrc/shard.hip, csrc/pipeline.hip; OPT-IN: BNV_EARLY_EXCHANGE=1): a sharded frame's records
+        # carry its CONTRIBUTION to the boundary voxels and leave behind the encode; the all-gather runs on `xchg`, a
+        # stream of its own, while the main stream still decodes the frame before.  Bit-identical results; it takes the
+        # collective's latency off the main stream's chain.  Priced on one GPU it is SLOWER (0.37 against 0.31 ms per
+        # frame for a rank of 8, profiles/r05_experiments.txt [e8]): the table kernel excludes every other kernel, so
+        # each stream's work of a frame has to fit into the window between two table kernels, and the encode stream's
+        # (encoder + finalize + emit, ~120 us) is as long as the main stream's chain WITH the exchange in it -- shortening
+        # that chain only closes the window earlier.  Default therefore: records of the rows after the upsert,
+        # all-gather on the main stream.  BNV_EXCHANGE_STREAM=0 / exchange_stream=False: early records, but the
+        # all-gather on the main stream (in-process drivers that run several shards in lock step on one stream).
+        self.early_exchange = (self.world > 1 and self.table is None
+                               and os.environ.get("BNV_EARLY_EXCHANGE", "0") == "1")
+        self.xchg = None
+        if self.early_exchange and exchange_stream and os.environ.get("BNV_EXCHANGE_STREAM", "1") != "0":
+            others = tuple(x for x in (self.enc, self.front, self.blend) if x is not None)
+            self.xchg = concurrent_stream(dev, self.main, exclude=others)
+            if not self.xchg.bnv_concurrent and self.front is not None:
+                # four hardware queues by default (GPU_MAX_HW_QUEUES): a fifth stream shares one.  Then with the front
+                # stream, which runs a frame or two ahead of everything else
+                self.xchg = concurrent_stream(dev, self.main, exclude=tuple(x for x in others if x is not self.front))
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
             if encoder_workgroups is None:
@@ -167,6 +190,11 @@ class FramePipe:
                 cfg.table_stream = self.table.cuda_stream
                 cfg.table_workgroups = self.table_workgroups
         cfg.encoder_workgroups = self.encoder_workgroups
+        cfg.early_exchange = int(self.early_exchange)
+        # BNV_PIPE_ENCODER_GATE=k (experiment; csrc/pipeline.hip): the encoder of a frame starts behind the table kernel of
+        # the k-th frame before it.  Measured with the early exchange (k = 2, 3): no better than ungated.
+        self.encoder_gate = int(os.environ.get("BNV_PIPE_ENCODER_GATE", 0))
+        cfg.encoder_gate = self.encoder_gate
         self._cfg = cfg
         h = C.c_void_p()
         _lib.check(lib.bnv_frame_pipe_create(C.byref(cfg), C.byref(h)), "bnv_frame_pipe_create")
@@ -322,6 +350,25 @@ class FramePipe:
         _lib.check(self._lib.bnv_frame_bound(self._h, slot, C.byref(m)), "bnv_frame_bound")
         return int(m.value)
 
+    def exchange_stream(self):
+        """The stream the caller's all-gather of an early exchange runs on (the main stream without one of its own)."""
+        return self.xchg if self.xchg is not None else torch.cuda.current_stream(self.dev)
+
+    def exchange_begin(self, slot, capacity):
+        """Early exchange: orders the exchange stream behind the slot's encode -> the slot's send block (header +
+        ``capacity`` records, int32 words) to all-gather ON THAT STREAM."""
+        if (capacity + 1) * REC_WORDS > self.send[slot].numel():
+            raise _lib.BnvError(f"exchange capacity {capacity} exceeds the slot's send block "
+                                f"({self.send[slot].numel() // REC_WORDS - 1} records)")
+        _lib.check(self._lib.bnv_frame_exchange_begin(self._h, slot, C.c_void_p(self.exchange_stream().cuda_stream)),
+                   "bnv_frame_exchange_begin")
+        return self.send[slot][: (capacity + 1) * REC_WORDS]
+
+    def exchange_end(self, slot):
+        """The slot's all-gather is enqueued on the exchange stream: finish() orders the main stream behind it."""
+        _lib.check(self._lib.bnv_frame_exchange_end(self._h, slot, C.c_void_p(self.exchange_stream().cuda_stream)),
+                   "bnv_frame_exchange_end")
+
     def upsert(self, slot, decode=True, ghost_rows=0):
         """Upsert of the slot's encoded voxels; ``ghost_rows``: rows the frame's install may create on top (the
         volume is grown for both BEFORE the upsert: the decode-origin stamps live in a workspace that growth
@@ -346,7 +393,7 @@ class FramePipe:
         ws = v._workspace(self.cap)
         _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),
                                               _lib.ptr(lws), self._epoch[slot]), "bnv_frame_upsert")
-        return None if self.send is None else self.send[slot]
+        return None if (self.send is None or self.early_exchange) else self.send[slot]
 
     def _vstruct(self):
         """The volume as the pipe's calls see it: with the persistent lattice tables switched on for them."""

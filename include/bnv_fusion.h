@@ -285,6 +285,21 @@ int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const voi
 int bnv_shard_install_reset(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
                             int64_t capacity, void* own_send_block, bnv_stream_t stream);
 
+/* EARLY EXCHANGE (round 5; opt-in: config.early_exchange).  The records above carry a row's values AFTER the
+ * frame's upsert, so the all-gather sits in the middle of the main stream's chain.  These carry the frame's
+ * CONTRIBUTION to the voxel instead -- {x, y, z; the frame's weight min(count / 32, 1); the frame's mean feature[8]},
+ * i.e. the encode's outputs -- and the receiver applies the running average of SparseVolume._integrate
+ * (sparse_volume.py:647-673) to its ghost row with the owner's arithmetic: the ghost row equals the owner's row bit for
+ * bit after every frame (every record of a voxel reaches the same ranks: the owners of the blocks around it are fixed
+ * before its first emission), and the exchange needs nothing but the ENCODED frame.
+ *   bnv_shard_emit   coords / feats / pcounts [n] = the encode's outputs for this rank's voxels (n_dev: device count or
+ *                    NULL); writes the header (count, sender = grid.shard_rank) and the boundary voxels' records;
+ *   bnv_shard_apply  blocks as for bnv_shard_install; the own block is skipped; ghost rows are created on demand. */
+int bnv_shard_emit(const bnv_grid_t* grid, const int64_t* coords, const float* feats, const int64_t* pcounts, int64_t n,
+                   const int32_t* n_dev, void* block, int64_t capacity, bnv_stream_t stream);
+int bnv_shard_apply(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world, int64_t capacity,
+                    bnv_stream_t stream);
+
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
 /* Bytes of scratch bnv_encode_pointcloud needs for up to max_points input points.  The scratch is
@@ -647,6 +662,11 @@ int bnv_decode_dense_mode(const float* feat_grid, const float* pts_weight, const
  *                                     (main_stream if none): blend into the slot's sdf, read-backs into the slot's
  *                                     pinned words
  *   bnv_frame_result                  HOST wait for the frame; copies the slot's pinned words out; frees the slot
+ * With config.early_exchange (sharded; bnv_shard_emit / bnv_shard_apply) the order is begin -> bound ->
+ * bnv_frame_exchange_begin(stream X) -> [the caller's all-gather on X] -> bnv_frame_exchange_end(X) -> upsert -> finish:
+ * begin appends the frame's contribution records to the slot's send block behind the encode, the all-gather runs on X
+ * while main_stream still decodes the frame before, and finish applies the received records to the ghost rows behind
+ * the upsert -- no collective on main_stream's chain.
  * The volume and its workspaces are passed per call (they are re-made when the volume grows).  The object owns HIP
  * events only; every buffer is the caller's and must outlive it. */
 #define BNV_PIPE_MAX_SLOTS 8
@@ -725,6 +745,13 @@ typedef struct bnv_frame_pipe_config {
    *                 frame t+2) their workgroup counts PARTITION the CUs -- encoder_workgroups + table_workgroups should
    *                 stay below the CU count so that the small kernels of the other streams always find a free CU. */
   int32_t table_workgroups;
+  /*   early_exchange  (sharded, not with table_stream) the exchange carries the frames' contributions and runs off
+   *                 main_stream: see bnv_frame_exchange_begin. */
+  int32_t early_exchange;
+  /*   encoder_gate  k > 0 (with blend_stream): the point encoder of a frame starts when the table kernel of the k-th
+   *                 frame before it is through (if that frame's finish has been enqueued by then), so that the two
+   *                 LDS-filling MLP kernels take turns instead of sharing the CUs; 0: no gate. */
+  int32_t encoder_gate;
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;
@@ -762,6 +789,11 @@ int bnv_frame_pipe_forget_workspaces(bnv_frame_pipe_t* pipe);
 int bnv_frame_upsert(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, void* vol_ws, size_t vol_ws_bytes,
                      void* lattice_ws, int32_t lattice_epoch);
 int bnv_frame_bound(bnv_frame_pipe_t* pipe, int slot, int32_t* max_bound_host);
+/* Early exchange: `stream` waits for the slot's encode (the send block then holds the frame's records: exchange its
+ * first 1 + capacity records on `stream`) / the exchange enqueued on `stream` is what bnv_frame_finish of the slot
+ * orders main_stream behind.  `stream` may be main_stream.  BNV_ERR_INVALID_ARGUMENT without config.early_exchange. */
+int bnv_frame_exchange_begin(bnv_frame_pipe_t* pipe, int slot, bnv_stream_t stream);
+int bnv_frame_exchange_end(bnv_frame_pipe_t* pipe, int slot, bnv_stream_t stream);
 int bnv_frame_finish(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, const void* blocks,
                      int64_t block_capacity, const float* sdfmlp_pack, const bnv_sdf_delta_t* delta_host,
                      void* lattice_ws, size_t lattice_ws_bytes, int32_t lattice_epoch);

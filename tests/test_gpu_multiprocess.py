@@ -17,11 +17,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda:0"
 
 
-def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=None, _tries=3, extra=()):
+def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=None, _tries=3, extra=(), env_extra=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, BNV_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     # children, not an exec of this (GPU-initialised) process
@@ -32,7 +33,7 @@ def _launch(world, mode, grid, frames, out, hw, checkpoint="fp32", ownership=Non
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0 and _tries > 1 and "EADDRINUSE" in (r.stdout + r.stderr):
         # the free port found above was taken before the rendezvous store listened on it: once more with another
-        return _launch(world, mode, grid, frames, out, hw, checkpoint, ownership, _tries - 1, extra)
+        return _launch(world, mode, grid, frames, out, hw, checkpoint, ownership, _tries - 1, extra, env_extra)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     return [torch.load(os.path.join(out, f"rank{k}.pt"), weights_only=False) for k in range(world)]
 
@@ -143,6 +144,30 @@ def test_spatial_sharding_with_frames_announced_ahead(tmp_path, single_512):
         order = torch.argsort((coords[:, 0] * 512 + coords[:, 1]) * 512 + coords[:, 2])
         assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
     assert all(r["meta"]["host_waits"] == len(ref) for r in ranks)
+
+
+@pytest.mark.parametrize("world,extra", [(4, ()), (3, ("--ahead",))])
+def test_spatial_sharding_early_exchange(tmp_path, single_512, world, extra):
+    """BNV_EARLY_EXCHANGE=1 (csrc/shard.hip): the frame's records carry its contributions to the boundary voxels, the
+    all-gather runs on a stream of its own before the upsert, the receivers apply running averages to their ghost rows
+    -- as real processes (with and without frames announced ahead), bit-identical to the single GPU, one host wait
+    and the same bytes per frame."""
+    ref, rows, tsdf, voxel = single_512
+    ranks = _launch(world, "spatial", 512, len(ref), tmp_path, (480, 640), extra=list(extra),
+                    env_extra={"BNV_EARLY_EXCHANGE": "1"})
+    assert all(r["meta"].get("early_exchange") for r in ranks)
+    for t, (rc, rs) in enumerate(ref):
+        coords = torch.cat([r["out"][t][0] for r in ranks])
+        sdf = torch.cat([r["out"][t][1] for r in ranks])
+        order = torch.argsort((coords[:, 0] * 512 + coords[:, 1]) * 512 + coords[:, 2])
+        assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
+    for r in ranks:
+        m = r["meta"]
+        assert m["host_waits"] == len(ref)
+        # (--ahead: the frame announced behind the last one is abandoned, but its TSDF side fusion was enqueued by begin)
+        assert extra or torch.equal(m["tsdf"], tsdf)
+        assert rows / world < m["rows"] < rows
+        assert m["exchanged_bytes"] / len(ref) < 48 * 1.6 * len(ref[-1][0])
 
 
 def test_spatial_sharding_eight_processes_512_full_frames(tmp_path, single_512):
