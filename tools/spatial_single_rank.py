@@ -53,6 +53,9 @@ ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-
 ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
                 "pipelined frames after the timed run")
 ap.add_argument("--no-latency", action="store_true")
+ap.add_argument("--exchange-delay", type=float, default=0.0,
+                help="microseconds a single-wave spin kernel adds behind the stand-in all-gather on the stream it runs on "
+                     "(the latency of a real 8-rank collective; bnv_probe_spin at 2.1 GHz)")
 ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode is enqueued before the host waits for "
                 "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
 ap.add_argument("--json", action="store_true", help="(internal) print the rank's figures as one JSON line at the end")
@@ -257,6 +260,8 @@ def price(rank, latency):
                 else:
                     blocks[:] = blocks[rank].clone()                      # (round 4's stand-in: copies of the own block)
                 blocks[:, 0, 1] = ranks_i32
+            if args.exchange_delay > 0:
+                _lib.check(lib.bnv_probe_spin(1, int(args.exchange_delay * 2100), _lib.stream_ptr()), "bnv_probe_spin")
         be.install(f, one, cap)
         stats["recv"] += one.numel() * 4
         return t4
@@ -387,7 +392,8 @@ def price(rank, latency):
               f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}, "
               + ("EARLY exchange (contribution records behind the encode, all-gather on "
                  + ("a stream of its own" if be.pipe.xchg is not None else "the main stream") + ")"
-                 if be.early_exchange else "exchange behind the upsert (round 4's order)") + ":")
+                 if be.early_exchange else "exchange behind the upsert (round 4's order)")
+              + (f", + {args.exchange_delay:.0f} us spin behind the stand-in all-gather" if args.exchange_delay else "") + ":")
         print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
               f"rank keeps this pace" + (f"  ({SEG} segments: median {np.median(seg_ms):.3f}, slowest {np.max(seg_ms):.3f} ms)"
                                          if SEG > 1 else ""))
