@@ -77,32 +77,14 @@ __global__ void k_shard_pack_header(ShardRec* __restrict__ block, int rank) {
   block[0].z = 0;
 }
 
-// one thread per (sender, record slot)
-__global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_t g,
-                                                       const ShardRec* __restrict__ blocks, int world,
-                                                       int64_t capacity, int32_t* __restrict__ error,
-                                                       ShardRec* __restrict__ own_block) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  // the frame pipeline (pipeline.hip) appends a frame's records from inside the upsert kernel; the block that was
-  // just exchanged starts its next frame empty (the collective that read it is complete: this kernel is behind it)
-  if (t == 0 && own_block) own_block[0].x = 0;
-  const int sender = (int)(t / capacity);
-  const int64_t i = t - (int64_t)sender * capacity;
-  bool want = false;
-  ShardRec r = {};
-  if (sender < world && sender != g.shard_rank) {
-    const ShardRec* blk = blocks + (size_t)sender * (size_t)(capacity + 1);
-    int cnt = blk[0].x;
-    // the sender's block overflowed, or it holds more records than were exchanged: records are missing
-    if (blk[0].z || cnt > capacity) *error = 4;
-    if (cnt > capacity) cnt = (int)capacity;
-    if (i < cnt) {
-      r = blk[1 + i];
-      want = shard_adjacent_to(r.x, r.y, r.z, g, g.shard_rank);
-    }
-  }
-  // probe / CAS-insert; keys are unique over all records of a frame (every voxel has one owner, and an owner sends a
-  // voxel once), so a slot / row is touched by one thread only
+// Ghost-row look-up shared by k_shard_install / k_shard_apply, one thread per record: the row of the record's voxel in
+// this rank's volume, created (hash slot claimed by CAS, row number from a wave-aggregated atomic on the row counter:
+// ghost rows need no particular order) when it does not exist yet.  Keys are unique over all records of a frame (every
+// voxel has one owner, and an owner sends a voxel once), so a slot / row is touched by one thread only.  Every lane of
+// the wave must call it (ballot); `want` = this lane holds a record for this rank.  -> row, or -1 (nothing to do, or an
+// error that has been written to *error); *created tells a fresh row (coordinates, brick entry and num_hits are set).
+__device__ __forceinline__ int64_t ghost_row(const bnv_volume_t& v, const ShardRec& r, bool want, bool* created_out,
+                                             int32_t* __restrict__ error) {
   uint64_t key;
   int32_t slot = -1, created = 0;
   if (want) {
@@ -130,7 +112,6 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
       *error = 2;
     }
   }
-  // rows of new ghost voxels: wave-aggregated atomic on the row counter (ghost rows need no particular order)
   const unsigned long long m = __ballot(created);
   int64_t row = -1;
   if (m) {
@@ -141,11 +122,12 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
     base = __shfl(base, leader, 64);
     if (created) row = (int64_t)base + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
   }
-  if (slot < 0) return;
+  *created_out = created != 0;
+  if (slot < 0) return -1;
   if (created) {
     if (row >= v.row_capacity) {
       *error = 3;
-      return;
+      return -1;
     }
     v.slot_rows[slot] = (int32_t)row;
     v.row_coords[row * 3 + 0] = r.x;
@@ -153,10 +135,39 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
     v.row_coords[row * 3 + 2] = r.z;
     brick_set(v, r.x, r.y, r.z, (int32_t)row);
     v.num_hits[row] = 0.f;
-  } else {
-    row = v.slot_rows[slot];
-    if (row < 0 || row >= v.row_capacity) return;
+    return row;
   }
+  row = v.slot_rows[slot];
+  return (row < 0 || row >= v.row_capacity) ? -1 : row;
+}
+
+// one thread per (sender, record slot)
+__global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_t g,
+                                                       const ShardRec* __restrict__ blocks, int world,
+                                                       int64_t capacity, int32_t* __restrict__ error,
+                                                       ShardRec* __restrict__ own_block) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // the frame pipeline (pipeline.hip) appends a frame's records from inside the upsert kernel; the block that was
+  // just exchanged starts its next frame empty (the collective that read it is complete: this kernel is behind it)
+  if (t == 0 && own_block) own_block[0].x = 0;
+  const int sender = (int)(t / capacity);
+  const int64_t i = t - (int64_t)sender * capacity;
+  bool want = false;
+  ShardRec r = {};
+  if (sender < world && sender != g.shard_rank) {
+    const ShardRec* blk = blocks + (size_t)sender * (size_t)(capacity + 1);
+    int cnt = blk[0].x;
+    // the sender's block overflowed, or it holds more records than were exchanged: records are missing
+    if (blk[0].z || cnt > capacity) *error = 4;
+    if (cnt > capacity) cnt = (int)capacity;
+    if (i < cnt) {
+      r = blk[1 + i];
+      want = shard_adjacent_to(r.x, r.y, r.z, g, g.shard_rank);
+    }
+  }
+  bool created;
+  const int64_t row = ghost_row(v, r, want, &created, error);
+  if (row < 0) return;
 #pragma unroll
   for (int f = 0; f < 8; ++f) v.features[row * 8 + f] = r.f[f];
   v.weights[row] = r.w;
@@ -226,60 +237,12 @@ __global__ __launch_bounds__(256) void k_shard_apply(bnv_volume_t v, bnv_grid_t 
       want = shard_adjacent_to(r.x, r.y, r.z, g, g.shard_rank);
     }
   }
-  uint64_t key;
-  int32_t slot = -1, created = 0;
-  if (want) {
-    if (pack_key(r.x, r.y, r.z, &key)) {
-      const uint32_t mask = (uint32_t)(v.n_slots - 1);
-      uint32_t s = mix64(key) & mask;
-      for (uint32_t probe = 0; probe <= mask; ++probe) {
-        uint64_t k = v.slot_keys[s];
-        if (k == kEmptyKey) {
-          k = atomicCAS((unsigned long long*)&v.slot_keys[s], (unsigned long long)kEmptyKey, (unsigned long long)key);
-          if (k == kEmptyKey) {
-            slot = (int32_t)s;
-            created = 1;
-            break;
-          }
-        }
-        if (k == key) {
-          slot = (int32_t)s;
-          break;
-        }
-        s = (s + 1) & mask;
-      }
-      if (slot < 0) *error = 1;
-    } else {
-      *error = 2;
-    }
-  }
-  const unsigned long long m = __ballot(created);
-  int64_t row = -1;
-  if (m) {
-    const int lane = threadIdx.x & 63;
-    const int leader = (int)__ffsll((long long)m) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&v.n_rows[0], (int)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (created) row = (int64_t)base + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
-  }
-  if (slot < 0) return;
+  bool created;
+  const int64_t row = ghost_row(v, r, want, &created, error);
+  if (row < 0) return;
   float w_old = 0.f;
   f32x4 fo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (created) {
-    if (row >= v.row_capacity) {
-      *error = 3;
-      return;
-    }
-    v.slot_rows[slot] = (int32_t)row;
-    v.row_coords[row * 3 + 0] = r.x;
-    v.row_coords[row * 3 + 1] = r.y;
-    v.row_coords[row * 3 + 2] = r.z;
-    brick_set(v, r.x, r.y, r.z, (int32_t)row);
-    v.num_hits[row] = 0.f;
-  } else {
-    row = v.slot_rows[slot];
-    if (row < 0 || row >= v.row_capacity) return;
+  if (!created) {
     w_old = v.weights[row];
     fo[0] = *(const f32x4*)&v.features[row * 8];
     fo[1] = *(const f32x4*)&v.features[row * 8 + 4];
