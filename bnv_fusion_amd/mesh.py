@@ -27,6 +27,25 @@ def _table(device):
     return _TABLES[key]
 
 
+def to_host(*tensors):
+    """Device tensors -> numpy arrays through PINNED host memory, all copies in flight at once, one synchronisation.  A
+    whole-volume mesh is ~100 MB (12 B per vertex, 24 B per triangle); ``tensor.cpu()`` stages pageable copies at a
+    quarter of the link's rate, and they were two thirds of an ``extract_mesh`` call.  The arrays own their pinned
+    blocks (torch's host allocator takes them back when the mesh is dropped and hands them to the next call)."""
+    hosts = []
+    for t in tensors:
+        t = t.detach()
+        if not t.is_cuda or t.numel() == 0:
+            hosts.append(t.cpu())
+            continue
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t.contiguous(), non_blocking=True)
+        hosts.append(h)
+    if any(t.is_cuda for t in tensors):
+        torch.cuda.current_stream(next(t.device for t in tensors if t.is_cuda)).synchronize()
+    return [h.numpy() for h in hosts]
+
+
 class TriMesh:
     def __init__(self, vertices, faces):
         self.vertices = np.asarray(vertices, dtype=np.float32).reshape(-1, 3)

@@ -575,7 +575,7 @@ class SparseVolume:
         marching cubes -- both on the GPU.  Returns (active_pts, mesh) like the reference (None when no
         voxel straddles the surface); ``mesh`` is a bnv_fusion_amd.mesh.TriMesh (vertices / faces /
         export), standing in for trimesh.Trimesh(process=False)."""
-        from .mesh import TriMesh, marching_cubes_lattice_indexed
+        from .mesh import TriMesh, marching_cubes_lattice_indexed, to_host
         assert self.active_coordinates is not None, "call self.to_tensor() first."
         active_pts = self.active_coordinates * self.voxel_size + self.min_coords
         sdf = self.decode_lattice(self.active_coordinates, nerf, sdf_delta, query_tensor=True)
@@ -584,10 +584,11 @@ class SparseVolume:
                                                             self.min_coords)
         if faces.shape[0] == 0:
             return None
-        mesh = TriMesh(verts.cpu().numpy(), faces.cpu().numpy())
+        v_host, f_host, pts_host = to_host(verts, faces, active_pts)
+        mesh = TriMesh(v_host, f_host)
         if path is not None:
             mesh.export(path)
-        return active_pts.detach().cpu().numpy(), mesh
+        return pts_host, mesh
 
     def meshlize_sdf(self, nerf, sdf_delta=None):
         """The decode half of meshlize only: (active_pts, sdf [M, 3, 3, 3]) on the device."""

@@ -25,7 +25,9 @@ for r in csv.DictReader(open(P("bench_kernel_stats.csv"))):
     kt[r["Name"].split("(")[0].replace("void ", "").replace("bnv::", "").split("<")[0]] = float(r["AverageNs"]) / 1e3
 roof, fe, su = d["roofline"], d["fp32_exact"], d.get("sustained", {})
 enc = d["kernels"]["pointnet_scatter"]
-opt, me, ms = d.get("optimize", {}), d.get("extract_mesh", {}), d.get("extract_mesh_sweep", {})
+# (the widened rows from the line of the round's final tree when there is one: extract_mesh's host copies changed late)
+_ft = jload("bench_line_final_tree.json") if os.path.exists(P("bench_line_final_tree.json")) else d
+opt, me, ms = (_ft.get(k) or d.get(k, {}) for k in ("optimize", "extract_mesh", "extract_mesh_sweep"))
 V = {
     "VALUE": f"{d['value']:.1f}", "MS": f"{d['ms_per_step']:.3f}", "BURST": f"{d['burst']['value']:.1f}",
     "SUST": f"{su.get('value', 0):.1f}", "SUST_W": f"{su.get('mean_package_power_w') or 0:.0f}",
