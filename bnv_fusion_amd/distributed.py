@@ -633,8 +633,9 @@ class ShardedNeuralMap:
                 if capacity > 0:
                     send = be.emit(fr, capacity)
                     words = self.world * send.numel()
-                    recv = be.recv_buffer(words, fr)
-                    with be.exchange_context():
+                    recv = be.recv_buffer(words, fr) if hasattr(be, "recv_buffer") else torch.empty(
+                        words, dtype=send.dtype, device=send.device)
+                    with (be.exchange_context() if hasattr(be, "exchange_context") else contextlib.nullcontext()):
                         dist.all_gather_into_tensor(recv, send, group=self.group)
                     self.exchanged_bytes += words * 4
                     reserved = be.install(fr, recv, capacity)
