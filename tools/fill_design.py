@@ -105,16 +105,20 @@ for label, name in rows:
     if s:
         tab.append(f"| {label} | {s['sum']} | {s['mom']} | {s['bnd']} | {s['mb']} | **{s['max_ms']}** | {s['mean_ms']} | {s['fps']} | `profiles/{R}_{name}.txt` |")
 V["SPATIAL_TABLE"] = "\n".join(tab)
+# the single-GPU frame the sharded ranks are held against: the FASTEST measured this round (the rank figures and the
+# single-GPU lines come from different boxes of the pool, which differ by +- 3 %: the conservative ratio)
+single_ms = min(d["ms_per_step"], ft["ms_per_step"])
+V["SINGLE_MS"] = f"{single_ms:.3f}"
 for w_ in (2, 4):
     sw = spatial(f"spatial_world{w_}")
     if sw:
         V[f"W{w_}_MS"] = sw["max_ms"]
-        V[f"W{w_}_X"] = f"{d['ms_per_step'] / float(sw['max_ms']):.2f}"
+        V[f"W{w_}_X"] = f"{single_ms / float(sw['max_ms']):.2f}"
 w8 = spatial("spatial_world8_all_ranks_256")
 if w8:
     V["W8_MS"] = w8["max_ms"]
-    V["W8_X"] = f"{d['ms_per_step'] / float(w8['max_ms']):.2f}"
-    V["W8_X2"] = f"{d['ms_per_step'] / (float(w8['max_ms']) + 0.012):.2f}"
+    V["W8_X"] = f"{single_ms / float(w8['max_ms']):.2f}"
+    V["W8_X2"] = f"{single_ms / (float(w8['max_ms']) + 0.012):.2f}"
 
 src = open(os.path.join(root, "tools", "design_template.md")).read()
 missing = set()
