@@ -74,12 +74,16 @@ commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], cap
 # csrc/decode.hip no longer is that file
 sha_path = f"{src}/decode_hip.sha256"
 decode_sha = open(sha_path).read().split()[0] if os.path.exists(sha_path) else None
-# (a rebuild of the summaries from the same gpurun_out/ keeps the commit the passes ran at)
-try:
+# (a rebuild of the summaries from the same gpurun_out/ keeps the commit the passes ran at; BNV_PROFILE_COMMIT names it
+# when the passes were re-run at another commit)
+if os.environ.get("BNV_PROFILE_COMMIT"):
+    commit = os.environ["BNV_PROFILE_COMMIT"]
+else:
+  try:
     old = json.load(open(f"{dst}/{R}_pmc_meta.json"))
     if old.get("decode_hip_sha256") == decode_sha and old.get("mlp_evals_per_launch") == dp["roofline"]["mlp_evals_per_launch"]:
         commit = old.get("commit") or commit
-except (OSError, ValueError):
+  except (OSError, ValueError):
     pass
 json.dump({"commit": commit, "decode_hip_sha256": decode_sha,
            "command": "python3 bench.py --no-cpu-baseline --no-alt-mode --no-stream-overlap --no-power-probe",
