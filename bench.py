@@ -861,9 +861,7 @@ def run_bench(args, rank, world, dev, dist, backend):
                 run["parity"] = parity_check(m, run)
                 if kind == "spatial":
                     extra = {"ownership": m.backend.ownership, "block_log2": m.backend.block_log2,
-                             "exchange": ("early: the frame's contributions, all-gathered off the main stream before the "
-                                          "upsert (BNV_EARLY_EXCHANGE=1)" if m.backend.early_exchange else
-                                          "rows after the upsert, one all-gather on the main stream"),
+                             "exchange": "rows after the upsert, one all-gather on the main stream",
                              "received_bytes_per_frame_and_rank": m.exchanged_bytes / max(m.host_waits, 1),
                              "host_waits_per_frame": 1, "encode_stream_overlaps_main_stream":
                                  bool(getattr(m.backend.pipe.enc, "bnv_concurrent", False))}

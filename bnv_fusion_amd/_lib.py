@@ -17,7 +17,7 @@ SYMBOLS = [
     "bnv_volume_clear", "bnv_volume_rehash", "bnv_volume_workspace_bytes", "bnv_volume_integrate",
     "bnv_volume_integrate_batch",
     "bnv_volume_insert", "bnv_volume_query", "bnv_volume_count_optim",
-    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_depth_to_points_padded", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_tsdf_integrate_batch_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_probe_mfma_rate", "bnv_probe_spin", "bnv_stream_create_cu_mask", "bnv_stream_destroy", "bnv_decode_lattice_count_offset",
+    "bnv_depth_workspace_bytes", "bnv_depth_to_points", "bnv_depth_to_points_padded", "bnv_tsdf_integrate", "bnv_tsdf_integrate_u16", "bnv_tsdf_integrate_batch_u16", "bnv_set_mlp_mode", "bnv_get_mlp_mode", "bnv_set_option", "bnv_profile_enable", "bnv_profile_read", "bnv_probe_mfma_rate", "bnv_probe_spin", "bnv_decode_lattice_count_offset",
     "bnv_decode_lattice_table_offset", "bnv_decode_lattice_list_offset", "bnv_lattice_neighbors",
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
@@ -25,11 +25,11 @@ SYMBOLS = [
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
     "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
-    "bnv_encode_finish_image_wg", "bnv_encode_finish_image_parts", "bnv_decode_lattice_snapshot_workspace_bytes", "bnv_decode_lattice_stamped_mark", "bnv_decode_lattice_snapshot_table", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
+    "bnv_encode_finish_image_wg", "bnv_encode_finish_image_parts", "bnv_shard_state_bytes", "bnv_shard_state_loads_offset", "bnv_shard_state_table_offset",
     "bnv_frame_pipe_create", "bnv_frame_pipe_destroy", "bnv_frame_begin_depth", "bnv_frame_begin_points",
     "bnv_frame_upsert", "bnv_frame_bound", "bnv_frame_finish", "bnv_frame_result", "bnv_frame_ready", "bnv_frame_pipe_timeline_enable", "bnv_frame_timeline",
     "bnv_frame_side_depth", "bnv_frame_cancel", "bnv_frame_pipe_forget_workspaces", "bnv_shard_state_configure",
-    "bnv_shard_emit", "bnv_shard_apply", "bnv_frame_exchange_begin", "bnv_frame_exchange_end",
+    
 ]
 
 
@@ -80,8 +80,7 @@ class FramePipeConfig(C.Structure):
                 ("enc_ws_max_points", C.c_int64), ("max_depth", C.c_double), ("tsdf", TsdfDesc),
                 ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
                 ("main_stream", C.c_void_p), ("enc_ws2", C.c_void_p), ("front_stream", C.c_void_p),
-                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32), ("table_stream", C.c_void_p),
-                ("table_workgroups", C.c_int32), ("early_exchange", C.c_int32), ("encoder_gate", C.c_int32)]
+                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32)]
 
 
 class BnvError(RuntimeError):
@@ -177,7 +176,6 @@ def load():
         "bnv_mc_emit_indexed": (C.c_int, [vp, vp, i64, vp, C.c_float, C.c_float, C.POINTER(C.c_float), vp, vp, vp, vp, vp,
                                           vp]),
         "bnv_decode_lattice_workspace_bytes": (sz, [i64, i64]),
-        "bnv_decode_lattice_snapshot_workspace_bytes": (sz, [i64, i64]),
         "bnv_encode_finish_image_parts": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
                                                     C.c_int, vp, C.c_int, C.c_int, vp]),
         "bnv_decode_lattice_count_offset": (sz, [i64]),
@@ -210,8 +208,6 @@ def load():
         "bnv_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64)]),
         "bnv_probe_mfma_rate": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "bnv_probe_spin": (C.c_int, [C.c_int, i64, vp]),
-        "bnv_stream_create_cu_mask": (C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(vp)]),
-        "bnv_stream_destroy": (C.c_int, [vp]),
         "bnv_decode_lattice": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, vp,
                                          C.POINTER(SdfDelta), vp, sz, i32, vp, vp]),
         "bnv_decode_dense": (C.c_int, [vp, vp, C.POINTER(i32), C.c_float, i32, vp, vp, i64, i32, vp, vp, vp, vp]),
@@ -219,10 +215,6 @@ def load():
                                                         vp, sz, i32, vp]),
         "bnv_encode_finish_image_wg": (C.c_int, [vp, i64, C.c_int, C.POINTER(Grid), vp, vp, sz, i64, vp, vp, vp, vp, i64,
                                                  C.c_int, vp, C.c_int, vp]),
-        "bnv_decode_lattice_stamped_mark": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, i64, vp, vp, sz,
-                                                      i32, vp]),
-        "bnv_decode_lattice_snapshot_table": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, vp, sz, C.c_int,
-                                                        vp]),
         "bnv_shard_state_bytes": (sz, [C.POINTER(i32), i32]),
         "bnv_shard_state_loads_offset": (sz, []),
         "bnv_shard_state_table_offset": (sz, []),
@@ -249,10 +241,6 @@ def load():
         "bnv_frame_side_depth": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), vp]),
         "bnv_frame_cancel": (C.c_int, [vp, C.c_int]),
-        "bnv_frame_exchange_begin": (C.c_int, [vp, C.c_int, vp]),
-        "bnv_frame_exchange_end": (C.c_int, [vp, C.c_int, vp]),
-        "bnv_shard_emit": (C.c_int, [C.POINTER(Grid), vp, vp, vp, i64, vp, vp, i64, vp]),
-        "bnv_shard_apply": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, C.c_int, i64, vp]),
         "bnv_frame_pipe_forget_workspaces": (C.c_int, [vp]),
         "bnv_shard_state_configure": (C.c_int, [vp, i32, i32, vp]),
     }

@@ -1932,12 +1932,11 @@ struct LatticeWs {
   uint32_t* need_mask;  // [row_capacity] bit l set: table[row][l] is read by a live lattice point
   int32_t* origin_stamp;  // [row_capacity] == epoch: the row's voxel is a decoded origin of this call
   int32_t* entries;   // [entry_capacity] (row << 5) | l
-  float* snap;        // [row_capacity][8] the feature rows the call's table entries read, as the marking kernel found them (null unless asked for)
   int64_t list_capacity;
   int64_t entry_capacity;
 };
 
-static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws, bool with_snap = false) {
+static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, LatticeWs* ws) {
   if (n < 1) n = 1;
   int64_t cap = 27 * n;
   if (cap > row_capacity) cap = row_capacity;
@@ -1958,13 +1957,10 @@ static size_t lattice_ws_layout(int64_t n, int64_t row_capacity, char* base, Lat
   int64_t ecap = 27 * cap;
   if (ecap > 216 * n) ecap = 216 * n;
   char* en = take(ecap * 4);
-  // (last, and only for callers that ask: every other address is the same with and without it)
-  char* sn = with_snap ? take(row_capacity * 8 * 4) : nullptr;
   if (ws) {
     ws->need_mask = (uint32_t*)nm;
     ws->origin_stamp = (int32_t*)os;
     ws->entries = (int32_t*)en;
-    ws->snap = (float*)sn;
     ws->entry_capacity = ecap;
     ws->stamp = (int32_t*)st;
     ws->table = (float*)tb;
@@ -2087,13 +2083,6 @@ struct MarkFused {
   int64_t row_limit;
   float min_pts;
   int32_t* nbr_rows_out;
-  // Snapshot (both null: none): the feature row of every row that gets a table entry is copied to snap[row] -- the
-  // table MLP then reads the snapshot, and the volume is free for the NEXT frame's upsert while it runs (the frame
-  // pipeline puts the table kernel on a stream of its own).  Every entry of a row that is an origin of the call is
-  // appended by that origin's threads, so its centre point's thread copies the row; entries in other rows (the
-  // fringe) are copied by whoever appends them (the same bytes from every writer).
-  const float* feat_src;
-  float* feat_snap;
   // Persistent tables (bnv_volume_t.lattice_have; null: none): bit l of have[row] = the entry (row, l) is in the
   // persistent table for the row's current features.  Entries in rows this call does not decode are listed only when
   // their bit is clear (and the bit is set: the table kernel behind fills them); the entries of the call's own rows
@@ -2101,14 +2090,7 @@ struct MarkFused {
   uint32_t* have;
 };
 
-__device__ __forceinline__ void snap_row(const MarkFused& F, int row) {
-  const f32x4* s4 = (const f32x4*)(F.feat_src + (size_t)row * 8);
-  f32x4* d4 = (f32x4*)(F.feat_snap + (size_t)row * 8);
-  d4[0] = s4[0];
-  d4[1] = s4[1];
-}
-
-template <bool FUSED, bool SNAP = false>
+template <bool FUSED>
 __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
@@ -2214,8 +2196,6 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
         xo |= s_ob[w + 1] << (64 - sh);
       }
       const uint32_t um = (uint32_t)xu & 0x7FFFFFFu, om = (uint32_t)xo & 0x7FFFFFFu, need = s_need[p];
-      if constexpr (SNAP)
-        if (p == 13 && nb27[13] >= 0) snap_row(F, nb27[13] & ~kOriginBit);   // the origin's own row
       if ((um & need) == need) {     // live
         uint32_t rest = need & ~om;  // corner voxels nobody decodes in this call
         if (!((rest >> 13) & 1u)) {  // the origin's own row (always, but for a caller's stale stamp array)
@@ -2250,7 +2230,6 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
           for (int k = 0; k < 8; ++k)
             if (rowk[k] >= 0 && !((seen[k] >> lk[k]) & 1u)) {
               // (at most 8 distinct corners, the own row among them: at < 8)
-              if constexpr (SNAP) snap_row(F, rowk[k]);
               ent[at & 7] = (rowk[k] << 5) | lk[k];
               keep |= 1u << (at & 7);
               ++at;
@@ -2327,7 +2306,7 @@ __global__ __launch_bounds__(kMarkThreads) void k_lattice_mark(const int32_t* __
 constexpr int kMoThreads = 256;                 // origins per workgroup
 constexpr int kMoExtra = 3072;                  // LDS room for fringe entries of a workgroup (beyond it: direct appends)
 constexpr int kMoWork = 2048;                   // LDS list of a workgroup's lattice points that have fringe corners
-template <bool FUSED, bool SNAP = false>
+template <bool FUSED>
 __global__ __launch_bounds__(kMoThreads) void k_lattice_mark_o(const int32_t* __restrict__ nbr_rows, int64_t n,
                                                                const int32_t* __restrict__ origin_stamp, int32_t epoch,
                                                                uint32_t* __restrict__ need_mask,
@@ -2404,7 +2383,6 @@ __global__ __launch_bounds__(kMoThreads) void k_lattice_mark_o(const int32_t* __
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (rowk[k] < 0 || ((seen[k] >> lk[k]) & 1u)) continue;
-      if constexpr (SNAP) snap_row(F, rowk[k]);
       const int e = (rowk[k] << 5) | lk[k];
       const int at = atomicAdd(&s_nx, 1);
       if (at < kMoExtra) {
@@ -2502,8 +2480,6 @@ __global__ __launch_bounds__(kMoThreads) void k_lattice_mark_o(const int32_t* __
     if (b >= n) live = 0;
     // the points whose entry in the origin's OWN row this thread lists (always, but for a caller's stale stamp array)
     const uint32_t own = ((om >> 13) & 1u) ? live : 0u;
-    if constexpr (SNAP)
-      if (own_row >= 0) snap_row(F, own_row);
     if (own && F.have) atomicOr(&F.have[own_row], own);   // (the upsert cleared the word; nobody else sets bits of an origin's row)
     // fringe entries: corner rows that are not decoded in this call.  A thread only LISTS its points that have such
     // corners (origin << 5 | p); the whole workgroup then works the list off, one point per thread and step, the (up
@@ -2965,10 +2941,6 @@ size_t bnv_decode_lattice_workspace_bytes(int64_t n_voxels, int64_t row_capacity
   return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr);
 }
 
-size_t bnv_decode_lattice_snapshot_workspace_bytes(int64_t n_voxels, int64_t row_capacity) {
-  return lattice_ws_layout(n_voxels, row_capacity, nullptr, nullptr, true);
-}
-
 size_t bnv_decode_lattice_count_offset(int64_t row_capacity) {
   LatticeWs ws;
   lattice_ws_layout(1, row_capacity, (char*)256, &ws);
@@ -3025,33 +2997,24 @@ static bool lattice_persist(const bnv_volume_t* vol) {
 }
 
 static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* n_dev, void* ws_ptr, size_t ws_bytes,
-                             int32_t epoch, bool clear, bnv_stream_t stream_, const float* snap_src = nullptr) {
+                             int32_t epoch, bool clear, bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || n < 0 || !ws_ptr || epoch == 0) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
-  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, snap_src != nullptr) > ws_bytes)
-    return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
   // entries listed, tile counter of the table kernel, spare (bnv_decode_lattice: cleared by k_lattice_neighbors)
   if (clear) BNV_HIP_CHECK(hipMemsetAsync(ws.n_list + 1, 0, 12, stream));
   if (n == 0) return BNV_OK;
   MarkFused F = {};
-  F.feat_src = snap_src;
-  F.feat_snap = snap_src ? ws.snap : nullptr;
-  F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
+  F.have = lattice_persist(vol) ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
   const dim3 ogrid(capped_grid((n + kMoThreads - 1) / kMoThreads, 4));
   const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0;
-  if (per_origin && snap_src)
-    hipLaunchKernelGGL((k_lattice_mark_o<false, true>), ogrid, dim3(kMoThreads), 0, stream, ws.nbr_rows, n,
-                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
-  else if (per_origin)
-    hipLaunchKernelGGL((k_lattice_mark_o<false, false>), ogrid, dim3(kMoThreads), 0, stream, ws.nbr_rows, n,
-                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
-  else if (snap_src)
-    hipLaunchKernelGGL((k_lattice_mark<false, true>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+  if (per_origin)
+    hipLaunchKernelGGL((k_lattice_mark_o<false>), ogrid, dim3(kMoThreads), 0, stream, ws.nbr_rows, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   else
-    hipLaunchKernelGGL((k_lattice_mark<false, false>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
+    hipLaunchKernelGGL((k_lattice_mark<false>), mgrid, dim3(kMarkThreads), 0, stream, ws.nbr_rows, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
@@ -3061,11 +3024,10 @@ static int lattice_mark_impl(const bnv_volume_t* vol, int64_t n, const int32_t* 
 static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* weights,
                                         int64_t row_limit, const int64_t* origins, int64_t n, const int32_t* n_dev,
                                         void* ws_ptr, size_t ws_bytes, int32_t epoch, bool prestamped,
-                                        bnv_stream_t stream_, const float* snap_src = nullptr) {
+                                        bnv_stream_t stream_) {
   if (!vol_ok_ro(vol) || !grid || !weights || n < 0 || epoch == 0 || !ws_ptr) return BNV_ERR_INVALID_ARGUMENT;
   LatticeWs ws;
-  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, snap_src != nullptr) > ws_bytes)
-    return BNV_ERR_WORKSPACE_TOO_SMALL;
+  if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws) > ws_bytes) return BNV_ERR_WORKSPACE_TOO_SMALL;
   hipStream_t stream = (hipStream_t)stream_;
   if (n == 0) return BNV_OK;
   if (!origins) return BNV_ERR_INVALID_ARGUMENT;
@@ -3081,24 +3043,16 @@ static int lattice_neighbors_mark_fused(const bnv_volume_t* vol, const bnv_grid_
   F.row_limit = row_limit;
   F.min_pts = (float)grid->min_pts_in_grid;
   F.nbr_rows_out = ws.nbr_rows;
-  F.feat_src = snap_src;
-  F.feat_snap = snap_src ? ws.snap : nullptr;
-  F.have = lattice_persist(vol) && !snap_src ? vol->lattice_have : nullptr;
+  F.have = lattice_persist(vol) ? vol->lattice_have : nullptr;
   const dim3 mgrid(capped_grid((n * 27 + kMarkThreads * kMarkChunks - 1) / (kMarkThreads * kMarkChunks), 2));
   const dim3 ogrid(capped_grid((n + kMoThreads - 1) / kMoThreads, 4));
   // (a shard's call keeps the per-point kernel: measured equal to slightly better there, profiles/r05_experiments.txt [e7])
   const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0 && grid->shard_world <= 1;
-  if (per_origin && snap_src)
-    hipLaunchKernelGGL((k_lattice_mark_o<true, true>), ogrid, dim3(kMoThreads), 0, stream, (const int32_t*)nullptr, n,
-                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
-  else if (per_origin)
-    hipLaunchKernelGGL((k_lattice_mark_o<true, false>), ogrid, dim3(kMoThreads), 0, stream, (const int32_t*)nullptr, n,
-                       ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
-  else if (snap_src)
-    hipLaunchKernelGGL((k_lattice_mark<true, true>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
+  if (per_origin)
+    hipLaunchKernelGGL((k_lattice_mark_o<true>), ogrid, dim3(kMoThreads), 0, stream, (const int32_t*)nullptr, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   else
-    hipLaunchKernelGGL((k_lattice_mark<true, false>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
+    hipLaunchKernelGGL((k_lattice_mark<true>), mgrid, dim3(kMarkThreads), 0, stream, (const int32_t*)nullptr, n,
                        ws.origin_stamp, epoch, ws.need_mask, ws.entries, ws.n_list + 1, ws.entry_capacity, n_dev, F);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
@@ -3137,9 +3091,13 @@ static int lattice_table_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, c
   a.n_list = ws.n_list;
   a.table = ws.table;
   a.need_mask = ws.need_mask;
-  if (lattice_persist(vol) && use_entries && features == vol->features) {
+  if (lattice_persist(vol)) {
+    // ONE predicate for the three stages (mark, table, blend all ask lattice_persist(vol)): a call that switches the
+    // persistent tables on works on the volume's own feature rows and on listed entries, or is rejected -- the marking
+    // kernel has kept its books in lattice_have and the blend will read vol->lattice_table
+    if (!use_entries || features != vol->features) return BNV_ERR_INVALID_ARGUMENT;
     a.table = vol->lattice_table;   // the listed entries are the ones the persistent table lacks
-    a.need_mask = nullptr;          // (the marking kernel kept its books in lattice_have)
+    a.need_mask = nullptr;
   }
   a.entries = use_entries ? ws.entries : nullptr;
   const int64_t evals = use_entries ? ws.entry_capacity : ws.list_capacity * 27;
@@ -3172,11 +3130,12 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
                                const float* weights, int64_t row_limit, const float* sdfmlp_pack,
                                const int64_t* origins, int64_t n, const int32_t* n_dev, const bnv_sdf_delta_t* delta,
                                void* ws_ptr, size_t ws_bytes, int32_t epoch, float* out_sdf, bool prestamped,
-                               bnv_stream_t stream, int stages = 7, bool snapshot = false, int table_workgroups = 0) {
-  // stages: 1 = neighbour rows + live entries (+ feature snapshot when `snapshot`), 2 = table MLP (from the snapshot
-  // when `snapshot`), 4 = blend
+                               bnv_stream_t stream, int stages = 7) {
+  // stages: 1 = neighbour rows + live entries, 2 = table MLP, 4 = blend
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!features || !grid || n < 0 || ((stages & 2) && !sdfmlp_pack)) return BNV_ERR_INVALID_ARGUMENT;
+  // persistent tables belong to the volume's own rows: have-bits set by a call that decodes other features would poison them
+  if (lattice_persist(vol) && features != vol->features) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   // neighbour rows -> entries read by live lattice points -> MLP on those entries only -> blend.  The marking kernel
   // looks the neighbour rows up itself (one launch and a 10 MB round trip less): always with the per-origin kernel on
@@ -3189,28 +3148,20 @@ static int decode_lattice_impl(const bnv_volume_t* vol, const bnv_grid_t* grid, 
     const int fused_opt = g_fused_mark.load(std::memory_order_relaxed);
     const bool per_origin = g_mark_per_origin.load(std::memory_order_relaxed) != 0;
     const bool fuse = fused_opt == 1 || (fused_opt < 0 && ((per_origin && vol->brick) || n <= 49152 || grid->shard_world > 1));   // (n may be a capacity: a shard's frame holds 1 / world of it)
-    const float* snap_src = snapshot ? features : nullptr;
     if (fuse) {
       rc = lattice_neighbors_mark_fused(vol, grid, weights, row_limit, origins, n, n_dev, ws_ptr, ws_bytes, epoch,
-                                        prestamped, stream, snap_src);
+                                        prestamped, stream);
       if (rc != BNV_OK) return rc;
     } else {
       rc = lattice_neighbors_impl(vol, grid, weights, row_limit, origins, n, n_dev, nullptr, 0, ws_ptr, ws_bytes, epoch,
                                   prestamped, stream);
       if (rc != BNV_OK) return rc;
-      rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream, snap_src);
+      rc = lattice_mark_impl(vol, n, n_dev, ws_ptr, ws_bytes, epoch, false, stream);
       if (rc != BNV_OK) return rc;
     }
   }
   if (stages & 2) {
-    const float* src = features;
-    if (snapshot) {
-      LatticeWs ws;
-      if (lattice_ws_layout(n, vol->row_capacity, (char*)ws_ptr, &ws, true) > ws_bytes)
-        return BNV_ERR_WORKSPACE_TOO_SMALL;
-      src = ws.snap;
-    }
-    rc = lattice_table_impl(vol, grid, src, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, table_workgroups, stream);
+    rc = lattice_table_impl(vol, grid, features, sdfmlp_pack, n, 1, ws_ptr, ws_bytes, 0, stream);
     if (rc != BNV_OK) return rc;
   }
   if (!(stages & 4) || !out_sdf) return BNV_OK;   // (the caller blends itself, bnv_decode_lattice_stamped_tables)
@@ -3230,23 +3181,7 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol, const bnv_grid_t*
                                       const int64_t* origins, int64_t n, const int32_t* n_dev, void* ws_ptr,
                                       size_t ws_bytes, int32_t epoch, bnv_stream_t stream) {
   return decode_lattice_impl(vol, grid, features, weights, row_limit, sdfmlp_pack, origins, n, n_dev, nullptr, ws_ptr,
-                             ws_bytes, epoch, nullptr, true, stream, 3, false);
-}
-
-int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
-                                    const int32_t* n_dev, void* ws_ptr, size_t ws_bytes, int32_t epoch,
-                                    bnv_stream_t stream) {
-  return decode_lattice_impl(vol, grid, features, weights, row_limit, nullptr, origins, n, n_dev, nullptr, ws_ptr,
-                             ws_bytes, epoch, nullptr, true, stream, 1, true);
-}
-
-int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* sdfmlp_pack,
-                                      int64_t n, void* ws_ptr, size_t ws_bytes, int max_workgroups,
-                                      bnv_stream_t stream) {
-  if (!vol || !vol->features || max_workgroups < 0) return BNV_ERR_INVALID_ARGUMENT;
-  return decode_lattice_impl(vol, grid, vol->features, nullptr, 0, sdfmlp_pack, nullptr, n, nullptr, nullptr, ws_ptr,
-                             ws_bytes, 1, nullptr, true, stream, 2, true, max_workgroups);
+                             ws_bytes, epoch, nullptr, true, stream, 3);
 }
 
 int bnv_decode_lattice_stamped(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,

@@ -15,11 +15,6 @@
 //                      finish:  install ghost rows (resets the send block), neighbours + mark, table MLP
 //   B (blend stream)   finish:  blend, counters / row count / evaluation count to pinned memory, done event
 //
-// EARLY EXCHANGE (config.early_exchange; shard.hip): the records carry the frame's contribution to a voxel instead of
-// the row after the upsert, so they leave behind finalize on E, the caller's all-gather runs on a stream of its own
-// between bnv_frame_exchange_begin / _end while M still decodes the frame before, and M's chain is upsert -> apply the
-// received contributions to the ghost rows -> mark -> table: no collective on the critical path.
-//
 // Why four.  The two MLP kernels each fill a CU's LDS, so they can only take turns, and M is one dependent chain:
 // upsert(t) -> all-gather -> install -> mark -> table(t) -> [blend(t)] -> upsert(t+1) ...  With two streams a rank's
 // frame of an 8-GPU run was table 150 us + encoder 60 us + ~90 us in which only small kernels ran: the encoder of
@@ -30,17 +25,6 @@
 // workspace is double-buffered by the caller); and the encoder is launched on a share of the CUs
 // (encoder_workgroups) so that the chain's small kernels find free CUs while it runs -- they cannot share a CU with
 // it (LDS, registers).  A cycle is then ~ [encoder(t+1) beside chain(t)] + table(t).
-//
-// FIVE streams (table_stream; OPT-IN: measured slower, see below).  The cycle above still has the two MLP kernels take
-// turns.  With the table MLP on a stream T of its own -- reading a SNAPSHOT of the feature rows its entries need, taken
-// by the marking kernel, so that the next frame's upsert may change the volume meanwhile -- three things run at once
-// in the steady state: table(t) on T, the chain of frame t+1 on M, the encoder of frame t+2 on E; E and T are meant to
-// be CU-MASKED streams (bnv_stream_create_cu_mask) of disjoint CU sets.  E then carries nothing but the encoder
-// kernel: finalize moves to the head of the frame's chain on M, the TSDF side fusion (gated by finalize's point
-// count) to B.  Measured (profiles/r04_cu_mask_experiment.txt, r04_fifth_stream_experiment.txt): both MLP kernels run
-// at the pace their CU share predicts, but the chain's small latency-bound kernels, squeezed into the wave slots the
-// persistent kernels leave, run 3-6 x slower (the blend, which fits beside the table kernel, 12 -> 60 us;
-// k_vol_integrate 14 -> 83 us) and bound the frame: 0.29-0.33 ms against 0.263 ms with four streams.
 //
 // E of frame t+1 depends on the frame only; the host wait for the bound of frame t+1 (bnv_frame_bound) returns
 // while M still holds most of frame t, and the GPU never waits for the host.  Nothing here allocates device memory;
@@ -74,8 +58,7 @@ __global__ void k_readback_words(const int32_t* __restrict__ counters, const int
 struct bnv_frame_pipe {
   bnv_frame_pipe_config_t cfg;
   int32_t* host_dev[BNV_PIPE_MAX_SLOTS];   // device-side address of the slots' pinned words (null: copy instead)
-  hipStream_t F, E, M, B, T;               // F == E, B == M, T == M when the config names no stream for them
-  hipEvent_t ev_mark[BNV_PIPE_MAX_SLOTS];  // the marking kernel (and its feature snapshot) of the slot's frame is through
+  hipStream_t F, E, M, B;                  // F == E, B == M when the config names no stream for them
   hipEvent_t ev_bound[BNV_PIPE_MAX_SLOTS], ev_enc[BNV_PIPE_MAX_SLOTS], ev_side[BNV_PIPE_MAX_SLOTS],
       ev_table[BNV_PIPE_MAX_SLOTS], ev_done[BNV_PIPE_MAX_SLOTS];
   hipEvent_t ev_encws[2];               // the encode workspace is free again (behind finalize of its last frame)
@@ -93,24 +76,6 @@ struct bnv_frame_pipe {
   int64_t n_points[BNV_PIPE_MAX_SLOTS];
   int32_t mlp_mode[BNV_PIPE_MAX_SLOTS];   // bnv_grid_t.mlp_mode a slot's frame was begun with (its decode uses the same)
   size_t bound_off;
-  // split mode (T != M): what finalize and the TSDF side fusion of the slot's frame need at upsert time
-  bool split;
-  const float* pts[BNV_PIPE_MAX_SLOTS];
-  int width[BNV_PIPE_MAX_SLOTS];
-  struct SideArgs {
-    bool on;
-    const void* depth;
-    const float* color;
-    int dtype, H, W;
-    float K[9], T[16];
-  } side[BNV_PIPE_MAX_SLOTS];
-  hipEvent_t ev_fin[BNV_PIPE_MAX_SLOTS];   // finalize of the slot's frame is through (split mode)
-  // early exchange (shard.hip): the frame's contribution records leave behind finalize on E; the caller's all-gather
-  // runs on a stream of its choosing between bnv_frame_exchange_begin / _end, off the main stream's chain
-  bool early;
-  hipEvent_t ev_xchg[BNV_PIPE_MAX_SLOTS];
-  bool xchg_set[BNV_PIPE_MAX_SLOTS];
-  uint64_t table_serial[BNV_PIPE_MAX_SLOTS];   // serial of the frame ev_table[slot] was recorded for last (0: never)
   // diagnostic timeline (bnv_frame_pipe_timeline_enable): timing events per slot and point, a base event
   bool tl_on;
   hipEvent_t tl_base;
@@ -174,11 +139,6 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   p->M = (hipStream_t)cfg->main_stream;
   p->F = cfg->front_stream ? (hipStream_t)cfg->front_stream : p->E;
   p->B = cfg->blend_stream ? (hipStream_t)cfg->blend_stream : p->M;
-  // the table kernel on a stream of its own needs the blend off the main stream as well (its workspace hazards are
-  // ordered through the blend's done event)
-  p->T = (cfg->table_stream && cfg->blend_stream) ? (hipStream_t)cfg->table_stream : p->M;
-  p->split = p->T != p->M;
-  p->early = cfg->early_exchange != 0 && !p->split && cfg->grid.shard_world > 1;
   p->tl_on = false;
   p->tl_base = nullptr;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s)
@@ -207,14 +167,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->n_points[s] = 0;
     p->enc_buf[s] = 0;
     p->mlp_mode[s] = cfg->grid.mlp_mode;
-    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = p->ev_mark[s] = nullptr;
-    p->ev_fin[s] = nullptr;
-    p->ev_xchg[s] = nullptr;
-    p->xchg_set[s] = false;
-    p->table_serial[s] = 0;
-    p->pts[s] = nullptr;
-    p->width[s] = 0;
-    p->side[s].on = false;
+    p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = nullptr;
     p->host_dev[s] = nullptr;
   }
   for (int k = 0; k < 2; ++k)
@@ -228,8 +181,7 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     else (void)hipGetLastError();
   }
   for (int s = 0; s < cfg->n_slots; ++s) {
-    hipEvent_t* evs[8] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s],
-                          &p->ev_mark[s], &p->ev_fin[s], &p->ev_xchg[s]};
+    hipEvent_t* evs[5] = {&p->ev_bound[s], &p->ev_enc[s], &p->ev_side[s], &p->ev_table[s], &p->ev_done[s]};
     for (hipEvent_t* e : evs)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
         bnv_frame_pipe_destroy(p);
@@ -253,8 +205,7 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* p) {
     for (int k = 0; k < BNV_PIPE_TIMELINE_POINTS; ++k)
       if (p->tl[s][k]) (void)hipEventDestroy(p->tl[s][k]);
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
-    hipEvent_t evs[8] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s], p->ev_mark[s],
-                         p->ev_fin[s], p->ev_xchg[s]};
+    hipEvent_t evs[5] = {p->ev_bound[s], p->ev_enc[s], p->ev_side[s], p->ev_table[s], p->ev_done[s]};
     for (hipEvent_t e : evs)
       if (e) (void)hipEventDestroy(e);
   }
@@ -277,51 +228,26 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
   tl_mark(p, slot, 1, p->F);   // (in front of the event E waits for: the timeline's point 2 can then never precede it)
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
-  if (c.encoder_gate > 0 && p->E != p->M) {
-    // The two MLP kernels exclude each other (each fills a CU's LDS): an encoder that starts while a table kernel runs
-    // only takes CUs from it, and M's small kernels then run with nothing beside them.  Gated, the encoder of frame
-    // t + 1 starts when the table kernel of frame t + 1 - gate is through -- beside M's upsert .. marking of the frame
-    // between them (gate 2 for callers that begin a frame before the previous frame's upsert).
-    const uint64_t want = p->serial[slot] > (uint64_t)c.encoder_gate ? p->serial[slot] - (uint64_t)c.encoder_gate : 0;
-    for (int s2 = 0; want && s2 < c.n_slots; ++s2)
-      if (p->table_serial[s2] == want) {
-        BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_table[s2], 0));
-        break;
-      }
-  }
   tl_mark(p, slot, 2, p->E);
   const bnv_grid_t g = slot_grid(p, slot);
-  // split mode: E carries the persistent MLP kernel only; finalize heads the frame's chain on M (bnv_frame_upsert)
   // (with the timeline on, the two parts are enqueued separately so that a mark fits between them: the same launches)
-  const bool two = p->split || p->tl_on;
+  const bool two = p->tl_on;
   int rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
                                          c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids,
                                          c.out_capacity, 0, b.counters, c.encoder_workgroups, two ? 1 : 3, p->E);
   if (rc != BNV_OK) return rc;
   tl_mark(p, slot, 3, p->E);
-  if (two && !p->split) {
+  if (two) {
     rc = bnv_encode_finish_image_parts(pts, n, image_width, &g, c.pointnet_pack, enc_ws, c.enc_ws_bytes,
                                        c.enc_ws_max_points, b.feats, b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity,
                                        0, b.counters, c.encoder_workgroups, 2, p->E);
     if (rc != BNV_OK) return rc;
   }
-  if (!p->split) tl_mark(p, slot, 4, p->E);
-  if (p->early) {
-    // the frame's contribution records (its emitted boundary voxels) into the slot's send block, behind finalize:
-    // ev_enc covers them, and bnv_frame_exchange_begin orders the caller's all-gather behind it
-    rc = bnv_shard_emit(&g, b.grid_ids, b.feats, b.pcounts, c.out_capacity, &b.counters->n_out, b.send_block,
-                        c.send_capacity, p->E);
-    if (rc != BNV_OK) return rc;
-    p->xchg_set[slot] = false;
-  }
+  tl_mark(p, slot, 4, p->E);
   BNV_HIP_CHECK(hipEventRecord(p->ev_enc[slot], p->E));
-  if (!p->split)
-    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
+  BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
   p->encws_used[p->enc_buf[slot]] = true;
   p->encws_slot[p->enc_buf[slot]] = slot;
-  p->pts[slot] = pts;
-  p->width[slot] = image_width;
-  p->side[slot].on = false;
   p->n_points[slot] = n;
   p->state[slot] = 1;
   return BNV_OK;
@@ -334,9 +260,6 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
   // the encode workspace alternates when there are two: the front end of this frame then only waits for the encoder
   // of the frame before the last one
   const int buf = p->cfg.enc_ws2 ? p->enc_next : 0;
-  // split mode: the workspace's event is recorded behind finalize, i.e. when its last frame is UPSERTED
-  if (p->split && p->encws_used[buf] && p->encws_slot[buf] >= 0 && p->state[p->encws_slot[buf]] == 1)
-    return BNV_ERR_INVALID_ARGUMENT;
   if (p->cfg.enc_ws2) p->enc_next ^= 1;
   p->enc_buf[slot] = buf;
   if (p->encws_used[buf] && p->F != p->E) BNV_HIP_CHECK(hipStreamWaitEvent(p->F, p->ev_encws[buf], 0));
@@ -348,24 +271,11 @@ static int begin_head(bnv_frame_pipe* p, int slot) {
 }
 
 // The TSDF side fusion of the slot's frame (run_e2e.py:99-109), gated on the device by the frame's in-bounds point
-// count: enqueued on E behind the frame's encode -- or, in split mode, remembered for bnv_frame_upsert (behind finalize,
-// which writes the gate, on B) -- and the slot's side event recorded behind it.
+// count: enqueued on E behind the frame's encode, and the slot's side event recorded behind it.
 static int side_depth(bnv_frame_pipe* p, int slot, const void* depth, int depth_dtype, int H, int W,
                       const double* intr_host, const double* T_wc_host, const float* color_im) {
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
-  if (c.tsdf.tsdf && p->split) {
-    bnv_frame_pipe::SideArgs& a = p->side[slot];
-    a.on = true;
-    a.depth = depth;
-    a.color = color_im;
-    a.dtype = depth_dtype;
-    a.H = H;
-    a.W = W;
-    for (int i = 0; i < 9; ++i) a.K[i] = (float)intr_host[i];
-    for (int i = 0; i < 16; ++i) a.T[i] = (float)T_wc_host[i];
-    return BNV_OK;
-  }
   if (c.tsdf.tsdf) {
     float K[9], T[16];
     for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
@@ -436,32 +346,6 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
   const bnv_frame_slot_t& b = c.slots[slot];
   BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
   tl_mark(p, slot, 5, p->M);
-  if (p->split) {
-    const bnv_grid_t g = slot_grid(p, slot);
-    int rc = bnv_encode_finish_image_parts(p->pts[slot], p->n_points[slot], p->width[slot], &g, c.pointnet_pack,
-                                           slot_encws(p, slot), c.enc_ws_bytes, c.enc_ws_max_points, b.feats,
-                                           b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters,
-                                           c.encoder_workgroups, 2, p->M);
-    if (rc != BNV_OK) return rc;
-    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->M));   // finalize has left the workspace clean
-    tl_mark(p, slot, 4, p->M);
-    const bnv_frame_pipe::SideArgs& a = p->side[slot];
-    if (a.on) {   // the TSDF side fusion, gated by the point count finalize wrote
-      BNV_HIP_CHECK(hipEventRecord(p->ev_fin[slot], p->M));
-      BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_fin[slot], 0));
-      const int32_t* gate = &b.counters->n_valid_points;
-      if (a.dtype == 0)
-        rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim,
-                                    c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)a.depth,
-                                    a.color, a.H, a.W, a.K, a.T, 1.0f, (float)c.max_depth, gate, p->B);
-      else
-        rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim,
-                                c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)a.depth, a.color,
-                                a.H, a.W, a.K, a.T, 1.0f, (float)c.max_depth, gate, p->B);
-      if (rc != BNV_OK) return rc;
-      BNV_HIP_CHECK(hipEventRecord(p->ev_side[slot], p->B));
-    }
-  }
   if (lattice_ws && p->B != p->M) {
     // the upsert stamps the decode's origins into lattice_ws and clears its control words: the blend (other stream)
     // of the frame that decoded into this workspace last must be through.  Callers alternate two workspaces, so
@@ -496,7 +380,7 @@ int bnv_frame_upsert(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, voi
     p->lws_serial[k] = p->serial[slot];
   }
   bnv_integrate_extras_t x = {};
-  if (c.grid.shard_world > 1 && !p->early) {
+  if (c.grid.shard_world > 1) {
     x.shard_block = b.send_block;
     x.shard_block_capacity = c.send_capacity;
     x.grid_host = &c.grid;
@@ -531,42 +415,11 @@ int bnv_frame_cancel(bnv_frame_pipe_t* p, int slot) {
   // sharded volume's owner table keeps the owners the frame gave to new blocks -- they are the same on every rank);
   // nothing of it reaches the volume.  The slot's done event covers the encode + side fusion, so the next frame begun
   // in the slot waits for them before it overwrites the slot's buffers.
-  const bnv_frame_pipe_config_t& c = p->cfg;
-  const bnv_frame_slot_t& b = c.slots[slot];
-  if (p->split) {
-    // finalize belongs to the upsert call in split mode: it still has to run (it cleans the encode workspace); the
-    // TSDF side fusion, which would follow it, is dropped with the frame
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_enc[slot], 0));
-    const bnv_grid_t g = slot_grid(p, slot);
-    const int rc = bnv_encode_finish_image_parts(p->pts[slot], p->n_points[slot], p->width[slot], &g, c.pointnet_pack,
-                                                 slot_encws(p, slot), c.enc_ws_bytes, c.enc_ws_max_points, b.feats,
-                                                 b.pcounts, b.flat_ids, b.grid_ids, c.out_capacity, 0, b.counters,
-                                                 c.encoder_workgroups, 2, p->M);
-    if (rc != BNV_OK) return rc;
-    BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->M));
-    BNV_HIP_CHECK(hipEventRecord(p->ev_fin[slot], p->M));
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_fin[slot], 0));
-    p->side[slot].on = false;
-  } else {
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_enc[slot], 0));
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));
-  }
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_enc[slot], 0));
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));
   BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
   p->used[slot] = true;
   p->state[slot] = 0;
-  return BNV_OK;
-}
-
-int bnv_frame_exchange_begin(bnv_frame_pipe_t* p, int slot, bnv_stream_t stream) {
-  if (!slot_ok(p, slot) || p->state[slot] != 1 || !p->early) return BNV_ERR_INVALID_ARGUMENT;
-  BNV_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, p->ev_enc[slot], 0));
-  return BNV_OK;
-}
-
-int bnv_frame_exchange_end(bnv_frame_pipe_t* p, int slot, bnv_stream_t stream) {
-  if (!slot_ok(p, slot) || (p->state[slot] != 1 && p->state[slot] != 2) || !p->early) return BNV_ERR_INVALID_ARGUMENT;
-  BNV_HIP_CHECK(hipEventRecord(p->ev_xchg[slot], (hipStream_t)stream));
-  p->xchg_set[slot] = true;
   return BNV_OK;
 }
 
@@ -593,21 +446,10 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
   int rc;
   tl_mark(p, slot, 7, p->M);
   if (c.grid.shard_world > 1 && blocks && block_capacity > 0) {
-    if (p->early) {
-      // the exchanged contribution records: the caller's all-gather ran on another stream, long ago as a rule
-      if (p->xchg_set[slot]) BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_xchg[slot], 0));
-      rc = bnv_shard_apply(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, p->M);
-    } else {
-      rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
-    }
+    rc = bnv_shard_install_reset(vol, &c.grid, blocks, c.grid.shard_world, block_capacity, b.send_block, p->M);
     if (rc != BNV_OK) return rc;
   }
   tl_mark(p, slot, 8, p->M);
-  // persistent lattice tables (bnv_volume_t.lattice_table): not with the snapshot schedule (its table kernel reads a
-  // copy of the rows, on a stream of its own)
-  bnv_volume_t vol_local = *vol;
-  if (p->split) vol_local.lattice_persist = 0;
-  vol = &vol_local;
   if (lattice_ws) {   // decode of the voxels the frame's upsert stamped, from the live rows
     if (!b.sdf || !sdfmlp_pack) return BNV_ERR_INVALID_ARGUMENT;
     const bnv_grid_t g = slot_grid(p, slot);
@@ -617,32 +459,14 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
       // decoded before it (blend stream) may still be reading
       BNV_HIP_CHECK(hipStreamWaitEvent(p->M, p->ev_done[p->last_decoded], 0));
     p->last_decoded = slot;
-    if (p->T != p->M) {
-      // marking + a snapshot of the feature rows the table entries read, on M; the table MLP on T from the snapshot:
-      // M is free for the next frame's upsert .. marking chain while this frame's table kernel runs
-      rc = bnv_decode_lattice_stamped_mark(vol, &g, vol->features, vol->weights, vol->row_capacity, b.grid_ids,
-                                           c.out_capacity, &b.counters->n_out, lattice_ws, lattice_ws_bytes,
-                                           lattice_epoch, p->M);
-      if (rc != BNV_OK) return rc;
-      BNV_HIP_CHECK(hipEventRecord(p->ev_mark[slot], p->M));
-      BNV_HIP_CHECK(hipStreamWaitEvent(p->T, p->ev_mark[slot], 0));
-      rc = bnv_decode_lattice_snapshot_table(vol, &g, sdfmlp_pack, c.out_capacity, lattice_ws, lattice_ws_bytes,
-                                             c.table_workgroups, p->T);
-      if (rc != BNV_OK) return rc;
-      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->T));
-      tl_mark(p, slot, 9, p->T);
+    rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
+                                           b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
+                                           lattice_ws_bytes, lattice_epoch, p->M);
+    if (rc != BNV_OK) return rc;
+    tl_mark(p, slot, 9, p->M);
+    if (p->B != p->M) {
+      BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
       BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
-    } else {
-      rc = bnv_decode_lattice_stamped_tables(vol, &g, vol->features, vol->weights, vol->row_capacity, sdfmlp_pack,
-                                             b.grid_ids, c.out_capacity, &b.counters->n_out, lattice_ws,
-                                             lattice_ws_bytes, lattice_epoch, p->M);
-      if (rc != BNV_OK) return rc;
-      tl_mark(p, slot, 9, p->M);
-      if (p->B != p->M) {
-        BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
-        p->table_serial[slot] = p->serial[slot];
-        BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
-      }
     }
     // the blend reads the workspace only: on B it leaves M to the next frame's upsert
     rc = bnv_lattice_blend(vol, &g, b.grid_ids, c.out_capacity, &b.counters->n_out, delta, lattice_ws, lattice_ws_bytes,

@@ -123,24 +123,3 @@ extern "C" int bnv_probe_spin(int n_blocks, int64_t cycles, void* stream) {
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }
-
-extern "C" int bnv_stream_create_cu_mask(int n_words, const uint32_t* cu_mask, void** stream_out) {
-  if (n_words < 1 || !cu_mask || !stream_out) return BNV_ERR_INVALID_ARGUMENT;
-  int dev = 0, cus = 0;
-  BNV_HIP_CHECK(hipGetDevice(&dev));
-  BNV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  if (n_words * 32 < cus) return BNV_ERR_INVALID_ARGUMENT;
-  bool any = false;
-  for (int i = 0; i < n_words; ++i) any = any || cu_mask[i] != 0;
-  if (!any) return BNV_ERR_INVALID_ARGUMENT;
-  hipStream_t st = nullptr;
-  BNV_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
-  *stream_out = (void*)st;
-  return BNV_OK;
-}
-
-extern "C" int bnv_stream_destroy(void* stream) {
-  if (!stream) return BNV_ERR_INVALID_ARGUMENT;
-  BNV_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
-  return BNV_OK;
-}

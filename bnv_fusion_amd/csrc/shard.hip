@@ -16,17 +16,6 @@
 //   k_shard_install  the other ranks' records that are adjacent to this rank: upsert as ghost rows (overwrite)
 //
 // HBM-bound and small: ~58 % of a frame's emitted voxels at 8^3-voxel blocks, 48 B each.
-//
-// EARLY EXCHANGE (round 5; opt-in, bnv_frame_pipe_config_t.early_exchange): the records carry the frame's CONTRIBUTION to a voxel --
-// {x, y, z, frame weight, frame mean feature}, what finalize has just produced -- instead of the row's values after
-// the upsert, and every receiver applies the reference's running average (sparse_volume.py:647-673) to its ghost row
-// with the arithmetic the owner uses on its own row: by induction over a voxel's emissions the ghost row equals the
-// owner's row bit for bit (the set of ranks a voxel's records reach never changes: every block of its 3x3x3
-// neighbourhood has its owner before the voxel is emitted for the first time).  The records then exist as soon as the
-// frame is ENCODED, and the frame's all-gather leaves the main stream's chain: it runs while the main stream still
-// decodes the frame before.
-//   k_shard_emit     finalize's emitted boundary voxels -> contribution records (nothing of the volume is read)
-//   k_shard_apply    the other ranks' records that are adjacent to this rank: running-average upsert of ghost rows
 #include "bnv_common.hpp"
 
 namespace bnv {
@@ -77,7 +66,7 @@ __global__ void k_shard_pack_header(ShardRec* __restrict__ block, int rank) {
   block[0].z = 0;
 }
 
-// Ghost-row look-up shared by k_shard_install / k_shard_apply, one thread per record: the row of the record's voxel in
+// Ghost-row look-up of k_shard_install, one thread per record: the row of the record's voxel in
 // this rank's volume, created (hash slot claimed by CAS, row number from a wave-aggregated atomic on the row counter:
 // ghost rows need no particular order) when it does not exist yet.  Keys are unique over all records of a frame (every
 // voxel has one owner, and an owner sends a voxel once), so a slot / row is touched by one thread only.  Every lane of
@@ -174,92 +163,6 @@ __global__ __launch_bounds__(256) void k_shard_install(bnv_volume_t v, bnv_grid_
   if (v.lattice_have) v.lattice_have[row] = 0u;   // a ghost row with new values: its table entries are stale
 }
 
-// ---- early exchange: contribution records ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shard_emit(bnv_grid_t g, const int64_t* __restrict__ coords,
-                                                    const float* __restrict__ feats,
-                                                    const int64_t* __restrict__ pcounts, int64_t n,
-                                                    const int32_t* __restrict__ n_dev, ShardRec* __restrict__ block,
-                                                    int64_t capacity) {
-  if (n_dev) n = (int64_t)*n_dev < n ? (int64_t)*n_dev : n;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if ((int64_t)blockIdx.x * 256 >= n) return;
-  bool send = false;
-  int x = 0, y = 0, z = 0;
-  if (i < n) {
-    x = (int)coords[i * 3 + 0];
-    y = (int)coords[i * 3 + 1];
-    z = (int)coords[i * 3 + 2];
-    send = shard_is_boundary(x, y, z, g);
-  }
-  const unsigned long long m = __ballot(send);
-  if (!m) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = (int)__ffsll((long long)m) - 1;
-  int base = 0;
-  if (lane == leader) base = atomicAdd(&block[0].x, (int)__popcll(m));
-  base = __shfl(base, leader, 64);
-  if (!send) return;
-  const int64_t slot = (int64_t)base + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
-  if (slot >= capacity) {
-    block[0].z = 1;
-    return;
-  }
-  ShardRec r;
-  r.x = x;
-  r.y = y;
-  r.z = z;
-  // the frame's weight exactly as the owner's upsert forms it (volume.hip: k_vol_integrate; :660)
-  r.w = fminf(__fdiv_rn((float)pcounts[i], 32.0f), 1.0f);
-  const f32x4 a = *(const f32x4*)&feats[i * 8], b = *(const f32x4*)&feats[i * 8 + 4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    r.f[f] = a[f];
-    r.f[4 + f] = b[f];
-  }
-  block[1 + slot] = r;
-}
-
-// one thread per (sender, record slot): probe / create the ghost row, then the owner's update on it
-__global__ __launch_bounds__(256) void k_shard_apply(bnv_volume_t v, bnv_grid_t g, const ShardRec* __restrict__ blocks,
-                                                     int world, int64_t capacity, int32_t* __restrict__ error) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int sender = (int)(t / capacity);
-  const int64_t i = t - (int64_t)sender * capacity;
-  bool want = false;
-  ShardRec r = {};
-  if (sender < world && sender != g.shard_rank) {
-    const ShardRec* blk = blocks + (size_t)sender * (size_t)(capacity + 1);
-    int cnt = blk[0].x;
-    if (blk[0].z || cnt > capacity) *error = 4;
-    if (cnt > capacity) cnt = (int)capacity;
-    if (i < cnt) {
-      r = blk[1 + i];
-      want = shard_adjacent_to(r.x, r.y, r.z, g, g.shard_rank);
-    }
-  }
-  bool created;
-  const int64_t row = ghost_row(v, r, want, &created, error);
-  if (row < 0) return;
-  float w_old = 0.f;
-  f32x4 fo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if (!created) {
-    w_old = v.weights[row];
-    fo[0] = *(const f32x4*)&v.features[row * 8];
-    fo[1] = *(const f32x4*)&v.features[row * 8 + 4];
-  }
-  // the owner's arithmetic, operation for operation (volume.hip: k_vol_integrate; sparse_volume.py:649-650)
-  const float w = r.w;
-  const float w_new = __fadd_rn(w_old, w);
-  f32x4 o[2];
-#pragma unroll
-  for (int f = 0; f < 8; ++f)
-    o[f >> 2][f & 3] = __fdiv_rn(__fadd_rn(__fmul_rn(fo[f >> 2][f & 3], w_old), __fmul_rn(r.f[f], w)), w_new);
-  *(f32x4*)&v.features[row * 8] = o[0];
-  *(f32x4*)&v.features[row * 8 + 4] = o[1];
-  v.weights[row] = w_new;
-  if (v.lattice_have) v.lattice_have[row] = 0u;
-}
-
 }  // namespace bnv
 
 using namespace bnv;
@@ -300,32 +203,6 @@ int bnv_shard_install_reset(const bnv_volume_t* vol, const bnv_grid_t* grid, con
 int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
                       int64_t capacity, bnv_stream_t stream) {
   return bnv_shard_install_reset(vol, grid, blocks, world, capacity, nullptr, stream);
-}
-
-int bnv_shard_emit(const bnv_grid_t* grid, const int64_t* coords, const float* feats, const int64_t* pcounts, int64_t n,
-                   const int32_t* n_dev, void* block, int64_t capacity, bnv_stream_t stream_) {
-  if (!grid || !block || n < 0 || capacity < 0 || grid->shard_world < 1) return BNV_ERR_INVALID_ARGUMENT;
-  if (n > 0 && (!coords || !feats || !pcounts)) return BNV_ERR_INVALID_ARGUMENT;
-  hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(k_shard_pack_header, dim3(1), dim3(1), 0, stream, (ShardRec*)block, grid->shard_rank);
-  BNV_LAUNCH_CHECK();
-  if (n == 0) return BNV_OK;
-  hipLaunchKernelGGL(k_shard_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *grid, coords, feats,
-                     pcounts, n, n_dev, (ShardRec*)block, capacity);
-  BNV_LAUNCH_CHECK();
-  return BNV_OK;
-}
-
-int bnv_shard_apply(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world, int64_t capacity,
-                    bnv_stream_t stream_) {
-  if (!shard_vol_ok(vol) || !grid || !blocks || world < 1 || world != grid->shard_world || capacity < 0)
-    return BNV_ERR_INVALID_ARGUMENT;
-  if (capacity == 0 || world == 1) return BNV_OK;
-  const int64_t total = (int64_t)world * capacity;
-  hipLaunchKernelGGL(k_shard_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, *vol,
-                     *grid, (const ShardRec*)blocks, world, capacity, vol->n_rows + 1);
-  BNV_LAUNCH_CHECK();
-  return BNV_OK;
 }
 
 }  // extern "C"

@@ -25,7 +25,6 @@ FRAME-PARALLEL (throughput of one frame stream; ``FrameParallelNeuralMap``, belo
 The frame logic talks to a backend; ``HipShardBackend`` / ``HipFrameBackend`` are the product backends (HIP kernels).
 tests/test_distributed_cpu.py drives the same logic over gloo with CPU backends of its own.
 """
-import contextlib
 import ctypes as C
 
 import numpy as np
@@ -143,7 +142,6 @@ def unflatten(ids, n_xyz):
     return np.stack([ids // (n[1] * n[2]), (ids // n[2]) % n[1], ids % n[2]], 1)
 
 
-_OFF6 = np.array([[-1, 0, 0], [1, 0, 0], [0, -1, 0], [0, 1, 0], [0, 0, -1], [0, 0, 1]], dtype=np.int64)
 OWN_RANK, OWN_ASSIGNED, OWN_TOUCHED = 0x3f, 0x40, 0x80        # bits of an owner-table byte (csrc/bnv_common.hpp)
 
 
@@ -166,7 +164,7 @@ class OwnershipModel:
                 untouched neighbour blocks pinned to the lattice rule (bx + 5 by + 7 bz) % world.
     ``region``  round 5's first touch (the default): contiguous regions.  cur[r] = the voxels THIS frame touches in
                 blocks rank r owns.  A new block without an owner, in walk order (bands stacked along ``axis``), goes to
-                the least-loaded owner among its six face neighbours that is not full (cur * world < touched voxels of
+                the least-loaded owner among the 26 blocks around it (``_OFF27``, as the device kernel) that is not full (cur * world < touched voxels of
                 the frame), else to the least-loaded rank of all; a new block pinned earlier keeps its owner.  Then the
                 untouched neighbour blocks of the new blocks are pinned to the owner of the first new block (walk order)
                 that reaches them -- regions grow outwards -- unless that rank is overloaded
@@ -348,8 +346,7 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None,
-                 exchange_stream=True):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None):
         from .sparse_volume import SparseVolume, make_grid
         import os
         ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
@@ -391,10 +388,7 @@ class HipShardBackend:
         self.inputs_resident = False      # True: frames are complete in device memory when they are passed in
         self.copy_results = True          # False: result() returns views into the slot buffers (valid for n_slots - 1 more frames)
         self.pipe = None
-        self._recv = {}
-        # False: the early exchange's all-gather runs on the main stream (drivers that run several shards of one process
-        # in lock step on one stream); True: on a stream of its own (FramePipe.xchg)
-        self._exchange_stream = bool(exchange_stream)
+        self._recv = None
         self._last_evals = 0
         self.last_owned_pairs = 0
 
@@ -404,20 +398,10 @@ class HipShardBackend:
             from .pipeline import FramePipe
             assert self.pipe is None or not any(self.pipe._busy), "a larger frame arrived while frames are in flight"
             self.pipe = FramePipe(self.volume, self.pointnet, n, n_slots=self.n_slots, tsdf_vol=self.tsdf_vol,
-                                  max_depth=self.max_depth, exchange_stream=self._exchange_stream)
+                                  max_depth=self.max_depth)
         self.pipe.inputs_resident = self.inputs_resident
         self.pipe.sdf_delta = self.sdf_delta
         return self.pipe
-
-    def stream_context(self, frame):
-        """Context every phase of a frame (and the caller's all-gather between them) runs under.  With CU-masked
-        pipeline streams the pipe runs on a main stream of its own when the caller's is the legacy default stream
-        (FramePipe: masked streams are blocking streams); the caller's stream is ordered before it unless the frames
-        are declared resident."""
-        pipe = self._pipe_for(frame)
-        if pipe.own_main and not self.inputs_resident:
-            pipe.main.wait_stream(torch.cuda.current_stream(self.volume._dev))
-        return pipe.stream_context()
 
     # ---- phases ---------------------------------------------------------------------------------
     def encode(self, frame):
@@ -441,55 +425,30 @@ class HipShardBackend:
             return 0
         return min(-(-bound // REC_QUANTUM) * REC_QUANTUM, self.pipe.send_cap)
 
-    @property
-    def early_exchange(self):
-        """True: the frame's records carry its contributions and are exchanged BEFORE the upsert (emit -> all-gather
-        under exchange_context() -> install -> upsert -> finish); False: round 4's order (upsert -> all-gather on the
-        main stream -> install -> finish).  Known once the pipe exists (after the first encode)."""
-        return bool(self.pipe is not None and self.pipe.early_exchange)
-
-    def emit(self, fr, capacity):
-        """Early exchange: this rank's block for the frame (header + ``capacity`` contribution records, int32 words),
-        complete on the exchange stream -- run the all-gather under ``exchange_context()``.  None when nothing is
-        exchanged."""
-        if capacity == 0:
-            return None
-        return self.pipe.exchange_begin(fr.slot, capacity)
-
-    def exchange_context(self):
-        """Context the early exchange's all-gather runs under: the pipe's exchange stream, if it has one."""
-        if self.pipe is not None and self.pipe.early_exchange and self.pipe.xchg is not None:
-            return torch.cuda.stream(self.pipe.xchg)
-        return contextlib.nullcontext()
-
     def upsert(self, fr, capacity, decode=True):
         """Main stream: upsert of the owned voxels in ONE launch that also stamps them as the frame's decode origins
-        and -- without the early exchange -- appends their boundary records to the slot's send block.  -> this rank's
-        block (header + ``capacity`` records, int32 words); None when nothing is exchanged or the exchange is early."""
+        and appends their boundary records to the slot's send block.  -> this rank's block (header + ``capacity``
+        records, int32 words); None when nothing is exchanged."""
         fr.decode = decode
         send = self.pipe.upsert(fr.slot, decode=decode, ghost_rows=(self.world - 1) * capacity)
-        if capacity == 0 or self.pipe.early_exchange:
+        if capacity == 0:
             return None
         if (capacity + 1) * REC_WORDS > send.numel():
             raise _lib.BnvError(f"exchange capacity {capacity} exceeds the slot's send block "
                                 f"({send.numel() // REC_WORDS - 1} records)")
         return send[: (capacity + 1) * REC_WORDS]
 
-    def recv_buffer(self, words, fr=None):
-        """The all-gather's output buffer -- one per slot with the early exchange (a frame's blocks wait for its finish
-        while the next frame's all-gather already runs)."""
-        k = fr.slot if (fr is not None and self.early_exchange) else -1
-        r = self._recv.get(k)
+    def recv_buffer(self, words):
+        """The all-gather's output buffer (written and read on the main stream: one serves every frame)."""
+        r = self._recv
         if r is None or r.numel() < words:
-            r = self._recv[k] = torch.empty(int(words * 1.5), dtype=torch.int32, device=self.dev)
+            r = self._recv = torch.empty(int(words * 1.5), dtype=torch.int32, device=self.dev)
         return r[:words]
 
     def install(self, fr, blocks, capacity):
         """blocks: [world * (capacity + 1) * REC_WORDS] int32 -- the all-gather's output; installed (and the send block
-        reset) / applied to the ghost rows (early exchange) by the frame's finish call."""
+        reset) by the frame's finish call."""
         fr.blocks, fr.capacity = blocks, capacity
-        if self.pipe.early_exchange:
-            self.pipe.exchange_end(fr.slot)
         return (self.world - 1) * capacity
 
     def decode(self, fr):
@@ -601,55 +560,57 @@ class ShardedNeuralMap:
             need = 1 + (1 if ahead else 0) - (1 if self._pre is not None else 0)
             while self._open and len(self._open) + (1 if self._pre is not None else 0) + need > ring:
                 self._open.pop(0).result()            # the slot ring is full: collect the oldest frame
-        ctx = be.stream_context(frame) if hasattr(be, "stream_context") else contextlib.nullcontext()
         if self._pre is not None and self._pre[0] is not frame:
             raise _lib.BnvError("fuse_and_decode_async: the frame announced as next_frame must be the next one passed "
                                 "(flush() integrates an announced frame that will not come, abandon() drops it)")
+        return self._frame(frame, decode, next_frame if ahead else None, ring)
+
+    def _frame(self, frame, decode, next_frame, ring):
+        be = self.backend
+        fr = None
+        upserted = False
         try:
-            return self._frame(frame, decode, next_frame if ahead else None, ctx, ring)
+            with torch.no_grad():
+                if self._pre is not None:
+                    fr, self._pre = self._pre[1], None
+                else:
+                    fr = be.encode(frame)
+                if next_frame is not None:
+                    self._pre = (next_frame, be.encode(next_frame))
+                bound = be.bound(fr)                       # the frame's one host wait
+                self.host_waits += 1
+                capacity = (be.exchange_capacity(bound) if hasattr(be, "exchange_capacity")
+                            else -(-bound // REC_QUANTUM) * REC_QUANTUM)
+                send = be.upsert(fr, capacity, decode)
+                upserted = True
+                return self._exchange_and_finish(be, fr, send, capacity, decode, ring)
         except Exception:
-            # a frame announced and begun ahead must not keep its slot when this one fails on the way
+            # Neither this frame (begun, not upserted: its slot would stay in state 1 and the ring would refuse it for
+            # good) nor a frame announced and begun ahead may keep its slot when this one fails on the way.  A frame
+            # that failed BEHIND its upsert cannot be taken back: its slot stays with the pipe (the volume holds it).
+            if fr is not None and not upserted and hasattr(be, "cancel"):
+                self._cancel(fr)
             self.abandon()
             raise
 
-    def _frame(self, frame, decode, next_frame, ctx, ring):
+    def _cancel(self, fr):
+        try:
+            self.backend.cancel(fr)
+        except Exception as e:      # (the original failure is what the caller must see; this one is reported)
+            import warnings
+            warnings.warn(f"ShardedNeuralMap: cancelling a begun frame failed as well: {e!r}")
+
+    def _exchange_and_finish(self, be, fr, send, capacity, decode, ring):
         import torch.distributed as dist
-        be = self.backend
-        with torch.no_grad(), ctx:
-            if self._pre is not None:
-                fr, self._pre = self._pre[1], None
-            else:
-                fr = be.encode(frame)
-            if next_frame is not None:
-                self._pre = (next_frame, be.encode(next_frame))
-            bound = be.bound(fr)                       # the frame's one host wait
-            self.host_waits += 1
-            capacity = (be.exchange_capacity(bound) if hasattr(be, "exchange_capacity")
-                        else -(-bound // REC_QUANTUM) * REC_QUANTUM)
-            reserved = 0
-            if getattr(be, "early_exchange", False):
-                # the records are the frame's contributions (complete behind its encode): THE collective of the frame
-                # runs on the exchange stream while the main stream still decodes the frame before; then the upsert
-                if capacity > 0:
-                    send = be.emit(fr, capacity)
-                    words = self.world * send.numel()
-                    recv = be.recv_buffer(words, fr) if hasattr(be, "recv_buffer") else torch.empty(
-                        words, dtype=send.dtype, device=send.device)
-                    with (be.exchange_context() if hasattr(be, "exchange_context") else contextlib.nullcontext()):
-                        dist.all_gather_into_tensor(recv, send, group=self.group)
-                    self.exchanged_bytes += words * 4
-                    reserved = be.install(fr, recv, capacity)
-                be.upsert(fr, capacity, decode)
-                return self._finish(be, fr, decode, reserved, ring)
-            send = be.upsert(fr, capacity, decode)
-            if capacity > 0:
-                words = self.world * send.numel()
-                recv = be.recv_buffer(words) if hasattr(be, "recv_buffer") else torch.empty(
-                    words, dtype=send.dtype, device=send.device)
-                dist.all_gather_into_tensor(recv, send, group=self.group)      # THE collective of the frame
-                self.exchanged_bytes += words * 4
-                reserved = be.install(fr, recv, capacity)
-            return self._finish(be, fr, decode, reserved, ring)
+        reserved = 0
+        if capacity > 0:
+            words = self.world * send.numel()
+            recv = be.recv_buffer(words) if hasattr(be, "recv_buffer") else torch.empty(
+                words, dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(recv, send, group=self.group)      # THE collective of the frame
+            self.exchanged_bytes += words * 4
+            reserved = be.install(fr, recv, capacity)
+        return self._finish(be, fr, decode, reserved, ring)
 
     def _finish(self, be, fr, decode, reserved, ring):
         sdf = be.decode(fr) if decode else None
@@ -671,18 +632,18 @@ class ShardedNeuralMap:
         if self._pre is not None:
             fr, self._pre = self._pre[1], None
             if hasattr(self.backend, "cancel"):
-                try:
-                    self.backend.cancel(fr)
-                except Exception:
-                    pass
+                self._cancel(fr)
 
     def flush(self):
         """End of a stream: a frame announced as ``next_frame`` that was never passed is integrated now (no decode;
         COLLECTIVE like every frame), then every open handle is collected.  -> the results of the frames that were
         still open, oldest first."""
+        last = None
         if self._pre is not None:
-            self.fuse_and_decode_async(self._pre[0], decode=False)
+            last = self.fuse_and_decode_async(self._pre[0], decode=False)
         out = []
+        if last is not None and last not in self._open:
+            self._open.append(last)          # (backends without a slot ring keep no list: the flushed frame is collected too)
         while self._open:
             h = self._open.pop(0)
             if h.pending:
@@ -761,8 +722,7 @@ class HipFrameBackend:
         self._side = concurrent_stream(self.dev, main, priority=-1)        # header / payload exchange: never behind the decode
         # the encode of batch k+1 depends on its frame only: on its own stream it runs beside batch k's upserts and
         # decode (its latency-bound kernels fill the decode's tail), as in NeuralMap.fuse_and_decode_async
-        import os
-        self.overlap_encode = os.environ.get("BNV_FP_ENCODE_STREAM", "1") != "0"
+        self.overlap_encode = True
         self._enc = concurrent_stream(self.dev, main, exclude=(self._side,))
         self._enc_src = None
 
@@ -965,12 +925,8 @@ class FrameParallelNeuralMap:
         # that becomes ready while one of them runs waits for its tail.  The exchange of batch k+1 is issued while
         # batch k's upserts run (small kernels, free CUs) and is needed a whole decode + encode later, and both MLP
         # kernels hand their tiles out dynamically, so workgroups displaced by the collective cost nothing but the
-        # collective's own CU time.  Leaving CUs free permanently instead (BNV_RESERVE_CUS=n, `reserve_cus`) costs
-        # 3-6 % of a batch on one GPU (tools/fp_single_rank.py --reserve 8) and is therefore off by default; the
-        # multi-GPU node is not available from here, so the knob stays.
-        if self.world > 1 and getattr(getattr(self.backend, "dev", None), "type", "cpu") == "cuda":
-            import os
-            _lib.load().bnv_set_option(b"reserve_cus", int(os.environ.get("BNV_RESERVE_CUS", "0")))
+        # collective's own CU time.  Leaving CUs free permanently instead (BNV_OPTIONS="reserve_cus=n") costs 3-6 % of a
+        # batch on one GPU (tools/fp_single_rank.py --reserve 8) and is therefore off by default.
         self._unsettled = []      # batches whose host bookkeeping has not been done yet (oldest first)
         self.max_unsettled = 3    # the host may run this many batches ahead of the GPU before it waits
 

@@ -71,6 +71,9 @@ class LocalNeRFModel(nn.Module):
         sd = {"nerf." + k: v for k, v in self.state_dict().items()}
         self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_mlp(sd)))
         self.sdf_bwd_pack.copy_(torch.from_numpy(weights.pack_sdf_mlp_bwd(sd)))
+        # sdf_pack is rewritten IN PLACE: whoever caches values computed from it (the frame pipe's persistent lattice
+        # tables) compares this counter, not the buffer's address
+        self.pack_version = getattr(self, "pack_version", 0) + 1
 
     @staticmethod
     def xyz_encoding(t):
@@ -111,6 +114,7 @@ class TcnnNeRFModel(nn.Module):
         p = self.model.params.detach().cpu().numpy()
         self.sdf_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn(p)))
         self.sdf_bwd_pack.copy_(torch.from_numpy(weights.pack_sdf_tcnn_bwd(p)))
+        self.pack_version = getattr(self, "pack_version", 0) + 1      # (as LocalNeRFModel.repack)
 
     xyz_encoding = staticmethod(LocalNeRFModel.xyz_encoding)
 

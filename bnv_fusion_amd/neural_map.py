@@ -120,8 +120,7 @@ class NeuralMap:
         # fuse_and_decode_async through the C frame pipeline (csrc/pipeline.hip: persistent slots, four streams -- front
         # end / encoder / upsert + decode tables / blend -- no per-frame tensor, event or pinned allocation); False:
         # the per-stage calls of rounds 1-3 on two streams.  Bit-identical results either way.
-        import os
-        self.frame_pipe = os.environ.get("BNV_NEURAL_MAP_PIPE", "1") != "0"
+        self.frame_pipe = True
         self.copy_results = True      # False: results are views into the pipeline's slots (valid for 2 more frames)
         self._pipe = None
         self._pipe_open = []

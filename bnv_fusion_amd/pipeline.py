@@ -11,9 +11,6 @@ A frame occupies a slot from ``begin`` to ``result``:
     ... all-gather of send[: (capacity + 1) * REC_WORDS] on the main stream ...
     pipe.finish(slot, blocks, capacity)   # main stream: install, lattice decode, read-backs
     words = pipe.result(slot)             # host wait; then pipe.outputs(slot, words)
-
-Sharded, early exchange (opt-in, BNV_EARLY_EXCHANGE=1; csrc/shard.hip): begin -> bound -> ``send = pipe.exchange_begin(slot, capacity)``
--> all-gather on ``pipe.exchange_stream()`` -> ``pipe.exchange_end(slot)`` -> upsert -> finish(slot, blocks, capacity).
 """
 import ctypes as C
 
@@ -30,20 +27,12 @@ W_COUNTERS, W_STATUS, W_EVALS, W_BOUNDS = 0, 8, 10, 16
 class FramePipe:
     # CUs the persistent point encoder leaves to the small kernels of the other streams in the four-stream schedule
     # (csrc/pipeline.hip): a share of 1 / 4 on a sharded volume, where a rank's encoder launch is small and the main
-    # stream's chain (upsert -> exchange -> install -> mark) runs beside it; all CUs otherwise.  BNV_PIPE_ENCODER_WGS
-    # overrides (0 = all CUs).
+    # stream's chain (upsert -> exchange -> install -> mark) runs beside it; all CUs otherwise.  The constructor's
+    # ``encoder_workgroups`` / BNV_PIPE_ENCODER_WGS override (0 = all CUs).
     ENCODER_SHARE_SHARDED = 0.75
-    # Five streams with CU-masked encoder and table streams (csrc/pipeline.hip): CUs of the table kernel, CUs of the
-    # encoder; the rest belongs to nobody (the chain's 1,024-thread kernels cannot share a CU with either MLP kernel).
-    # BNV_PIPE_CU_SPLIT="table,encoder" overrides; "0" = the four-stream schedule.
-    # Measured (profiles/r04_cu_mask_experiment.txt): the partition works, but a rank's frame gets SLOWER (0.29-0.33
-    # against 0.263 ms at world 8): with both MLP kernels resident all the time the chain's 1,024-thread kernels find
-    # too few CUs.  Opt-in therefore (cu_split=(160, 64), multiples of 32: an equal number of CUs per shader engine --
-    # other counts leave workgroups of the persistent kernels waiting for a CU and double their time).
-    CU_SPLIT_SHARDED = None
 
     def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None,
-                 streams=4, encoder_workgroups=None, cu_split=None, exchange_stream=True):
+                 streams=4, encoder_workgroups=None, persistent_tables=None):
         from .frontend import DEPTH_DTYPES
         self._dtypes = DEPTH_DTYPES
         self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
@@ -61,81 +50,24 @@ class FramePipe:
         from .streams import concurrent_stream
         import os
         self.main = torch.cuda.current_stream(dev)
-        self._masked = []                                     # CU-masked streams this pipe created (destroyed with it)
-        split = os.environ.get("BNV_PIPE_CU_SPLIT")
-        if split is not None:
-            split = tuple(int(x) for x in split.split(",")) if split not in ("", "0") else None
-        elif cu_split is not None:
-            split = tuple(cu_split) if cu_split else None
-        else:
-            split = self.CU_SPLIT_SHARDED if (self.world > 1 and int(os.environ.get("BNV_PIPE_STREAMS", streams)) >= 4
-                                              and _lib.model_mode(pointnet) != 2) else None
-        cus = int(lib.bnv_num_compute_units())
-        if split is not None and (len(split) != 2 or min(split) < 1 or sum(split) > cus):
-            raise ValueError(f"FramePipe: CU split {split} does not fit {cus} CUs")
-        self.cu_split = split
-        # hipExtStreamCreateWithCUMask makes BLOCKING streams: every operation on the legacy default stream (torch's
-        # default "current stream") waits for them and holds them back in turn (measured: 1.2 ms per frame instead of
-        # 0.27).  The pipe then runs on a main stream of its own; callers enter it through stream_context() (the
-        # sharded backend does), and nothing of a frame may touch the default stream.
-        # BNV_PIPE_MAIN_HIGH=1 (experiment): a HIGH-PRIORITY main stream of the pipe's own without CU masks -- the chain on it
-        # (upsert .. table) is a rank's critical path, the front end / encoder of later frames run ahead on the others
-        high = os.environ.get("BNV_PIPE_MAIN_HIGH", "0") == "1"
-        self.own_main = (split is not None or high) and self.main.cuda_stream == 0
-        if self.own_main:
-            # (high priority: the chain on it is the frame's critical path; front end and blend run ahead / behind)
-            self.main = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BNV_PIPE_MAIN_PRIORITY", -1)))
-        if split is not None:
-            # table kernel on CUs [0, t), encoder on [t, t + e) of the device's enumeration (which interleaves the
-            # XCDs: each set takes an equal share of every XCD)
-            self.table = self._masked_stream(range(0, split[0]), cus)
-            self.enc = self._masked_stream(range(split[0], split[0] + split[1]), cus)
-            encoder_workgroups = split[1]
-        else:
-            self.enc = concurrent_stream(dev, self.main)      # verified to overlap the main stream
-        # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four)
-        streams = int(os.environ.get("BNV_PIPE_STREAMS", streams))
+        self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
+        # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four);
+        # streams=2: round 3's two-stream schedule (kept for the A/B in tests and tools).  The schedules measured
+        # slower -- table MLP on a fifth stream from a feature snapshot, CU-masked streams, an early exchange of
+        # contribution records, a gated encoder, a high-priority main stream -- were removed in round 6; their records
+        # are profiles/r04_cu_mask_experiment.txt, r04_fifth_stream_experiment.txt and r05_experiments.txt [e8], [e9].
+        streams = int(streams)
         self.front = self.blend = None
-        if split is None:
-            self.table = None
-        if streams >= 4 or split is not None:
+        if streams >= 4:
             self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
             self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
-        # streams = 5 WITHOUT masks (BNV_PIPE_STREAMS=5, BNV_PIPE_CU_SPLIT=0): the table MLP on an ordinary stream of
-        # its own.  Correct but slower than four streams: with both MLP kernels in flight all the time and nothing
-        # reserving CUs, the chain's small kernels crawl (profiles/r04_fifth_stream_experiment.txt).
-        if streams >= 5 and split is None:
-            self.table = concurrent_stream(dev, self.main, exclude=(self.enc, self.front, self.blend))
         self.double_buffered = self.front is not None
-        # early exchange (csrc/shard.hip, csrc/pipeline.hip; OPT-IN: BNV_EARLY_EXCHANGE=1): a sharded frame's records
-        # carry its CONTRIBUTION to the boundary voxels and leave behind the encode; the all-gather runs on `xchg`, a
-        # stream of its own, while the main stream still decodes the frame before.  Bit-identical results; it takes the
-        # collective's latency off the main stream's chain.  Priced on one GPU it is SLOWER (0.37 against 0.31 ms per
-        # frame for a rank of 8, profiles/r05_experiments.txt [e8]): the table kernel excludes every other kernel, so
-        # each stream's work of a frame has to fit into the window between two table kernels, and the encode stream's
-        # (encoder + finalize + emit, ~120 us) is as long as the main stream's chain WITH the exchange in it -- shortening
-        # that chain only closes the window earlier.  Default therefore: records of the rows after the upsert,
-        # all-gather on the main stream.  BNV_EXCHANGE_STREAM=0 / exchange_stream=False: early records, but the
-        # all-gather on the main stream (in-process drivers that run several shards in lock step on one stream).
-        self.early_exchange = (self.world > 1 and self.table is None
-                               and os.environ.get("BNV_EARLY_EXCHANGE", "0") == "1")
-        self.xchg = None
-        if self.early_exchange and exchange_stream and os.environ.get("BNV_EXCHANGE_STREAM", "1") != "0":
-            others = tuple(x for x in (self.enc, self.front, self.blend) if x is not None)
-            self.xchg = concurrent_stream(dev, self.main, exclude=others)
-            if not self.xchg.bnv_concurrent and self.front is not None:
-                # four hardware queues by default (GPU_MAX_HW_QUEUES): a fifth stream shares one.  Then with the front
-                # stream, which runs a frame or two ahead of everything else
-                self.xchg = concurrent_stream(dev, self.main, exclude=tuple(x for x in others if x is not self.front))
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
             if encoder_workgroups is None:
                 cus = int(lib.bnv_num_compute_units())
                 encoder_workgroups = int(cus * self.ENCODER_SHARE_SHARDED) if (self.world > 1 and streams >= 4) else 0
         self.encoder_workgroups = int(encoder_workgroups)
-        # five streams: both MLP kernels are in flight all the time and their workgroup counts partition the CUs (the
-        # encoder's and the table kernel's share of a frame's MLP work, a few CUs left to the small kernels)
-        self.table_workgroups = split[0] if split is not None else int(os.environ.get("BNV_PIPE_TABLE_WGS", 0))
         res = v._n_xyz_host
         nvox = res[0] * res[1] * res[2]
         self.cap = max(min(8 * self.max_points // max(pointnet.min_pts_in_grid, 1) + 1, nvox), 1)
@@ -186,15 +118,7 @@ class FramePipe:
         if self.double_buffered:
             cfg.enc_ws2 = self._enc_ws2.data_ptr()
             cfg.front_stream, cfg.blend_stream = self.front.cuda_stream, self.blend.cuda_stream
-            if self.table is not None:
-                cfg.table_stream = self.table.cuda_stream
-                cfg.table_workgroups = self.table_workgroups
         cfg.encoder_workgroups = self.encoder_workgroups
-        cfg.early_exchange = int(self.early_exchange)
-        # BNV_PIPE_ENCODER_GATE=k (experiment; csrc/pipeline.hip): the encoder of a frame starts behind the table kernel of
-        # the k-th frame before it.  Measured with the early exchange (k = 2, 3): no better than ungated.
-        self.encoder_gate = int(os.environ.get("BNV_PIPE_ENCODER_GATE", 0))
-        cfg.encoder_gate = self.encoder_gate
         self._cfg = cfg
         h = C.c_void_p()
         _lib.check(lib.bnv_frame_pipe_create(C.byref(cfg), C.byref(h)), "bnv_frame_pipe_create")
@@ -209,57 +133,34 @@ class FramePipe:
         self._lws_generation = v._lws_generation
         # persistent lattice tables (include/bnv_fusion.h: bnv_volume_t.lattice_table): SDF table entries of rows a
         # frame did not update are carried over instead of re-evaluated (~5 % of a frame's entries in a steady scan).
-        # Not with the snapshot schedule (table stream); BNV_PERSISTENT_TABLES=0 switches it off.
-        self.persistent_tables = self.table is None and os.environ.get("BNV_PERSISTENT_TABLES", "1") != "0"
+        # ``persistent_tables=False`` / BNV_PERSISTENT_TABLES=0 switches it off (every entry recomputed each frame).
+        if persistent_tables is None:
+            persistent_tables = os.environ.get("BNV_PERSISTENT_TABLES", "1") != "0"
+        self.persistent_tables = bool(persistent_tables)
         if self.persistent_tables:
             if v._phave is not None:
                 v.invalidate_tables()      # tables another pipe (another model's networks, perhaps) left on this volume
             v.enable_persistent_tables()
-        self._tables_mode = None
+        # what the carried-over entries were computed with: (arithmetic mode, the SDF network's pack version)
+        self._tables_key = None
         self._slot_mode = [None] * self.n_slots
-        # with a table stream, three: a frame's upsert (which stamps into the workspace) then waits for the blend of
-        # the frame THREE back, not two -- with two the chain of frame t+2 could only start behind table(t) + blend(t)
-        # and the table stream idled for the rest of that chain
-        self.n_lattice_ws = int(os.environ.get("BNV_PIPE_LATTICE_WS", 3 if self.table is not None else 2))
+        self.n_lattice_ws = 2
         self._words = (C.c_int32 * HOST_WORDS)()
         self._keep = [None] * S
         self.inputs_resident = False
         torch.cuda.synchronize(dev)      # the zero-filled buffers above are complete before any other stream uses them
 
-    def stream_context(self):
-        """Context in which the caller drives the pipe (and everything between its phases): the pipe's own main stream
-        when it has one (CU-masked streams, see __init__), nothing otherwise."""
-        import contextlib
-        return torch.cuda.stream(self.main) if self.own_main else contextlib.nullcontext()
-
     @property
     def tsdf_stream(self):
         """The stream the TSDF side fusion of a frame runs on (a synchronous TSDF update on another stream must be
-        ordered before it): the blend stream with a table stream, the encode stream otherwise (csrc/pipeline.hip)."""
-        return self.blend if self.table is not None else self.enc
-
-    def _masked_stream(self, cu_ids, cus):
-        words = (cus + 31) // 32
-        mask = (C.c_uint32 * words)()
-        for i in cu_ids:
-            mask[i // 32] |= 1 << (i % 32)
-        out = C.c_void_p()
-        with torch.cuda.device(self.dev):
-            _lib.check(self._lib.bnv_stream_create_cu_mask(words, mask, C.byref(out)), "bnv_stream_create_cu_mask")
-        self._masked.append(out.value)
-        st = torch.cuda.ExternalStream(out.value, device=self.dev)
-        st.bnv_concurrent = True          # a queue of its own
-        return st
+        ordered before it): the encode stream (csrc/pipeline.hip)."""
+        return self.enc
 
     def close(self):
-        """Destroys the C object and the CU-masked streams (every frame must have been collected)."""
+        """Destroys the C object (every frame must have been collected)."""
         if getattr(self, "_h", None):
             self._lib.bnv_frame_pipe_destroy(self._h)
             self._h = None
-        for h in getattr(self, "_masked", []):
-            torch.cuda.synchronize(self.dev)
-            self._lib.bnv_stream_destroy(C.c_void_p(h))
-        self._masked = []
 
     def __del__(self):
         try:
@@ -350,25 +251,6 @@ class FramePipe:
         _lib.check(self._lib.bnv_frame_bound(self._h, slot, C.byref(m)), "bnv_frame_bound")
         return int(m.value)
 
-    def exchange_stream(self):
-        """The stream the caller's all-gather of an early exchange runs on (the main stream without one of its own)."""
-        return self.xchg if self.xchg is not None else torch.cuda.current_stream(self.dev)
-
-    def exchange_begin(self, slot, capacity):
-        """Early exchange: orders the exchange stream behind the slot's encode -> the slot's send block (header +
-        ``capacity`` records, int32 words) to all-gather ON THAT STREAM."""
-        if (capacity + 1) * REC_WORDS > self.send[slot].numel():
-            raise _lib.BnvError(f"exchange capacity {capacity} exceeds the slot's send block "
-                                f"({self.send[slot].numel() // REC_WORDS - 1} records)")
-        _lib.check(self._lib.bnv_frame_exchange_begin(self._h, slot, C.c_void_p(self.exchange_stream().cuda_stream)),
-                   "bnv_frame_exchange_begin")
-        return self.send[slot][: (capacity + 1) * REC_WORDS]
-
-    def exchange_end(self, slot):
-        """The slot's all-gather is enqueued on the exchange stream: finish() orders the main stream behind it."""
-        _lib.check(self._lib.bnv_frame_exchange_end(self._h, slot, C.c_void_p(self.exchange_stream().cuda_stream)),
-                   "bnv_frame_exchange_end")
-
     def upsert(self, slot, decode=True, ghost_rows=0):
         """Upsert of the slot's encoded voxels; ``ghost_rows``: rows the frame's install may create on top (the
         volume is grown for both BEFORE the upsert: the decode-origin stamps live in a workspace that growth
@@ -382,8 +264,7 @@ class FramePipe:
         self._decode[slot] = bool(decode)
         lws = None
         if decode:
-            lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0,
-                                                          snapshot=self.table is not None)
+            lws, self._epoch[slot] = v._lattice_workspace(self.cap, self._lws_next if self.double_buffered else 0)
             self._lws_next = (self._lws_next + 1) % self.n_lattice_ws
             if self._lws_generation != v._lws_generation:
                 # the volume has re-made its decode workspaces (it grew): the pointers the C object remembers are gone
@@ -393,7 +274,7 @@ class FramePipe:
         ws = v._workspace(self.cap)
         _lib.check(self._lib.bnv_frame_upsert(self._h, slot, C.byref(v._struct()), _lib.ptr(ws), ws.numel(),
                                               _lib.ptr(lws), self._epoch[slot]), "bnv_frame_upsert")
-        return None if (self.send is None or self.early_exchange) else self.send[slot]
+        return None if self.send is None else self.send[slot]
 
     def _vstruct(self):
         """The volume as the pipe's calls see it: with the persistent lattice tables switched on for them."""
@@ -407,12 +288,14 @@ class FramePipe:
         nerf = self.pointnet.nerf
         lws = self._lws[slot]
         d, keep = v._delta(self.sdf_delta)
-        if self.persistent_tables and lws is not None and (self._slot_mode[slot] != self._tables_mode or v._tables_dirty):
-            # table entries are carried across frames: entries computed in another arithmetic mode (or from features
-            # somebody wrote behind the library's back) must not be.  On the main stream, in front of this frame's marking
-            if self._tables_mode is not None or v._tables_dirty:
+        key = (self._slot_mode[slot], getattr(nerf, "pack_version", 0))
+        if self.persistent_tables and lws is not None and key != self._tables_key:
+            # table entries are carried across frames: entries computed in another arithmetic mode, or with other SDF
+            # weights (load_state_dict -> repack() rewrites nerf.sdf_pack in place on the same model object), must not
+            # be.  On the main stream, in front of this frame's marking
+            if self._tables_key is not None:
                 v.invalidate_tables()
-            self._tables_mode = self._slot_mode[slot]
+            self._tables_key = key
         _lib.check(self._lib.bnv_frame_finish(self._h, slot, C.byref(self._vstruct()), _lib.ptr(blocks), int(capacity),
                                               _lib.ptr(nerf.sdf_pack), C.byref(d), _lib.ptr(lws),
                                               lws.numel() if lws is not None else 0, self._epoch[slot]),

@@ -88,11 +88,11 @@ class SparseVolume:
         self._epoch = 0
         self._lws_generation = 0      # counts re-makes of the decode workspaces (the frame pipeline forgets old pointers)
         # persistent lattice tables of the frame pipeline (include/bnv_fusion.h: bnv_volume_t.lattice_table): made on
-        # demand (enable_persistent_tables), re-made zeroed with the row arrays; _tables_dirty: features may have been
-        # written behind the library's back (through the tensors of to_tensor()), the next pipelined frame starts afresh
+        # demand (enable_persistent_tables), re-made zeroed with the row arrays.  Every method of this class that writes
+        # features clears the rows' have-words on the device; what the entries ALSO depend on -- the SDF network's
+        # weights and arithmetic mode -- is watched by the frame pipe (FramePipe.finish: mode, model, pack version)
         self._ptable = None
         self._phave = None
-        self._tables_dirty = False
         self.reset(capacity)
         self.avg_n_pts = 0
         self.n_pts_list = []
@@ -263,7 +263,6 @@ class SparseVolume:
     def _make_persistent_tables(self):
         self._ptable = torch.empty(self._row_capacity * 27, dtype=torch.float32, device=self._dev)
         self._phave = torch.zeros(self._row_capacity, dtype=torch.int32, device=self._dev)
-        self._tables_dirty = False
 
     def enable_persistent_tables(self):
         """The frame pipeline's persistent lattice tables (112 bytes per row of capacity): SDF table entries of rows a
@@ -272,11 +271,12 @@ class SparseVolume:
             self._make_persistent_tables()
 
     def invalidate_tables(self):
-        """Call after writing ``features`` by any means other than this class's methods (an optimiser stepping the
-        Parameter made from ``to_tensor()``'s tensor): the persistent table entries are those of the old features."""
+        """Forgets every persistent table entry (on the current stream).  Needed after writing the volume's feature
+        ROWS by any means other than this class's methods -- ``to_tensor()`` returns a copy, and the optimiser's way back
+        (``insert``) clears the rows' words itself -- and after changing the SDF network the entries were computed with
+        (the frame pipe does that itself: it watches the model object, its arithmetic mode and its pack version)."""
         if self._phave is not None:
             self._phave.zero_()
-        self._tables_dirty = False
 
     def _workspace(self, n):
         need = int(self._lib.bnv_volume_workspace_bytes(int(n)))
@@ -530,15 +530,13 @@ class SparseVolume:
                    "bnv_decode_lattice")
         return out
 
-    def _lattice_workspace(self, n, which=0, snapshot=False):
+    def _lattice_workspace(self, n, which=0):
         """(workspace of the lattice decode for up to n voxels, a fresh epoch).  Re-made (zero-filled) when the volume
         grows: its front part is indexed by row.  ``which`` = 1: a second workspace -- the frame pipeline alternates
-        two, so that a frame's blend (on a stream of its own) and the next frame's marking never share one.
-        ``snapshot``: with room for the feature snapshot of the five-stream pipeline (32 bytes per row at the end)."""
-        size = self._lib.bnv_decode_lattice_snapshot_workspace_bytes if snapshot else self._lib.bnv_decode_lattice_workspace_bytes
-        need = int(size(int(n), self._row_capacity))
+        two, so that a frame's blend (on a stream of its own) and the next frame's marking never share one."""
+        need = int(self._lib.bnv_decode_lattice_workspace_bytes(int(n), self._row_capacity))
         if which:
-            # (which = 1, 2, ..: further workspaces; the five-stream pipeline rotates three)
+            # (which = 1, 2, ..: further workspaces)
             if self._lattice_ws2 is None:
                 self._lattice_ws2 = {}
             ws = self._lattice_ws2.get(which)

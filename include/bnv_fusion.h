@@ -130,12 +130,17 @@ typedef struct bnv_volume {
    * of this library that writes a row's features clears the row's word (the upserts, the ghost-row install, insert);
    * the per-frame decode then evaluates only the entries a frame reads that are not there yet -- entries in rows the
    * frame did not update are carried over from earlier frames -- and the blend reads lattice_table.  A caller that
-   * changes features by any other means (the optimiser writes through the tensor of to_tensor()) zeroes lattice_have.
+   * changes features by any other means zeroes lattice_have (the optimiser does not: it steps a COPY, to_tensor(), and
+   * writes it back through insert, which clears the words); so does a caller that changes the SDF network's weights
+   * (the entries are functions of both: SparseVolume.invalidate_tables, which the frame pipe calls when the model's
+   * pack version moves).
    * bnv_volume_clear / bnv_volume_rehash leave both alone: the owner re-makes them with the row arrays. */
   float* lattice_table;
   uint32_t* lattice_have;
   /* 1: THIS call's lattice decode reads and extends the persistent tables (the frame pipeline sets it for its own
-   * calls); 0: the call keeps to its workspace (every other decode: its features argument need not be the volume's). */
+   * calls): its `features` argument must then be the volume's own array and the table stage must work on listed
+   * entries -- anything else is rejected with BNV_ERR_INVALID_ARGUMENT (the three stages share ONE predicate);
+   * 0: the call keeps to its workspace (every other decode: its features argument need not be the volume's). */
   int32_t lattice_persist;
 } bnv_volume_t;
 
@@ -209,13 +214,6 @@ int bnv_probe_mfma_rate(int shape, int operands, int iters, void* stream, double
  * strictly in submission order; one spin on each of two streams, timed with events, tells whether they overlap.  The
  * frame pipeline picks its encode stream that way (bnv_fusion_amd/streams.py). */
 int bnv_probe_spin(int n_blocks, int64_t cycles, void* stream);
-/* A HIP stream whose kernels run only on the compute units named in `cu_mask` (bit i of word i / 32 = CU i of the
- * device's enumeration, which interleaves the XCDs: a run of low bits takes an equal share of every XCD), and its
- * release.  `n_words` x 32 must cover the device's CUs and at least one CU must be named.  The sharded frame pipeline
- * gives each of its two persistent MLP kernels a stream with a disjoint mask, so that neither can take the CUs the other
- * (or the small kernels between them) needs; the streams are the caller's, like every stream of this interface. */
-int bnv_stream_create_cu_mask(int n_words, const uint32_t* cu_mask, void** stream_out);
-int bnv_stream_destroy(void* stream);
 
 /* ---- front end: depth image -> input_pts (FusionInferenceAbstractDataset.__getitem__,
  * src/datasets/fusion_inference_dataset.py:40-90; geometry.py:150-171; kornia depth_to_normals) --------
@@ -284,21 +282,6 @@ int bnv_shard_install(const bnv_volume_t* vol, const bnv_grid_t* grid, const voi
  * back to 0: the block is then ready for the records bnv_volume_integrate_frame appends for the next frame. */
 int bnv_shard_install_reset(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world,
                             int64_t capacity, void* own_send_block, bnv_stream_t stream);
-
-/* EARLY EXCHANGE (round 5; opt-in: config.early_exchange).  The records above carry a row's values AFTER the
- * frame's upsert, so the all-gather sits in the middle of the main stream's chain.  These carry the frame's
- * CONTRIBUTION to the voxel instead -- {x, y, z; the frame's weight min(count / 32, 1); the frame's mean feature[8]},
- * i.e. the encode's outputs -- and the receiver applies the running average of SparseVolume._integrate
- * (sparse_volume.py:647-673) to its ghost row with the owner's arithmetic: the ghost row equals the owner's row bit for
- * bit after every frame (every record of a voxel reaches the same ranks: the owners of the blocks around it are fixed
- * before its first emission), and the exchange needs nothing but the ENCODED frame.
- *   bnv_shard_emit   coords / feats / pcounts [n] = the encode's outputs for this rank's voxels (n_dev: device count or
- *                    NULL); writes the header (count, sender = grid.shard_rank) and the boundary voxels' records;
- *   bnv_shard_apply  blocks as for bnv_shard_install; the own block is skipped; ghost rows are created on demand. */
-int bnv_shard_emit(const bnv_grid_t* grid, const int64_t* coords, const float* feats, const int64_t* pcounts, int64_t n,
-                   const int32_t* n_dev, void* block, int64_t capacity, bnv_stream_t stream);
-int bnv_shard_apply(const bnv_volume_t* vol, const bnv_grid_t* grid, const void* blocks, int world, int64_t capacity,
-                    bnv_stream_t stream);
 
 /* ---- encode: LitFusionPointNet.encode_pointcloud (local_point_fusion.py:81-165) ------------ */
 
@@ -574,22 +557,6 @@ int bnv_decode_lattice_stamped_tables(const bnv_volume_t* vol_host, const bnv_gr
                                       const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
                                       bnv_stream_t stream);
 
-/* The same in two halves that may run on different streams: `_mark` = neighbour rows + live entries on `stream`, which
- * also copies the feature row of every row that gets a table entry into the workspace (`ws` of
- * bnv_decode_lattice_snapshot_workspace_bytes: the plain workspace + 32 bytes per row at its end); `_snapshot_table` =
- * the table MLP reading that snapshot instead of the volume.  Behind `_mark` the volume's rows are free to change (the next
- * frame's upsert) while the table kernel runs elsewhere -- results are those of the state `_mark` saw.  The caller
- * orders `_snapshot_table` behind `_mark` (an event) and bnv_lattice_blend behind the table. */
-size_t bnv_decode_lattice_snapshot_workspace_bytes(int64_t n_voxels, int64_t row_capacity);
-int bnv_decode_lattice_stamped_mark(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
-                                    const float* weights, int64_t row_limit, const int64_t* origins, int64_t n,
-                                    const int32_t* n_dev, void* ws, size_t ws_bytes, int32_t epoch,
-                                    bnv_stream_t stream);
-/* max_workgroups: the persistent table kernel is launched on at most this many workgroups (one per CU; 0 = all) */
-int bnv_decode_lattice_snapshot_table(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host,
-                                      const float* sdfmlp_pack, int64_t n, void* ws, size_t ws_bytes,
-                                      int max_workgroups, bnv_stream_t stream);
-
 /* The three stages of bnv_decode_lattice, callable separately so that a sharded volume can exchange
  * corner-voxel tables between them (bnv_fusion_amd/distributed.py).  They share one workspace:
  *   neighbors: row of each of the 27 neighbour voxels of every origin (-1: absent or weight below
@@ -662,11 +629,6 @@ int bnv_decode_dense_mode(const float* feat_grid, const float* pts_weight, const
  *                                     (main_stream if none): blend into the slot's sdf, read-backs into the slot's
  *                                     pinned words
  *   bnv_frame_result                  HOST wait for the frame; copies the slot's pinned words out; frees the slot
- * With config.early_exchange (sharded; bnv_shard_emit / bnv_shard_apply) the order is begin -> bound ->
- * bnv_frame_exchange_begin(stream X) -> [the caller's all-gather on X] -> bnv_frame_exchange_end(X) -> upsert -> finish:
- * begin appends the frame's contribution records to the slot's send block behind the encode, the all-gather runs on X
- * while main_stream still decodes the frame before, and finish applies the received records to the ghost rows behind
- * the upsert -- no collective on main_stream's chain.
  * The volume and its workspaces are passed per call (they are re-made when the volume grows).  The object owns HIP
  * events only; every buffer is the caller's and must outlive it. */
 #define BNV_PIPE_MAX_SLOTS 8
@@ -729,29 +691,6 @@ typedef struct bnv_frame_pipe_config {
   void* enc_ws2;
   bnv_stream_t front_stream, blend_stream;
   int32_t encoder_workgroups;
-  /*   table_stream  (with blend_stream) the table MLP of the decode runs here, reading a snapshot of the feature rows
-   *                 the marking kernel took (bnv_decode_lattice_stamped_mark / _snapshot_table; the decode workspaces
-   *                 passed to upsert / finish must then be bnv_decode_lattice_snapshot_workspace_bytes long):
-   *                 main_stream goes on to the next frame's upsert .. marking chain while the table kernel of this
-   *                 frame runs.  In this mode encode_stream carries NOTHING but the persistent point-encoder kernel --
-   *                 finalize runs at the head of the frame's chain on main_stream, the TSDF side fusion on
-   *                 blend_stream -- so that encode_stream and table_stream can be CU-masked streams
-   *                 (bnv_stream_create_cu_mask) with disjoint masks of encoder_workgroups / table_workgroups CUs: each
-   *                 MLP kernel owns its CUs, the rest (and whatever fits beside them) serves the small kernels.  A
-   *                 frame's upsert must be enqueued before the frame after the next one begins. */
-  bnv_stream_t table_stream;
-  /*   table_workgroups  with table_stream: workgroups of the persistent table kernel (0 = all CUs).  The two MLP kernels
-   *                 each fill a CU's LDS; with both in flight all the time (table of frame t beside the encoder of
-   *                 frame t+2) their workgroup counts PARTITION the CUs -- encoder_workgroups + table_workgroups should
-   *                 stay below the CU count so that the small kernels of the other streams always find a free CU. */
-  int32_t table_workgroups;
-  /*   early_exchange  (sharded, not with table_stream) the exchange carries the frames' contributions and runs off
-   *                 main_stream: see bnv_frame_exchange_begin. */
-  int32_t early_exchange;
-  /*   encoder_gate  k > 0 (with blend_stream): the point encoder of a frame starts when the table kernel of the k-th
-   *                 frame before it is through (if that frame's finish has been enqueued by then), so that the two
-   *                 LDS-filling MLP kernels take turns instead of sharing the CUs; 0: no gate. */
-  int32_t encoder_gate;
 } bnv_frame_pipe_config_t;
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;
@@ -767,7 +706,7 @@ int bnv_frame_pipe_destroy(bnv_frame_pipe_t* pipe);
 int bnv_frame_pipe_set_mlp_mode(bnv_frame_pipe_t* pipe, int32_t grid_mlp_mode);
 /* depth as bnv_encode_begin_depth (dtype 0 = uint16 mm, 1 = float32 m); color_im: folded colour image or NULL.  The
  * device buffers of a frame (depth, color_im, input_pts) are read by kernels enqueued up to the frame's bnv_frame_upsert
- * (the TSDF side fusion, finalize with a table_stream): they must stay valid until the frame's result is in. */
+ * (the TSDF side fusion): they must stay valid until the frame's result is in. */
 int bnv_frame_begin_depth(bnv_frame_pipe_t* pipe, int slot, const void* depth, int depth_dtype, int H, int W,
                           const double* intr_host, const double* T_wc_host, const float* color_im);
 int bnv_frame_begin_points(bnv_frame_pipe_t* pipe, int slot, const float* input_pts, int64_t n_points);
@@ -789,11 +728,6 @@ int bnv_frame_pipe_forget_workspaces(bnv_frame_pipe_t* pipe);
 int bnv_frame_upsert(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, void* vol_ws, size_t vol_ws_bytes,
                      void* lattice_ws, int32_t lattice_epoch);
 int bnv_frame_bound(bnv_frame_pipe_t* pipe, int slot, int32_t* max_bound_host);
-/* Early exchange: `stream` waits for the slot's encode (the send block then holds the frame's records: exchange its
- * first 1 + capacity records on `stream`) / the exchange enqueued on `stream` is what bnv_frame_finish of the slot
- * orders main_stream behind.  `stream` may be main_stream.  BNV_ERR_INVALID_ARGUMENT without config.early_exchange. */
-int bnv_frame_exchange_begin(bnv_frame_pipe_t* pipe, int slot, bnv_stream_t stream);
-int bnv_frame_exchange_end(bnv_frame_pipe_t* pipe, int slot, bnv_stream_t stream);
 int bnv_frame_finish(bnv_frame_pipe_t* pipe, int slot, const bnv_volume_t* vol_host, const void* blocks,
                      int64_t block_capacity, const float* sdfmlp_pack, const bnv_sdf_delta_t* delta_host,
                      void* lattice_ws, size_t lattice_ws_bytes, int32_t lattice_epoch);

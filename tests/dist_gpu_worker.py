@@ -69,8 +69,7 @@ def main():
         table, loads = nm.backend.owner_table()
         meta = {"host_waits": nm.host_waits, "exchanged_bytes": nm.exchanged_bytes, "rows": nm.volume.num_rows(),
                 "tsdf": nm.backend.tsdf_vol.tsdf.cpu(), "ownership": nm.backend.ownership, "owner_table": table,
-                "owner_loads": loads, "mlp_evals": evals, "block_log2": nm.backend.block_log2, "axis": nm.backend.axis,
-                "early_exchange": nm.backend.early_exchange}
+                "owner_loads": loads, "mlp_evals": evals, "block_log2": nm.backend.block_log2, "axis": nm.backend.axis}
     else:
         nm = FrameParallelNeuralMap(np.array([dims] * 3), voxel, model, device="cuda:0", tsdf=True)
         batches = [frames[b0: b0 + world] for b0 in range(0, len(frames), world)]

@@ -19,12 +19,8 @@ class OracleShardBackend:
     """The shard protocol of bnv_fusion_amd.distributed.ShardedNeuralMap on the CPU oracle: same phases, same record
     layout (12 int32 words: x, y, z, weight bits, 8 feature bits; block = header record + capacity records)."""
 
-    def __init__(self, dims, voxel, rank, world, ownership="hash", early=False):
+    def __init__(self, dims, voxel, rank, world, ownership="hash"):
         from oracle import bnv_oracle as orc
-        # early exchange (csrc/shard.hip: k_shard_emit / k_shard_apply): the records carry the frame's CONTRIBUTION to a
-        # boundary voxel (its weight and mean feature), exchanged before the upsert, and the receiver applies the
-        # running average to its ghost row
-        self.early_exchange = early
         from bnv_fusion_amd import distributed as D
         self.orc, self.D = orc, D
         self.sd = orc.load_weights(WEIGHTS_FP32)
@@ -54,29 +50,12 @@ class OracleShardBackend:
         o.integrate(v, g[own], f[own], c[own])
         return D.ShardFrame(grid_ids=g[own], counts=counts, n_avg=n, feats=f[own], pcounts=c[own])
 
-    def emit(self, fr, capacity):
-        """Early exchange: this rank's contribution records of the frame (what the encode produced, nothing of the
-        volume)."""
-        D = self.D
-        g = fr.grid_ids.numpy()
-        bnd = self.rule.is_boundary(g) if len(g) else np.zeros(0, dtype=bool)
-        assert int(bnd.sum()) <= fr.counts[self.rank] <= capacity
-        block = torch.zeros((capacity + 1, D.REC_WORDS), dtype=torch.int32)
-        block[0, 0], block[0, 1] = int(bnd.sum()), self.rank
-        if bnd.any():
-            m = torch.from_numpy(bnd)
-            w = torch.clip(fr.pcounts[m] / 32, max=1).float().reshape(-1)       # local_point_fusion.py:660
-            block[1: 1 + int(bnd.sum()), :3] = fr.grid_ids[m].int()
-            block[1: 1 + int(bnd.sum()), 3] = w.contiguous().view(torch.int32)
-            block[1: 1 + int(bnd.sum()), 4:] = fr.feats[m].float().contiguous().view(torch.int32)
-        return block.reshape(-1)
-
     def bound(self, fr):
         return int(fr.counts.max()) if self.world > 1 else 0
 
     def upsert(self, fr, capacity, decode=True):
         """(the oracle backend has already upserted in encode: this is the pack half)"""
-        if capacity == 0 or self.early_exchange:
+        if capacity == 0:
             return None
         D, v = self.D, self.vol
         g = fr.grid_ids.numpy()
@@ -106,13 +85,7 @@ class OracleShardBackend:
                 k = keys[mine]
                 f_rec = rec[mine, 4:].contiguous().view(torch.float32)
                 w_rec = rec[mine, 3:4].contiguous().view(torch.float32)
-                if self.early_exchange:
-                    # the owner's running average (oracle integrate, local_point_fusion.py:649-650) on the ghost row
-                    old_f, old_w, hits = v.query(k)
-                    new_w = old_w + w_rec
-                    v.insert(k, (old_f * old_w + f_rec * w_rec) / new_w, new_w, hits)
-                else:
-                    v.insert(k, f_rec, w_rec, torch.zeros(len(k), 1))
+                v.insert(k, f_rec, w_rec, torch.zeros(len(k), 1))
                 self.installed += len(k)
         return 0
 
@@ -140,13 +113,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, frames, dims, voxel, ret, ownership="hash", early=False):
+def _worker(rank, world, port, frames, dims, voxel, ret, ownership="hash"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bnv_fusion_amd.distributed import ShardedNeuralMap, all_gather_var
-    nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world, ownership, early))
+    nm = ShardedNeuralMap(dims, voxel, None, backend=OracleShardBackend(dims, voxel, rank, world, ownership))
     # an empty frame first (no point inside the volume): bound 0 on every rank -> no collective, (empty, empty) out
     far = torch.from_numpy(frames[0]).clone()
     far[..., :3] += 50.0
@@ -167,17 +140,16 @@ def _worker(rank, world, port, frames, dims, voxel, ret, ownership="hash", early
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ownership", ["hash", "region", "first_touch", "region+early", "first_touch+early"])
+@pytest.mark.parametrize("ownership", ["hash", "region", "first_touch"])
 def test_two_shards_equal_single_process(ownership):
     from oracle import bnv_oracle as orc
     from bnv_fusion_amd.distributed import OwnershipModel, touched_voxels, unflatten, voxel_owner
     z = np.load(os.path.join(GOLDEN, "sequence_64.npz"))
     frames = list(z["frames"])      # 12 frames x 6000 points: weights reach min_pts
     dims, voxel = z["dims"], float(z["voxel_size"])
-    ownership, _, early = ownership.partition("+")      # "+early": contribution records, applied as running averages
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, _free_port(), frames, dims, voxel, ret, ownership, bool(early)), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), frames, dims, voxel, ret, ownership), nprocs=2, join=True)
         coords, sdf, n0 = ret["coords"], ret["sdf"], ret["n0"]
         tables = [ret["table0"], ret["table1"]]
         rows = [ret["rows0"], ret["rows1"]]
@@ -188,8 +160,7 @@ def test_two_shards_equal_single_process(ownership):
         f, c, _, g, _ = orc.encode_pointcloud(sd, torch.from_numpy(fr), vol.n_xyz, vol.min_coords, vol.max_coords, voxel)
         orc.integrate(vol, g, f, c)
     ref = vol.decode_pts(orc.lattice_coords(g.numpy()), sd, None, is_coords=True, query_tensor=False)[0, :, :, 0]
-    # every row a rank holds -- its own and its ghost rows -- carries the single volume's values, bit for bit (with the
-    # early exchange the ghost rows are running averages the receiver formed itself from the owners' contributions)
+    # every row a rank holds -- its own and its ghost rows -- carries the single volume's values, bit for bit
     for keys, feats, weights in rows:
         f1, w1, _ = vol.query(torch.from_numpy(keys))
         assert np.array_equal(f1.numpy(), feats) and np.array_equal(w1.numpy(), weights) and len(keys) > 0

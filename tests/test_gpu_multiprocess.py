@@ -146,30 +146,6 @@ def test_spatial_sharding_with_frames_announced_ahead(tmp_path, single_512):
     assert all(r["meta"]["host_waits"] == len(ref) for r in ranks)
 
 
-@pytest.mark.parametrize("world,extra", [(4, ()), (3, ("--ahead",))])
-def test_spatial_sharding_early_exchange(tmp_path, single_512, world, extra):
-    """BNV_EARLY_EXCHANGE=1 (csrc/shard.hip): the frame's records carry its contributions to the boundary voxels, the
-    all-gather runs on a stream of its own before the upsert, the receivers apply running averages to their ghost rows
-    -- as real processes (with and without frames announced ahead), bit-identical to the single GPU, one host wait
-    and the same bytes per frame."""
-    ref, rows, tsdf, voxel = single_512
-    ranks = _launch(world, "spatial", 512, len(ref), tmp_path, (480, 640), extra=list(extra),
-                    env_extra={"BNV_EARLY_EXCHANGE": "1"})
-    assert all(r["meta"].get("early_exchange") for r in ranks)
-    for t, (rc, rs) in enumerate(ref):
-        coords = torch.cat([r["out"][t][0] for r in ranks])
-        sdf = torch.cat([r["out"][t][1] for r in ranks])
-        order = torch.argsort((coords[:, 0] * 512 + coords[:, 1]) * 512 + coords[:, 2])
-        assert torch.equal(coords[order], rc) and torch.equal(sdf[order], rs), t
-    for r in ranks:
-        m = r["meta"]
-        assert m["host_waits"] == len(ref)
-        # (--ahead: the frame announced behind the last one is abandoned, but its TSDF side fusion was enqueued by begin)
-        assert extra or torch.equal(m["tsdf"], tsdf)
-        assert rows / world < m["rows"] < rows
-        assert m["exchanged_bytes"] / len(ref) < 48 * 1.6 * len(ref[-1][0])
-
-
 def test_spatial_sharding_eight_processes_512_full_frames(tmp_path, single_512):
     """BASELINE config 3's shape: 512^3 grid, 640x480 frames, the active-voxel set sharded over EIGHT processes (they
     share this box's GPU over gloo; the 8-GPU RCCL run is the driver's), one all-gather of boundary records and one

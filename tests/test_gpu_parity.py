@@ -470,20 +470,14 @@ def test_full_size_fuse_decode_properties(big, orc, sd):
                                                      (2, "region", False), (3, "region", True), (5, "region", True),
                                                      (3, "region", "scatter"), (2, "region:x4", False),
                                                      (4, "region:z", True), (3, "first_touch:4", False),
-                                                     (3, "first_touch", "odd"), (3, "region", "odd"),
-                                                     (3, "region+early", True), (4, "first_touch+early", False),
-                                                     (2, "hash+early", False), (3, "region+early", "odd"),
-                                                     (5, "region+early", True)])
-def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing, monkeypatch):
+                                                     (3, "first_touch", "odd"), (3, "region", "odd")])
+def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing):
     """``world`` shards of the spatially sharded volume driven phase by phase in ONE process (the all-gather is a
     torch.stack): encode with ownership, upsert, pack boundary records, install ghost rows, decode -- the union of
     the shards' outputs is bit-identical to the single volume; bounds hold; device predicates == host restatements.
     All ownership rules (block hash; first-touch tables, include/bnv_fusion.h: bnv_grid_t.shard_state -- the fine
     interleave of round 4 and the contiguous regions of round 5, "rule:x4" = bands stacked along x and 16^3 blocks); the
     device's owner table equals the host restatement (distributed.OwnershipModel) fed the same frames; ``growing``:
-    "+early" = the early exchange (BNV_EARLY_EXCHANGE=1; csrc/shard.hip: the records carry the frame's contributions,
-    leave behind the encode and are applied to the ghost rows as running averages -- the ghost rows still equal the
-    owners' rows bit for bit) instead of the default one (rows after the upsert, installed by overwriting);
     the surface patch drifts through the volume, so that frames keep touching blocks for the first time -- among
     them blocks that had been pinned earlier as neighbours of touched ones; ``"scatter"``: a 252^3 grid and thousands of
     small point clusters all over it, so that the FIRST frame brings more new blocks (> 4,096) than the kernels' short
@@ -497,13 +491,11 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing, m
         dims = np.array([250 * voxel] * 3)
     if odd:
         dims = np.array([46 * voxel] * 3)          # 48^3 voxels = 6^3 = 216 blocks
-    ownership, _, early_opt = ownership.partition("+")
-    monkeypatch.setenv("BNV_EARLY_EXCHANGE", "1" if early_opt else "0")
     ownership, _, opt = ownership.partition(":")
     axis = {"x": 0, "y": 1, "z": 2}.get(opt[:1], None)
     blog = int(opt.lstrip("xyz")) if opt.lstrip("xyz") else 3
     shards = [D.HipShardBackend(dims, voxel, model, r, world, capacity=(1 << 17) if scatter else 4096, device=DEV,
-                                ownership=ownership, block_log2=blog, axis=axis, exchange_stream=False)
+                                ownership=ownership, block_log2=blog, axis=axis)
               for r in range(world)]       # (one process, one stream: the exchange is a torch.stack on it)
     n_xyz = shards[0].volume._n_xyz_host
     host_rule = D.OwnershipModel(ownership, world, n_xyz, blog, axis=shards[0].axis)
@@ -567,25 +559,17 @@ def test_hip_shards_equal_single_volume(bnv, model, world, ownership, growing, m
         counts = [b.pipe.host[f.slot, W_BOUNDS: W_BOUNDS + world].clone() for b, f in zip(shards, frs)]
         assert all(torch.equal(c, counts[0]) for c in counts)
         cap = -(-bounds[0] // D.REC_QUANTUM) * D.REC_QUANTUM
-        early = shards[0].early_exchange
-        assert early == bool(early_opt)
-        if early:
-            # the encode has appended the contribution records of the frame's boundary voxels to the slot's send block
-            blocks = torch.stack([b.emit(f, cap) for b, f in zip(shards, frs)])
-        else:
-            # the upsert launch appends the boundary records of the voxels it has just updated to the slot's send block
-            blocks = torch.stack([b.upsert(f, cap) for b, f in zip(shards, frs)])
+        # the upsert launch appends the boundary records of the voxels it has just updated to the slot's send block
+        blocks = torch.stack([b.upsert(f, cap) for b, f in zip(shards, frs)])
         hdr = blocks.view(world, cap + 1, D.REC_WORDS)[:, 0, :3].cpu()
         for r in range(world):
             assert int(hdr[r, 1]) == r and int(hdr[r, 2]) == 0 and int(hdr[r, 0]) <= int(counts[0][r])
         outs = []
         for b, f in zip(shards, frs):
             res = b.install(f, blocks.view(-1), cap)
-            if early:
-                assert b.upsert(f, cap) is None
             outs.append(b.result(b.finish(f, b.decode(f), res)))
         for b, f in zip(shards, frs):      # the install has reset the send block for the slot's next frame
-            assert early or (int(b.pipe.send[f.slot, 0]) == 0 and int(b.pipe.send[f.slot, 1]) == b.rank)
+            assert int(b.pipe.send[f.slot, 0]) == 0 and int(b.pipe.send[f.slot, 1]) == b.rank
         if scatter and fr is frames_np[0]:
             t0_, _ = shards[0].owner_table()
             assert int(((t0_ & 0x80) != 0).sum()) > 4096        # more new blocks in one frame than the short list holds

@@ -51,15 +51,14 @@ def _run_pipe(pipe, frames, depth_in_flight, decode=True):
     return outs
 
 
-@pytest.mark.parametrize("cu_split", [None, (160, 64)])
+@pytest.mark.parametrize("streams", [4, 2])
 @pytest.mark.parametrize("in_flight", [1, 3])
 @pytest.mark.parametrize("kind", ["depth", "points"])
-def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, cu_split):
+def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, streams):
     """One GPU: the pipe's outputs, volume and TSDF volume equal NeuralMap.fuse_and_decode's, frame by frame, with
     one or several frames in flight (slots reused: 14 frames through 4 slots), from depth images (front end fused,
-    TSDF side fusion) and from input_pts; an empty frame in the middle.  ``cu_split``: the five-stream schedule on
-    CU-masked streams (table MLP from a feature snapshot on 160 CUs, encoder on 64, finalize on the main stream, TSDF
-    on the blend stream, three decode workspaces, the pipe on a main stream of its own)."""
+    TSDF side fusion) and from input_pts; an empty frame in the middle.  ``streams``: the four-stream schedule (front
+    end / encoder / main chain / blend) and round 3's two-stream one (encode / main)."""
     from bnv_fusion_amd import synthetic
     from bnv_fusion_amd.frontend import depth_to_input_pts
     from bnv_fusion_amd.pipeline import FramePipe
@@ -85,11 +84,9 @@ def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, cu_split):
     if tsdf:
         mn, mx, _ = get_world_range(dims3, 0.025)
         tv = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=DEV)
-    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv, cu_split=cu_split)
-    assert pipe.cu_split == cu_split and (pipe.table is not None) == (cu_split is not None)
-    assert pipe.own_main == (cu_split is not None)      # the tests run on the legacy default stream
-    with pipe.stream_context():
-        got = _run_pipe(pipe, frames, in_flight)
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv, streams=streams)
+    assert pipe.double_buffered == (streams == 4)
+    got = _run_pipe(pipe, frames, in_flight)
     torch.cuda.synchronize()
     for t, ((rc, rs), (gc, gs)) in enumerate(zip(ref, got)):
         if rc is None:
@@ -330,54 +327,6 @@ def test_frame_timeline_is_ordered_and_changes_nothing(bnv):
         assert torch.equal(c0, c1) and torch.equal(s0, s1)
 
 
-def test_cu_masked_streams_partition_the_gpu():
-    """bnv_stream_create_cu_mask: a stream masked to a quarter of the CUs serves 16 single-wave spin workgroups per CU
-    of the DEVICE in about twice the time the whole device needs (a CU holds 32 waves), two streams with disjoint masks
-    run side by side, bad arguments are refused."""
-    import ctypes as C
-    from bnv_fusion_amd import _lib
-    lib = _lib.require_device(0)
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    words = (cus + 31) // 32
-
-    def masked(bits):
-        m = (C.c_uint32 * words)()
-        for b in bits:
-            m[b // 32] |= 1 << (b % 32)
-        out = C.c_void_p()
-        _lib.check(lib.bnv_stream_create_cu_mask(words, m, C.byref(out)), "bnv_stream_create_cu_mask")
-        return out.value, torch.cuda.ExternalStream(out.value, device=torch.device(DEV))
-
-    def timed(streams, blocks):
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
-        torch.cuda.synchronize()
-        for (a, b), st, n in zip(ev, streams, blocks):
-            a.record(st)
-            _lib.check(lib.bnv_probe_spin(n, 100_000, C.c_void_p(st.cuda_stream)), "bnv_probe_spin")
-            b.record(st)
-        torch.cuda.synchronize()
-        return max(ev[0][0].elapsed_time(b) for _, b in ev)
-
-    plain = torch.cuda.Stream(device=DEV)
-    hq, quarter = masked(range(cus // 4))
-    hr, rest = masked(range(cus // 4, cus))
-    for st in (plain, quarter, rest):
-        timed([st], [16 * cus])
-    whole = min(timed([plain], [16 * cus]) for _ in range(3))
-    part = min(timed([quarter], [16 * cus]) for _ in range(3))
-    assert 1.5 * whole < part < 3.0 * whole, (whole, part)
-    both = min(timed([quarter, rest], [4 * cus, 12 * cus]) for _ in range(3))      # 16 per CU of each mask: one round each
-    assert both < 1.7 * whole, (whole, both)
-    zero = (C.c_uint32 * words)()
-    out = C.c_void_p()
-    assert lib.bnv_stream_create_cu_mask(words, zero, C.byref(out)) != 0               # no CU named
-    assert lib.bnv_stream_create_cu_mask(words - 1, zero, C.byref(out)) != 0           # does not cover the device
-    assert lib.bnv_stream_create_cu_mask(words, None, C.byref(out)) != 0 and lib.bnv_stream_destroy(None) != 0
-    torch.cuda.synchronize()
-    for h in (hq, hr):
-        _lib.check(lib.bnv_stream_destroy(C.c_void_p(h)), "bnv_stream_destroy")
-
-
 def test_frame_pipe_integrate_only_frames_and_tsdf_prior(bnv):
     """FramePipe with frames that are only fused (decode=False: run_e2e.py's integrate) followed by frames decoded WITH
     the TSDF prior (sdf_delta, sparse_volume.py:819-832) and a smaller frame in between: equal to NeuralMap."""
@@ -612,3 +561,42 @@ def test_persistent_tables_do_not_survive_a_change_of_model(bnv):
     for t, ((ca, sa), (cb, sb)) in enumerate(zip(outs[True], outs[False])):
         assert torch.equal(ca, cb) and torch.equal(sa, sb), t
     assert float((outs[True][-1][1] != voxel).float().mean()) > 0.05
+
+
+def test_persistent_tables_do_not_survive_new_weights_in_the_same_model(bnv):
+    """``load_state_dict`` on the SAME model object mid-stream (repack() rewrites nerf.sdf_pack in place, NeuralMap keeps
+    its pipe): the carried-over table entries were computed with the old SDF weights and must be dropped -- the pipe
+    watches the network's pack version.  Same outputs as the per-stage path, bit for bit; and they DO differ from a run
+    that keeps the old weights (the change is visible in the decode)."""
+    from bnv_fusion_amd import synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    dims3 = np.array([dims] * 3)
+    frames = _frames(16)
+    outs = {}
+    for use_pipe in (True, False):
+        m = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+        nm = bnv.NeuralMap(dims3, voxel, m, device=DEV)
+        nm.frame_pipe = use_pipe
+        res, pipe0 = [], None
+        for t, fr in enumerate(frames):
+            if t == 11:
+                pipe0 = nm._pipe
+                v0 = m.nerf.pack_version
+                sd = {k: v.clone() for k, v in m.state_dict().items()}
+                sd["nerf.fc_alpha.bias"] += 0.25
+                sd["nerf.geo_layer1.weight"] *= 1.02
+                m.load_state_dict(sd)
+                assert m.nerf.pack_version == v0 + 1
+            res.append(nm.fuse_and_decode_async(fr).result())
+        outs[use_pipe] = res
+        if use_pipe:
+            assert nm._pipe is pipe0 and pipe0 is not None and pipe0.persistent_tables      # the pipe was kept
+    for t, ((ca, sa), (cb, sb)) in enumerate(zip(outs[True], outs[False])):
+        assert torch.equal(ca, cb) and torch.equal(sa, sb), t
+    live = outs[True][-1][1] != voxel
+    assert float(live.float().mean()) > 0.05
+    # the same frames with the old weights throughout: the last frames decode differently
+    m = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+    nm = bnv.NeuralMap(dims3, voxel, m, device=DEV)
+    old = [nm.fuse_and_decode_async(fr).result() for fr in frames]
+    assert torch.equal(old[10][1], outs[True][10][1]) and not torch.equal(old[-1][1], outs[True][-1][1])

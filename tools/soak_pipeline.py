@@ -61,24 +61,14 @@ def run(depth):
             if nxt is not None and depth > 1:
                 pre[0] = be.encode(nxt)
             cap = be.exchange_capacity(be.bound(f))
-            early = be.early_exchange
-            send = be.emit(f, cap) if early else be.upsert(f, cap, True)
+            send = be.upsert(f, cap, True)
             if cap:
-                one = be.recv_buffer(args.world * send.numel(), f)
+                one = be.recv_buffer(args.world * send.numel())
                 blocks = one.view(args.world, cap + 1, D.REC_WORDS)
-                with be.exchange_context():
-                    dist.all_gather_into_tensor(blocks[args.rank].reshape(-1), send)
-                    if early:
-                        # contribution records must be unique per voxel and frame: the other ranks send nothing here
-                        # (the real exchange of a world of 8 runs in tests/test_gpu_multiprocess.py)
-                        blocks[:, 0, 0] = 0
-                        blocks[args.rank, 0, 0] = send[0]
-                    else:
-                        blocks[:] = blocks[args.rank].clone()
-                    blocks[:, 0, 1] = ranks
+                dist.all_gather_into_tensor(blocks[args.rank].reshape(-1), send)
+                blocks[:] = blocks[args.rank].clone()
+                blocks[:, 0, 1] = ranks
                 be.install(f, one, cap)
-            if early:
-                be.upsert(f, cap, True)
             h = be.finish(f, be.decode(f), 0)
 
             class H:

@@ -48,8 +48,6 @@ ap.add_argument("--preroll", type=int, default=None, help="frames fused (not dec
                 "and the region rule has met the sweep)")
 ap.add_argument("--record", default=None, help="(internal) record pass: all W shards in this process, blocks saved to this file")
 ap.add_argument("--ghosts", default=None, help="recorded blocks of the other ranks (from --record); without it --rank records first")
-ap.add_argument("--cu-split", default=None, help="'table,encoder' CUs of the CU-masked five-stream schedule; 0 = four streams "
-                "(default: the package's)")
 ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
                 "pipelined frames after the timed run")
 ap.add_argument("--no-latency", action="store_true")
@@ -60,8 +58,6 @@ ap.add_argument("--ahead", type=int, default=1, help="1: the next frame's encode
                 "this frame's exchange bound (ShardedNeuralMap's next_frame); 0: the loop of round 3")
 ap.add_argument("--json", action="store_true", help="(internal) print the rank's figures as one JSON line at the end")
 args = ap.parse_args()
-if args.cu_split is not None:
-    os.environ["BNV_PIPE_CU_SPLIT"] = args.cu_split
 W = args.world
 
 if args.all_ranks:
@@ -155,7 +151,7 @@ def record(path):
     blocks and every rank's work, and runs the single volume beside them."""
     os.environ["BNV_PERSISTENT_TABLES"] = "0"     # the counts of this pass are the FULL work of a frame, like the single
     shards = [D.HipShardBackend(np.array([dims] * 3), voxel, model, r, W, capacity=1 << 21, device="cuda:0", tsdf=False,
-                                n_slots=2, exchange_stream=False, **SHARD_KW) for r in range(W)]     # volume's beside it: their ratio is the halo
+                                n_slots=2, **SHARD_KW) for r in range(W)]     # volume's beside it: their ratio is the halo
     for b in shards:
         b.inputs_resident, b.copy_results = True, False
     model.shard = (0, 1, 3)
@@ -180,15 +176,12 @@ def record(path):
             bounds = [b.bound(f) for b, f in zip(shards, frs)]
             assert len(set(bounds)) == 1, bounds
             cap = shards[0].exchange_capacity(bounds[0])
-            early = shards[0].early_exchange     # (records = the frame's contributions, exchanged before the upsert)
-            sends = [(b.emit(f, cap) if early else b.upsert(f, cap, decode)) for b, f in zip(shards, frs)]
+            sends = [b.upsert(f, cap, decode) for b, f in zip(shards, frs)]
             blk = torch.stack(sends).clone() if cap else None
             w = []
             for b, f in zip(shards, frs):
                 if cap:
                     b.install(f, blk.view(-1), cap)
-                if early:
-                    b.upsert(f, cap, decode)
                 h = b.finish(f, b.decode(f) if decode else None, 0)
                 c, _ = b.result(h)
                 w.append((0 if c is None else len(c), b.last_owned_pairs, b._last_evals))
@@ -214,7 +207,7 @@ def record(path):
           f"all-gather {W * (np.mean(caps[PREROLL + 8:]) + 1) * 48 / 1e6:.2f} MB per rank and frame")
     torch.save({"blocks": blocks_of, "caps": caps, "work": work, "single_evals": single_evals, "world": W,
                 "ownership": shards[0].ownership, "block_log2": shards[0].block_log2, "axis": shards[0].axis,
-                "scene": args.scene, "grid": args.grid, "preroll": PREROLL, "early": shards[0].early_exchange}, path)
+                "scene": args.scene, "grid": args.grid, "preroll": PREROLL}, path)
 
 
 if args.record:
@@ -225,7 +218,6 @@ GH = None
 if args.ghosts:
     GH = torch.load(args.ghosts, weights_only=False)
     assert GH["world"] == W and GH["scene"] == args.scene and GH["grid"] == args.grid and GH["preroll"] == PREROLL
-    assert GH.get("early", False) == (os.environ.get("BNV_EARLY_EXCHANGE", "0") == "1"), "record pass used the other exchange"
     SHARD_KW.update(ownership=GH["ownership"], block_log2=GH["block_log2"], axis=GH["axis"])
     GH["dev"] = [None if b is None else b.cuda() for b in GH["blocks"]]
 
@@ -241,27 +233,22 @@ def price(rank, latency):
     TRACE = []
 
     def exchange(f, send, cap, t):
-        one = be.recv_buffer(W * send.numel(), f)
+        one = be.recv_buffer(W * send.numel())
         blocks = one.view(W, cap + 1, D.REC_WORDS)
-        with be.exchange_context():       # (the exchange stream with the early exchange; nothing otherwise)
-            if GH is not None:
-                # the other ranks' REAL blocks of this frame (record pass), one device copy = the payload the collective
-                # would land; then the collective call itself (1-rank group) lands this rank's own block over its slot
-                assert GH["caps"][t] == cap, (t, GH["caps"][t], cap)
-                one.copy_(GH["dev"][t].view(-1))
-                dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
-                t4 = time.perf_counter()
-            else:
-                dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
-                t4 = time.perf_counter()
-                if be.early_exchange:
-                    blocks[:, 0, 0] = 0          # (contribution records must be unique: no foreign records without --ghosts)
-                    blocks[rank, 0, 0] = send[0]
-                else:
-                    blocks[:] = blocks[rank].clone()                      # (round 4's stand-in: copies of the own block)
-                blocks[:, 0, 1] = ranks_i32
-            if args.exchange_delay > 0:
-                _lib.check(lib.bnv_probe_spin(1, int(args.exchange_delay * 2100), _lib.stream_ptr()), "bnv_probe_spin")
+        if GH is not None:
+            # the other ranks' REAL blocks of this frame (record pass), one device copy = the payload the collective
+            # would land; then the collective call itself (1-rank group) lands this rank's own block over its slot
+            assert GH["caps"][t] == cap, (t, GH["caps"][t], cap)
+            one.copy_(GH["dev"][t].view(-1))
+            dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
+            t4 = time.perf_counter()
+        else:
+            dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
+            t4 = time.perf_counter()
+            blocks[:] = blocks[rank].clone()                      # (round 4's stand-in: copies of the own block)
+            blocks[:, 0, 1] = ranks_i32
+        if args.exchange_delay > 0:
+            _lib.check(lib.bnv_probe_spin(1, int(args.exchange_delay * 2100), _lib.stream_ptr()), "bnv_probe_spin")
         be.install(f, one, cap)
         stats["recv"] += one.numel() * 4
         return t4
@@ -286,14 +273,9 @@ def price(rank, latency):
             E, M = be.pipe.enc, be.pipe.main
             e0 = ev(E); f = begin(fr, nxt); e1 = ev(E)
             cap = be.exchange_capacity(be.bound(f))
-            if be.early_exchange:
-                if cap:
-                    exchange(f, be.emit(f, cap), cap, t)
-                m0 = ev(M); be.upsert(f, cap, decode); m1 = ev(M)
-            else:
-                m0 = ev(M); send = be.upsert(f, cap, decode); m1 = ev(M)
-                if cap:
-                    exchange(f, send, cap, t)
+            m0 = ev(M); send = be.upsert(f, cap, decode); m1 = ev(M)
+            if cap:
+                exchange(f, send, cap, t)
             m2 = ev(M)
             h = be.finish(f, be.decode(f) if decode else None, 0)
             m3 = ev(M)
@@ -305,20 +287,6 @@ def price(rank, latency):
         bound = be.bound(f); stats["waits"] += 1                     # the frame's one host wait
         t2 = time.perf_counter()
         cap = be.exchange_capacity(bound)
-        if be.early_exchange:
-            # bound -> emit -> all-gather on the exchange stream -> upsert -> finish
-            t3 = t4 = t5 = time.perf_counter()
-            if cap:
-                t4 = exchange(f, be.emit(f, cap), cap, t)
-                t5 = time.perf_counter()
-            be.upsert(f, cap, decode)
-            t5b = time.perf_counter()
-            h = be.finish(f, be.decode(f) if decode else None, 0)
-            t6 = time.perf_counter()
-            for k, d in zip(HOST, (t1 - t0, t2 - t1, t5b - t5, t4 - t3, t5 - t4, t6 - t5b)):
-                HOST[k] += d
-            stats["enq"] += t6 - t0 - (t5 - t4)
-            return h
         send = be.upsert(f, cap, decode)
         t3 = t4 = t5 = time.perf_counter()
         if cap:
@@ -355,7 +323,7 @@ def price(rank, latency):
             collect(pend.pop(0))
 
     out = {}
-    with torch.no_grad(), be.stream_context(frames[0]):
+    with torch.no_grad():
         run(range(PREROLL), 2, decode=False)
         run(range(PREROLL, PREROLL + 8), 2)
         idx = [PREROLL + (i % POOL) for i in range(args.frames)]
@@ -390,9 +358,6 @@ def price(rank, latency):
             out["single_evals"] = float(np.mean(GH["single_evals"][PREROLL + 8:]))
         print(f"rank {rank} of a simulated world of {W}, {args.grid}^3, 640x480, {args.checkpoint} networks, {n} frames, "
               f"{args.in_flight} in flight, {args.reserve} CUs reserved, ownership {be.ownership}, "
-              + ("EARLY exchange (contribution records behind the encode, all-gather on "
-                 + ("a stream of its own" if be.pipe.xchg is not None else "the main stream") + ")"
-                 if be.early_exchange else "exchange behind the upsert (round 4's order)")
               + (f", + {args.exchange_delay:.0f} us spin behind the stand-in all-gather" if args.exchange_delay else "") + ":")
         print(f"  pipelined wall clock  {1e3 * dt / n:.3f} ms per frame  -> {n / dt:.0f} frames/s for the rank set if every "
               f"rank keeps this pace" + (f"  ({SEG} segments: median {np.median(seg_ms):.3f}, slowest {np.max(seg_ms):.3f} ms)"
@@ -406,9 +371,8 @@ def price(rank, latency):
         pp = be.pipe
         print("  pipeline streams verified concurrent with the main stream and with one another: " + ", ".join(
             f"{n} {getattr(st, 'bnv_concurrent', None)}" for n, st in (("encode", pp.enc), ("front", pp.front),
-                                                                     ("blend", pp.blend), ("table", pp.table),
-                                                                     ("exchange", pp.xchg)) if st is not None)
-              + f"; encoder / table workgroups {pp.encoder_workgroups} / {pp.table_workgroups}; CU split {pp.cu_split}")
+                                                                     ("blend", pp.blend)) if st is not None)
+              + f"; encoder workgroups {pp.encoder_workgroups}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}" + (f" (record pass, all {W} shards with the real exchange: {out['evals_rec']:.0f})"
                                                   if GH is not None else " (NO real ghost rows: --ghosts / --all-ranks)")
@@ -433,8 +397,7 @@ def price(rank, latency):
             d = lambda a, b: float(np.nanmean(T[4:, a] - T[4:, b]))       # noqa: E731
             x = lambda a, b: float(np.nanmean(T[5:, a] - T[4:-1, b]))     # noqa: E731  (frame t+1's point a - frame t's point b)
             print(f"    durations: front end {d(1, 0):.1f}, encoder {d(3, 2):.1f}, finalize {d(4, 3):.1f}, upsert {d(6, 5):.1f}, "
-                  + ("upsert done -> finish starts " if be.early_exchange else "exchange (host-enqueued) ")
-                  + f"{d(7, 6):.1f}, " + ("apply" if be.early_exchange else "install") + f" {d(8, 7):.1f}, marking + table {d(9, 8):.1f}, blend + read-back {d(10, 9):.1f}")
+                  + f"exchange (host-enqueued) {d(7, 6):.1f}, install {d(8, 7):.1f}, marking + table {d(9, 8):.1f}, blend + read-back {d(10, 9):.1f}")
             print(f"    waits: bound copied -> encoder starts {d(2, 1):.1f}, finalize done -> upsert starts {d(5, 4):.1f}")
             print(f"    across frames: cycle (table done to table done) {x(9, 9):.1f}; table(t) done -> upsert(t+1) starts {x(5, 9):.1f}; "
                   f"encoder(t+1) starts - table(t) done {x(2, 9):.1f}; encoder(t+1) done - table(t) done {x(3, 9):.1f}; "
