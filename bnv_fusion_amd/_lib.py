@@ -22,6 +22,8 @@ SYMBOLS = [
     "bnv_lattice_mark", "bnv_lattice_table", "bnv_lattice_blend",
     "bnv_decode_pts", "bnv_sdfmlp_bwd_pack_floats", "bnv_sdfmlp_tcnn_bwd_pack_floats", "bnv_decode_pts_backward",
     "bnv_png_unfilter", "bnv_mc_count", "bnv_mc_emit", "bnv_mc_count_indexed", "bnv_mc_emit_indexed", "bnv_ray_samples", "bnv_ray_loss", "bnv_volume_count_optim_pts",
+    "bnv_volume_count_optim_splits", "bnv_volume_apply_split_counts", "bnv_decode_pts_splits",
+    "bnv_decode_pts_backward_splits", "bnv_ray_loss_splits", "bnv_optim_step",
     "bnv_decode_lattice_workspace_bytes", "bnv_decode_lattice", "bnv_decode_dense",
     "bnv_shard_install_reset", "bnv_volume_integrate_frame", "bnv_decode_lattice_stamped", "bnv_readback_words",
     "bnv_decode_dense_mode", "bnv_frame_pipe_set_mlp_mode", "bnv_decode_lattice_stamped_tables",
@@ -168,6 +170,15 @@ def load():
         "bnv_ray_samples": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp,
                                       C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
         "bnv_ray_loss": (C.c_int, [vp, vp, vp, vp, i64, vp, vp, vp]),
+        "bnv_ray_loss_splits": (C.c_int, [vp, vp, vp, vp, i64, i64, vp, vp, vp]),
+        "bnv_volume_count_optim_splits": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, C.c_int, i64, i64, vp, vp]),
+        "bnv_volume_apply_split_counts": (C.c_int, [vp, vp, i64, vp]),
+        "bnv_decode_pts_splits": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, i64, C.c_int,
+                                            C.POINTER(SdfDelta), vp, i64, vp, vp]),
+        "bnv_decode_pts_backward_splits": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, vp, i64,
+                                                     C.c_int, vp, i64, vp, vp, vp]),
+        "bnv_optim_step": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, vp, i64, vp, vp, vp, i64, C.c_int,
+                                     C.POINTER(SdfDelta), vp, i64, vp, vp, vp, vp, vp, vp, vp]),
         "bnv_volume_count_optim_pts": (C.c_int, [C.POINTER(Volume), C.POINTER(Grid), vp, i64, C.c_int, vp, i64, vp, i32,
                                                  vp]),
         "bnv_mc_count": (C.c_int, [vp, i64, vp, C.c_float, vp, vp, vp]),

@@ -112,6 +112,12 @@ struct DecodeArgs {
   float* nf_out;     // optional [n, 8]: the features the evaluation used
   int32_t* status;   // optional: [1] = 5 when a feature leaves the certified range of the split arithmetic
   int32_t half_tail; // k_lattice_table_x: hand the last partial round out as 64-evaluation tiles
+  // PTS, several ray splits of an optimiser step in ONE call (bnv_optim_step, bnv_decode_pts_splits): query q belongs
+  // to split q / split_samples; bit s of split_mask[row] = split s touches the row (bnv_volume_count_optim_splits).
+  // The weight the mask decision of a split-s query sees is weights[row] + 1 for every split <= s that touches the
+  // row -- count_optim (sparse_volume.py:602-622) called split by split, render_utils.py:491-497.  Null: plain weights.
+  const uint32_t* split_mask;
+  int64_t split_samples;
 };
 
 __device__ __forceinline__ f32x16 frag256(const float* __restrict__ b, int w, int h) {
@@ -818,10 +824,12 @@ __device__ __forceinline__ float pts_corner(const DecodeArgs& A, int64_t q, int 
   return __fmul_rn(__fmul_rn(1.f - fabsf(loc[0]), 1.f - fabsf(loc[1])), 1.f - fabsf(loc[2]));
 }
 
-// Classifies chunk `chunk`; returns the number of live queries (uniform).  Masked queries get their final
-// value written to A.out when WRITE_MASKED (forward); live ones are listed in C_LIST in ascending order.
-template <bool WRITE_MASKED>
-__device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t chunk, float* __restrict__ lds) {
+// Classifies chunk `chunk`; returns the number of live queries (uniform).  Masked queries are finished here:
+// masked(q, value) gets their final value (forward: written to A.out; fused optimiser step: their loss term); live
+// ones are listed in C_LIST in ascending order.
+template <class MaskedFn>
+__device__ __forceinline__ int pts_classify_chunk_fn(const DecodeArgs& A, int64_t chunk, float* __restrict__ lds,
+                                                     MaskedFn masked) {
   int* c_row = (int*)(lds + C_ROW);
   int* c_list = (int*)(lds + C_LIST);
   int* c_cnt = (int*)(lds + C_CNT);
@@ -843,7 +851,16 @@ __device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t c
       if (pack_key((int64_t)corner[0], (int64_t)corner[1], (int64_t)corner[2], &key))
         row = volume_find(A.vol.slot_keys, A.vol.slot_rows, (uint32_t)(A.vol.n_slots - 1), key);
       if (row >= A.row_limit) row = -1;
-      if (row >= 0) wvol = A.weights[row];
+      if (row >= 0) {
+        wvol = A.weights[row];
+        if (A.split_mask) {   // count_optim of the splits up to and including this query's, one exact +1 each
+          uint32_t m = A.split_mask[row] & ((2u << (uint32_t)(q / A.split_samples)) - 1u);
+          while (m) {
+            wvol = __fadd_rn(wvol, 1.0f);
+            m &= m - 1u;
+          }
+        }
+      }
       if (A.delta.data) dlt = sample_delta(A.delta, A.grid, corner);
     }
     // the 8 corners of a query sit in 8 consecutive lanes: sums in corner order, like the reference's dim-1 sum
@@ -864,10 +881,10 @@ __device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t c
     if (k == 0 && q < A.n) {
       if (live) {
         live_bits |= 1u << it;
-      } else if (WRITE_MASKED) {
+      } else {
         float o = voxel;
         if (A.delta.data) o = __fadd_rn(o, dacc);
-        A.out[q] = o;
+        masked(q, o);
       }
     }
   }
@@ -899,6 +916,13 @@ __device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t c
   }
   __syncthreads();
   return *c_cnt;
+}
+
+template <bool WRITE_MASKED>
+__device__ __forceinline__ int pts_classify_chunk(const DecodeArgs& A, int64_t chunk, float* __restrict__ lds) {
+  return pts_classify_chunk_fn(A, chunk, lds, [&](int64_t q, float o) {
+    if (WRITE_MASKED) A.out[q] = o;
+  });
 }
 
 // front end of one tile of 16 live queries: thread e < 128 = (live query e >> 3, corner e & 7)
@@ -1207,6 +1231,190 @@ __global__ __launch_bounds__(512, 2) void k_decode_pts_bwd(DecodeBwdArgs B) {
     }
     __syncthreads();
    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_optim_step (round 6): ONE launch for what an optimiser step of the reference spends five forward and five
+// backward decode_pts calls on (run_e2e.py:127-153: 5,000 rays in splits of 1,000; render_utils.py:461-590).
+// The L1 ray loss is elementwise -- d loss / d pred_q = sign(pred_q - target_q) * weight_q / n_valid(split) -- so the
+// gradient a query sends back is known as soon as ITS forward value is: the forward (which k_decode_pts_bwd
+// recomputes anyway for the ReLU masks) yields pred, the loss term and the seed of the backward in the same tile,
+// and the separate forward kernel, the loss kernel and the round trip of pred / grad through memory all go.  All
+// splits of a step ride in one launch: the weight a mask decision sees is reconstructed per split from
+// split_mask (DecodeArgs), so every decision is the one the split-by-split sequence takes; chunks of 128 queries
+// are handed out dynamically (a ray split has < 1 tile of live queries per workgroup: five launches of each kernel
+// left 3/4 of every launch's time to launch latency and one-tile rounds).  Arithmetic: the split-f16 forward /
+// backward of k_decode_pts_bwd (fp32 checkpoints; SDF within 1e-8 of the exact-fp32 forward, gradients to 1e-6).
+// ---------------------------------------------------------------------------------------------------
+struct OptimArgs {
+  DecodeBwdArgs b;          // b.d: the queries (coords = the step's samples, split_mask / split_samples); b.grad_features
+  const float* target;      // [n]  L1 target of every sample (bnv_ray_samples)
+  const float* wgt;         // [n]  valid x ray mask
+  const float* n_valid;     // [n_splits]  sum of the split's ray masks + 1e-4 (render_utils.py:553)
+  float* loss;              // [0] += sum over the splits of their losses; [1]: int32 chunk counter (zeroed by the caller)
+  float* pred;              // optional [n]: the decoded SDF (tests, diagnostics)
+};
+
+__global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const DecodeBwdArgs& B = O.b;
+  const DecodeArgs& A = B.d;
+  const float voxel = A.grid.voxel_size;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  int* l_row = (int*)(lds + L_WVOL);
+  __shared__ int s_chunk;
+  __shared__ float s_red[8];
+  const int64_t n_chunks = (A.n + PC_Q - 1) / PC_Q;
+  float loss_acc = 0.f;
+  auto loss_term = [&](int64_t q, float pred) -> float {      // -> d loss / d pred_q
+    const float inv = 1.f / O.n_valid[A.split_samples > 0 ? q / A.split_samples : 0];
+    const float wq = O.wgt[q] * inv;
+    const float d = pred - O.target[q];
+    loss_acc += fabsf(d) * wq;
+    if (O.pred) O.pred[q] = pred;
+    return d > 0.f ? wq : (d < 0.f ? -wq : 0.f);               // d|x|/dx with torch's sign(0) = 0
+  };
+  for (;;) {
+    __syncthreads();                                           // (s_chunk of the round before has been read)
+    if (threadIdx.x == 0) s_chunk = atomicAdd((int*)(O.loss + 1), 1);
+    __syncthreads();
+    const int64_t chunk = s_chunk;
+    if (chunk >= n_chunks) break;
+    const int n_live = pts_classify_chunk_fn(A, chunk, lds, [&](int64_t q, float o) { (void)loss_term(q, o); });
+    for (int tile = 0; tile * 16 < n_live; ++tile) {
+      if (threadIdx.x < DM) pts_stage_tile<1>(A, chunk, tile, n_live, lds, l_row);
+      __syncthreads();
+      const float* pack = A.pack;
+      const float* bpack = B.bwd_pack;
+      asm volatile("" : "+s"(pack), "+s"(bpack));
+      const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
+      const _Float16* pb = (const _Float16*)bpack;
+      // ---------------- forward, keeping the sign bits of the pre-activations ---------------------------
+      f32x16 acc[4];
+      mlp_layer_hb<2, true>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
+      const uint64_t m0 = positive_bits(acc);
+      __syncthreads();
+      store_relu_h(lds, acc, w, j, h);
+      __syncthreads();
+      mlp_layer_hb<16, true>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
+      const uint64_t m1 = positive_bits(acc);
+      __syncthreads();
+      store_relu_h(lds, acc, w, j, h);
+      __syncthreads();
+      mlp_layer_hb<16, true>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
+      const uint64_t m2 = positive_bits(acc);
+      __syncthreads();
+      store_relu_h(lds, acc, w, j, h);
+      __syncthreads();
+      mlp_layer_hb<16, true>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+      {
+        // fc_alpha (the forward's last layer) and the backward's seed delta_3 = wa * [z3 > 0] from the same fragment
+        const uint64_t m3 = positive_bits(acc);
+        const f32x16 wa = frag256(pack + SD_WA, w, h);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+          float sp = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sp = fmaf(wa[r], relu_bits(acc[pt][r]), sp);
+          lds[L_PART + (w * 2 + h) * DM + pt * 32 + j] = sp;
+          acc[pt] = wa;
+        }
+        __syncthreads();                      // layer 3 has read its operands; the partial sums are in place
+        store_masked_h(lds, acc, m3, w, j, h);
+      }
+      if (threadIdx.x < DM) {
+        // evaluation e = (live query e >> 3, corner e & 7): alpha -> the query's SDF (sums in corner order, like the
+        // forward kernel) -> its loss term -> the gradient every one of its 8 evaluations starts from
+        const int e = threadIdx.x;
+        float al = pack[SD_BA];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) al += lds[L_PART + p * DM + e];
+        const float wk = lds[L_WTRI + e];
+        const float ak = __fmul_rn(__fmul_rn(al, voxel), wk);
+        const float dk = __fmul_rn(lds[L_DELTA + e], wk);
+        float sum = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          sum = __fadd_rn(sum, __shfl(ak, (e & 56) + kk));
+          dsum = __fadd_rn(dsum, __shfl(dk, (e & 56) + kk));
+        }
+        if (A.delta.data) sum = __fadd_rn(sum, dsum);
+        const int li = tile * 16 + (e >> 3);
+        float go = 0.f;
+        if (li < n_live) {
+          const int64_t q = chunk * PC_Q + ((const int*)(lds + C_LIST))[li];
+          float g = 0.f;
+          if ((e & 7) == 0) g = loss_term(q, sum);
+          g = __shfl(g, e & 56);
+          go = g * voxel * wk;
+        }
+        lds[L_ALPHA + e] = go;
+      }
+      __syncthreads();
+      // ---------------- backward with a unit seed (as k_decode_pts_bwd) ---------------------------------
+      mlp_layer_hb<16, false>(pb + SB_W3T, nullptr, lds, acc, w, lane, j, h);
+      __syncthreads();
+      store_masked_h(lds, acc, m2, w, j, h);
+      __syncthreads();
+      mlp_layer_hb<16, false>(pb + SB_W2T, nullptr, lds, acc, w, lane, j, h);
+      __syncthreads();
+      store_masked_h(lds, acc, m1, w, j, h);
+      __syncthreads();
+      mlp_layer_hb<16, false>(pb + SB_W1T, nullptr, lds, acc, w, lane, j, h);
+      __syncthreads();
+      store_masked_h(lds, acc, m0, w, j, h);
+      __syncthreads();
+      if (w < 4) {
+        f32x16 g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+        const _Float16* wl = pb + SB_W0T + lane * 8;
+        const float* hh = lds + L_HL + (h * DM + w * 32 + j) * 4;
+        const float* hl = lds + L_HLO + (h * DM + w * 32 + j) * 4;
+#pragma unroll 4
+        for (int ks = 0; ks < 16; ++ks) {
+          const half8 a_hi = *(const half8*)(wl + (ks * 2) * 64 * 8);
+          const half8 a_lo = *(const half8*)(wl + (ks * 2 + 1) * 64 * 8);
+          const half8 b_hi = *(const half8*)(hh + ks * 2 * DM * 4);
+          const half8 b_lo = *(const half8*)(hl + ks * 2 * DM * 4);
+          g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, g, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, g, 0, 0, 0);
+        }
+        const int col = w * 32 + j;
+        const float sg = lds[L_ALPHA + col];
+        const int row = l_row[col];
+        if (sg != 0.f && row >= 0) {
+          float* gf = B.grad_features + (size_t)row * 8;
+          if (h == 0) {
+            unsafeAtomicAdd(gf + 0, g[5] * sg);
+            unsafeAtomicAdd(gf + 1, g[6] * sg);
+            unsafeAtomicAdd(gf + 2, g[7] * sg);
+            unsafeAtomicAdd(gf + 7, g[8] * sg);
+          } else {
+            unsafeAtomicAdd(gf + 3, g[4] * sg);
+            unsafeAtomicAdd(gf + 4, g[5] * sg);
+            unsafeAtomicAdd(gf + 5, g[6] * sg);
+            unsafeAtomicAdd(gf + 6, g[7] * sg);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // the workgroup's share of the loss: one atomic
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss_acc += __shfl_xor(loss_acc, o);
+  if (lane == 0) s_red[w] = loss_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += s_red[i];
+    if (t != 0.f) unsafeAtomicAdd(O.loss, t);
   }
 }
 
@@ -2778,6 +2986,7 @@ int bnv_decode_init() {
                                     C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts_bwd_t, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     C_TOTAL * 4));
+  BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_optim_step, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<0>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<1>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
   BNV_HIP_CHECK(hipFuncSetAttribute((const void*)k_decode_pts<2>, hipFuncAttributeMaxDynamicSharedMemorySize, C_TOTAL * 4));
@@ -2837,15 +3046,24 @@ int bnv_set_option(const char* name, int value) {
   return BNV_ERR_INVALID_ARGUMENT;
 }
 
-int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
-                   int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,
-                   const bnv_sdf_delta_t* delta, float* out_sdf, bnv_stream_t stream) {
+// split_mask == NULL: one split (plain weights); else split_samples > 0 queries per split, at most 31 splits
+static bool splits_ok(const uint32_t* split_mask, int64_t split_samples, int64_t n) {
+  if (!split_mask) return true;
+  return split_samples > 0 && (n + split_samples - 1) / split_samples <= 31;
+}
+
+int bnv_decode_pts_splits(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
+                          int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,
+                          const bnv_sdf_delta_t* delta, const uint32_t* split_mask, int64_t split_samples,
+                          float* out_sdf, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || n < 0) return BNV_ERR_INVALID_ARGUMENT;
-  if (!mlp_mode_field_ok(grid->mlp_mode)) return BNV_ERR_INVALID_ARGUMENT;
+  if (!mlp_mode_field_ok(grid->mlp_mode) || !splits_ok(split_mask, split_samples, n)) return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   if (!coords || !out_sdf) return BNV_ERR_INVALID_ARGUMENT;
   DecodeArgs a = {};
+  a.split_mask = split_mask;
+  a.split_samples = split_mask ? split_samples : 0;
   a.vol = *vol;
   a.grid = *grid;
   a.features = features;
@@ -2860,20 +3078,30 @@ int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float*
   return launch_decode(MODE_PTS, mlp_mode_of(grid->mlp_mode), a, (n + 15) / 16, (hipStream_t)stream);
 }
 
+int bnv_decode_pts(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
+                   int64_t row_limit, const float* sdfmlp_pack, const float* coords, int64_t n, int is_coords,
+                   const bnv_sdf_delta_t* delta, float* out_sdf, bnv_stream_t stream) {
+  return bnv_decode_pts_splits(vol, grid, features, weights, row_limit, sdfmlp_pack, coords, n, is_coords, delta,
+                               nullptr, 0, out_sdf, stream);
+}
+
 size_t bnv_sdfmlp_bwd_pack_floats(void) { return SB_PACK_FLOATS; }
 size_t bnv_sdfmlp_tcnn_bwd_pack_floats(void) { return TB_TOTAL / 2; }
 
-int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
-                            const float* weights, int64_t row_limit, const float* sdfmlp_pack,
-                            const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
-                            const float* grad_sdf, float* grad_features, bnv_stream_t stream) {
+int bnv_decode_pts_backward_splits(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                                   const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                                   const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
+                                   const uint32_t* split_mask, int64_t split_samples, const float* grad_sdf,
+                                   float* grad_features, bnv_stream_t stream) {
   if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
   if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0 ||
-      !mlp_mode_field_ok(grid->mlp_mode))
+      !mlp_mode_field_ok(grid->mlp_mode) || !splits_ok(split_mask, split_samples, n))
     return BNV_ERR_INVALID_ARGUMENT;
   if (n == 0) return BNV_OK;
   if (!coords || !grad_sdf || !grad_features) return BNV_ERR_INVALID_ARGUMENT;
   DecodeBwdArgs b = {};
+  b.d.split_mask = split_mask;
+  b.d.split_samples = split_mask ? split_samples : 0;
   b.d.vol = *vol;
   b.d.grid = *grid;
   b.d.features = features;
@@ -2893,6 +3121,57 @@ int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, con
     hipLaunchKernelGGL(k_decode_pts_bwd_t, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
   else
     hipLaunchKernelGGL(k_decode_pts_bwd, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, b);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_decode_pts_backward(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features,
+                            const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                            const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
+                            const float* grad_sdf, float* grad_features, bnv_stream_t stream) {
+  return bnv_decode_pts_backward_splits(vol, grid, features, weights, row_limit, sdfmlp_pack, sdfmlp_bwd_pack, coords,
+                                        n, is_coords, nullptr, 0, grad_sdf, grad_features, stream);
+}
+
+int bnv_optim_step(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* features, const float* weights,
+                   int64_t row_limit, const float* sdfmlp_pack, const float* sdfmlp_bwd_pack, const float* pts,
+                   int64_t n, int is_coords, const bnv_sdf_delta_t* delta, const uint32_t* split_mask,
+                   int64_t split_samples, const float* target, const float* sample_weight, const float* n_valid,
+                   float* loss_and_counter, float* pred, float* grad_features, bnv_stream_t stream) {
+  if (g_num_cus <= 0) return BNV_ERR_NOT_INITIALISED;
+  if (!vol_ok_ro(vol) || !grid || !features || !weights || !sdfmlp_pack || !sdfmlp_bwd_pack || n < 0 ||
+      !mlp_mode_field_ok(grid->mlp_mode) || !splits_ok(split_mask, split_samples, n))
+    return BNV_ERR_INVALID_ARGUMENT;
+  // the fused kernel is the split-f16 forward + backward of the fp32 decoder (modes 1 / 3 / 0 share it as
+  // bnv_decode_pts_backward does); the tiny-cuda-nn decoder keeps its separate kernels
+  if (mlp_mode_of(grid->mlp_mode) == 2) return BNV_ERR_INVALID_ARGUMENT;
+  if (n == 0) return BNV_OK;
+  if (!pts || !target || !sample_weight || !n_valid || !loss_and_counter || !grad_features) return BNV_ERR_INVALID_ARGUMENT;
+  OptimArgs o = {};
+  o.b.d.vol = *vol;
+  o.b.d.grid = *grid;
+  o.b.d.features = features;
+  o.b.d.weights = weights;
+  o.b.d.row_limit = row_limit;
+  o.b.d.pack = sdfmlp_pack;
+  o.b.d.coords = pts;
+  o.b.d.n = n;
+  o.b.d.is_coords = is_coords;
+  if (delta) o.b.d.delta = *delta;
+  o.b.d.split_mask = split_mask;
+  o.b.d.split_samples = split_mask ? split_samples : 0;
+  o.b.bwd_pack = sdfmlp_bwd_pack;
+  o.b.grad_features = grad_features;
+  o.target = target;
+  o.wgt = sample_weight;
+  o.n_valid = n_valid;
+  o.loss = loss_and_counter;
+  o.pred = pred;
+  int64_t nblk = (n + PC_Q - 1) / PC_Q;
+  const int64_t cus = g_num_cus - g_reserve_cus.load(std::memory_order_relaxed);
+  if (nblk > cus) nblk = cus;
+  ProfScope prof(PROF_DECODE_PTS, (hipStream_t)stream);
+  hipLaunchKernelGGL(k_optim_step, dim3((unsigned)nblk), dim3(512), C_TOTAL * 4, (hipStream_t)stream, o);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

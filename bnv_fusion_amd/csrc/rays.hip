@@ -133,13 +133,15 @@ __global__ __launch_bounds__(256) void k_ray_samples(RayArgs A) {
   A.weight[o] = valid ? A.ray_mask[r] : 0.f;
 }
 
+// (split_samples > 0: sample i belongs to split i / split_samples and n_valid holds one value per split)
 __global__ __launch_bounds__(256) void k_ray_loss(const float* __restrict__ pred, const float* __restrict__ target,
                                                   const float* __restrict__ weight, const float* __restrict__ n_valid,
-                                                  int64_t m, float* __restrict__ loss, float* __restrict__ grad) {
+                                                  int64_t m, int64_t split_samples, float* __restrict__ loss,
+                                                  float* __restrict__ grad) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const float inv = 1.f / *n_valid;
   float l = 0.f;
   if (i < m) {
+    const float inv = 1.f / n_valid[split_samples > 0 ? i / split_samples : 0];
     const float w = weight[i] * inv;
     const float d = pred[i] - target[i];
     l = fabsf(d) * w;
@@ -176,6 +178,48 @@ __global__ __launch_bounds__(256) void k_count_optim_pts(bnv_volume_t v, bnv_gri
   if (atomicExch(&stamp[row], epoch) != epoch) weights[row] = __fadd_rn(weights[row], 1.0f);
 }
 
+// The same for ALL ray splits of an optimiser step at once (sample q belongs to split q / split_samples): nothing is
+// added yet -- bit s of split_mask[row] records that split s touches the row, the decode kernels rebuild from it the
+// weight each split's mask decisions see (DecodeArgs::split_mask), and k_apply_split_counts adds the +1s afterwards.
+__global__ __launch_bounds__(256) void k_count_optim_splits(bnv_volume_t v, bnv_grid_t g, const float* __restrict__ pts,
+                                                            int64_t m, int is_coords, int64_t row_limit,
+                                                            int64_t split_samples, uint32_t* __restrict__ split_mask) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m * 8) return;
+  const int64_t q = t >> 3;
+  const int cb = kCornerCeilBits[t & 7];
+  int64_t c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float x = pts[q * 3 + a];
+    if (!is_coords) x = __fdiv_rn(__fsub_rn(x, g.bound_min[a]), g.voxel_size);
+    c[a] = (int64_t)(((cb >> a) & 1) ? ceilf(x) : floorf(x));
+  }
+  uint64_t key;
+  if (!pack_key(c[0], c[1], c[2], &key)) return;
+  const int row = volume_find(v.slot_keys, v.slot_rows, (uint32_t)(v.n_slots - 1), key);
+  if (row < 0 || row >= row_limit) return;
+  const uint32_t bit = 1u << (uint32_t)(q / split_samples);
+  if (!(split_mask[row] & bit)) atomicOr(&split_mask[row], bit);     // (most corners of a ray's samples repeat a row)
+}
+
+// weights[row] += 1 once per split that touched the row, as sequential exact fp32 additions (what the split-by-split
+// calls of count_optim leave behind); the masks are cleared for the next step.
+__global__ __launch_bounds__(256) void k_apply_split_counts(float* __restrict__ weights, uint32_t* __restrict__ split_mask,
+                                                            int64_t n_rows) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rows) return;
+  uint32_t m = split_mask[r];
+  if (!m) return;
+  float w = weights[r];
+  while (m) {
+    w = __fadd_rn(w, 1.0f);
+    m &= m - 1u;
+  }
+  weights[r] = w;
+  split_mask[r] = 0u;
+}
+
 }  // namespace bnv
 
 using namespace bnv;
@@ -205,12 +249,40 @@ int bnv_ray_samples(const float* uv, const float* gt_pts, const float* ray_mask,
   return BNV_OK;
 }
 
-int bnv_ray_loss(const float* pred, const float* target, const float* weight, const float* n_valid, int64_t m,
-                 float* loss, float* grad, bnv_stream_t stream) {
-  if (m < 0 || (m > 0 && (!pred || !target || !weight || !n_valid || !loss || !grad))) return BNV_ERR_INVALID_ARGUMENT;
+int bnv_ray_loss_splits(const float* pred, const float* target, const float* weight, const float* n_valid, int64_t m,
+                        int64_t split_samples, float* loss, float* grad, bnv_stream_t stream) {
+  if (m < 0 || split_samples < 0 || (m > 0 && (!pred || !target || !weight || !n_valid || !loss || !grad)))
+    return BNV_ERR_INVALID_ARGUMENT;
   if (m == 0) return BNV_OK;
   hipLaunchKernelGGL(k_ray_loss, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, target,
-                     weight, n_valid, m, loss, grad);
+                     weight, n_valid, m, split_samples, loss, grad);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_ray_loss(const float* pred, const float* target, const float* weight, const float* n_valid, int64_t m,
+                 float* loss, float* grad, bnv_stream_t stream) {
+  return bnv_ray_loss_splits(pred, target, weight, n_valid, m, 0, loss, grad, stream);
+}
+
+int bnv_volume_count_optim_splits(const bnv_volume_t* vol, const bnv_grid_t* grid, const float* pts, int64_t m,
+                                  int is_coords, int64_t row_limit, int64_t split_samples, uint32_t* split_mask,
+                                  bnv_stream_t stream) {
+  if (!vol || !grid || m < 0 || !split_mask || split_samples < 1 || (m + split_samples - 1) / split_samples > 31)
+    return BNV_ERR_INVALID_ARGUMENT;
+  if (m == 0) return BNV_OK;
+  if (!pts) return BNV_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_count_optim_splits, dim3((unsigned)((m * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     *vol, *grid, pts, m, is_coords, row_limit, split_samples, split_mask);
+  BNV_LAUNCH_CHECK();
+  return BNV_OK;
+}
+
+int bnv_volume_apply_split_counts(float* weights, uint32_t* split_mask, int64_t n_rows, bnv_stream_t stream) {
+  if (n_rows < 0 || (n_rows > 0 && (!weights || !split_mask))) return BNV_ERR_INVALID_ARGUMENT;
+  if (n_rows == 0) return BNV_OK;
+  hipLaunchKernelGGL(k_apply_split_counts, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     weights, split_mask, n_rows);
   BNV_LAUNCH_CHECK();
   return BNV_OK;
 }

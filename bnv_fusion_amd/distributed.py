@@ -332,6 +332,95 @@ def all_gather_var(t, group=None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
 
 
+def first_contact(rank, world, device, group=None, backend=None, n_gathers=5, timeout_s=60.0, records=512,
+                  identity=None):
+    """First contact of a freshly made process group, BEFORE anything is timed (bench.py --gpus N; RCCL with more than
+    one rank has never run on the development boxes, so the first minutes on a node must fail loudly, not hang):
+
+    * every rank reports {rank, host, pid, device, device name, PCI bus id, uuid} (all_gather_object) and the rank
+      count the backend itself reports; a world size that differs from ``world`` raises;
+    * with a GPU backend every rank must sit on a DISTINCT physical device -- two ranks on one GPU (a launcher that
+      did not set LOCAL_RANK, a container that exposes one device) would run, slowly, and report a meaningless scaling
+      curve: raises, naming the ranks that clash (``identity`` overrides what is compared: tests);
+    * ``n_gathers`` all-gathers shaped like a frame's exchange ((1 + records) 48-byte records per rank), each block
+      tagged with its sender and the round, each waited for with ITS OWN timeout (``timeout_s``), and the landed
+      blocks checked on the host: a collective that does not complete, or lands the wrong data, raises a RuntimeError
+      that names the round -- the caller turns it into a non-zero exit (never a re-exec: bench.py's ranks are children
+      of the launcher).
+
+    -> a dict for the bench line's ``distributed`` entry.  CPU backends (gloo) run the same checks on host tensors."""
+    import datetime
+    import os
+    import socket
+    import time
+    import torch.distributed as dist
+    dev = torch.device(device)
+    on_gpu = dev.type == "cuda"
+    me = {"rank": int(rank), "host": socket.gethostname(), "pid": os.getpid(), "device": str(dev)}
+    if on_gpu:
+        pr = torch.cuda.get_device_properties(dev)
+        bus = "%04x:%02x:%02x" % (int(getattr(pr, "pci_domain_id", 0)), int(getattr(pr, "pci_bus_id", -1)),
+                                  int(getattr(pr, "pci_device_id", 0)))
+        me.update(device_name=pr.name, pci_bus_id=bus, uuid=str(getattr(pr, "uuid", "")),
+                  compute_units=int(pr.multi_processor_count))
+    me["identity"] = identity if identity is not None else (
+        (me["host"], me.get("pci_bus_id"), me.get("uuid")) if on_gpu else (me["host"], me["pid"]))
+    seen = dist.get_world_size(group)
+    if seen != int(world):
+        raise RuntimeError(f"first contact: the process group reports {seen} ranks, the launcher said {world}")
+    ranks = [None] * seen
+    dist.all_gather_object(ranks, me, group=group)
+    if sorted(r["rank"] for r in ranks) != list(range(seen)):
+        raise RuntimeError(f"first contact: ranks are not 0..{seen - 1}: {[r['rank'] for r in ranks]}")
+    ranks.sort(key=lambda r: r["rank"])
+    by_id = {}
+    for r in ranks:
+        by_id.setdefault(tuple(r["identity"]) if isinstance(r["identity"], (list, tuple)) else r["identity"], []).append(r["rank"])
+    clash = [v for v in by_id.values() if len(v) > 1]
+    if clash and (on_gpu or identity is not None):
+        raise RuntimeError(f"first contact: ranks {clash} share a device ({[ranks[v[0]]['identity'] for v in clash]}): "
+                           "one process per GPU -- check LOCAL_RANK / the visible devices")
+    words = (1 + int(records)) * REC_WORDS
+    send = torch.zeros(words, dtype=torch.int32, device=dev)
+    recv = torch.empty(seen * words, dtype=torch.int32, device=dev)
+    ms = []
+    for k in range(int(n_gathers)):
+        send.fill_(int(rank) * 1000 + k)
+        send[0], send[1] = int(records), int(rank)              # a block's header: {count, sender}
+        recv.fill_(-1)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+        try:
+            done = work.wait(datetime.timedelta(seconds=float(timeout_s)))
+            if on_gpu:
+                torch.cuda.synchronize(dev)
+        except Exception as e:       # noqa: BLE001 -- the backend's own timeout / abort
+            raise RuntimeError(f"first contact: all-gather {k + 1} of {n_gathers} failed on rank {rank} "
+                               f"({seen} ranks, {words * 4} bytes per rank): {type(e).__name__}: {e}") from e
+        if done is False:
+            raise RuntimeError(f"first contact: all-gather {k + 1} of {n_gathers} did not complete within {timeout_s} s "
+                               f"on rank {rank}")
+        ms.append(1e3 * (time.perf_counter() - t0))
+        got = recv.view(seen, words).cpu()
+        for r in range(seen):
+            if int(got[r, 1]) != r or int(got[r, 0]) != int(records) or not bool((got[r, 2:] == r * 1000 + k).all()):
+                raise RuntimeError(f"first contact: all-gather {k + 1} landed wrong data for sender {r} on rank {rank} "
+                                   f"(header {got[r, :2].tolist()}, payload {int(got[r, 2])})")
+    ver = None
+    if on_gpu and (backend or "nccl") == "nccl":
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:           # noqa: BLE001
+            ver = None
+    for r in ranks:
+        r.pop("identity", None)
+    return {"ranks_seen_by_backend": seen, "distinct_devices": len(by_id), "ranks": ranks, "rccl_version": ver,
+            "first_contact": {"all_gathers": int(n_gathers), "bytes_per_rank": words * 4, "timeout_s": float(timeout_s),
+                              "ms_this_rank": ms, "data_checked": True}}
+
+
 class ShardFrame:
     """One frame on its way through a shard backend (everything a later phase needs)."""
 

@@ -301,13 +301,22 @@ class NeuralMap:
         lo = 0 if last_frame == -1 else last_frame
         cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
 
+        from .optimize import key_frame_points
+        cache = {}        # per key frame: every pixel's world point + validity (7.4 MB per 640x480 frame; at most 64 kept)
+
         def batches():
             for _ in range(n_iters):
-                f = self.frames[int(torch.randint(lo, len(self.frames), (1,), generator=cpu_gen))]
-                d = f["depth"]
-                if d.dtype in (torch.uint16, torch.int16):
-                    d = d.to(torch.float32) / 1000.0
-                yield sample_key_frame(d, f["intr_mat"], f["T_wc"], sampling_size, ray_max_dist, generator)
+                k = int(torch.randint(lo, len(self.frames), (1,), generator=cpu_gen))
+                f = self.frames[k]
+                pts = cache.get(k)
+                if pts is None:
+                    d = f["depth"]
+                    if d.dtype in (torch.uint16, torch.int16):
+                        d = d.to(torch.float32) / 1000.0
+                    pts = key_frame_points(d, f["intr_mat"], f["T_wc"], ray_max_dist)
+                    if len(cache) < 64:
+                        cache[k] = pts
+                yield sample_key_frame(None, None, None, sampling_size, ray_max_dist, generator, points=pts)
 
         return optimize_volume(self.volume, self.pointnet.nerf, batches(), self.truncated_units,
                                self.truncated_dist, ray_max_dist, sdf_delta=delta,

@@ -123,10 +123,55 @@ def calculate_loss(volume, rays, nerf, truncated_units, truncated_dist, ray_max_
     return {"depth_bce_loss": loss}
 
 
-def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generator=None):
+def key_frame_points(depth, intr_mat, T_wc, ray_max_dist):
+    """The part of _sample_key_frame that depends on the frame alone: every pixel's world point (float64 arithmetic of
+    geometry.py:150-171, rounded to float32 as the sampler's ``.float()`` does after its gather) and validity
+    (common.py:110-113).  -> (pts [H * W, 3] f32, mask [H * W] f32, H, W, host copies of T_wc / intr_mat)."""
+    dev = depth.device
+    intr_mat, T_wc = torch.as_tensor(intr_mat), torch.as_tensor(T_wc)
+    depth = depth.to(torch.float64)
+    mask = (depth > 0) & (depth < ray_max_dist)                       # common.py:110-113
+    depth = depth * mask
+    H, W = depth.shape
+    K = intr_mat.to(dev, torch.float32)
+    T = T_wc.to(dev, torch.float32).to(torch.float64)
+    # geometry.py:163-168 forms the normalised pixel coordinates in float32 before the float64 product
+    u = ((torch.arange(W, device=dev, dtype=torch.float32) - K[0, 2]) / K[0, 0]).to(torch.float64)
+    v = ((torch.arange(H, device=dev, dtype=torch.float32) - K[1, 2]) / K[1, 1]).to(torch.float64)
+    pts_c = torch.stack([u[None, :].expand(H, W), v[:, None].expand(H, W), torch.ones_like(depth)], -1)
+    pts_c = pts_c * depth[..., None]                                  # geometry.py:150-171
+    pts_w = pts_c.reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    return {"pts": pts_w.float(), "mask": mask.reshape(-1).float(), "H": H, "W": W,
+            "intr_mat": intr_mat.to(dev).float().reshape(1, 3, 3), "T_wc": T_wc.to(dev).float().reshape(1, 4, 4),
+            "T_wc_host": T_wc.detach().cpu().numpy().astype(np.float32).reshape(4, 4),
+            "intr_host": intr_mat.detach().cpu().numpy().astype(np.float32).reshape(3, 3)}
+
+
+def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generator=None, points=None):
     """IterableInferenceDataset._sample_key_frame (fusion_inference_dataset.py:373-420) for a depth map
     already on the device: ``sampling_size`` random pixels with their back-projected world points, validity
-    and 3x3 neighbourhoods.  depth [H, W] metres; intr_mat [3, 3]; T_wc [4, 4] -> rays dict (batch 1)."""
+    and 3x3 neighbourhoods.  depth [H, W] metres; intr_mat [3, 3]; T_wc [4, 4] -> rays dict (batch 1).
+    ``points``: the frame's ``key_frame_points`` when the caller keeps them (NeuralMap.optimize does, per key frame:
+    the reference re-reads the depth image in DataLoader workers beside the optimiser, off its critical path)."""
+    if points is not None:
+        dev = points["pts"].device
+        H, W = points["H"], points["W"]
+        if generator is not None and generator.device.type == "cpu":
+            idx = torch.randperm(H * W, generator=generator)[:sampling_size].to(dev)
+        else:
+            idx = torch.randperm(H * W, device=dev, generator=generator)[:sampling_size]
+        px, py = idx % W, idx // W
+        r = torch.arange(-1, 2, device=dev)
+        oy, ox = torch.meshgrid(r, r, indexing="ij")
+        nidx = (py[:, None] + oy.reshape(-1)[None]).clamp(0, H - 1) * W + (px[:, None] + ox.reshape(-1)[None]).clamp(0, W - 1)
+        return {"uv": torch.stack([px, py], -1).float().unsqueeze(0),
+                "rgb": torch.zeros(1, len(idx), 3, device=dev),
+                "gt_pts": points["pts"][idx].unsqueeze(0),
+                "intr_mat": points["intr_mat"], "T_wc": points["T_wc"],
+                "T_wc_host": points["T_wc_host"], "intr_host": points["intr_host"],
+                "mask": points["mask"][idx].unsqueeze(0),
+                "neighbor_pts": points["pts"][nidx].unsqueeze(0),
+                "neighbor_masks": points["mask"][nidx].unsqueeze(0)}
     dev = depth.device
     intr_mat, T_wc = torch.as_tensor(intr_mat), torch.as_tensor(T_wc)
     depth = depth.to(torch.float64)
@@ -169,7 +214,7 @@ def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generat
 
 
 def ray_split_step(volume, rays, nerf, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
-                   generator=None, grad=None):
+                   generator=None, grad=None, return_pred=False):
     """calculate_loss + backward of one ray split with the fused kernels (csrc/rays.hip + the decode_pts
     forward / backward kernels): 6 launches instead of the ~180 of the torch formulation above, whose results
     it reproduces (same uniforms in the same order: fine strata first, then coarse).  ``d loss / d features`` is
@@ -206,14 +251,91 @@ def ray_split_step(volume, rays, nerf, truncated_units, truncated_dist, ray_max_
                                 _lib.ptr(loss), _lib.ptr(g), _lib.stream_ptr()), "bnv_ray_loss")
     if grad is not None:
         volume.decode_pts_backward(pts, nerf, g, grad)
-    return loss, pts
+    return (loss, pts, pred.view(n, S)) if return_pred else (loss, pts)
+
+
+def ray_batch_step(volume, rays, nerf, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
+                   generator=None, grad=None, train_ray_splits=1000, return_pred=False):
+    """ALL ray splits of one optimiser step at once (include/bnv_fusion.h: bnv_optim_step) -- what
+    ``for lo in range(0, n_rays, train_ray_splits): ray_split_step(...)`` computes (run_e2e.py:127-153), in 5 launches
+    instead of 6 per split: one sampling launch for every ray, count_optim of all splits recorded as per-row split masks,
+    ONE forward + loss + backward kernel whose mask decisions see exactly the weights the split-by-split sequence would
+    (weights[row] + 1 per split up to the query's own that touches the row), then the +1s applied.  The uniforms are drawn
+    split by split in the reference's order when the generator is a CPU generator (bit-for-bit the reference's stream);
+    with a device generator (or none) in two calls for the whole step.  ``d loss / d features`` of the SUM of the splits'
+    losses is ACCUMULATED into ``grad``; returns (sum of the splits' losses [1], pts [n, S, 3][, pred [n, S]])."""
+    lib = _lib.load()
+    uv = rays["uv"][0].float().contiguous()
+    dev = uv.device
+    n = int(uv.shape[0])
+    n_fine, n_coarse = int(truncated_units * 2), int(ray_max_dist * 5)
+    S = n_fine + n_coarse
+    per = int(train_ray_splits)
+    n_splits = -(-n // per)
+    if n_splits > 31:
+        raise ValueError(f"{n_splits} ray splits in one step (at most 31: raise train_ray_splits)")
+    if generator is not None and generator.device.type == "cpu":
+        uf, uc = [], []
+        for lo in range(0, n, per):                 # the reference's order: a split's fine strata, then its coarse ones
+            k = min(per, n - lo)
+            uf.append(torch.rand(1, k, n_fine, generator=generator))
+            uc.append(torch.rand(1, k, n_coarse, generator=generator))
+        u_f = torch.cat(uf, 1).to(dev).contiguous()
+        u_c = torch.cat(uc, 1).to(dev).contiguous()
+    else:
+        u_f = torch.rand((1, n, n_fine), device=dev, generator=generator)
+        u_c = torch.rand((1, n, n_coarse), device=dev, generator=generator)
+    T = rays["T_wc_host"] if rays.get("T_wc_host") is not None else rays["T_wc"].detach().cpu().numpy()
+    K = rays["intr_host"] if rays.get("intr_host") is not None else rays["intr_mat"].detach().cpu().numpy()
+    T = (C.c_float * 16)(*np.asarray(T, dtype=np.float32).reshape(-1)[:16].tolist())
+    K = (C.c_float * 9)(*np.asarray(K, dtype=np.float32).reshape(-1)[:9].tolist())
+    gt = rays["gt_pts"][0].float().contiguous()
+    rm = rays["mask"][0].float().contiguous()
+    nb = rays["neighbor_pts"][0].float().contiguous()
+    nbm = rays["neighbor_masks"][0].float().contiguous()
+    pts = torch.empty((n, S, 3), dtype=torch.float32, device=dev)
+    target = torch.empty((n, S), dtype=torch.float32, device=dev)
+    weight = torch.empty((n, S), dtype=torch.float32, device=dev)
+    _lib.check(lib.bnv_ray_samples(_lib.ptr(uv), _lib.ptr(gt), _lib.ptr(rm), _lib.ptr(nb), _lib.ptr(nbm),
+                                   int(nb.shape[1]), T, K, _lib.ptr(u_f), _lib.ptr(u_c), n, n_fine, n_coarse,
+                                   float(truncated_dist), _lib.ptr(pts), _lib.ptr(target), _lib.ptr(weight),
+                                   _lib.stream_ptr()), "bnv_ray_samples")
+    # per split: sum of its ray masks + 1e-4 (render_utils.py:553)
+    if n % per == 0:
+        n_valid = rm.view(n_splits, per).sum(1) + 1e-4
+    else:
+        n_valid = torch.stack([rm[lo: lo + per].sum() for lo in range(0, n, per)]) + 1e-4
+    n_valid = n_valid.float().contiguous()
+    split_samples = per * S
+    volume.count_optim_splits(pts, split_samples)
+    loss2 = torch.zeros(2, dtype=torch.float32, device=dev)
+    pred = torch.empty((n, S), dtype=torch.float32, device=dev) if return_pred else None
+    if grad is None:
+        grad = torch.zeros_like(volume.features.detach())        # (the kernel needs somewhere to accumulate)
+    if _lib.model_mode(nerf) == 2 or not hasattr(nerf, "sdf_bwd_pack"):
+        # tiny-cuda-nn decoder: its own forward / backward kernels, all splits per launch
+        p = volume.decode_pts_splits(pts, nerf, sdf_delta, split_samples)
+        g = torch.empty_like(p)
+        _lib.check(lib.bnv_ray_loss_splits(_lib.ptr(p), _lib.ptr(target), _lib.ptr(weight), _lib.ptr(n_valid), n * S,
+                                           split_samples, _lib.ptr(loss2), _lib.ptr(g), _lib.stream_ptr()),
+                   "bnv_ray_loss_splits")
+        volume.decode_pts_backward_splits(pts, nerf, g, grad, split_samples)
+        if pred is not None:
+            pred.copy_(p.view(n, S))
+    else:
+        volume.optim_step(pts, nerf, sdf_delta, split_samples, target, weight, n_valid, loss2, grad, pred)
+    volume.apply_split_counts()
+    out = (loss2[:1], pts)
+    return out + (pred,) if return_pred else out
 
 
 def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, ray_max_dist, sdf_delta=None,
-                    train_ray_splits=1000, lr=0.001, generator=None, fused=True):
+                    train_ray_splits=1000, lr=0.001, generator=None, fused=True, batched=True):
     """NeuralMap.optimize (run_e2e.py:111-162): Adam on ``volume.features`` over an iterable of ray
     batches, ``train_ray_splits`` rays per backward, then the optimised features are written back into the
-    hash volume.  Returns the list of per-iteration losses (device scalars)."""
+    hash volume.  Returns the list of per-iteration losses (device scalars).  ``fused``: the HIP ray kernels instead of
+    the torch formulation; ``batched`` (with ``fused``): all splits of a step per launch (ray_batch_step) instead of split
+    by split (ray_split_step) -- same decisions, same weights, gradients equal up to the order of float atomics."""
     volume.to_tensor()
     volume.features = torch.nn.Parameter(volume.features)
     optimizer = torch.optim.Adam([volume.features], lr=lr)
@@ -230,6 +352,14 @@ def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, 
         if fused and volume.features.grad is None:
             volume.features.grad = torch.zeros_like(volume.features)
         whole = ("T_wc", "intr_mat", "T_wc_host", "intr_host")
+        if fused and batched and -(-n_rays // train_ray_splits) <= 31:
+            # every split of the step in one set of launches (same mask decisions, same count_optim as split by split)
+            loss, _ = ray_batch_step(volume, rays, nerf, truncated_units, truncated_dist, ray_max_dist,
+                                     sdf_delta=sdf_delta, generator=generator, grad=volume.features.grad,
+                                     train_ray_splits=train_ray_splits)
+            optimizer.step()
+            history.append(loss[0])
+            continue
         for lo in range(0, n_rays, train_ray_splits):
             part = {k: (v[:, lo: lo + train_ray_splits] if k not in whole else v) for k, v in rays.items()}
             if fused:

@@ -433,6 +433,69 @@ class SparseVolume:
                                                         _lib.ptr(self._stamp), self._epoch, _lib.stream_ptr()),
                    "bnv_volume_count_optim_pts")
 
+    # ---- all ray splits of an optimiser step at once (include/bnv_fusion.h: bnv_optim_step) -------------------------
+    def _split_mask(self):
+        """uint32 per row of the to_tensor() snapshot, zero between steps (bnv_volume_apply_split_counts clears it)."""
+        m = getattr(self, "_split_mask_buf", None)
+        if m is None or m.numel() < self._row_capacity:
+            m = self._split_mask_buf = torch.zeros(self._row_capacity, dtype=torch.int32, device=self._dev)
+        return m
+
+    def count_optim_splits(self, pts, split_samples, is_coords=False):
+        """count_optim (sparse_volume.py:602-622) of every split of a step, deferred: records in the split mask which
+        splits touch which row (sample q of ``pts`` belongs to split q // split_samples); the weights change when
+        ``apply_split_counts`` is called, behind the decodes that need the per-split values."""
+        f, w, h, lim = self._snapshot()
+        p = pts.detach().reshape(-1, 3).float().contiguous()
+        _lib.check(self._lib.bnv_volume_count_optim_splits(
+            C.byref(self._struct()), C.byref(self._grid), _lib.ptr(p), int(p.shape[0]), 1 if is_coords else 0, lim,
+            int(split_samples), _lib.ptr(self._split_mask()), _lib.stream_ptr()), "bnv_volume_count_optim_splits")
+
+    def apply_split_counts(self):
+        f, w, h, lim = self._snapshot()
+        _lib.check(self._lib.bnv_volume_apply_split_counts(_lib.ptr(w), _lib.ptr(self._split_mask()), lim,
+                                                           _lib.stream_ptr()), "bnv_volume_apply_split_counts")
+
+    def optim_step(self, pts, nerf, sdf_delta, split_samples, target, sample_weight, n_valid, loss2, grad_features,
+                   pred=None):
+        """Forward + L1 ray loss + backward of all samples of a step in ONE launch (fp32 decoders).  ``loss2``: float
+        [2], zero on entry ([0] accumulates the loss, [1] is the kernel's work counter)."""
+        grid = self._grid_for(nerf)
+        f, w, _, lim = self._snapshot()
+        c = pts.detach().reshape(-1, 3).float().contiguous()
+        d, keep = self._delta(sdf_delta)
+        assert grad_features.shape == f.shape and grad_features.is_contiguous()
+        _lib.check(self._lib.bnv_optim_step(
+            C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack),
+            _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]), 0, C.byref(d), _lib.ptr(self._split_mask()),
+            int(split_samples), _lib.ptr(target), _lib.ptr(sample_weight), _lib.ptr(n_valid), _lib.ptr(loss2),
+            _lib.ptr(pred), _lib.ptr(grad_features), _lib.stream_ptr()), "bnv_optim_step")
+
+    def decode_pts_splits(self, pts, nerf, sdf_delta, split_samples):
+        """bnv_decode_pts whose mask decisions see the deferred count_optim of the splits (tiny-cuda-nn decoders, tests)."""
+        grid = self._grid_for(nerf)
+        c = pts.detach().reshape(-1, 3).float().contiguous()
+        f, w, _, lim = self._snapshot()
+        d, keep = self._delta(sdf_delta)
+        out = torch.empty(int(c.shape[0]), dtype=torch.float32, device=self._dev)
+        _lib.check(self._lib.bnv_decode_pts_splits(
+            C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack),
+            _lib.ptr(c), int(c.shape[0]), 0, C.byref(d), _lib.ptr(self._split_mask()), int(split_samples),
+            _lib.ptr(out), _lib.stream_ptr()), "bnv_decode_pts_splits")
+        return out
+
+    def decode_pts_backward_splits(self, pts, nerf, grad_sdf, grad_features, split_samples):
+        grid = self._grid_for(nerf)
+        f, w, _, lim = self._snapshot()
+        c = pts.detach().reshape(-1, 3).float().contiguous()
+        g = grad_sdf.detach().reshape(-1).float().contiguous()
+        assert grad_features.shape == f.shape and grad_features.is_contiguous()
+        _lib.check(self._lib.bnv_decode_pts_backward_splits(
+            C.byref(self._struct()), C.byref(grid), _lib.ptr(f), _lib.ptr(w), int(lim), _lib.ptr(nerf.sdf_pack),
+            _lib.ptr(nerf.sdf_bwd_pack), _lib.ptr(c), int(c.shape[0]), 0, _lib.ptr(self._split_mask()),
+            int(split_samples), _lib.ptr(g), _lib.ptr(grad_features), _lib.stream_ptr()),
+            "bnv_decode_pts_backward_splits")
+
     def decode_pts_backward(self, coords, nerf, grad_sdf, grad_features, is_coords=False):
         """Accumulates d(sum(grad_sdf * decode_pts(coords))) / d features into ``grad_features`` [M, 8] (the
         to_tensor() snapshot rows).  The autograd edge of decode_pts calls this; the fused optimiser step too."""

@@ -497,6 +497,47 @@ int bnv_volume_count_optim_pts(const bnv_volume_t* vol_host, const bnv_grid_t* g
                                int64_t m, int is_coords, float* weights, int64_t row_limit,
                                int32_t* stamp, int32_t epoch, bnv_stream_t stream);
 
+/* ---- one optimiser step in a handful of launches (round 6).  NeuralMap.optimize (run_e2e.py:111-162) cuts a step's
+ * 5,000 rays into splits of train_ray_splits = 1,000 and runs render_with_rays -> count_optim -> decode_pts -> loss ->
+ * backward split by split (render_utils.py:461-590).  What couples the splits is count_optim: a split's mask
+ * decisions (min over the 8 corner weights >= min_pts, sparse_volume.py:816-818) see the +1s of the splits before it
+ * and its own.  These entries run ALL splits of a step together and keep every decision: sample q belongs to split
+ * q / split_samples (at most 31 splits);
+ *   bnv_volume_count_optim_splits  bit s of split_mask[row] (uint32 per row of the to_tensor() snapshot, zeroed once by
+ *                                  the caller) = split s touches the row; weights are NOT changed yet;
+ *   bnv_decode_pts_splits / bnv_decode_pts_backward_splits   bnv_decode_pts / _backward whose corner weights are
+ *                                  weights[row] + 1 per split <= the query's that touches the row (exact fp32 adds);
+ *   bnv_ray_loss_splits            bnv_ray_loss with one n_valid per split;
+ *   bnv_optim_step                 forward + loss + backward of all samples in ONE kernel (fp32 decoder, split-f16
+ *                                  arithmetic as bnv_decode_pts_backward): the L1 loss is elementwise, so a query's
+ *                                  gradient is known in the tile that computes its value.  loss_and_counter: float[2],
+ *                                  zeroed by the caller -- [0] accumulates the sum of the splits' losses, [1] is the
+ *                                  kernel's chunk counter; pred (optional) [n] gets the decoded SDF; grad_features is
+ *                                  accumulated into like bnv_decode_pts_backward's;
+ *   bnv_volume_apply_split_counts  weights[row] += 1 per set bit (sequential adds), masks cleared: the state the
+ *                                  split-by-split sequence leaves. */
+int bnv_volume_count_optim_splits(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* pts, int64_t m,
+                                  int is_coords, int64_t row_limit, int64_t split_samples, uint32_t* split_mask,
+                                  bnv_stream_t stream);
+int bnv_volume_apply_split_counts(float* weights, uint32_t* split_mask, int64_t n_rows, bnv_stream_t stream);
+int bnv_decode_pts_splits(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                          const float* weights, int64_t row_limit, const float* sdfmlp_pack, const float* coords,
+                          int64_t n, int is_coords, const bnv_sdf_delta_t* delta_host, const uint32_t* split_mask,
+                          int64_t split_samples, float* out_sdf, bnv_stream_t stream);
+int bnv_decode_pts_backward_splits(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                                   const float* weights, int64_t row_limit, const float* sdfmlp_pack,
+                                   const float* sdfmlp_bwd_pack, const float* coords, int64_t n, int is_coords,
+                                   const uint32_t* split_mask, int64_t split_samples, const float* grad_sdf,
+                                   float* grad_features, bnv_stream_t stream);
+int bnv_ray_loss_splits(const float* pred, const float* target, const float* weight, const float* n_valid, int64_t m,
+                        int64_t split_samples, float* loss, float* grad, bnv_stream_t stream);
+int bnv_optim_step(const bnv_volume_t* vol_host, const bnv_grid_t* grid_host, const float* features,
+                   const float* weights, int64_t row_limit, const float* sdfmlp_pack, const float* sdfmlp_bwd_pack,
+                   const float* pts, int64_t n, int is_coords, const bnv_sdf_delta_t* delta_host,
+                   const uint32_t* split_mask, int64_t split_samples, const float* target, const float* sample_weight,
+                   const float* n_valid, float* loss_and_counter, float* pred, float* grad_features,
+                   bnv_stream_t stream);
+
 /* ---- per-voxel marching cubes on decoded lattices -------------------------------------------- */
 
 /* SparseVolume.meshlize after the decode (sparse_volume.py:740-756): for every voxel whose 3x3x3

@@ -424,3 +424,51 @@ def test_first_touch_tables_keep_the_exchange_invariant(rule):
         if rule == "region":
             assert m.interleave == drifting
         assert m.load.max() <= (1.6 if rule == "region" else 1.25) * m.load.mean()
+
+
+def _contact_worker(rank, world, port, ret, same_identity):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bnv_fusion_amd.distributed import first_contact
+    try:
+        ret[rank] = first_contact(rank, world, "cpu", backend="gloo", timeout_s=30.0, records=64,
+                                  identity=("box", 7) if same_identity else None)
+    except RuntimeError as e:
+        ret[rank] = str(e)
+    dist.destroy_process_group()
+
+
+def test_first_contact_reports_and_checks_the_rank_set():
+    """bnv_fusion_amd.distributed.first_contact (bench.py --gpus N runs it before the timed region): every rank's
+    identity and the backend's own rank count come back, five frame-shaped all-gathers complete inside their timeout
+    and their data is checked; two ranks that claim the SAME device are refused with a message naming them; a world
+    size that contradicts the launcher is refused."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_contact_worker, args=(2, _free_port(), ret, False), nprocs=2, join=True)
+        for r in (0, 1):
+            c = ret[r]
+            assert isinstance(c, dict), c
+            assert c["ranks_seen_by_backend"] == 2 and c["distinct_devices"] == 2
+            assert [x["rank"] for x in c["ranks"]] == [0, 1] and c["ranks"][0]["pid"] != c["ranks"][1]["pid"]
+            fc = c["first_contact"]
+            assert fc["all_gathers"] == 5 and len(fc["ms_this_rank"]) == 5 and fc["data_checked"]
+            assert fc["bytes_per_rank"] == 65 * 48
+        ret2 = mgr.dict()
+        mp.spawn(_contact_worker, args=(2, _free_port(), ret2, True), nprocs=2, join=True)
+        assert all(isinstance(ret2[r], str) and "share a device" in ret2[r] and "[[0, 1]]" in ret2[r] for r in (0, 1))
+
+
+def test_first_contact_refuses_a_wrong_world_size():
+    import torch.distributed as dist
+    from bnv_fusion_amd.distributed import first_contact
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(RuntimeError, match="reports 1 ranks, the launcher said 2"):
+            first_contact(0, 2, "cpu", backend="gloo")
+        c = first_contact(0, 1, "cpu", backend="gloo", n_gathers=2)
+        assert c["ranks_seen_by_backend"] == 1 and c["rccl_version"] is None
+    finally:
+        dist.destroy_process_group()

@@ -266,3 +266,99 @@ def test_fused_ray_split_equals_the_torch_formulation(bnv, model):
     assert abs(float(loss) - float(l2.detach())) <= 1e-5 * float(l2.detach())
     assert (grad - vol2.features.grad).abs().max() <= 1e-4 * vol2.features.grad.abs().max()
     assert torch.equal(vol.weights, vol2.weights)
+
+
+def _split_rays(rays, lo, hi):
+    whole = ("T_wc", "intr_mat", "T_wc_host", "intr_host")
+    return {k: (v if k in whole else v[:, lo:hi]) for k, v in rays.items()}
+
+
+@pytest.mark.parametrize("with_delta", [False, True])
+def test_batched_step_equals_split_by_split(bnv, model, with_delta):
+    """optimize.ray_batch_step (bnv_optim_step: ALL ray splits of a step in one forward + loss + backward launch, the
+    count_optim of the splits deferred as per-row split masks) against the split-by-split sequence of ray_split_step
+    (count_optim -> decode_pts -> loss -> backward per split, the reference's order run_e2e.py:127-153): same sample
+    points, the same mask decision for every sample -- with weights set so that a corner only goes live once TWO splits
+    have touched it, i.e. the decisions differ from split to split --, same values, same loss, same gradient, and the
+    same weights afterwards, bit for bit."""
+    from bnv_fusion_amd import optimize
+    dec = np.load(os.path.join(GOLDEN, "decode_64.npz"))
+    op = np.load(os.path.join(GOLDEN, "optimize_64.npz"))
+    rays = {k[5:]: torch.from_numpy(op[k]).to(DEV) for k in op.files if k.startswith("rays_")}
+    delta = torch.from_numpy(dec["sdf_delta"]).to(DEV) if with_delta else None
+    args = (int(op["truncated_units"]), float(op["truncated_dist"]), int(op["ray_max_dist"]))
+    n, per = int(rays["uv"].shape[1]), 40            # 4 splits of 40 rays x 35 samples (1,400: not a multiple of a chunk)
+    vols = []
+    for _ in range(2):
+        v = _insertion_order_volume(bnv)
+        v.weights.copy_(torch.clamp(v.weights, max=6.5))      # live needs 6.5 + 1 + 1: two splits must touch a corner
+        v.features = torch.nn.Parameter(v.features)
+        vols.append(v)
+    va, vb = vols
+    # A: split by split
+    gen = torch.Generator().manual_seed(7)
+    grad_a = torch.zeros_like(va.features)
+    loss_a, pts_a, pred_a = [], [], []
+    for lo in range(0, n, per):
+        l, p, q = optimize.ray_split_step(va, _split_rays(rays, lo, lo + per), model.nerf, *args, sdf_delta=delta,
+                                          generator=gen, grad=grad_a, return_pred=True)
+        loss_a.append(l)
+        pts_a.append(p)
+        pred_a.append(q)
+    pts_a, pred_a = torch.cat(pts_a), torch.cat(pred_a)
+    # B: all splits at once
+    grad_b = torch.zeros_like(vb.features)
+    loss_b, pts_b, pred_b = optimize.ray_batch_step(vb, rays, model.nerf, *args, sdf_delta=delta,
+                                                    generator=torch.Generator().manual_seed(7), grad=grad_b,
+                                                    train_ray_splits=per, return_pred=True)
+    assert torch.equal(pts_a, pts_b)
+    assert torch.equal(va.weights, vb.weights)                       # count_optim: same +1s, same float sums
+    assert not vb._split_mask().any()                                # the masks are clear for the next step
+    voxel = float(va.voxel_size)
+    masked_a = pred_a == voxel if delta is None else None
+    if masked_a is not None:
+        masked_b = pred_b == voxel
+        assert torch.equal(masked_a, masked_b)                       # every mask decision
+        live = (~masked_a).view(n // per, -1).float().mean(1)
+        assert float(live[0]) == 0.0 and float(live[-1]) > 0.02 and float(live[1]) > 0.0, live   # they DO differ by split
+    assert float((pred_a - pred_b).abs().max()) <= 2e-7
+    la = float(sum(float(x) for x in loss_a))
+    assert abs(float(loss_b) - la) <= 2e-6 * abs(la)
+    assert float(grad_a.abs().max()) > 0
+    assert float((grad_a - grad_b).abs().max()) <= 2e-5 * float(grad_a.abs().max())
+
+
+def test_batched_optimize_follows_the_split_by_split_optimiser(bnv):
+    """NeuralMap.optimize through optimize_volume(batched=True) -- one fused launch per step -- against batched=False
+    (round 5's split-by-split step) from the same generator: the same losses step for step (to float-atomics order) and
+    the same final weights (count_optim) bit for bit."""
+    from bnv_fusion_amd import optimize, synthetic
+    dims, voxel = synthetic.GRID_DIMS[128]
+    outs = []
+    for batched in (True, False):
+        model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
+        nm = bnv.NeuralMap(np.array([dims] * 3), voxel, model, capacity=200000, device=DEV, tsdf=False)
+        H, W = 240, 320
+        for t in range(0, 20, 2):
+            frame = {"depth": torch.from_numpy(synthetic.depth_u16(t, H, W)).to(DEV),
+                     "intr_mat": synthetic.intrinsics(H, W), "T_wc": synthetic.pose(t)}
+            nm.integrate(frame)
+            nm.frames.append(frame)
+        gen = torch.Generator().manual_seed(3)
+
+        def batches():
+            for i in range(6):
+                f = nm.frames[i % len(nm.frames)]
+                yield optimize.sample_key_frame(f["depth"].float() / 1000.0, f["intr_mat"], f["T_wc"], 2500, 3, gen)
+
+        hist = optimize.optimize_volume(nm.volume, model.nerf, batches(), nm.truncated_units, nm.truncated_dist, 3,
+                                        train_ray_splits=500, generator=gen, batched=batched)
+        outs.append((torch.stack([h.reshape(()) for h in hist]).cpu(), nm.volume.weights.clone(),
+                     nm.volume.features.clone()))
+    (ha, wa, fa), (hb, wb, fb) = outs
+    assert torch.equal(wa, wb)
+    assert float((ha[0] - hb[0]).abs() / hb[0].abs()) <= 1e-5, (ha, hb)      # the first step: identical inputs
+    # later steps: Adam's first updates are +-lr whatever a gradient's size, so an entry whose gradient is rounding
+    # noise around zero (float atomics sum in no fixed order, in either path) can step the other way
+    assert float(((ha - hb).abs() / hb.abs()).max()) <= 2e-3, (ha, hb)
+    assert float((fa - fb).abs().max()) <= 1.3e-2 and float((fa - fb).abs().mean()) <= 1e-4
