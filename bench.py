@@ -280,7 +280,7 @@ def _event_ms(fn, reps, stream=None):
     return e0.elapsed_time(e1) / reps
 
 
-def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
+def optimize_entry(nm, model, frames, mlp_mode, n_iters=200):
     """SURVEY.md section 8 f-3, the global optimiser at the reference's configuration (run_e2e.py:111-162,
     fusion_pointnet_model.yaml): Adam steps on the volume features, 5,000 rays of a random key frame per step in splits
     of 1,000 rays, 20 fine + 15 coarse samples per ray.  -> steps/s ("speed on global fusion", run_e2e.py:289), the two
@@ -292,19 +292,30 @@ def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
     voxel = nm.volume.voxel_size
     nm.frames = list(frames)
     gen = torch.Generator(device=dev).manual_seed(0)
-    nm.optimize(n_iters=3, last_frame=-1, generator=gen)                     # warm-up (allocations, Adam state)
+    nm.optimize(n_iters=40, last_frame=-1, generator=gen)     # warm-up (allocations, Adam state, the key frames' points)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hist = nm.optimize(n_iters=n_iters, last_frame=-1, generator=gen)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # ---- one split (1,000 rays x 35 samples) through the two kernels alone
     vol = nm.volume
     vol.to_tensor()
     vol.features = torch.nn.Parameter(vol.features)
     f = frames[3]
     d = f["depth"]
     d = d.to(torch.float32) / 1000.0 if d.dtype in (torch.uint16, torch.int16) else d
+    # ---- the step's fused launch set (round 6): all 5 splits sampled, counted, decoded forward + loss + backward in ONE
+    # kernel (k_optim_step), the counts applied -- timed with HIP events on a fixed ray batch
+    rays5 = optimize.sample_key_frame(d, f["intr_mat"], f["T_wc"], 5000, 3, generator=gen)
+    grad5 = torch.zeros_like(vol.features)
+    w_keep = vol.weights.clone()
+    _, _, pred5 = optimize.ray_batch_step(vol, rays5, model.nerf, nm.truncated_units, nm.truncated_dist, 3,
+                                          generator=gen, grad=grad5, return_pred=True)
+    live5 = int((pred5 != voxel).sum())
+    step_ms = _event_ms(lambda: optimize.ray_batch_step(vol, rays5, model.nerf, nm.truncated_units, nm.truncated_dist, 3,
+                                                        generator=gen, grad=grad5), 20)
+    vol.weights.copy_(w_keep)            # (the timing loop's count_optim calls are not part of the optimisation)
+    # ---- one split (1,000 rays x 35 samples) through the separate forward / backward kernels (decode_pts + autograd)
     rays = optimize.sample_key_frame(d, f["intr_mat"], f["T_wc"], 1000, 3, generator=gen)
     with torch.no_grad():
         out = optimize.render_with_rays(vol, rays, model.nerf, None, nm.truncated_units, nm.truncated_dist, 3, generator=gen)
@@ -363,10 +374,18 @@ def optimize_entry(nm, model, frames, mlp_mode, n_iters=40):
     vol.features = vol.features.detach()
     live_s = float((ref.detach() != voxel).float().mean())
     return {"what": "NeuralMap.optimize (run_e2e.py:111-162): Adam steps on the volume features; 5,000 rays of a random "
-                    "key frame per step in 5 splits of 1,000 rays x (20 fine + 15 coarse) samples, decode_pts forward + "
-                    "backward per split",
+                    "key frame per step in 5 splits of 1,000 rays x (20 fine + 15 coarse) samples; all splits of a step in "
+                    "one forward + loss + backward launch (bnv_optim_step), mask decisions and count_optim those of the "
+                    "split-by-split sequence",
             "value": n_iters / dt, "unit": "optimisation steps/s", "ms_per_step": 1e3 * dt / n_iters, "steps": n_iters,
             "volume_rows": int(vol.num_rows()), "loss_first": float(hist[0]), "loss_last": float(hist[-1]),
+            "step_launch_set": {"what": "optimize.ray_batch_step on a fixed batch of 5,000 rays: k_ray_samples + "
+                                        "k_count_optim_splits + k_optim_step (forward + L1 loss + backward of all 5 splits) "
+                                        "+ k_apply_split_counts + 2 uniform draws",
+                                "avg_ms": step_ms, "queries": int(pred5.numel()), "live_queries_first_call": live5,
+                                "algorithmic_tflops": 3 * live5 * 8.0 * FLOP_PER_EVAL / (step_ms * 1e-3) / 1e12,
+                                "frac_of_peak": 3 * live5 * 8.0 * FLOP_PER_EVAL / (step_ms * 1e-3) / 1e12 / PEAK_TFLOPS[mlp_mode],
+                                "algorithmic_flop": "live queries x 8 corners x 402,432 x 3 (forward + 2 x backward)"},
             "split": {"queries": n_q, "live_queries": live,
                       "k_decode_pts": {"avg_ms": fwd_ms, "tflops": flop_fwd / (fwd_ms * 1e-3) / 1e12,
                                        "frac_of_peak": flop_fwd / (fwd_ms * 1e-3) / 1e12 / peak,

@@ -302,20 +302,24 @@ class NeuralMap:
         cpu_gen = generator if (generator is not None and generator.device.type == "cpu") else None
 
         from .optimize import key_frame_points
-        cache = {}        # per key frame: every pixel's world point + validity (7.4 MB per 640x480 frame; at most 64 kept)
+        # per key frame: every pixel's world point + validity (4.9 MB per 640x480 frame; the 256 used last are kept,
+        # across calls: the reference's DataLoader workers re-read the depth image beside the optimiser)
+        cache = self.__dict__.setdefault("_key_frame_points", {})
 
         def batches():
             for _ in range(n_iters):
                 k = int(torch.randint(lo, len(self.frames), (1,), generator=cpu_gen))
                 f = self.frames[k]
-                pts = cache.get(k)
+                hit = cache.get(id(f))
+                pts = hit[1] if hit is not None and hit[0] is f and hit[2] == ray_max_dist else None
                 if pts is None:
                     d = f["depth"]
                     if d.dtype in (torch.uint16, torch.int16):
                         d = d.to(torch.float32) / 1000.0
                     pts = key_frame_points(d, f["intr_mat"], f["T_wc"], ray_max_dist)
-                    if len(cache) < 64:
-                        cache[k] = pts
+                    if len(cache) >= 256:
+                        cache.pop(next(iter(cache)))
+                    cache[id(f)] = (f, pts, ray_max_dist)
                 yield sample_key_frame(None, None, None, sampling_size, ray_max_dist, generator, points=pts)
 
         return optimize_volume(self.volume, self.pointnet.nerf, batches(), self.truncated_units,
