@@ -435,7 +435,8 @@ class HipShardBackend:
     holds the previous frame) and ``result``."""
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
-                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None):
+                 device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None,
+                 schedule=None, encoder_workgroups=None):
         from .sparse_volume import SparseVolume, make_grid
         import os
         ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
@@ -478,6 +479,8 @@ class HipShardBackend:
         self.copy_results = True          # False: result() returns views into the slot buffers (valid for n_slots - 1 more frames)
         self.pipe = None
         self._recv = None
+        self._pipe_kw = {k: v for k, v in (("schedule", schedule), ("encoder_workgroups", encoder_workgroups))
+                         if v is not None}
         self._last_evals = 0
         self.last_owned_pairs = 0
 
@@ -487,7 +490,7 @@ class HipShardBackend:
             from .pipeline import FramePipe
             assert self.pipe is None or not any(self.pipe._busy), "a larger frame arrived while frames are in flight"
             self.pipe = FramePipe(self.volume, self.pointnet, n, n_slots=self.n_slots, tsdf_vol=self.tsdf_vol,
-                                  max_depth=self.max_depth)
+                                  max_depth=self.max_depth, **self._pipe_kw)
         self.pipe.inputs_resident = self.inputs_resident
         self.pipe.sdf_delta = self.sdf_delta
         return self.pipe
