@@ -2,7 +2,7 @@
 # Collects everything profiles/<round>_* is built from (run on the GPU box through gpurun; tools/make_profiles.py then
 # builds the committed summaries from gpurun_out/).  Kernel trace and PMC passes are separate runs, as the pool requires.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 sha256sum bnv_fusion_amd/csrc/decode.hip > $O/decode_hip.sha256
@@ -29,6 +29,9 @@ GPU_MAX_HW_QUEUES=4 python3 tools/queue_probe.py 2>&1 | grep "prio\|MAX" > $O/qu
 python3 tools/mlp_launch_overhead.py 2>&1 | grep -v "$F" > $O/mlp_launch_overhead.txt
 # the widened rows (global optimiser, whole-volume mesh extraction): their kernels in a trace of their own
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_widened -o w -- python3 tools/bench_optimize.py > $O/trace_widened_stdout.log 2>&1
+# the optimiser loop alone: steps/s over 40 and 200 steps, the step's phases synchronised, and its kernel table
+python3 tools/optimize_profile.py 2>&1 | grep -v "$F" > $O/optimize_profile.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_optimize -o opt -- python3 tools/optimize_profile.py > $O/trace_optimize_stdout.log 2>&1
 python3 tools/fp_single_rank.py --replay 8 > $O/fp_replay8.txt 2>&1
 # functional only: both multi-GPU decompositions as two gloo ranks sharing this GPU (no RCCL: it refuses two ranks per GPU)
 BNV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --no-cpu-baseline 2> $O/bench_line_2rank_gloo.err | tail -1 > $O/bench_line_2rank_gloo.json

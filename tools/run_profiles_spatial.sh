@@ -2,7 +2,7 @@
 # The multi-GPU part of tools/run_profiles.sh: the spatially sharded frame priced on one GPU, every rank, with the other
 # ranks' real ghost rows (tools/spatial_single_rank.py).  bash tools/run_profiles_spatial.sh r05
 set -u
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -13,6 +13,11 @@ F="RCCL\|HIP version\|ROCm version\|Hostname\|Librccl\|socket.cpp\|amdgpu.ids"
 # 256^3 and 512^3, the room sweep (a camera that turns and walks) under both rules; then worlds 2 and 4
 SP="python3 tools/spatial_single_rank.py --all-ranks --in-flight 3"
 $SP --world 8 --frames 2000 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256.txt
+# ... and with 30 us of simulated collective latency behind the stand-in all-gather (VERDICT r05 item 1's condition)
+$SP --world 8 --frames 2000 --exchange-delay 30 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_delay30.txt
+$SP --world 8 --frames 2000 --grid 512 --exchange-delay 30 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512_delay30.txt
+# ... and round 5's schedule (no encoder gate, TSDF on the encode stream, every event wait enqueued) on the same box
+$SP --world 8 --frames 2000 --schedule 0 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_r05_schedule.txt
 $SP --world 8 --frames 2000 --ownership first_touch 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_first_touch.txt
 $SP --world 8 --frames 2000 --grid 512 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512.txt
 $SP --world 8 --frames 1000 --scene sweep 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_sweep.txt
