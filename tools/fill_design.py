@@ -10,7 +10,7 @@ import re
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 P = lambda name: os.path.join(root, "profiles", f"{R}_{name}")      # noqa: E731
 
 
@@ -62,6 +62,12 @@ if opt:
               "OPT_ERR": f"{opt['parity']['sdf_max_abs_err_vs_oracle']:.1e}",
               "OPT_GERR": f"{opt['parity']['grad_max_err_over_max_grad_vs_oracle_autograd']:.1e}",
               "OPT_CPU": f"{opt['cpu_baseline']['value']:.2f}"})
+    sl = opt.get("step_launch_set")
+    if sl:
+        V.update({"OPT_STEP_MS": f"{sl['avg_ms']:.3f}", "OPT_STEP_LIVE": f"{sl['live_queries_first_call']:,}",
+                  "OPT_STEP_FRAC": f"{sl['frac_of_peak']:.3f}"})
+if d.get("tcnn_quick"):
+    V["TCNN_QUICK"] = f"{d['tcnn_quick']['value']:.0f}"
 if me and ms:
     V.update({"MESH_VOX": f"{me['active_voxels']:,}", "MESH_MS": f"{me['value']:.1f}",
               "MESH_CPU": f"{ms['cpu_baseline']['value'] / 1e3:.0f}", "MESHS_MS": f"{ms['value']:.1f}",
@@ -91,6 +97,9 @@ def spatial(name):
 
 
 rows = [("world 8, pan 256³, **region** (default)", "spatial_world8_all_ranks_256"),
+        ("… with 30 µs of simulated collective latency (`--exchange-delay 30`)", "spatial_world8_all_ranks_256_delay30"),
+        ("… under round 5's order of launches (`--schedule 0`), same box", "spatial_world8_all_ranks_256_r05_schedule"),
+        ("world 8, pan 512³, region, 30 µs of collective latency", "spatial_world8_all_ranks_512_delay30"),
         ("world 8, pan 256³, first touch 8³ (round 4's rule)", "spatial_world8_all_ranks_256_first_touch"),
         ("world 8, pan 512³, region", "spatial_world8_all_ranks_512"),
         ("world 8, room sweep 256³, region (falls back to the interleave)", "spatial_world8_all_ranks_sweep"),
@@ -119,6 +128,13 @@ if w8:
     V["W8_MS"] = w8["max_ms"]
     V["W8_X"] = f"{single_ms / float(w8['max_ms']):.2f}"
     V["W8_X2"] = f"{single_ms / (float(w8['max_ms']) + 0.012):.2f}"
+w8d = spatial("spatial_world8_all_ranks_256_delay30")
+if w8d:
+    V["W8D_MS"] = w8d["max_ms"]
+    V["W8D_X"] = f"{single_ms / float(w8d['max_ms']):.2f}"
+w8d5 = spatial("spatial_world8_all_ranks_512_delay30")
+if w8d5:
+    V["W8D512_MS"] = w8d5["max_ms"]
 
 src = open(os.path.join(root, "tools", "design_template.md")).read()
 missing = set()
