@@ -148,7 +148,11 @@ def post_process_mesh(mesh, vertex_threshold=0.005):
     ``merge_close_vertices(eps)`` replaces every cluster of vertices closer than ``eps`` by its mean -- here a cluster
     is a connected component of the "closer than eps" graph, Open3D grows clusters greedily in vertex order, which
     differs where chains of near vertices exist; ``filter_smooth_simple(1)``: v <- (v + sum of its edge neighbours) /
-    (1 + their number).  -> a new TriMesh."""
+    (1 + their number).  Unreferenced vertices: the reference's Open3D chain does NOT drop them (its
+    ``remove_unreferenced_vertices`` call is commented out, o3d_helper.py:230) but hands the result to
+    ``trimesh.Trimesh(vertices, faces)`` with the default ``process=True``, whose vertex merge keeps referenced vertices
+    only [from memory of trimesh 3.x] -- so they are dropped here; against Open3D's intermediate mesh the vertex count and
+    the face indices can therefore differ (same surface).  -> a new TriMesh."""
     from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import connected_components
     from scipy.spatial import cKDTree
