@@ -349,7 +349,6 @@ def first_contact(rank, world, device, group=None, backend=None, n_gathers=5, ti
       of the launcher).
 
     -> a dict for the bench line's ``distributed`` entry.  CPU backends (gloo) run the same checks on host tensors."""
-    import datetime
     import os
     import socket
     import time
@@ -392,16 +391,23 @@ def first_contact(rank, world, device, group=None, backend=None, n_gathers=5, ti
             torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+        # the HOST polls with its own deadline (with RCCL, work.wait() only orders the current stream behind the
+        # collective and a device synchronisation on a wedged collective would never return)
+        t_end = t0 + float(timeout_s)
         try:
-            done = work.wait(datetime.timedelta(seconds=float(timeout_s)))
+            while not work.is_completed():
+                if time.perf_counter() > t_end:
+                    raise RuntimeError(f"first contact: all-gather {k + 1} of {n_gathers} did not complete within "
+                                       f"{timeout_s} s on rank {rank} ({seen} ranks, {words * 4} bytes per rank)")
+                time.sleep(0.0005)
+            work.wait()
             if on_gpu:
                 torch.cuda.synchronize(dev)
+        except RuntimeError:
+            raise
         except Exception as e:       # noqa: BLE001 -- the backend's own timeout / abort
             raise RuntimeError(f"first contact: all-gather {k + 1} of {n_gathers} failed on rank {rank} "
                                f"({seen} ranks, {words * 4} bytes per rank): {type(e).__name__}: {e}") from e
-        if done is False:
-            raise RuntimeError(f"first contact: all-gather {k + 1} of {n_gathers} did not complete within {timeout_s} s "
-                               f"on rank {rank}")
         ms.append(1e3 * (time.perf_counter() - t0))
         got = recv.view(seen, words).cpu()
         for r in range(seen):

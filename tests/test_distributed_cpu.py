@@ -472,3 +472,32 @@ def test_first_contact_refuses_a_wrong_world_size():
         assert c["ranks_seen_by_backend"] == 1 and c["rccl_version"] is None
     finally:
         dist.destroy_process_group()
+
+
+def _contact_timeout_worker(rank, world, port, ret):
+    import time
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bnv_fusion_amd.distributed import first_contact
+    try:
+        # rank 1 takes part in the identity exchange and then never shows up for the all-gather
+        ret[rank] = first_contact(rank, world, "cpu", backend="gloo", timeout_s=1.5, records=8, n_gathers=1 if rank == 0 else 0)
+        if rank == 1:
+            time.sleep(4.0)
+    except RuntimeError as e:
+        ret[rank] = str(e)
+    os._exit(0)          # (the process group holds a collective that will never complete: no orderly shutdown)
+
+
+def test_first_contact_times_out_on_a_rank_that_never_arrives():
+    """A collective that does not complete fails the rank that waits for it after first_contact's OWN timeout, with a
+    message that names the round -- not after the process group's (minutes)."""
+    import time
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        t0 = time.time()
+        mp.spawn(_contact_timeout_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+        assert time.time() - t0 < 60
+        assert isinstance(ret[0], str) and "all-gather 1 of 1 did not complete within 1.5 s on rank 0" in ret[0], ret[0]
+        assert isinstance(ret[1], dict)
