@@ -82,7 +82,7 @@ class FramePipeConfig(C.Structure):
                 ("enc_ws_max_points", C.c_int64), ("max_depth", C.c_double), ("tsdf", TsdfDesc),
                 ("n_slots", C.c_int32), ("slots", FrameSlot * 8), ("encode_stream", C.c_void_p),
                 ("main_stream", C.c_void_p), ("enc_ws2", C.c_void_p), ("front_stream", C.c_void_p),
-                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32), ("schedule", C.c_int32)]
+                ("blend_stream", C.c_void_p), ("encoder_workgroups", C.c_int32)]
 
 
 class BnvError(RuntimeError):

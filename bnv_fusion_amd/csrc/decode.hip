@@ -1284,6 +1284,9 @@ __global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
     const int64_t chunk = s_chunk;
     if (chunk >= n_chunks) break;
     const int n_live = pts_classify_chunk_fn(A, chunk, lds, [&](int64_t q, float o) { (void)loss_term(q, o); });
+#if defined(BNV_OPTIM_PHASES) && BNV_OPTIM_PHASES == 1      // development probe (tools/optim_phases.sh): classification only
+    continue;
+#endif
     for (int tile = 0; tile * 16 < n_live; ++tile) {
       if (threadIdx.x < DM) pts_stage_tile<1>(A, chunk, tile, n_live, lds, l_row);
       __syncthreads();
@@ -1354,6 +1357,9 @@ __global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
         lds[L_ALPHA + e] = go;
       }
       __syncthreads();
+#if defined(BNV_OPTIM_PHASES) && BNV_OPTIM_PHASES == 2      // development probe: classification + forward + loss only
+      continue;
+#endif
       // ---------------- backward with a unit seed (as k_decode_pts_bwd) ---------------------------------
       mlp_layer_hb<16, false>(pb + SB_W3T, nullptr, lds, acc, w, lane, j, h);
       __syncthreads();

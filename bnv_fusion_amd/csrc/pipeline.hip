@@ -82,21 +82,14 @@ struct bnv_frame_pipe {
   hipEvent_t tl[BNV_PIPE_MAX_SLOTS][BNV_PIPE_TIMELINE_POINTS];
   bool tl_set[BNV_PIPE_MAX_SLOTS][BNV_PIPE_TIMELINE_POINTS];
   int encws_slot[2];                       // the slot whose frame used the encode workspace last
-  // schedule (config.schedule, BNV_SCHED_*)
-  int last_table_slot;                     // slot whose ev_table was recorded last (-1: none): the encoder gate
-  struct SideArgs {                        // BNV_SCHED_TSDF_LATE: the frame's TSDF side fusion, launched by its finish
-    bool on;
-    const void* depth;
-    const float* color;
-    int dtype, H, W;
-    float K[9], T[16];
-  } side[BNV_PIPE_MAX_SLOTS];
 };
 
-// `stream` waits for `ev` -- unless the schedule elides waits and the event has already fired (everything recorded in
-// front of it is then complete: the barrier packet would only cost the stream a few microseconds)
+// `stream` waits for `ev` -- unless the event has already fired at the host's call (everything recorded in front of it is
+// then complete: the barrier packet would only cost the stream a few microseconds of its serial chain; round 6,
+// profiles/r06_experiments.txt [s1]: 0.304 -> 0.301 ms per frame for a rank of 8)
 static hipError_t wait_event(const bnv_frame_pipe* p, hipStream_t stream, hipEvent_t ev) {
-  if ((p->cfg.schedule & BNV_SCHED_ELIDE_WAITS) && hipEventQuery(ev) == hipSuccess) return hipSuccess;
+  (void)p;
+  if (hipEventQuery(ev) == hipSuccess) return hipSuccess;
   (void)hipGetLastError();                 // (hipErrorNotReady is not an error)
   return hipStreamWaitEvent(stream, ev, 0);
 }
@@ -177,7 +170,6 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
   }
   p->next_serial = 1;
   p->last_decoded = -1;
-  p->last_table_slot = -1;
   for (int s = 0; s < BNV_PIPE_MAX_SLOTS; ++s) {
     p->serial[s] = 0;
     p->state[s] = 0;
@@ -186,7 +178,6 @@ int bnv_frame_pipe_create(const bnv_frame_pipe_config_t* cfg, bnv_frame_pipe_t**
     p->enc_buf[s] = 0;
     p->mlp_mode[s] = cfg->grid.mlp_mode;
     p->ev_bound[s] = p->ev_enc[s] = p->ev_side[s] = p->ev_table[s] = p->ev_done[s] = nullptr;
-    p->side[s].on = false;
     p->host_dev[s] = nullptr;
   }
   for (int k = 0; k < 2; ++k)
@@ -247,13 +238,6 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
   tl_mark(p, slot, 1, p->F);   // (in front of the event E waits for: the timeline's point 2 can then never precede it)
   BNV_HIP_CHECK(hipEventRecord(p->ev_bound[slot], p->F));
   if (p->E != p->F) BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_bound[slot], 0));
-  if ((c.schedule & BNV_SCHED_ENCODER_GATE) && p->E != p->M && p->last_table_slot >= 0)
-    // The two MLP kernels exclude each other (each fills a CU's LDS): an encoder that becomes ready while a table
-    // kernel runs only takes CUs from it.  It starts behind the table kernel enqueued last -- the frame before the
-    // previous one's when the caller begins a frame ahead (next_frame) -- i.e. at the head of the window in which the
-    // main stream runs the previous frame's upsert .. marking chain.  (Round 5's schedule had this by accident: the
-    // TSDF kernel in front of the encoder sat stalled under the table kernel.)
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->E, p->ev_table[p->last_table_slot], 0));
   tl_mark(p, slot, 2, p->E);
   const bnv_grid_t g = slot_grid(p, slot);
   // (with the timeline on, the two parts are enqueued separately so that a mark fits between them: the same launches)
@@ -274,7 +258,6 @@ static int begin_tail(bnv_frame_pipe* p, int slot, const float* pts, int64_t n, 
   BNV_HIP_CHECK(hipEventRecord(p->ev_encws[p->enc_buf[slot]], p->E));   // finalize has left the workspace clean
   p->encws_used[p->enc_buf[slot]] = true;
   p->encws_slot[p->enc_buf[slot]] = slot;
-  p->side[slot].on = false;
   p->n_points[slot] = n;
   p->state[slot] = 1;
   return BNV_OK;
@@ -303,20 +286,6 @@ static int side_depth(bnv_frame_pipe* p, int slot, const void* depth, int depth_
                       const double* intr_host, const double* T_wc_host, const float* color_im) {
   const bnv_frame_pipe_config_t& c = p->cfg;
   const bnv_frame_slot_t& b = c.slots[slot];
-  if (c.tsdf.tsdf && (c.schedule & BNV_SCHED_TSDF_LATE) && p->B != p->M) {
-    // remembered: bnv_frame_finish launches it on the blend stream behind the frame's blend (nothing of the frame's
-    // chain waits for it there, and the encode stream carries the encoder + finalize only)
-    bnv_frame_pipe::SideArgs& a = p->side[slot];
-    a.on = true;
-    a.depth = depth;
-    a.color = color_im;
-    a.dtype = depth_dtype;
-    a.H = H;
-    a.W = W;
-    for (int i = 0; i < 9; ++i) a.K[i] = (float)intr_host[i];
-    for (int i = 0; i < 16; ++i) a.T[i] = (float)T_wc_host[i];
-    return BNV_OK;
-  }
   if (c.tsdf.tsdf) {
     float K[9], T[16];
     for (int i = 0; i < 9; ++i) K[i] = (float)intr_host[i];
@@ -457,8 +426,7 @@ int bnv_frame_cancel(bnv_frame_pipe_t* p, int slot) {
   // nothing of it reaches the volume.  The slot's done event covers the encode + side fusion, so the next frame begun
   // in the slot waits for them before it overwrites the slot's buffers.
   BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_enc[slot], 0));
-  if (p->side[slot].on) p->side[slot].on = false;   // (a TSDF side fusion that had not been launched yet goes with the frame)
-  else BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));
   BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
   p->used[slot] = true;
   p->state[slot] = 0;
@@ -508,7 +476,6 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
     tl_mark(p, slot, 9, p->M);
     if (p->B != p->M) {
       BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
-      p->last_table_slot = slot;
       BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
     }
     // the blend reads the workspace only: on B it leaves M to the next frame's upsert
@@ -517,7 +484,6 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
     if (rc != BNV_OK) return rc;
   } else if (p->B != p->M) {
     BNV_HIP_CHECK(hipEventRecord(p->ev_table[slot], p->M));
-    p->last_table_slot = slot;
     BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_table[slot], 0));
   }
   int32_t *stamp = nullptr, *ctl = nullptr;
@@ -536,24 +502,7 @@ int bnv_frame_finish(bnv_frame_pipe_t* p, int slot, const bnv_volume_t* vol, con
     BNV_HIP_CHECK(hipMemcpyAsync(b.host_words + BNV_PIPE_WORD_STATUS, vol->n_rows, 8, hipMemcpyDeviceToHost, p->B));
   }
   tl_mark(p, slot, 10, p->B);
-  if (p->side[slot].on) {
-    // BNV_SCHED_TSDF_LATE: the frame's TSDF side fusion here, behind its blend and read-backs (the gate -- the
-    // frame's in-bounds point count -- was written by its finalize, which the upsert has waited for)
-    const bnv_frame_pipe::SideArgs& a = p->side[slot];
-    const int32_t* gate = &b.counters->n_valid_points;
-    if (a.dtype == 0)
-      rc = bnv_tsdf_integrate_u16(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim,
-                                  c.tsdf.origin, c.tsdf.voxel_size, c.tsdf.trunc_margin, (const uint16_t*)a.depth,
-                                  a.color, a.H, a.W, a.K, a.T, 1.0f, (float)c.max_depth, gate, p->B);
-    else
-      rc = bnv_tsdf_integrate(c.tsdf.tsdf, c.tsdf.weight, a.color ? c.tsdf.color : nullptr, c.tsdf.dim, c.tsdf.origin,
-                              c.tsdf.voxel_size, c.tsdf.trunc_margin, (const float*)a.depth, a.color, a.H, a.W, a.K,
-                              a.T, 1.0f, (float)c.max_depth, gate, p->B);
-    if (rc != BNV_OK) return rc;
-    p->side[slot].on = false;
-  } else {
-    BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
-  }
+  BNV_HIP_CHECK(hipStreamWaitEvent(p->B, p->ev_side[slot], 0));   // the frame's event covers its TSDF update too
   BNV_HIP_CHECK(hipEventRecord(p->ev_done[slot], p->B));
   p->used[slot] = true;
   p->state[slot] = 3;

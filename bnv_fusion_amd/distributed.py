@@ -442,7 +442,7 @@ class HipShardBackend:
 
     def __init__(self, dimensions, voxel_size, pointnet, rank, world, min_pts_in_grid=8, capacity=1 << 20,
                  device="cuda:0", tsdf=False, max_depth=3.0, n_slots=4, ownership=None, block_log2=None, axis=None,
-                 schedule=None, encoder_workgroups=None):
+                 encoder_workgroups=None):
         from .sparse_volume import SparseVolume, make_grid
         import os
         ownership = ownership or os.environ.get("BNV_SHARD_OWNERSHIP", DEFAULT_OWNERSHIP)
@@ -485,8 +485,7 @@ class HipShardBackend:
         self.copy_results = True          # False: result() returns views into the slot buffers (valid for n_slots - 1 more frames)
         self.pipe = None
         self._recv = None
-        self._pipe_kw = {k: v for k, v in (("schedule", schedule), ("encoder_workgroups", encoder_workgroups))
-                         if v is not None}
+        self._pipe_kw = {} if encoder_workgroups is None else {"encoder_workgroups": encoder_workgroups}
         self._last_evals = 0
         self.last_owned_pairs = 0
 

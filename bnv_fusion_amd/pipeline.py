@@ -19,7 +19,6 @@ import torch
 
 from . import _lib
 
-SCHED_ENCODER_GATE, SCHED_TSDF_LATE, SCHED_ELIDE_WAITS = 1, 2, 4      # include/bnv_fusion.h: BNV_SCHED_*
 REC_WORDS = 12          # BNV_SHARD_RECORD_BYTES / 4
 HOST_WORDS = 96         # BNV_PIPE_HOST_WORDS
 W_COUNTERS, W_STATUS, W_EVALS, W_BOUNDS = 0, 8, 10, 16
@@ -31,15 +30,9 @@ class FramePipe:
     # stream's chain (upsert -> exchange -> install -> mark) runs beside it; all CUs otherwise.  The constructor's
     # ``encoder_workgroups`` / BNV_PIPE_ENCODER_WGS override (0 = all CUs).
     ENCODER_SHARE_SHARDED = 0.75
-    # bnv_frame_pipe_config_t.schedule of a sharded volume's pipe (one GPU: 0, round 5's order -- its frame is the two
-    # MLP kernels and nothing waits in its windows); the constructor's ``schedule`` overrides.  Measured equal to round
-    # 5's order (0.305 / 0.319 against 0.304 / 0.321 ms per frame for a rank of 8 at 0 / 30 us of collective latency,
-    # profiles/r06_experiments.txt [s1]) -- but here the two MLP kernels take turns by construction, not because a TSDF
-    # kernel happens to sit stalled in front of the encoder
-    SCHEDULE_SHARDED = SCHED_ENCODER_GATE | SCHED_TSDF_LATE | SCHED_ELIDE_WAITS
 
     def __init__(self, volume, pointnet, max_points, n_slots=4, tsdf_vol=None, max_depth=3.0, sdf_delta=None,
-                 streams=4, encoder_workgroups=None, persistent_tables=None, schedule=None):
+                 streams=4, encoder_workgroups=None, persistent_tables=None):
         from .frontend import DEPTH_DTYPES
         self._dtypes = DEPTH_DTYPES
         self.volume, self.pointnet, self.tsdf_vol = volume, pointnet, tsdf_vol
@@ -69,9 +62,6 @@ class FramePipe:
             self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
             self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
         self.double_buffered = self.front is not None
-        if schedule is None:
-            schedule = self.SCHEDULE_SHARDED if (self.world > 1 and streams >= 4) else 0
-        self.schedule = int(schedule)
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")
             if encoder_workgroups is None:
@@ -129,7 +119,6 @@ class FramePipe:
             cfg.enc_ws2 = self._enc_ws2.data_ptr()
             cfg.front_stream, cfg.blend_stream = self.front.cuda_stream, self.blend.cuda_stream
         cfg.encoder_workgroups = self.encoder_workgroups
-        cfg.schedule = self.schedule
         self._cfg = cfg
         h = C.c_void_p()
         _lib.check(lib.bnv_frame_pipe_create(C.byref(cfg), C.byref(h)), "bnv_frame_pipe_create")
@@ -164,9 +153,8 @@ class FramePipe:
     @property
     def tsdf_stream(self):
         """The stream the TSDF side fusion of a frame runs on (a synchronous TSDF update on another stream must be
-        ordered before it): the encode stream, or the blend stream when the schedule launches it late
-        (csrc/pipeline.hip: BNV_SCHED_TSDF_LATE)."""
-        return self.blend if (self.schedule & SCHED_TSDF_LATE and self.blend is not None) else self.enc
+        ordered before it): the encode stream (csrc/pipeline.hip)."""
+        return self.enc
 
     def close(self):
         """Destroys the C object (every frame must have been collected)."""

@@ -732,23 +732,7 @@ typedef struct bnv_frame_pipe_config {
   void* enc_ws2;
   bnv_stream_t front_stream, blend_stream;
   int32_t encoder_workgroups;
-  /* Round 6: how the frame's launches are ordered on the streams above (a bit set; 0 = round 5's schedule; results are
-   * identical whatever is set).  A sharded frame's cycle is `table kernel + a window` in which BOTH the main stream's
-   * chain and the encode stream's work of the next frame must fit (nothing gets a wave beside the table kernel); these
-   * shorten the two:
-   *   BNV_SCHED_ENCODER_GATE  (with blend_stream) the point encoder of a frame starts behind the table kernel that was
-   *                           enqueued last: the two LDS-filling MLP kernels take turns by construction;
-   *   BNV_SCHED_TSDF_LATE     (with blend_stream) the TSDF side fusion of a frame is launched by bnv_frame_finish on
-   *                           blend_stream, behind the frame's blend, instead of on encode_stream by begin: nothing on the
-   *                           frame's path queues behind it.  A frame that is cancelled then leaves the TSDF volume alone;
-   *   BNV_SCHED_ELIDE_WAITS   an event wait is not enqueued when the event has already fired at the host's call.
-   * (A fourth re-ordering -- marking the origins no ghost row can touch while the exchange is in flight on another
-   * stream -- was built and measured 20-100 % slower: profiles/r06_experiments.txt [s1]-[s3].) */
-  int32_t schedule;
 } bnv_frame_pipe_config_t;
-#define BNV_SCHED_ENCODER_GATE 1
-#define BNV_SCHED_TSDF_LATE 2
-#define BNV_SCHED_ELIDE_WAITS 4
 
 typedef struct bnv_frame_pipe bnv_frame_pipe_t;
 /* A frame's read-backs in one launch for callers that drive the stages themselves: the encode's counters (8 int32)

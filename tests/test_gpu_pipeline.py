@@ -51,16 +51,14 @@ def _run_pipe(pipe, frames, depth_in_flight, decode=True):
     return outs
 
 
-@pytest.mark.parametrize("streams,schedule", [(4, 0), (4, 7), (2, 0), (4, 2)])
+@pytest.mark.parametrize("streams", [4, 2])
 @pytest.mark.parametrize("in_flight", [1, 3])
 @pytest.mark.parametrize("kind", ["depth", "points"])
-def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, streams, schedule):
+def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, streams):
     """One GPU: the pipe's outputs, volume and TSDF volume equal NeuralMap.fuse_and_decode's, frame by frame, with
     one or several frames in flight (slots reused: 14 frames through 4 slots), from depth images (front end fused,
     TSDF side fusion) and from input_pts; an empty frame in the middle.  ``streams``: the four-stream schedule (front
-    end / encoder / main chain / blend) and round 3's two-stream one (encode / main).  ``schedule``: round 5's order of
-    launches (0) and round 6's bits (include/bnv_fusion.h: BNV_SCHED_*: the encoder gated on the last table kernel, the
-    TSDF side fusion launched by finish on the blend stream, fired event waits elided) -- identical results."""
+    end / encoder / main chain / blend) and round 3's two-stream one (encode / main)."""
     from bnv_fusion_amd import synthetic
     from bnv_fusion_amd.frontend import depth_to_input_pts
     from bnv_fusion_amd.pipeline import FramePipe
@@ -86,8 +84,8 @@ def test_frame_pipe_equals_per_stage_path(bnv, in_flight, kind, streams, schedul
     if tsdf:
         mn, mx, _ = get_world_range(dims3, 0.025)
         tv = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=DEV)
-    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv, streams=streams, schedule=schedule)
-    assert pipe.double_buffered == (streams == 4) and pipe.schedule == schedule
+    pipe = FramePipe(vol, model, 240 * 320, n_slots=4, tsdf_vol=tv, streams=streams)
+    assert pipe.double_buffered == (streams == 4)
     got = _run_pipe(pipe, frames, in_flight)
     torch.cuda.synchronize()
     for t, ((rc, rs), (gc, gs)) in enumerate(zip(ref, got)):
@@ -602,39 +600,3 @@ def test_persistent_tables_do_not_survive_new_weights_in_the_same_model(bnv):
     nm = bnv.NeuralMap(dims3, voxel, m, device=DEV)
     old = [nm.fuse_and_decode_async(fr).result() for fr in frames]
     assert torch.equal(old[10][1], outs[True][10][1]) and not torch.equal(old[-1][1], outs[True][-1][1])
-
-
-@pytest.mark.parametrize("schedule", [0, 2])
-def test_cancelled_frame_and_the_tsdf_side_volume(bnv, schedule):
-    """What a cancelled frame leaves in the TSDF side volume depends on where the schedule launches its side fusion
-    (include/bnv_fusion.h: BNV_SCHED_TSDF_LATE): round 5's order enqueues it with the frame's encode -- it stays done, as
-    bnv_frame_cancel documents --; launched late by finish, it goes with the frame.  The feature volume never sees the frame."""
-    from bnv_fusion_amd import synthetic
-    from bnv_fusion_amd.pipeline import FramePipe
-    from bnv_fusion_amd.sparse_volume import get_world_range
-    from bnv_fusion_amd.tsdf import TSDFVolume
-    dims, voxel = synthetic.GRID_DIMS[128]
-    dims3 = np.array([dims] * 3)
-    model = bnv.load_pretrained(device=DEV, voxel_size=voxel)
-    frames = _frames(9)
-    mn, mx, _ = get_world_range(dims3, 0.025)
-    tv = TSDFVolume(np.stack([mn, mx], 1), 0.025, device=DEV)
-    vol = bnv.SparseVolume(8, voxel, dims3, 8, device=DEV)
-    pipe = FramePipe(vol, model, 240 * 320, n_slots=3, tsdf_vol=tv, schedule=schedule)
-    for t, fr in enumerate(frames):
-        s = pipe.begin(fr)
-        if t == 4:
-            pipe.cancel(s)
-            continue
-        pipe.bound(s)
-        pipe.upsert(s)
-        pipe.finish(s)
-        pipe.result(s)
-    torch.cuda.synchronize()
-    assert float(tv.weight.max()) == (9.0 if schedule == 0 else 8.0)
-    ref_nm = bnv.NeuralMap(dims3, voxel, model, device=DEV)
-    for fr in frames[:4] + frames[5:]:
-        ref_nm.integrate(fr)
-    n = ref_nm.volume.num_rows()
-    assert vol.num_rows() == n and torch.equal(vol._features[:n], ref_nm.volume._features[:n])
-    pipe.close()

@@ -98,7 +98,6 @@ def spatial(name):
 
 rows = [("world 8, pan 256³, **region** (default)", "spatial_world8_all_ranks_256"),
         ("… with 30 µs of simulated collective latency (`--exchange-delay 30`)", "spatial_world8_all_ranks_256_delay30"),
-        ("… under round 5's order of launches (`--schedule 0`), same box", "spatial_world8_all_ranks_256_r05_schedule"),
         ("world 8, pan 512³, region, 30 µs of collective latency", "spatial_world8_all_ranks_512_delay30"),
         ("world 8, pan 256³, first touch 8³ (round 4's rule)", "spatial_world8_all_ranks_256_first_touch"),
         ("world 8, pan 512³, region", "spatial_world8_all_ranks_512"),

@@ -38,7 +38,7 @@ dp = last_json(f"{src}/trace_stdout.log")
 for name, obj in (("bench_line", d), ("bench_line_tcnn", dt), ("bench_line_profiled_run", dp)):
     open(f"{dst}/{R}_{name}.json", "w").write(json.dumps(obj) + "\n")
 for t in ("spatial_world8", "spatial_world8_all_ranks_256", "spatial_world8_all_ranks_256_first_touch", "spatial_world8_all_ranks_512",
-          "spatial_world8_all_ranks_256_delay30", "spatial_world8_all_ranks_512_delay30", "spatial_world8_all_ranks_256_r05_schedule",
+          "spatial_world8_all_ranks_256_delay30", "spatial_world8_all_ranks_512_delay30",
           "optimize_profile",
           "spatial_world8_all_ranks_sweep", "spatial_world8_all_ranks_sweep_first_touch", "spatial_world8_all_ranks_sweep_first_touch16",
           "spatial_world8_tcnn", "spatial_world8_timeline", "spatial_world2", "spatial_world4", "fp_replay8", "queue_probe",
@@ -172,7 +172,7 @@ with open(f"{dst}/{R}_README.md", "w") as f:
         open(f"{dst}/{R}_bench_line_8rank_gloo_functional.json", "w").write(json.dumps(d8) + "\n")
         pr = d8.get("spatial_sharding", {}).get("per_rank", [])
         W(f"* `{R}_bench_line_8rank_gloo_functional.json` -- `BNV_DIST_BACKEND=gloo python bench.py --gpus 8 --steps 20 --preheat 64`: EIGHT ranks sharing this one GPU over gloo (functional: its rates mean nothing), the real exchange among 8 shards: `spatial_sharding.per_rank[].mlp_evals_per_frame` = {[int(x['mlp_evals_per_frame']) for x in pr]}; parity of rank 0's outputs against the oracle {d8.get('spatial_sharding', {}).get('parity', {}).get('sdf_max_abs_err_vs_oracle')}.\n")
-    W(f"* `{R}_spatial_world8_all_ranks_256_delay30.txt`, `{R}_spatial_world8_all_ranks_512_delay30.txt` -- the same with `--exchange-delay 30` (a 30 us spin kernel behind the stand-in all-gather: the latency of a real 8-rank collective): {tail_of('spatial_world8_all_ranks_256_delay30', 3)} || 512^3: {tail_of('spatial_world8_all_ranks_512_delay30', 3)}.  `{R}_spatial_world8_all_ranks_256_r05_schedule.txt`: `--schedule 0` (round 5's order of launches) on the same box: {tail_of('spatial_world8_all_ranks_256_r05_schedule', 3)}.\n")
+    W(f"* `{R}_spatial_world8_all_ranks_256_delay30.txt`, `{R}_spatial_world8_all_ranks_512_delay30.txt` -- the same with `--exchange-delay 30` (a 30 us spin kernel behind the stand-in all-gather: the latency of a real 8-rank collective): {tail_of('spatial_world8_all_ranks_256_delay30', 3)} || 512^3: {tail_of('spatial_world8_all_ranks_512_delay30', 3)}.\n")
     ost = glob.glob(f"{src}/trace_optimize/**/*kernel_stats.csv", recursive=True)
     if ost:
         shutil.copy(ost[0], f"{dst}/{R}_optimize_kernel_stats.csv")

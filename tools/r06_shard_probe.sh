@@ -1,6 +1,6 @@
 #!/bin/bash
-# One rank of a simulated world of 8 (real ghost rows), sustained, at --exchange-delay 0 and 30, under a list of schedule
-# settings: the quick A/B of round 6's schedule work.
+# One rank of a simulated world of 8 (real ghost rows), sustained, at --exchange-delay 0 and 30, under a list of settings
+# (e.g. "--encoder-wgs 224"): the quick A/B of round 6's work on the sharded cycle.
 #   tools/r06_shard_probe.sh <tag> <rank> "<args of config 1>" "<args of config 2>" ...
 TAG=$1; RANK=$2; shift; shift
 O=gpurun_out/r06_probe_$TAG

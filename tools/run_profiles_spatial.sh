@@ -16,8 +16,6 @@ $SP --world 8 --frames 2000 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_25
 # ... and with 30 us of simulated collective latency behind the stand-in all-gather (VERDICT r05 item 1's condition)
 $SP --world 8 --frames 2000 --exchange-delay 30 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_delay30.txt
 $SP --world 8 --frames 2000 --grid 512 --exchange-delay 30 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512_delay30.txt
-# ... and round 5's schedule (no encoder gate, TSDF on the encode stream, every event wait enqueued) on the same box
-$SP --world 8 --frames 2000 --schedule 0 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_r05_schedule.txt
 $SP --world 8 --frames 2000 --ownership first_touch 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_256_first_touch.txt
 $SP --world 8 --frames 2000 --grid 512 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_512.txt
 $SP --world 8 --frames 1000 --scene sweep 2>&1 | grep -v "$F" > $O/spatial_world8_all_ranks_sweep.txt

@@ -48,8 +48,6 @@ ap.add_argument("--preroll", type=int, default=None, help="frames fused (not dec
                 "and the region rule has met the sweep)")
 ap.add_argument("--record", default=None, help="(internal) record pass: all W shards in this process, blocks saved to this file")
 ap.add_argument("--ghosts", default=None, help="recorded blocks of the other ranks (from --record); without it --rank records first")
-ap.add_argument("--schedule", type=int, default=None, help="bnv_frame_pipe_config_t.schedule of the timed rank's pipe "
-                "(BNV_SCHED_* bits: 1 encoder gate, 2 late TSDF, 4 elide waits; default: the package's)")
 ap.add_argument("--encoder-wgs", type=int, default=None, help="workgroups of the persistent point encoder (default: the package's)")
 ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
                 "pipelined frames after the timed run")
@@ -227,7 +225,7 @@ if args.ghosts:
 
 def price(rank, latency):
     be = D.HipShardBackend(np.array([dims] * 3), voxel, model, rank, W, capacity=1 << 21, device="cuda:0", tsdf=True,
-                           n_slots=max(4, args.in_flight + 2 + args.ahead), schedule=args.schedule,
+                           n_slots=max(4, args.in_flight + 2 + args.ahead),
                            encoder_workgroups=args.encoder_wgs, **SHARD_KW)
     be.inputs_resident = True
     be.copy_results = False
@@ -376,7 +374,7 @@ def price(rank, latency):
         print("  pipeline streams verified concurrent with the main stream and with one another: " + ", ".join(
             f"{n} {getattr(st, 'bnv_concurrent', None)}" for n, st in (("encode", pp.enc), ("front", pp.front),
                                                                      ("blend", pp.blend)) if st is not None)
-              + f"; encoder workgroups {pp.encoder_workgroups}; schedule {pp.schedule}")
+              + f"; encoder workgroups {pp.encoder_workgroups}")
         print(f"  voxels owned per frame {out['own']:.0f}; (point, corner) pairs encoded {out['pairs']:.0f}; SDF-MLP "
               f"evaluations {out['evals']:.0f}" + (f" (record pass, all {W} shards with the real exchange: {out['evals_rec']:.0f})"
                                                   if GH is not None else " (NO real ghost rows: --ghosts / --all-ranks)")
