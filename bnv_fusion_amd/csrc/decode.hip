@@ -1296,23 +1296,28 @@ __global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
       const _Float16* ph = (const _Float16*)(pack + SD_TOTAL);
       const _Float16* pb = (const _Float16*)bpack;
       // ---------------- forward, keeping the sign bits of the pre-activations ---------------------------
+      // (the 256-wide layers are LOOPS, not three copies of the tile code each way: unrolled, the kernel's body is ~90 KB of
+      // instructions against a 64 KB instruction cache, and every tile streamed all of it through the cache)
+      constexpr int LAYER_HALVES = 8 * 16 * 2 * 64 * 8;
+      static_assert(SH_W2 - SH_W1 == LAYER_HALVES && SH_W3 - SH_W2 == LAYER_HALVES, "forward layers are equally spaced");
+      static_assert(SB_W2T - SB_W3T == LAYER_HALVES && SB_W1T - SB_W2T == LAYER_HALVES, "backward layers too");
       f32x16 acc[4];
       mlp_layer_hb<2, true>(ph + SH_W0, pack + SD_B0, lds, acc, w, lane, j, h);
       const uint64_t m0 = positive_bits(acc);
+      uint64_t m1 = 0, m2 = 0;
       __syncthreads();
       store_relu_h(lds, acc, w, j, h);
       __syncthreads();
-      mlp_layer_hb<16, true>(ph + SH_W1, pack + SD_B0 + 256, lds, acc, w, lane, j, h);
-      const uint64_t m1 = positive_bits(acc);
-      __syncthreads();
-      store_relu_h(lds, acc, w, j, h);
-      __syncthreads();
-      mlp_layer_hb<16, true>(ph + SH_W2, pack + SD_B0 + 512, lds, acc, w, lane, j, h);
-      const uint64_t m2 = positive_bits(acc);
-      __syncthreads();
-      store_relu_h(lds, acc, w, j, h);
-      __syncthreads();
-      mlp_layer_hb<16, true>(ph + SH_W3, pack + SD_B0 + 768, lds, acc, w, lane, j, h);
+#pragma unroll 1
+      for (int l = 1;; ++l) {
+        mlp_layer_hb<16, true>(ph + SH_W1 + (l - 1) * LAYER_HALVES, pack + SD_B0 + 256 * l, lds, acc, w, lane, j, h);
+        if (l == 3) break;
+        const uint64_t m = positive_bits(acc);
+        if (l == 1) m1 = m; else m2 = m;
+        __syncthreads();
+        store_relu_h(lds, acc, w, j, h);
+        __syncthreads();
+      }
       {
         // fc_alpha (the forward's last layer) and the backward's seed delta_3 = wa * [z3 > 0] from the same fragment
         const uint64_t m3 = positive_bits(acc);
@@ -1361,18 +1366,17 @@ __global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
       continue;
 #endif
       // ---------------- backward with a unit seed (as k_decode_pts_bwd) ---------------------------------
-      mlp_layer_hb<16, false>(pb + SB_W3T, nullptr, lds, acc, w, lane, j, h);
-      __syncthreads();
-      store_masked_h(lds, acc, m2, w, j, h);
-      __syncthreads();
-      mlp_layer_hb<16, false>(pb + SB_W2T, nullptr, lds, acc, w, lane, j, h);
-      __syncthreads();
-      store_masked_h(lds, acc, m1, w, j, h);
-      __syncthreads();
-      mlp_layer_hb<16, false>(pb + SB_W1T, nullptr, lds, acc, w, lane, j, h);
-      __syncthreads();
-      store_masked_h(lds, acc, m0, w, j, h);
-      __syncthreads();
+#pragma unroll 1
+      for (int l = 0; l < 3; ++l) {
+        mlp_layer_hb<16, false>(pb + SB_W3T + l * LAYER_HALVES, nullptr, lds, acc, w, lane, j, h);
+        const uint64_t m = l == 0 ? m2 : (l == 1 ? m1 : m0);
+        __syncthreads();
+        store_masked_h(lds, acc, m, w, j, h);
+        __syncthreads();
+      }
+#if defined(BNV_OPTIM_PHASES) && BNV_OPTIM_PHASES == 3      // development probe: ... + the three 256-wide backward layers
+      continue;
+#endif
       if (w < 4) {
         f32x16 g;
 #pragma unroll
@@ -1393,7 +1397,11 @@ __global__ __launch_bounds__(512) void k_optim_step(OptimArgs O) {
         const int col = w * 32 + j;
         const float sg = lds[L_ALPHA + col];
         const int row = l_row[col];
+#if defined(BNV_OPTIM_PHASES) && BNV_OPTIM_PHASES == 4      // development probe: everything but the gradient's atomics
+        if (sg == 12345.f && row >= 0) {
+#else
         if (sg != 0.f && row >= 0) {
+#endif
           float* gf = B.grad_features + (size_t)row * 8;
           if (h == 0) {
             unsafeAtomicAdd(gf + 0, g[5] * sg);
