@@ -86,7 +86,7 @@ PARITY_VOXELS = 2048
 # at 640x480 on top of ~350,000 known rows).  What growing from the reference's 100,000 rows costs is reported
 # separately (`growth`).
 CAPACITY = 1 << 22
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def pmc_traffic(kernel_substr, evals_now):
@@ -1106,12 +1106,15 @@ def run_bench(args, rank, world, dev, dist, backend):
             nmt = bnv.NeuralMap(dims3, voxel, mt, capacity=CAPACITY, device=dev, tsdf=with_tsdf)
             nmt.inputs_resident, nmt.copy_results = True, False
             drv.run(nmt, "single", list(range(args.preroll)), decode=False)
-            rt = timed(nmt, "single", 2, step_idx, warm_idx, preheat=min(args.preheat, 300))
+            # (50 of these frames are 11 ms: one hiccup of the box halves the figure -- the median of three passes)
+            rts = [timed(nmt, "single", 2, step_idx, warm_idx, preheat=min(args.preheat, 300) if k == 0 else 0)
+                   for k in range(3)]
+            rt = sorted(rts, key=lambda r: r["elapsed"])[1]
             chk = oracle_lattice_check(nmt.volume, rt["coords"], rt["sdf"], tcnn=True, n_voxels=256) \
                 if rt["coords"] is not None else None
             extras["tcnn_quick"] = {**entry(rt, chk), "dtype": DTYPE[2],
                                     "note": "tiny-cuda-nn networks of the reference's default checkpoint, the same "
-                                            "timed steps behind 300 pre-heat frames; parity UNPINNED (the reference's "
+                                            "timed steps behind 300 pre-heat frames, the median of three passes; parity UNPINNED (the reference's "
                                             "fp16 arithmetic is CUDA-only): checked against the oracle's restatement"}
             del nmt, mt
             model.shard = (0, 1, 3)
