@@ -1112,7 +1112,11 @@ def run_bench(args, rank, world, dev, dist, backend):
             rt = sorted(rts, key=lambda r: r["elapsed"])[1]
             chk = oracle_lattice_check(nmt.volume, rt["coords"], rt["sdf"], tcnn=True, n_voxels=256) \
                 if rt["coords"] is not None else None
+            pq = getattr(nmt, "_pipe", None)
             extras["tcnn_quick"] = {**entry(rt, chk), "dtype": DTYPE[2],
+                                    "passes_frames_per_s": [r["fps"] for r in rts],
+                                    "pipe_streams_concurrent": None if pq is None else [
+                                        getattr(st, "bnv_concurrent", None) for st in (pq.enc, pq.front, pq.blend)],
                                     "note": "tiny-cuda-nn networks of the reference's default checkpoint, the same "
                                             "timed steps behind 300 pre-heat frames, the median of three passes; parity UNPINNED (the reference's "
                                             "fp16 arithmetic is CUDA-only): checked against the oracle's restatement"}

@@ -47,20 +47,21 @@ class FramePipe:
         assert 1 <= self.n_slots <= 8
         self.max_points = int(max_points)
         self.world = int(v.shard[1])
-        from .streams import concurrent_stream
+        from .streams import pipe_streams
         import os
         self.main = torch.cuda.current_stream(dev)
-        self.enc = concurrent_stream(dev, self.main)          # verified to overlap the main stream
+        streams = int(streams)
+        # side streams verified to overlap the main stream and one another, shared by the pipes of the process
+        side = pipe_streams(dev, self.main, 3 if streams >= 4 else 1)
+        self.enc = side[0]
         # the front end (voxelise + rank) and the blend on streams of their own (csrc/pipeline.hip: why four);
         # streams=2: round 3's two-stream schedule (kept for the A/B in tests and tools).  The schedules measured
         # slower -- table MLP on a fifth stream from a feature snapshot, CU-masked streams, an early exchange of
         # contribution records, a gated encoder, a high-priority main stream -- were removed in round 6; their records
         # are profiles/r04_cu_mask_experiment.txt, r04_fifth_stream_experiment.txt and r05_experiments.txt [e8], [e9].
-        streams = int(streams)
         self.front = self.blend = None
         if streams >= 4:
-            self.front = concurrent_stream(dev, self.main, exclude=(self.enc,))
-            self.blend = concurrent_stream(dev, self.main, exclude=(self.enc, self.front))
+            self.front, self.blend = side[1], side[2]
         self.double_buffered = self.front is not None
         if encoder_workgroups is None:
             encoder_workgroups = os.environ.get("BNV_PIPE_ENCODER_WGS")

@@ -58,3 +58,21 @@ def concurrent_stream(device, main=None, priority=0, exclude=()):
                 return cand
     cand.bnv_concurrent = False
     return cand
+
+
+_PIPE_STREAMS = {}
+
+
+def pipe_streams(device, main=None, n=3):
+    """The frame pipeline's side streams for ``main`` on ``device`` -- (encode, front end, blend), verified concurrent
+    with ``main`` and with one another -- made ONCE per (device, main stream) and shared by every FramePipe of the
+    process: a second pipe (another volume, another checkpoint) gets the streams the first one verified instead of
+    drawing new candidates from torch's pool, whose mapping onto the hardware queues depends on how many streams the
+    process has created by then.  Pipes that share streams only add ordering between their launches."""
+    dev = torch.device(device)
+    main = main or torch.cuda.current_stream(dev)
+    key = (dev.index or 0, int(main.cuda_stream))
+    got = _PIPE_STREAMS.setdefault(key, [])
+    while len(got) < n:
+        got.append(concurrent_stream(dev, main, exclude=tuple(got)))
+    return tuple(got[:n])

@@ -48,6 +48,10 @@ ap.add_argument("--preroll", type=int, default=None, help="frames fused (not dec
                 "and the region rule has met the sweep)")
 ap.add_argument("--record", default=None, help="(internal) record pass: all W shards in this process, blocks saved to this file")
 ap.add_argument("--ghosts", default=None, help="recorded blocks of the other ranks (from --record); without it --rank records first")
+ap.add_argument("--exchange", default="torch", choices=["torch", "on_stream"],
+                help="torch: the collective call of torch.distributed (a one-rank group here: ProcessGroupNCCL runs it on its "
+                     "own stream, two event hops); on_stream: what a collective enqueued on the main stream itself amounts to "
+                     "for one rank (a device copy of the own block, no hop)")
 ap.add_argument("--encoder-wgs", type=int, default=None, help="workgroups of the persistent point encoder (default: the package's)")
 ap.add_argument("--timeline", type=int, default=0, help="GPU timestamps of every stage (bnv_frame_timeline) over this many "
                 "pipelined frames after the timed run")
@@ -242,7 +246,10 @@ def price(rank, latency):
             # would land; then the collective call itself (1-rank group) lands this rank's own block over its slot
             assert GH["caps"][t] == cap, (t, GH["caps"][t], cap)
             one.copy_(GH["dev"][t].view(-1))
-            dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
+            if args.exchange == "on_stream":
+                blocks[rank].reshape(-1).copy_(send)
+            else:
+                dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
             t4 = time.perf_counter()
         else:
             dist.all_gather_into_tensor(blocks[rank].reshape(-1), send)
