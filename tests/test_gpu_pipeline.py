@@ -284,6 +284,12 @@ def test_side_streams_are_verified_to_overlap():
     assert lib.bnv_probe_spin(0, 10, None) != 0 and lib.bnv_probe_spin(1, -1, None) != 0      # bad arguments are refused
     t = streams.concurrent_stream(DEV, main, exclude=(s,))
     assert t.cuda_stream not in (main.cuda_stream, s.cuda_stream)
+    # the pipes of a process share ONE verified set per (device, main stream): a second pipe does not draw new candidates
+    a = streams.pipe_streams(DEV, main, 3)
+    b = streams.pipe_streams(DEV, main, 3)
+    assert len(a) == 3 and all(x is y for x, y in zip(a, b)) and all(x.bnv_concurrent for x in a)
+    assert len({x.cuda_stream for x in a} | {main.cuda_stream}) == 4
+    assert streams.pipe_streams(DEV, main, 1)[0] is a[0]
 
 
 def test_frame_timeline_is_ordered_and_changes_nothing(bnv):
