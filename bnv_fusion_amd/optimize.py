@@ -141,10 +141,36 @@ def key_frame_points(depth, intr_mat, T_wc, ray_max_dist):
     pts_c = torch.stack([u[None, :].expand(H, W), v[:, None].expand(H, W), torch.ones_like(depth)], -1)
     pts_c = pts_c * depth[..., None]                                  # geometry.py:150-171
     pts_w = pts_c.reshape(-1, 3) @ T[:3, :3].T + T[:3, 3]
+    r = torch.arange(-1, 2, device=dev)
+    oy, ox = torch.meshgrid(r, r, indexing="ij")                      # np.meshgrid(range_, range_) order: x fastest
     return {"pts": pts_w.float(), "mask": mask.reshape(-1).float(), "H": H, "W": W,
+            "oy": oy.reshape(1, -1), "ox": ox.reshape(1, -1), "zero_rgb": {},
             "intr_mat": intr_mat.to(dev).float().reshape(1, 3, 3), "T_wc": T_wc.to(dev).float().reshape(1, 4, 4),
             "T_wc_host": T_wc.detach().cpu().numpy().astype(np.float32).reshape(4, 4),
             "intr_host": intr_mat.detach().cpu().numpy().astype(np.float32).reshape(3, 3)}
+
+
+def random_subset(n, k, device, generator=None):
+    """``torch.randperm(n)[:k]`` in distribution -- k indices out of n without replacement, in random order
+    (fusion_inference_dataset.py:383) -- without permuting all n on the device: a full permutation of a 640x480 image is a
+    sort of 307,200 keys (18 merge passes, 135 us per optimiser step) to pick 5,000 rays.  2 k indices are drawn WITH
+    replacement and every repeat of an earlier draw is dropped, which is sequential sampling with rejection -- the same
+    distribution; the first k survivors are kept, in draw order.  With k <= n / 8 the expected number of repeats among the
+    2 k draws is <= k / 4 and fewer than k survivors would need more than k of them (never seen; such a slot would hold
+    index 0).  Larger k: the permutation."""
+    if k * 8 > n:
+        return torch.randperm(n, device=device, generator=generator)[:k]
+    m = 2 * k
+    draws = torch.randint(n, (m,), device=device, generator=generator)
+    s, order = torch.sort(draws, stable=True)                  # equal values stay in draw order
+    rep_sorted = torch.zeros(m, dtype=torch.bool, device=device)
+    rep_sorted[1:] = s[1:] == s[:-1]                           # a later draw of a value already drawn
+    rep = torch.empty_like(rep_sorted)
+    rep[order] = rep_sorted
+    pos = torch.cumsum(~rep, 0) - 1                            # rank among the survivors, in draw order
+    out = torch.zeros(k + 1, dtype=draws.dtype, device=device)
+    out.scatter_(0, torch.where(~rep & (pos < k), pos, torch.full_like(pos, k)), draws)     # (slot k: the rest)
+    return out[:k]
 
 
 def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generator=None, points=None):
@@ -159,13 +185,14 @@ def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generat
         if generator is not None and generator.device.type == "cpu":
             idx = torch.randperm(H * W, generator=generator)[:sampling_size].to(dev)
         else:
-            idx = torch.randperm(H * W, device=dev, generator=generator)[:sampling_size]
+            idx = random_subset(H * W, sampling_size, dev, generator)
         px, py = idx % W, idx // W
-        r = torch.arange(-1, 2, device=dev)
-        oy, ox = torch.meshgrid(r, r, indexing="ij")
-        nidx = (py[:, None] + oy.reshape(-1)[None]).clamp(0, H - 1) * W + (px[:, None] + ox.reshape(-1)[None]).clamp(0, W - 1)
+        nidx = (py[:, None] + points["oy"]).clamp(0, H - 1) * W + (px[:, None] + points["ox"]).clamp(0, W - 1)
+        rgb = points["zero_rgb"].get(len(idx))        # (all zeros, read-only downstream: one tensor per batch size)
+        if rgb is None:
+            rgb = points["zero_rgb"][len(idx)] = torch.zeros(1, len(idx), 3, device=dev)
         return {"uv": torch.stack([px, py], -1).float().unsqueeze(0),
-                "rgb": torch.zeros(1, len(idx), 3, device=dev),
+                "rgb": rgb,
                 "gt_pts": points["pts"][idx].unsqueeze(0),
                 "intr_mat": points["intr_mat"], "T_wc": points["T_wc"],
                 "T_wc_host": points["T_wc_host"], "intr_host": points["intr_host"],
@@ -189,7 +216,7 @@ def sample_key_frame(depth, intr_mat, T_wc, sampling_size, ray_max_dist, generat
     if generator is not None and generator.device.type == "cpu":
         idx = torch.randperm(H * W, generator=generator)[:sampling_size].to(dev)
     else:
-        idx = torch.randperm(H * W, device=dev, generator=generator)[:sampling_size]
+        idx = random_subset(H * W, sampling_size, dev, generator)
     px, py = idx % W, idx // W
     uv = torch.stack([px, py], -1).float()
     r = torch.arange(-1, 2, device=dev)
@@ -338,7 +365,8 @@ def optimize_volume(volume, nerf, ray_batches, truncated_units, truncated_dist, 
     by split (ray_split_step) -- same decisions, same weights, gradients equal up to the order of float atomics."""
     volume.to_tensor()
     volume.features = torch.nn.Parameter(volume.features)
-    optimizer = torch.optim.Adam([volume.features], lr=lr)
+    # (one fused update kernel on the device instead of the foreach implementation's eight: the same formula)
+    optimizer = torch.optim.Adam([volume.features], lr=lr, **({"fused": True} if volume.features.is_cuda else {}))
     history = []
     for rays in ray_batches:
         optimizer.zero_grad(set_to_none=False)

@@ -45,3 +45,29 @@ def test_sequence_layout_round_trip(tmp_path):
     half = datasets.FusionInferenceDataset(str(tmp_path), "scene3d/demo", downsample_scale=0.5, device="cpu")[0]
     assert tuple(half["depth"].shape) == (30, 40) and np.isclose(half["intr_mat"][0, 0], K[0, 0] * 0.5)
     assert np.array_equal(half["depth"].numpy(), depths[0][::2, ::2])
+
+
+def test_random_subset_is_a_sample_without_replacement_in_random_order():
+    """optimize.random_subset stands in for ``torch.randperm(n)[:k]`` (fusion_inference_dataset.py:383) without permuting
+    all n: k distinct indices, every index equally likely, every index equally likely to come first; large k falls back to
+    the permutation."""
+    import torch
+    from bnv_fusion_amd.optimize import random_subset
+    g = torch.Generator().manual_seed(3)
+    x = random_subset(640 * 480, 5000, "cpu", g)
+    assert x.shape == (5000,) and x.dtype == torch.int64 and x.unique().numel() == 5000
+    assert 0 <= int(x.min()) and int(x.max()) < 640 * 480
+    assert (x[1:] < x[:-1]).float().mean() > 0.4          # (not sorted: draw order)
+    n, k, reps = 64, 8, 8000
+    cnt, first = torch.zeros(n), torch.zeros(n)
+    for _ in range(reps):
+        y = random_subset(n, k, "cpu", g)
+        assert y.unique().numel() == k
+        cnt[y] += 1
+        first[y[0]] += 1
+    exp = reps * k / n
+    assert float((cnt - exp).abs().max()) < 6 * (exp * (1 - k / n)) ** 0.5
+    assert float((first - reps / n).abs().max()) < 6 * (reps / n) ** 0.5
+    z = random_subset(40, 8, "cpu", g)                    # k > n / 8: the permutation itself
+    assert z.unique().numel() == 8 and int(z.max()) < 40
+

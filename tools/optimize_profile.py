@@ -36,7 +36,7 @@ for n_iters in (40, 200):
 vol = nm.volume
 vol.to_tensor()
 vol.features = torch.nn.Parameter(vol.features)
-opt = torch.optim.Adam([vol.features], lr=1e-3)
+opt = torch.optim.Adam([vol.features], lr=1e-3, fused=True)      # as optimize.optimize_volume
 vol.features.grad = torch.zeros_like(vol.features)
 f = nm.frames[3]
 pts_cache = optimize.key_frame_points(f["depth"].float() / 1000.0, f["intr_mat"], f["T_wc"], 3)
